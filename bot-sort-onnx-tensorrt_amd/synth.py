@@ -1,0 +1,129 @@
+"""Seeded synthetic detection streams for the tracker-only benchmark and the parity tests.
+
+The tracker hot path takes *pre-extracted* arrays (BASELINE.json north_star): per frame
+integer-pixel boxes, detector scores and L2-normalised ReID features.  This generator is
+shared by the golden-fixture script, the CPU oracle, the GPU parity tests and bench.py so that
+every leg sees byte-identical inputs for a given (config, seed).
+
+Scene model (with the feature noise scaled by 1/sqrt(D) so the appearance
+term of the fused cost is actually exercised at every D):
+  * K identities on a square canvas of side ceil(125*sqrt(K)) px, w~U(30,80), h~U(60,160),
+    centres do a N(0, 2 px) random walk per frame;
+  * frame 0 shows every identity with score ~U(0.9,1) (all become confirmed tracks, since
+    tracks born at frame 1 are activated immediately, reference D:565-566);
+  * later frames show M identities drawn without replacement; 1/8 of them get a low score
+    ~U(0.12,0.38) (second association), the rest ~U(0.9,1); optional churn replaces a fraction
+    of the detections with brand-new identities (births / unconfirmed-track stage);
+  * detection feature = normalise(prototype + (0.3/sqrt(D)) * N(0,1)), float32.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+# name -> (tracks K, detections M, feature dim D): BASELINE.json configs + the headline target
+CONFIGS = {
+    "c1": (64, 32, 2048),
+    "c2": (512, 256, 2048),
+    "c3": (4096, 1024, 2048),
+    "target": (10000, 2000, 2048),
+    "c5": (16384, 4096, 384),
+}
+
+
+@dataclass
+class Frame:
+    boxes: np.ndarray            # int32 [M,4] tlbr pixels
+    scores: np.ndarray           # float32 [M]
+    feats: np.ndarray            # float32 [M,D], L2-normalised
+    face_feats: Optional[np.ndarray]   # float32 [M,Df] or None
+    ident: np.ndarray            # int64 [M] ground-truth identity (not seen by the tracker)
+
+
+class SyntheticStream:
+    def __init__(self, n_ids: int, n_dets: int, feat_dim: int, seed: int = 1234,
+                 churn: float = 0.0, low_frac: float = 0.125, face_dim: int = 0,
+                 feat_noise: float = 0.3):
+        self.rng = np.random.default_rng(seed)
+        self.K0 = n_ids
+        self.M = n_dets
+        self.D = feat_dim
+        self.Df = face_dim
+        self.churn = churn
+        self.low_frac = low_frac
+        self.feat_noise = feat_noise
+        self.side = int(math.ceil(125.0 * math.sqrt(n_ids)))
+        self.cx = np.empty(0)
+        self.cy = np.empty(0)
+        self.w = np.empty(0)
+        self.h = np.empty(0)
+        self.proto = np.empty((0, feat_dim), dtype=np.float32)
+        self.fproto = np.empty((0, face_dim), dtype=np.float32)
+        self._spawn(n_ids)
+        self.t = 0
+
+    def _spawn(self, k: int):
+        r = self.rng
+        margin = 100.0
+        self.cx = np.concatenate([self.cx, r.uniform(margin, self.side - margin, k)])
+        self.cy = np.concatenate([self.cy, r.uniform(margin, self.side - margin, k)])
+        self.w = np.concatenate([self.w, r.uniform(30.0, 80.0, k)])
+        self.h = np.concatenate([self.h, r.uniform(60.0, 160.0, k)])
+        p = r.standard_normal((k, self.D)).astype(np.float32)
+        p /= np.linalg.norm(p, axis=1, keepdims=True)
+        self.proto = np.concatenate([self.proto, p])
+        if self.Df:
+            q = r.standard_normal((k, self.Df)).astype(np.float32)
+            q /= np.linalg.norm(q, axis=1, keepdims=True)
+            self.fproto = np.concatenate([self.fproto, q])
+
+    def _observe(self, ids: np.ndarray, scores: np.ndarray) -> Frame:
+        r = self.rng
+        x1 = np.rint(self.cx[ids] - self.w[ids] / 2)
+        y1 = np.rint(self.cy[ids] - self.h[ids] / 2)
+        x2 = np.rint(self.cx[ids] + self.w[ids] / 2)
+        y2 = np.rint(self.cy[ids] + self.h[ids] / 2)
+        boxes = np.stack([x1, y1, x2, y2], axis=1).astype(np.int32)
+        f = self.proto[ids] + (self.feat_noise / math.sqrt(self.D)) * \
+            r.standard_normal((len(ids), self.D)).astype(np.float32)
+        f = (f / np.linalg.norm(f, axis=1, keepdims=True)).astype(np.float32)
+        ff = None
+        if self.Df:
+            ff = self.fproto[ids] + (self.feat_noise / math.sqrt(self.Df)) * \
+                r.standard_normal((len(ids), self.Df)).astype(np.float32)
+            ff = (ff / np.linalg.norm(ff, axis=1, keepdims=True)).astype(np.float32)
+        return Frame(boxes, scores.astype(np.float32), np.ascontiguousarray(f), ff, ids.astype(np.int64))
+
+    def next(self) -> Frame:
+        r = self.rng
+        if self.t == 0:
+            ids = np.arange(self.K0)
+            fr = self._observe(ids, r.uniform(0.9, 1.0, len(ids)))
+            self.t += 1
+            return fr
+        k = len(self.cx)
+        self.cx += r.normal(0.0, 2.0, k)
+        self.cy += r.normal(0.0, 2.0, k)
+        n_new = int(round(self.churn * self.M))
+        ids = r.choice(k, size=self.M - n_new, replace=False)
+        if n_new:
+            self._spawn(n_new)
+            ids = np.concatenate([ids, np.arange(k, k + n_new)])
+        n_low = int(self.low_frac * self.M)
+        scores = r.uniform(0.9, 1.0, len(ids))
+        if n_low:
+            low_pos = r.choice(len(ids) - n_new, size=min(n_low, len(ids) - n_new - 1), replace=False) \
+                if len(ids) - n_new > 1 else np.empty(0, dtype=np.int64)
+            scores[low_pos] = r.uniform(0.12, 0.38, len(low_pos))
+        perm = r.permutation(len(ids))
+        fr = self._observe(ids[perm], scores[perm])
+        self.t += 1
+        return fr
+
+
+def make_stream(config: str, seed: int = 1234, **kw) -> SyntheticStream:
+    k, m, d = CONFIGS[config]
+    return SyntheticStream(k, m, d, seed=seed, **kw)

@@ -1,0 +1,314 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures tests/golden/*.npz by running the REFERENCE ITSELF.
+
+Runs only in the build container (needs /root/reference).  The fixtures are data: inputs (or
+the seeds that regenerate them, with a checksum) and the outputs the reference produced under
+this image's NumPy/SciPy.  Re-run:  python tests/golden/make_golden.py
+
+G1 Kalman known-answer vectors         (D:118-380)
+G2 iou_distance cases                  (D:1695-1761)
+G3 fused stage-1 / stage-3 costs       (D:1539-1554, D:1590-1602)
+G4 linear_assignment wrapper cases     (D:1682-1693; lap.lapjv served by the oracle restatement,
+                                        cross-checked with scipy.optimize.linear_sum_assignment)
+G5 end-to-end config-1 trace, 100 frames (64 tracks x 32 dets x 2048-d)
+G6 lifecycle traces (frame_rate=3 => max_time_lost=30, identity churn, low-score dets, faces)
+"""
+from __future__ import annotations
+
+import hashlib
+import importlib
+import os
+import sys
+
+import numpy as np
+import scipy
+import scipy.optimize
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+
+from tests.golden import ref_harness as rh   # noqa: E402
+
+synth = importlib.import_module("bot-sort-onnx-tensorrt_amd.synth")
+VERS = np.asarray([np.__version__, scipy.__version__])
+
+
+def checksum(*arrays) -> str:
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def save(name, **kw):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, versions=VERS, **kw)
+    print("wrote", name, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
+# ------------------------------------------------------------------------------------------ G1
+def g1_kalman(mod):
+    rng = np.random.default_rng(101)
+    kf = mod.KalmanFilter()
+    n = 32
+    meas32 = np.stack([rng.uniform(50, 3000, n), rng.uniform(50, 3000, n),
+                       rng.uniform(30, 80, n), rng.uniform(60, 160, n)], 1).astype(np.float32)
+    init_mean = []
+    init_cov = []
+    for z in meas32:
+        m, c = kf.initiate(z)
+        init_mean.append(m)
+        init_cov.append(c)
+    init_mean = np.asarray(init_mean)
+    init_cov = np.asarray(init_cov)
+    # a few predict/update rounds in f64 to get generic (dense) covariances
+    mean = init_mean.astype(np.float64)
+    cov = init_cov.astype(np.float64)
+    for it in range(3):
+        mean, cov = kf.multi_predict(mean, cov)
+        for i in range(n):
+            z = (mean[i, :4] + rng.normal(0, 2.0, 4)).astype(np.float32)
+            mean[i], cov[i] = kf.update(mean[i], cov[i], z)
+    state_mean, state_cov = mean.copy(), cov.copy()
+    # velocities must be non-trivial for the vw,vh=0 rule
+    pm, pc = [], []
+    for i in range(n):
+        a, b = kf.predict(state_mean[i], state_cov[i])
+        pm.append(a)
+        pc.append(b)
+    mp_mean, mp_cov = kf.multi_predict(state_mean.copy(), state_cov.copy())
+    # STrack.multi_predict's rule (D:529-532): rows whose state != Tracked get mean[6]=mean[7]=0
+    not_tracked = (np.arange(n) % 3 == 0)
+    zm = state_mean.copy()
+    zm[not_tracked, 6:8] = 0
+    mpz_mean, mpz_cov = kf.multi_predict(zm, state_cov.copy())
+    prj = [kf.project(state_mean[i], state_cov[i]) for i in range(n)]
+    upd_z = (state_mean[:, :4] + rng.normal(0, 3.0, (n, 4))).astype(np.float32)
+    upd = [kf.update(mp_mean[i], mp_cov[i], upd_z[i]) for i in range(n)]
+    gate_meas = np.stack([state_mean[0, :4] + rng.normal(0, 8.0, 4) for _ in range(16)])
+    gate = {}
+    for i in range(4):
+        for only_pos in (False, True):
+            for metric in ("maha", "gaussian"):
+                gate["gate_%d_%d_%s" % (i, int(only_pos), metric)] = kf.gating_distance(
+                    state_mean[i], state_cov[i], gate_meas, only_position=only_pos, metric=metric)
+    save("g1_kalman.npz", meas32=meas32, init_mean=init_mean, init_cov=init_cov,
+         state_mean=state_mean, state_cov=state_cov,
+         predict_mean=np.asarray(pm), predict_cov=np.asarray(pc),
+         multi_predict_mean=mp_mean, multi_predict_cov=mp_cov,
+         not_tracked=not_tracked, multi_predict_z_mean=mpz_mean, multi_predict_z_cov=mpz_cov,
+         project_mean=np.asarray([p[0] for p in prj]), project_cov=np.asarray([p[1] for p in prj]),
+         update_z=upd_z, update_mean=np.asarray([u[0] for u in upd]),
+         update_cov=np.asarray([u[1] for u in upd]),
+         gate_meas=gate_meas, **gate)
+
+
+# ------------------------------------------------------------------------------------------ G2
+def g2_iou(mod):
+    rng = np.random.default_rng(202)
+
+    def rand_boxes(k, integer):
+        x1 = rng.uniform(0, 600, k)
+        y1 = rng.uniform(0, 600, k)
+        w = rng.uniform(30, 200, k)
+        h = rng.uniform(60, 300, k)
+        b = np.stack([x1, y1, x1 + w, y1 + h], 1)
+        return np.rint(b) if integer else b
+
+    a64 = rand_boxes(64, False)                         # predicted tracks: generic float64
+    b32 = rand_boxes(32, True).astype(np.float32)       # detections: integer pixels as float32
+    # special rows: identical, touching (xmax == xmin), disjoint, nested (det inside track), track inside det
+    b32[0] = [10, 10, 50, 90]
+    a64[0] = [10, 10, 50, 90]
+    a64[1] = [50, 10, 90, 90]            # touches b32[0] in x -> 0
+    a64[2] = [1000, 1000, 1100, 1200]    # disjoint from everything
+    a64[3] = [0.25, 0.5, 100.75, 200.125]   # contains b32[0]
+    a64[4] = [20.5, 30.25, 30.125, 60.75]   # inside b32[0]
+    a32 = rand_boxes(16, False).astype(np.float32)      # never-predicted tracks: float32 arithmetic
+    g32 = rand_boxes(8, False).astype(np.float32)       # non-integer float32 "detections"
+    out = {}
+
+    def run(tag, a, b):
+        out[tag + "_a"] = a
+        out[tag + "_b"] = b
+        r = mod.iou_distance(list(a), list(b)) if (len(a) or len(b)) else mod.iou_distance([], [])
+        out[tag + "_cost"] = np.asarray(r)
+        out[tag + "_dtype"] = np.asarray(str(np.asarray(r).dtype))
+
+    run("f64xf32", a64, b32)
+    run("f32xf32", a32, b32)
+    run("f64xf64", a64, a64[:24][::-1].copy())
+    run("f32xf64", a32, a64[:8])
+    run("f64xg32", a64[:16], g32)
+    run("f32xg32", a32, g32)
+    out["empty_n0_cost"] = np.asarray(mod.iou_distance([], list(b32)))
+    out["empty_m0_cost"] = np.asarray(mod.iou_distance(list(a64), []))
+    save("g2_iou.npz", **out)
+
+
+# ------------------------------------------------------------------------------------------ G3
+def g3_fused(mod):
+    """Drive BoTSORT.update with crafted similarity matrices (threshold edges, the face
+    0.9999999 rule) and record what reaches linear_assignment."""
+    K, M, D, DF = 24, 24, 64, 16
+    st = synth.SyntheticStream(K, M, D, seed=303, churn=0.15, face_dim=DF)
+    ref = rh.ReferenceRunner(D, face_dim=DF, frame_rate=30)
+    rng = np.random.default_rng(33)
+    out = {}
+    n_rec = 0
+    for f in range(6):
+        fr = st.next()
+        crafted = {}
+
+        def body_override(s):
+            s = np.array(s, copy=True)
+            n, m = s.shape
+            if n and m and f >= 1:
+                # exact edge values: 1 - 0.75 == 0.25 (not > 0.25), next float32 above/below
+                edge = np.asarray([0.75, np.nextafter(np.float32(0.75), np.float32(0)),
+                                   np.nextafter(np.float32(0.75), np.float32(1)), 0.5, 0.0, 1.0],
+                                  dtype=np.float32)
+                idx = rng.integers(0, n * m, size=min(12, n * m))
+                s.reshape(-1)[idx] = edge[rng.integers(0, len(edge), size=len(idx))]
+            crafted["body"] = s.copy()
+            return s
+
+        def face_override(s):
+            s = np.array(s, copy=True)
+            n, m = s.shape
+            if n and m and f >= 1:
+                magic = np.float32(0.9999999)
+                vals = np.asarray([magic, np.nextafter(magic, np.float32(0)), np.float32(1.0),
+                                   np.float32(0.8), np.float32(0.75)], dtype=np.float32)
+                idx = rng.integers(0, n * m, size=min(12, n * m))
+                s.reshape(-1)[idx] = vals[rng.integers(0, len(vals), size=len(idx))]
+            crafted["face"] = s.copy()
+            return s
+
+        ref.body.sim_override = body_override
+        ref.face.sim_override = face_override
+        unconf = [t for t in ref.bot.tracked_stracks if not t.is_activated]
+        unconf_feats = np.asarray([t.body_curr_feature for t in unconf], dtype=np.float32).reshape(-1, D)
+        ref.update_arrays(fr.boxes, fr.scores, fr.feats, fr.face_feats)
+        s1 = ref.stage(0)
+        if s1["cost"].size and "body" in crafted:
+            hi = np.nonzero(fr.scores.astype(np.float64) > 0.40)[0]
+            out["s1_%d_iou" % n_rec] = ref.iou_calls[0]
+            out["s1_%d_body_sim" % n_rec] = crafted["body"][:, hi]
+            out["s1_%d_face_sim" % n_rec] = crafted["face"][:, hi]
+            out["s1_%d_cost" % n_rec] = s1["cost"]
+            s3 = ref.stage(2)
+            if s3["cost"].size:
+                left = hi[s1["u_det"]]
+                out["s3_%d_iou" % n_rec] = ref.iou_calls[2]
+                out["s3_%d_trk_feats" % n_rec] = unconf_feats
+                out["s3_%d_det_feats" % n_rec] = fr.feats[left].copy()
+                out["s3_%d_cost" % n_rec] = s3["cost"]
+            n_rec += 1
+    out["n_rec"] = np.asarray(n_rec)
+    save("g3_fused.npz", **out)
+
+
+# ------------------------------------------------------------------------------------------ G4
+def g4_lap(mod):
+    rng = np.random.default_rng(404)
+    out = {}
+    cases = []
+
+    def rand_cost(n, m, frac_inf=0.6):
+        c = rng.uniform(0.0, 1.0, (n, m))
+        c[rng.uniform(size=(n, m)) < frac_inf] = 1.0        # disjoint pairs cost exactly 1 (Q15)
+        return c
+
+    cases.append(("n_gt_m", rand_cost(24, 9), 0.8))
+    cases.append(("n_lt_m", rand_cost(7, 20), 0.8))
+    cases.append(("square", rand_cost(16, 16, 0.3), 0.7))
+    cases.append(("dense", rng.uniform(0.0, 1.0, (20, 14)), 0.5))
+    cases.append(("all_above", rng.uniform(0.81, 1.0, (6, 5)), 0.8))
+    cases.append(("one_by_one_hit", np.asarray([[0.3]]), 0.8))
+    cases.append(("one_by_one_miss", np.asarray([[0.9]]), 0.8))
+    cases.append(("chain", np.asarray([[0.10, 0.20, 1.0], [0.15, 1.0, 1.0], [1.0, 0.27, 0.30], [1.0, 1.0, 0.05]]), 0.8))
+    out["names"] = np.asarray([c[0] for c in cases])
+    for name, c, th in cases:
+        m, ua, ub = mod.linear_assignment(c, th)
+        out[name + "_cost"] = c
+        out[name + "_thresh"] = np.asarray(th)
+        out[name + "_m"] = np.asarray(m, dtype=np.int64).reshape(-1, 2)
+        out[name + "_ua"] = np.asarray(ua, dtype=np.int64)
+        out[name + "_ub"] = np.asarray(ub, dtype=np.int64)
+        # independent cross-check of optimality on the same extended matrix
+        n, mm = c.shape
+        ext = np.full((n + mm, n + mm), th / 2.0)
+        ext[n:, mm:] = 0
+        ext[:n, :mm] = c
+        r, cc = scipy.optimize.linear_sum_assignment(ext)
+        xs = np.full(n, -1, dtype=np.int64)
+        for i, j in zip(r, cc):
+            if i < n and j < mm:
+                xs[i] = j
+        x = np.full(n, -1, dtype=np.int64)
+        for i, j in out[name + "_m"]:
+            x[i] = j
+        assert np.array_equal(xs, x), ("scipy cross-check failed", name)
+        out[name + "_scipy_x"] = xs
+    for shape in ((0, 5), (4, 0), (0, 0)):
+        m, ua, ub = mod.linear_assignment(np.zeros(shape), 0.8)
+        tag = "empty_%d_%d" % shape
+        out[tag + "_m"] = np.asarray(m, dtype=np.int64).reshape(-1, 2)
+        out[tag + "_ua"] = np.asarray(ua, dtype=np.int64)
+        out[tag + "_ub"] = np.asarray(ub, dtype=np.int64)
+    save("g4_lap.npz", **out)
+
+
+# ------------------------------------------------------------------------------------ G5 / G6
+def trace(name, K, M, D, frames, seed, churn=0.0, frame_rate=30, face_dim=0, keep_cost=(1, 2, 50)):
+    st = synth.SyntheticStream(K, M, D, seed=seed, churn=churn, face_dim=face_dim)
+    ref = rh.ReferenceRunner(D, face_dim=face_dim, frame_rate=frame_rate)
+    out = {"K": K, "M": M, "D": D, "frames": frames, "seed": seed, "churn": churn,
+           "frame_rate": frame_rate, "face_dim": face_dim}
+    h = hashlib.sha256()
+    for f in range(frames):
+        fr = st.next()
+        h.update(fr.boxes.tobytes())
+        h.update(fr.scores.tobytes())
+        h.update(fr.feats.tobytes())
+        if fr.face_feats is not None:
+            h.update(fr.face_feats.tobytes())
+        ref.update_arrays(fr.boxes, fr.scores, fr.feats, fr.face_feats)
+        for k in range(3):
+            s = ref.stage(k)
+            p = "f%d_s%d_" % (f, k + 1)
+            out[p + "m"] = s["m"].astype(np.int32)
+            out[p + "u_trk"] = s["u_trk"].astype(np.int32)
+            out[p + "u_det"] = s["u_det"].astype(np.int32)
+            out[p + "cost_sum"] = np.asarray(s["cost"].sum())
+            out[p + "cost_shape"] = np.asarray(s["cost"].shape)
+            if f in keep_cost:
+                out[p + "cost"] = s["cost"]
+        for nm, lst in (("trk", ref.bot.tracked_stracks), ("lost", ref.bot.lost_stracks)):
+            t = rh.table(lst)
+            p = "f%d_%s_" % (f, nm)
+            for key, v in t.items():
+                out[p + key] = v.astype(np.int32) if key != "mean" else v
+        out["f%d_n_removed" % f] = np.asarray(len(ref.bot.removed_stracks))
+    out["input_sha256"] = np.asarray(h.hexdigest())
+    out["last_id"] = np.asarray(ref.mod.BaseTrack._count)
+    save(name, **out)
+
+
+def main():
+    if not rh.reference_available():
+        raise SystemExit("needs /root/reference (build container only)")
+    mod = rh.load_reference()
+    g1_kalman(mod)
+    g2_iou(mod)
+    g3_fused(mod)
+    g4_lap(mod)
+    trace("g5_c1_trace.npz", 64, 32, 2048, 100, seed=1234)
+    trace("g6_lifecycle.npz", 64, 32, 128, 120, seed=7, churn=0.1, frame_rate=3, keep_cost=(1, 2, 40))
+    trace("g6_faces.npz", 48, 24, 64, 60, seed=9, churn=0.05, frame_rate=3, face_dim=32, keep_cost=(1, 2, 30))
+
+
+if __name__ == "__main__":
+    main()
