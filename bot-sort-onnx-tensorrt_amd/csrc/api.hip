@@ -1,0 +1,91 @@
+// api.hip -- library-level entry points: version, error reporting, contexts, scratch arena.
+#include <stdarg.h>
+
+#include "bts_internal.h"
+
+static thread_local char g_err[512] = "";
+
+void bts_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int bts_arena::ensure(size_t bytes) {
+    if (bytes <= cap) return BTS_OK;
+    if (base) { (void)hipFree(base); base = nullptr; cap = 0; }
+    const size_t want = bts_align(bytes + bytes / 4, 1 << 20);
+    if (hipMalloc((void **)&base, want) != hipSuccess) {
+        (void)hipGetLastError();
+        bts_set_error("device allocation of %zu bytes failed", want);
+        base = nullptr;
+        return BTS_ENOMEM;
+    }
+    cap = want;
+    return BTS_OK;
+}
+
+void bts_arena::release() {
+    if (base) (void)hipFree(base);
+    base = nullptr;
+    cap = 0;
+}
+
+extern "C" {
+
+const char *bts_version(void) { return "botsort_hip 0.1.0 (gfx950)"; }
+const char *bts_last_error(void) { return g_err; }
+
+const char *bts_status_string(int status) {
+    switch (status) {
+        case BTS_OK: return "ok";
+        case BTS_EINVAL: return "invalid argument";
+        case BTS_EHIP: return "HIP runtime error";
+        case BTS_ENOMEM: return "out of memory";
+        case BTS_ECAPACITY: return "tracker capacity exceeded";
+        case BTS_ENODEVICE: return "no usable gfx950 device";
+        default: return "unknown status";
+    }
+}
+
+int bts_context_create(bts_context **out, int device_ordinal) {
+    BTS_REQUIRE(out, "out");
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        bts_set_error("no HIP device visible");
+        return BTS_ENODEVICE;
+    }
+    BTS_REQUIRE(device_ordinal >= 0 && device_ordinal < count, "device ordinal out of range");
+    hipDeviceProp_t prop;
+    BTS_HIP(hipGetDeviceProperties(&prop, device_ordinal));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        bts_set_error("device %d is %s; this library carries gfx950 code only", device_ordinal, prop.gcnArchName);
+        return BTS_ENODEVICE;
+    }
+    BTS_HIP(hipSetDevice(device_ordinal));
+    bts_context *ctx = new (std::nothrow) bts_context();
+    if (!ctx) { bts_set_error("host allocation failed"); return BTS_ENOMEM; }
+    ctx->device = device_ordinal;
+    ctx->n_cu = prop.multiProcessorCount;
+    *out = ctx;
+    return BTS_OK;
+}
+
+int bts_context_destroy(bts_context *ctx) {
+    if (!ctx) return BTS_OK;
+    ctx->scratch.release();
+    delete ctx;
+    return BTS_OK;
+}
+
+int bts_context_set_cos_kernel(bts_context *ctx, int which) {
+    BTS_REQUIRE(ctx, "ctx");
+    BTS_REQUIRE(which == BTS_COS_MFMA_F32 || which == BTS_COS_VALU_F32, "unknown cosine kernel");
+    ctx->cos_kernel = which;
+    return BTS_OK;
+}
+
+}  // extern "C"

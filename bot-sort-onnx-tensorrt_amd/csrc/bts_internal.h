@@ -1,0 +1,121 @@
+// bts_internal.h -- shared host-side plumbing of libbotsort_hip.so (gfx950 only).
+//
+// Error handling: every C-ABI entry point is wrapped so that no C++ exception leaves the library;
+// failures set a thread-local message (bts_last_error) and return a negative bts_status.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/botsort_hip.h"
+
+#define BTS_WAVE 64
+
+void bts_set_error(const char *fmt, ...);
+
+#define BTS_HIP(call)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            bts_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__,   \
+                          __LINE__);                                                         \
+            return BTS_EHIP;                                                                 \
+        }                                                                                    \
+    } while (0)
+
+#define BTS_REQUIRE(cond, msg)                                      \
+    do {                                                            \
+        if (!(cond)) {                                              \
+            bts_set_error("invalid argument: %s (%s)", msg, #cond); \
+            return BTS_EINVAL;                                      \
+        }                                                           \
+    } while (0)
+
+#define BTS_LAUNCH_CHECK()                                                                   \
+    do {                                                                                     \
+        hipError_t e_ = hipGetLastError();                                                   \
+        if (e_ != hipSuccess) {                                                              \
+            bts_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_),         \
+                          __FILE__, __LINE__);                                               \
+            return BTS_EHIP;                                                                 \
+        }                                                                                    \
+    } while (0)
+
+static inline int bts_cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline size_t bts_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// A growable device scratch arena owned by a context (standalone API calls) -- never touched
+// inside a tracker step (the tracker preallocates everything at create time so that a step is
+// pure kernel enqueues and can be captured in a hipGraph).
+struct bts_arena {
+    char *base = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes);
+    void release();
+};
+
+struct bts_context {
+    int device = 0;
+    int cos_kernel = BTS_COS_MFMA_F32;
+    int n_cu = 256;
+    bts_arena scratch;
+};
+
+// ---- assignment solver (lap.hip) -------------------------------------------------------------
+// Device-side work area of the exact sparse linear-assignment solver.  All sizes are capacities;
+// the live sizes are read by the kernels from `dims` (device memory) so that a tracker step never
+// needs the host to know them.
+struct bts_lap_work {
+    int32_t n_cap = 0, m_cap = 0;
+    int64_t e_cap = 0;
+    int32_t *hdr = nullptr;      // [16] counters, see lap.hip
+    int32_t *e_row = nullptr;    // [e_cap] unsorted feasible edges (row, col, cost)
+    int32_t *e_col = nullptr;
+    double *e_cost = nullptr;
+    int32_t *deg = nullptr;      // [n_cap] feasible edges per row
+    int32_t *cdeg = nullptr;     // [m_cap] feasible edges per column
+    int32_t *rptr = nullptr;     // [n_cap+1] CSR row pointers
+    int32_t *cursor = nullptr;   // [n_cap] fill cursors / component cursors
+    int32_t *csr_col = nullptr;  // [e_cap]
+    double *csr_cost = nullptr;  // [e_cap]
+    int32_t *parent = nullptr;   // [n_cap+m_cap] union-find forest (when it does not fit LDS)
+    int32_t *comp_of = nullptr;  // [n_cap] component id of a root row
+    int32_t *crow_ptr = nullptr; // [n_cap+1]
+    int32_t *ccol_ptr = nullptr; // [n_cap+1]
+    int32_t *ccur_r = nullptr;   // [n_cap+1] grouping cursors
+    int32_t *ccur_c = nullptr;   // [n_cap+1]
+    int32_t *crows = nullptr;    // [n_cap] rows grouped by component
+    int32_t *crows_s = nullptr;  // [n_cap] ... sorted ascending inside each component
+    int32_t *ccols = nullptr;    // [m_cap] columns grouped by component
+    double *u = nullptr;         // [n_cap] row duals
+    double *v = nullptr;         // [m_cap] column duals
+    double *dist = nullptr;      // [m_cap] tentative distances of a search
+    int32_t *pred = nullptr;     // [m_cap] predecessor row of a column in the search tree
+    int32_t *scanned = nullptr;  // [m_cap]
+    size_t bytes = 0;
+};
+
+size_t bts_lap_work_bytes(int n_cap, int m_cap, int64_t e_cap);
+// carve `w` out of a device block of bts_lap_work_bytes() bytes
+void bts_lap_work_carve(bts_lap_work *w, void *block, int n_cap, int m_cap, int64_t e_cap);
+
+// Enqueue: dense cost[n x m] (leading dimension ld, live sizes in dims[0], dims[1] on device,
+// bounded by n_max/m_max known to the host) -> x[n], y[m].
+int bts_lap_enqueue_dense(const bts_lap_work *w, const double *cost, int ld, const int32_t *dims,
+                          int n_max, int m_max, double cost_limit, int32_t *x, int32_t *y,
+                          hipStream_t stream);
+// Enqueue the solver on an edge list already appended to w->e_* (hdr[0] = edge count).
+int bts_lap_enqueue_edges(const bts_lap_work *w, const int32_t *dims, int n_max, int m_max,
+                          double cost_limit, int32_t *x, int32_t *y, hipStream_t stream);
+// reset hdr before edges are appended
+int bts_lap_enqueue_reset(const bts_lap_work *w, hipStream_t stream);
+
+// ---- cosine similarity (cosine.hip) ------------------------------------------------------------
+// sim[i*ld+j] = max(0, <A[a_idx[i]], B[b_idx[j]]>) ; a_idx/b_idx nullable (= identity); the live
+// sizes come from dims (device, nullable -> use n_max/m_max).
+int bts_cos_enqueue(int which, const float *a, const int32_t *a_idx, int lda, const float *b,
+                    const int32_t *b_idx, int ldb, int d, const int32_t *dims, int n_max,
+                    int m_max, float *sim, int ld, hipStream_t stream);

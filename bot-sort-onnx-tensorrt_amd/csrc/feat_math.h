@@ -1,0 +1,70 @@
+// feat_math.h -- workgroup-cooperative float32 feature-row arithmetic (D:492-514).
+// Every function must be called by all threads of a workgroup (blockDim.x a multiple of 64,
+// at most 1024) with workgroup-uniform arguments.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace feat {
+
+// sum over the workgroup; result returned to every thread
+__device__ __forceinline__ float block_sum(float v) {
+    __shared__ float part[16];
+    __shared__ float total;
+#pragma unroll
+    for (int off = 32; off; off >>= 1) v += __shfl_xor(v, off);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();                      // protects `part`/`total` across back-to-back calls
+    if (lane == 0) part[wid] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.0f;
+        for (int w = 0; w < nw; ++w) s += part[w];
+        total = s;
+    }
+    __syncthreads();
+    return total;
+}
+
+__device__ __forceinline__ bool vec4_ok(const void *p, int d) { return ((uintptr_t)p % 16 == 0) && (d % 4 == 0); }
+
+// row /= ||row||_2   (np.linalg.norm of a float32 vector = sqrt(dot(x,x)) in float32)
+__device__ __forceinline__ void renorm_row(float *row, int d) {
+    float ss = 0.0f;
+    if (vec4_ok(row, d)) {
+        float4 *r4 = reinterpret_cast<float4 *>(row);
+        for (int k = threadIdx.x; k < d / 4; k += blockDim.x) {
+            const float4 v = r4[k];
+            ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+        const float nrm = sqrtf(block_sum(ss));
+        for (int k = threadIdx.x; k < d / 4; k += blockDim.x) {
+            float4 v = r4[k];
+            v.x /= nrm; v.y /= nrm; v.z /= nrm; v.w /= nrm;
+            r4[k] = v;
+        }
+    } else {
+        for (int k = threadIdx.x; k < d; k += blockDim.x) ss += row[k] * row[k];
+        const float nrm = sqrtf(block_sum(ss));
+        for (int k = threadIdx.x; k < d; k += blockDim.x) row[k] /= nrm;
+    }
+}
+
+// curr = f ; smooth = normalise(has ? alpha*smooth + beta*f : f)
+__device__ __forceinline__ void ema_row(float *curr, float *smooth, const float *f, int d, bool has, float alpha,
+                                        float beta) {
+    float ss = 0.0f;
+    for (int k = threadIdx.x; k < d; k += blockDim.x) {
+        const float fv = f[k];
+        const float s = has ? alpha * smooth[k] + beta * fv : fv;
+        ss += s * s;
+    }
+    const float nrm = sqrtf(block_sum(ss));
+    for (int k = threadIdx.x; k < d; k += blockDim.x) {
+        const float fv = f[k];
+        const float s = has ? alpha * smooth[k] + beta * fv : fv;
+        curr[k] = fv;
+        smooth[k] = s / nrm;
+    }
+}
+
+}  // namespace feat

@@ -1,0 +1,64 @@
+// features.hip -- ReID feature bookkeeping of a track (reference demo_bottrack_onnx_tflite.py:
+// 492-514, STrack.update_body_features / update_face_features):
+//     curr   = f
+//     smooth = f                          (first feature of the track)
+//            = alpha*smooth + (1-alpha)*f (afterwards; float32, alpha = 0.9 as a python float)
+//     smooth /= ||smooth||_2
+// plus the in-place renormalisation the reference applies to every detection's feature row when
+// the detection record is built (the first call aliases `smooth = f` and normalises in place,
+// quirk Q8).  One workgroup per row: a row is read once from HBM and stays in L2 for the second
+// sweep; float4 accesses, wavefront __shfl reduction of the squared norm.
+#include "bts_internal.h"
+#include "feat_math.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void k_feature_ema(float *__restrict__ curr, float *__restrict__ smooth,
+                                                     uint8_t *__restrict__ has_smooth,
+                                                     const int32_t *__restrict__ trk_idx,
+                                                     const float *__restrict__ det_feats,
+                                                     const int32_t *__restrict__ det_idx, int k, int d, float alpha,
+                                                     float beta) {
+    const int q = blockIdx.x;
+    if (q >= k) return;
+    const long t = trk_idx ? trk_idx[q] : q, s = det_idx ? det_idx[q] : q;
+    feat::ema_row(curr + t * d, smooth + t * d, det_feats + s * d, d, has_smooth[t] != 0, alpha, beta);
+    if (threadIdx.x == 0) has_smooth[t] = 1;
+}
+
+__global__ __launch_bounds__(256) void k_feature_renorm(float *__restrict__ feats, const int32_t *__restrict__ idx,
+                                                        int k, int d) {
+    const int q = blockIdx.x;
+    if (q >= k) return;
+    const long s = idx ? idx[q] : q;
+    feat::renorm_row(feats + s * d, d);
+}
+
+}  // namespace
+
+extern "C" {
+
+int bts_feature_ema(bts_context *ctx, float *curr, float *smooth, uint8_t *has_smooth,
+                    const int32_t *trk_idx, const float *det_feats, const int32_t *det_idx, int k, int d,
+                    double alpha, bts_stream stream) {
+    BTS_REQUIRE(ctx && k >= 0 && d > 0, "ctx, k, d");
+    if (k == 0) return BTS_OK;
+    BTS_REQUIRE(curr && smooth && has_smooth && det_feats, "null pointer");
+    // alpha and (1 - alpha) are python floats in the reference, demoted to float32 by the array
+    const float alpha32 = (float)alpha, beta = (float)(1.0 - alpha);
+    hipLaunchKernelGGL(k_feature_ema, dim3(k), dim3(256), 0, (hipStream_t)stream, curr, smooth, has_smooth,
+                       trk_idx, det_feats, det_idx, k, d, alpha32, beta);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+
+int bts_feature_renorm(bts_context *ctx, float *feats, const int32_t *idx, int k, int d, bts_stream stream) {
+    BTS_REQUIRE(ctx && k >= 0 && d > 0, "ctx, k, d");
+    if (k == 0) return BTS_OK;
+    BTS_REQUIRE(feats, "null pointer");
+    hipLaunchKernelGGL(k_feature_renorm, dim3(k), dim3(256), 0, (hipStream_t)stream, feats, idx, k, d);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+
+}  // extern "C"

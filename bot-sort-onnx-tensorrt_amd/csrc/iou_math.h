@@ -1,0 +1,44 @@
+// iou_math.h -- one (track box, detection box) IoU cost with the reference's dtype flow.
+//
+// Restates bbox_iou / iou_distance (demo_bottrack_onnx_tflite.py:1695-1713, 1745-1761): boxes are
+// tlbr, touching or disjoint boxes give IoU exactly 0 (cost exactly 1), no "+1" pixel convention.
+// The reference evaluates the expression with NumPy *scalars*, so every intermediate is float32
+// exactly when both of its operands are float32 (detections, never-predicted tracks) and float64
+// otherwise; max/min return one of their arguments.  Boxes are carried as float64 plus an
+// "is float32" flag (a float32 value is exactly representable), and the float32 branches below
+// reproduce those roundings bit for bit.  The final `1 - iou` is always float64.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace iou {
+
+__device__ __forceinline__ double sub(double hi, double lo, bool f32) {
+    return f32 ? (double)((float)hi - (float)lo) : hi - lo;
+}
+__device__ __forceinline__ double mul(double p, double q, bool f32) {
+    return f32 ? (double)((float)p * (float)q) : p * q;
+}
+
+__device__ __forceinline__ double area(const double b[4], bool f32) {
+    return mul(sub(b[2], b[0], f32), sub(b[3], b[1], f32), f32);
+}
+
+// cost = 1 - IoU(a, b); area_a / area_b precomputed with area() above.
+__device__ __forceinline__ double cost(const double a[4], bool a32, double area_a, const double b[4],
+                                       bool b32, double area_b) {
+    const bool tx0 = b[0] > a[0], ty0 = b[1] > a[1], tx1 = b[2] < a[2], ty1 = b[3] < a[3];
+    const double x_lo = tx0 ? b[0] : a[0], y_lo = ty0 ? b[1] : a[1];
+    const double x_hi = tx1 ? b[2] : a[2], y_hi = ty1 ? b[3] : a[3];
+    if (x_hi <= x_lo || y_hi <= y_lo) return 1.0;   // D:1705 (also the common case: no division)
+    const bool w32 = (tx0 ? b32 : a32) && (tx1 ? b32 : a32);
+    const bool h32 = (ty0 ? b32 : a32) && (ty1 ? b32 : a32);
+    const bool i32 = w32 && h32;
+    const double inter = mul(sub(x_hi, x_lo, w32), sub(y_hi, y_lo, h32), i32);
+    const bool ab32 = a32 && b32;
+    const double s = ab32 ? (double)((float)area_a + (float)area_b) : area_a + area_b;
+    const double den = (ab32 && i32) ? (double)((float)s - (float)inter) : s - inter;
+    const double q = i32 ? (double)((float)inter / (float)den) : inter / den;
+    return 1.0 - q;
+}
+
+}  // namespace iou

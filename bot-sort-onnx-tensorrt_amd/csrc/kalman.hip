@@ -1,0 +1,198 @@
+// kalman.hip -- batched Kalman kernels behind the C ABI (include/botsort_hip.h).
+//
+// One thread owns one track: its 8-vector and 8x8 covariance live in registers for the whole
+// predict / update, so each state element is read from HBM once and written once.  These
+// standalone entry points take the reference's array-of-rows layout (mean[n,8], cov[n,8,8]); the
+// resident tracker (tracker.hip) calls the same kf:: arithmetic on its component-major table,
+// where consecutive lanes touch consecutive addresses.
+#include "bts_internal.h"
+#include "kf_math.h"
+
+namespace {
+
+struct StateView {       // element (track t, component c) at base[t * st + c * sc]
+    double *mean; long mean_st, mean_sc;
+    double *cov;  long cov_st, cov_sc;
+};
+
+__device__ __forceinline__ void load_state(const StateView &v, long t, double m[8], double P[64]) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) m[c] = v.mean[t * v.mean_st + c * v.mean_sc];
+#pragma unroll
+    for (int c = 0; c < 64; ++c) P[c] = v.cov[t * v.cov_st + c * v.cov_sc];
+}
+__device__ __forceinline__ void store_state(const StateView &v, long t, const double m[8], const double P[64]) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v.mean[t * v.mean_st + c * v.mean_sc] = m[c];
+#pragma unroll
+    for (int c = 0; c < 64; ++c) v.cov[t * v.cov_st + c * v.cov_sc] = P[c];
+}
+
+__global__ __launch_bounds__(64) void k_initiate(const float *__restrict__ meas, int n, StateView v) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    float z[4] = {meas[t * 4 + 0], meas[t * 4 + 1], meas[t * 4 + 2], meas[t * 4 + 3]};
+    double m[8], P[64];
+    kf::initiate(z, m, P);
+    store_state(v, t, m, P);
+}
+
+__global__ __launch_bounds__(64) void k_multi_predict(StateView v, const uint8_t *__restrict__ zero_vel,
+                                                      const uint8_t *__restrict__ row_f32, int n,
+                                                      double *__restrict__ tlbr_out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    double m[8], P[64];
+    load_state(v, t, m, P);
+    if (zero_vel && zero_vel[t]) { m[6] = 0.0; m[7] = 0.0; }   // D:529-532
+    const bool f32 = row_f32 && row_f32[t];
+    kf::predict(m, P, f32);
+    store_state(v, t, m, P);
+    if (tlbr_out) {
+        double b[4];
+        kf::mean_to_tlbr(m, false, b);
+        tlbr_out[t * 4 + 0] = b[0]; tlbr_out[t * 4 + 1] = b[1];
+        tlbr_out[t * 4 + 2] = b[2]; tlbr_out[t * 4 + 3] = b[3];
+    }
+}
+
+__global__ __launch_bounds__(64) void k_project(StateView v, const uint8_t *__restrict__ row_f32, int n,
+                                                double *__restrict__ pmean, double *__restrict__ pcov) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    double m[8], P[64], S[16];
+    load_state(v, t, m, P);
+    kf::project(m, P, row_f32 && row_f32[t], S);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) pmean[t * 4 + c] = m[c];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) pcov[t * 16 + c] = S[c];
+}
+
+__global__ __launch_bounds__(64) void k_update(StateView v, const uint8_t *__restrict__ row_f32,
+                                               const int32_t *__restrict__ trk_idx,
+                                               const float *__restrict__ meas,
+                                               const int32_t *__restrict__ meas_idx, int k) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= k) return;
+    const int t = trk_idx ? trk_idx[q] : q;
+    const int d = meas_idx ? meas_idx[q] : q;
+    float z[4] = {meas[d * 4 + 0], meas[d * 4 + 1], meas[d * 4 + 2], meas[d * 4 + 3]};
+    double m[8], P[64];
+    load_state(v, t, m, P);
+    kf::update(m, P, z, row_f32 && row_f32[t]);
+    store_state(v, t, m, P);
+}
+
+// gating_distance for every (track, measurement) pair, D:338-380.  One thread per track keeps
+// the Cholesky factor in registers and walks the measurements; a block shares them through LDS.
+__global__ __launch_bounds__(64) void k_gating(StateView v, int n, const double *__restrict__ meas, int m,
+                                               int only_position, int metric, double *__restrict__ out) {
+    __shared__ double zs[64 * 4];
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    double mu[8], P[64], S[16], L[16];
+    const bool live = t < n;
+    if (live) {
+        load_state(v, t, mu, P);
+        kf::project(mu, P, false, S);
+        if (only_position) {   // 2x2 problem embedded in the 4x4 routines
+            S[2] = S[3] = S[6] = S[7] = S[8] = S[9] = S[12] = S[13] = S[11] = S[14] = 0.0;
+            S[10] = 1.0; S[15] = 1.0;
+        }
+        kf::chol4(S, L);
+    }
+    const int dim = only_position ? 2 : 4;
+    for (int j0 = 0; j0 < m; j0 += 64) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < 64 * 4; e += 64) {
+            const int j = j0 + e / 4;
+            zs[e] = j < m ? meas[j * 4 + (e & 3)] : 0.0;
+        }
+        __syncthreads();
+        if (!live) continue;
+        const int jn = min(64, m - j0);
+        for (int jj = 0; jj < jn; ++jj) {
+            double d[4] = {0, 0, 0, 0};
+            for (int a = 0; a < dim; ++a) d[a] = zs[jj * 4 + a] - mu[a];
+            double r = 0.0;
+            if (metric == 1) {
+                for (int a = 0; a < dim; ++a) r += d[a] * d[a];
+            } else {   // forward substitution L y = d, sum y^2
+                double y[4];
+                for (int i = 0; i < dim; ++i) {
+                    double s = d[i];
+                    for (int kk = 0; kk < i; ++kk) s -= L[i * 4 + kk] * y[kk];
+                    y[i] = s / L[i * 4 + i];
+                }
+                for (int a = 0; a < dim; ++a) r += y[a] * y[a];
+            }
+            out[(long)t * m + j0 + jj] = r;
+        }
+    }
+}
+
+StateView aos(double *mean, double *cov) { return StateView{mean, 8, 1, cov, 64, 1}; }
+
+}  // namespace
+
+extern "C" {
+
+int bts_kf_initiate(bts_context *ctx, const float *meas_xywh, int n, double *mean, double *cov,
+                    bts_stream stream) {
+    BTS_REQUIRE(ctx && n >= 0, "ctx, n");
+    if (n == 0) return BTS_OK;
+    BTS_REQUIRE(meas_xywh && mean && cov, "null pointer");
+    hipLaunchKernelGGL(k_initiate, dim3(bts_cdiv(n, 64)), dim3(64), 0, (hipStream_t)stream, meas_xywh, n,
+                       aos(mean, cov));
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+
+int bts_kf_multi_predict(bts_context *ctx, double *mean, double *cov, const uint8_t *zero_vel,
+                         const uint8_t *row_f32, int n, double *tlbr_out, bts_stream stream) {
+    BTS_REQUIRE(ctx && n >= 0, "ctx, n");
+    if (n == 0) return BTS_OK;
+    BTS_REQUIRE(mean && cov, "null pointer");
+    hipLaunchKernelGGL(k_multi_predict, dim3(bts_cdiv(n, 64)), dim3(64), 0, (hipStream_t)stream,
+                       aos(mean, cov), zero_vel, row_f32, n, tlbr_out);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+
+int bts_kf_project(bts_context *ctx, const double *mean, const double *cov, const uint8_t *row_f32,
+                   int n, double *pmean, double *pcov, bts_stream stream) {
+    BTS_REQUIRE(ctx && n >= 0, "ctx, n");
+    if (n == 0) return BTS_OK;
+    BTS_REQUIRE(mean && cov && pmean && pcov, "null pointer");
+    hipLaunchKernelGGL(k_project, dim3(bts_cdiv(n, 64)), dim3(64), 0, (hipStream_t)stream,
+                       aos(const_cast<double *>(mean), const_cast<double *>(cov)), row_f32, n, pmean, pcov);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+
+int bts_kf_update(bts_context *ctx, double *mean, double *cov, const uint8_t *row_f32,
+                  const int32_t *trk_idx, const float *meas_xywh, const int32_t *meas_idx, int k,
+                  bts_stream stream) {
+    BTS_REQUIRE(ctx && k >= 0, "ctx, k");
+    if (k == 0) return BTS_OK;
+    BTS_REQUIRE(mean && cov && meas_xywh, "null pointer");
+    hipLaunchKernelGGL(k_update, dim3(bts_cdiv(k, 64)), dim3(64), 0, (hipStream_t)stream, aos(mean, cov),
+                       row_f32, trk_idx, meas_xywh, meas_idx, k);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+
+int bts_kf_gating(bts_context *ctx, const double *mean, const double *cov, int n, const double *meas,
+                  int m, int only_position, int metric, double *out, bts_stream stream) {
+    BTS_REQUIRE(ctx && n >= 0 && m >= 0, "ctx, n, m");
+    BTS_REQUIRE(metric == 0 || metric == 1, "metric must be 0 (maha) or 1 (gaussian)");
+    if (n == 0 || m == 0) return BTS_OK;
+    BTS_REQUIRE(mean && cov && meas && out, "null pointer");
+    hipLaunchKernelGGL(k_gating, dim3(bts_cdiv(n, 64)), dim3(64), 0, (hipStream_t)stream,
+                       aos(const_cast<double *>(mean), const_cast<double *>(cov)), n, meas, m,
+                       only_position, metric, out);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+
+}  // extern "C"

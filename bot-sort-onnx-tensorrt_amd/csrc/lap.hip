@@ -1,0 +1,367 @@
+// lap.hip -- exact linear assignment with the semantics of
+//     lap.lapjv(cost, extend_cost=True, cost_limit=L)          (reference call site D:1682-1693)
+// i.e. minimise  sum(matched cost) + (L/2) * (#unmatched rows + #unmatched columns).
+//
+// The reference reaches a dense Jonker-Volgenant solver (third-party lap==0.4.0) on an
+// (n+m) x (n+m) padded matrix.  On the GPU that matrix is never formed.  Instead:
+//   1. only entries with cost <= L can appear in an optimum (matching such a pair must beat two
+//      dummies at L/2 each), so the problem is reduced to its *feasible edges* (sparsify);
+//   2. the objective equals  const + sum(matched cost) + L * (#unmatched rows): every row gets a
+//      private zero-reduced "exit" of cost L and columns may stay free (dual v_j = 0 while free);
+//   3. the feasible graph splits into connected components (union-find, root = smallest row),
+//      which are independent sub-problems: one wavefront solves one component with the
+//      Jonker-Volgenant / Hungarian shortest-augmenting-path step (Dijkstra over reduced costs,
+//      row duals u, column duals v), lanes working across the component's columns/edges and
+//      __shfl butterflies picking the (distance, column) lexicographic minimum.
+// The result is the optimal assignment; when the optimum is unique it is what lapjv returns.
+// Tie-breaking (unpinned in the reference): rows in ascending order, smallest
+// column on equal distance, a real column preferred over staying unmatched on equality.
+// Everything is deterministic regardless of the order edges were appended in.
+#include "bts_internal.h"
+
+namespace {
+
+enum { H_EDGES = 0, H_COMPS = 1, H_ERR = 2 };
+
+#define RLX(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+
+struct LapArgs {
+    bts_lap_work w;
+    const int32_t *dims;
+    int n_max, m_max;
+    double limit;
+    int32_t *x, *y;
+};
+
+// Lanes of one wavefront hand values to each other through global memory (lane 0 publishes a
+// decision, every lane reads it back): drain this wave's outstanding stores/loads before going on.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ---- 1. sparsify a dense matrix: one wavefront per row, ordered ballot append -------------------
+__global__ __launch_bounds__(256) void k_edges_dense(bts_lap_work w, const double *__restrict__ cost, int ld,
+                                                     const int32_t *__restrict__ dims, int n_max, int m_max,
+                                                     double limit) {
+    const int n = dims ? dims[0] : n_max, m = dims ? dims[1] : m_max;
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwave = (gridDim.x * blockDim.x) >> 6;
+    for (int i = wave; i < n; i += nwave) {
+        const double *row = cost + (long)i * ld;
+        for (int j0 = 0; j0 < m; j0 += 64) {
+            const int j = j0 + lane;
+            const double c = j < m ? row[j] : 0.0;
+            const bool ok = j < m && c <= limit;
+            const unsigned long long mask = __ballot(ok);
+            if (mask == 0) continue;
+            const int cnt = __popcll(mask);
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&w.hdr[H_EDGES], cnt);
+            base = __shfl(base, 0);
+            if ((long)base + cnt > w.e_cap) { if (lane == 0) w.hdr[H_ERR] = 1; continue; }
+            if (ok) {
+                const int pos = base + __popcll(mask & ((1ull << lane) - 1));
+                w.e_row[pos] = i; w.e_col[pos] = j; w.e_cost[pos] = c;
+            }
+        }
+    }
+}
+
+// ---- 2. single-workgroup preparation: CSR by row, components, grouping --------------------------
+__device__ int find_root(int32_t *parent, int x) {
+    int p = RLX(&parent[x]);
+    while (p != x) {
+        const int gp = RLX(&parent[p]);
+        if (gp != p) __hip_atomic_store(&parent[x], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // path halving
+        x = p; p = gp;
+    }
+    return x;
+}
+
+__device__ void unite(int32_t *parent, int a, int b) {
+    int ra = find_root(parent, a), rb = find_root(parent, b);
+    while (ra != rb) {
+        if (ra < rb) { const int t = ra; ra = rb; rb = t; }      // hook the larger root under the smaller
+        const int old = atomicCAS(&parent[ra], ra, rb);
+        if (old == ra) return;
+        ra = find_root(parent, old);
+        rb = find_root(parent, rb);
+    }
+}
+
+// exclusive scan of arr[0..len) in place (values via RLX), total returned to every thread.
+// `tmp` is LDS of blockDim.x ints.
+__device__ int block_exscan(int32_t *arr, int len, int32_t *tmp) {
+    const int nth = blockDim.x, tid = threadIdx.x;
+    const int per = (len + nth - 1) / nth;
+    const int lo = min(len, tid * per), hi = min(len, lo + per);
+    int s = 0;
+    for (int k = lo; k < hi; ++k) s += RLX(&arr[k]);
+    tmp[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < nth; off <<= 1) {      // Hillis-Steele inclusive scan of the partials
+        const int v = tid >= off ? tmp[tid - off] : 0;
+        __syncthreads();
+        tmp[tid] += v;
+        __syncthreads();
+    }
+    const int total = tmp[nth - 1];
+    int run = tid ? tmp[tid - 1] : 0;
+    __syncthreads();
+    for (int k = lo; k < hi; ++k) { const int v = RLX(&arr[k]); arr[k] = run; run += v; }
+    __syncthreads();
+    return total;
+}
+
+__global__ __launch_bounds__(1024) void k_prepare(LapArgs A) {
+    __shared__ int32_t tmp[1024];
+    const bts_lap_work &w = A.w;
+    const int n = A.dims ? A.dims[0] : A.n_max, m = A.dims ? A.dims[1] : A.m_max;
+    const int tid = threadIdx.x, nth = blockDim.x;
+    int E = RLX(&w.hdr[H_EDGES]);
+    if ((long)E > w.e_cap) E = (int)w.e_cap;
+
+    for (int i = tid; i < n; i += nth) { w.deg[i] = 0; w.parent[i] = i; A.x[i] = -1; }
+    for (int j = tid; j < m; j += nth) { w.cdeg[j] = 0; w.parent[n + j] = n + j; A.y[j] = -1; w.v[j] = 0.0; }
+    __syncthreads();
+    for (int e = tid; e < E; e += nth) {
+        const int i = w.e_row[e], j = w.e_col[e];
+        atomicAdd(&w.deg[i], 1);
+        atomicAdd(&w.cdeg[j], 1);
+        unite(w.parent, i, n + j);
+    }
+    __syncthreads();
+    // flatten: every active node points at its root (a row: rows have the smaller node ids)
+    for (int i = tid; i < n; i += nth)
+        if (RLX(&w.deg[i]) > 0) { const int r = find_root(w.parent, i); __hip_atomic_store(&w.parent[i], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    for (int j = tid; j < m; j += nth)
+        if (RLX(&w.cdeg[j]) > 0) { const int r = find_root(w.parent, n + j); __hip_atomic_store(&w.parent[n + j], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __syncthreads();
+    // CSR row pointers
+    for (int i = tid; i < n; i += nth) w.rptr[i] = RLX(&w.deg[i]);
+    __syncthreads();
+    block_exscan(w.rptr, n, tmp);
+    if (tid == 0) w.rptr[n] = E;
+    for (int i = tid; i < n; i += nth) w.cursor[i] = RLX(&w.rptr[i]);
+    // component ids: rank of each root row among the roots
+    for (int i = tid; i < n; i += nth) w.comp_of[i] = (RLX(&w.deg[i]) > 0 && RLX(&w.parent[i]) == i) ? 1 : 0;
+    __syncthreads();
+    const int C = block_exscan(w.comp_of, n, tmp);
+    if (tid == 0) w.hdr[H_COMPS] = C;
+    // component sizes -> pointers
+    for (int c = tid; c <= C; c += nth) { w.crow_ptr[c] = 0; w.ccol_ptr[c] = 0; }
+    __syncthreads();
+    for (int i = tid; i < n; i += nth)
+        if (RLX(&w.deg[i]) > 0) atomicAdd(&w.crow_ptr[RLX(&w.comp_of[RLX(&w.parent[i])])], 1);
+    for (int j = tid; j < m; j += nth)
+        if (RLX(&w.cdeg[j]) > 0) atomicAdd(&w.ccol_ptr[RLX(&w.comp_of[RLX(&w.parent[n + j])])], 1);
+    __syncthreads();
+    block_exscan(w.crow_ptr, C + 1, tmp);
+    block_exscan(w.ccol_ptr, C + 1, tmp);
+    for (int c = tid; c < C; c += nth) { w.ccur_r[c] = RLX(&w.crow_ptr[c]); w.ccur_c[c] = RLX(&w.ccol_ptr[c]); }
+    __syncthreads();
+    // fills
+    for (int e = tid; e < E; e += nth) {
+        const int pos = atomicAdd(&w.cursor[w.e_row[e]], 1);
+        w.csr_col[pos] = w.e_col[e];
+        w.csr_cost[pos] = w.e_cost[e];
+    }
+    for (int i = tid; i < n; i += nth)
+        if (RLX(&w.deg[i]) > 0) w.crows[atomicAdd(&w.ccur_r[RLX(&w.comp_of[RLX(&w.parent[i])])], 1)] = i;
+    for (int j = tid; j < m; j += nth)
+        if (RLX(&w.cdeg[j]) > 0) w.ccols[atomicAdd(&w.ccur_c[RLX(&w.comp_of[RLX(&w.parent[n + j])])], 1)] = j;
+}
+
+// ---- 3. one wavefront per component: shortest augmenting paths ----------------------------------
+__device__ void solve_component(const LapArgs &A, int c, int lane) {
+    const bts_lap_work &w = A.w;
+    const double limit = A.limit;
+    const double INF = __builtin_huge_val();
+    int32_t *x = A.x, *y = A.y;
+    const int rs = w.crow_ptr[c], r = w.crow_ptr[c + 1] - rs;
+    const int cs = w.ccol_ptr[c], cn = w.ccol_ptr[c + 1] - cs;
+
+    // rows in ascending order (the grouping pass appended them in arbitrary order)
+    for (int k = lane; k < r; k += 64) {
+        const int mine = w.crows[rs + k];
+        int rank = 0;
+        for (int q = 0; q < r; ++q) rank += w.crows[rs + q] < mine;
+        w.crows_s[rs + rank] = mine;
+    }
+    wave_sync();
+    // row duals start at the row minimum (<= limit): all reduced costs >= 0, exits >= 0
+    for (int k = lane; k < r; k += 64) {
+        const int i = w.crows_s[rs + k];
+        double mn = limit;
+        for (int e = w.rptr[i]; e < w.rptr[i + 1]; ++e) mn = fmin(mn, w.csr_cost[e]);
+        w.u[i] = mn;
+    }
+    wave_sync();
+
+    for (int t = 0; t < r; ++t) {
+        const int i0 = w.crows_s[rs + t];
+        for (int k = lane; k < cn; k += 64) { const int j = w.ccols[cs + k]; w.dist[j] = INF; w.scanned[j] = 0; }
+        wave_sync();
+        double exit_d = limit - w.u[i0];   // leave i0 unmatched
+        int exit_row = i0;
+        int cur = i0;
+        double dcur = 0.0, mu = 0.0;
+        int end_col = -1;                  // >= 0: path ends at this free column
+        for (;;) {
+            const double ucur = w.u[cur];
+            const int e1 = w.rptr[cur + 1];
+            for (int e = w.rptr[cur] + lane; e < e1; e += 64) {
+                const int j = w.csr_col[e];
+                if (!w.scanned[j]) {
+                    const double nd = dcur + ((w.csr_cost[e] - ucur) - w.v[j]);
+                    if (nd < w.dist[j]) { w.dist[j] = nd; w.pred[j] = cur; }
+                }
+            }
+            wave_sync();
+            double bd = INF;
+            int bj = 0x7fffffff;
+            for (int k = lane; k < cn; k += 64) {
+                const int j = w.ccols[cs + k];
+                if (!w.scanned[j]) {
+                    const double dj = w.dist[j];
+                    if (dj < bd || (dj == bd && j < bj)) { bd = dj; bj = j; }
+                }
+            }
+#pragma unroll
+            for (int off = 32; off; off >>= 1) {
+                const double od = __shfl_xor(bd, off);
+                const int oj = __shfl_xor(bj, off);
+                if (od < bd || (od == bd && oj < bj)) { bd = od; bj = oj; }
+            }
+            if (!(bd < INF) || exit_d < bd) { mu = exit_d; break; }
+            const int owner = y[bj];
+            if (owner < 0) { mu = bd; end_col = bj; break; }
+            if (lane == 0) w.scanned[bj] = 1;
+            wave_sync();
+            cur = owner; dcur = bd;
+            const double e2 = bd + (limit - w.u[owner]);
+            if (e2 < exit_d) { exit_d = e2; exit_row = owner; }
+        }
+        // dual update (before the matching changes: y[] still names the tree rows)
+        for (int k = lane; k < cn; k += 64) {
+            const int j = w.ccols[cs + k];
+            if (w.scanned[j]) {
+                const double delta = mu - w.dist[j];
+                w.u[y[j]] += delta;
+                w.v[j] -= delta;
+            }
+        }
+        if (lane == 0) w.u[i0] += mu;
+        wave_sync();
+        // augment
+        int j = end_col;
+        if (j < 0) {
+            if (exit_row == i0) continue;     // i0 stays unmatched
+            j = x[exit_row];
+            if (lane == 0) x[exit_row] = -1;
+        }
+        for (;;) {
+            const int i = w.pred[j];
+            const int jn = x[i];
+            wave_sync();
+            if (lane == 0) { x[i] = j; y[j] = i; }
+            if (i == i0) break;
+            j = jn;
+        }
+        wave_sync();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_solve(LapArgs A) {
+    const int C = A.w.hdr[H_COMPS];
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwave = (gridDim.x * blockDim.x) >> 6;
+    for (int c = wave; c < C; c += nwave) solve_component(A, c, lane);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------- host
+static size_t carve(size_t &off, size_t bytes) { const size_t o = off; off = bts_align(off + bytes); return o; }
+
+static void layout(bts_lap_work *w, char *base, size_t &off, int n, int m, int64_t e) {
+#define SLOT(field, type, count) { size_t o = carve(off, sizeof(type) * (size_t)(count)); w->field = base ? (type *)(base + o) : nullptr; }
+    SLOT(hdr, int32_t, 16);
+    SLOT(e_row, int32_t, e); SLOT(e_col, int32_t, e); SLOT(e_cost, double, e);
+    SLOT(deg, int32_t, n); SLOT(cdeg, int32_t, m); SLOT(rptr, int32_t, n + 1); SLOT(cursor, int32_t, n);
+    SLOT(csr_col, int32_t, e); SLOT(csr_cost, double, e);
+    SLOT(parent, int32_t, n + m); SLOT(comp_of, int32_t, n);
+    SLOT(crow_ptr, int32_t, n + 1); SLOT(ccol_ptr, int32_t, n + 1);
+    SLOT(ccur_r, int32_t, n + 1); SLOT(ccur_c, int32_t, n + 1);
+    SLOT(crows, int32_t, n); SLOT(crows_s, int32_t, n); SLOT(ccols, int32_t, m);
+    SLOT(u, double, n); SLOT(v, double, m); SLOT(dist, double, m);
+    SLOT(pred, int32_t, m); SLOT(scanned, int32_t, m);
+#undef SLOT
+}
+
+size_t bts_lap_work_bytes(int n_cap, int m_cap, int64_t e_cap) {
+    bts_lap_work w; size_t off = 0;
+    layout(&w, nullptr, off, n_cap < 1 ? 1 : n_cap, m_cap < 1 ? 1 : m_cap, e_cap < 1 ? 1 : e_cap);
+    return off;
+}
+
+void bts_lap_work_carve(bts_lap_work *w, void *block, int n_cap, int m_cap, int64_t e_cap) {
+    size_t off = 0;
+    n_cap = n_cap < 1 ? 1 : n_cap; m_cap = m_cap < 1 ? 1 : m_cap; e_cap = e_cap < 1 ? 1 : e_cap;
+    layout(w, (char *)block, off, n_cap, m_cap, e_cap);
+    w->n_cap = n_cap; w->m_cap = m_cap; w->e_cap = e_cap; w->bytes = off;
+}
+
+int bts_lap_enqueue_reset(const bts_lap_work *w, hipStream_t stream) {
+    BTS_HIP(hipMemsetAsync(w->hdr, 0, 16 * sizeof(int32_t), stream));
+    return BTS_OK;
+}
+
+int bts_lap_enqueue_edges(const bts_lap_work *w, const int32_t *dims, int n_max, int m_max,
+                          double cost_limit, int32_t *x, int32_t *y, hipStream_t stream) {
+    LapArgs A{*w, dims, n_max, m_max, cost_limit, x, y};
+    hipLaunchKernelGGL(k_prepare, dim3(1), dim3(1024), 0, stream, A);
+    BTS_LAUNCH_CHECK();
+    const int waves = n_max < m_max ? n_max : m_max;   // #components <= min(n, m)
+    int blocks = bts_cdiv(waves < 1 ? 1 : waves, 4);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_solve, dim3(blocks), dim3(256), 0, stream, A);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+
+int bts_lap_enqueue_dense(const bts_lap_work *w, const double *cost, int ld, const int32_t *dims,
+                          int n_max, int m_max, double cost_limit, int32_t *x, int32_t *y,
+                          hipStream_t stream) {
+    int rc = bts_lap_enqueue_reset(w, stream);
+    if (rc) return rc;
+    if (n_max > 0 && m_max > 0) {
+        int blocks = bts_cdiv(n_max, 4);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(k_edges_dense, dim3(blocks), dim3(256), 0, stream, *w, cost, ld, dims, n_max, m_max,
+                           cost_limit);
+        BTS_LAUNCH_CHECK();
+    }
+    return bts_lap_enqueue_edges(w, dims, n_max, m_max, cost_limit, x, y, stream);
+}
+
+extern "C" int bts_lapjv(bts_context *ctx, const double *cost, int n, int m, int ld, double cost_limit,
+                         int32_t *x, int32_t *y, bts_stream stream) {
+    BTS_REQUIRE(ctx && n >= 0 && m >= 0, "ctx, n, m");
+    BTS_REQUIRE(cost_limit == cost_limit && cost_limit < 1e300, "cost_limit must be finite");
+    if (n == 0 && m == 0) return BTS_OK;
+    BTS_REQUIRE((n == 0 || x) && (m == 0 || y), "null x / y");
+    BTS_REQUIRE(n == 0 || m == 0 || (cost && ld >= m), "null cost / ld < m");
+    const int64_t e_cap = (int64_t)n * m;
+    BTS_REQUIRE(e_cap < (1ll << 31), "n*m must fit int32");
+    const size_t bytes = bts_lap_work_bytes(n, m, e_cap);
+    // the arena is reused across calls on one context: order reuse after earlier work on it
+    if (bytes > ctx->scratch.cap) BTS_HIP(hipDeviceSynchronize());
+    int rc = ctx->scratch.ensure(bytes);
+    if (rc) return rc;
+    bts_lap_work w;
+    bts_lap_work_carve(&w, ctx->scratch.base, n, m, e_cap);
+    return bts_lap_enqueue_dense(&w, cost, ld, nullptr, n, m, cost_limit, x, y, (hipStream_t)stream);
+}

@@ -1,0 +1,751 @@
+// tracker.hip -- the resident BoT-SORT tracker: one BoTSORT.update (tracking half, reference
+// demo_bottrack_onnx_tflite.py:1414-1639) as a chain of kernel enqueues with NO host round trip.
+//
+// State lives in HBM in a slot-indexed structure-of-arrays track table (DESIGN.md "data layout"):
+//   mean[8][T], cov[64][T]      float64, component-major -> lane t touches address base+t: coalesced
+//   body_curr/smooth[T][D]      float32 ReID rows (the matcher reads `curr`, quirk Q1)
+//   state/ids/frame counters[T] int32
+//   tracked[], lost[]           ordered slot lists = the reference's tracked_stracks / lost_stracks
+// All per-frame sizes (pool rows N, high/low detections, ...) are computed on the device and read
+// by later kernels from `hdr`; grids are sized for capacity and surplus workgroups exit at once.
+// That is what makes a step capturable in a hipGraph and lets frames be enqueued back to back.
+#include "bts_internal.h"
+#include "feat_math.h"
+#include "iou_math.h"
+#include "kf_math.h"
+
+namespace {
+
+enum {   // hdr[] fields
+    H_FRAME = 0, H_NTRACKED, H_NLOST, H_NREMOVED, H_LASTID, H_NPOOL, H_NHI, H_NLO, H_NUNC, H_NR2, H_NLEFT,
+    H_ERR, H_NCONF, H_ALLF32, H_NFREE, H_NDETS, H_NT2, H_NL2, H_NBORN,
+    H_DIMS1 = 24, H_DIMS2 = 26, H_DIMS3 = 28, H_DIMSD = 30, H_SIZE = 32
+};
+enum { F_REFIND = 1, F_LOSTNOW = 2, F_REMOVEDNOW = 4 };
+enum { ERR_TRACK_CAPACITY = 1, ERR_LAP_EDGES = 2 };
+
+struct Dev {
+    int T, Mx, D, Df;
+    // thresholds (float64 like the python attributes)
+    double high, low, new_thr, match1, match2, match3, prox, dedupe_thr;
+    float app, ema_a, ema_b;
+    int max_time_lost;
+    // track table
+    double *mean, *cov;
+    uint8_t *f32, *in_removed, *in_use, *flag;
+    int32_t *state, *is_activated, *track_id, *frame_id, *start_frame, *tracklet_len, *det_index;
+    float *score;
+    float *body_curr, *body_smooth, *face_curr, *face_smooth;
+    uint8_t *has_body, *has_face;
+    int32_t *tracked, *lost, *tracked2, *lost2, *free_list;
+    int32_t *hdr;
+    // per-frame work
+    int32_t *pool_slot, *unc_slot, *hi_idx, *lo_idx, *r2_row, *r2_slot, *left_hi, *left_det, *born_slot;
+    double *pool_tlbr, *unc_tlbr, *det_tlbr, *r2_tlbr;
+    uint8_t *unc_f32, *ones;
+    float *det_xywh;
+    float *sim, *fsim;
+    double *cost1, *cost2, *cost3;
+    int32_t *x1, *y1, *x2, *y2, *x3, *y3;
+    // dedupe
+    double *tl_tlbr, *ll_tlbr;
+    uint8_t *tl_f32, *ll_f32, *drop_t, *drop_l;
+    int32_t *tl_age, *ll_age;
+    // inputs of the current step
+    const int32_t *boxes;
+    const float *scores;
+    float *feats, *face_feats;
+    int m;
+};
+
+// ---- single-workgroup helpers ---------------------------------------------------------------------
+__device__ int block_exscan_i(int v, int32_t *tmp, int *total) {   // exclusive scan of one value per thread
+    const int tid = threadIdx.x, nth = blockDim.x;
+    __syncthreads();
+    tmp[tid] = v;
+    __syncthreads();
+    for (int off = 1; off < nth; off <<= 1) {
+        const int t = tid >= off ? tmp[tid - off] : 0;
+        __syncthreads();
+        tmp[tid] += t;
+        __syncthreads();
+    }
+    *total = tmp[nth - 1];
+    return tmp[tid] - v;
+}
+
+// Ordered compaction of the indices k in [0, L) with pred(k): emit(position, k). Returns the count.
+template <class Pred, class Emit>
+__device__ int block_compact(int L, int32_t *tmp, Pred pred, Emit emit) {
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const int per = (L + nth - 1) / nth;
+    const int lo = min(L, tid * per), hi = min(L, lo + per);
+    int cnt = 0;
+    for (int k = lo; k < hi; ++k) cnt += pred(k) ? 1 : 0;
+    int total;
+    int pos = block_exscan_i(cnt, tmp, &total);
+    for (int k = lo; k < hi; ++k)
+        if (pred(k)) emit(pos++, k);
+    __syncthreads();
+    return total;
+}
+
+__device__ __forceinline__ void load_state(const Dev &d, int slot, double m[8], double P[64]) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) m[c] = d.mean[(long)c * d.T + slot];
+#pragma unroll
+    for (int c = 0; c < 64; ++c) P[c] = d.cov[(long)c * d.T + slot];
+}
+__device__ __forceinline__ void store_state(const Dev &d, int slot, const double m[8], const double P[64]) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) d.mean[(long)c * d.T + slot] = m[c];
+#pragma unroll
+    for (int c = 0; c < 64; ++c) d.cov[(long)c * d.T + slot] = P[c];
+}
+__device__ __forceinline__ void slot_tlbr(const Dev &d, int slot, double out[4]) {
+    double m[8];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) m[c] = d.mean[(long)c * d.T + slot];
+    kf::mean_to_tlbr(m, d.f32[slot] != 0, out);
+}
+
+// ---- K1: frame prologue (1 workgroup) ---------------------------------------------------------------
+// D:1414-1423 (split tracked into confirmed / unconfirmed, pool = confirmed ++ lost) and the
+// detection records of D:1488-1532 (high: score > 0.40, low: 0.1 <= score <= 0.40; float32 boxes).
+__global__ __launch_bounds__(1024) void tk_prep(Dev d) {
+    __shared__ int32_t tmp[1024];
+    __shared__ int s_allf32;
+    int32_t *h = d.hdr;
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const int nt = h[H_NTRACKED], nl = h[H_NLOST], m = d.m;
+    if (tid == 0) s_allf32 = 1;
+    const int nconf = block_compact(nt, tmp, [&](int k) { return d.is_activated[d.tracked[k]] != 0; },
+                                    [&](int p, int k) { d.pool_slot[p] = d.tracked[k]; });
+    const int nunc = block_compact(nt, tmp, [&](int k) { return d.is_activated[d.tracked[k]] == 0; },
+                                   [&](int p, int k) { d.unc_slot[p] = d.tracked[k]; });
+    for (int k = tid; k < nl; k += nth) d.pool_slot[nconf + k] = d.lost[k];
+    const int N = nconf + nl;
+    __syncthreads();
+    int all32 = 1;
+    for (int k = tid; k < N; k += nth) { const int s = d.pool_slot[k]; d.flag[s] = 0; if (!d.f32[s]) all32 = 0; }
+    for (int k = tid; k < nunc; k += nth) d.flag[d.unc_slot[k]] = 0;
+    if (!all32) s_allf32 = 0;
+    // detections
+    for (int j = tid; j < m; j += nth) {
+        const int x1 = d.boxes[j * 4 + 0], y1 = d.boxes[j * 4 + 1], x2 = d.boxes[j * 4 + 2], y2 = d.boxes[j * 4 + 3];
+        const float tx = (float)x1, ty = (float)y1, w = (float)(x2 - x1), hh = (float)(y2 - y1);   // _tlwh, D:465
+        d.det_tlbr[j * 4 + 0] = (double)tx; d.det_tlbr[j * 4 + 1] = (double)ty;
+        d.det_tlbr[j * 4 + 2] = (double)(w + tx); d.det_tlbr[j * 4 + 3] = (double)(hh + ty);         // D:635-642
+        d.det_xywh[j * 4 + 0] = tx + w / 2; d.det_xywh[j * 4 + 1] = ty + hh / 2;                     // D:663-670
+        d.det_xywh[j * 4 + 2] = w; d.det_xywh[j * 4 + 3] = hh;
+    }
+    const int nhi = block_compact(m, tmp, [&](int j) { return (double)d.scores[j] > d.high; },
+                                  [&](int p, int j) { d.hi_idx[p] = j; });
+    const int nlo = block_compact(m, tmp, [&](int j) { const double s = (double)d.scores[j]; return s <= d.high && s >= d.low; },
+                                  [&](int p, int j) { d.lo_idx[p] = j; });
+    __syncthreads();
+    if (tid == 0) {
+        h[H_FRAME] += 1;
+        h[H_NPOOL] = N; h[H_NCONF] = nconf; h[H_NUNC] = nunc; h[H_NHI] = nhi; h[H_NLO] = nlo; h[H_NDETS] = m;
+        h[H_ALLF32] = (N > 0 && s_allf32) ? 1 : 0;
+        h[H_DIMS1] = N; h[H_DIMS1 + 1] = nhi;
+        h[H_NR2] = 0; h[H_NLEFT] = 0; h[H_NBORN] = 0;
+        h[H_DIMS2] = 0; h[H_DIMS2 + 1] = nlo; h[H_DIMS3] = nunc; h[H_DIMS3 + 1] = 0;
+    }
+}
+
+// ---- K2: STrack.multi_predict over the pool (D:524-536 + D:265-302) ---------------------------------
+__global__ __launch_bounds__(256) void tk_predict(Dev d) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= d.hdr[H_NPOOL]) return;
+    const int s = d.pool_slot[r];
+    double m[8], P[64];
+    load_state(d, s, m, P);
+    if (d.state[s] != BTS_TRACKED) { m[6] = 0.0; m[7] = 0.0; }
+    kf::predict(m, P, d.hdr[H_ALLF32] != 0);   // a batch is float32 only if every row is (np.asarray)
+    store_state(d, s, m, P);
+    d.f32[s] = 0;
+    double b[4];
+    kf::mean_to_tlbr(m, false, b);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) d.pool_tlbr[r * 4 + c] = b[c];
+}
+
+// ---- cost tiles ----------------------------------------------------------------------------------------
+constexpr int CT_ROWS = 16, CT_COLS = 256;
+
+__device__ __forceinline__ float face_fixup(float s) {
+    const double dd = fabs((double)s - 0.9999999);
+    return dd <= 1e-08 + 1e-08 * 0.9999999 ? 0.0f : s;
+}
+
+// STAGE 1: cost = min(iou_d, emb) with the appearance gate (D:1539-1554)
+// STAGE 2: cost = iou_d (D:1570)      STAGE 3: D:1590-1602
+template <int STAGE>
+__global__ __launch_bounds__(CT_COLS) void tk_cost(Dev d) {
+    __shared__ double sa[CT_ROWS][4];
+    __shared__ double sarea[CT_ROWS];
+    __shared__ int sflag[CT_ROWS];
+    const int32_t *h = d.hdr;
+    const int n = STAGE == 1 ? h[H_NPOOL] : STAGE == 2 ? h[H_NR2] : h[H_NUNC];
+    const int m = STAGE == 1 ? h[H_NHI] : STAGE == 2 ? h[H_NLO] : h[H_NLEFT];
+    const int i0 = blockIdx.y * CT_ROWS, q = blockIdx.x * CT_COLS + threadIdx.x;
+    if (i0 >= n || blockIdx.x * CT_COLS >= m) return;
+    const double *abox = STAGE == 1 ? d.pool_tlbr : STAGE == 2 ? d.r2_tlbr : d.unc_tlbr;
+    if (threadIdx.x < CT_ROWS && i0 + threadIdx.x < n) {
+        const int i = i0 + threadIdx.x;
+        double box[4] = {abox[i * 4 + 0], abox[i * 4 + 1], abox[i * 4 + 2], abox[i * 4 + 3]};
+        const bool f = STAGE == 3 ? d.unc_f32[i] != 0 : false;
+        for (int c = 0; c < 4; ++c) sa[threadIdx.x][c] = box[c];
+        sarea[threadIdx.x] = iou::area(box, f);
+        sflag[threadIdx.x] = f;
+    }
+    __syncthreads();
+    if (q >= m) return;
+    const int det = STAGE == 1 ? d.hi_idx[q] : STAGE == 2 ? d.lo_idx[q] : d.left_det[q];
+    const double bb[4] = {d.det_tlbr[det * 4 + 0], d.det_tlbr[det * 4 + 1], d.det_tlbr[det * 4 + 2], d.det_tlbr[det * 4 + 3]};
+    const double area_b = iou::area(bb, true);
+    double *cost = STAGE == 1 ? d.cost1 : STAGE == 2 ? d.cost2 : d.cost3;
+    const int rows = min(CT_ROWS, n - i0);
+    for (int r = 0; r < rows; ++r) {
+        const double aa[4] = {sa[r][0], sa[r][1], sa[r][2], sa[r][3]};
+        const double iou_d = iou::cost(aa, sflag[r] != 0, sarea[r], bb, true, area_b);
+        const long o = (long)(i0 + r) * d.Mx + q;
+        double c = iou_d;
+        if (STAGE == 1) {
+            float emb = 1.0f - d.sim[o];
+            const float face = 1.0f - (d.Df ? face_fixup(d.fsim[o]) : 0.0f);
+            if (fminf(emb, face) > d.app) emb = 1.0f;
+            c = fmin(iou_d, (double)emb);
+        } else if (STAGE == 3) {
+            float emb = 1.0f - d.sim[o];
+            if (emb > d.app) emb = 1.0f;
+            if (iou_d > d.prox) emb = 1.0f;
+            c = fmin(iou_d, (double)emb);
+        }
+        cost[o] = c;
+    }
+}
+
+// ---- detection feature rows: in-place renormalisation (quirk Q8) ------------------------------------------
+__global__ __launch_bounds__(256) void tk_renorm(Dev d) {
+    const int32_t *h = d.hdr;
+    const int nhi = h[H_NHI], nlo = h[H_NLO], q = blockIdx.x;
+    if (q >= nhi + nlo) return;
+    const long det = q < nhi ? d.hi_idx[q] : d.lo_idx[q - nhi];
+    feat::renorm_row(d.feats + det * d.D, d.D);
+    if (d.Df) feat::renorm_row(d.face_feats + det * d.Df, d.Df);
+}
+
+// ---- match application: Kalman update + lifecycle (D:570-610) ---------------------------------------------
+template <int STAGE>
+__global__ __launch_bounds__(256) void tk_apply_kf(Dev d) {
+    const int32_t *h = d.hdr;
+    const int n = STAGE == 1 ? h[H_NPOOL] : STAGE == 2 ? h[H_NR2] : h[H_NUNC];
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int s = STAGE == 1 ? d.pool_slot[r] : STAGE == 2 ? d.r2_slot[r] : d.unc_slot[r];
+    const int xq = STAGE == 1 ? d.x1[r] : STAGE == 2 ? d.x2[r] : d.x3[r];
+    if (xq < 0) {
+        if (STAGE == 2) { d.state[s] = BTS_LOST; d.flag[s] |= F_LOSTNOW; }                 // D:1582-1586
+        if (STAGE == 3) { d.state[s] = BTS_REMOVED; d.flag[s] |= F_REMOVEDNOW; }           // D:1609-1612
+        return;
+    }
+    const int det = STAGE == 1 ? d.hi_idx[xq] : STAGE == 2 ? d.lo_idx[xq] : d.left_det[xq];
+    const float z[4] = {d.det_xywh[det * 4 + 0], d.det_xywh[det * 4 + 1], d.det_xywh[det * 4 + 2], d.det_xywh[det * 4 + 3]};
+    double m[8], P[64];
+    load_state(d, s, m, P);
+    kf::update(m, P, z, d.f32[s] != 0);
+    store_state(d, s, m, P);
+    d.f32[s] = 0;
+    const int frame = h[H_FRAME];
+    if (d.state[s] == BTS_TRACKED) {
+        d.tracklet_len[s] += 1;                         // STrack.update
+    } else {
+        d.tracklet_len[s] = 0;                          // STrack.re_activate (new_id=False)
+        d.flag[s] |= F_REFIND;
+    }
+    d.state[s] = BTS_TRACKED;
+    d.is_activated[s] = 1;
+    d.frame_id[s] = frame;
+    d.score[s] = d.scores[det];
+    d.det_index[s] = det;
+}
+
+template <int STAGE>
+__global__ __launch_bounds__(256) void tk_apply_feat(Dev d) {
+    const int32_t *h = d.hdr;
+    const int n = STAGE == 1 ? h[H_NPOOL] : STAGE == 2 ? h[H_NR2] : h[H_NUNC];
+    const int r = blockIdx.x;
+    if (r >= n) return;
+    const int xq = STAGE == 1 ? d.x1[r] : STAGE == 2 ? d.x2[r] : d.x3[r];
+    if (xq < 0) return;
+    const long s = STAGE == 1 ? d.pool_slot[r] : STAGE == 2 ? d.r2_slot[r] : d.unc_slot[r];
+    const long det = STAGE == 1 ? d.hi_idx[xq] : STAGE == 2 ? d.lo_idx[xq] : d.left_det[xq];
+    feat::ema_row(d.body_curr + s * d.D, d.body_smooth + s * d.D, d.feats + det * d.D, d.D, d.has_body[s] != 0,
+                  d.ema_a, d.ema_b);
+    if (d.Df)
+        feat::ema_row(d.face_curr + s * d.Df, d.face_smooth + s * d.Df, d.face_feats + det * d.Df, d.Df,
+                      d.has_face[s] != 0, d.ema_a, d.ema_b);
+    if (threadIdx.x == 0) { d.has_body[s] = 1; if (d.Df) d.has_face[s] = 1; }
+}
+
+// ---- after stage 1: rows of stage 2, columns of stage 3 (1 workgroup) ------------------------------------
+__global__ __launch_bounds__(1024) void tk_after1(Dev d) {
+    __shared__ int32_t tmp[1024];
+    int32_t *h = d.hdr;
+    const int N = h[H_NPOOL], nhi = h[H_NHI], nunc = h[H_NUNC];
+    // r_tracked: unmatched pool rows that are still Tracked (D:1569).  Matched rows were set to
+    // Tracked by tk_apply_kf<1>, so the row test is on x1, the state test sees pre-frame state.
+    const int nr2 = block_compact(N, tmp, [&](int r) { return d.x1[r] < 0 && d.state[d.pool_slot[r]] == BTS_TRACKED; },
+                                  [&](int p, int r) {
+                                      d.r2_row[p] = r; d.r2_slot[p] = d.pool_slot[r];
+                                      for (int c = 0; c < 4; ++c) d.r2_tlbr[p * 4 + c] = d.pool_tlbr[r * 4 + c];
+                                  });
+    const int nleft = block_compact(nhi, tmp, [&](int q) { return d.y1[q] < 0; },
+                                    [&](int p, int q) { d.left_hi[p] = q; d.left_det[p] = d.hi_idx[q]; });
+    for (int k = threadIdx.x; k < nunc; k += blockDim.x) {     // unconfirmed boxes (may be float32 state)
+        const int s = d.unc_slot[k];
+        double b[4];
+        slot_tlbr(d, s, b);
+        for (int c = 0; c < 4; ++c) d.unc_tlbr[k * 4 + c] = b[c];
+        d.unc_f32[k] = d.f32[s];
+    }
+    if (threadIdx.x == 0) {
+        h[H_NR2] = nr2; h[H_NLEFT] = nleft;
+        h[H_DIMS2] = nr2; h[H_DIMS3 + 1] = nleft;
+    }
+}
+
+// ---- births + list merge (1 workgroup), D:1614-1636 ----------------------------------------------------------
+__global__ __launch_bounds__(1024) void tk_merge(Dev d) {
+    __shared__ int32_t tmp[1024];
+    int32_t *h = d.hdr;
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const int frame = h[H_FRAME], nleft = h[H_NLEFT], nfree = h[H_NFREE], last_id = h[H_LASTID];
+    const int nt = h[H_NTRACKED], nl = h[H_NLOST], N = h[H_NPOOL], nconf = h[H_NCONF], nunc = h[H_NUNC];
+    // births in ascending leftover-detection order (new ids ascending, quirk Q7)
+    for (int k = tid; k < nleft; k += nth) d.born_slot[k] = -1;
+    __syncthreads();
+    const int nborn_want = block_compact(
+        nleft, tmp, [&](int k) { return d.y3[k] < 0 && !((double)d.scores[d.left_det[k]] < d.new_thr); },
+        [&](int b, int k) {
+            if (b >= nfree) return;
+            const int s = d.free_list[b], det = d.left_det[k];
+            d.born_slot[k] = s;
+            d.track_id[s] = last_id + 1 + b;
+            d.state[s] = BTS_TRACKED;
+            d.is_activated[s] = frame == 1 ? 1 : 0;          // D:565-566
+            d.frame_id[s] = frame; d.start_frame[s] = frame; d.tracklet_len[s] = 0;
+            d.score[s] = d.scores[det]; d.det_index[s] = det;
+            d.f32[s] = 1; d.in_removed[s] = 0; d.flag[s] = 0;
+            d.has_body[s] = 1; d.has_face[s] = d.Df ? 1 : 0;
+        });
+    const int nborn = min(nborn_want, nfree);
+    // expiry of lost tracks (D:1623-1627); re-found ones carry frame_id == frame
+    int expired = 0;
+    for (int k = tid; k < nl; k += nth) {
+        const int s = d.lost[k];
+        if (frame - d.frame_id[s] > d.max_time_lost) { d.state[s] = BTS_REMOVED; d.flag[s] |= F_REMOVEDNOW; ++expired; }
+    }
+    int tot_expired;
+    block_exscan_i(expired, tmp, &tot_expired);
+    int removed_unc = 0;
+    for (int k = tid; k < nunc; k += nth) removed_unc += (d.flag[d.unc_slot[k]] & F_REMOVEDNOW) ? 1 : 0;
+    int tot_removed_unc;
+    block_exscan_i(removed_unc, tmp, &tot_removed_unc);
+    // tracked' = [old tracked still Tracked] ++ births ++ re-found (pool order)
+    const int n_keep = block_compact(nt, tmp, [&](int k) { return d.state[d.tracked[k]] == BTS_TRACKED; },
+                                     [&](int p, int k) { d.tracked2[p] = d.tracked[k]; });
+    const int n_b = block_compact(nleft, tmp, [&](int k) { return d.born_slot[k] >= 0; },
+                                  [&](int p, int k) { d.tracked2[n_keep + p] = d.born_slot[k]; });
+    const int n_rf = block_compact(N, tmp, [&](int r) { return (d.flag[d.pool_slot[r]] & F_REFIND) != 0; },
+                                   [&](int p, int r) { d.tracked2[n_keep + n_b + p] = d.pool_slot[r]; });
+    // lost' = ([old lost not re-found] ++ newly lost (pool order)) minus ids already in removed (Q6)
+    const int n_l0 = block_compact(nl, tmp,
+                                   [&](int k) { const int s = d.lost[k]; return d.state[s] != BTS_TRACKED && !d.in_removed[s]; },
+                                   [&](int p, int k) { d.lost2[p] = d.lost[k]; });
+    const int n_l1 = block_compact(nconf, tmp,
+                                   [&](int r) { const int s = d.pool_slot[r]; return (d.flag[s] & F_LOSTNOW) && !d.in_removed[s]; },
+                                   [&](int p, int r) { d.lost2[n_l0 + p] = d.pool_slot[r]; });
+    __syncthreads();
+    // removed_stracks.extend(removed_now): remember the ids (here: slots) for the next frames
+    for (int k = tid; k < nl; k += nth) { const int s = d.lost[k]; if (d.flag[s] & F_REMOVEDNOW) d.in_removed[s] = 1; }
+    for (int k = tid; k < nunc; k += nth) { const int s = d.unc_slot[k]; if (d.flag[s] & F_REMOVEDNOW) d.in_removed[s] = 1; }
+    if (tid == 0) {
+        h[H_NT2] = n_keep + n_b + n_rf;
+        h[H_NL2] = n_l0 + n_l1;
+        h[H_NBORN] = nborn;
+        h[H_LASTID] = last_id + nborn;
+        h[H_NREMOVED] += tot_expired + tot_removed_unc;
+        if (nborn_want > nfree) h[H_ERR] |= ERR_TRACK_CAPACITY;
+        h[H_DIMSD] = n_keep + n_b + n_rf; h[H_DIMSD + 1] = n_l0 + n_l1;
+    }
+}
+
+// Kalman initiate + feature rows of the newborn tracks (D:556-568, D:492-514): one workgroup per
+// leftover detection.
+__global__ __launch_bounds__(256) void tk_birth_init(Dev d) {
+    const int k = blockIdx.x;
+    if (k >= d.hdr[H_NLEFT]) return;
+    const long s = d.born_slot[k];
+    if (s < 0) return;
+    const long det = d.left_det[k];
+    if (threadIdx.x == 0) {
+        const float z[4] = {d.det_xywh[det * 4 + 0], d.det_xywh[det * 4 + 1], d.det_xywh[det * 4 + 2], d.det_xywh[det * 4 + 3]};
+        double m[8], P[64];
+        kf::initiate(z, m, P);
+        store_state(d, (int)s, m, P);
+    }
+    // the detection row was renormalised in place; curr and smooth alias it in the reference
+    for (int c = threadIdx.x; c < d.D; c += blockDim.x) {
+        const float v = d.feats[det * d.D + c];
+        d.body_curr[s * d.D + c] = v; d.body_smooth[s * d.D + c] = v;
+    }
+    for (int c = threadIdx.x; c < d.Df; c += blockDim.x) {
+        const float v = d.face_feats[det * d.Df + c];
+        d.face_curr[s * d.Df + c] = v; d.face_smooth[s * d.Df + c] = v;
+    }
+}
+
+// ---- duplicate removal between tracked' and lost' (D:1665-1680) -----------------------------------------------
+__global__ __launch_bounds__(256) void tk_list_boxes(Dev d) {
+    const int32_t *h = d.hdr;
+    const int nt = h[H_NT2], nl = h[H_NL2];
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < nt) {
+        const int s = d.tracked2[k];
+        double b[4];
+        slot_tlbr(d, s, b);
+        for (int c = 0; c < 4; ++c) d.tl_tlbr[k * 4 + c] = b[c];
+        d.tl_f32[k] = d.f32[s]; d.tl_age[k] = d.frame_id[s] - d.start_frame[s]; d.drop_t[k] = 0;
+    }
+    if (k < nl) {
+        const int s = d.lost2[k];
+        double b[4];
+        slot_tlbr(d, s, b);
+        for (int c = 0; c < 4; ++c) d.ll_tlbr[k * 4 + c] = b[c];
+        d.ll_f32[k] = d.f32[s]; d.ll_age[k] = d.frame_id[s] - d.start_frame[s]; d.drop_l[k] = 0;
+    }
+}
+
+__global__ __launch_bounds__(CT_COLS) void tk_dedupe(Dev d) {
+    __shared__ double sa[CT_ROWS][4];
+    __shared__ double sarea[CT_ROWS];
+    __shared__ int sflag[CT_ROWS];
+    __shared__ int sage[CT_ROWS];
+    const int n = d.hdr[H_NT2], m = d.hdr[H_NL2];
+    const int i0 = blockIdx.y * CT_ROWS, j = blockIdx.x * CT_COLS + threadIdx.x;
+    if (i0 >= n || blockIdx.x * CT_COLS >= m) return;
+    if (threadIdx.x < CT_ROWS && i0 + threadIdx.x < n) {
+        const int i = i0 + threadIdx.x;
+        double box[4] = {d.tl_tlbr[i * 4 + 0], d.tl_tlbr[i * 4 + 1], d.tl_tlbr[i * 4 + 2], d.tl_tlbr[i * 4 + 3]};
+        const bool f = d.tl_f32[i] != 0;
+        for (int c = 0; c < 4; ++c) sa[threadIdx.x][c] = box[c];
+        sarea[threadIdx.x] = iou::area(box, f);
+        sflag[threadIdx.x] = f;
+        sage[threadIdx.x] = d.tl_age[i];
+    }
+    __syncthreads();
+    if (j >= m) return;
+    const double bb[4] = {d.ll_tlbr[j * 4 + 0], d.ll_tlbr[j * 4 + 1], d.ll_tlbr[j * 4 + 2], d.ll_tlbr[j * 4 + 3]};
+    const bool bf = d.ll_f32[j] != 0;
+    const double area_b = iou::area(bb, bf);
+    const int agej = d.ll_age[j];
+    const int rows = min(CT_ROWS, n - i0);
+    bool dropj = false;
+    for (int r = 0; r < rows; ++r) {
+        const double aa[4] = {sa[r][0], sa[r][1], sa[r][2], sa[r][3]};
+        if (iou::cost(aa, sflag[r] != 0, sarea[r], bb, bf, area_b) < d.dedupe_thr) {
+            if (sage[r] > agej) dropj = true;
+            else d.drop_t[i0 + r] = 1;
+        }
+    }
+    if (dropj) d.drop_l[j] = 1;
+}
+
+// ---- frame epilogue (1 workgroup): final lists, slot recycling ------------------------------------------------
+__global__ __launch_bounds__(1024) void tk_finalize(Dev d) {
+    __shared__ int32_t tmp[1024];
+    int32_t *h = d.hdr;
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const int nt2 = h[H_NT2], nl2 = h[H_NL2];
+    const int nt = block_compact(nt2, tmp, [&](int k) { return !d.drop_t[k]; }, [&](int p, int k) { d.tracked[p] = d.tracked2[k]; });
+    const int nl = block_compact(nl2, tmp, [&](int k) { return !d.drop_l[k]; }, [&](int p, int k) { d.lost[p] = d.lost2[k]; });
+    for (int s = tid; s < d.T; s += nth) d.in_use[s] = 0;
+    __syncthreads();
+    for (int k = tid; k < nt; k += nth) d.in_use[d.tracked[k]] = 1;
+    for (int k = tid; k < nl; k += nth) d.in_use[d.lost[k]] = 1;
+    __syncthreads();
+    const int nfree = block_compact(d.T, tmp, [&](int s) { return !d.in_use[s]; }, [&](int p, int s) { d.free_list[p] = s; });
+    if (tid == 0) { h[H_NTRACKED] = nt; h[H_NLOST] = nl; h[H_NFREE] = nfree; }
+}
+
+__global__ __launch_bounds__(1024) void tk_reset(Dev d) {
+    const int tid = threadIdx.x, nth = blockDim.x;
+    for (int s = tid; s < d.T; s += nth) {
+        d.free_list[s] = s; d.in_use[s] = 0; d.in_removed[s] = 0; d.flag[s] = 0; d.f32[s] = 0; d.state[s] = BTS_NEW;
+        d.is_activated[s] = 0; d.track_id[s] = 0; d.has_body[s] = 0; d.has_face[s] = 0;
+    }
+    for (int k = tid; k < H_SIZE; k += nth) d.hdr[k] = 0;
+    __syncthreads();
+    if (tid == 0) d.hdr[H_NFREE] = d.T;
+    for (int j = tid; j < d.Mx; j += nth) d.ones[j] = 1;
+}
+
+// ---- export -----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tk_export(Dev d, int which, int32_t *ints, double *mean, double *tlbr, float *score) {
+    const int n = which == 0 ? d.hdr[H_NTRACKED] : d.hdr[H_NLOST];
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int s = which == 0 ? d.tracked[k] : d.lost[k];
+    ints[k * 8 + 0] = d.track_id[s]; ints[k * 8 + 1] = d.state[s]; ints[k * 8 + 2] = d.is_activated[s];
+    ints[k * 8 + 3] = d.frame_id[s]; ints[k * 8 + 4] = d.start_frame[s]; ints[k * 8 + 5] = d.tracklet_len[s];
+    ints[k * 8 + 6] = d.det_index[s]; ints[k * 8 + 7] = s;
+    for (int c = 0; c < 8; ++c) mean[k * 8 + c] = d.mean[(long)c * d.T + s];
+    double b[4];
+    slot_tlbr(d, s, b);
+    for (int c = 0; c < 4; ++c) tlbr[k * 4 + c] = b[c];
+    score[k] = d.score[s];
+}
+
+}  // namespace
+
+// =========================================================================================== host side
+struct bts_tracker {
+    bts_context *ctx = nullptr;
+    bts_tracker_config cfg;
+    Dev dv;
+    bts_lap_work lap;
+    char *block = nullptr;
+    size_t bytes = 0;
+    // export staging
+    int32_t *x_ints = nullptr; double *x_mean = nullptr, *x_tlbr = nullptr; float *x_score = nullptr;
+    int32_t *host_hdr = nullptr;   // pinned
+};
+
+static size_t take(size_t &off, size_t bytes) { const size_t o = off; off = bts_align(off + bytes); return o; }
+
+static void tracker_layout(bts_tracker *t, char *base, size_t &off) {
+    Dev &d = t->dv;
+    const size_t T = d.T, M = d.Mx, D = d.D, Df = d.Df ? d.Df : 1;
+#define SLOT(ptr, type, count) { size_t o = take(off, sizeof(type) * (size_t)(count)); ptr = base ? (type *)(base + o) : nullptr; }
+    SLOT(d.mean, double, 8 * T); SLOT(d.cov, double, 64 * T);
+    SLOT(d.f32, uint8_t, T); SLOT(d.in_removed, uint8_t, T); SLOT(d.in_use, uint8_t, T); SLOT(d.flag, uint8_t, T);
+    SLOT(d.has_body, uint8_t, T); SLOT(d.has_face, uint8_t, T);
+    SLOT(d.state, int32_t, T); SLOT(d.is_activated, int32_t, T); SLOT(d.track_id, int32_t, T);
+    SLOT(d.frame_id, int32_t, T); SLOT(d.start_frame, int32_t, T); SLOT(d.tracklet_len, int32_t, T);
+    SLOT(d.det_index, int32_t, T); SLOT(d.score, float, T);
+    SLOT(d.body_curr, float, T * D); SLOT(d.body_smooth, float, T * D);
+    SLOT(d.face_curr, float, T * Df); SLOT(d.face_smooth, float, T * Df);
+    SLOT(d.tracked, int32_t, T); SLOT(d.lost, int32_t, T); SLOT(d.tracked2, int32_t, T); SLOT(d.lost2, int32_t, T);
+    SLOT(d.free_list, int32_t, T); SLOT(d.hdr, int32_t, H_SIZE);
+    SLOT(d.pool_slot, int32_t, T); SLOT(d.unc_slot, int32_t, T); SLOT(d.hi_idx, int32_t, M); SLOT(d.lo_idx, int32_t, M);
+    SLOT(d.r2_row, int32_t, T); SLOT(d.r2_slot, int32_t, T); SLOT(d.left_hi, int32_t, M); SLOT(d.left_det, int32_t, M);
+    SLOT(d.born_slot, int32_t, M);
+    SLOT(d.pool_tlbr, double, 4 * T); SLOT(d.unc_tlbr, double, 4 * T); SLOT(d.det_tlbr, double, 4 * M);
+    SLOT(d.r2_tlbr, double, 4 * T); SLOT(d.unc_f32, uint8_t, T); SLOT(d.ones, uint8_t, M); SLOT(d.det_xywh, float, 4 * M);
+    SLOT(d.sim, float, T * M); SLOT(d.fsim, float, d.Df ? T * M : 1);
+    SLOT(d.cost1, double, T * M);
+    if (t->cfg.record_costs) { SLOT(d.cost2, double, T * M); SLOT(d.cost3, double, T * M); }
+    else { d.cost2 = d.cost1; d.cost3 = d.cost1; }
+    SLOT(d.x1, int32_t, T); SLOT(d.y1, int32_t, M); SLOT(d.x2, int32_t, T); SLOT(d.y2, int32_t, M);
+    SLOT(d.x3, int32_t, T); SLOT(d.y3, int32_t, M);
+    SLOT(d.tl_tlbr, double, 4 * T); SLOT(d.ll_tlbr, double, 4 * T); SLOT(d.tl_f32, uint8_t, T); SLOT(d.ll_f32, uint8_t, T);
+    SLOT(d.drop_t, uint8_t, T); SLOT(d.drop_l, uint8_t, T); SLOT(d.tl_age, int32_t, T); SLOT(d.ll_age, int32_t, T);
+    SLOT(t->x_ints, int32_t, 8 * T); SLOT(t->x_mean, double, 8 * T); SLOT(t->x_tlbr, double, 4 * T); SLOT(t->x_score, float, T);
+#undef SLOT
+}
+
+extern "C" {
+
+int bts_tracker_default_config(bts_tracker_config *cfg) {
+    BTS_REQUIRE(cfg, "cfg");
+    memset(cfg, 0, sizeof(*cfg));
+    cfg->max_tracks = 1024; cfg->max_dets = 512; cfg->feat_dim = 2048; cfg->face_dim = 0;
+    cfg->frame_rate = 30; cfg->track_buffer = 300;
+    cfg->track_high_thresh = 0.40; cfg->track_low_thresh = 0.1; cfg->new_track_thresh = 0.9;
+    cfg->match_thresh = 0.8; cfg->second_match_thresh = 0.5; cfg->unconfirmed_match_thresh = 0.7;
+    cfg->proximity_thresh = 0.5; cfg->appearance_thresh = 0.25; cfg->dedupe_thresh = 0.15;
+    cfg->ema_alpha = 0.9; cfg->record_costs = 0;
+    return BTS_OK;
+}
+
+int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_tracker **out) {
+    BTS_REQUIRE(ctx && cfg && out, "null argument");
+    *out = nullptr;
+    BTS_REQUIRE(cfg->max_tracks > 0 && cfg->max_dets > 0 && cfg->feat_dim > 0 && cfg->face_dim >= 0, "capacities");
+    BTS_REQUIRE((int64_t)cfg->max_tracks * cfg->max_dets < (1ll << 31), "max_tracks * max_dets must fit int32");
+    bts_tracker *t = new (std::nothrow) bts_tracker();
+    if (!t) { bts_set_error("host allocation failed"); return BTS_ENOMEM; }
+    t->ctx = ctx; t->cfg = *cfg;
+    Dev &d = t->dv;
+    memset(&d, 0, sizeof(d));
+    d.T = cfg->max_tracks; d.Mx = cfg->max_dets; d.D = cfg->feat_dim; d.Df = cfg->face_dim;
+    d.high = cfg->track_high_thresh; d.low = cfg->track_low_thresh; d.new_thr = cfg->new_track_thresh;
+    d.match1 = cfg->match_thresh; d.match2 = cfg->second_match_thresh; d.match3 = cfg->unconfirmed_match_thresh;
+    d.prox = cfg->proximity_thresh; d.app = (float)cfg->appearance_thresh; d.dedupe_thr = cfg->dedupe_thresh;
+    d.ema_a = (float)cfg->ema_alpha; d.ema_b = (float)(1.0 - cfg->ema_alpha);
+    d.max_time_lost = (int)((double)cfg->frame_rate / 30.0 * cfg->track_buffer);    // D:1276-1277
+    size_t off = 0;
+    tracker_layout(t, nullptr, off);
+    const int64_t e_cap = (int64_t)d.T * d.Mx;
+    const size_t lap_off = off;
+    off += bts_lap_work_bytes(d.T, d.Mx, e_cap);
+    t->bytes = off;
+    if (hipMalloc((void **)&t->block, t->bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        bts_set_error("device allocation of %zu bytes for the track table failed", t->bytes);
+        delete t;
+        return BTS_ENOMEM;
+    }
+    off = 0;
+    tracker_layout(t, t->block, off);
+    bts_lap_work_carve(&t->lap, t->block + lap_off, d.T, d.Mx, e_cap);
+    if (hipHostMalloc((void **)&t->host_hdr, H_SIZE * sizeof(int32_t)) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(t->block);
+        bts_set_error("pinned host allocation failed");
+        delete t;
+        return BTS_ENOMEM;
+    }
+    int rc = bts_tracker_reset(t, nullptr);
+    if (rc == BTS_OK && hipStreamSynchronize(nullptr) != hipSuccess) rc = BTS_EHIP;
+    if (rc != BTS_OK) { bts_tracker_destroy(t); return rc; }
+    *out = t;
+    return BTS_OK;
+}
+
+int bts_tracker_destroy(bts_tracker *t) {
+    if (!t) return BTS_OK;
+    if (t->block) (void)hipFree(t->block);
+    if (t->host_hdr) (void)hipHostFree(t->host_hdr);
+    delete t;
+    return BTS_OK;
+}
+
+int bts_tracker_reset(bts_tracker *t, bts_stream stream) {
+    BTS_REQUIRE(t, "tracker");
+    hipLaunchKernelGGL(tk_reset, dim3(1), dim3(1024), 0, (hipStream_t)stream, t->dv);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+
+int bts_tracker_step(bts_tracker *t, const int32_t *boxes, const float *scores, float *feats,
+                     float *face_feats, int m, bts_stream stream) {
+    BTS_REQUIRE(t && m >= 0, "tracker, m");
+    if (m > t->cfg.max_dets) {
+        bts_set_error("%d detections exceed max_dets=%d", m, t->cfg.max_dets);
+        return BTS_ECAPACITY;
+    }
+    BTS_REQUIRE(m == 0 || (boxes && scores && feats), "null detection arrays");
+    BTS_REQUIRE(t->cfg.face_dim == 0 || m == 0 || face_feats, "face_feats required when face_dim > 0");
+    hipStream_t s = (hipStream_t)stream;
+    Dev d = t->dv;
+    d.boxes = boxes; d.scores = scores; d.feats = feats; d.face_feats = face_feats; d.m = m;
+    const int T = d.T, M = d.Mx;
+    const int cos_kernel = t->ctx->cos_kernel;
+    const dim3 cost_grid(bts_cdiv(M, CT_COLS), bts_cdiv(T, CT_ROWS));
+    int rc;
+#define LAUNCH(kern, grid, block) hipLaunchKernelGGL(kern, grid, block, 0, s, d); BTS_LAUNCH_CHECK()
+
+    LAUNCH(tk_prep, dim3(1), dim3(1024));
+    LAUNCH(tk_predict, dim3(bts_cdiv(T, 256)), dim3(256));
+    // ---- first association: pool x high-score detections
+    rc = bts_cos_enqueue(cos_kernel, d.body_curr, d.pool_slot, d.D, feats, d.hi_idx, d.D, d.D, d.hdr + H_DIMS1, T, M,
+                         d.sim, M, s);
+    if (rc) return rc;
+    if (d.Df) {
+        rc = bts_cos_enqueue(cos_kernel, d.face_curr, d.pool_slot, d.Df, face_feats, d.hi_idx, d.Df, d.Df,
+                             d.hdr + H_DIMS1, T, M, d.fsim, M, s);
+        if (rc) return rc;
+    }
+    LAUNCH(tk_cost<1>, cost_grid, dim3(CT_COLS));
+    rc = bts_lap_enqueue_dense(&t->lap, d.cost1, M, d.hdr + H_DIMS1, T, M, d.match1, d.x1, d.y1, s);
+    if (rc) return rc;
+    LAUNCH(tk_renorm, dim3(M), dim3(256));
+    LAUNCH(tk_after1, dim3(1), dim3(1024));          // reads pre-update states: before tk_apply_kf<1>
+    LAUNCH(tk_apply_kf<1>, dim3(bts_cdiv(T, 256)), dim3(256));
+    LAUNCH(tk_apply_feat<1>, dim3(T), dim3(256));
+    // ---- second association: remaining tracked rows x low-score detections
+    LAUNCH(tk_cost<2>, cost_grid, dim3(CT_COLS));
+    rc = bts_lap_enqueue_dense(&t->lap, d.cost2, M, d.hdr + H_DIMS2, T, M, d.match2, d.x2, d.y2, s);
+    if (rc) return rc;
+    LAUNCH(tk_apply_kf<2>, dim3(bts_cdiv(T, 256)), dim3(256));
+    LAUNCH(tk_apply_feat<2>, dim3(T), dim3(256));
+    // ---- unconfirmed tracks x leftover high-score detections
+    rc = bts_cos_enqueue(cos_kernel, d.body_curr, d.unc_slot, d.D, feats, d.left_det, d.D, d.D, d.hdr + H_DIMS3, T, M,
+                         d.sim, M, s);
+    if (rc) return rc;
+    LAUNCH(tk_cost<3>, cost_grid, dim3(CT_COLS));
+    rc = bts_lap_enqueue_dense(&t->lap, d.cost3, M, d.hdr + H_DIMS3, T, M, d.match3, d.x3, d.y3, s);
+    if (rc) return rc;
+    LAUNCH(tk_apply_kf<3>, dim3(bts_cdiv(T, 256)), dim3(256));
+    LAUNCH(tk_apply_feat<3>, dim3(T), dim3(256));
+    // ---- births, list merge, duplicate removal
+    LAUNCH(tk_merge, dim3(1), dim3(1024));
+    LAUNCH(tk_birth_init, dim3(M), dim3(256));
+    LAUNCH(tk_list_boxes, dim3(bts_cdiv(T, 256)), dim3(256));
+    LAUNCH(tk_dedupe, dim3(bts_cdiv(T, CT_COLS), bts_cdiv(T, CT_ROWS)), dim3(CT_COLS));
+    LAUNCH(tk_finalize, dim3(1), dim3(1024));
+#undef LAUNCH
+    return BTS_OK;
+}
+
+int bts_tracker_counts(bts_tracker *t, int32_t *counts12_host, bts_stream stream) {
+    BTS_REQUIRE(t && counts12_host, "null argument");
+    BTS_HIP(hipMemcpyAsync(t->host_hdr, t->dv.hdr, H_SIZE * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    BTS_HIP(hipStreamSynchronize((hipStream_t)stream));
+    const int32_t *h = t->host_hdr;
+    const int map[12] = {H_FRAME, H_NTRACKED, H_NLOST, H_NREMOVED, H_LASTID, H_NPOOL, H_NHI, H_NLO, H_NUNC, H_NR2, H_NLEFT, H_ERR};
+    for (int k = 0; k < 12; ++k) counts12_host[k] = h[map[k]];
+    return BTS_OK;
+}
+
+int bts_tracker_export(bts_tracker *t, int which, int32_t *ints_host, double *mean_host,
+                       double *tlbr_host, float *score_host, bts_stream stream) {
+    BTS_REQUIRE(t && (which == 0 || which == 1), "tracker, which");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(tk_export, dim3(bts_cdiv(t->dv.T, 256)), dim3(256), 0, s, t->dv, which, t->x_ints, t->x_mean,
+                       t->x_tlbr, t->x_score);
+    BTS_LAUNCH_CHECK();
+    BTS_HIP(hipMemcpyAsync(t->host_hdr, t->dv.hdr, H_SIZE * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    BTS_HIP(hipStreamSynchronize(s));
+    const int n = which == 0 ? t->host_hdr[H_NTRACKED] : t->host_hdr[H_NLOST];
+    if (n > 0) {
+        if (ints_host) BTS_HIP(hipMemcpyAsync(ints_host, t->x_ints, sizeof(int32_t) * 8 * n, hipMemcpyDeviceToHost, s));
+        if (mean_host) BTS_HIP(hipMemcpyAsync(mean_host, t->x_mean, sizeof(double) * 8 * n, hipMemcpyDeviceToHost, s));
+        if (tlbr_host) BTS_HIP(hipMemcpyAsync(tlbr_host, t->x_tlbr, sizeof(double) * 4 * n, hipMemcpyDeviceToHost, s));
+        if (score_host) BTS_HIP(hipMemcpyAsync(score_host, t->x_score, sizeof(float) * n, hipMemcpyDeviceToHost, s));
+        BTS_HIP(hipStreamSynchronize(s));
+    }
+    return n;
+}
+
+int bts_tracker_stage_result(bts_tracker *t, int stage, int32_t *x_host, int32_t *y_host,
+                             double *cost_host, int32_t *n_rows, int32_t *n_cols, bts_stream stream) {
+    BTS_REQUIRE(t && stage >= 1 && stage <= 3, "tracker, stage");
+    hipStream_t s = (hipStream_t)stream;
+    BTS_HIP(hipMemcpyAsync(t->host_hdr, t->dv.hdr, H_SIZE * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    BTS_HIP(hipStreamSynchronize(s));
+    const int32_t *h = t->host_hdr;
+    const int rows = stage == 1 ? h[H_NPOOL] : stage == 2 ? h[H_NR2] : h[H_NUNC];
+    const int cols = stage == 1 ? h[H_NHI] : stage == 2 ? h[H_NLO] : h[H_NLEFT];
+    if (n_rows) *n_rows = rows;
+    if (n_cols) *n_cols = cols;
+    const Dev &d = t->dv;
+    const int32_t *xs = stage == 1 ? d.x1 : stage == 2 ? d.x2 : d.x3;
+    const int32_t *ys = stage == 1 ? d.y1 : stage == 2 ? d.y2 : d.y3;
+    if (x_host && rows > 0) BTS_HIP(hipMemcpyAsync(x_host, xs, sizeof(int32_t) * rows, hipMemcpyDeviceToHost, s));
+    if (y_host && cols > 0) BTS_HIP(hipMemcpyAsync(y_host, ys, sizeof(int32_t) * cols, hipMemcpyDeviceToHost, s));
+    if (cost_host && rows > 0 && cols > 0) {
+        BTS_REQUIRE(t->cfg.record_costs, "cost matrices are kept only when record_costs was set");
+        const double *c = stage == 1 ? d.cost1 : stage == 2 ? d.cost2 : d.cost3;
+        BTS_HIP(hipMemcpy2DAsync(cost_host, sizeof(double) * cols, c, sizeof(double) * d.Mx, sizeof(double) * cols, rows,
+                                 hipMemcpyDeviceToHost, s));
+    }
+    BTS_HIP(hipStreamSynchronize(s));
+    return BTS_OK;
+}
+
+}  // extern "C"

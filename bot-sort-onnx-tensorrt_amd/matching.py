@@ -1,0 +1,156 @@
+"""Association functions with the reference's names and return conventions
+(demo_bottrack_onnx_tflite.py:1682-1761), computed by HIP kernels through the C ABI
+(csrc/assoc.hip, csrc/cosine.hip, csrc/lap.hip).  Inputs may be lists of STrack-like objects
+(anything with `.tlbr`) or lists / arrays of tlbr boxes, as in the reference (D:1753-1758).
+"""
+from __future__ import annotations
+
+from typing import Sequence
+
+import numpy as np
+
+from . import _lib
+
+
+def _dev(a, dtype):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).cuda()
+
+
+def _boxes(items) -> "tuple[np.ndarray, np.ndarray]":
+    """-> float64 [K,4] boxes and uint8 [K] 'was float32' flags (the kernels reproduce NumPy's
+    scalar dtype flow from them, include/botsort_hip.h conventions)."""
+    k = len(items)
+    out = np.empty((k, 4), dtype=np.float64)
+    f32 = np.zeros(k, dtype=np.uint8)
+    for i, it in enumerate(items):
+        b = np.asarray(it.tlbr if hasattr(it, "tlbr") else it)
+        out[i] = b
+        f32[i] = 1 if b.dtype == np.float32 else 0
+    return out, f32
+
+
+def bbox_ious(atlbrs, btlbrs) -> np.ndarray:
+    """D:1731-1743 -- IoU matrix (not the cost)."""
+    return 1 - _iou_cost(atlbrs, btlbrs)
+
+
+def _iou_cost(a_items, b_items) -> np.ndarray:
+    import torch
+    n, m = len(a_items), len(b_items)
+    if n == 0 or m == 0:
+        return 1 - np.zeros((n, m), dtype=np.float32)            # D:1739-1741
+    lib = _lib.load(require_gpu=True)
+    a, af = _boxes(a_items)
+    b, bf = _boxes(b_items)
+    da, daf, db, dbf = _dev(a, np.float64), _dev(af, np.uint8), _dev(b, np.float64), _dev(bf, np.uint8)
+    cost = torch.empty((n, m), dtype=torch.float64, device="cuda")
+    _lib.check(lib.bts_iou_distance(_lib.default_context().handle, _lib.ptr(da), _lib.ptr(daf), n, _lib.ptr(db),
+                                    _lib.ptr(dbf), m, _lib.ptr(cost), m, _lib.current_stream()))
+    return cost.cpu().numpy()
+
+
+def iou_distance(atracks, btracks) -> np.ndarray:
+    """D:1745-1761: cost = 1 - IoU."""
+    return _iou_cost(atracks, btracks)
+
+
+def bbox_iou(box1, box2) -> float:
+    """D:1695-1713 (one pair; goes through the same kernel)."""
+    return float(1 - _iou_cost([np.asarray(box1)], [np.asarray(box2)])[0, 0])
+
+
+def cosine_similarity(track_feats, det_feats) -> np.ndarray:
+    """max(0, T @ D.T) in float32 -- the D:1599 definition."""
+    import torch
+    t = np.ascontiguousarray(track_feats, dtype=np.float32)
+    d = np.ascontiguousarray(det_feats, dtype=np.float32)
+    n, m = len(t), len(d)
+    if n == 0 or m == 0:
+        return np.zeros((n, m), dtype=np.float32)
+    lib = _lib.load(require_gpu=True)
+    dt, dd = _dev(t, np.float32), _dev(d, np.float32)
+    sim = torch.empty((n, m), dtype=torch.float32, device="cuda")
+    _lib.check(lib.bts_cos_similarity(_lib.default_context().handle, _lib.ptr(dt), n, _lib.ptr(dd), m, t.shape[1],
+                                      _lib.ptr(sim), m, _lib.current_stream()))
+    return sim.cpu().numpy()
+
+
+def fuse_cost_stage1(iou_d, body_sim, face_sim=None, proximity_thresh=0.5, appearance_thresh=0.25) -> np.ndarray:
+    """D:1539-1554."""
+    import torch
+    n, m = iou_d.shape
+    if n == 0 or m == 0:
+        return np.zeros((n, m))
+    lib = _lib.load(require_gpu=True)
+    di, db = _dev(iou_d, np.float64), _dev(body_sim, np.float32)
+    df = None if face_sim is None else _dev(face_sim, np.float32)
+    out = torch.empty((n, m), dtype=torch.float64, device="cuda")
+    _lib.check(lib.bts_fuse_cost_stage1(_lib.default_context().handle, _lib.ptr(di), m, _lib.ptr(db), _lib.ptr(df), m,
+                                        n, m, proximity_thresh, appearance_thresh, _lib.ptr(out), m,
+                                        _lib.current_stream()))
+    return out.cpu().numpy()
+
+
+def fuse_cost_stage3(iou_d, body_sim, proximity_thresh=0.5, appearance_thresh=0.25) -> np.ndarray:
+    """D:1590-1602."""
+    import torch
+    n, m = iou_d.shape
+    if n == 0 or m == 0:
+        return np.zeros((n, m))
+    lib = _lib.load(require_gpu=True)
+    di, db = _dev(iou_d, np.float64), _dev(body_sim, np.float32)
+    out = torch.empty((n, m), dtype=torch.float64, device="cuda")
+    _lib.check(lib.bts_fuse_cost_stage3(_lib.default_context().handle, _lib.ptr(di), m, _lib.ptr(db), m, n, m,
+                                        proximity_thresh, appearance_thresh, _lib.ptr(out), m,
+                                        _lib.current_stream()))
+    return out.cpu().numpy()
+
+
+def lapjv(cost, extend_cost=True, cost_limit=np.inf):
+    """`lap.lapjv(cost, extend_cost=True, cost_limit=L)` as the reference calls it (D:1686):
+    returns (opt, x, y)."""
+    import torch
+    if not extend_cost or not np.isfinite(cost_limit):
+        raise NotImplementedError("only lapjv(extend_cost=True, cost_limit=<finite>) is provided")
+    c = np.ascontiguousarray(cost, dtype=np.float64)
+    n, m = c.shape
+    lib = _lib.load(require_gpu=True)
+    dc = _dev(c, np.float64)
+    x = torch.empty((max(n, 1),), dtype=torch.int32, device="cuda")
+    y = torch.empty((max(m, 1),), dtype=torch.int32, device="cuda")
+    _lib.check(lib.bts_lapjv(_lib.default_context().handle, _lib.ptr(dc), n, m, m, float(cost_limit), _lib.ptr(x),
+                             _lib.ptr(y), _lib.current_stream()))
+    xs, ys = x[:n].cpu().numpy(), y[:m].cpu().numpy()
+    rows = np.nonzero(xs >= 0)[0]
+    opt = float(c[rows, xs[rows]].sum())
+    return opt, xs, ys
+
+
+def linear_assignment(cost_matrix: np.ndarray, thresh: float):
+    """D:1682-1693, including its return-type quirks (Q14)."""
+    if cost_matrix.size == 0:
+        return (np.empty((0, 2), dtype=int), tuple(range(cost_matrix.shape[0])),
+                tuple(range(cost_matrix.shape[1])))
+    _, x, y = lapjv(cost_matrix, extend_cost=True, cost_limit=thresh)
+    matches = np.asarray([[ix, mx] for ix, mx in enumerate(x) if mx >= 0])
+    return matches, np.where(x < 0)[0], np.where(y < 0)[0]
+
+
+def dedupe_flags(a_items, b_items, age_a: Sequence[int], age_b: Sequence[int], thresh: float = 0.15):
+    """The pair test of remove_duplicate_stracks (D:1665-1680) -> (drop_a[n], drop_b[m]) bool."""
+    import torch
+    n, m = len(a_items), len(b_items)
+    if n == 0 or m == 0:
+        return np.zeros(n, dtype=bool), np.zeros(m, dtype=bool)
+    lib = _lib.load(require_gpu=True)
+    a, af = _boxes(a_items)
+    b, bf = _boxes(b_items)
+    da, daf, db, dbf = _dev(a, np.float64), _dev(af, np.uint8), _dev(b, np.float64), _dev(bf, np.uint8)
+    ga, gb = _dev(age_a, np.int32), _dev(age_b, np.int32)
+    fa = torch.empty((n,), dtype=torch.uint8, device="cuda")
+    fb = torch.empty((m,), dtype=torch.uint8, device="cuda")
+    _lib.check(lib.bts_dedupe_pairs(_lib.default_context().handle, _lib.ptr(da), _lib.ptr(daf), _lib.ptr(ga), n,
+                                    _lib.ptr(db), _lib.ptr(dbf), _lib.ptr(gb), m, float(thresh), _lib.ptr(fa),
+                                    _lib.ptr(fb), _lib.current_stream()))
+    return fa.cpu().numpy().astype(bool), fb.cpu().numpy().astype(bool)

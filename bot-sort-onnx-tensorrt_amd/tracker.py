@@ -1,0 +1,396 @@
+"""`STrack` / `BoTSORT` with the reference's call surface (demo_bottrack_onnx_tflite.py:382-688,
+1252-1639) over the resident HIP tracker (csrc/tracker.hip, C ABI `bts_tracker_*`).
+
+The per-frame association cascade, Kalman filtering, feature bookkeeping and list merging all
+run on the MI355X with no host round trip; this module only
+  * hands the frame's detections to the device (`BoTSORT.update_arrays`, or `update(image)` which
+    first calls the -- unchanged, out-of-scope -- detector / ReID encoders like the reference),
+  * and, for drop-in compatibility, mirrors the resulting track lists into light `STrack` objects
+    exposing what the reference's caller reads (D:2135-2185): `tlbr`, `track_id`, `body`, ...
+`update_arrays(..., export=False)` skips that mirror for throughput-critical loops.
+"""
+from __future__ import annotations
+
+import ctypes
+from collections import deque
+from typing import List, Optional
+
+import numpy as np
+
+from . import _lib
+from .kalman_filter import KalmanFilter
+
+
+class TrackState:                      # D:382-387
+    New = 0
+    Tracked = 1
+    Lost = 2
+    LongLost = 3
+    Removed = 4
+
+
+class BaseTrack:                       # D:389-437 (the ID counter lives in the device tracker)
+    _count = 0
+    track_id = 0
+    is_activated = False
+    state = TrackState.New
+    score = 0
+    start_frame = 0
+    frame_id = 0
+
+    @property
+    def end_frame(self):
+        return self.frame_id
+
+    @staticmethod
+    def next_id():
+        BaseTrack._count += 1
+        return BaseTrack._count
+
+    @staticmethod
+    def clear_count():
+        BaseTrack._count = 0
+
+    def mark_lost(self):
+        self.state = TrackState.Lost
+
+    def mark_long_lost(self):
+        self.state = TrackState.LongLost
+
+    def mark_removed(self):
+        self.state = TrackState.Removed
+
+
+class STrack(BaseTrack):
+    """Host mirror of one track (or one detection record).  Kalman state and ReID features live
+    in the device track table; `mean` is refreshed from it after every frame."""
+    shared_kalman = None
+
+    def __init__(self, tlwh, score, feature_history=300, body=None, body_feature=None, face_feature=None):
+        self._tlwh = np.asarray(tlwh, dtype=np.float32)            # D:465
+        self.kalman_filter = None
+        self.mean, self.covariance = None, None
+        self.is_activated = False
+        self.score = score
+        self.tracklet_len = 0
+        self.alpha = 0.9                                           # D:473
+        self.body = body
+        self.body_curr_feature = body_feature
+        self.body_smooth_feature = None
+        self.face_curr_feature = face_feature
+        self.face_smooth_feature = None
+        self.body_features = deque([], maxlen=feature_history)
+        self.face_features = deque([], maxlen=feature_history)
+        self.det_index = -1
+        self.slot = -1
+        self._dev_tlbr = None       # STrack.tlbr as evaluated on the device (float32 flow for fresh tracks)
+
+    # ---- box formats, D:624-685
+    @property
+    def tlwh(self):
+        if self.mean is None:
+            return self._tlwh.copy()
+        ret = self.mean[:4].copy()
+        ret[:2] -= ret[2:] / 2
+        return ret
+
+    @property
+    def tlbr(self):
+        if self._dev_tlbr is not None:
+            return self._dev_tlbr.copy()
+        ret = self.tlwh.copy()
+        ret[2:] += ret[:2]
+        return ret
+
+    @property
+    def xywh(self):
+        ret = self.tlwh.copy()
+        ret[:2] += ret[2:] / 2.0
+        return ret
+
+    @staticmethod
+    def tlwh_to_xyah(tlwh):
+        ret = np.asarray(tlwh).copy()
+        ret[:2] += ret[2:] / 2
+        ret[2] /= ret[3]
+        return ret
+
+    @staticmethod
+    def tlwh_to_xywh(tlwh):
+        ret = np.asarray(tlwh).copy()
+        ret[:2] += ret[2:] / 2
+        return ret
+
+    def to_xywh(self):
+        return self.tlwh_to_xywh(self.tlwh)
+
+    @staticmethod
+    def tlbr_to_tlwh(tlbr):
+        ret = np.asarray(tlbr).copy()
+        ret[2:] -= ret[:2]
+        return ret
+
+    @staticmethod
+    def tlwh_to_tlbr(tlwh):
+        ret = np.asarray(tlwh).copy()
+        ret[2:] += ret[:2]
+        return ret
+
+    @staticmethod
+    def multi_predict(stracks: "List[STrack]"):
+        """D:524-536 on host mirrors (API parity; the tracker predicts on the device table)."""
+        if len(stracks) == 0:
+            return
+        kf = STrack.shared_kalman or KalmanFilter()
+        STrack.shared_kalman = kf
+        mean = np.asarray([st.mean.copy() for st in stracks])
+        cov = np.asarray([st.covariance for st in stracks])
+        zero = np.asarray([st.state != TrackState.Tracked for st in stracks])
+        mean, cov = kf.multi_predict(mean, cov, zero_velocity=zero)
+        for i, st in enumerate(stracks):
+            st.mean, st.covariance = mean[i], cov[i]
+
+    def __repr__(self):
+        return "OT_{}_({}-{})".format(self.track_id, self.start_frame, self.end_frame)   # D:687-688
+
+
+class DeviceTracker:
+    """Thin owner of a `bts_tracker` handle."""
+
+    def __init__(self, max_tracks: int, max_dets: int, feat_dim: int, face_dim: int = 0, frame_rate: int = 30,
+                 record_costs: bool = False, device: int = 0, context: Optional[_lib.Context] = None, **thresholds):
+        lib = _lib.load(require_gpu=True)
+        self.ctx = context or _lib.default_context(device)
+        cfg = _lib.TrackerConfig()
+        _lib.check(lib.bts_tracker_default_config(ctypes.byref(cfg)))
+        cfg.max_tracks, cfg.max_dets, cfg.feat_dim, cfg.face_dim = max_tracks, max_dets, feat_dim, face_dim
+        cfg.frame_rate = frame_rate
+        cfg.record_costs = 1 if record_costs else 0
+        for k, v in thresholds.items():
+            if not hasattr(cfg, k):
+                raise TypeError("unknown tracker option %r" % k)
+            setattr(cfg, k, v)
+        self.cfg = cfg
+        h = ctypes.c_void_p()
+        _lib.check(lib.bts_tracker_create(self.ctx.handle, ctypes.byref(cfg), ctypes.byref(h)))
+        self.handle = h
+        self._lib = lib
+        t = max_tracks
+        self._ints = np.empty((t, 8), dtype=np.int32)
+        self._mean = np.empty((t, 8), dtype=np.float64)
+        self._tlbr = np.empty((t, 4), dtype=np.float64)
+        self._score = np.empty((t,), dtype=np.float32)
+
+    def reset(self):
+        _lib.check(self._lib.bts_tracker_reset(self.handle, _lib.current_stream()))
+
+    def step(self, boxes, scores, feats, face_feats=None):
+        """boxes int32 [M,4] (tlbr pixels), scores float32 [M], feats float32 [M,D] -- CUDA tensors.
+        Enqueues one BoTSORT.update on the current stream; returns immediately."""
+        m = int(boxes.shape[0])
+        _lib.check(self._lib.bts_tracker_step(self.handle, _lib.ptr(boxes), _lib.ptr(scores), _lib.ptr(feats),
+                                              _lib.ptr(face_feats), m, _lib.current_stream()))
+
+    def counts(self) -> dict:
+        c = np.zeros(12, dtype=np.int32)
+        _lib.check(self._lib.bts_tracker_counts(self.handle, c.ctypes.data, _lib.current_stream()))
+        keys = ("frame_id", "n_tracked", "n_lost", "n_removed", "last_id", "n_pool", "n_hi", "n_lo", "n_unconfirmed",
+                "n_stage2_rows", "n_stage3_cols", "errors")
+        return dict(zip(keys, (int(v) for v in c)))
+
+    def export(self, which: int) -> dict:
+        n = _lib.check(self._lib.bts_tracker_export(self.handle, which, self._ints.ctypes.data, self._mean.ctypes.data,
+                                                    self._tlbr.ctypes.data, self._score.ctypes.data,
+                                                    _lib.current_stream()))
+        i = self._ints[:n]
+        return {"track_id": i[:, 0].astype(np.int64), "state": i[:, 1].astype(np.int64),
+                "is_activated": i[:, 2].astype(np.int64), "frame_id": i[:, 3].astype(np.int64),
+                "start_frame": i[:, 4].astype(np.int64), "tracklet_len": i[:, 5].astype(np.int64),
+                "det_index": i[:, 6].astype(np.int64), "slot": i[:, 7].astype(np.int64),
+                "mean": self._mean[:n].copy(), "tlbr": self._tlbr[:n].copy(), "score": self._score[:n].copy()}
+
+    def stage_result(self, stage: int, want_cost: bool = False) -> dict:
+        nr, nc = ctypes.c_int32(0), ctypes.c_int32(0)
+        t, m = self.cfg.max_tracks, self.cfg.max_dets
+        x = np.empty(t, dtype=np.int32)
+        y = np.empty(m, dtype=np.int32)
+        cost = None
+        if want_cost:
+            # sizes first, then the matrix
+            _lib.check(self._lib.bts_tracker_stage_result(self.handle, stage, None, None, None, ctypes.byref(nr),
+                                                          ctypes.byref(nc), _lib.current_stream()))
+            cost = np.empty((nr.value, nc.value), dtype=np.float64)
+        _lib.check(self._lib.bts_tracker_stage_result(self.handle, stage, x.ctypes.data, y.ctypes.data,
+                                                      cost.ctypes.data if cost is not None and cost.size else None,
+                                                      ctypes.byref(nr), ctypes.byref(nc), _lib.current_stream()))
+        x, y = x[:nr.value], y[:nc.value]
+        rows = np.nonzero(x >= 0)[0]
+        return {"x": x, "y": y, "m": np.stack([rows, x[rows]], axis=1).astype(np.int64).reshape(-1, 2),
+                "u_trk": np.nonzero(x < 0)[0].astype(np.int64), "u_det": np.nonzero(y < 0)[0].astype(np.int64),
+                "cost": cost}
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.bts_tracker_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class BoTSORT:
+    """D:1252-1639.  `update(image)` keeps the reference signature; `update_arrays` is the
+    tracker-only entry point fed with pre-extracted detections (BASELINE.json north_star)."""
+
+    def __init__(self, object_detection_model=None, body_feature_extractor_model=None,
+                 face_feature_extractor_model=None, frame_rate: int = 30, *, max_tracks: int = 4096,
+                 max_dets: int = 1024, feat_dim: Optional[int] = None, face_dim: Optional[int] = None,
+                 record_costs: bool = False, device: int = 0):
+        self.tracked_stracks: List[STrack] = []
+        self.lost_stracks: List[STrack] = []
+        self.removed_stracks: List[STrack] = []
+        BaseTrack.clear_count()                                   # D:1264
+        self.frame_id = 0
+        self.track_high_thresh = 0.40                             # D:1268-1277
+        self.track_low_thresh = 0.1
+        self.new_track_thresh = 0.9
+        self.match_thresh = 0.8
+        self.track_buffer = 300
+        self.feature_history = 300
+        self.proximity_thresh = 0.5
+        self.appearance_thresh = 0.25
+        self.buffer_size = int(frame_rate / 30.0 * self.track_buffer)
+        self.max_time_lost = self.buffer_size
+        self.kalman_filter = KalmanFilter()
+        self.detector = object_detection_model
+        self.body_encoder = body_feature_extractor_model
+        self.face_encoder = face_feature_extractor_model
+        if feat_dim is None:
+            feat_dim = getattr(body_feature_extractor_model, "feature_size", 2048)
+        if face_dim is None:
+            face_dim = 0
+        self.feat_dim, self.face_dim = int(feat_dim), int(face_dim)
+        self.device_tracker = DeviceTracker(max_tracks, max_dets, self.feat_dim, self.face_dim, frame_rate,
+                                            record_costs=record_costs, device=device)
+        self._mirror = {}          # track_id -> STrack
+        self._last_dets = None
+
+    # ---- tracker-only entry point
+    def update_arrays(self, boxes, scores, body_feats, face_feats=None, bodies=None, export: bool = True):
+        """boxes[M,4] integer tlbr pixels, scores[M], body_feats[M,D] float32 (L2-normalised),
+        face_feats[M,Df] float32 or None; NumPy arrays or CUDA tensors.  NOTE: like the reference
+        (quirk Q8) rows of the feature arrays of used detections are renormalised in place -- on
+        the device copy."""
+        import torch
+
+        def dev(a, dtype):
+            if isinstance(a, torch.Tensor):
+                return a.to(device="cuda", dtype=dtype).contiguous()
+            return torch.from_numpy(np.ascontiguousarray(a, dtype={torch.int32: np.int32, torch.float32: np.float32}[dtype])).cuda()
+
+        m = len(boxes)
+        b = dev(np.asarray(boxes).reshape(m, 4) if not isinstance(boxes, torch.Tensor) else boxes, torch.int32)
+        s = dev(scores, torch.float32)
+        f = dev(np.asarray(body_feats).reshape(m, self.feat_dim) if not isinstance(body_feats, torch.Tensor) else body_feats,
+                torch.float32)
+        ff = None
+        if self.face_dim:
+            if face_feats is None:
+                raise ValueError("face_feats is required when the tracker was built with face_dim > 0")
+            ff = dev(face_feats, torch.float32)
+        self.device_tracker.step(b, s, f, ff)
+        self.frame_id += 1
+        self._keep = (b, s, f, ff)      # inputs stay alive until the stream has consumed them
+        if not export:
+            return None
+        return self._export(bodies)
+
+    def _export(self, bodies=None) -> List[STrack]:
+        dt = self.device_tracker
+        out = []
+        for which in (0, 1):
+            tab = dt.export(which)
+            lst = []
+            for k in range(len(tab["track_id"])):
+                tid = int(tab["track_id"][k])
+                st = self._mirror.get(tid)
+                if st is None:
+                    st = STrack(np.zeros(4, dtype=np.float32), 0.0, self.feature_history)
+                    st.track_id = tid
+                    self._mirror[tid] = st
+                st.mean = tab["mean"][k]
+                st._dev_tlbr = tab["tlbr"][k]
+                st.state = int(tab["state"][k])
+                st.is_activated = bool(tab["is_activated"][k])
+                st.frame_id = int(tab["frame_id"][k])
+                st.start_frame = int(tab["start_frame"][k])
+                st.tracklet_len = int(tab["tracklet_len"][k])
+                st.score = float(tab["score"][k])
+                st.det_index = int(tab["det_index"][k])
+                st.slot = int(tab["slot"][k])
+                if bodies is not None and st.frame_id == self.frame_id and 0 <= st.det_index < len(bodies):
+                    st.body = bodies[st.det_index]
+                    if hasattr(st.body, "trackid"):
+                        st.body.trackid = tid                                  # D:612-622 (body only)
+                lst.append(st)
+            out.append(lst)
+        self.tracked_stracks, self.lost_stracks = out
+        live = {t.track_id for t in self.tracked_stracks} | {t.track_id for t in self.lost_stracks}
+        for tid in [t for t in self._mirror if t not in live]:
+            st = self._mirror.pop(tid)
+            st.state = TrackState.Removed
+            self.removed_stracks.append(st)
+        return self.tracked_stracks
+
+    # ---- reference signature (detector + encoders are the caller's objects, unchanged)
+    def update(self, image: np.ndarray) -> List[STrack]:
+        """D:1291: detect -> encode -> track.  Only the tracking half runs here; detection-side
+        part association (D:1303-1412) is out of scope."""
+        if self.detector is None or self.body_encoder is None:
+            raise RuntimeError("update(image) needs detector/encoder models; use update_arrays for pre-extracted detections")
+        boxes = [b for b in self.detector(image) if getattr(b, "classid", 0) == 0]
+        m = len(boxes)
+        arr = np.asarray([[b.x1, b.y1, b.x2, b.y2] for b in boxes], dtype=np.int32).reshape(m, 4)
+        scores = np.asarray([b.score for b in boxes], dtype=np.float32)
+        feats = np.zeros((m, self.feat_dim), dtype=np.float32)
+        ffeats = None
+        if m:
+            crops = [image[b.y1:b.y2, b.x1:b.x2, :] for b in boxes]
+            # the encoder's own similarity output is not used: the device computes it (D:1599 form)
+            _, feats = self.body_encoder(base_images=crops, target_features=np.zeros((0, self.feat_dim), dtype=np.float32))
+            if self.face_dim and self.face_encoder is not None:
+                ffeats, _ = self.face_encoder(base_images=crops, target_features=np.zeros((0, self.face_dim), dtype=np.float32))
+        if self.face_dim and ffeats is None:
+            ffeats = np.zeros((m, self.face_dim), dtype=np.float32)
+        return self.update_arrays(arr, scores, np.asarray(feats, dtype=np.float32), ffeats, bodies=boxes)
+
+
+# list helpers with the reference's semantics (D:1642-1680), on host mirrors
+def joint_stracks(tlista, tlistb):
+    exists, res = {}, []
+    for t in tlista:
+        exists[t.track_id] = 1
+        res.append(t)
+    for t in tlistb:
+        if not exists.get(t.track_id, 0):
+            exists[t.track_id] = 1
+            res.append(t)
+    return res
+
+
+def sub_stracks(tlista, tlistb):
+    stracks = {t.track_id: t for t in tlista}
+    for t in tlistb:
+        if t.track_id in stracks:
+            del stracks[t.track_id]
+    return list(stracks.values())
+
+
+def remove_duplicate_stracks(stracksa, stracksb):
+    from .matching import dedupe_flags
+    da, db = dedupe_flags(stracksa, stracksb, [t.frame_id - t.start_frame for t in stracksa],
+                          [t.frame_id - t.start_frame for t in stracksb], 0.15)
+    return ([t for i, t in enumerate(stracksa) if not da[i]], [t for i, t in enumerate(stracksb) if not db[i]])

@@ -1,0 +1,201 @@
+/*
+ * botsort_hip.h -- C ABI of libbotsort_hip.so: the MI355X (gfx950) BoT-SORT tracker hot path.
+ *
+ * The reference (PINTO0309/BoT-SORT-ONNX-TensorRT, demo_bottrack_onnx_tflite.py, cited D:line) has
+ * no FFI layer: its boundary is the Python call surface of one module.  Each entry point below
+ * names the reference function it replaces; the Python facade in bot-sort-onnx-tensorrt_amd/
+ * binds them with ctypes (INTEGRATION.md shows the stub a maintainer would add to the reference).
+ *
+ * Conventions
+ *   - every function returns int: 0 = BTS_OK, negative = bts_status; no C++ exception crosses;
+ *     bts_last_error() gives a thread-local message for the last failure.
+ *   - all array arguments are RAW DEVICE POINTERS owned by the caller (e.g. a PyTorch-ROCm
+ *     tensor's data_ptr()), row-major, with explicit sizes / leading dimensions.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream). Calls only enqueue
+ *     work; nothing synchronises unless the function says so.
+ *   - Kalman state and association costs are float64 (what the reference computes, SURVEY.md
+ *     8(a)); ReID features and similarities are float32; detections' boxes are float32 / int32.
+ *   - `*_f32` flag arrays (uint8, may be NULL = all 0) mark rows whose values were float32 in the
+ *     reference (never-predicted tracks, detections): the kernels then evaluate the same
+ *     sub-expressions in float32 that NumPy scalar arithmetic does, so results are bit-identical.
+ *   - one bts_context per (GPU, host thread); one bts_tracker per video stream. Neither is
+ *     thread-safe; different objects are independent.
+ */
+#ifndef BOTSORT_HIP_H
+#define BOTSORT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bts_context bts_context;
+typedef struct bts_tracker bts_tracker;
+typedef void *bts_stream;
+
+enum bts_status {
+    BTS_OK = 0,
+    BTS_EINVAL = -1,    /* bad argument */
+    BTS_EHIP = -2,      /* HIP runtime error (see bts_last_error) */
+    BTS_ENOMEM = -3,    /* device/host allocation failed */
+    BTS_ECAPACITY = -4, /* tracker capacity (tracks or detections) exceeded */
+    BTS_ENODEVICE = -5  /* no usable gfx950 device */
+};
+
+/* track states, D:382-387 */
+enum bts_track_state { BTS_NEW = 0, BTS_TRACKED = 1, BTS_LOST = 2, BTS_LONGLOST = 3, BTS_REMOVED = 4 };
+
+/* which cosine-similarity kernel bts_cos_similarity / the tracker use */
+enum bts_cos_kernel { BTS_COS_MFMA_F32 = 0, BTS_COS_VALU_F32 = 1 };
+
+const char *bts_version(void);
+const char *bts_last_error(void);
+const char *bts_status_string(int status);
+
+int bts_context_create(bts_context **out, int device_ordinal);
+int bts_context_destroy(bts_context *ctx);
+int bts_context_set_cos_kernel(bts_context *ctx, int which);
+
+/* ------------------------------------------------------------------ Kalman filter (D:118-380) */
+
+/* KalmanFilter.initiate, D:166-197. meas[n,4] = (cx,cy,w,h) float32 -> mean[n,8], cov[n,8,8].
+ * The std-devs are evaluated in float32 as NumPy 2 does for a float32 measurement. */
+int bts_kf_initiate(bts_context *ctx, const float *meas_xywh, int n, double *mean, double *cov,
+                    bts_stream stream);
+
+/* KalmanFilter.multi_predict (D:265-302) fused with STrack.multi_predict's rule (D:524-536):
+ * rows with zero_vel[i] != 0 (nullable) get mean[6]=mean[7]=0 first.  In place.  Rows flagged in
+ * row_f32 (nullable) evaluate the process noise in float32, as NumPy does for a float32 batch.
+ * tlbr_out[n,4] (nullable) receives the predicted boxes (STrack.tlbr, D:624-642). */
+int bts_kf_multi_predict(bts_context *ctx, double *mean, double *cov, const uint8_t *zero_vel,
+                         const uint8_t *row_f32, int n, double *tlbr_out, bts_stream stream);
+
+/* KalmanFilter.project, D:236-263 -> pmean[n,4], pcov[n,4,4]. */
+int bts_kf_project(bts_context *ctx, const double *mean, const double *cov, const uint8_t *row_f32,
+                   int n, double *pmean, double *pcov, bts_stream stream);
+
+/* KalmanFilter.update (D:304-336) over a match list: for q in [0,k) the track row trk_idx[q]
+ * (of mean/cov) is corrected in place with measurement meas_xywh[meas_idx[q]] (float32 cx,cy,w,h).
+ * trk_idx entries must be distinct.  4x4 innovation Cholesky + two triangular solves per row. */
+int bts_kf_update(bts_context *ctx, double *mean, double *cov, const uint8_t *row_f32,
+                  const int32_t *trk_idx, const float *meas_xywh, const int32_t *meas_idx, int k,
+                  bts_stream stream);
+
+/* KalmanFilter.gating_distance (D:338-380) for every (track, measurement) pair -> out[n,m].
+ * metric: 0 = 'maha', 1 = 'gaussian'.  meas[m,4] float64. */
+int bts_kf_gating(bts_context *ctx, const double *mean, const double *cov, int n, const double *meas,
+                  int m, int only_position, int metric, double *out, bts_stream stream);
+
+/* -------------------------------------------------------------- association costs (D:1539-1761) */
+
+/* iou_distance / bbox_ious / bbox_iou, D:1695-1761: cost[i*ld+j] = 1 - IoU(a[i], b[j]), tlbr boxes. */
+int bts_iou_distance(bts_context *ctx, const double *a_tlbr, const uint8_t *a_f32, int n,
+                     const double *b_tlbr, const uint8_t *b_f32, int m, double *cost, int ld,
+                     bts_stream stream);
+
+/* sim[i*ld+j] = max(0, <trk_feats[i,:], det_feats[j,:]>) in float32 -- the D:1599 definition that
+ * also stands in for the ReID ONNX graphs' similarity output (D:1453-1483). Rows have stride d. */
+int bts_cos_similarity(bts_context *ctx, const float *trk_feats, int n, const float *det_feats, int m,
+                       int d, float *sim, int ld, bts_stream stream);
+
+/* Fused first-association cost, D:1539-1554 (face_sim nullable = all zeros; the D:1481-1483
+ * "0.9999999" fix-up is applied to face_sim on the fly). */
+int bts_fuse_cost_stage1(bts_context *ctx, const double *iou_d, int ld_iou, const float *body_sim,
+                         const float *face_sim, int ld_sim, int n, int m, double proximity_thresh,
+                         double appearance_thresh, double *cost, int ld_cost, bts_stream stream);
+
+/* Fused unconfirmed-track cost, D:1590-1602. */
+int bts_fuse_cost_stage3(bts_context *ctx, const double *iou_d, int ld_iou, const float *body_sim,
+                         int ld_sim, int n, int m, double proximity_thresh, double appearance_thresh,
+                         double *cost, int ld_cost, bts_stream stream);
+
+/* linear_assignment -> lap.lapjv(cost, extend_cost=True, cost_limit), D:1682-1693.
+ * x[n] = column of row i or -1; y[m] = row of column j or -1. Exact (optimal) solution. */
+int bts_lapjv(bts_context *ctx, const double *cost, int n, int m, int ld, double cost_limit,
+              int32_t *x, int32_t *y, bts_stream stream);
+
+/* STrack.update_body_features / update_face_features, D:492-514, for k (track,det) pairs
+ * (trk_idx / det_idx nullable = identity; rows of length d, float32):
+ * curr[trk] = det row; smooth[trk] = normalise(alpha*smooth + (1-alpha)*det), or normalise(det)
+ * when has_smooth[trk]==0 (then set to 1).  alpha is the python float of D:473 (0.9). */
+int bts_feature_ema(bts_context *ctx, float *curr, float *smooth, uint8_t *has_smooth,
+                    const int32_t *trk_idx, const float *det_feats, const int32_t *det_idx, int k, int d,
+                    double alpha, bts_stream stream);
+
+/* The in-place L2 renormalisation the reference applies to a detection's feature row when its
+ * STrack record is built (first update_*_features call aliases and normalises, D:496-502, Q8):
+ * feats[idx[q], :] /= ||.||_2 for q in [0,k) (idx nullable = identity). */
+int bts_feature_renorm(bts_context *ctx, float *feats, const int32_t *idx, int k, int d, bts_stream stream);
+
+/* remove_duplicate_stracks, D:1665-1680: drop_a[n] / drop_b[m] flags (uint8, overwritten) for
+ * pairs with 1-IoU < thresh; age_* = frame_id - start_frame. */
+int bts_dedupe_pairs(bts_context *ctx, const double *a_tlbr, const uint8_t *a_f32, const int32_t *age_a,
+                     int n, const double *b_tlbr, const uint8_t *b_f32, const int32_t *age_b, int m,
+                     double thresh, uint8_t *drop_a, uint8_t *drop_b, bts_stream stream);
+
+/* -------------------------------------------------- whole-frame tracker, BoTSORT.update D:1414-1639 */
+
+typedef struct bts_tracker_config {
+    int32_t max_tracks;      /* capacity of the resident track table (tracked + lost + unconfirmed) */
+    int32_t max_dets;        /* max detections per frame */
+    int32_t feat_dim;        /* body ReID feature dimension D */
+    int32_t face_dim;        /* face ReID dimension, 0 = no face features */
+    int32_t frame_rate;      /* D:1258; buffer_size = int(frame_rate/30*track_buffer) */
+    int32_t track_buffer;    /* D:1272, default 300 */
+    double track_high_thresh;   /* 0.40 D:1268 */
+    double track_low_thresh;    /* 0.1  D:1269 */
+    double new_track_thresh;    /* 0.9  D:1270 */
+    double match_thresh;        /* 0.8  D:1271 */
+    double second_match_thresh; /* 0.5  D:1571 */
+    double unconfirmed_match_thresh; /* 0.7 D:1604 */
+    double proximity_thresh;    /* 0.5  D:1274 */
+    double appearance_thresh;   /* 0.25 D:1275 */
+    double dedupe_thresh;       /* 0.15 D:1667 */
+    double ema_alpha;           /* 0.9  D:473 */
+    int32_t record_costs;       /* keep the three cost matrices of the last frame for inspection */
+} bts_tracker_config;
+
+/* Fill cfg with the reference's hard-coded values (D:1268-1277). */
+int bts_tracker_default_config(bts_tracker_config *cfg);
+
+int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_tracker **out);
+int bts_tracker_destroy(bts_tracker *trk);
+/* Back to frame 0, no tracks, ID counter 0 (what constructing a new BoTSORT does, D:1261-1266). */
+int bts_tracker_reset(bts_tracker *trk, bts_stream stream);
+
+/* One BoTSORT.update on pre-extracted arrays (tracking half, D:1414-1639), fully on device:
+ *   boxes[m,4]  int32 tlbr pixels (what the detector emits, D:1009-1012)
+ *   scores[m]   float32
+ *   feats[m,D]  float32, L2-normalised; rows of used detections are renormalised IN PLACE (Q8)
+ *   face_feats[m,Df] float32 or NULL
+ * Enqueues the whole association cascade on `stream`; no host synchronisation. */
+int bts_tracker_step(bts_tracker *trk, const int32_t *boxes, const float *scores, float *feats,
+                     float *face_feats, int m, bts_stream stream);
+
+/* Sizes after the last enqueued step (synchronises `stream`):
+ * counts[0]=frame_id [1]=n_tracked [2]=n_lost [3]=n_removed_total [4]=last_track_id
+ * [5]=pool rows N of the last frame [6]=high dets [7]=low dets [8]=unconfirmed rows
+ * [9]=stage-2 rows [10]=stage-3 cols [11]=error flags (0 = none) */
+int bts_tracker_counts(bts_tracker *trk, int32_t *counts12_host, bts_stream stream);
+
+/* Copy the tracked (which=0) or lost (which=1) list, in list order, to HOST buffers (each
+ * nullable, sized for max_tracks rows).  Synchronises `stream`.  Returns the row count or <0.
+ * ints[row,8] = track_id, state, is_activated, frame_id, start_frame, tracklet_len, det_index, slot
+ * mean[row,8] float64; tlbr[row,4] float64 (STrack.tlbr); score[row] float32. */
+int bts_tracker_export(bts_tracker *trk, int which, int32_t *ints_host, double *mean_host,
+                       double *tlbr_host, float *score_host, bts_stream stream);
+
+/* Last frame's association results to HOST (synchronises): for stage s in {1,2,3}
+ * x_host[rows], y_host[cols] (nullable); returns rows via *n_rows, cols via *n_cols.
+ * If record_costs was set, cost_host (nullable) receives rows*cols float64, row-major. */
+int bts_tracker_stage_result(bts_tracker *trk, int stage, int32_t *x_host, int32_t *y_host,
+                             double *cost_host, int32_t *n_rows, int32_t *n_cols, bts_stream stream);
+
+/* Device pointer to body_curr_feature / covariance rows etc. is intentionally not exposed:
+ * the track table is owned by the library (DESIGN.md "data layout in HBM"). */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BOTSORT_HIP_H */

@@ -1,0 +1,64 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library loads, exports every symbol that
+include/botsort_hip.h declares, and the Python binding covers all of them.  No compute calls."""
+import ctypes
+import importlib
+import os
+import re
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(REPO, "include", "botsort_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(bts_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib_mod = importlib.import_module("bot-sort-onnx-tensorrt_amd._lib")
+    if not os.path.exists(lib_mod.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    names = _declared()
+    assert len(names) >= 25
+    lib = lib_mod.load()
+    for n in names:
+        assert hasattr(lib, n), "library does not export %s" % n
+    assert sorted(lib_mod.SIGNATURES) == names, "Python binding and header disagree"
+    assert b"gfx950" in lib.bts_version()
+    assert lib.bts_status_string(-4) == b"tracker capacity exceeded"
+
+
+def test_default_config_matches_reference_constants():
+    lib_mod = importlib.import_module("bot-sort-onnx-tensorrt_amd._lib")
+    lib = lib_mod.load()
+    cfg = lib_mod.TrackerConfig()
+    assert lib.bts_tracker_default_config(ctypes.byref(cfg)) == 0
+    # demo_bottrack_onnx_tflite.py:1268-1277, 1571, 1604, 1667, 473
+    assert (cfg.track_high_thresh, cfg.track_low_thresh, cfg.new_track_thresh) == (0.40, 0.1, 0.9)
+    assert (cfg.match_thresh, cfg.second_match_thresh, cfg.unconfirmed_match_thresh) == (0.8, 0.5, 0.7)
+    assert (cfg.proximity_thresh, cfg.appearance_thresh, cfg.dedupe_thresh) == (0.5, 0.25, 0.15)
+    assert cfg.track_buffer == 300 and cfg.frame_rate == 30 and cfg.ema_alpha == 0.9
+
+
+def test_product_path_never_imports_the_oracle():
+    pkg_dir = os.path.join(REPO, "bot-sort-onnx-tensorrt_amd")
+    for root, _, files in os.walk(pkg_dir):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(root, f)).read()
+                assert not re.search(r"(import\s+oracle|from\s+oracle|oracle[./]|liboracle|bts_oracle)", src), f
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    lib_mod = importlib.import_module("bot-sort-onnx-tensorrt_amd._lib")
+    with pytest.raises(lib_mod.BtsError):
+        lib_mod.Context(0)
+    pkg = importlib.import_module("bot-sort-onnx-tensorrt_amd")
+    with pytest.raises(pkg.BtsError):
+        pkg.iou_distance([[0, 0, 1, 1]], [[0, 0, 1, 1]])
