@@ -522,6 +522,9 @@ struct bts_tracker {
     // export staging
     int32_t *x_ints = nullptr; double *x_mean = nullptr, *x_tlbr = nullptr; float *x_score = nullptr;
     int32_t *host_hdr = nullptr;   // pinned
+    // optional per-segment timing (bts_tracker_profile_*): a ring of hipEvent pairs
+    int prof_seg = -1, prof_cap = 0, prof_n = 0;
+    hipEvent_t *prof_ev = nullptr;
 };
 
 static size_t take(size_t &off, size_t bytes) { const size_t o = off; off = bts_align(off + bytes); return o; }
@@ -616,8 +619,37 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
     return BTS_OK;
 }
 
+int bts_tracker_profile_enable(bts_tracker *t, int segment, int capacity) {
+    BTS_REQUIRE(t && capacity >= 0, "tracker, capacity");
+    for (int k = 0; k < 2 * t->prof_cap; ++k) (void)hipEventDestroy(t->prof_ev[k]);
+    delete[] t->prof_ev;
+    t->prof_ev = nullptr; t->prof_cap = 0; t->prof_n = 0; t->prof_seg = segment;
+    if (capacity == 0) return BTS_OK;
+    t->prof_ev = new (std::nothrow) hipEvent_t[2 * capacity];
+    if (!t->prof_ev) { bts_set_error("host allocation failed"); return BTS_ENOMEM; }
+    for (int k = 0; k < 2 * capacity; ++k) BTS_HIP(hipEventCreate(&t->prof_ev[k]));
+    t->prof_cap = capacity;
+    return BTS_OK;
+}
+
+int bts_tracker_profile_read(bts_tracker *t, double *total_ms, int32_t *count) {
+    BTS_REQUIRE(t && total_ms && count, "null argument");
+    double tot = 0.0;
+    for (int k = 0; k < t->prof_n; ++k) {
+        BTS_HIP(hipEventSynchronize(t->prof_ev[2 * k + 1]));
+        float ms = 0.0f;
+        BTS_HIP(hipEventElapsedTime(&ms, t->prof_ev[2 * k], t->prof_ev[2 * k + 1]));
+        tot += ms;
+    }
+    *total_ms = tot; *count = t->prof_n;
+    t->prof_n = 0;
+    return BTS_OK;
+}
+
 int bts_tracker_destroy(bts_tracker *t) {
     if (!t) return BTS_OK;
+    for (int k = 0; k < 2 * t->prof_cap; ++k) (void)hipEventDestroy(t->prof_ev[k]);
+    delete[] t->prof_ev;
     if (t->block) (void)hipFree(t->block);
     if (t->host_hdr) (void)hipHostFree(t->host_hdr);
     delete t;
@@ -641,6 +673,9 @@ int bts_tracker_step(bts_tracker *t, const int32_t *boxes, const float *scores, 
     BTS_REQUIRE(m == 0 || (boxes && scores && feats), "null detection arrays");
     BTS_REQUIRE(t->cfg.face_dim == 0 || m == 0 || face_feats, "face_feats required when face_dim > 0");
     hipStream_t s = (hipStream_t)stream;
+    const bool prof_room = t->prof_cap > 0 && t->prof_n < t->prof_cap;
+    auto seg_begin = [&](int id) { if (prof_room && t->prof_seg == id) (void)hipEventRecord(t->prof_ev[2 * t->prof_n], s); };
+    auto seg_end = [&](int id) { if (prof_room && t->prof_seg == id) { (void)hipEventRecord(t->prof_ev[2 * t->prof_n + 1], s); t->prof_n++; } };
     Dev d = t->dv;
     d.boxes = boxes; d.scores = scores; d.feats = feats; d.face_feats = face_feats; d.m = m;
     const int T = d.T, M = d.Mx;
@@ -649,31 +684,47 @@ int bts_tracker_step(bts_tracker *t, const int32_t *boxes, const float *scores, 
     int rc;
 #define LAUNCH(kern, grid, block) hipLaunchKernelGGL(kern, grid, block, 0, s, d); BTS_LAUNCH_CHECK()
 
+    seg_begin(BTS_SEG_STEP);
+    seg_begin(BTS_SEG_PREP);
     LAUNCH(tk_prep, dim3(1), dim3(1024));
+    seg_end(BTS_SEG_PREP);
+    seg_begin(BTS_SEG_PREDICT);
     LAUNCH(tk_predict, dim3(bts_cdiv(T, 256)), dim3(256));
+    seg_end(BTS_SEG_PREDICT);
     // ---- first association: pool x high-score detections
+    seg_begin(BTS_SEG_COS1);
     rc = bts_cos_enqueue(cos_kernel, d.body_curr, d.pool_slot, d.D, feats, d.hi_idx, d.D, d.D, d.hdr + H_DIMS1, T, M,
                          d.sim, M, s);
     if (rc) return rc;
+    seg_end(BTS_SEG_COS1);
     if (d.Df) {
         rc = bts_cos_enqueue(cos_kernel, d.face_curr, d.pool_slot, d.Df, face_feats, d.hi_idx, d.Df, d.Df,
                              d.hdr + H_DIMS1, T, M, d.fsim, M, s);
         if (rc) return rc;
     }
+    seg_begin(BTS_SEG_COST1);
     LAUNCH(tk_cost<1>, cost_grid, dim3(CT_COLS));
+    seg_end(BTS_SEG_COST1);
+    seg_begin(BTS_SEG_LAP1);
     rc = bts_lap_enqueue_dense(&t->lap, d.cost1, M, d.hdr + H_DIMS1, T, M, d.match1, d.x1, d.y1, s);
     if (rc) return rc;
+    seg_end(BTS_SEG_LAP1);
+    seg_begin(BTS_SEG_APPLY1);
     LAUNCH(tk_renorm, dim3(M), dim3(256));
     LAUNCH(tk_after1, dim3(1), dim3(1024));          // reads pre-update states: before tk_apply_kf<1>
     LAUNCH(tk_apply_kf<1>, dim3(bts_cdiv(T, 256)), dim3(256));
     LAUNCH(tk_apply_feat<1>, dim3(T), dim3(256));
+    seg_end(BTS_SEG_APPLY1);
     // ---- second association: remaining tracked rows x low-score detections
+    seg_begin(BTS_SEG_STAGE2);
     LAUNCH(tk_cost<2>, cost_grid, dim3(CT_COLS));
     rc = bts_lap_enqueue_dense(&t->lap, d.cost2, M, d.hdr + H_DIMS2, T, M, d.match2, d.x2, d.y2, s);
     if (rc) return rc;
     LAUNCH(tk_apply_kf<2>, dim3(bts_cdiv(T, 256)), dim3(256));
     LAUNCH(tk_apply_feat<2>, dim3(T), dim3(256));
+    seg_end(BTS_SEG_STAGE2);
     // ---- unconfirmed tracks x leftover high-score detections
+    seg_begin(BTS_SEG_STAGE3);
     rc = bts_cos_enqueue(cos_kernel, d.body_curr, d.unc_slot, d.D, feats, d.left_det, d.D, d.D, d.hdr + H_DIMS3, T, M,
                          d.sim, M, s);
     if (rc) return rc;
@@ -682,12 +733,18 @@ int bts_tracker_step(bts_tracker *t, const int32_t *boxes, const float *scores, 
     if (rc) return rc;
     LAUNCH(tk_apply_kf<3>, dim3(bts_cdiv(T, 256)), dim3(256));
     LAUNCH(tk_apply_feat<3>, dim3(T), dim3(256));
+    seg_end(BTS_SEG_STAGE3);
     // ---- births, list merge, duplicate removal
+    seg_begin(BTS_SEG_MERGE);
     LAUNCH(tk_merge, dim3(1), dim3(1024));
     LAUNCH(tk_birth_init, dim3(M), dim3(256));
+    seg_end(BTS_SEG_MERGE);
+    seg_begin(BTS_SEG_DEDUPE);
     LAUNCH(tk_list_boxes, dim3(bts_cdiv(T, 256)), dim3(256));
     LAUNCH(tk_dedupe, dim3(bts_cdiv(T, CT_COLS), bts_cdiv(T, CT_ROWS)), dim3(CT_COLS));
     LAUNCH(tk_finalize, dim3(1), dim3(1024));
+    seg_end(BTS_SEG_DEDUPE);
+    seg_end(BTS_SEG_STEP);
 #undef LAUNCH
     return BTS_OK;
 }

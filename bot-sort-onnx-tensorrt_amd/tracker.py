@@ -229,6 +229,18 @@ class DeviceTracker:
                 "u_trk": np.nonzero(x < 0)[0].astype(np.int64), "u_det": np.nonzero(y < 0)[0].astype(np.int64),
                 "cost": cost}
 
+    SEGMENTS = {"prep": 0, "predict": 1, "cos1": 2, "cost1": 3, "lap1": 4, "apply1": 5, "stage2": 6, "stage3": 7,
+                "merge": 8, "dedupe": 9, "step": 100}
+
+    def profile_enable(self, segment: str, capacity: int):
+        _lib.check(self._lib.bts_tracker_profile_enable(self.handle, self.SEGMENTS[segment], int(capacity)))
+
+    def profile_read(self):
+        """-> (total_ms, count) of the hipEvent pairs recorded since the last read."""
+        tot, cnt = ctypes.c_double(0.0), ctypes.c_int32(0)
+        _lib.check(self._lib.bts_tracker_profile_read(self.handle, ctypes.byref(tot), ctypes.byref(cnt)))
+        return tot.value, cnt.value
+
     def close(self):
         if getattr(self, "handle", None):
             self._lib.bts_tracker_destroy(self.handle)

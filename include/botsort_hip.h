@@ -192,6 +192,17 @@ int bts_tracker_export(bts_tracker *trk, int which, int32_t *ints_host, double *
 int bts_tracker_stage_result(bts_tracker *trk, int stage, int32_t *x_host, int32_t *y_host,
                              double *cost_host, int32_t *n_rows, int32_t *n_cols, bts_stream stream);
 
+/* Measurement hook (bench.py's roofline leg): wrap one kernel group of every following
+ * bts_tracker_step in a hipEvent pair recorded on the step's stream.  `capacity` pairs are kept
+ * (steps beyond that are not timed); capacity 0 disables.  Events are created here, never in a step. */
+enum bts_segment {
+    BTS_SEG_PREP = 0, BTS_SEG_PREDICT = 1, BTS_SEG_COS1 = 2, BTS_SEG_COST1 = 3, BTS_SEG_LAP1 = 4, BTS_SEG_APPLY1 = 5,
+    BTS_SEG_STAGE2 = 6, BTS_SEG_STAGE3 = 7, BTS_SEG_MERGE = 8, BTS_SEG_DEDUPE = 9, BTS_SEG_STEP = 100
+};
+int bts_tracker_profile_enable(bts_tracker *trk, int segment, int capacity);
+/* Synchronises on the recorded events; returns their summed duration and count, then clears them. */
+int bts_tracker_profile_read(bts_tracker *trk, double *total_ms, int32_t *count);
+
 /* Device pointer to body_curr_feature / covariance rows etc. is intentionally not exposed:
  * the track table is owned by the library (DESIGN.md "data layout in HBM"). */
 

@@ -40,7 +40,7 @@ def _replay_golden(bts, name, synth):
     K, M, D, frames = int(g["K"]), int(g["M"]), int(g["D"]), int(g["frames"])
     fd = int(g["face_dim"])
     st = synth.SyntheticStream(K, M, D, seed=int(g["seed"]), churn=float(g["churn"]), face_dim=fd)
-    trk = bts.DeviceTracker(max_tracks=4 * K + 64, max_dets=M + 8, feat_dim=D, face_dim=fd,
+    trk = bts.DeviceTracker(max_tracks=4 * K + 64, max_dets=max(K, M) + 8, feat_dim=D, face_dim=fd,
                             frame_rate=int(g["frame_rate"]), record_costs=True)
     h = hashlib.sha256()
     worst_mean = 0.0
@@ -90,7 +90,7 @@ def _against_oracle(bts, synth, K, M, D, frames, churn=0.0, frame_rate=30, seed=
     from oracle import bts_oracle as bo
     st = synth.SyntheticStream(K, M, D, seed=seed, churn=churn, face_dim=face_dim)
     ora = bo.TrackerOracle(frame_rate=frame_rate)
-    trk = bts.DeviceTracker(max_tracks=2 * K + int(frames * churn * M) + 64, max_dets=M, feat_dim=D, face_dim=face_dim,
+    trk = bts.DeviceTracker(max_tracks=2 * K + int(frames * churn * M) + 64, max_dets=max(K, M), feat_dim=D, face_dim=face_dim,
                             frame_rate=frame_rate)
     matched = 0
     for f in range(frames):
@@ -178,7 +178,7 @@ def test_botsort_facade(bts, synth):
     """the drop-in object: BoTSORT.update_arrays returns STrack mirrors like the reference's update()."""
     from oracle import bts_oracle as bo
     st = synth.SyntheticStream(48, 24, 128, seed=5, churn=0.05)
-    bot = bts.BoTSORT(frame_rate=30, max_tracks=256, max_dets=32, feat_dim=128)
+    bot = bts.BoTSORT(frame_rate=30, max_tracks=256, max_dets=64, feat_dim=128)
     ora = bo.TrackerOracle()
     for f in range(15):
         fr = st.next()
