@@ -90,6 +90,7 @@ struct bts_lap_work {
     int32_t *crows = nullptr;    // [n_cap] rows grouped by component
     int32_t *crows_s = nullptr;  // [n_cap] ... sorted ascending inside each component
     int32_t *ccols = nullptr;    // [m_cap] columns grouped by component
+    int32_t *comp_list = nullptr; // [n_cap] components that need the augmenting-path solver
     double *u = nullptr;         // [n_cap] row duals
     double *v = nullptr;         // [m_cap] column duals
     double *dist = nullptr;      // [m_cap] tentative distances of a search

@@ -18,10 +18,11 @@
 // column on equal distance, a real column preferred over staying unmatched on equality.
 // Everything is deterministic regardless of the order edges were appended in.
 #include "bts_internal.h"
+#include "block_scan.h"
 
 namespace {
 
-enum { H_EDGES = 0, H_COMPS = 1, H_ERR = 2 };
+enum { H_EDGES = 0, H_COMPS = 1, H_ERR = 2, H_HARD = 3 };   // hdr: edges, components, overflow flag, components for k_solve
 
 #define RLX(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 
@@ -92,24 +93,14 @@ __device__ void unite(int32_t *parent, int a, int b) {
 }
 
 // exclusive scan of arr[0..len) in place (values via RLX), total returned to every thread.
-// `tmp` is LDS of blockDim.x ints.
 __device__ int block_exscan(int32_t *arr, int len, int32_t *tmp) {
     const int nth = blockDim.x, tid = threadIdx.x;
     const int per = (len + nth - 1) / nth;
     const int lo = min(len, tid * per), hi = min(len, lo + per);
     int s = 0;
     for (int k = lo; k < hi; ++k) s += RLX(&arr[k]);
-    tmp[tid] = s;
-    __syncthreads();
-    for (int off = 1; off < nth; off <<= 1) {      // Hillis-Steele inclusive scan of the partials
-        const int v = tid >= off ? tmp[tid - off] : 0;
-        __syncthreads();
-        tmp[tid] += v;
-        __syncthreads();
-    }
-    const int total = tmp[nth - 1];
-    int run = tid ? tmp[tid - 1] : 0;
-    __syncthreads();
+    int total;
+    int run = bscan::exscan(s, tmp, &total);
     for (int k = lo; k < hi; ++k) { const int v = RLX(&arr[k]); arr[k] = run; run += v; }
     __syncthreads();
     return total;
@@ -123,8 +114,15 @@ __global__ __launch_bounds__(1024) void k_prepare(LapArgs A) {
     int E = RLX(&w.hdr[H_EDGES]);
     if ((long)E > w.e_cap) E = (int)w.e_cap;
 
+    if (E == 0) {                               // nothing feasible: everything stays unmatched
+        for (int i = tid; i < n; i += nth) A.x[i] = -1;
+        for (int j = tid; j < m; j += nth) A.y[j] = -1;
+        if (tid == 0) { w.hdr[H_COMPS] = 0; w.hdr[H_HARD] = 0; }
+        return;
+    }
     for (int i = tid; i < n; i += nth) { w.deg[i] = 0; w.parent[i] = i; A.x[i] = -1; }
     for (int j = tid; j < m; j += nth) { w.cdeg[j] = 0; w.parent[n + j] = n + j; A.y[j] = -1; w.v[j] = 0.0; }
+    if (tid == 0) w.hdr[H_HARD] = 0;
     __syncthreads();
     for (int e = tid; e < E; e += nth) {
         const int i = w.e_row[e], j = w.e_col[e];
@@ -172,6 +170,20 @@ __global__ __launch_bounds__(1024) void k_prepare(LapArgs A) {
         if (RLX(&w.deg[i]) > 0) w.crows[atomicAdd(&w.ccur_r[RLX(&w.comp_of[RLX(&w.parent[i])])], 1)] = i;
     for (int j = tid; j < m; j += nth)
         if (RLX(&w.cdeg[j]) > 0) w.ccols[atomicAdd(&w.ccur_c[RLX(&w.comp_of[RLX(&w.parent[n + j])])], 1)] = j;
+    __syncthreads();
+    // A component of one row and one column (by far the common case in a tracking frame) is
+    // decided here: any feasible edge beats two dummies (cost <= limit), ties prefer the match.
+    // Everything else is queued for the augmenting-path solver.
+    for (int c = tid; c < C; c += nth) {
+        const int rs = RLX(&w.crow_ptr[c]), r = RLX(&w.crow_ptr[c + 1]) - rs;
+        const int cs = RLX(&w.ccol_ptr[c]), cn = RLX(&w.ccol_ptr[c + 1]) - cs;
+        if (r == 1 && cn == 1) {
+            const int i = RLX(&w.crows[rs]), j = RLX(&w.ccols[cs]);
+            A.x[i] = j; A.y[j] = i;
+        } else {
+            w.comp_list[atomicAdd(&w.hdr[H_HARD], 1)] = c;
+        }
+    }
 }
 
 // ---- 3. one wavefront per component: shortest augmenting paths ----------------------------------
@@ -275,10 +287,10 @@ __device__ void solve_component(const LapArgs &A, int c, int lane) {
 }
 
 __global__ __launch_bounds__(256) void k_solve(LapArgs A) {
-    const int C = A.w.hdr[H_COMPS];
+    const int C = A.w.hdr[H_HARD];
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwave = (gridDim.x * blockDim.x) >> 6;
-    for (int c = wave; c < C; c += nwave) solve_component(A, c, lane);
+    for (int q = wave; q < C; q += nwave) solve_component(A, A.w.comp_list[q], lane);
 }
 
 }  // namespace
@@ -295,7 +307,7 @@ static void layout(bts_lap_work *w, char *base, size_t &off, int n, int m, int64
     SLOT(parent, int32_t, n + m); SLOT(comp_of, int32_t, n);
     SLOT(crow_ptr, int32_t, n + 1); SLOT(ccol_ptr, int32_t, n + 1);
     SLOT(ccur_r, int32_t, n + 1); SLOT(ccur_c, int32_t, n + 1);
-    SLOT(crows, int32_t, n); SLOT(crows_s, int32_t, n); SLOT(ccols, int32_t, m);
+    SLOT(crows, int32_t, n); SLOT(crows_s, int32_t, n); SLOT(ccols, int32_t, m); SLOT(comp_list, int32_t, n);
     SLOT(u, double, n); SLOT(v, double, m); SLOT(dist, double, m);
     SLOT(pred, int32_t, m); SLOT(scanned, int32_t, m);
 #undef SLOT

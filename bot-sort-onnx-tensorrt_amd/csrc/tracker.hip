@@ -10,6 +10,7 @@
 // by later kernels from `hdr`; grids are sized for capacity and surplus workgroups exit at once.
 // That is what makes a step capturable in a hipGraph and lets frames be enqueued back to back.
 #include "bts_internal.h"
+#include "block_scan.h"
 #include "feat_math.h"
 #include "iou_math.h"
 #include "kf_math.h"
@@ -48,9 +49,9 @@ struct Dev {
     double *cost1, *cost2, *cost3;
     int32_t *x1, *y1, *x2, *y2, *x3, *y3;
     // dedupe
-    double *tl_tlbr, *ll_tlbr;
-    uint8_t *tl_f32, *ll_f32, *drop_t, *drop_l;
-    int32_t *tl_age, *ll_age;
+    uint8_t *drop_t, *drop_l;
+    int32_t *lap_hdr;          // 3 x 16 ints: per-stage counters of the assignment solver
+    int record;                // keep dense cost matrices (tests / inspection)
     // inputs of the current step
     const int32_t *boxes;
     const float *scores;
@@ -58,37 +59,10 @@ struct Dev {
     int m;
 };
 
-// ---- single-workgroup helpers ---------------------------------------------------------------------
-__device__ int block_exscan_i(int v, int32_t *tmp, int *total) {   // exclusive scan of one value per thread
-    const int tid = threadIdx.x, nth = blockDim.x;
-    __syncthreads();
-    tmp[tid] = v;
-    __syncthreads();
-    for (int off = 1; off < nth; off <<= 1) {
-        const int t = tid >= off ? tmp[tid - off] : 0;
-        __syncthreads();
-        tmp[tid] += t;
-        __syncthreads();
-    }
-    *total = tmp[nth - 1];
-    return tmp[tid] - v;
-}
-
-// Ordered compaction of the indices k in [0, L) with pred(k): emit(position, k). Returns the count.
+// ---- single-workgroup helpers: bscan::exscan / bscan::compact (block_scan.h) ------------------------
 template <class Pred, class Emit>
-__device__ int block_compact(int L, int32_t *tmp, Pred pred, Emit emit) {
-    const int tid = threadIdx.x, nth = blockDim.x;
-    const int per = (L + nth - 1) / nth;
-    const int lo = min(L, tid * per), hi = min(L, lo + per);
-    int cnt = 0;
-    for (int k = lo; k < hi; ++k) cnt += pred(k) ? 1 : 0;
-    int total;
-    int pos = block_exscan_i(cnt, tmp, &total);
-    for (int k = lo; k < hi; ++k)
-        if (pred(k)) emit(pos++, k);
-    __syncthreads();
-    return total;
-}
+__device__ __forceinline__ int block_compact(int L, int32_t *tmp, Pred pred, Emit emit) { return bscan::compact(L, tmp, pred, emit); }
+__device__ __forceinline__ int block_exscan_i(int v, int32_t *tmp, int *total) { return bscan::exscan(v, tmp, total); }
 
 __device__ __forceinline__ void load_state(const Dev &d, int slot, double m[8], double P[64]) {
 #pragma unroll
@@ -144,6 +118,7 @@ __global__ __launch_bounds__(1024) void tk_prep(Dev d) {
     const int nlo = block_compact(m, tmp, [&](int j) { const double s = (double)d.scores[j]; return s <= d.high && s >= d.low; },
                                   [&](int p, int j) { d.lo_idx[p] = j; });
     __syncthreads();
+    if (tid < 48) d.lap_hdr[tid] = 0;
     if (tid == 0) {
         h[H_FRAME] += 1;
         h[H_NPOOL] = N; h[H_NCONF] = nconf; h[H_NUNC] = nunc; h[H_NHI] = nhi; h[H_NLO] = nlo; h[H_NDETS] = m;
@@ -181,8 +156,11 @@ __device__ __forceinline__ float face_fixup(float s) {
 
 // STAGE 1: cost = min(iou_d, emb) with the appearance gate (D:1539-1554)
 // STAGE 2: cost = iou_d (D:1570)      STAGE 3: D:1590-1602
+// The same tile also feeds the assignment solver directly: every entry <= the stage's match
+// threshold is appended to the solver's edge list (entries above it can never be matched), so the
+// dense matrix is only written when cost recording is on.
 template <int STAGE>
-__global__ __launch_bounds__(CT_COLS) void tk_cost(Dev d) {
+__global__ __launch_bounds__(CT_COLS) void tk_edges(Dev d, bts_lap_work w) {
     __shared__ double sa[CT_ROWS][4];
     __shared__ double sarea[CT_ROWS];
     __shared__ int sflag[CT_ROWS];
@@ -206,6 +184,7 @@ __global__ __launch_bounds__(CT_COLS) void tk_cost(Dev d) {
     const double bb[4] = {d.det_tlbr[det * 4 + 0], d.det_tlbr[det * 4 + 1], d.det_tlbr[det * 4 + 2], d.det_tlbr[det * 4 + 3]};
     const double area_b = iou::area(bb, true);
     double *cost = STAGE == 1 ? d.cost1 : STAGE == 2 ? d.cost2 : d.cost3;
+    const double limit = STAGE == 1 ? d.match1 : STAGE == 2 ? d.match2 : d.match3;
     const int rows = min(CT_ROWS, n - i0);
     for (int r = 0; r < rows; ++r) {
         const double aa[4] = {sa[r][0], sa[r][1], sa[r][2], sa[r][3]};
@@ -223,7 +202,12 @@ __global__ __launch_bounds__(CT_COLS) void tk_cost(Dev d) {
             if (iou_d > d.prox) emb = 1.0f;
             c = fmin(iou_d, (double)emb);
         }
-        cost[o] = c;
+        if (d.record) cost[o] = c;
+        if (c <= limit) {
+            const int pos = atomicAdd(&w.hdr[0], 1);
+            if (pos < w.e_cap) { w.e_row[pos] = i0 + r; w.e_col[pos] = q; w.e_cost[pos] = c; }
+            else w.hdr[2] = 1;
+        }
     }
 }
 
@@ -237,21 +221,39 @@ __global__ __launch_bounds__(256) void tk_renorm(Dev d) {
     if (d.Df) feat::renorm_row(d.face_feats + det * d.Df, d.Df);
 }
 
-// ---- match application: Kalman update + lifecycle (D:570-610) ---------------------------------------------
+// ---- match application (D:570-610): Kalman update + lifecycle by the first workgroups (one thread
+// per row, state in registers), ReID feature bookkeeping by the rest (one workgroup per row). -----------
 template <int STAGE>
-__global__ __launch_bounds__(256) void tk_apply_kf(Dev d) {
+__global__ __launch_bounds__(256) void tk_apply(Dev d, int kf_blocks) {
     const int32_t *h = d.hdr;
     const int n = STAGE == 1 ? h[H_NPOOL] : STAGE == 2 ? h[H_NR2] : h[H_NUNC];
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int32_t *rslot = STAGE == 1 ? d.pool_slot : STAGE == 2 ? d.r2_slot : d.unc_slot;
+    const int32_t *xs = STAGE == 1 ? d.x1 : STAGE == 2 ? d.x2 : d.x3;
+    const int32_t *cdet = STAGE == 1 ? d.hi_idx : STAGE == 2 ? d.lo_idx : d.left_det;
+    if ((int)blockIdx.x >= kf_blocks) {                       // ---- feature rows
+        const int r = blockIdx.x - kf_blocks;
+        if (r >= n) return;
+        const int xq = xs[r];
+        if (xq < 0) return;
+        const long s = rslot[r], det = cdet[xq];
+        feat::ema_row(d.body_curr + s * d.D, d.body_smooth + s * d.D, d.feats + det * d.D, d.D, d.has_body[s] != 0,
+                      d.ema_a, d.ema_b);
+        if (d.Df)
+            feat::ema_row(d.face_curr + s * d.Df, d.face_smooth + s * d.Df, d.face_feats + det * d.Df, d.Df,
+                          d.has_face[s] != 0, d.ema_a, d.ema_b);
+        if (threadIdx.x == 0) { d.has_body[s] = 1; if (d.Df) d.has_face[s] = 1; }
+        return;
+    }
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;      // ---- Kalman + lifecycle
     if (r >= n) return;
-    const int s = STAGE == 1 ? d.pool_slot[r] : STAGE == 2 ? d.r2_slot[r] : d.unc_slot[r];
-    const int xq = STAGE == 1 ? d.x1[r] : STAGE == 2 ? d.x2[r] : d.x3[r];
+    const int s = rslot[r];
+    const int xq = xs[r];
     if (xq < 0) {
         if (STAGE == 2) { d.state[s] = BTS_LOST; d.flag[s] |= F_LOSTNOW; }                 // D:1582-1586
         if (STAGE == 3) { d.state[s] = BTS_REMOVED; d.flag[s] |= F_REMOVEDNOW; }           // D:1609-1612
         return;
     }
-    const int det = STAGE == 1 ? d.hi_idx[xq] : STAGE == 2 ? d.lo_idx[xq] : d.left_det[xq];
+    const int det = cdet[xq];
     const float z[4] = {d.det_xywh[det * 4 + 0], d.det_xywh[det * 4 + 1], d.det_xywh[det * 4 + 2], d.det_xywh[det * 4 + 3]};
     double m[8], P[64];
     load_state(d, s, m, P);
@@ -270,24 +272,6 @@ __global__ __launch_bounds__(256) void tk_apply_kf(Dev d) {
     d.frame_id[s] = frame;
     d.score[s] = d.scores[det];
     d.det_index[s] = det;
-}
-
-template <int STAGE>
-__global__ __launch_bounds__(256) void tk_apply_feat(Dev d) {
-    const int32_t *h = d.hdr;
-    const int n = STAGE == 1 ? h[H_NPOOL] : STAGE == 2 ? h[H_NR2] : h[H_NUNC];
-    const int r = blockIdx.x;
-    if (r >= n) return;
-    const int xq = STAGE == 1 ? d.x1[r] : STAGE == 2 ? d.x2[r] : d.x3[r];
-    if (xq < 0) return;
-    const long s = STAGE == 1 ? d.pool_slot[r] : STAGE == 2 ? d.r2_slot[r] : d.unc_slot[r];
-    const long det = STAGE == 1 ? d.hi_idx[xq] : STAGE == 2 ? d.lo_idx[xq] : d.left_det[xq];
-    feat::ema_row(d.body_curr + s * d.D, d.body_smooth + s * d.D, d.feats + det * d.D, d.D, d.has_body[s] != 0,
-                  d.ema_a, d.ema_b);
-    if (d.Df)
-        feat::ema_row(d.face_curr + s * d.Df, d.face_smooth + s * d.Df, d.face_feats + det * d.Df, d.Df,
-                      d.has_face[s] != 0, d.ema_a, d.ema_b);
-    if (threadIdx.x == 0) { d.has_body[s] = 1; if (d.Df) d.has_face[s] = 1; }
 }
 
 // ---- after stage 1: rows of stage 2, columns of stage 3 (1 workgroup) ------------------------------------
@@ -372,6 +356,8 @@ __global__ __launch_bounds__(1024) void tk_merge(Dev d) {
     // removed_stracks.extend(removed_now): remember the ids (here: slots) for the next frames
     for (int k = tid; k < nl; k += nth) { const int s = d.lost[k]; if (d.flag[s] & F_REMOVEDNOW) d.in_removed[s] = 1; }
     for (int k = tid; k < nunc; k += nth) { const int s = d.unc_slot[k]; if (d.flag[s] & F_REMOVEDNOW) d.in_removed[s] = 1; }
+    for (int k = tid; k < n_keep + n_b + n_rf; k += nth) d.drop_t[k] = 0;
+    for (int k = tid; k < n_l0 + n_l1; k += nth) d.drop_l[k] = 0;
     if (tid == 0) {
         h[H_NT2] = n_keep + n_b + n_rf;
         h[H_NL2] = n_l0 + n_l1;
@@ -408,27 +394,7 @@ __global__ __launch_bounds__(256) void tk_birth_init(Dev d) {
     }
 }
 
-// ---- duplicate removal between tracked' and lost' (D:1665-1680) -----------------------------------------------
-__global__ __launch_bounds__(256) void tk_list_boxes(Dev d) {
-    const int32_t *h = d.hdr;
-    const int nt = h[H_NT2], nl = h[H_NL2];
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < nt) {
-        const int s = d.tracked2[k];
-        double b[4];
-        slot_tlbr(d, s, b);
-        for (int c = 0; c < 4; ++c) d.tl_tlbr[k * 4 + c] = b[c];
-        d.tl_f32[k] = d.f32[s]; d.tl_age[k] = d.frame_id[s] - d.start_frame[s]; d.drop_t[k] = 0;
-    }
-    if (k < nl) {
-        const int s = d.lost2[k];
-        double b[4];
-        slot_tlbr(d, s, b);
-        for (int c = 0; c < 4; ++c) d.ll_tlbr[k * 4 + c] = b[c];
-        d.ll_f32[k] = d.f32[s]; d.ll_age[k] = d.frame_id[s] - d.start_frame[s]; d.drop_l[k] = 0;
-    }
-}
-
+// ---- duplicate removal between tracked' and lost' (D:1665-1680): boxes straight from the table ------------
 __global__ __launch_bounds__(CT_COLS) void tk_dedupe(Dev d) {
     __shared__ double sa[CT_ROWS][4];
     __shared__ double sarea[CT_ROWS];
@@ -438,20 +404,23 @@ __global__ __launch_bounds__(CT_COLS) void tk_dedupe(Dev d) {
     const int i0 = blockIdx.y * CT_ROWS, j = blockIdx.x * CT_COLS + threadIdx.x;
     if (i0 >= n || blockIdx.x * CT_COLS >= m) return;
     if (threadIdx.x < CT_ROWS && i0 + threadIdx.x < n) {
-        const int i = i0 + threadIdx.x;
-        double box[4] = {d.tl_tlbr[i * 4 + 0], d.tl_tlbr[i * 4 + 1], d.tl_tlbr[i * 4 + 2], d.tl_tlbr[i * 4 + 3]};
-        const bool f = d.tl_f32[i] != 0;
+        const int s = d.tracked2[i0 + threadIdx.x];
+        double box[4];
+        slot_tlbr(d, s, box);
+        const bool f = d.f32[s] != 0;
         for (int c = 0; c < 4; ++c) sa[threadIdx.x][c] = box[c];
         sarea[threadIdx.x] = iou::area(box, f);
         sflag[threadIdx.x] = f;
-        sage[threadIdx.x] = d.tl_age[i];
+        sage[threadIdx.x] = d.frame_id[s] - d.start_frame[s];
     }
     __syncthreads();
     if (j >= m) return;
-    const double bb[4] = {d.ll_tlbr[j * 4 + 0], d.ll_tlbr[j * 4 + 1], d.ll_tlbr[j * 4 + 2], d.ll_tlbr[j * 4 + 3]};
-    const bool bf = d.ll_f32[j] != 0;
+    const int sj = d.lost2[j];
+    double bb[4];
+    slot_tlbr(d, sj, bb);
+    const bool bf = d.f32[sj] != 0;
     const double area_b = iou::area(bb, bf);
-    const int agej = d.ll_age[j];
+    const int agej = d.frame_id[sj] - d.start_frame[sj];
     const int rows = min(CT_ROWS, n - i0);
     bool dropj = false;
     for (int r = 0; r < rows; ++r) {
@@ -554,8 +523,7 @@ static void tracker_layout(bts_tracker *t, char *base, size_t &off) {
     else { d.cost2 = d.cost1; d.cost3 = d.cost1; }
     SLOT(d.x1, int32_t, T); SLOT(d.y1, int32_t, M); SLOT(d.x2, int32_t, T); SLOT(d.y2, int32_t, M);
     SLOT(d.x3, int32_t, T); SLOT(d.y3, int32_t, M);
-    SLOT(d.tl_tlbr, double, 4 * T); SLOT(d.ll_tlbr, double, 4 * T); SLOT(d.tl_f32, uint8_t, T); SLOT(d.ll_f32, uint8_t, T);
-    SLOT(d.drop_t, uint8_t, T); SLOT(d.drop_l, uint8_t, T); SLOT(d.tl_age, int32_t, T); SLOT(d.ll_age, int32_t, T);
+    SLOT(d.drop_t, uint8_t, T); SLOT(d.drop_l, uint8_t, T); SLOT(d.lap_hdr, int32_t, 48);
     SLOT(t->x_ints, int32_t, 8 * T); SLOT(t->x_mean, double, 8 * T); SLOT(t->x_tlbr, double, 4 * T); SLOT(t->x_score, float, T);
 #undef SLOT
 }
@@ -590,6 +558,7 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
     d.prox = cfg->proximity_thresh; d.app = (float)cfg->appearance_thresh; d.dedupe_thr = cfg->dedupe_thresh;
     d.ema_a = (float)cfg->ema_alpha; d.ema_b = (float)(1.0 - cfg->ema_alpha);
     d.max_time_lost = (int)((double)cfg->frame_rate / 30.0 * cfg->track_buffer);    // D:1276-1277
+    d.record = cfg->record_costs ? 1 : 0;
     size_t off = 0;
     tracker_layout(t, nullptr, off);
     const int64_t e_cap = (int64_t)d.T * d.Mx;
@@ -679,10 +648,14 @@ int bts_tracker_step(bts_tracker *t, const int32_t *boxes, const float *scores, 
     Dev d = t->dv;
     d.boxes = boxes; d.scores = scores; d.feats = feats; d.face_feats = face_feats; d.m = m;
     const int T = d.T, M = d.Mx;
+    const int mc = m > 0 ? m : 1;                 // host-known bound on every detection-indexed extent
     const int cos_kernel = t->ctx->cos_kernel;
-    const dim3 cost_grid(bts_cdiv(M, CT_COLS), bts_cdiv(T, CT_ROWS));
+    const dim3 tile_grid(bts_cdiv(mc, CT_COLS), bts_cdiv(T, CT_ROWS));
+    const int kf_blocks = bts_cdiv(T, 256);
+    bts_lap_work lap[3] = {t->lap, t->lap, t->lap};
+    for (int k = 0; k < 3; ++k) lap[k].hdr = d.lap_hdr + 16 * k;
     int rc;
-#define LAUNCH(kern, grid, block) hipLaunchKernelGGL(kern, grid, block, 0, s, d); BTS_LAUNCH_CHECK()
+#define LAUNCH(kern, grid, block, ...) hipLaunchKernelGGL(kern, grid, block, 0, s, d, ##__VA_ARGS__); BTS_LAUNCH_CHECK()
 
     seg_begin(BTS_SEG_STEP);
     seg_begin(BTS_SEG_PREP);
@@ -693,54 +666,50 @@ int bts_tracker_step(bts_tracker *t, const int32_t *boxes, const float *scores, 
     seg_end(BTS_SEG_PREDICT);
     // ---- first association: pool x high-score detections
     seg_begin(BTS_SEG_COS1);
-    rc = bts_cos_enqueue(cos_kernel, d.body_curr, d.pool_slot, d.D, feats, d.hi_idx, d.D, d.D, d.hdr + H_DIMS1, T, M,
+    rc = bts_cos_enqueue(cos_kernel, d.body_curr, d.pool_slot, d.D, feats, d.hi_idx, d.D, d.D, d.hdr + H_DIMS1, T, mc,
                          d.sim, M, s);
     if (rc) return rc;
     seg_end(BTS_SEG_COS1);
     if (d.Df) {
         rc = bts_cos_enqueue(cos_kernel, d.face_curr, d.pool_slot, d.Df, face_feats, d.hi_idx, d.Df, d.Df,
-                             d.hdr + H_DIMS1, T, M, d.fsim, M, s);
+                             d.hdr + H_DIMS1, T, mc, d.fsim, M, s);
         if (rc) return rc;
     }
     seg_begin(BTS_SEG_COST1);
-    LAUNCH(tk_cost<1>, cost_grid, dim3(CT_COLS));
+    LAUNCH(tk_edges<1>, tile_grid, dim3(CT_COLS), lap[0]);
     seg_end(BTS_SEG_COST1);
     seg_begin(BTS_SEG_LAP1);
-    rc = bts_lap_enqueue_dense(&t->lap, d.cost1, M, d.hdr + H_DIMS1, T, M, d.match1, d.x1, d.y1, s);
+    rc = bts_lap_enqueue_edges(&lap[0], d.hdr + H_DIMS1, T, mc, d.match1, d.x1, d.y1, s);
     if (rc) return rc;
     seg_end(BTS_SEG_LAP1);
     seg_begin(BTS_SEG_APPLY1);
-    LAUNCH(tk_renorm, dim3(M), dim3(256));
-    LAUNCH(tk_after1, dim3(1), dim3(1024));          // reads pre-update states: before tk_apply_kf<1>
-    LAUNCH(tk_apply_kf<1>, dim3(bts_cdiv(T, 256)), dim3(256));
-    LAUNCH(tk_apply_feat<1>, dim3(T), dim3(256));
+    LAUNCH(tk_renorm, dim3(mc), dim3(256));
+    LAUNCH(tk_after1, dim3(1), dim3(1024));          // reads pre-update states: before tk_apply<1>
+    LAUNCH(tk_apply<1>, dim3(kf_blocks + T), dim3(256), kf_blocks);
     seg_end(BTS_SEG_APPLY1);
     // ---- second association: remaining tracked rows x low-score detections
     seg_begin(BTS_SEG_STAGE2);
-    LAUNCH(tk_cost<2>, cost_grid, dim3(CT_COLS));
-    rc = bts_lap_enqueue_dense(&t->lap, d.cost2, M, d.hdr + H_DIMS2, T, M, d.match2, d.x2, d.y2, s);
+    LAUNCH(tk_edges<2>, tile_grid, dim3(CT_COLS), lap[1]);
+    rc = bts_lap_enqueue_edges(&lap[1], d.hdr + H_DIMS2, T, mc, d.match2, d.x2, d.y2, s);
     if (rc) return rc;
-    LAUNCH(tk_apply_kf<2>, dim3(bts_cdiv(T, 256)), dim3(256));
-    LAUNCH(tk_apply_feat<2>, dim3(T), dim3(256));
+    LAUNCH(tk_apply<2>, dim3(kf_blocks + T), dim3(256), kf_blocks);
     seg_end(BTS_SEG_STAGE2);
     // ---- unconfirmed tracks x leftover high-score detections
     seg_begin(BTS_SEG_STAGE3);
-    rc = bts_cos_enqueue(cos_kernel, d.body_curr, d.unc_slot, d.D, feats, d.left_det, d.D, d.D, d.hdr + H_DIMS3, T, M,
+    rc = bts_cos_enqueue(cos_kernel, d.body_curr, d.unc_slot, d.D, feats, d.left_det, d.D, d.D, d.hdr + H_DIMS3, T, mc,
                          d.sim, M, s);
     if (rc) return rc;
-    LAUNCH(tk_cost<3>, cost_grid, dim3(CT_COLS));
-    rc = bts_lap_enqueue_dense(&t->lap, d.cost3, M, d.hdr + H_DIMS3, T, M, d.match3, d.x3, d.y3, s);
+    LAUNCH(tk_edges<3>, tile_grid, dim3(CT_COLS), lap[2]);
+    rc = bts_lap_enqueue_edges(&lap[2], d.hdr + H_DIMS3, T, mc, d.match3, d.x3, d.y3, s);
     if (rc) return rc;
-    LAUNCH(tk_apply_kf<3>, dim3(bts_cdiv(T, 256)), dim3(256));
-    LAUNCH(tk_apply_feat<3>, dim3(T), dim3(256));
+    LAUNCH(tk_apply<3>, dim3(kf_blocks + T), dim3(256), kf_blocks);
     seg_end(BTS_SEG_STAGE3);
     // ---- births, list merge, duplicate removal
     seg_begin(BTS_SEG_MERGE);
     LAUNCH(tk_merge, dim3(1), dim3(1024));
-    LAUNCH(tk_birth_init, dim3(M), dim3(256));
+    LAUNCH(tk_birth_init, dim3(mc), dim3(256));
     seg_end(BTS_SEG_MERGE);
     seg_begin(BTS_SEG_DEDUPE);
-    LAUNCH(tk_list_boxes, dim3(bts_cdiv(T, 256)), dim3(256));
     LAUNCH(tk_dedupe, dim3(bts_cdiv(T, CT_COLS), bts_cdiv(T, CT_ROWS)), dim3(CT_COLS));
     LAUNCH(tk_finalize, dim3(1), dim3(1024));
     seg_end(BTS_SEG_DEDUPE);
