@@ -82,6 +82,7 @@ struct bts_lap_work {
     int32_t *csr_col = nullptr;  // [e_cap]
     double *csr_cost = nullptr;  // [e_cap]
     int32_t *parent = nullptr;   // [n_cap+m_cap] union-find forest (when it does not fit LDS)
+    int32_t *rootv = nullptr;    // [n_cap+m_cap] root of every node, written after all unions are done
     int32_t *comp_of = nullptr;  // [n_cap] component id of a root row
     int32_t *crow_ptr = nullptr; // [n_cap+1]
     int32_t *ccol_ptr = nullptr; // [n_cap+1]

@@ -67,4 +67,39 @@ __device__ __forceinline__ void ema_row(float *curr, float *smooth, const float 
     }
 }
 
+// ---- float16 shadow rows for the appearance pre-filter -----------------------------------------------
+// h[k] = half(256 * f[k]) (the power-of-two scale keeps small components of a unit vector out of the
+// float16 subnormal range; it is undone exactly on the accumulated dot product), *norm = ||f||_2.
+constexpr float HALF_SCALE = 256.0f;
+constexpr float HALF_UNSCALE = 1.0f / (256.0f * 256.0f);
+
+__device__ __forceinline__ void to_half_row(const float *f, _Float16 *h, float *norm, int d) {
+    float ss = 0.0f;
+    for (int k = threadIdx.x; k < d; k += blockDim.x) {
+        const float v = f[k];
+        ss += v * v;
+        h[k] = (_Float16)(v * HALF_SCALE);
+    }
+    const float tot = block_sum(ss);
+    if (threadIdx.x == 0) *norm = sqrtf(tot);
+}
+
+// <a, b> over d floats by one wavefront, every lane gets the result.  Fixed evaluation order
+// (lane-strided fma chains, then an xor butterfly), so the value is reproducible.
+__device__ __forceinline__ float wave_dot(const float *a, const float *b, int d, int lane) {
+    float acc = 0.0f;
+    if (vec4_ok(a, d) && vec4_ok(b, d)) {
+        const float4 *a4 = reinterpret_cast<const float4 *>(a), *b4 = reinterpret_cast<const float4 *>(b);
+        for (int k = lane; k < d / 4; k += 64) {
+            const float4 x = a4[k], y = b4[k];
+            acc = fmaf(x.x, y.x, acc); acc = fmaf(x.y, y.y, acc); acc = fmaf(x.z, y.z, acc); acc = fmaf(x.w, y.w, acc);
+        }
+    } else {
+        for (int k = lane; k < d; k += 64) acc = fmaf(a[k], b[k], acc);
+    }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) acc += __shfl_xor(acc, off);
+    return acc;
+}
+
 }  // namespace feat

@@ -24,7 +24,11 @@ namespace {
 
 enum { H_EDGES = 0, H_COMPS = 1, H_ERR = 2, H_HARD = 3 };   // hdr: edges, components, overflow flag, components for k_solve
 
+// Every word of the work area that is the target of an atomic (or is read back after atomics) is
+// accessed ONLY with agent-scope atomics: a plain store that is still on its way to L2 can land
+// after atomics issued behind a later barrier and wipe them out (observed: lost increments).
 #define RLX(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define RST(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 
 struct LapArgs {
     bts_lap_work w;
@@ -81,6 +85,14 @@ __device__ int find_root(int32_t *parent, int x) {
     return x;
 }
 
+// read-only walk to the root: used once every union is done, so that what it returns is final
+// (a compressing find running next to it could still move parent[] entries to non-root ancestors)
+__device__ int find_root_ro(const int32_t *parent, int x) {
+    int p = RLX(&parent[x]);
+    while (p != x) { x = p; p = RLX(&parent[x]); }
+    return x;
+}
+
 __device__ void unite(int32_t *parent, int a, int b) {
     int ra = find_root(parent, a), rb = find_root(parent, b);
     while (ra != rb) {
@@ -101,7 +113,7 @@ __device__ int block_exscan(int32_t *arr, int len, int32_t *tmp) {
     for (int k = lo; k < hi; ++k) s += RLX(&arr[k]);
     int total;
     int run = bscan::exscan(s, tmp, &total);
-    for (int k = lo; k < hi; ++k) { const int v = RLX(&arr[k]); arr[k] = run; run += v; }
+    for (int k = lo; k < hi; ++k) { const int v = RLX(&arr[k]); RST(&arr[k], run); run += v; }
     __syncthreads();
     return total;
 }
@@ -115,14 +127,14 @@ __global__ __launch_bounds__(1024) void k_prepare(LapArgs A) {
     if ((long)E > w.e_cap) E = (int)w.e_cap;
 
     if (E == 0) {                               // nothing feasible: everything stays unmatched
-        for (int i = tid; i < n; i += nth) A.x[i] = -1;
-        for (int j = tid; j < m; j += nth) A.y[j] = -1;
-        if (tid == 0) { w.hdr[H_COMPS] = 0; w.hdr[H_HARD] = 0; }
+        for (int i = tid; i < n; i += nth) RST(&A.x[i], -1);
+        for (int j = tid; j < m; j += nth) RST(&A.y[j], -1);
+        if (tid == 0) { RST(&w.hdr[H_COMPS], 0); RST(&w.hdr[H_HARD], 0); }
         return;
     }
-    for (int i = tid; i < n; i += nth) { w.deg[i] = 0; w.parent[i] = i; A.x[i] = -1; }
-    for (int j = tid; j < m; j += nth) { w.cdeg[j] = 0; w.parent[n + j] = n + j; A.y[j] = -1; w.v[j] = 0.0; }
-    if (tid == 0) w.hdr[H_HARD] = 0;
+    for (int i = tid; i < n; i += nth) { RST(&w.deg[i], 0); RST(&w.parent[i], i); RST(&A.x[i], -1); }
+    for (int j = tid; j < m; j += nth) { RST(&w.cdeg[j], 0); RST(&w.parent[n + j], n + j); RST(&A.y[j], -1); RST(&w.v[j], 0.0); }
+    if (tid == 0) RST(&w.hdr[H_HARD], 0);
     __syncthreads();
     for (int e = tid; e < E; e += nth) {
         const int i = w.e_row[e], j = w.e_col[e];
@@ -131,45 +143,45 @@ __global__ __launch_bounds__(1024) void k_prepare(LapArgs A) {
         unite(w.parent, i, n + j);
     }
     __syncthreads();
-    // flatten: every active node points at its root (a row: rows have the smaller node ids)
+    // roots of all active nodes (a row: rows have the smaller node ids); read-only walks
     for (int i = tid; i < n; i += nth)
-        if (RLX(&w.deg[i]) > 0) { const int r = find_root(w.parent, i); __hip_atomic_store(&w.parent[i], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        if (RLX(&w.deg[i]) > 0) RST(&w.rootv[i], find_root_ro(w.parent, i));
     for (int j = tid; j < m; j += nth)
-        if (RLX(&w.cdeg[j]) > 0) { const int r = find_root(w.parent, n + j); __hip_atomic_store(&w.parent[n + j], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        if (RLX(&w.cdeg[j]) > 0) RST(&w.rootv[n + j], find_root_ro(w.parent, n + j));
     __syncthreads();
     // CSR row pointers
-    for (int i = tid; i < n; i += nth) w.rptr[i] = RLX(&w.deg[i]);
+    for (int i = tid; i < n; i += nth) RST(&w.rptr[i], RLX(&w.deg[i]));
     __syncthreads();
     block_exscan(w.rptr, n, tmp);
-    if (tid == 0) w.rptr[n] = E;
-    for (int i = tid; i < n; i += nth) w.cursor[i] = RLX(&w.rptr[i]);
+    if (tid == 0) RST(&w.rptr[n], E);
+    for (int i = tid; i < n; i += nth) RST(&w.cursor[i], RLX(&w.rptr[i]));
     // component ids: rank of each root row among the roots
-    for (int i = tid; i < n; i += nth) w.comp_of[i] = (RLX(&w.deg[i]) > 0 && RLX(&w.parent[i]) == i) ? 1 : 0;
+    for (int i = tid; i < n; i += nth) RST(&w.comp_of[i], (RLX(&w.deg[i]) > 0 && RLX(&w.rootv[i]) == i) ? 1 : 0);
     __syncthreads();
     const int C = block_exscan(w.comp_of, n, tmp);
-    if (tid == 0) w.hdr[H_COMPS] = C;
+    if (tid == 0) RST(&w.hdr[H_COMPS], C);
     // component sizes -> pointers
-    for (int c = tid; c <= C; c += nth) { w.crow_ptr[c] = 0; w.ccol_ptr[c] = 0; }
+    for (int c = tid; c <= C; c += nth) { RST(&w.crow_ptr[c], 0); RST(&w.ccol_ptr[c], 0); }
     __syncthreads();
     for (int i = tid; i < n; i += nth)
-        if (RLX(&w.deg[i]) > 0) atomicAdd(&w.crow_ptr[RLX(&w.comp_of[RLX(&w.parent[i])])], 1);
+        if (RLX(&w.deg[i]) > 0) atomicAdd(&w.crow_ptr[RLX(&w.comp_of[RLX(&w.rootv[i])])], 1);
     for (int j = tid; j < m; j += nth)
-        if (RLX(&w.cdeg[j]) > 0) atomicAdd(&w.ccol_ptr[RLX(&w.comp_of[RLX(&w.parent[n + j])])], 1);
+        if (RLX(&w.cdeg[j]) > 0) atomicAdd(&w.ccol_ptr[RLX(&w.comp_of[RLX(&w.rootv[n + j])])], 1);
     __syncthreads();
     block_exscan(w.crow_ptr, C + 1, tmp);
     block_exscan(w.ccol_ptr, C + 1, tmp);
-    for (int c = tid; c < C; c += nth) { w.ccur_r[c] = RLX(&w.crow_ptr[c]); w.ccur_c[c] = RLX(&w.ccol_ptr[c]); }
+    for (int c = tid; c < C; c += nth) { RST(&w.ccur_r[c], RLX(&w.crow_ptr[c])); RST(&w.ccur_c[c], RLX(&w.ccol_ptr[c])); }
     __syncthreads();
     // fills
     for (int e = tid; e < E; e += nth) {
         const int pos = atomicAdd(&w.cursor[w.e_row[e]], 1);
-        w.csr_col[pos] = w.e_col[e];
-        w.csr_cost[pos] = w.e_cost[e];
+        RST(&w.csr_col[pos], w.e_col[e]);
+        RST(&w.csr_cost[pos], w.e_cost[e]);
     }
     for (int i = tid; i < n; i += nth)
-        if (RLX(&w.deg[i]) > 0) w.crows[atomicAdd(&w.ccur_r[RLX(&w.comp_of[RLX(&w.parent[i])])], 1)] = i;
+        if (RLX(&w.deg[i]) > 0) RST(&w.crows[atomicAdd(&w.ccur_r[RLX(&w.comp_of[RLX(&w.rootv[i])])], 1)], i);
     for (int j = tid; j < m; j += nth)
-        if (RLX(&w.cdeg[j]) > 0) w.ccols[atomicAdd(&w.ccur_c[RLX(&w.comp_of[RLX(&w.parent[n + j])])], 1)] = j;
+        if (RLX(&w.cdeg[j]) > 0) RST(&w.ccols[atomicAdd(&w.ccur_c[RLX(&w.comp_of[RLX(&w.rootv[n + j])])], 1)], j);
     __syncthreads();
     // A component of one row and one column (by far the common case in a tracking frame) is
     // decided here: any feasible edge beats two dummies (cost <= limit), ties prefer the match.
@@ -179,65 +191,192 @@ __global__ __launch_bounds__(1024) void k_prepare(LapArgs A) {
         const int cs = RLX(&w.ccol_ptr[c]), cn = RLX(&w.ccol_ptr[c + 1]) - cs;
         if (r == 1 && cn == 1) {
             const int i = RLX(&w.crows[rs]), j = RLX(&w.ccols[cs]);
-            A.x[i] = j; A.y[j] = i;
+            RST(&A.x[i], j); RST(&A.y[j], i);
         } else {
-            w.comp_list[atomicAdd(&w.hdr[H_HARD], 1)] = c;
+            RST(&w.comp_list[atomicAdd(&w.hdr[H_HARD], 1)], c);
         }
     }
 }
 
 // ---- 3. one wavefront per component: shortest augmenting paths ----------------------------------
+// Lanes of the wave exchange state through memory that the same wave wrote earlier in the kernel.
+// Such accesses go straight to L2 (relaxed agent-scope atomics = sc1 loads / write-through stores):
+// a plain load may be served from a vector-L1 line that predates the store.
+#define LDG(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define STG(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+
+// order LDS traffic between lanes of one wavefront (DS operations of a wave execute in order; this
+// only stops the compiler from moving accesses across the hand-off)
+__device__ __forceinline__ void lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+constexpr int SM_EDGES = 512;      // edge budget of the register/LDS solver, per wavefront
+struct SmallLds {
+    double ecost[SM_EDGES];
+    int32_t ecol[SM_EDGES];
+    int32_t rstart[65];
+    int32_t rows[64];
+};
+
+// Components with <= 64 rows, <= 64 columns and <= SM_EDGES edges (all but pathological crowd
+// clusters): lane k owns local row k (u, its column) AND local column k (v, owner, distance,
+// predecessor, scanned); the adjacency sits in LDS; every step of the Dijkstra search is a handful
+// of __shfl / ds_bpermute operations -- no global memory inside the search.
+__device__ bool solve_small(const LapArgs &A, int c, int lane, SmallLds &L) {
+    const bts_lap_work &w = A.w;
+    const double limit = A.limit, INF = __builtin_huge_val();
+    const int rs = LDG(&w.crow_ptr[c]), r = LDG(&w.crow_ptr[c + 1]) - rs;
+    const int cs = LDG(&w.ccol_ptr[c]), cn = LDG(&w.ccol_ptr[c + 1]) - cs;
+    if (r > 64 || cn > 64) return false;
+    // rows ascending (grouping appended them in arbitrary order)
+    int my_row = lane < r ? LDG(&w.crows[rs + lane]) : 0x7fffffff;
+    {
+        int rank = 0;
+        for (int q = 0; q < r; ++q) rank += __shfl(my_row, q) < my_row ? 1 : 0;
+        if (lane < r) L.rows[rank] = my_row;
+        lds_sync();
+        my_row = lane < r ? L.rows[lane] : -1;
+    }
+    const int my_col = lane < cn ? LDG(&w.ccols[cs + lane]) : 0x7fffffff;
+    // local CSR
+    const int e_lo = lane < r ? LDG(&w.rptr[my_row]) : 0, deg = lane < r ? LDG(&w.rptr[my_row + 1]) - e_lo : 0;
+    int incl = deg;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+    const int etot = __shfl(incl, 63);
+    if (etot > SM_EDGES) return false;
+    L.rstart[lane] = incl - deg;
+    if (lane == 63) L.rstart[64] = etot;
+    if (lane < cn) STG(&w.pred[my_col], lane);          // global column id -> local lane (scratch reuse)
+    wave_sync();
+    double u = limit;
+    for (int e = 0; e < deg; ++e) {
+        const double cc = LDG(&w.csr_cost[e_lo + e]);
+        L.ecost[incl - deg + e] = cc;
+        L.ecol[incl - deg + e] = LDG(&w.pred[LDG(&w.csr_col[e_lo + e])]);
+        u = fmin(u, cc);
+    }
+    lds_sync();
+    int xr = -1, yc = -1;       // row -> local column, column -> local row
+    double v = 0.0;
+    for (int i0 = 0; i0 < r; ++i0) {
+        double dist = INF;
+        int pred = -1;
+        bool scanned = false;
+        double exit_d = limit - __shfl(u, i0);
+        int exit_row = i0, cur = i0, end_col = -1;
+        double dcur = 0.0, mu = 0.0;
+        for (;;) {
+            const double ucur = __shfl(u, cur);
+            const int e0 = L.rstart[cur], e1 = L.rstart[cur + 1];
+            for (int e = e0; e < e1; ++e) {
+                if (L.ecol[e] == lane && !scanned) {
+                    const double nd = dcur + ((L.ecost[e] - ucur) - v);
+                    if (nd < dist) { dist = nd; pred = cur; }
+                }
+            }
+            double bd = (lane < cn && !scanned) ? dist : INF;
+            int bcol = my_col, bl = lane;
+#pragma unroll
+            for (int off = 32; off; off >>= 1) {
+                const double od = __shfl_xor(bd, off);
+                const int oc = __shfl_xor(bcol, off), ol = __shfl_xor(bl, off);
+                if (od < bd || (od == bd && oc < bcol)) { bd = od; bcol = oc; bl = ol; }
+            }
+            if (!(bd < INF) || exit_d < bd) { mu = exit_d; break; }
+            const int owner = __shfl(yc, bl);
+            if (owner < 0) { mu = bd; end_col = bl; break; }
+            if (lane == bl) scanned = true;
+            cur = owner; dcur = bd;
+            const double e2 = bd + (limit - __shfl(u, owner));
+            if (e2 < exit_d) { exit_d = e2; exit_row = owner; }
+        }
+        // duals: every scanned column hands its delta to the row that owns it
+        const double delta = scanned ? mu - dist : 0.0;
+        if (scanned) v -= delta;
+        const double dfrom = __shfl(delta, xr >= 0 ? xr : 0);
+        if (xr >= 0) u += dfrom;
+        if (lane == i0) u += mu;
+        // augment
+        int j = end_col;
+        if (j < 0) {
+            if (exit_row == i0) continue;
+            j = __shfl(xr, exit_row);
+            if (lane == exit_row) xr = -1;
+        }
+        for (;;) {
+            const int i = __shfl(pred, j);
+            const int jn = __shfl(xr, i);
+            if (lane == i) xr = j;
+            if (lane == j) yc = i;
+            if (i == i0) break;
+            j = jn;
+        }
+    }
+    const int xcol = __shfl(my_col, xr >= 0 ? xr : 0), yrow = __shfl(my_row, yc >= 0 ? yc : 0);
+    if (lane < r) A.x[my_row] = xr >= 0 ? xcol : -1;
+    if (lane < cn) A.y[my_col] = yc >= 0 ? yrow : -1;
+    return true;
+}
+
+// General path (any component size): state in global memory.
 __device__ void solve_component(const LapArgs &A, int c, int lane) {
     const bts_lap_work &w = A.w;
     const double limit = A.limit;
     const double INF = __builtin_huge_val();
     int32_t *x = A.x, *y = A.y;
-    const int rs = w.crow_ptr[c], r = w.crow_ptr[c + 1] - rs;
-    const int cs = w.ccol_ptr[c], cn = w.ccol_ptr[c + 1] - cs;
+    const int rs = LDG(&w.crow_ptr[c]), r = LDG(&w.crow_ptr[c + 1]) - rs;
+    const int cs = LDG(&w.ccol_ptr[c]), cn = LDG(&w.ccol_ptr[c + 1]) - cs;
 
     // rows in ascending order (the grouping pass appended them in arbitrary order)
     for (int k = lane; k < r; k += 64) {
-        const int mine = w.crows[rs + k];
+        const int mine = LDG(&w.crows[rs + k]);
         int rank = 0;
-        for (int q = 0; q < r; ++q) rank += w.crows[rs + q] < mine;
-        w.crows_s[rs + rank] = mine;
+        for (int q = 0; q < r; ++q) rank += LDG(&w.crows[rs + q]) < mine;
+        STG(&w.crows_s[rs + rank], mine);
     }
     wave_sync();
     // row duals start at the row minimum (<= limit): all reduced costs >= 0, exits >= 0
     for (int k = lane; k < r; k += 64) {
-        const int i = w.crows_s[rs + k];
+        const int i = LDG(&w.crows_s[rs + k]);
         double mn = limit;
-        for (int e = w.rptr[i]; e < w.rptr[i + 1]; ++e) mn = fmin(mn, w.csr_cost[e]);
-        w.u[i] = mn;
+        for (int e = LDG(&w.rptr[i]); e < LDG(&w.rptr[i + 1]); ++e) mn = fmin(mn, LDG(&w.csr_cost[e]));
+        STG(&w.u[i], mn);
+    }
+    for (int k = lane; k < cn; k += 64) STG(&w.v[LDG(&w.ccols[cs + k])], 0.0);
+        for (int k = lane; k < r; k += 64) STG(&x[LDG(&w.crows[rs + k])], -1);
+        for (int k = lane; k < cn; k += 64) STG(&y[LDG(&w.ccols[cs + k])], -1);
     }
     wave_sync();
 
     for (int t = 0; t < r; ++t) {
-        const int i0 = w.crows_s[rs + t];
-        for (int k = lane; k < cn; k += 64) { const int j = w.ccols[cs + k]; w.dist[j] = INF; w.scanned[j] = 0; }
+        const int i0 = LDG(&w.crows_s[rs + t]);
+        for (int k = lane; k < cn; k += 64) { const int j = LDG(&w.ccols[cs + k]); STG(&w.dist[j], INF); STG(&w.scanned[j], 0); }
         wave_sync();
-        double exit_d = limit - w.u[i0];   // leave i0 unmatched
+        double exit_d = limit - LDG(&w.u[i0]);   // leave i0 unmatched
         int exit_row = i0;
         int cur = i0;
         double dcur = 0.0, mu = 0.0;
         int end_col = -1;                  // >= 0: path ends at this free column
         for (;;) {
-            const double ucur = w.u[cur];
-            const int e1 = w.rptr[cur + 1];
-            for (int e = w.rptr[cur] + lane; e < e1; e += 64) {
-                const int j = w.csr_col[e];
-                if (!w.scanned[j]) {
-                    const double nd = dcur + ((w.csr_cost[e] - ucur) - w.v[j]);
-                    if (nd < w.dist[j]) { w.dist[j] = nd; w.pred[j] = cur; }
+            const double ucur = LDG(&w.u[cur]);
+            const int e1 = LDG(&w.rptr[cur + 1]);
+            for (int e = LDG(&w.rptr[cur]) + lane; e < e1; e += 64) {
+                const int j = LDG(&w.csr_col[e]);
+                if (!LDG(&w.scanned[j])) {
+                    const double nd = dcur + ((LDG(&w.csr_cost[e]) - ucur) - LDG(&w.v[j]));
+                    if (nd < LDG(&w.dist[j])) { STG(&w.dist[j], nd); STG(&w.pred[j], cur); }
                 }
             }
             wave_sync();
             double bd = INF;
             int bj = 0x7fffffff;
             for (int k = lane; k < cn; k += 64) {
-                const int j = w.ccols[cs + k];
-                if (!w.scanned[j]) {
-                    const double dj = w.dist[j];
+                const int j = LDG(&w.ccols[cs + k]);
+                if (!LDG(&w.scanned[j])) {
+                    const double dj = LDG(&w.dist[j]);
                     if (dj < bd || (dj == bd && j < bj)) { bd = dj; bj = j; }
                 }
             }
@@ -248,37 +387,40 @@ __device__ void solve_component(const LapArgs &A, int c, int lane) {
                 if (od < bd || (od == bd && oj < bj)) { bd = od; bj = oj; }
             }
             if (!(bd < INF) || exit_d < bd) { mu = exit_d; break; }
-            const int owner = y[bj];
+            const int owner = LDG(&y[bj]);
             if (owner < 0) { mu = bd; end_col = bj; break; }
-            if (lane == 0) w.scanned[bj] = 1;
+            if (lane == 0) STG(&w.scanned[bj], 1);
             wave_sync();
             cur = owner; dcur = bd;
-            const double e2 = bd + (limit - w.u[owner]);
+            const double e2 = bd + (limit - LDG(&w.u[owner]));
             if (e2 < exit_d) { exit_d = e2; exit_row = owner; }
         }
         // dual update (before the matching changes: y[] still names the tree rows)
         for (int k = lane; k < cn; k += 64) {
-            const int j = w.ccols[cs + k];
-            if (w.scanned[j]) {
-                const double delta = mu - w.dist[j];
-                w.u[y[j]] += delta;
-                w.v[j] -= delta;
+            const int j = LDG(&w.ccols[cs + k]);
+            if (LDG(&w.scanned[j])) {
+                const double delta = mu - LDG(&w.dist[j]);
+                const int own = LDG(&y[j]);
+                STG(&w.u[own], LDG(&w.u[own]) + delta);
+                STG(&w.v[j], LDG(&w.v[j]) - delta);
             }
         }
-        if (lane == 0) w.u[i0] += mu;
+        wave_sync();
+        if (lane == 0) STG(&w.u[i0], LDG(&w.u[i0]) + mu);
         wave_sync();
         // augment
         int j = end_col;
         if (j < 0) {
             if (exit_row == i0) continue;     // i0 stays unmatched
-            j = x[exit_row];
-            if (lane == 0) x[exit_row] = -1;
+            j = LDG(&x[exit_row]);
+            wave_sync();
+            if (lane == 0) STG(&x[exit_row], -1);
         }
         for (;;) {
-            const int i = w.pred[j];
-            const int jn = x[i];
+            const int i = LDG(&w.pred[j]);
+            const int jn = LDG(&x[i]);
             wave_sync();
-            if (lane == 0) { x[i] = j; y[j] = i; }
+            if (lane == 0) { STG(&x[i], j); STG(&y[j], i); }
             if (i == i0) break;
             j = jn;
         }
@@ -287,10 +429,14 @@ __device__ void solve_component(const LapArgs &A, int c, int lane) {
 }
 
 __global__ __launch_bounds__(256) void k_solve(LapArgs A) {
-    const int C = A.w.hdr[H_HARD];
+    __shared__ SmallLds lds[4];
+    const int C = LDG(&A.w.hdr[H_HARD]);
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwave = (gridDim.x * blockDim.x) >> 6;
-    for (int q = wave; q < C; q += nwave) solve_component(A, A.w.comp_list[q], lane);
+    for (int q = wave; q < C; q += nwave) {
+        const int c = LDG(&A.w.comp_list[q]);
+        if (!solve_small(A, c, lane, lds[threadIdx.x >> 6])) solve_component(A, c, lane);
+    }
 }
 
 }  // namespace
@@ -304,7 +450,7 @@ static void layout(bts_lap_work *w, char *base, size_t &off, int n, int m, int64
     SLOT(e_row, int32_t, e); SLOT(e_col, int32_t, e); SLOT(e_cost, double, e);
     SLOT(deg, int32_t, n); SLOT(cdeg, int32_t, m); SLOT(rptr, int32_t, n + 1); SLOT(cursor, int32_t, n);
     SLOT(csr_col, int32_t, e); SLOT(csr_cost, double, e);
-    SLOT(parent, int32_t, n + m); SLOT(comp_of, int32_t, n);
+    SLOT(parent, int32_t, n + m); SLOT(rootv, int32_t, n + m); SLOT(comp_of, int32_t, n);
     SLOT(crow_ptr, int32_t, n + 1); SLOT(ccol_ptr, int32_t, n + 1);
     SLOT(ccur_r, int32_t, n + 1); SLOT(ccur_c, int32_t, n + 1);
     SLOT(crows, int32_t, n); SLOT(crows_s, int32_t, n); SLOT(ccols, int32_t, m); SLOT(comp_list, int32_t, n);

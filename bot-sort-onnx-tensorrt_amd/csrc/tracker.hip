@@ -52,6 +52,11 @@ struct Dev {
     uint8_t *drop_t, *drop_l;
     int32_t *lap_hdr;          // 3 x 16 ints: per-stage counters of the assignment solver
     int record;                // keep dense cost matrices (tests / inspection)
+    int filter;                // appearance term by float16-MFMA pre-filter + exact float32 refine
+    _Float16 *body_h, *face_h, *det_h, *dface_h;      // float16 shadows of body_curr/face_curr and of the frame's rows
+    float *body_n, *face_n, *det_n, *dface_n;         // their float32 L2 norms
+    float *approx;                                     // [T][Mx] split-K accumulation of the pre-filter (self-cleaning)
+    float eps_body, eps_face;                          // relative error bounds of the float16 dot products
     // inputs of the current step
     const int32_t *boxes;
     const float *scores;
@@ -130,7 +135,16 @@ __global__ __launch_bounds__(1024) void tk_prep(Dev d) {
 }
 
 // ---- K2: STrack.multi_predict over the pool (D:524-536 + D:265-302) ---------------------------------
-__global__ __launch_bounds__(256) void tk_predict(Dev d) {
+// Workgroups past the first `pred_blocks` turn this frame's (raw) detection rows into float16
+// shadows + norms for the appearance pre-filter: independent work sharing one launch.
+__global__ __launch_bounds__(256) void tk_predict(Dev d, int pred_blocks) {
+    if ((int)blockIdx.x >= pred_blocks) {
+        const long j = blockIdx.x - pred_blocks;
+        if (j >= d.m) return;
+        feat::to_half_row(d.feats + j * d.D, d.det_h + j * d.D, d.det_n + j, d.D);
+        if (d.Df) feat::to_half_row(d.face_feats + j * d.Df, d.dface_h + j * d.Df, d.dface_n + j, d.Df);
+        return;
+    }
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= d.hdr[H_NPOOL]) return;
     const int s = d.pool_slot[r];
@@ -159,7 +173,11 @@ __device__ __forceinline__ float face_fixup(float s) {
 // The same tile also feeds the assignment solver directly: every entry <= the stage's match
 // threshold is appended to the solver's edge list (entries above it can never be matched), so the
 // dense matrix is only written when cost recording is on.
-template <int STAGE>
+// MODE 0: fused dense form (similarities read from the dense float32 matrix), emits edges.
+// MODE 1: pre-filter form -- stage 1 emits the IoU edges only (appearance edges come from
+//         k_filter); stage 3 refines the few overlapping pairs with an exact wavefront dot product.
+// MODE 2: record only (dense cost matrix for inspection, no edges).
+template <int STAGE, int MODE>
 __global__ __launch_bounds__(CT_COLS) void tk_edges(Dev d, bts_lap_work w) {
     __shared__ double sa[CT_ROWS][4];
     __shared__ double sarea[CT_ROWS];
@@ -179,17 +197,42 @@ __global__ __launch_bounds__(CT_COLS) void tk_edges(Dev d, bts_lap_work w) {
         sflag[threadIdx.x] = f;
     }
     __syncthreads();
-    if (q >= m) return;
-    const int det = STAGE == 1 ? d.hi_idx[q] : STAGE == 2 ? d.lo_idx[q] : d.left_det[q];
+    const bool live = q < m;
+    const int det = !live ? 0 : STAGE == 1 ? d.hi_idx[q] : STAGE == 2 ? d.lo_idx[q] : d.left_det[q];
     const double bb[4] = {d.det_tlbr[det * 4 + 0], d.det_tlbr[det * 4 + 1], d.det_tlbr[det * 4 + 2], d.det_tlbr[det * 4 + 3]};
     const double area_b = iou::area(bb, true);
     double *cost = STAGE == 1 ? d.cost1 : STAGE == 2 ? d.cost2 : d.cost3;
     const double limit = STAGE == 1 ? d.match1 : STAGE == 2 ? d.match2 : d.match3;
     const int rows = min(CT_ROWS, n - i0);
+    const int lane = threadIdx.x & 63;
+    auto emit = [&](int row, double c) {
+        const int pos = atomicAdd(&w.hdr[0], 1);
+        if (pos < w.e_cap) { w.e_row[pos] = row; w.e_col[pos] = q; w.e_cost[pos] = c; }
+        else w.hdr[2] = 1;
+    };
     for (int r = 0; r < rows; ++r) {
         const double aa[4] = {sa[r][0], sa[r][1], sa[r][2], sa[r][3]};
         const double iou_d = iou::cost(aa, sflag[r] != 0, sarea[r], bb, true, area_b);
         const long o = (long)(i0 + r) * d.Mx + q;
+        if (MODE == 1) {
+            if (live && iou_d <= limit) emit(i0 + r, iou_d);
+            if (STAGE == 3) {
+                // appearance can only lower the cost where the proximity gate is open (D:1600-1601):
+                // those few pairs get an exact float32 dot product computed by the whole wavefront
+                unsigned long long todo = __ballot(live && iou_d <= d.prox);
+                while (todo) {
+                    const int src = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
+                    const long sdet = __shfl(det, src);
+                    const long strk = d.unc_slot[i0 + r];
+                    const float sim = fmaxf(0.0f, feat::wave_dot(d.body_curr + strk * d.D, d.feats + sdet * d.D, d.D, lane));
+                    const float emb = 1.0f - sim;
+                    if (lane == src && !(emb > d.app) && (double)emb <= limit) emit(i0 + r, (double)emb);
+                }
+            }
+            continue;
+        }
+        if (!live) continue;
         double c = iou_d;
         if (STAGE == 1) {
             float emb = 1.0f - d.sim[o];
@@ -202,11 +245,186 @@ __global__ __launch_bounds__(CT_COLS) void tk_edges(Dev d, bts_lap_work w) {
             if (iou_d > d.prox) emb = 1.0f;
             c = fmin(iou_d, (double)emb);
         }
-        if (d.record) cost[o] = c;
-        if (c <= limit) {
-            const int pos = atomicAdd(&w.hdr[0], 1);
-            if (pos < w.e_cap) { w.e_row[pos] = i0 + r; w.e_col[pos] = q; w.e_cost[pos] = c; }
-            else w.hdr[2] = 1;
+        if (MODE == 2 || d.record) cost[o] = c;
+        if (MODE == 0 && c <= limit) emit(i0 + r, c);
+    }
+}
+
+// ---- appearance pre-filter: float16 MFMA GEMM + exact float32 refine ------------------------------------------
+// Stage-1 appearance can change a cost only where  min(1 - body_sim, 1 - face_sim) <= appearance_thresh
+// (D:1543-1547), i.e. for similarities >= 0.75 -- about one pair per detection out of N*M.  So the
+// N x M x D contraction runs on the float16 matrix cores (16x the float32 rate) over float16 shadows of
+// the features, and only pairs whose *bounded-error* approximation could reach the gate are
+// recomputed exactly in float32 (same value the dense float32 path produces up to summation order)
+// and appended to the solver's edge list as (row, col, 1 - sim).  A pair may then appear twice (its IoU
+// edge and its appearance edge): the solver's relaxation takes the minimum, which is np.minimum of D:1554.
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int FBM = 128, FBN = 128, FBK = 64, FLD = FBK + 8;   // halves; +8 keeps 16-B rows on distinct LDS slots
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, slot = bid / 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
+// exact gate of one (pool row i, high-detection column q) pair, evaluated by a whole wavefront
+__device__ __forceinline__ void refine_emit1(const Dev &d, const bts_lap_work &w, int i, int q, int lane) {
+    const long s = d.pool_slot[i], det = d.hi_idx[q];
+    const float bsim = fmaxf(0.0f, feat::wave_dot(d.body_curr + s * d.D, d.feats + det * d.D, d.D, lane));
+    const float emb = 1.0f - bsim;
+    float face = 1.0f;
+    if (d.Df) face = 1.0f - face_fixup(fmaxf(0.0f, feat::wave_dot(d.face_curr + s * d.Df, d.face_feats + det * d.Df, d.Df, lane)));
+    if (lane == 0 && !(fminf(emb, face) > d.app) && (double)emb <= d.match1) {
+        const int pos = atomicAdd(&w.hdr[0], 1);
+        if (pos < w.e_cap) { w.e_row[pos] = i; w.e_col[pos] = q; w.e_cost[pos] = (double)emb; }
+        else w.hdr[2] = 1;
+    }
+}
+
+// candidate test: could the exact similarity reach the gate?  (NaN/inf approximations are candidates)
+__device__ __forceinline__ bool is_candidate(float approx, float na, float nb, float gate, float eps_rel) {
+    return !(approx < gate - eps_rel * na * nb - 3e-5f);
+}
+
+template <bool FACE>
+__global__ __launch_bounds__(256) void k_filter(Dev d, bts_lap_work w, int m_max) {
+    __shared__ __attribute__((aligned(16))) _Float16 As[FBM * FLD];
+    __shared__ __attribute__((aligned(16))) _Float16 Bs[FBN * FLD];
+    const int n = d.hdr[H_NPOOL], m = d.hdr[H_NHI];
+    const int Dd = FACE ? d.Df : d.D;
+    const _Float16 *A = FACE ? d.face_h : d.body_h, *B = FACE ? d.dface_h : d.det_h;
+    const int nbn = (m_max + FBN - 1) / FBN;
+    const int vb = xcd_remap(blockIdx.x, gridDim.x);
+    const int bm = vb / nbn, bn = vb % nbn;
+    if (bm * FBM >= n || bn * FBN >= m) return;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid >> 1, wc = wid & 1;
+    // K range of this split
+    const int kt_all = (Dd + FBK - 1) / FBK, kt_per = (kt_all + gridDim.y - 1) / gridDim.y;
+    const int kt0 = blockIdx.y * kt_per, kt1 = min(kt_all, kt0 + kt_per);
+    if (kt0 >= kt1) return;
+
+    const int srow = tid >> 3, sk = (tid & 7) * 8;          // 128 rows x 8 chunks of 8 halves
+    const _Float16 *arow[4], *brow[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int i = bm * FBM + srow + 32 * s, j = bn * FBN + srow + 32 * s;
+        arow[s] = i < n ? A + (long)d.pool_slot[i] * Dd : nullptr;
+        brow[s] = j < m ? B + (long)d.hi_idx[j] * Dd : nullptr;
+    }
+    uint4 ra[4], rb[4];
+    auto stage_load = [&](int k0) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int k = k0 + sk;
+            ra[s] = (arow[s] && k < Dd) ? *reinterpret_cast<const uint4 *>(arow[s] + k) : make_uint4(0, 0, 0, 0);
+            rb[s] = (brow[s] && k < Dd) ? *reinterpret_cast<const uint4 *>(brow[s] + k) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto stage_write = [&]() {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            *reinterpret_cast<uint4 *>(&As[(srow + 32 * s) * FLD + sk]) = ra[s];
+            *reinterpret_cast<uint4 *>(&Bs[(srow + 32 * s) * FLD + sk]) = rb[s];
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+    const int frow = lane & 31, fh = lane >> 5;
+    stage_load(kt0 * FBK);
+    for (int kt = kt0; kt < kt1; ++kt) {
+        __syncthreads();
+        stage_write();
+        __syncthreads();
+        if (kt + 1 < kt1) stage_load((kt + 1) * FBK);
+#pragma unroll
+        for (int t = 0; t < FBK / 16; ++t) {
+            half8 fa[2], fb[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+                fa[mi] = *reinterpret_cast<const half8 *>(&As[(wr * 64 + mi * 32 + frow) * FLD + t * 16 + fh * 8]);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+                fb[ni] = *reinterpret_cast<const half8 *>(&Bs[(wc * 64 + ni * 32 + frow) * FLD + t * 16 + fh * 8]);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
+        }
+    }
+    // epilogue: the tile's row/column norms go through LDS (the operand tiles are dead now)
+    const float *na = FACE ? d.face_n : d.body_n, *nb = FACE ? d.dface_n : d.det_n;
+    const float eps = FACE ? d.eps_face : d.eps_body, gate = 1.0f - d.app;
+    const bool split = gridDim.y > 1;
+    __syncthreads();
+    float *snorm = reinterpret_cast<float *>(As);          // [0,128): rows, [128,256): columns
+    {
+        const int g = tid < FBM ? bm * FBM + tid : bn * FBN + (tid - FBM);
+        float v = 0.0f;
+        if (tid < FBM) { if (g < n) v = na[d.pool_slot[g]]; }
+        else if (g < m) v = nb[d.hi_idx[g]];
+        snorm[tid] = v;
+    }
+    __syncthreads();
+    unsigned long long cmask = 0;      // bit (mi*2+ni)*16 + r: accumulator element is a candidate
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int qq = wc * 64 + ni * 32 + frow, q = bn * FBN + qq;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ii = wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh, i = bm * FBM + ii;
+                const float val = acc[mi][ni][r] * feat::HALF_UNSCALE;
+                const bool in = i < n && q < m;
+                if (split) {
+                    if (in) atomicAdd(&d.approx[(long)i * d.Mx + q], val);
+                } else if (in && is_candidate(val, snorm[ii], snorm[FBM + qq], gate, eps)) {
+                    cmask |= 1ull << ((mi * 2 + ni) * 16 + r);
+                }
+            }
+        }
+    if (split || __ballot(cmask != 0) == 0) return;
+    for (int b = 0; b < 64; ++b) {       // rare: about one candidate per detection column
+        unsigned long long todo = __ballot((cmask >> b) & 1);
+        const int t4 = b >> 4, r = b & 15, mi = t4 >> 1, ni = t4 & 1;
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int i = bm * FBM + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (src >> 5);
+            const int q = bn * FBN + wc * 64 + ni * 32 + (src & 31);
+            refine_emit1(d, w, i, q, lane);
+        }
+    }
+}
+
+// split-K form: the partial products were accumulated into `approx`; scan it (and clear it for the
+// next frame), refine the candidates.
+template <bool FACE>
+__global__ __launch_bounds__(CT_COLS) void k_filter_scan(Dev d, bts_lap_work w) {
+    const int n = d.hdr[H_NPOOL], m = d.hdr[H_NHI];
+    const int i0 = blockIdx.y * CT_ROWS, q = blockIdx.x * CT_COLS + threadIdx.x;
+    if (i0 >= n || blockIdx.x * CT_COLS >= m) return;
+    const int lane = threadIdx.x & 63;
+    const float *na = FACE ? d.face_n : d.body_n, *nb = FACE ? d.dface_n : d.det_n;
+    const float eps = FACE ? d.eps_face : d.eps_body, gate = 1.0f - d.app;
+    const bool live = q < m;
+    const float nbq = live ? nb[d.hi_idx[q]] : 0.0f;
+    const int rows = min(CT_ROWS, n - i0);
+    for (int r = 0; r < rows; ++r) {
+        const int i = i0 + r;
+        float val = 0.0f;
+        if (live) { float *p = &d.approx[(long)i * d.Mx + q]; val = *p; *p = 0.0f; }
+        unsigned long long todo = __ballot(live && is_candidate(val, na[d.pool_slot[i]], nbq, gate, eps));
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            refine_emit1(d, w, i, __shfl(q, src), lane);
         }
     }
 }
@@ -241,6 +459,10 @@ __global__ __launch_bounds__(256) void tk_apply(Dev d, int kf_blocks) {
         if (d.Df)
             feat::ema_row(d.face_curr + s * d.Df, d.face_smooth + s * d.Df, d.face_feats + det * d.Df, d.Df,
                           d.has_face[s] != 0, d.ema_a, d.ema_b);
+        if (d.filter) {
+            feat::to_half_row(d.feats + det * d.D, d.body_h + s * d.D, d.body_n + s, d.D);
+            if (d.Df) feat::to_half_row(d.face_feats + det * d.Df, d.face_h + s * d.Df, d.face_n + s, d.Df);
+        }
         if (threadIdx.x == 0) { d.has_body[s] = 1; if (d.Df) d.has_face[s] = 1; }
         return;
     }
@@ -392,6 +614,10 @@ __global__ __launch_bounds__(256) void tk_birth_init(Dev d) {
         const float v = d.face_feats[det * d.Df + c];
         d.face_curr[s * d.Df + c] = v; d.face_smooth[s * d.Df + c] = v;
     }
+    if (d.filter) {
+        feat::to_half_row(d.feats + det * d.D, d.body_h + s * d.D, d.body_n + s, d.D);
+        if (d.Df) feat::to_half_row(d.face_feats + det * d.Df, d.face_h + s * d.Df, d.face_n + s, d.Df);
+    }
 }
 
 // ---- duplicate removal between tracked' and lost' (D:1665-1680): boxes straight from the table ------------
@@ -524,6 +750,11 @@ static void tracker_layout(bts_tracker *t, char *base, size_t &off) {
     SLOT(d.x1, int32_t, T); SLOT(d.y1, int32_t, M); SLOT(d.x2, int32_t, T); SLOT(d.y2, int32_t, M);
     SLOT(d.x3, int32_t, T); SLOT(d.y3, int32_t, M);
     SLOT(d.drop_t, uint8_t, T); SLOT(d.drop_l, uint8_t, T); SLOT(d.lap_hdr, int32_t, 48);
+    if (d.filter) {
+        SLOT(d.body_h, _Float16, T * D); SLOT(d.det_h, _Float16, M * D); SLOT(d.body_n, float, T); SLOT(d.det_n, float, M);
+        SLOT(d.face_h, _Float16, T * Df); SLOT(d.dface_h, _Float16, M * Df); SLOT(d.face_n, float, T); SLOT(d.dface_n, float, M);
+        SLOT(d.approx, float, T * M);
+    }
     SLOT(t->x_ints, int32_t, 8 * T); SLOT(t->x_mean, double, 8 * T); SLOT(t->x_tlbr, double, 4 * T); SLOT(t->x_score, float, T);
 #undef SLOT
 }
@@ -538,7 +769,7 @@ int bts_tracker_default_config(bts_tracker_config *cfg) {
     cfg->track_high_thresh = 0.40; cfg->track_low_thresh = 0.1; cfg->new_track_thresh = 0.9;
     cfg->match_thresh = 0.8; cfg->second_match_thresh = 0.5; cfg->unconfirmed_match_thresh = 0.7;
     cfg->proximity_thresh = 0.5; cfg->appearance_thresh = 0.25; cfg->dedupe_thresh = 0.15;
-    cfg->ema_alpha = 0.9; cfg->record_costs = 0;
+    cfg->ema_alpha = 0.9; cfg->record_costs = 0; cfg->appearance_mode = BTS_APPEARANCE_FILTER;
     return BTS_OK;
 }
 
@@ -559,6 +790,10 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
     d.ema_a = (float)cfg->ema_alpha; d.ema_b = (float)(1.0 - cfg->ema_alpha);
     d.max_time_lost = (int)((double)cfg->frame_rate / 30.0 * cfg->track_buffer);    // D:1276-1277
     d.record = cfg->record_costs ? 1 : 0;
+    // the float16 pre-filter needs 16-byte rows of halves; otherwise the dense float32 form is used
+    d.filter = (cfg->appearance_mode == BTS_APPEARANCE_FILTER && d.D % 8 == 0 && d.Df % 8 == 0) ? 1 : 0;
+    d.eps_body = 1.1f / 1024.0f + (float)d.D / 4194304.0f;
+    d.eps_face = 1.1f / 1024.0f + (float)d.Df / 4194304.0f;
     size_t off = 0;
     tracker_layout(t, nullptr, off);
     const int64_t e_cap = (int64_t)d.T * d.Mx;
@@ -580,6 +815,12 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
         bts_set_error("pinned host allocation failed");
         delete t;
         return BTS_ENOMEM;
+    }
+    if (t->dv.filter && hipMemset(t->dv.approx, 0, sizeof(float) * (size_t)t->dv.T * t->dv.Mx) != hipSuccess) {
+        (void)hipGetLastError();
+        bts_set_error("hipMemset failed");
+        bts_tracker_destroy(t);
+        return BTS_EHIP;
     }
     int rc = bts_tracker_reset(t, nullptr);
     if (rc == BTS_OK && hipStreamSynchronize(nullptr) != hipSuccess) rc = BTS_EHIP;
@@ -662,21 +903,45 @@ int bts_tracker_step(bts_tracker *t, const int32_t *boxes, const float *scores, 
     LAUNCH(tk_prep, dim3(1), dim3(1024));
     seg_end(BTS_SEG_PREP);
     seg_begin(BTS_SEG_PREDICT);
-    LAUNCH(tk_predict, dim3(bts_cdiv(T, 256)), dim3(256));
+    LAUNCH(tk_predict, dim3(kf_blocks + (d.filter ? mc : 0)), dim3(256), kf_blocks);
     seg_end(BTS_SEG_PREDICT);
+    const bool dense = !d.filter || d.record;
+    // split-K factor of the pre-filter: small problems have too few 128x128 tiles to fill 256 CUs
+    int split = 1;
+    {
+        const int tiles = bts_cdiv(T, FBM) * bts_cdiv(mc, FBN), kt_all = bts_cdiv(d.D, FBK);
+        while (tiles * split < 256 && split * 2 <= kt_all && split < 16) split *= 2;
+    }
+    const dim3 filt_grid(bts_cdiv(T, FBM) * bts_cdiv(mc, FBN), split);
     // ---- first association: pool x high-score detections
     seg_begin(BTS_SEG_COS1);
-    rc = bts_cos_enqueue(cos_kernel, d.body_curr, d.pool_slot, d.D, feats, d.hi_idx, d.D, d.D, d.hdr + H_DIMS1, T, mc,
-                         d.sim, M, s);
-    if (rc) return rc;
-    seg_end(BTS_SEG_COS1);
-    if (d.Df) {
-        rc = bts_cos_enqueue(cos_kernel, d.face_curr, d.pool_slot, d.Df, face_feats, d.hi_idx, d.Df, d.Df,
-                             d.hdr + H_DIMS1, T, mc, d.fsim, M, s);
+    if (dense) {
+        rc = bts_cos_enqueue(cos_kernel, d.body_curr, d.pool_slot, d.D, feats, d.hi_idx, d.D, d.D, d.hdr + H_DIMS1, T, mc,
+                             d.sim, M, s);
         if (rc) return rc;
+        if (d.Df) {
+            rc = bts_cos_enqueue(cos_kernel, d.face_curr, d.pool_slot, d.Df, face_feats, d.hi_idx, d.Df, d.Df,
+                                 d.hdr + H_DIMS1, T, mc, d.fsim, M, s);
+            if (rc) return rc;
+        }
     }
+    if (d.filter) {
+        LAUNCH(k_filter<false>, filt_grid, dim3(256), lap[0], mc);
+        if (split > 1) { LAUNCH(k_filter_scan<false>, tile_grid, dim3(CT_COLS), lap[0]); }
+        if (d.Df) {
+            const int fsplit = split < bts_cdiv(d.Df, FBK) ? split : bts_cdiv(d.Df, FBK);
+            LAUNCH(k_filter<true>, dim3(filt_grid.x, fsplit), dim3(256), lap[0], mc);
+            if (fsplit > 1) { LAUNCH(k_filter_scan<true>, tile_grid, dim3(CT_COLS), lap[0]); }
+        }
+    }
+    seg_end(BTS_SEG_COS1);
     seg_begin(BTS_SEG_COST1);
-    LAUNCH(tk_edges<1>, tile_grid, dim3(CT_COLS), lap[0]);
+    if (d.filter) {
+        LAUNCH((tk_edges<1, 1>), tile_grid, dim3(CT_COLS), lap[0]);
+        if (d.record) { LAUNCH((tk_edges<1, 2>), tile_grid, dim3(CT_COLS), lap[0]); }
+    } else {
+        LAUNCH((tk_edges<1, 0>), tile_grid, dim3(CT_COLS), lap[0]);
+    }
     seg_end(BTS_SEG_COST1);
     seg_begin(BTS_SEG_LAP1);
     rc = bts_lap_enqueue_edges(&lap[0], d.hdr + H_DIMS1, T, mc, d.match1, d.x1, d.y1, s);
@@ -689,17 +954,24 @@ int bts_tracker_step(bts_tracker *t, const int32_t *boxes, const float *scores, 
     seg_end(BTS_SEG_APPLY1);
     // ---- second association: remaining tracked rows x low-score detections
     seg_begin(BTS_SEG_STAGE2);
-    LAUNCH(tk_edges<2>, tile_grid, dim3(CT_COLS), lap[1]);
+    LAUNCH((tk_edges<2, 0>), tile_grid, dim3(CT_COLS), lap[1]);
     rc = bts_lap_enqueue_edges(&lap[1], d.hdr + H_DIMS2, T, mc, d.match2, d.x2, d.y2, s);
     if (rc) return rc;
     LAUNCH(tk_apply<2>, dim3(kf_blocks + T), dim3(256), kf_blocks);
     seg_end(BTS_SEG_STAGE2);
     // ---- unconfirmed tracks x leftover high-score detections
     seg_begin(BTS_SEG_STAGE3);
-    rc = bts_cos_enqueue(cos_kernel, d.body_curr, d.unc_slot, d.D, feats, d.left_det, d.D, d.D, d.hdr + H_DIMS3, T, mc,
-                         d.sim, M, s);
-    if (rc) return rc;
-    LAUNCH(tk_edges<3>, tile_grid, dim3(CT_COLS), lap[2]);
+    if (dense) {
+        rc = bts_cos_enqueue(cos_kernel, d.body_curr, d.unc_slot, d.D, feats, d.left_det, d.D, d.D, d.hdr + H_DIMS3, T, mc,
+                             d.sim, M, s);
+        if (rc) return rc;
+    }
+    if (d.filter) {
+        LAUNCH((tk_edges<3, 1>), tile_grid, dim3(CT_COLS), lap[2]);
+        if (d.record) { LAUNCH((tk_edges<3, 2>), tile_grid, dim3(CT_COLS), lap[2]); }
+    } else {
+        LAUNCH((tk_edges<3, 0>), tile_grid, dim3(CT_COLS), lap[2]);
+    }
     rc = bts_lap_enqueue_edges(&lap[2], d.hdr + H_DIMS3, T, mc, d.match3, d.x3, d.y3, s);
     if (rc) return rc;
     LAUNCH(tk_apply<3>, dim3(kf_blocks + T), dim3(256), kf_blocks);

@@ -136,6 +136,13 @@ int bts_dedupe_pairs(bts_context *ctx, const double *a_tlbr, const uint8_t *a_f3
 
 /* -------------------------------------------------- whole-frame tracker, BoTSORT.update D:1414-1639 */
 
+/* How the stage-1/3 appearance term (D:1539-1554, D:1590-1602) is evaluated inside the tracker:
+ * FILTER: float16-MFMA pre-filter over float16 shadows of the features + exact float32 recomputation
+ *         of every pair that could pass the appearance gate (results identical to DENSE up to float32
+ *         summation order; no N x M matrix is materialised);
+ * DENSE:  the dense float32 similarity and cost matrices, as the reference forms them. */
+enum bts_appearance_mode { BTS_APPEARANCE_FILTER = 0, BTS_APPEARANCE_DENSE = 1 };
+
 typedef struct bts_tracker_config {
     int32_t max_tracks;      /* capacity of the resident track table (tracked + lost + unconfirmed) */
     int32_t max_dets;        /* max detections per frame */
@@ -154,6 +161,7 @@ typedef struct bts_tracker_config {
     double dedupe_thresh;       /* 0.15 D:1667 */
     double ema_alpha;           /* 0.9  D:473 */
     int32_t record_costs;       /* keep the three cost matrices of the last frame for inspection */
+    int32_t appearance_mode;    /* enum bts_appearance_mode */
 } bts_tracker_config;
 
 /* Fill cfg with the reference's hard-coded values (D:1268-1277). */

@@ -86,12 +86,12 @@ def test_golden_faces(bts, synth):
     _replay_golden(bts, "g6_faces.npz", synth)
 
 
-def _against_oracle(bts, synth, K, M, D, frames, churn=0.0, frame_rate=30, seed=4321, face_dim=0):
+def _against_oracle(bts, synth, K, M, D, frames, churn=0.0, frame_rate=30, seed=4321, face_dim=0, **opts):
     from oracle import bts_oracle as bo
     st = synth.SyntheticStream(K, M, D, seed=seed, churn=churn, face_dim=face_dim)
     ora = bo.TrackerOracle(frame_rate=frame_rate)
     trk = bts.DeviceTracker(max_tracks=2 * K + int(frames * churn * M) + 64, max_dets=max(K, M), feat_dim=D, face_dim=face_dim,
-                            frame_rate=frame_rate)
+                            frame_rate=frame_rate, **opts)
     matched = 0
     for f in range(frames):
         fr = st.next()
@@ -122,6 +122,69 @@ def _against_oracle(bts, synth, K, M, D, frames, churn=0.0, frame_rate=30, seed=
 def test_c2_stream_vs_oracle(bts, synth):
     """BASELINE config 2: 512 tracks x 256 detections x 2048-d, IoU + cosine fused cost."""
     assert _against_oracle(bts, synth, 512, 256, 2048, frames=12) > 2000
+
+
+def test_c2_stream_dense_mode_vs_oracle(bts, synth):
+    """same stream through the dense float32 appearance path (BTS_APPEARANCE_DENSE)."""
+    assert _against_oracle(bts, synth, 512, 256, 2048, frames=8, appearance_mode=1) > 1500
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_appearance_gate_band(bts, mode):
+    """Appearance-only re-association with similarities in a narrow band around the 0.75 gate
+    (boxes teleport every frame, so IoU never helps): the float16 pre-filter must hand every pair
+    that the exact float32 value puts inside the gate to the solver, and nothing else may match."""
+    import torch
+    from oracle import bts_oracle as bo
+    rng = np.random.default_rng(31)
+    K, D = 96, 512
+    proto = rng.standard_normal((K, D)).astype(np.float64)
+    proto /= np.linalg.norm(proto, axis=1, keepdims=True)
+    trk = bts.DeviceTracker(max_tracks=4 * K, max_dets=K, feat_dim=D, appearance_mode=mode, record_costs=True)
+    ora = bo.TrackerOracle()
+    used_app = 0
+    for f in range(6):
+        cx = rng.permutation(K) * 400 + 100 + rng.integers(0, 50, K)
+        cy = rng.integers(100, 4000, K)
+        boxes = np.stack([cx, cy, cx + 60, cy + 120], 1).astype(np.int32)
+        scores = rng.uniform(0.91, 0.99, K).astype(np.float32)
+        # rotate each prototype by an angle whose cosine sits within +-0.01 of the gate (but not
+        # closer than 3e-5: the float32 summation order of the CPU BLAS is not ours)
+        c = 0.75 + rng.uniform(3e-5, 0.01, K) * rng.choice([-1.0, 1.0], K)
+        if f == 0:
+            c[:] = 1.0
+        noise = rng.standard_normal((K, D))
+        noise -= (noise * proto).sum(1, keepdims=True) * proto
+        noise /= np.linalg.norm(noise, axis=1, keepdims=True)
+        feats = (c[:, None] * proto + np.sqrt(1 - c[:, None] ** 2) * noise).astype(np.float32)
+        perm = rng.permutation(K)
+        boxes, scores, feats = boxes[perm], scores[perm], np.ascontiguousarray(feats[perm])
+        trk.step(torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda(), torch.from_numpy(feats.copy()).cuda())
+        ora.update_arrays(boxes, scores.astype(np.float64), feats.copy())
+        for k in (1, 2, 3):
+            r = trk.stage_result(k, want_cost=True)
+            assert np.array_equal(r["m"], ora.trace["m%d" % k]), (f, k)
+            if r["cost"] is not None and r["cost"].size:
+                assert np.abs(r["cost"] - ora.trace["cost%d" % k]).max() <= 2e-6
+        used_app += len(ora.trace["m1"])
+        # the prototypes drift to the last matched feature (curr), so refresh them from the oracle
+        for t in ora.tracked + ora.lost:
+            pass
+        t0 = bo.TrackerOracle.table(ora.tracked)
+        t1 = trk.export(0)
+        assert np.array_equal(t1["track_id"], t0["track_id"])
+        # next frame rotates around each identity's latest stored feature
+        by_id = {}
+        for t in ora.tracked + ora.lost:
+            by_id[t.track_id] = np.asarray(t.body_curr, dtype=np.float64)
+        if f == 0:
+            ident_of_id = {t.track_id: perm[t.det_index] for t in ora.tracked}
+        for tid, ident in ident_of_id.items():
+            if tid in by_id:
+                v = by_id[tid]
+                proto[ident] = v / np.linalg.norm(v)
+    assert used_app > 100
+    trk.close()
 
 
 def test_churn_lifecycle_vs_oracle(bts, synth):
