@@ -346,9 +346,6 @@ __device__ void solve_component(const LapArgs &A, int c, int lane) {
         STG(&w.u[i], mn);
     }
     for (int k = lane; k < cn; k += 64) STG(&w.v[LDG(&w.ccols[cs + k])], 0.0);
-        for (int k = lane; k < r; k += 64) STG(&x[LDG(&w.crows[rs + k])], -1);
-        for (int k = lane; k < cn; k += 64) STG(&y[LDG(&w.ccols[cs + k])], -1);
-    }
     wave_sync();
 
     for (int t = 0; t < r; ++t) {
