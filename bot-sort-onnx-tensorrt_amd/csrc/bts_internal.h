@@ -77,7 +77,7 @@ struct bts_lap_work {
     double *e_cost = nullptr;
     int32_t *deg = nullptr;      // [n_cap] feasible edges per row
     int32_t *cdeg = nullptr;     // [m_cap] feasible edges per column
-    int32_t *rptr = nullptr;     // [n_cap+1] CSR row pointers
+    int32_t *rptr = nullptr;     // [n_cap+1] CSR row pointers, indexed by slot_of_row
     int32_t *cursor = nullptr;   // [n_cap] fill cursors / component cursors
     int32_t *csr_col = nullptr;  // [e_cap]
     double *csr_cost = nullptr;  // [e_cap]
@@ -92,6 +92,9 @@ struct bts_lap_work {
     int32_t *crows_s = nullptr;  // [n_cap] ... sorted ascending inside each component
     int32_t *ccols = nullptr;    // [m_cap] columns grouped by component
     int32_t *comp_list = nullptr; // [n_cap] components that need the augmenting-path solver
+    int32_t *slot_of_row = nullptr; // [n_cap] dense index of an active row (valid while deg > 0)
+    int32_t *arow = nullptr;      // [n_cap] active rows (have a feasible edge), in order of first sight
+    int32_t *acol = nullptr;      // [m_cap] active columns
     double *u = nullptr;         // [n_cap] row duals
     double *v = nullptr;         // [m_cap] column duals
     double *dist = nullptr;      // [m_cap] tentative distances of a search
@@ -110,8 +113,10 @@ int bts_lap_enqueue_dense(const bts_lap_work *w, const double *cost, int ld, con
                           int n_max, int m_max, double cost_limit, int32_t *x, int32_t *y,
                           hipStream_t stream);
 // Enqueue the solver on an edge list already appended to w->e_* (hdr[0] = edge count).
+// `fresh`: x/y already hold -1 and deg/cdeg are zero (the tracker keeps both invariants; the
+// standalone entry point passes 0 and the kernel establishes them itself, O(n+m)).
 int bts_lap_enqueue_edges(const bts_lap_work *w, const int32_t *dims, int n_max, int m_max,
-                          double cost_limit, int32_t *x, int32_t *y, hipStream_t stream);
+                          double cost_limit, int32_t *x, int32_t *y, int fresh, hipStream_t stream);
 // reset hdr before edges are appended
 int bts_lap_enqueue_reset(const bts_lap_work *w, hipStream_t stream);
 

@@ -53,6 +53,37 @@ __device__ __forceinline__ void renorm_row(float *row, int d) {
 __device__ __forceinline__ void ema_row(float *curr, float *smooth, const float *f, int d, bool has, float alpha,
                                         float beta) {
     float ss = 0.0f;
+    if (vec4_ok(curr, d) && vec4_ok(smooth, d) && vec4_ok(f, d)) {      // 16 B per lane, values stay in registers
+        const float4 *f4 = reinterpret_cast<const float4 *>(f);
+        float4 *c4 = reinterpret_cast<float4 *>(curr), *s4 = reinterpret_cast<float4 *>(smooth);
+        const int nv = d / 4;
+        if (nv <= 2 * (int)blockDim.x) {
+            float4 fv[2], sv[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int k = threadIdx.x + t * blockDim.x;
+                if (k < nv) {
+                    fv[t] = f4[k];
+                    if (has) {
+                        const float4 o = s4[k];
+                        sv[t].x = alpha * o.x + beta * fv[t].x; sv[t].y = alpha * o.y + beta * fv[t].y;
+                        sv[t].z = alpha * o.z + beta * fv[t].z; sv[t].w = alpha * o.w + beta * fv[t].w;
+                    } else sv[t] = fv[t];
+                    ss += sv[t].x * sv[t].x + sv[t].y * sv[t].y + sv[t].z * sv[t].z + sv[t].w * sv[t].w;
+                }
+            }
+            const float nrm = sqrtf(block_sum(ss));
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int k = threadIdx.x + t * blockDim.x;
+                if (k < nv) {
+                    c4[k] = fv[t];
+                    s4[k] = make_float4(sv[t].x / nrm, sv[t].y / nrm, sv[t].z / nrm, sv[t].w / nrm);
+                }
+            }
+            return;
+        }
+    }
     for (int k = threadIdx.x; k < d; k += blockDim.x) {
         const float fv = f[k];
         const float s = has ? alpha * smooth[k] + beta * fv : fv;

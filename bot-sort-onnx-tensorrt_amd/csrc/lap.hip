@@ -22,7 +22,8 @@
 
 namespace {
 
-enum { H_EDGES = 0, H_COMPS = 1, H_ERR = 2, H_HARD = 3 };   // hdr: edges, components, overflow flag, components for k_solve
+enum { H_EDGES = 0, H_COMPS = 1, H_ERR = 2, H_HARD = 3, H_NA = 4, H_MA = 5 };   // hdr: edges, components, overflow flag,
+                                                                              // components for k_solve, active rows / columns
 
 // Every word of the work area that is the target of an atomic (or is read back after atomics) is
 // accessed ONLY with agent-scope atomics: a plain store that is still on its way to L2 can land
@@ -36,6 +37,7 @@ struct LapArgs {
     int n_max, m_max;
     double limit;
     int32_t *x, *y;
+    int fresh;
 };
 
 // Lanes of one wavefront hand values to each other through global memory (lane 0 publishes a
@@ -118,6 +120,9 @@ __device__ int block_exscan(int32_t *arr, int len, int32_t *tmp) {
     return total;
 }
 
+// Work is proportional to the number of feasible edges E, not to n + m: only rows/columns that
+// own an edge ("active") are ever touched.  Invariant kept across calls: deg[] / cdeg[] are zero
+// outside this kernel (it clears the entries it raised before it ends).
 __global__ __launch_bounds__(1024) void k_prepare(LapArgs A) {
     __shared__ int32_t tmp[1024];
     const bts_lap_work &w = A.w;
@@ -125,65 +130,72 @@ __global__ __launch_bounds__(1024) void k_prepare(LapArgs A) {
     const int tid = threadIdx.x, nth = blockDim.x;
     int E = RLX(&w.hdr[H_EDGES]);
     if ((long)E > w.e_cap) E = (int)w.e_cap;
-
-    if (E == 0) {                               // nothing feasible: everything stays unmatched
-        for (int i = tid; i < n; i += nth) RST(&A.x[i], -1);
-        for (int j = tid; j < m; j += nth) RST(&A.y[j], -1);
-        if (tid == 0) { RST(&w.hdr[H_COMPS], 0); RST(&w.hdr[H_HARD], 0); }
-        return;
+    if (!A.fresh) {
+        for (int i = tid; i < n; i += nth) { RST(&w.deg[i], 0); RST(&A.x[i], -1); }
+        for (int j = tid; j < m; j += nth) { RST(&w.cdeg[j], 0); RST(&A.y[j], -1); }
+        __syncthreads();
     }
-    for (int i = tid; i < n; i += nth) { RST(&w.deg[i], 0); RST(&w.parent[i], i); RST(&A.x[i], -1); }
-    for (int j = tid; j < m; j += nth) { RST(&w.cdeg[j], 0); RST(&w.parent[n + j], n + j); RST(&A.y[j], -1); RST(&w.v[j], 0.0); }
-    if (tid == 0) RST(&w.hdr[H_HARD], 0);
-    __syncthreads();
+    if (E == 0) return;                                   // hdr counters are already zero
+    // 1. degrees; a node seen for the first time gets a dense slot and its own union-find cell
     for (int e = tid; e < E; e += nth) {
         const int i = w.e_row[e], j = w.e_col[e];
-        atomicAdd(&w.deg[i], 1);
-        atomicAdd(&w.cdeg[j], 1);
-        unite(w.parent, i, n + j);
+        if (atomicAdd(&w.deg[i], 1) == 0) {
+            const int s = atomicAdd(&w.hdr[H_NA], 1);
+            RST(&w.arow[s], i); RST(&w.slot_of_row[i], s); RST(&w.parent[i], i);
+        }
+        if (atomicAdd(&w.cdeg[j], 1) == 0) {
+            const int s = atomicAdd(&w.hdr[H_MA], 1);
+            RST(&w.acol[s], j); RST(&w.parent[n + j], n + j); RST(&w.v[j], 0.0);
+        }
     }
     __syncthreads();
-    // roots of all active nodes (a row: rows have the smaller node ids); read-only walks
-    for (int i = tid; i < n; i += nth)
-        if (RLX(&w.deg[i]) > 0) RST(&w.rootv[i], find_root_ro(w.parent, i));
-    for (int j = tid; j < m; j += nth)
-        if (RLX(&w.cdeg[j]) > 0) RST(&w.rootv[n + j], find_root_ro(w.parent, n + j));
+    // 2. connected components of the feasible graph
+    for (int e = tid; e < E; e += nth) unite(w.parent, w.e_row[e], n + w.e_col[e]);
     __syncthreads();
-    // CSR row pointers
-    for (int i = tid; i < n; i += nth) RST(&w.rptr[i], RLX(&w.deg[i]));
+    // 3. final roots (read-only walks: every union is done), component ids handed out by the roots
+    const int NA = RLX(&w.hdr[H_NA]), MA = RLX(&w.hdr[H_MA]);
+    for (int s = tid; s < NA; s += nth) {
+        const int i = RLX(&w.arow[s]), r = find_root_ro(w.parent, i);
+        RST(&w.rootv[i], r);
+        RST(&w.rptr[s], RLX(&w.deg[i]));
+        if (r == i) {                                     // roots are rows: rows have the smaller node ids
+            const int c = atomicAdd(&w.hdr[H_COMPS], 1);
+            RST(&w.comp_of[i], c); RST(&w.crow_ptr[c], 0); RST(&w.ccol_ptr[c], 0);
+        }
+    }
+    for (int s = tid; s < MA; s += nth) { const int j = RLX(&w.acol[s]); RST(&w.rootv[n + j], find_root_ro(w.parent, n + j)); }
     __syncthreads();
-    block_exscan(w.rptr, n, tmp);
-    if (tid == 0) RST(&w.rptr[n], E);
-    for (int i = tid; i < n; i += nth) RST(&w.cursor[i], RLX(&w.rptr[i]));
-    // component ids: rank of each root row among the roots
-    for (int i = tid; i < n; i += nth) RST(&w.comp_of[i], (RLX(&w.deg[i]) > 0 && RLX(&w.rootv[i]) == i) ? 1 : 0);
+    // 4. component sizes
+    const int C = RLX(&w.hdr[H_COMPS]);
+    for (int s = tid; s < NA; s += nth) atomicAdd(&w.crow_ptr[RLX(&w.comp_of[RLX(&w.rootv[RLX(&w.arow[s])])])], 1);
+    for (int s = tid; s < MA; s += nth) atomicAdd(&w.ccol_ptr[RLX(&w.comp_of[RLX(&w.rootv[n + RLX(&w.acol[s])])])], 1);
     __syncthreads();
-    const int C = block_exscan(w.comp_of, n, tmp);
-    if (tid == 0) RST(&w.hdr[H_COMPS], C);
-    // component sizes -> pointers
-    for (int c = tid; c <= C; c += nth) { RST(&w.crow_ptr[c], 0); RST(&w.ccol_ptr[c], 0); }
-    __syncthreads();
-    for (int i = tid; i < n; i += nth)
-        if (RLX(&w.deg[i]) > 0) atomicAdd(&w.crow_ptr[RLX(&w.comp_of[RLX(&w.rootv[i])])], 1);
-    for (int j = tid; j < m; j += nth)
-        if (RLX(&w.cdeg[j]) > 0) atomicAdd(&w.ccol_ptr[RLX(&w.comp_of[RLX(&w.rootv[n + j])])], 1);
-    __syncthreads();
-    block_exscan(w.crow_ptr, C + 1, tmp);
-    block_exscan(w.ccol_ptr, C + 1, tmp);
+    // 5. pointers
+    block_exscan(w.rptr, NA, tmp);
+    block_exscan(w.crow_ptr, C, tmp);
+    block_exscan(w.ccol_ptr, C, tmp);
+    if (tid == 0) { RST(&w.rptr[NA], E); RST(&w.crow_ptr[C], NA); RST(&w.ccol_ptr[C], MA); }
+    for (int s = tid; s < NA; s += nth) RST(&w.cursor[s], RLX(&w.rptr[s]));
     for (int c = tid; c < C; c += nth) { RST(&w.ccur_r[c], RLX(&w.crow_ptr[c])); RST(&w.ccur_c[c], RLX(&w.ccol_ptr[c])); }
     __syncthreads();
-    // fills
+    // 6. fills: CSR by row slot, rows / columns grouped by component
     for (int e = tid; e < E; e += nth) {
-        const int pos = atomicAdd(&w.cursor[w.e_row[e]], 1);
+        const int pos = atomicAdd(&w.cursor[RLX(&w.slot_of_row[w.e_row[e]])], 1);
         RST(&w.csr_col[pos], w.e_col[e]);
         RST(&w.csr_cost[pos], w.e_cost[e]);
     }
-    for (int i = tid; i < n; i += nth)
-        if (RLX(&w.deg[i]) > 0) RST(&w.crows[atomicAdd(&w.ccur_r[RLX(&w.comp_of[RLX(&w.rootv[i])])], 1)], i);
-    for (int j = tid; j < m; j += nth)
-        if (RLX(&w.cdeg[j]) > 0) RST(&w.ccols[atomicAdd(&w.ccur_c[RLX(&w.comp_of[RLX(&w.rootv[n + j])])], 1)], j);
+    for (int s = tid; s < NA; s += nth) {
+        const int i = RLX(&w.arow[s]);
+        RST(&w.crows[atomicAdd(&w.ccur_r[RLX(&w.comp_of[RLX(&w.rootv[i])])], 1)], i);
+        RST(&w.deg[i], 0);                                // restore the invariant
+    }
+    for (int s = tid; s < MA; s += nth) {
+        const int j = RLX(&w.acol[s]);
+        RST(&w.ccols[atomicAdd(&w.ccur_c[RLX(&w.comp_of[RLX(&w.rootv[n + j])])], 1)], j);
+        RST(&w.cdeg[j], 0);
+    }
     __syncthreads();
-    // A component of one row and one column (by far the common case in a tracking frame) is
+    // 7. A component of one row and one column (by far the common case in a tracking frame) is
     // decided here: any feasible edge beats two dummies (cost <= limit), ties prefer the match.
     // Everything else is queued for the augmenting-path solver.
     for (int c = tid; c < C; c += nth) {
@@ -241,7 +253,8 @@ __device__ bool solve_small(const LapArgs &A, int c, int lane, SmallLds &L) {
     }
     const int my_col = lane < cn ? LDG(&w.ccols[cs + lane]) : 0x7fffffff;
     // local CSR
-    const int e_lo = lane < r ? LDG(&w.rptr[my_row]) : 0, deg = lane < r ? LDG(&w.rptr[my_row + 1]) - e_lo : 0;
+    const int my_slot = lane < r ? LDG(&w.slot_of_row[my_row]) : 0;
+    const int e_lo = lane < r ? LDG(&w.rptr[my_slot]) : 0, deg = lane < r ? LDG(&w.rptr[my_slot + 1]) - e_lo : 0;
     int incl = deg;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off); if (lane >= off) incl += t; }
@@ -342,10 +355,10 @@ __device__ void solve_component(const LapArgs &A, int c, int lane) {
     for (int k = lane; k < r; k += 64) {
         const int i = LDG(&w.crows_s[rs + k]);
         double mn = limit;
-        for (int e = LDG(&w.rptr[i]); e < LDG(&w.rptr[i + 1]); ++e) mn = fmin(mn, LDG(&w.csr_cost[e]));
+        const int sl = LDG(&w.slot_of_row[i]);
+        for (int e = LDG(&w.rptr[sl]); e < LDG(&w.rptr[sl + 1]); ++e) mn = fmin(mn, LDG(&w.csr_cost[e]));
         STG(&w.u[i], mn);
     }
-    for (int k = lane; k < cn; k += 64) STG(&w.v[LDG(&w.ccols[cs + k])], 0.0);
     wave_sync();
 
     for (int t = 0; t < r; ++t) {
@@ -359,8 +372,9 @@ __device__ void solve_component(const LapArgs &A, int c, int lane) {
         int end_col = -1;                  // >= 0: path ends at this free column
         for (;;) {
             const double ucur = LDG(&w.u[cur]);
-            const int e1 = LDG(&w.rptr[cur + 1]);
-            for (int e = LDG(&w.rptr[cur]) + lane; e < e1; e += 64) {
+            const int scur = LDG(&w.slot_of_row[cur]);
+            const int e1 = LDG(&w.rptr[scur + 1]);
+            for (int e = LDG(&w.rptr[scur]) + lane; e < e1; e += 64) {
                 const int j = LDG(&w.csr_col[e]);
                 if (!LDG(&w.scanned[j])) {
                     const double nd = dcur + ((LDG(&w.csr_cost[e]) - ucur) - LDG(&w.v[j]));
@@ -451,6 +465,7 @@ static void layout(bts_lap_work *w, char *base, size_t &off, int n, int m, int64
     SLOT(crow_ptr, int32_t, n + 1); SLOT(ccol_ptr, int32_t, n + 1);
     SLOT(ccur_r, int32_t, n + 1); SLOT(ccur_c, int32_t, n + 1);
     SLOT(crows, int32_t, n); SLOT(crows_s, int32_t, n); SLOT(ccols, int32_t, m); SLOT(comp_list, int32_t, n);
+    SLOT(slot_of_row, int32_t, n); SLOT(arow, int32_t, n); SLOT(acol, int32_t, m);
     SLOT(u, double, n); SLOT(v, double, m); SLOT(dist, double, m);
     SLOT(pred, int32_t, m); SLOT(scanned, int32_t, m);
 #undef SLOT
@@ -475,8 +490,8 @@ int bts_lap_enqueue_reset(const bts_lap_work *w, hipStream_t stream) {
 }
 
 int bts_lap_enqueue_edges(const bts_lap_work *w, const int32_t *dims, int n_max, int m_max,
-                          double cost_limit, int32_t *x, int32_t *y, hipStream_t stream) {
-    LapArgs A{*w, dims, n_max, m_max, cost_limit, x, y};
+                          double cost_limit, int32_t *x, int32_t *y, int fresh, hipStream_t stream) {
+    LapArgs A{*w, dims, n_max, m_max, cost_limit, x, y, fresh};
     hipLaunchKernelGGL(k_prepare, dim3(1), dim3(1024), 0, stream, A);
     BTS_LAUNCH_CHECK();
     const int waves = n_max < m_max ? n_max : m_max;   // #components <= min(n, m)
@@ -499,7 +514,7 @@ int bts_lap_enqueue_dense(const bts_lap_work *w, const double *cost, int ld, con
                            cost_limit);
         BTS_LAUNCH_CHECK();
     }
-    return bts_lap_enqueue_edges(w, dims, n_max, m_max, cost_limit, x, y, stream);
+    return bts_lap_enqueue_edges(w, dims, n_max, m_max, cost_limit, x, y, 0, stream);
 }
 
 extern "C" int bts_lapjv(bts_context *ctx, const double *cost, int n, int m, int ld, double cost_limit,

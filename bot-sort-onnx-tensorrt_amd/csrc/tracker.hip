@@ -135,17 +135,19 @@ __global__ __launch_bounds__(1024) void tk_prep(Dev d) {
 }
 
 // ---- K2: STrack.multi_predict over the pool (D:524-536 + D:265-302) ---------------------------------
-// Workgroups past the first `pred_blocks` turn this frame's (raw) detection rows into float16
-// shadows + norms for the appearance pre-filter: independent work sharing one launch.
-__global__ __launch_bounds__(256) void tk_predict(Dev d, int pred_blocks) {
-    if ((int)blockIdx.x >= pred_blocks) {
-        const long j = blockIdx.x - pred_blocks;
-        if (j >= d.m) return;
-        feat::to_half_row(d.feats + j * d.D, d.det_h + j * d.D, d.det_n + j, d.D);
-        if (d.Df) feat::to_half_row(d.face_feats + j * d.Df, d.dface_h + j * d.Df, d.dface_n + j, d.Df);
-        return;
-    }
+// float16 shadows + norms of this frame's (raw) detection rows for the appearance pre-filter
+__global__ __launch_bounds__(256) void tk_cvt(Dev d) {
+    const long j = blockIdx.x;
+    if (j >= d.m) return;
+    feat::to_half_row(d.feats + j * d.D, d.det_h + j * d.D, d.det_n + j, d.D);
+    if (d.Df) feat::to_half_row(d.face_feats + j * d.Df, d.dface_h + j * d.Df, d.dface_n + j, d.Df);
+}
+
+__global__ __launch_bounds__(256) void tk_predict(Dev d) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    // the three assignment vectors start out "unmatched" (the solver only writes matches)
+    if (r < d.T) { d.x1[r] = -1; d.x2[r] = -1; d.x3[r] = -1; }
+    if (r < d.m) { d.y1[r] = -1; d.y2[r] = -1; d.y3[r] = -1; }
     if (r >= d.hdr[H_NPOOL]) return;
     const int s = d.pool_slot[r];
     double m[8], P[64];
@@ -439,17 +441,18 @@ __global__ __launch_bounds__(256) void tk_renorm(Dev d) {
     if (d.Df) feat::renorm_row(d.face_feats + det * d.Df, d.Df);
 }
 
-// ---- match application (D:570-610): Kalman update + lifecycle by the first workgroups (one thread
-// per row, state in registers), ReID feature bookkeeping by the rest (one workgroup per row). -----------
-template <int STAGE>
-__global__ __launch_bounds__(256) void tk_apply(Dev d, int kf_blocks) {
+// ---- match application (D:570-610).  FEAT=false: Kalman update + lifecycle, one thread per row with
+// the state in registers.  FEAT=true: ReID feature bookkeeping, one workgroup per row.  (Two launches:
+// the Kalman part needs the whole register file, the feature part wants occupancy.) ---------------------
+template <int STAGE, bool FEAT>
+__global__ __launch_bounds__(256) void tk_apply(Dev d) {
     const int32_t *h = d.hdr;
     const int n = STAGE == 1 ? h[H_NPOOL] : STAGE == 2 ? h[H_NR2] : h[H_NUNC];
     const int32_t *rslot = STAGE == 1 ? d.pool_slot : STAGE == 2 ? d.r2_slot : d.unc_slot;
     const int32_t *xs = STAGE == 1 ? d.x1 : STAGE == 2 ? d.x2 : d.x3;
     const int32_t *cdet = STAGE == 1 ? d.hi_idx : STAGE == 2 ? d.lo_idx : d.left_det;
-    if ((int)blockIdx.x >= kf_blocks) {                       // ---- feature rows
-        const int r = blockIdx.x - kf_blocks;
+    if (FEAT) {                                               // ---- feature rows: one workgroup each
+        const int r = blockIdx.x;
         if (r >= n) return;
         const int xq = xs[r];
         if (xq < 0) return;
@@ -822,6 +825,13 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
         bts_tracker_destroy(t);
         return BTS_EHIP;
     }
+    // the assignment work area keeps "degree arrays are zero between calls" (lap.hip)
+    if (hipMemset(t->block + lap_off, 0, t->bytes - lap_off) != hipSuccess) {
+        (void)hipGetLastError();
+        bts_set_error("hipMemset failed");
+        bts_tracker_destroy(t);
+        return BTS_EHIP;
+    }
     int rc = bts_tracker_reset(t, nullptr);
     if (rc == BTS_OK && hipStreamSynchronize(nullptr) != hipSuccess) rc = BTS_EHIP;
     if (rc != BTS_OK) { bts_tracker_destroy(t); return rc; }
@@ -903,7 +913,8 @@ int bts_tracker_step(bts_tracker *t, const int32_t *boxes, const float *scores, 
     LAUNCH(tk_prep, dim3(1), dim3(1024));
     seg_end(BTS_SEG_PREP);
     seg_begin(BTS_SEG_PREDICT);
-    LAUNCH(tk_predict, dim3(kf_blocks + (d.filter ? mc : 0)), dim3(256), kf_blocks);
+    LAUNCH(tk_predict, dim3(kf_blocks), dim3(256));
+    if (d.filter) { LAUNCH(tk_cvt, dim3(mc), dim3(256)); }
     seg_end(BTS_SEG_PREDICT);
     const bool dense = !d.filter || d.record;
     // split-K factor of the pre-filter: small problems have too few 128x128 tiles to fill 256 CUs
@@ -944,20 +955,22 @@ int bts_tracker_step(bts_tracker *t, const int32_t *boxes, const float *scores, 
     }
     seg_end(BTS_SEG_COST1);
     seg_begin(BTS_SEG_LAP1);
-    rc = bts_lap_enqueue_edges(&lap[0], d.hdr + H_DIMS1, T, mc, d.match1, d.x1, d.y1, s);
+    rc = bts_lap_enqueue_edges(&lap[0], d.hdr + H_DIMS1, T, mc, d.match1, d.x1, d.y1, 1, s);
     if (rc) return rc;
     seg_end(BTS_SEG_LAP1);
     seg_begin(BTS_SEG_APPLY1);
     LAUNCH(tk_renorm, dim3(mc), dim3(256));
     LAUNCH(tk_after1, dim3(1), dim3(1024));          // reads pre-update states: before tk_apply<1>
-    LAUNCH(tk_apply<1>, dim3(kf_blocks + T), dim3(256), kf_blocks);
+    LAUNCH((tk_apply<1, false>), dim3(kf_blocks), dim3(256));
+    LAUNCH((tk_apply<1, true>), dim3(T), dim3(256));
     seg_end(BTS_SEG_APPLY1);
     // ---- second association: remaining tracked rows x low-score detections
     seg_begin(BTS_SEG_STAGE2);
     LAUNCH((tk_edges<2, 0>), tile_grid, dim3(CT_COLS), lap[1]);
-    rc = bts_lap_enqueue_edges(&lap[1], d.hdr + H_DIMS2, T, mc, d.match2, d.x2, d.y2, s);
+    rc = bts_lap_enqueue_edges(&lap[1], d.hdr + H_DIMS2, T, mc, d.match2, d.x2, d.y2, 1, s);
     if (rc) return rc;
-    LAUNCH(tk_apply<2>, dim3(kf_blocks + T), dim3(256), kf_blocks);
+    LAUNCH((tk_apply<2, false>), dim3(kf_blocks), dim3(256));
+    LAUNCH((tk_apply<2, true>), dim3(T), dim3(256));
     seg_end(BTS_SEG_STAGE2);
     // ---- unconfirmed tracks x leftover high-score detections
     seg_begin(BTS_SEG_STAGE3);
@@ -972,9 +985,10 @@ int bts_tracker_step(bts_tracker *t, const int32_t *boxes, const float *scores, 
     } else {
         LAUNCH((tk_edges<3, 0>), tile_grid, dim3(CT_COLS), lap[2]);
     }
-    rc = bts_lap_enqueue_edges(&lap[2], d.hdr + H_DIMS3, T, mc, d.match3, d.x3, d.y3, s);
+    rc = bts_lap_enqueue_edges(&lap[2], d.hdr + H_DIMS3, T, mc, d.match3, d.x3, d.y3, 1, s);
     if (rc) return rc;
-    LAUNCH(tk_apply<3>, dim3(kf_blocks + T), dim3(256), kf_blocks);
+    LAUNCH((tk_apply<3, false>), dim3(kf_blocks), dim3(256));
+    LAUNCH((tk_apply<3, true>), dim3(T), dim3(256));
     seg_end(BTS_SEG_STAGE3);
     // ---- births, list merge, duplicate removal
     seg_begin(BTS_SEG_MERGE);
