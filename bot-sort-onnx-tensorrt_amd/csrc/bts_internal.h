@@ -95,6 +95,7 @@ struct bts_lap_work {
     int32_t *slot_of_row = nullptr; // [n_cap] dense index of an active row (valid while deg > 0)
     int32_t *arow = nullptr;      // [n_cap] active rows (have a feasible edge), in order of first sight
     int32_t *acol = nullptr;      // [m_cap] active columns
+    int32_t *hard = nullptr;      // [e_cap] indices of edges that are not isolated pairs
     double *u = nullptr;         // [n_cap] row duals
     double *v = nullptr;         // [m_cap] column duals
     double *dist = nullptr;      // [m_cap] tentative distances of a search
@@ -113,10 +114,19 @@ int bts_lap_enqueue_dense(const bts_lap_work *w, const double *cost, int ld, con
                           int n_max, int m_max, double cost_limit, int32_t *x, int32_t *y,
                           hipStream_t stream);
 // Enqueue the solver on an edge list already appended to w->e_* (hdr[0] = edge count).
+// One assignment problem on an edge list already appended to w.e_* (w.hdr[0] = edge count).
 // `fresh`: x/y already hold -1 and deg/cdeg are zero (the tracker keeps both invariants; the
 // standalone entry point passes 0 and the kernel establishes them itself, O(n+m)).
-int bts_lap_enqueue_edges(const bts_lap_work *w, const int32_t *dims, int n_max, int m_max,
-                          double cost_limit, int32_t *x, int32_t *y, int fresh, hipStream_t stream);
+struct bts_lap_problem {
+    bts_lap_work w;
+    const int32_t *dims;   // device: live n, m (nullable -> n_max, m_max)
+    int n_max, m_max;
+    double limit;
+    int32_t *x, *y;
+    int fresh;
+};
+// Enqueue 1 or 2 independent problems (they share the two launches).
+int bts_lap_enqueue(const bts_lap_problem *probs, int count, hipStream_t stream);
 // reset hdr before edges are appended
 int bts_lap_enqueue_reset(const bts_lap_work *w, hipStream_t stream);
 

@@ -22,7 +22,7 @@
 
 namespace {
 
-enum { H_EDGES = 0, H_COMPS = 1, H_ERR = 2, H_HARD = 3, H_NA = 4, H_MA = 5 };   // hdr: edges, components, overflow flag,
+enum { H_EDGES = 0, H_COMPS = 1, H_ERR = 2, H_HARD = 3, H_NA = 4, H_MA = 5, H_NH = 6 };   // hdr: edges, components, overflow flag,
                                                                               // components for k_solve, active rows / columns
 
 // Every word of the work area that is the target of an atomic (or is read back after atomics) is
@@ -31,14 +31,8 @@ enum { H_EDGES = 0, H_COMPS = 1, H_ERR = 2, H_HARD = 3, H_NA = 4, H_MA = 5 };   
 #define RLX(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define RST(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 
-struct LapArgs {
-    bts_lap_work w;
-    const int32_t *dims;
-    int n_max, m_max;
-    double limit;
-    int32_t *x, *y;
-    int fresh;
-};
+typedef bts_lap_problem LapArgs;
+
 
 // Lanes of one wavefront hand values to each other through global memory (lane 0 publishes a
 // decision, every lane reads it back): drain this wave's outstanding stores/loads before going on.
@@ -87,6 +81,20 @@ __device__ int find_root(int32_t *parent, int x) {
     return x;
 }
 
+// same, for an array that no atomic ever touches
+__device__ int block_exscan_plain(int32_t *arr, int len, int32_t *tmp) {
+    const int nth = blockDim.x, tid = threadIdx.x;
+    const int per = (len + nth - 1) / nth;
+    const int lo = min(len, tid * per), hi = min(len, lo + per);
+    int s = 0;
+    for (int k = lo; k < hi; ++k) s += arr[k];
+    int total;
+    int run = bscan::exscan(s, tmp, &total);
+    for (int k = lo; k < hi; ++k) { const int v = arr[k]; arr[k] = run; run += v; }
+    __syncthreads();
+    return total;
+}
+
 // read-only walk to the root: used once every union is done, so that what it returns is final
 // (a compressing find running next to it could still move parent[] entries to non-root ancestors)
 __device__ int find_root_ro(const int32_t *parent, int x) {
@@ -120,10 +128,20 @@ __device__ int block_exscan(int32_t *arr, int len, int32_t *tmp) {
     return total;
 }
 
-// Work is proportional to the number of feasible edges E, not to n + m: only rows/columns that
-// own an edge ("active") are ever touched.  Invariant kept across calls: deg[] / cdeg[] are zero
-// outside this kernel (it clears the entries it raised before it ends).
-__global__ __launch_bounds__(1024) void k_prepare(LapArgs A) {
+// Work is proportional to the number of feasible edges E, not to n + m, and the heavy part only to
+// the edges that are NOT isolated pairs:
+//   * an edge whose row and column have degree 1 is a whole component by itself: it is matched on
+//     the spot (any feasible edge beats two dummies, cost <= limit; ties prefer the match);
+//   * the remaining "hard" edges get dense row slots, a union-find pass (components), a CSR by row
+//     and per-component row/column lists for k_solve.
+// Invariant kept across calls: deg[] / cdeg[] are zero outside this kernel.
+// Memory discipline: words that are targets of atomics (deg, cdeg, hdr, parent, crow_ptr, ccol_ptr,
+// cursor, ccur_*) are only ever touched with agent-scope atomics (RLX / RST / atomicAdd / CAS); the
+// other arrays are written once and read after a workgroup barrier with plain accesses.
+constexpr int FIRST = 0x40000000;    // "already has a slot" flag inside deg / cdeg
+
+__global__ __launch_bounds__(1024) void k_prepare(LapArgs A0, LapArgs A1) {
+    const LapArgs &A = blockIdx.x ? A1 : A0;
     __shared__ int32_t tmp[1024];
     const bts_lap_work &w = A.w;
     const int n = A.dims ? A.dims[0] : A.n_max, m = A.dims ? A.dims[1] : A.m_max;
@@ -131,83 +149,89 @@ __global__ __launch_bounds__(1024) void k_prepare(LapArgs A) {
     int E = RLX(&w.hdr[H_EDGES]);
     if ((long)E > w.e_cap) E = (int)w.e_cap;
     if (!A.fresh) {
-        for (int i = tid; i < n; i += nth) { RST(&w.deg[i], 0); RST(&A.x[i], -1); }
-        for (int j = tid; j < m; j += nth) { RST(&w.cdeg[j], 0); RST(&A.y[j], -1); }
+        for (int i = tid; i < n; i += nth) { RST(&w.deg[i], 0); A.x[i] = -1; }
+        for (int j = tid; j < m; j += nth) { RST(&w.cdeg[j], 0); A.y[j] = -1; }
         __syncthreads();
     }
     if (E == 0) return;                                   // hdr counters are already zero
-    // 1. degrees; a node seen for the first time gets a dense slot and its own union-find cell
+    // 1. degrees
+    for (int e = tid; e < E; e += nth) { atomicAdd(&w.deg[w.e_row[e]], 1); atomicAdd(&w.cdeg[w.e_col[e]], 1); }
+    __syncthreads();
+    // 2. isolated pairs are final; everything else is queued
     for (int e = tid; e < E; e += nth) {
         const int i = w.e_row[e], j = w.e_col[e];
-        if (atomicAdd(&w.deg[i], 1) == 0) {
+        if (RLX(&w.deg[i]) == 1 && RLX(&w.cdeg[j]) == 1) { A.x[i] = j; A.y[j] = i; }
+        else w.hard[atomicAdd(&w.hdr[H_NH], 1)] = e;
+    }
+    __syncthreads();
+    // (degrees of the isolated pairs go back to zero only now: the test above must see 1 for both ends)
+    for (int e = tid; e < E; e += nth) {
+        const int i = w.e_row[e], j = w.e_col[e];
+        if (A.x[i] == j && RLX(&w.deg[i]) == 1 && RLX(&w.cdeg[j]) == 1) { RST(&w.deg[i], 0); RST(&w.cdeg[j], 0); }
+    }
+    const int EH = RLX(&w.hdr[H_NH]);
+    if (EH == 0) return;
+    // 3. dense slots for the rows / columns of hard edges, union-find cells
+    for (int h = tid; h < EH; h += nth) {
+        const int e = w.hard[h], i = w.e_row[e], j = w.e_col[e];
+        if (!(atomicOr(&w.deg[i], FIRST) & FIRST)) {
             const int s = atomicAdd(&w.hdr[H_NA], 1);
-            RST(&w.arow[s], i); RST(&w.slot_of_row[i], s); RST(&w.parent[i], i);
+            w.arow[s] = i; w.slot_of_row[i] = s; RST(&w.parent[i], i);
         }
-        if (atomicAdd(&w.cdeg[j], 1) == 0) {
+        if (!(atomicOr(&w.cdeg[j], FIRST) & FIRST)) {
             const int s = atomicAdd(&w.hdr[H_MA], 1);
-            RST(&w.acol[s], j); RST(&w.parent[n + j], n + j); RST(&w.v[j], 0.0);
+            w.acol[s] = j; RST(&w.parent[n + j], n + j); w.v[j] = 0.0;
         }
     }
     __syncthreads();
-    // 2. connected components of the feasible graph
-    for (int e = tid; e < E; e += nth) unite(w.parent, w.e_row[e], n + w.e_col[e]);
+    // 4. connected components of the hard graph
+    for (int h = tid; h < EH; h += nth) { const int e = w.hard[h]; unite(w.parent, w.e_row[e], n + w.e_col[e]); }
     __syncthreads();
-    // 3. final roots (read-only walks: every union is done), component ids handed out by the roots
+    // 5. final roots (read-only walks: every union is done); the roots hand out component ids
     const int NA = RLX(&w.hdr[H_NA]), MA = RLX(&w.hdr[H_MA]);
     for (int s = tid; s < NA; s += nth) {
-        const int i = RLX(&w.arow[s]), r = find_root_ro(w.parent, i);
-        RST(&w.rootv[i], r);
-        RST(&w.rptr[s], RLX(&w.deg[i]));
+        const int i = w.arow[s], r = find_root_ro(w.parent, i);
+        w.rootv[i] = r;
+        w.rptr[s] = RLX(&w.deg[i]) & ~FIRST;
         if (r == i) {                                     // roots are rows: rows have the smaller node ids
             const int c = atomicAdd(&w.hdr[H_COMPS], 1);
-            RST(&w.comp_of[i], c); RST(&w.crow_ptr[c], 0); RST(&w.ccol_ptr[c], 0);
+            w.comp_of[i] = c; RST(&w.crow_ptr[c], 0); RST(&w.ccol_ptr[c], 0);
         }
     }
-    for (int s = tid; s < MA; s += nth) { const int j = RLX(&w.acol[s]); RST(&w.rootv[n + j], find_root_ro(w.parent, n + j)); }
+    for (int s = tid; s < MA; s += nth) { const int j = w.acol[s]; w.rootv[n + j] = find_root_ro(w.parent, n + j); }
     __syncthreads();
-    // 4. component sizes
+    // 6. component sizes
     const int C = RLX(&w.hdr[H_COMPS]);
-    for (int s = tid; s < NA; s += nth) atomicAdd(&w.crow_ptr[RLX(&w.comp_of[RLX(&w.rootv[RLX(&w.arow[s])])])], 1);
-    for (int s = tid; s < MA; s += nth) atomicAdd(&w.ccol_ptr[RLX(&w.comp_of[RLX(&w.rootv[n + RLX(&w.acol[s])])])], 1);
+    for (int s = tid; s < NA; s += nth) atomicAdd(&w.crow_ptr[w.comp_of[w.rootv[w.arow[s]]]], 1);
+    for (int s = tid; s < MA; s += nth) atomicAdd(&w.ccol_ptr[w.comp_of[w.rootv[n + w.acol[s]]]], 1);
     __syncthreads();
-    // 5. pointers
-    block_exscan(w.rptr, NA, tmp);
+    // 7. pointers
+    block_exscan_plain(w.rptr, NA, tmp);
     block_exscan(w.crow_ptr, C, tmp);
     block_exscan(w.ccol_ptr, C, tmp);
-    if (tid == 0) { RST(&w.rptr[NA], E); RST(&w.crow_ptr[C], NA); RST(&w.ccol_ptr[C], MA); }
-    for (int s = tid; s < NA; s += nth) RST(&w.cursor[s], RLX(&w.rptr[s]));
+    if (tid == 0) { w.rptr[NA] = EH; RST(&w.crow_ptr[C], NA); RST(&w.ccol_ptr[C], MA); }
+    __syncthreads();
+    for (int s = tid; s < NA; s += nth) RST(&w.cursor[s], w.rptr[s]);
     for (int c = tid; c < C; c += nth) { RST(&w.ccur_r[c], RLX(&w.crow_ptr[c])); RST(&w.ccur_c[c], RLX(&w.ccol_ptr[c])); }
     __syncthreads();
-    // 6. fills: CSR by row slot, rows / columns grouped by component
-    for (int e = tid; e < E; e += nth) {
-        const int pos = atomicAdd(&w.cursor[RLX(&w.slot_of_row[w.e_row[e]])], 1);
-        RST(&w.csr_col[pos], w.e_col[e]);
-        RST(&w.csr_cost[pos], w.e_cost[e]);
+    // 8. fills: CSR by row slot, rows / columns grouped by component; degrees back to zero
+    for (int h = tid; h < EH; h += nth) {
+        const int e = w.hard[h];
+        const int pos = atomicAdd(&w.cursor[w.slot_of_row[w.e_row[e]]], 1);
+        w.csr_col[pos] = w.e_col[e];
+        w.csr_cost[pos] = w.e_cost[e];
     }
     for (int s = tid; s < NA; s += nth) {
-        const int i = RLX(&w.arow[s]);
-        RST(&w.crows[atomicAdd(&w.ccur_r[RLX(&w.comp_of[RLX(&w.rootv[i])])], 1)], i);
-        RST(&w.deg[i], 0);                                // restore the invariant
+        const int i = w.arow[s];
+        w.crows[atomicAdd(&w.ccur_r[w.comp_of[w.rootv[i]]], 1)] = i;
+        RST(&w.deg[i], 0);
     }
     for (int s = tid; s < MA; s += nth) {
-        const int j = RLX(&w.acol[s]);
-        RST(&w.ccols[atomicAdd(&w.ccur_c[RLX(&w.comp_of[RLX(&w.rootv[n + j])])], 1)], j);
+        const int j = w.acol[s];
+        w.ccols[atomicAdd(&w.ccur_c[w.comp_of[w.rootv[n + j]]], 1)] = j;
         RST(&w.cdeg[j], 0);
     }
-    __syncthreads();
-    // 7. A component of one row and one column (by far the common case in a tracking frame) is
-    // decided here: any feasible edge beats two dummies (cost <= limit), ties prefer the match.
-    // Everything else is queued for the augmenting-path solver.
-    for (int c = tid; c < C; c += nth) {
-        const int rs = RLX(&w.crow_ptr[c]), r = RLX(&w.crow_ptr[c + 1]) - rs;
-        const int cs = RLX(&w.ccol_ptr[c]), cn = RLX(&w.ccol_ptr[c + 1]) - cs;
-        if (r == 1 && cn == 1) {
-            const int i = RLX(&w.crows[rs]), j = RLX(&w.ccols[cs]);
-            RST(&A.x[i], j); RST(&A.y[j], i);
-        } else {
-            RST(&w.comp_list[atomicAdd(&w.hdr[H_HARD], 1)], c);
-        }
-    }
+    if (tid == 0) RST(&w.hdr[H_HARD], C);                 // every component goes to k_solve
 }
 
 // ---- 3. one wavefront per component: shortest augmenting paths ----------------------------------
@@ -439,15 +463,14 @@ __device__ void solve_component(const LapArgs &A, int c, int lane) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_solve(LapArgs A) {
+__global__ __launch_bounds__(256) void k_solve(LapArgs A0, LapArgs A1) {
     __shared__ SmallLds lds[4];
+    const LapArgs &A = blockIdx.y ? A1 : A0;
     const int C = LDG(&A.w.hdr[H_HARD]);
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwave = (gridDim.x * blockDim.x) >> 6;
-    for (int q = wave; q < C; q += nwave) {
-        const int c = LDG(&A.w.comp_list[q]);
+    for (int c = wave; c < C; c += nwave)
         if (!solve_small(A, c, lane, lds[threadIdx.x >> 6])) solve_component(A, c, lane);
-    }
 }
 
 }  // namespace
@@ -465,7 +488,7 @@ static void layout(bts_lap_work *w, char *base, size_t &off, int n, int m, int64
     SLOT(crow_ptr, int32_t, n + 1); SLOT(ccol_ptr, int32_t, n + 1);
     SLOT(ccur_r, int32_t, n + 1); SLOT(ccur_c, int32_t, n + 1);
     SLOT(crows, int32_t, n); SLOT(crows_s, int32_t, n); SLOT(ccols, int32_t, m); SLOT(comp_list, int32_t, n);
-    SLOT(slot_of_row, int32_t, n); SLOT(arow, int32_t, n); SLOT(acol, int32_t, m);
+    SLOT(slot_of_row, int32_t, n); SLOT(arow, int32_t, n); SLOT(acol, int32_t, m); SLOT(hard, int32_t, e);
     SLOT(u, double, n); SLOT(v, double, m); SLOT(dist, double, m);
     SLOT(pred, int32_t, m); SLOT(scanned, int32_t, m);
 #undef SLOT
@@ -489,15 +512,18 @@ int bts_lap_enqueue_reset(const bts_lap_work *w, hipStream_t stream) {
     return BTS_OK;
 }
 
-int bts_lap_enqueue_edges(const bts_lap_work *w, const int32_t *dims, int n_max, int m_max,
-                          double cost_limit, int32_t *x, int32_t *y, int fresh, hipStream_t stream) {
-    LapArgs A{*w, dims, n_max, m_max, cost_limit, x, y, fresh};
-    hipLaunchKernelGGL(k_prepare, dim3(1), dim3(1024), 0, stream, A);
+int bts_lap_enqueue(const bts_lap_problem *probs, int count, hipStream_t stream) {
+    const bts_lap_problem &A = probs[0], &B = probs[count > 1 ? 1 : 0];
+    hipLaunchKernelGGL(k_prepare, dim3(count), dim3(1024), 0, stream, A, B);
     BTS_LAUNCH_CHECK();
-    const int waves = n_max < m_max ? n_max : m_max;   // #components <= min(n, m)
-    int blocks = bts_cdiv(waves < 1 ? 1 : waves, 4);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_solve, dim3(blocks), dim3(256), 0, stream, A);
+    int waves = 1;
+    for (int k = 0; k < count; ++k) {
+        const int w_ = probs[k].n_max < probs[k].m_max ? probs[k].n_max : probs[k].m_max;   // #components <= min(n, m)
+        if (w_ > waves) waves = w_;
+    }
+    int blocks = bts_cdiv(waves, 4);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_solve, dim3(blocks, count), dim3(256), 0, stream, A, B);
     BTS_LAUNCH_CHECK();
     return BTS_OK;
 }
@@ -514,7 +540,8 @@ int bts_lap_enqueue_dense(const bts_lap_work *w, const double *cost, int ld, con
                            cost_limit);
         BTS_LAUNCH_CHECK();
     }
-    return bts_lap_enqueue_edges(w, dims, n_max, m_max, cost_limit, x, y, 0, stream);
+    bts_lap_problem P{*w, dims, n_max, m_max, cost_limit, x, y, 0};
+    return bts_lap_enqueue(&P, 1, stream);
 }
 
 extern "C" int bts_lapjv(bts_context *ctx, const double *cost, int n, int m, int ld, double cost_limit,

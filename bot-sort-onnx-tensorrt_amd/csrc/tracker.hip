@@ -57,6 +57,9 @@ struct Dev {
     float *body_n, *face_n, *det_n, *dface_n;         // their float32 L2 norms
     float *approx;                                     // [T][Mx] split-K accumulation of the pre-filter (self-cleaning)
     float eps_body, eps_face;                          // relative error bounds of the float16 dot products
+    int32_t *cand_i, *cand_q, *cand_n;                 // appearance candidates (pool row, high-det column), count
+    int32_t *app_q;                                    // [T] pool row -> column whose stage-1 edge k_refine emitted (-1: none)
+    int cand_cap;
     // inputs of the current step
     const int32_t *boxes;
     const float *scores;
@@ -91,7 +94,7 @@ __device__ __forceinline__ void slot_tlbr(const Dev &d, int slot, double out[4])
 // ---- K1: frame prologue (1 workgroup) ---------------------------------------------------------------
 // D:1414-1423 (split tracked into confirmed / unconfirmed, pool = confirmed ++ lost) and the
 // detection records of D:1488-1532 (high: score > 0.40, low: 0.1 <= score <= 0.40; float32 boxes).
-__global__ __launch_bounds__(1024) void tk_prep(Dev d) {
+__device__ __forceinline__ void prep_body(const Dev &d) {
     __shared__ int32_t tmp[1024];
     __shared__ int s_allf32;
     int32_t *h = d.hdr;
@@ -124,6 +127,7 @@ __global__ __launch_bounds__(1024) void tk_prep(Dev d) {
                                   [&](int p, int j) { d.lo_idx[p] = j; });
     __syncthreads();
     if (tid < 48) d.lap_hdr[tid] = 0;
+    if (tid == 48 && d.filter) *d.cand_n = 0;
     if (tid == 0) {
         h[H_FRAME] += 1;
         h[H_NPOOL] = N; h[H_NCONF] = nconf; h[H_NUNC] = nunc; h[H_NHI] = nhi; h[H_NLO] = nlo; h[H_NDETS] = m;
@@ -136,17 +140,22 @@ __global__ __launch_bounds__(1024) void tk_prep(Dev d) {
 
 // ---- K2: STrack.multi_predict over the pool (D:524-536 + D:265-302) ---------------------------------
 // float16 shadows + norms of this frame's (raw) detection rows for the appearance pre-filter
-__global__ __launch_bounds__(256) void tk_cvt(Dev d) {
-    const long j = blockIdx.x;
+__device__ __forceinline__ void cvt_body(const Dev &d, long j) {
     if (j >= d.m) return;
     feat::to_half_row(d.feats + j * d.D, d.det_h + j * d.D, d.det_n + j, d.D);
     if (d.Df) feat::to_half_row(d.face_feats + j * d.Df, d.dface_h + j * d.Df, d.dface_n + j, d.Df);
 }
 
+// one launch: workgroup 0 builds the frame's lists, the others convert the detection rows
+__global__ __launch_bounds__(1024) void tk_front(Dev d) {
+    if (blockIdx.x == 0) prep_body(d);
+    else cvt_body(d, (long)blockIdx.x - 1);
+}
+
 __global__ __launch_bounds__(256) void tk_predict(Dev d) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     // the three assignment vectors start out "unmatched" (the solver only writes matches)
-    if (r < d.T) { d.x1[r] = -1; d.x2[r] = -1; d.x3[r] = -1; }
+    if (r < d.T) { d.x1[r] = -1; d.x2[r] = -1; d.x3[r] = -1; if (d.filter) d.app_q[r] = -1; }
     if (r < d.m) { d.y1[r] = -1; d.y2[r] = -1; d.y3[r] = -1; }
     if (r >= d.hdr[H_NPOOL]) return;
     const int s = d.pool_slot[r];
@@ -180,7 +189,7 @@ __device__ __forceinline__ float face_fixup(float s) {
 //         k_filter); stage 3 refines the few overlapping pairs with an exact wavefront dot product.
 // MODE 2: record only (dense cost matrix for inspection, no edges).
 template <int STAGE, int MODE>
-__global__ __launch_bounds__(CT_COLS) void tk_edges(Dev d, bts_lap_work w) {
+__device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w) {
     __shared__ double sa[CT_ROWS][4];
     __shared__ double sarea[CT_ROWS];
     __shared__ int sflag[CT_ROWS];
@@ -217,7 +226,7 @@ __global__ __launch_bounds__(CT_COLS) void tk_edges(Dev d, bts_lap_work w) {
         const double iou_d = iou::cost(aa, sflag[r] != 0, sarea[r], bb, true, area_b);
         const long o = (long)(i0 + r) * d.Mx + q;
         if (MODE == 1) {
-            if (live && iou_d <= limit) emit(i0 + r, iou_d);
+            if (live && iou_d <= limit && !(STAGE == 1 && d.app_q[i0 + r] == q)) emit(i0 + r, iou_d);
             if (STAGE == 3) {
                 // appearance can only lower the cost where the proximity gate is open (D:1600-1601):
                 // those few pairs get an exact float32 dot product computed by the whole wavefront
@@ -252,6 +261,16 @@ __global__ __launch_bounds__(CT_COLS) void tk_edges(Dev d, bts_lap_work w) {
     }
 }
 
+template <int STAGE, int MODE>
+__global__ __launch_bounds__(CT_COLS) void tk_edges(Dev d, bts_lap_work w) { edges_tile<STAGE, MODE>(d, w); }
+
+// stages 2 and 3 are independent of each other (disjoint tracks and detections): one launch, z selects
+template <int MODE3>
+__global__ __launch_bounds__(CT_COLS) void tk_edges23(Dev d, bts_lap_work w2, bts_lap_work w3) {
+    if (blockIdx.z == 0) edges_tile<2, 0>(d, w2);
+    else edges_tile<3, MODE3>(d, w3);
+}
+
 // ---- appearance pre-filter: float16 MFMA GEMM + exact float32 refine ------------------------------------------
 // Stage-1 appearance can change a cost only where  min(1 - body_sim, 1 - face_sim) <= appearance_thresh
 // (D:1543-1547), i.e. for similarities >= 0.75 -- about one pair per detection out of N*M.  So the
@@ -277,8 +296,19 @@ __device__ __forceinline__ void refine_emit1(const Dev &d, const bts_lap_work &w
     float face = 1.0f;
     if (d.Df) face = 1.0f - face_fixup(fmaxf(0.0f, feat::wave_dot(d.face_curr + s * d.Df, d.face_feats + det * d.Df, d.Df, lane)));
     if (lane == 0 && !(fminf(emb, face) > d.app) && (double)emb <= d.match1) {
+        // One edge per pair where possible: the first appearance partner of a row also carries the
+        // pair's IoU cost (np.minimum of D:1554) and the IoU tile kernel, which runs after this
+        // one, skips that pair.  Further partners of the same row fall back to a second
+        // (harmless) edge for the pair.
+        double c = (double)emb;
+        const int old = atomicCAS(&d.app_q[i], -1, q);
+        if (old == -1 || old == q) {
+            const double aa[4] = {d.pool_tlbr[i * 4 + 0], d.pool_tlbr[i * 4 + 1], d.pool_tlbr[i * 4 + 2], d.pool_tlbr[i * 4 + 3]};
+            const double bb[4] = {d.det_tlbr[det * 4 + 0], d.det_tlbr[det * 4 + 1], d.det_tlbr[det * 4 + 2], d.det_tlbr[det * 4 + 3]};
+            c = fmin(c, iou::cost(aa, false, iou::area(aa, false), bb, true, iou::area(bb, true)));
+        }
         const int pos = atomicAdd(&w.hdr[0], 1);
-        if (pos < w.e_cap) { w.e_row[pos] = i; w.e_col[pos] = q; w.e_cost[pos] = (double)emb; }
+        if (pos < w.e_cap) { w.e_row[pos] = i; w.e_col[pos] = q; w.e_cost[pos] = c; }
         else w.hdr[2] = 1;
     }
 }
@@ -391,50 +421,53 @@ __global__ __launch_bounds__(256) void k_filter(Dev d, bts_lap_work w, int m_max
                 }
             }
         }
-    if (split || __ballot(cmask != 0) == 0) return;
+    if (split || cmask == 0) return;
     for (int b = 0; b < 64; ++b) {       // rare: about one candidate per detection column
-        unsigned long long todo = __ballot((cmask >> b) & 1);
+        if (!((cmask >> b) & 1)) continue;
         const int t4 = b >> 4, r = b & 15, mi = t4 >> 1, ni = t4 & 1;
-        while (todo) {
-            const int src = __ffsll((long long)todo) - 1;
-            todo &= todo - 1;
-            const int i = bm * FBM + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (src >> 5);
-            const int q = bn * FBN + wc * 64 + ni * 32 + (src & 31);
-            refine_emit1(d, w, i, q, lane);
-        }
+        const int i = bm * FBM + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        const int q = bn * FBN + wc * 64 + ni * 32 + frow;
+        const int pos = atomicAdd(d.cand_n, 1);
+        if (pos < d.cand_cap) { d.cand_i[pos] = i; d.cand_q[pos] = q; }
     }
 }
 
 // split-K form: the partial products were accumulated into `approx`; scan it (and clear it for the
 // next frame), refine the candidates.
 template <bool FACE>
-__global__ __launch_bounds__(CT_COLS) void k_filter_scan(Dev d, bts_lap_work w) {
+__global__ __launch_bounds__(CT_COLS) void k_filter_scan(Dev d) {
     const int n = d.hdr[H_NPOOL], m = d.hdr[H_NHI];
     const int i0 = blockIdx.y * CT_ROWS, q = blockIdx.x * CT_COLS + threadIdx.x;
-    if (i0 >= n || blockIdx.x * CT_COLS >= m) return;
-    const int lane = threadIdx.x & 63;
+    if (i0 >= n || q >= m) return;
     const float *na = FACE ? d.face_n : d.body_n, *nb = FACE ? d.dface_n : d.det_n;
     const float eps = FACE ? d.eps_face : d.eps_body, gate = 1.0f - d.app;
-    const bool live = q < m;
-    const float nbq = live ? nb[d.hi_idx[q]] : 0.0f;
+    const float nbq = nb[d.hi_idx[q]];
     const int rows = min(CT_ROWS, n - i0);
     for (int r = 0; r < rows; ++r) {
         const int i = i0 + r;
-        float val = 0.0f;
-        if (live) { float *p = &d.approx[(long)i * d.Mx + q]; val = *p; *p = 0.0f; }
-        unsigned long long todo = __ballot(live && is_candidate(val, na[d.pool_slot[i]], nbq, gate, eps));
-        while (todo) {
-            const int src = __ffsll((long long)todo) - 1;
-            todo &= todo - 1;
-            refine_emit1(d, w, i, __shfl(q, src), lane);
+        float *p = &d.approx[(long)i * d.Mx + q];
+        const float val = *p;
+        *p = 0.0f;
+        if (is_candidate(val, na[d.pool_slot[i]], nbq, gate, eps)) {
+            const int pos = atomicAdd(d.cand_n, 1);
+            if (pos < d.cand_cap) { d.cand_i[pos] = i; d.cand_q[pos] = q; }
         }
     }
 }
 
+// one wavefront per candidate: exact float32 similarity, the D:1543-1547 gate, edge emission
+__global__ __launch_bounds__(256) void k_refine(Dev d, bts_lap_work w) {
+    int nc = *d.cand_n;
+    if (nc > d.cand_cap) { nc = d.cand_cap; if (threadIdx.x == 0 && blockIdx.x == 0) d.hdr[H_ERR] |= ERR_LAP_EDGES; }
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwave = (gridDim.x * blockDim.x) >> 6;
+    for (int k = wave; k < nc; k += nwave) refine_emit1(d, w, d.cand_i[k], d.cand_q[k], lane);
+}
+
 // ---- detection feature rows: in-place renormalisation (quirk Q8) ------------------------------------------
-__global__ __launch_bounds__(256) void tk_renorm(Dev d) {
+__device__ __forceinline__ void renorm_body(const Dev &d, int q) {
     const int32_t *h = d.hdr;
-    const int nhi = h[H_NHI], nlo = h[H_NLO], q = blockIdx.x;
+    const int nhi = h[H_NHI], nlo = h[H_NLO];
     if (q >= nhi + nlo) return;
     const long det = q < nhi ? d.hi_idx[q] : d.lo_idx[q - nhi];
     feat::renorm_row(d.feats + det * d.D, d.D);
@@ -445,7 +478,7 @@ __global__ __launch_bounds__(256) void tk_renorm(Dev d) {
 // the state in registers.  FEAT=true: ReID feature bookkeeping, one workgroup per row.  (Two launches:
 // the Kalman part needs the whole register file, the feature part wants occupancy.) ---------------------
 template <int STAGE, bool FEAT>
-__global__ __launch_bounds__(256) void tk_apply(Dev d) {
+__device__ __forceinline__ void apply_body(const Dev &d) {
     const int32_t *h = d.hdr;
     const int n = STAGE == 1 ? h[H_NPOOL] : STAGE == 2 ? h[H_NR2] : h[H_NUNC];
     const int32_t *rslot = STAGE == 1 ? d.pool_slot : STAGE == 2 ? d.r2_slot : d.unc_slot;
@@ -499,8 +532,17 @@ __global__ __launch_bounds__(256) void tk_apply(Dev d) {
     d.det_index[s] = det;
 }
 
+template <int STAGE, bool FEAT>
+__global__ __launch_bounds__(256) void tk_apply(Dev d) { apply_body<STAGE, FEAT>(d); }
+
+template <bool FEAT>
+__global__ __launch_bounds__(256) void tk_apply23(Dev d) {
+    if (blockIdx.y == 0) apply_body<2, FEAT>(d);
+    else apply_body<3, FEAT>(d);
+}
+
 // ---- after stage 1: rows of stage 2, columns of stage 3 (1 workgroup) ------------------------------------
-__global__ __launch_bounds__(1024) void tk_after1(Dev d) {
+__device__ __forceinline__ void after1_body(const Dev &d) {
     __shared__ int32_t tmp[1024];
     int32_t *h = d.hdr;
     const int N = h[H_NPOOL], nhi = h[H_NHI], nunc = h[H_NUNC];
@@ -524,6 +566,12 @@ __global__ __launch_bounds__(1024) void tk_after1(Dev d) {
         h[H_NR2] = nr2; h[H_NLEFT] = nleft;
         h[H_DIMS2] = nr2; h[H_DIMS3 + 1] = nleft;
     }
+}
+
+// one launch after the first assignment: workgroup 0 prepares stages 2/3, the others renormalise rows
+__global__ __launch_bounds__(1024) void tk_mid1(Dev d) {
+    if (blockIdx.x == 0) after1_body(d);
+    else renorm_body(d, (int)blockIdx.x - 1);
 }
 
 // ---- births + list merge (1 workgroup), D:1614-1636 ----------------------------------------------------------
@@ -714,7 +762,8 @@ struct bts_tracker {
     bts_context *ctx = nullptr;
     bts_tracker_config cfg;
     Dev dv;
-    bts_lap_work lap;
+    bts_lap_work lap;      // stages 1 and 2 (sequential)
+    bts_lap_work lap3;     // stage 3 runs next to stage 2: its own work area
     char *block = nullptr;
     size_t bytes = 0;
     // export staging
@@ -757,6 +806,7 @@ static void tracker_layout(bts_tracker *t, char *base, size_t &off) {
         SLOT(d.body_h, _Float16, T * D); SLOT(d.det_h, _Float16, M * D); SLOT(d.body_n, float, T); SLOT(d.det_n, float, M);
         SLOT(d.face_h, _Float16, T * Df); SLOT(d.dface_h, _Float16, M * Df); SLOT(d.face_n, float, T); SLOT(d.dface_n, float, M);
         SLOT(d.approx, float, T * M);
+        SLOT(d.cand_i, int32_t, T * M); SLOT(d.cand_q, int32_t, T * M); SLOT(d.cand_n, int32_t, 4); SLOT(d.app_q, int32_t, T);
     }
     SLOT(t->x_ints, int32_t, 8 * T); SLOT(t->x_mean, double, 8 * T); SLOT(t->x_tlbr, double, 4 * T); SLOT(t->x_score, float, T);
 #undef SLOT
@@ -795,12 +845,15 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
     d.record = cfg->record_costs ? 1 : 0;
     // the float16 pre-filter needs 16-byte rows of halves; otherwise the dense float32 form is used
     d.filter = (cfg->appearance_mode == BTS_APPEARANCE_FILTER && d.D % 8 == 0 && d.Df % 8 == 0) ? 1 : 0;
+    d.cand_cap = (int)((int64_t)d.T * d.Mx);
     d.eps_body = 1.1f / 1024.0f + (float)d.D / 4194304.0f;
     d.eps_face = 1.1f / 1024.0f + (float)d.Df / 4194304.0f;
     size_t off = 0;
     tracker_layout(t, nullptr, off);
     const int64_t e_cap = (int64_t)d.T * d.Mx;
     const size_t lap_off = off;
+    off += bts_lap_work_bytes(d.T, d.Mx, e_cap);
+    const size_t lap3_off = off;
     off += bts_lap_work_bytes(d.T, d.Mx, e_cap);
     t->bytes = off;
     if (hipMalloc((void **)&t->block, t->bytes) != hipSuccess) {
@@ -812,6 +865,7 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
     off = 0;
     tracker_layout(t, t->block, off);
     bts_lap_work_carve(&t->lap, t->block + lap_off, d.T, d.Mx, e_cap);
+    bts_lap_work_carve(&t->lap3, t->block + lap3_off, d.T, d.Mx, e_cap);
     if (hipHostMalloc((void **)&t->host_hdr, H_SIZE * sizeof(int32_t)) != hipSuccess) {
         (void)hipGetLastError();
         (void)hipFree(t->block);
@@ -903,18 +957,17 @@ int bts_tracker_step(bts_tracker *t, const int32_t *boxes, const float *scores, 
     const int cos_kernel = t->ctx->cos_kernel;
     const dim3 tile_grid(bts_cdiv(mc, CT_COLS), bts_cdiv(T, CT_ROWS));
     const int kf_blocks = bts_cdiv(T, 256);
-    bts_lap_work lap[3] = {t->lap, t->lap, t->lap};
+    bts_lap_work lap[3] = {t->lap, t->lap, t->lap3};
     for (int k = 0; k < 3; ++k) lap[k].hdr = d.lap_hdr + 16 * k;
     int rc;
 #define LAUNCH(kern, grid, block, ...) hipLaunchKernelGGL(kern, grid, block, 0, s, d, ##__VA_ARGS__); BTS_LAUNCH_CHECK()
 
     seg_begin(BTS_SEG_STEP);
     seg_begin(BTS_SEG_PREP);
-    LAUNCH(tk_prep, dim3(1), dim3(1024));
+    LAUNCH(tk_front, dim3(1 + (d.filter ? mc : 0)), dim3(1024));
     seg_end(BTS_SEG_PREP);
     seg_begin(BTS_SEG_PREDICT);
     LAUNCH(tk_predict, dim3(kf_blocks), dim3(256));
-    if (d.filter) { LAUNCH(tk_cvt, dim3(mc), dim3(256)); }
     seg_end(BTS_SEG_PREDICT);
     const bool dense = !d.filter || d.record;
     // split-K factor of the pre-filter: small problems have too few 128x128 tiles to fill 256 CUs
@@ -938,12 +991,13 @@ int bts_tracker_step(bts_tracker *t, const int32_t *boxes, const float *scores, 
     }
     if (d.filter) {
         LAUNCH(k_filter<false>, filt_grid, dim3(256), lap[0], mc);
-        if (split > 1) { LAUNCH(k_filter_scan<false>, tile_grid, dim3(CT_COLS), lap[0]); }
+        if (split > 1) { LAUNCH(k_filter_scan<false>, tile_grid, dim3(CT_COLS)); }
         if (d.Df) {
             const int fsplit = split < bts_cdiv(d.Df, FBK) ? split : bts_cdiv(d.Df, FBK);
             LAUNCH(k_filter<true>, dim3(filt_grid.x, fsplit), dim3(256), lap[0], mc);
-            if (fsplit > 1) { LAUNCH(k_filter_scan<true>, tile_grid, dim3(CT_COLS), lap[0]); }
+            if (fsplit > 1) { LAUNCH(k_filter_scan<true>, tile_grid, dim3(CT_COLS)); }
         }
+        LAUNCH(k_refine, dim3(bts_cdiv(mc, 2) < 1024 ? bts_cdiv(mc, 2) : 1024), dim3(256), lap[0]);
     }
     seg_end(BTS_SEG_COS1);
     seg_begin(BTS_SEG_COST1);
@@ -955,41 +1009,37 @@ int bts_tracker_step(bts_tracker *t, const int32_t *boxes, const float *scores, 
     }
     seg_end(BTS_SEG_COST1);
     seg_begin(BTS_SEG_LAP1);
-    rc = bts_lap_enqueue_edges(&lap[0], d.hdr + H_DIMS1, T, mc, d.match1, d.x1, d.y1, 1, s);
+    bts_lap_problem prob[3] = {{lap[0], d.hdr + H_DIMS1, T, mc, d.match1, d.x1, d.y1, 1},
+                               {lap[1], d.hdr + H_DIMS2, T, mc, d.match2, d.x2, d.y2, 1},
+                               {lap[2], d.hdr + H_DIMS3, T, mc, d.match3, d.x3, d.y3, 1}};
+    rc = bts_lap_enqueue(&prob[0], 1, s);
     if (rc) return rc;
     seg_end(BTS_SEG_LAP1);
     seg_begin(BTS_SEG_APPLY1);
-    LAUNCH(tk_renorm, dim3(mc), dim3(256));
-    LAUNCH(tk_after1, dim3(1), dim3(1024));          // reads pre-update states: before tk_apply<1>
+    LAUNCH(tk_mid1, dim3(1 + mc), dim3(1024));       // stage-2/3 lists read pre-update states: before tk_apply<1>
     LAUNCH((tk_apply<1, false>), dim3(kf_blocks), dim3(256));
     LAUNCH((tk_apply<1, true>), dim3(T), dim3(256));
     seg_end(BTS_SEG_APPLY1);
-    // ---- second association: remaining tracked rows x low-score detections
+    // ---- second association (remaining tracked rows x low-score detections) and the unconfirmed
+    //      tracks (x leftover high-score detections): independent problems, shared launches
     seg_begin(BTS_SEG_STAGE2);
-    LAUNCH((tk_edges<2, 0>), tile_grid, dim3(CT_COLS), lap[1]);
-    rc = bts_lap_enqueue_edges(&lap[1], d.hdr + H_DIMS2, T, mc, d.match2, d.x2, d.y2, 1, s);
-    if (rc) return rc;
-    LAUNCH((tk_apply<2, false>), dim3(kf_blocks), dim3(256));
-    LAUNCH((tk_apply<2, true>), dim3(T), dim3(256));
-    seg_end(BTS_SEG_STAGE2);
-    // ---- unconfirmed tracks x leftover high-score detections
-    seg_begin(BTS_SEG_STAGE3);
     if (dense) {
         rc = bts_cos_enqueue(cos_kernel, d.body_curr, d.unc_slot, d.D, feats, d.left_det, d.D, d.D, d.hdr + H_DIMS3, T, mc,
                              d.sim, M, s);
         if (rc) return rc;
     }
+    const dim3 tile_grid2(tile_grid.x, tile_grid.y, 2);
     if (d.filter) {
-        LAUNCH((tk_edges<3, 1>), tile_grid, dim3(CT_COLS), lap[2]);
+        LAUNCH(tk_edges23<1>, tile_grid2, dim3(CT_COLS), lap[1], lap[2]);
         if (d.record) { LAUNCH((tk_edges<3, 2>), tile_grid, dim3(CT_COLS), lap[2]); }
     } else {
-        LAUNCH((tk_edges<3, 0>), tile_grid, dim3(CT_COLS), lap[2]);
+        LAUNCH(tk_edges23<0>, tile_grid2, dim3(CT_COLS), lap[1], lap[2]);
     }
-    rc = bts_lap_enqueue_edges(&lap[2], d.hdr + H_DIMS3, T, mc, d.match3, d.x3, d.y3, 1, s);
+    rc = bts_lap_enqueue(&prob[1], 2, s);
     if (rc) return rc;
-    LAUNCH((tk_apply<3, false>), dim3(kf_blocks), dim3(256));
-    LAUNCH((tk_apply<3, true>), dim3(T), dim3(256));
-    seg_end(BTS_SEG_STAGE3);
+    LAUNCH(tk_apply23<false>, dim3(kf_blocks, 2), dim3(256));
+    LAUNCH(tk_apply23<true>, dim3(T, 2), dim3(256));
+    seg_end(BTS_SEG_STAGE2);
     // ---- births, list merge, duplicate removal
     seg_begin(BTS_SEG_MERGE);
     LAUNCH(tk_merge, dim3(1), dim3(1024));
