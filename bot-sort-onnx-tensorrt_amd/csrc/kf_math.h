@@ -170,3 +170,77 @@ __device__ __forceinline__ void mean_to_tlbr(const double m[8], bool f32, double
 }
 
 }  // namespace kf
+
+// ---- eight lanes per track -------------------------------------------------------------------------
+// Lane i of an aligned 8-lane group owns row i of the 8x8 covariance (8 doubles) and element i of
+// the mean: a track's 64+8 doubles are one contiguous, fully coalesced HBM row, the per-lane
+// register footprint is ~1/8 of the one-thread-per-track form, and the dependent float64 chains
+// (Cholesky, solves, K S K^T) are ~8x shorter.  Cross-row terms travel by __shfl inside the group.
+// The arithmetic is the same sequence of operations as kf::predict / kf::update above (so the
+// results are bit-identical to them).
+namespace kf8 {
+
+__device__ __forceinline__ double grp(double v, int src) { return __shfl(v, src, 8); }
+
+__device__ __forceinline__ void predict(double &mi, double Pr[8], int i, bool f32) {
+    const double w = grp(mi, 2), h = grp(mi, 3);
+    const double wh = (i & 1) ? h : w;                         // row i's noise uses w for even, h for odd i
+    const double q = kf::sq_scaled(i < 4 ? kf::W_POS : kf::W_VEL, wh, f32);
+    const double up = grp(mi, (i + 4) & 7);
+    if (i < 4) mi = mi + up;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {                              // left = F P : rows 0..3 += rows 4..7
+        const double lower = grp(Pr[j], (i + 4) & 7);
+        if (i < 4) Pr[j] = Pr[j] + lower;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Pr[j] = Pr[j] + Pr[j + 4];     // left F^T : cols 0..3 += cols 4..7
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (j == i) Pr[j] += q;
+}
+
+__device__ __forceinline__ void update(double &mi, double Pr[8], int i, const float z[4], bool f32) {
+    double S[16], L[16];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) S[a * 4 + b] = grp(Pr[b], a);
+    const double w = grp(mi, 2), h = grp(mi, 3);
+    const double r_w = kf::sq_scaled(kf::W_POS, w, f32), r_h = kf::sq_scaled(kf::W_POS, h, f32);
+    S[0] += r_w; S[5] += r_h; S[10] += r_w; S[15] += r_h;
+    kf::chol4(S, L);
+    double K[4] = {Pr[0], Pr[1], Pr[2], Pr[3]};                // row i of P H^T -> row i of the gain
+    kf::chol4_solve(L, K);
+    double y[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) y[a] = (double)z[a] - grp(mi, a);
+    double s = 0.0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) s += y[a] * K[a];
+    mi = mi + s;
+    double KS[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        double t = 0.0;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) t += K[a] * S[a * 4 + b];
+        KS[b] = t;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        double t = 0.0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) t += KS[b] * grp(K[b], j);
+        Pr[j] = Pr[j] - t;
+    }
+}
+
+// STrack.tlbr from the group's mean; every lane gets the box
+__device__ __forceinline__ void tlbr(double mi, bool f32, double out[4]) {
+    double m[8];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) m[c] = grp(mi, c);
+    kf::mean_to_tlbr(m, f32, out);
+}
+
+}  // namespace kf8

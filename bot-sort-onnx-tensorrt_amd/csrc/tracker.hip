@@ -2,7 +2,7 @@
 // demo_bottrack_onnx_tflite.py:1414-1639) as a chain of kernel enqueues with NO host round trip.
 //
 // State lives in HBM in a slot-indexed structure-of-arrays track table (DESIGN.md "data layout"):
-//   mean[8][T], cov[64][T]      float64, component-major -> lane t touches address base+t: coalesced
+//   mean[T][8], cov[T][64]      float64 rows: 8 lanes own one track, a wavefront reads 8 contiguous 576-B rows
 //   body_curr/smooth[T][D]      float32 ReID rows (the matcher reads `curr`, quirk Q1)
 //   state/ids/frame counters[T] int32
 //   tracked[], lost[]           ordered slot lists = the reference's tracked_stracks / lost_stracks
@@ -74,20 +74,33 @@ __device__ __forceinline__ int block_exscan_i(int v, int32_t *tmp, int *total) {
 
 __device__ __forceinline__ void load_state(const Dev &d, int slot, double m[8], double P[64]) {
 #pragma unroll
-    for (int c = 0; c < 8; ++c) m[c] = d.mean[(long)c * d.T + slot];
+    for (int c = 0; c < 8; ++c) m[c] = d.mean[(long)slot * 8 + c];
 #pragma unroll
-    for (int c = 0; c < 64; ++c) P[c] = d.cov[(long)c * d.T + slot];
+    for (int c = 0; c < 64; ++c) P[c] = d.cov[(long)slot * 64 + c];
 }
 __device__ __forceinline__ void store_state(const Dev &d, int slot, const double m[8], const double P[64]) {
 #pragma unroll
-    for (int c = 0; c < 8; ++c) d.mean[(long)c * d.T + slot] = m[c];
+    for (int c = 0; c < 8; ++c) d.mean[(long)slot * 8 + c] = m[c];
 #pragma unroll
-    for (int c = 0; c < 64; ++c) d.cov[(long)c * d.T + slot] = P[c];
+    for (int c = 0; c < 64; ++c) d.cov[(long)slot * 64 + c] = P[c];
+}
+// 8-lane form: lane i of the group holds element i of the mean and row i of the covariance
+__device__ __forceinline__ void load_row(const Dev &d, int slot, int i, double &mi, double Pr[8]) {
+    mi = d.mean[(long)slot * 8 + i];
+    const double2 *p = reinterpret_cast<const double2 *>(d.cov + (long)slot * 64 + i * 8);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const double2 v = p[j]; Pr[2 * j] = v.x; Pr[2 * j + 1] = v.y; }
+}
+__device__ __forceinline__ void store_row(const Dev &d, int slot, int i, double mi, const double Pr[8]) {
+    d.mean[(long)slot * 8 + i] = mi;
+    double2 *p = reinterpret_cast<double2 *>(d.cov + (long)slot * 64 + i * 8);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p[j] = make_double2(Pr[2 * j], Pr[2 * j + 1]);
 }
 __device__ __forceinline__ void slot_tlbr(const Dev &d, int slot, double out[4]) {
     double m[8];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) m[c] = d.mean[(long)c * d.T + slot];
+    for (int c = 0; c < 4; ++c) m[c] = d.mean[(long)slot * 8 + c];
     kf::mean_to_tlbr(m, d.f32[slot] != 0, out);
 }
 
@@ -153,22 +166,22 @@ __global__ __launch_bounds__(1024) void tk_front(Dev d) {
 }
 
 __global__ __launch_bounds__(256) void tk_predict(Dev d) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
     // the three assignment vectors start out "unmatched" (the solver only writes matches)
-    if (r < d.T) { d.x1[r] = -1; d.x2[r] = -1; d.x3[r] = -1; if (d.filter) d.app_q[r] = -1; }
-    if (r < d.m) { d.y1[r] = -1; d.y2[r] = -1; d.y3[r] = -1; }
+    if (g < d.T) { d.x1[g] = -1; d.x2[g] = -1; d.x3[g] = -1; if (d.filter) d.app_q[g] = -1; }
+    if (g < d.m) { d.y1[g] = -1; d.y2[g] = -1; d.y3[g] = -1; }
+    const int r = g >> 3, i = g & 7;                     // 8 lanes per pool row
     if (r >= d.hdr[H_NPOOL]) return;
     const int s = d.pool_slot[r];
-    double m[8], P[64];
-    load_state(d, s, m, P);
-    if (d.state[s] != BTS_TRACKED) { m[6] = 0.0; m[7] = 0.0; }
-    kf::predict(m, P, d.hdr[H_ALLF32] != 0);   // a batch is float32 only if every row is (np.asarray)
-    store_state(d, s, m, P);
-    d.f32[s] = 0;
+    double mi, Pr[8];
+    load_row(d, s, i, mi, Pr);
+    if (i >= 6 && d.state[s] != BTS_TRACKED) mi = 0.0;   // D:529-532
+    kf8::predict(mi, Pr, i, d.hdr[H_ALLF32] != 0);       // a batch is float32 only if every row is (np.asarray)
+    store_row(d, s, i, mi, Pr);
     double b[4];
-    kf::mean_to_tlbr(m, false, b);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) d.pool_tlbr[r * 4 + c] = b[c];
+    kf8::tlbr(mi, false, b);
+    if (i < 4) d.pool_tlbr[r * 4 + i] = b[i];
+    if (i == 0) d.f32[s] = 0;
 }
 
 // ---- cost tiles ----------------------------------------------------------------------------------------
@@ -502,21 +515,25 @@ __device__ __forceinline__ void apply_body(const Dev &d) {
         if (threadIdx.x == 0) { d.has_body[s] = 1; if (d.Df) d.has_face[s] = 1; }
         return;
     }
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;      // ---- Kalman + lifecycle
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;      // ---- Kalman + lifecycle: 8 lanes per row
+    const int r = g >> 3, i = g & 7;
     if (r >= n) return;
     const int s = rslot[r];
     const int xq = xs[r];
     if (xq < 0) {
-        if (STAGE == 2) { d.state[s] = BTS_LOST; d.flag[s] |= F_LOSTNOW; }                 // D:1582-1586
-        if (STAGE == 3) { d.state[s] = BTS_REMOVED; d.flag[s] |= F_REMOVEDNOW; }           // D:1609-1612
+        if (i == 0) {
+            if (STAGE == 2) { d.state[s] = BTS_LOST; d.flag[s] |= F_LOSTNOW; }                 // D:1582-1586
+            if (STAGE == 3) { d.state[s] = BTS_REMOVED; d.flag[s] |= F_REMOVEDNOW; }           // D:1609-1612
+        }
         return;
     }
     const int det = cdet[xq];
     const float z[4] = {d.det_xywh[det * 4 + 0], d.det_xywh[det * 4 + 1], d.det_xywh[det * 4 + 2], d.det_xywh[det * 4 + 3]};
-    double m[8], P[64];
-    load_state(d, s, m, P);
-    kf::update(m, P, z, d.f32[s] != 0);
-    store_state(d, s, m, P);
+    double mi, Pr[8];
+    load_row(d, s, i, mi, Pr);
+    kf8::update(mi, Pr, i, z, d.f32[s] != 0);
+    store_row(d, s, i, mi, Pr);
+    if (i != 0) return;
     d.f32[s] = 0;
     const int frame = h[H_FRAME];
     if (d.state[s] == BTS_TRACKED) {
@@ -748,7 +765,7 @@ __global__ __launch_bounds__(256) void tk_export(Dev d, int which, int32_t *ints
     ints[k * 8 + 0] = d.track_id[s]; ints[k * 8 + 1] = d.state[s]; ints[k * 8 + 2] = d.is_activated[s];
     ints[k * 8 + 3] = d.frame_id[s]; ints[k * 8 + 4] = d.start_frame[s]; ints[k * 8 + 5] = d.tracklet_len[s];
     ints[k * 8 + 6] = d.det_index[s]; ints[k * 8 + 7] = s;
-    for (int c = 0; c < 8; ++c) mean[k * 8 + c] = d.mean[(long)c * d.T + s];
+    for (int c = 0; c < 8; ++c) mean[k * 8 + c] = d.mean[(long)s * 8 + c];
     double b[4];
     slot_tlbr(d, s, b);
     for (int c = 0; c < 4; ++c) tlbr[k * 4 + c] = b[c];
@@ -956,7 +973,7 @@ int bts_tracker_step(bts_tracker *t, const int32_t *boxes, const float *scores, 
     const int mc = m > 0 ? m : 1;                 // host-known bound on every detection-indexed extent
     const int cos_kernel = t->ctx->cos_kernel;
     const dim3 tile_grid(bts_cdiv(mc, CT_COLS), bts_cdiv(T, CT_ROWS));
-    const int kf_blocks = bts_cdiv(T, 256);
+    const int kf_blocks = bts_cdiv(T * 8 > M ? T * 8 : M, 256);   // 8 lanes per track
     bts_lap_work lap[3] = {t->lap, t->lap, t->lap3};
     for (int k = 0; k < 3; ++k) lap[k].hdr = d.lap_hdr + 16 * k;
     int rc;
