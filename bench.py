@@ -31,7 +31,13 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+F16_MFMA_PEAK_TF = 2500.0      # dense f16/bf16 MFMA peak (not the 2:1-sparse headline)
 F32_MFMA_PEAK_TF = 157.3       # dense f32-input MFMA peak (= f32 vector peak)
+SEGMENTS = ("prep", "predict", "cos1", "cost1", "lap1", "apply1", "stage2", "merge", "dedupe")   # launch groups of a step
+KERNELS = {   # single kernels that can dominate a step -> name in the rocprofv3 kernel trace
+    "k_filter": "k_filter<false>", "k_lap_prepare": "k_prepare", "k_lap_solve": "k_solve", "k_edges1": "tk_edges<1,*>",
+    "predict": "tk_predict", "k_apply_kf1": "tk_apply<1,false>", "k_apply_feat1": "tk_apply<1,true>",
+}
 
 
 def parse():
@@ -40,34 +46,31 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="c2")
-    ap.add_argument("--segment", default="auto", help="kernel group timed for the roofline object")
+    ap.add_argument("--segment", default="auto", help="kernel timed for the roofline object (auto = the dominant one)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--breakdown", action="store_true", help="print a per-segment timing table to stderr")
+    ap.add_argument("--dense", action="store_true", help="dense float32 appearance path instead of the f16 pre-filter")
+    ap.add_argument("--breakdown", action="store_true", help="also report the per-segment timing table")
     return ap.parse_args()
 
 
-def segment_model(seg, K, M, D):
-    """Algorithmic work of one launch group for a steady-state frame (pool N = K rows, M detections of
-    which 7/8 are high-score, ~M matches): (bound, amount, unit-of-amount). DESIGN.md 'kernels'."""
-    N, Mh, Ml, Km = K, M - M // 8, M // 8, M
-    if seg == "cos1":       # 2*N*Mh*D flop; operands read once, similarity written once
-        return "mfma", 2.0 * N * Mh * D, "flop"
+def kernel_model(kern, K, M, D, dense):
+    """Algorithmic work of ONE launch of a kernel in a steady-state frame (pool N = K rows, M detections,
+    7/8 of them high-score, ~M matches, ~1.2 feasible edges per detection): (bound, amount, unit, peak).
+    Formulas: DESIGN.md section 3."""
+    N, Mh, Km = K, M - M // 8, M - M // 8
+    E = int(1.2 * Mh)
+    if kern == "k_filter":     # appearance contraction 2*N*Mh*D flop on the f16 matrix cores
+        return "mfma", 2.0 * N * Mh * D, "flop", F16_MFMA_PEAK_TF
     table = {
-        "prep": (N + M) * 16 + M * 48,
-        "predict": 2 * N * 72 * 8 + N * 32,
-        "cost1": N * Mh * (4 + 8) + (N + Mh) * 32,
-        "lap1": N * Mh * 8 + (N + Mh) * 4,
-        "apply1": Km * (2 * 72 + 4) * 8 + 4 * Km * D * 4 + 2 * M * D * 4,
-        "stage2": (N - Km) * Ml * 16,
-        "stage3": 0,
-        "merge": (N + M) * 16,
-        "dedupe": (N + M) * 40,
+        "predict": 2 * N * 72 * 8 + N * 32,                     # each state row read + written once, box written
+        "k_apply_kf1": Km * (2 * 72 + 4) * 8,                   # matched rows read + written, measurement read
+        "k_apply_feat1": Km * D * (4 + 4 + 4 + 4 + 2),          # det row, smooth r+w, curr w, f16 shadow w
+        "k_edges1": (N + Mh) * 32 + E * 16,                     # boxes in, sparse edges out (N*Mh IoU tests are compute)
+        "k_lap_prepare": E * (16 + 16) + 8 * Mh,                # edge list in, CSR/groups out, isolated pairs written
+        "k_lap_solve": E * 16 + 8 * Mh,
     }
-    # whole step: SURVEY.md 8(d) formula with f64 Kalman/cost, f32 features
-    table["step"] = (2 * N * 72 * 8 + Km * (2 * 72 + 4) * 8 + (N + M) * 16 + (N + M) * D * 4 + 2 * N * M * 8
-                     + 4 * Km * D * 4 + 4 * (N + M))
-    return "hbm", float(table[seg]), "byte"
+    return "hbm", float(table[kern]), "byte", HBM_PEAK_GBS
 
 
 def cpu_baseline(pkg, K, M, D, seed, budget_s):
@@ -108,6 +111,10 @@ def cpu_baseline(pkg, K, M, D, seed, budget_s):
                       % (n, n + 1, t_used, os.cpu_count() or 0)}
 
 
+def ms_seed(pkg, rank):
+    return pkg.multistream.stream_seed(1234, rank)      # one independent video stream per GPU
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -122,99 +129,76 @@ def main():
     torch.cuda.set_device(local % torch.cuda.device_count())
     pkg = importlib.import_module("bot-sort-onnx-tensorrt_amd")
     K, M, D = pkg.synth.CONFIGS[a.workload]
-    seed = 1234 + rank                       # one independent video stream per GPU
-    n_frames = a.warmup + a.steps
     assert a.warmup >= 3, "warmup must cover the two pool-building frames"
 
-    st = pkg.synth.SyntheticStream(K, M, D, seed=seed)
-    frames = []
-    for _ in range(n_frames):
+    st = pkg.synth.SyntheticStream(K, M, D, seed=ms_seed(pkg, rank))
+    PROBE = 6
+
+    def next_frame():
         fr = st.next()
-        frames.append((torch.from_numpy(fr.boxes).cuda(), torch.from_numpy(fr.scores).cuda(),
-                       torch.from_numpy(fr.feats).cuda()))
-    trk = pkg.DeviceTracker(max_tracks=K + 64, max_dets=max(K, M), feat_dim=D, device=torch.cuda.current_device())
+        return (torch.from_numpy(fr.boxes).cuda(), torch.from_numpy(fr.scores).cuda(), torch.from_numpy(fr.feats).cuda())
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
+    frames = [next_frame() for _ in range(a.warmup)]
+    trk = pkg.DeviceTracker(max_tracks=K + 64, max_dets=max(K, M), feat_dim=D, device=torch.cuda.current_device(),
+                            appearance_mode=1 if a.dense else 0)
 
-    segment = a.segment
-    if segment == "auto":
-        # choose the dominant kernel group from a short untimed probe after the pool exists
-        segment = "cos1"
+    ms = importlib.import_module("bot-sort-onnx-tensorrt_amd.multistream")
+    ddist = dist if world > 1 else None
+
     for k in range(a.warmup):
         trk.step(*frames[k])
     torch.cuda.synchronize()
-    if a.segment == "auto" or a.breakdown:
-        probe = {}
-        snapshot = frames[a.warmup:a.warmup + min(8, a.steps)]
-        for seg in ("prep", "predict", "cos1", "cost1", "lap1", "apply1", "stage2", "stage3", "merge", "dedupe", "step"):
-            # timing probe on throw-away trackers would change state; instead time segments of the
-            # real steps below.  Here: nothing -- see `--breakdown` pass after the timed region.
-            probe[seg] = None
+    # untimed probe (more warm-up): which kernel group dominates a step?
+    breakdown = {}
+    for seg in SEGMENTS + tuple(k for k in KERNELS if k not in SEGMENTS) + ("step",):
+        trk.profile_enable(seg, PROBE)
+        for _ in range(PROBE):
+            trk.step(*next_frame())
+        ms_, n_ = trk.profile_read()
+        breakdown[seg] = 1e3 * ms_ / max(n_, 1)
+    segment = a.segment if a.segment != "auto" else max(KERNELS, key=lambda k: breakdown[k])
     trk.profile_enable(segment, a.steps)
+    timed = [next_frame() for _ in range(a.steps)]
 
-    barrier()
+    ms.barrier(ddist)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for k in range(a.warmup, a.warmup + a.steps):
-        trk.step(*frames[k])
+    for fr in timed:
+        trk.step(*fr)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    barrier()
+    ms.barrier(ddist)
     seg_ms, seg_n = trk.profile_read()
     counts = trk.counts()
-    assert counts["errors"] == 0 and counts["frame_id"] == n_frames, counts
-
-    elapsed = t1 - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
-
-    breakdown = None
+    assert counts["errors"] == 0, counts
+    elapsed = ms.max_over_ranks(t1 - t0, ddist)
     if a.breakdown and rank == 0:
-        # extra untimed frames, one segment at a time (the stream just keeps going)
-        breakdown = {}
-        extra = []
-        for _ in range(12 * 11):
-            fr = st.next()
-            extra.append((torch.from_numpy(fr.boxes).cuda(), torch.from_numpy(fr.scores).cuda(),
-                          torch.from_numpy(fr.feats).cuda()))
-        i = 0
-        for seg in ("prep", "predict", "cos1", "cost1", "lap1", "apply1", "stage2", "stage3", "merge", "dedupe", "step"):
-            trk.profile_enable(seg, 12)
-            for _ in range(12):
-                trk.step(*extra[i]); i += 1
-            ms, n = trk.profile_read()
-            breakdown[seg] = 1e3 * ms / max(n, 1)
         sys.stderr.write("segment us/step: " + json.dumps({k: round(v, 1) for k, v in breakdown.items()}) + "\n")
 
     if rank == 0:
-        bound, amount, unit = segment_model(segment, K, M, D)
+        bound, amount, unit, peak = kernel_model(segment, K, M, D, a.dense)
         seg_s = (seg_ms / 1e3) / max(seg_n, 1)
         if bound == "mfma":
-            achieved, peak, runit = amount / seg_s / 1e12, F32_MFMA_PEAK_TF, "TFLOP/s"
+            achieved, runit = amount / seg_s / 1e12, "TFLOP/s"
         else:
-            achieved, peak, runit = amount / seg_s / 1e9, HBM_PEAK_GBS, "GB/s"
+            achieved, runit = amount / seg_s / 1e9, "GB/s"
         out = {
             "metric": "tracker update-steps/sec (N_tracks x M_dets)",
-            "value": world * a.steps / elapsed,
+            "value": ms.aggregate_throughput(a.steps, elapsed, world),
             "unit": "steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * elapsed / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64", "data": "synthetic (seeded stream generator, SURVEY.md 8d; frames resident in HBM before the timed region)",
             "config": {"workload": "%s: %d tracks x %d detections/frame x %d-d ReID, IoU+cosine fused cost, "
                                    "3-stage association, one stream per GPU" % (a.workload, K, M, D),
                        "tracks": K, "dets": M, "feat_dim": D, "streams": world, "parallelism": "1 stream/GPU, no collective"},
-            "roofline": {"kernel": segment, "bound": bound, "achieved": achieved, "peak": peak, "unit": runit,
+            "roofline": {"kernel": KERNELS[segment], "bound": bound, "achieved": achieved, "peak": peak, "unit": runit,
                          "frac": achieved / peak, "traffic": None,
                          "avg_us": 1e6 * seg_s, "launches_timed": seg_n,
                          "algorithmic_per_launch": amount, "algorithmic_unit": unit},
         }
-        if breakdown:
-            out["segments_us"] = breakdown
+        out["segments_us"] = {k: round(v, 2) for k, v in breakdown.items()}
         if not a.no_cpu:
             out["cpu_baseline"] = cpu_baseline(pkg, K, M, D, 1234, a.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -14,10 +14,10 @@ from .matching import (bbox_iou, bbox_ious, cosine_similarity, fuse_cost_stage1,
                        lapjv, linear_assignment)
 from .tracker import (BaseTrack, BoTSORT, DeviceTracker, STrack, TrackState, joint_stracks, remove_duplicate_stracks,
                       sub_stracks)
-from . import synth
+from . import multistream, synth
 
 __all__ = [
     "BtsError", "Context", "LIB_PATH", "KalmanFilter", "TrackState", "BaseTrack", "STrack", "BoTSORT", "DeviceTracker",
     "linear_assignment", "lapjv", "iou_distance", "bbox_ious", "bbox_iou", "cosine_similarity", "fuse_cost_stage1",
-    "fuse_cost_stage3", "joint_stracks", "sub_stracks", "remove_duplicate_stracks", "synth",
+    "fuse_cost_stage3", "joint_stracks", "sub_stracks", "remove_duplicate_stracks", "synth", "multistream",
 ]

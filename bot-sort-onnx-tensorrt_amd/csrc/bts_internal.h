@@ -126,7 +126,8 @@ struct bts_lap_problem {
     int fresh;
 };
 // Enqueue 1 or 2 independent problems (they share the two launches).
-int bts_lap_enqueue(const bts_lap_problem *probs, int count, hipStream_t stream);
+// `ev` (nullable): four pre-created events recorded around k_prepare and k_solve (measurement hook).
+int bts_lap_enqueue(const bts_lap_problem *probs, int count, hipStream_t stream, hipEvent_t *ev = nullptr);
 // reset hdr before edges are appended
 int bts_lap_enqueue_reset(const bts_lap_work *w, hipStream_t stream);
 

@@ -512,10 +512,12 @@ int bts_lap_enqueue_reset(const bts_lap_work *w, hipStream_t stream) {
     return BTS_OK;
 }
 
-int bts_lap_enqueue(const bts_lap_problem *probs, int count, hipStream_t stream) {
+int bts_lap_enqueue(const bts_lap_problem *probs, int count, hipStream_t stream, hipEvent_t *ev) {
     const bts_lap_problem &A = probs[0], &B = probs[count > 1 ? 1 : 0];
+    if (ev) (void)hipEventRecord(ev[0], stream);
     hipLaunchKernelGGL(k_prepare, dim3(count), dim3(1024), 0, stream, A, B);
     BTS_LAUNCH_CHECK();
+    if (ev) { (void)hipEventRecord(ev[1], stream); (void)hipEventRecord(ev[2], stream); }
     int waves = 1;
     for (int k = 0; k < count; ++k) {
         const int w_ = probs[k].n_max < probs[k].m_max ? probs[k].n_max : probs[k].m_max;   // #components <= min(n, m)
@@ -525,6 +527,7 @@ int bts_lap_enqueue(const bts_lap_problem *probs, int count, hipStream_t stream)
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(k_solve, dim3(blocks, count), dim3(256), 0, stream, A, B);
     BTS_LAUNCH_CHECK();
+    if (ev) (void)hipEventRecord(ev[3], stream);
     return BTS_OK;
 }
 

@@ -912,13 +912,13 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
 
 int bts_tracker_profile_enable(bts_tracker *t, int segment, int capacity) {
     BTS_REQUIRE(t && capacity >= 0, "tracker, capacity");
-    for (int k = 0; k < 2 * t->prof_cap; ++k) (void)hipEventDestroy(t->prof_ev[k]);
+    for (int k = 0; t->prof_ev && k < 2 * t->prof_cap + 2; ++k) (void)hipEventDestroy(t->prof_ev[k]);
     delete[] t->prof_ev;
     t->prof_ev = nullptr; t->prof_cap = 0; t->prof_n = 0; t->prof_seg = segment;
     if (capacity == 0) return BTS_OK;
-    t->prof_ev = new (std::nothrow) hipEvent_t[2 * capacity];
+    t->prof_ev = new (std::nothrow) hipEvent_t[2 * capacity + 2];
     if (!t->prof_ev) { bts_set_error("host allocation failed"); return BTS_ENOMEM; }
-    for (int k = 0; k < 2 * capacity; ++k) BTS_HIP(hipEventCreate(&t->prof_ev[k]));
+    for (int k = 0; k < 2 * capacity + 2; ++k) BTS_HIP(hipEventCreate(&t->prof_ev[k]));
     t->prof_cap = capacity;
     return BTS_OK;
 }
@@ -939,7 +939,7 @@ int bts_tracker_profile_read(bts_tracker *t, double *total_ms, int32_t *count) {
 
 int bts_tracker_destroy(bts_tracker *t) {
     if (!t) return BTS_OK;
-    for (int k = 0; k < 2 * t->prof_cap; ++k) (void)hipEventDestroy(t->prof_ev[k]);
+    for (int k = 0; t->prof_ev && k < 2 * t->prof_cap + 2; ++k) (void)hipEventDestroy(t->prof_ev[k]);
     delete[] t->prof_ev;
     if (t->block) (void)hipFree(t->block);
     if (t->host_hdr) (void)hipHostFree(t->host_hdr);
@@ -1007,7 +1007,9 @@ int bts_tracker_step(bts_tracker *t, const int32_t *boxes, const float *scores, 
         }
     }
     if (d.filter) {
+        seg_begin(BTS_SEG_K_FILTER);
         LAUNCH(k_filter<false>, filt_grid, dim3(256), lap[0], mc);
+        seg_end(BTS_SEG_K_FILTER);
         if (split > 1) { LAUNCH(k_filter_scan<false>, tile_grid, dim3(CT_COLS)); }
         if (d.Df) {
             const int fsplit = split < bts_cdiv(d.Df, FBK) ? split : bts_cdiv(d.Df, FBK);
@@ -1018,24 +1020,41 @@ int bts_tracker_step(bts_tracker *t, const int32_t *boxes, const float *scores, 
     }
     seg_end(BTS_SEG_COS1);
     seg_begin(BTS_SEG_COST1);
+    seg_begin(BTS_SEG_K_EDGES1);
     if (d.filter) {
         LAUNCH((tk_edges<1, 1>), tile_grid, dim3(CT_COLS), lap[0]);
         if (d.record) { LAUNCH((tk_edges<1, 2>), tile_grid, dim3(CT_COLS), lap[0]); }
     } else {
         LAUNCH((tk_edges<1, 0>), tile_grid, dim3(CT_COLS), lap[0]);
     }
+    seg_end(BTS_SEG_K_EDGES1);
     seg_end(BTS_SEG_COST1);
     seg_begin(BTS_SEG_LAP1);
     bts_lap_problem prob[3] = {{lap[0], d.hdr + H_DIMS1, T, mc, d.match1, d.x1, d.y1, 1},
                                {lap[1], d.hdr + H_DIMS2, T, mc, d.match2, d.x2, d.y2, 1},
                                {lap[2], d.hdr + H_DIMS3, T, mc, d.match3, d.x3, d.y3, 1}};
-    rc = bts_lap_enqueue(&prob[0], 1, s);
-    if (rc) return rc;
+    {
+        hipEvent_t ev4[4];
+        const bool want = prof_room && (t->prof_seg == BTS_SEG_K_LAP_PREPARE || t->prof_seg == BTS_SEG_K_LAP_SOLVE);
+        if (want) {   // only the selected pair is kept; the other two land on a scratch pair at the ring's end
+            hipEvent_t *keep = &t->prof_ev[2 * t->prof_n], *junk = &t->prof_ev[2 * t->prof_cap];
+            const bool prep = t->prof_seg == BTS_SEG_K_LAP_PREPARE;
+            ev4[0] = prep ? keep[0] : junk[0]; ev4[1] = prep ? keep[1] : junk[1];
+            ev4[2] = prep ? junk[0] : keep[0]; ev4[3] = prep ? junk[1] : keep[1];
+        }
+        rc = bts_lap_enqueue(&prob[0], 1, s, want ? ev4 : nullptr);
+        if (rc) return rc;
+        if (want) t->prof_n++;
+    }
     seg_end(BTS_SEG_LAP1);
     seg_begin(BTS_SEG_APPLY1);
     LAUNCH(tk_mid1, dim3(1 + mc), dim3(1024));       // stage-2/3 lists read pre-update states: before tk_apply<1>
+    seg_begin(BTS_SEG_K_APPLY_KF1);
     LAUNCH((tk_apply<1, false>), dim3(kf_blocks), dim3(256));
+    seg_end(BTS_SEG_K_APPLY_KF1);
+    seg_begin(BTS_SEG_K_APPLY_FEAT1);
     LAUNCH((tk_apply<1, true>), dim3(T), dim3(256));
+    seg_end(BTS_SEG_K_APPLY_FEAT1);
     seg_end(BTS_SEG_APPLY1);
     // ---- second association (remaining tracked rows x low-score detections) and the unconfirmed
     //      tracks (x leftover high-score detections): independent problems, shared launches

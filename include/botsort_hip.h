@@ -205,7 +205,11 @@ int bts_tracker_stage_result(bts_tracker *trk, int stage, int32_t *x_host, int32
  * (steps beyond that are not timed); capacity 0 disables.  Events are created here, never in a step. */
 enum bts_segment {
     BTS_SEG_PREP = 0, BTS_SEG_PREDICT = 1, BTS_SEG_COS1 = 2, BTS_SEG_COST1 = 3, BTS_SEG_LAP1 = 4, BTS_SEG_APPLY1 = 5,
-    BTS_SEG_STAGE2 = 6, BTS_SEG_STAGE3 = 7, BTS_SEG_MERGE = 8, BTS_SEG_DEDUPE = 9, BTS_SEG_STEP = 100
+    BTS_SEG_STAGE2 = 6, BTS_SEG_STAGE3 = 7, BTS_SEG_MERGE = 8, BTS_SEG_DEDUPE = 9,
+    /* single kernels */
+    BTS_SEG_K_FILTER = 20, BTS_SEG_K_LAP_PREPARE = 21, BTS_SEG_K_LAP_SOLVE = 22, BTS_SEG_K_EDGES1 = 23,
+    BTS_SEG_K_APPLY_KF1 = 24, BTS_SEG_K_APPLY_FEAT1 = 25,
+    BTS_SEG_STEP = 100
 };
 int bts_tracker_profile_enable(bts_tracker *trk, int segment, int capacity);
 /* Synchronises on the recorded events; returns their summed duration and count, then clears them. */
