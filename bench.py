@@ -35,7 +35,7 @@ F16_MFMA_PEAK_TF = 2500.0      # dense f16/bf16 MFMA peak (not the 2:1-sparse he
 F32_MFMA_PEAK_TF = 157.3       # dense f32-input MFMA peak (= f32 vector peak)
 SEGMENTS = ("prep", "predict", "cos1", "cost1", "lap1", "apply1", "stage2", "merge", "dedupe")   # launch groups of a step
 KERNELS = {   # single kernels that can dominate a step -> name in the rocprofv3 kernel trace
-    "k_filter": "k_filter<false>", "k_lap_prepare": "k_prepare", "k_lap_solve": "k_solve", "k_edges1": "tk_edges<1,*>",
+    "k_filter": "k_filter<false>", "k_lap_prepare": "k_lap", "k_edges1": "tk_edges<1,*>",
     "predict": "tk_predict", "k_apply_kf1": "tk_apply<1,false>", "k_apply_feat1": "tk_apply<1,true>",
 }
 
@@ -67,8 +67,7 @@ def kernel_model(kern, K, M, D, dense):
         "k_apply_kf1": Km * (2 * 72 + 4) * 8,                   # matched rows read + written, measurement read
         "k_apply_feat1": Km * D * (4 + 4 + 4 + 4 + 2),          # det row, smooth r+w, curr w, f16 shadow w
         "k_edges1": (N + Mh) * 32 + E * 16,                     # boxes in, sparse edges out (N*Mh IoU tests are compute)
-        "k_lap_prepare": E * (16 + 16) + 8 * Mh,                # edge list in, CSR/groups out, isolated pairs written
-        "k_lap_solve": E * 16 + 8 * Mh,
+        "k_lap_prepare": E * 16 + 8 * Mh,                       # edge list in, assignment vectors out
     }
     return "hbm", float(table[kern]), "byte", HBM_PEAK_GBS
 

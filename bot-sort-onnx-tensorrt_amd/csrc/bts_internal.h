@@ -68,10 +68,12 @@ struct bts_context {
 // Device-side work area of the exact sparse linear-assignment solver.  All sizes are capacities;
 // the live sizes are read by the kernels from `dims` (device memory) so that a tracker step never
 // needs the host to know them.
+constexpr int BTS_LAP_HDR_INTS = 64;   // counters (first 128-byte line) + the ready flag (second line)
+
 struct bts_lap_work {
     int32_t n_cap = 0, m_cap = 0;
     int64_t e_cap = 0;
-    int32_t *hdr = nullptr;      // [16] counters, see lap.hip
+    int32_t *hdr = nullptr;      // [BTS_LAP_HDR_INTS] counters, see lap.hip
     int32_t *e_row = nullptr;    // [e_cap] unsorted feasible edges (row, col, cost)
     int32_t *e_col = nullptr;
     double *e_cost = nullptr;
@@ -93,6 +95,13 @@ struct bts_lap_work {
     int32_t *ccols = nullptr;    // [m_cap] columns grouped by component
     int32_t *comp_list = nullptr; // [n_cap] components that need the augmenting-path solver
     int32_t *slot_of_row = nullptr; // [n_cap] dense index of an active row (valid while deg > 0)
+    int32_t *slot_of_col = nullptr; // [m_cap]
+    int32_t *col_local = nullptr; // [m_cap] lane of a column inside its component
+    int32_t *colid = nullptr;     // [m_cap] packed components: column ids, grouped
+    int4 *cdesc = nullptr;        // [n_cap] packed components: {first row, rows, first column, columns}
+    int4 *rowinfo = nullptr;      // [n_cap] packed components: {row id, first edge, end edge, -}
+    int32_t *rpos = nullptr, *gstart = nullptr, *rlo = nullptr, *rhi = nullptr;   // [n_cap(+1)] grouped positions / edge ranges
+    int32_t *csr_lcol = nullptr;  // [e_cap] packed components: column lane of each CSR edge
     int32_t *arow = nullptr;      // [n_cap] active rows (have a feasible edge), in order of first sight
     int32_t *acol = nullptr;      // [m_cap] active columns
     int32_t *hard = nullptr;      // [e_cap] indices of edges that are not isolated pairs

@@ -22,7 +22,8 @@
 
 namespace {
 
-enum { H_EDGES = 0, H_COMPS = 1, H_ERR = 2, H_HARD = 3, H_NA = 4, H_MA = 5, H_NH = 6 };   // hdr: edges, components, overflow flag,
+enum { H_EDGES = 0, H_COMPS = 1, H_ERR = 2, H_HARD = 3, H_NA = 4, H_MA = 5, H_NH = 6, H_MODE = 8,
+       H_READY = 32 };   // the flag the helper workgroups poll sits in its own 128-byte line   // hdr: edges, components, overflow flag,
                                                                               // components for k_solve, active rows / columns
 
 // Every word of the work area that is the target of an atomic (or is read back after atomics) is
@@ -39,6 +40,13 @@ typedef bts_lap_problem LapArgs;
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// order LDS traffic between lanes of one wavefront (DS operations of a wave execute in order; this
+// only stops the compiler from moving accesses across the hand-off)
+__device__ __forceinline__ void lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -132,45 +140,144 @@ __device__ int block_exscan(int32_t *arr, int len, int32_t *tmp) {
 // the edges that are NOT isolated pairs:
 //   * an edge whose row and column have degree 1 is a whole component by itself: it is matched on
 //     the spot (any feasible edge beats two dummies, cost <= limit; ties prefer the match);
-//   * the remaining "hard" edges get dense row slots, a union-find pass (components), a CSR by row
-//     and per-component row/column lists for k_solve.
+//   * the remaining "hard" edges get dense row/column slots, a union-find pass (components) and
+//     are exported as PACKED COMPONENTS: descriptor {first row, rows, first col, cols}, per-row
+//     {row id, edge range}, column ids, and edges {column lane, cost}.  One wavefront solves one
+//     component from three coalesced reads.
+// Workgroup 0 of the launch prepares; it publishes the packed problem on hdr[H_READY] and the helper
+// workgroups of the same launch (spinning on that one word) share the components with it.
+// Two forms of the preparation:
+//   SMALL (<= SM_EH hard edges, components <= 64 x 64 with <= SM_EDGES edges): slot space, in LDS;
+//   LARGE: node space, in the global work area (any size; oversize components go to the general
+//          global-memory solver).
 // Invariant kept across calls: deg[] / cdeg[] are zero outside this kernel.
 // Memory discipline: words that are targets of atomics (deg, cdeg, hdr, parent, crow_ptr, ccol_ptr,
 // cursor, ccur_*) are only ever touched with agent-scope atomics (RLX / RST / atomicAdd / CAS); the
-// other arrays are written once and read after a workgroup barrier with plain accesses.
+// other arrays are written once and read after a workgroup barrier / the publish with plain accesses.
 constexpr int FIRST = 0x40000000;    // "already has a slot" flag inside deg / cdeg
+constexpr int SM_EH = 2048;          // hard-edge budget of the LDS form
+constexpr int SM_EDGES = 512;        // edge budget of the register/LDS solver, per wavefront
 
-__global__ __launch_bounds__(1024) void k_prepare(LapArgs A0, LapArgs A1) {
-    const LapArgs &A = blockIdx.x ? A1 : A0;
-    __shared__ int32_t tmp[1024];
+struct SmallPipe {                   // LDS image of the hard sub-problem (slot space); 68 B per hard edge
+    int32_t he[SM_EH], hr[SM_EH], hc[SM_EH];      // hard edge -> edge index, row slot, column slot
+    int32_t arow[SM_EH], acol[SM_EH];             // slot -> global row / column
+    int32_t parent[2 * SM_EH];                    // union-find: row slots [0,SM_EH), column slots [SM_EH, 2 SM_EH)
+    int32_t rptr[SM_EH + 1];
+    int32_t cid[SM_EH];                           // root row slot -> component
+    int32_t comp[SM_EH], ccomp[SM_EH];            // row slot / column slot -> component
+    int32_t crp[SM_EH + 1], ccp[SM_EH + 1];       // component -> first row / column of its group
+    int32_t ecnt[SM_EH];                          // component -> edges
+    int32_t rpos[SM_EH];                          // row slot -> position in the grouped row list
+    int32_t lane_of_col[SM_EH];                   // column slot -> lane inside its component
+    int32_t gstart[SM_EH + 1];                    // grouped row position -> first edge (edges of a component are contiguous)
+    int32_t NA, MA, C, maxr, maxc, maxe, EH;
+    // arrays with disjoint lifetimes share storage
+    __device__ int32_t *cursor() { return parent; }            // (after the roots are known)
+    __device__ int32_t *cur_r() { return parent + SM_EH; }
+    __device__ int32_t *cur_c() { return cid; }                // (after comp / ccomp hold component ids)
+};
+
+__device__ int find_root_lds(int32_t *parent, int x) {
+    int p = parent[x];
+    while (p != x) { x = p; p = parent[x]; }
+    return x;
+}
+
+// SMALL preparation, entirely in LDS (the global work area's deg/cdeg are not touched).  The node
+// table (degree, then slot, of every row and column) borrows the storage of the arrays that only
+// come alive after it is dead.  Returns 0 when the problem is fully prepared/solved as far as this
+// workgroup goes, -1 when the LARGE form has to take over (nothing global was changed except x/y of
+// isolated pairs, which the LARGE form rewrites identically).
+constexpr int TABLE_CAP = 12 * SM_EH;      // node-table entries that fit in the borrowed storage
+
+__device__ int small_pipeline(const LapArgs &A, SmallPipe &L, int E, int n, int m, int32_t *tmp) {
     const bts_lap_work &w = A.w;
-    const int n = A.dims ? A.dims[0] : A.n_max, m = A.dims ? A.dims[1] : A.m_max;
     const int tid = threadIdx.x, nth = blockDim.x;
-    int E = RLX(&w.hdr[H_EDGES]);
-    if ((long)E > w.e_cap) E = (int)w.e_cap;
-    if (!A.fresh) {
-        for (int i = tid; i < n; i += nth) { RST(&w.deg[i], 0); A.x[i] = -1; }
-        for (int j = tid; j < m; j += nth) { RST(&w.cdeg[j], 0); A.y[j] = -1; }
-        __syncthreads();
-    }
-    if (E == 0) return;                                   // hdr counters are already zero
-    // 1. degrees
-    for (int e = tid; e < E; e += nth) { atomicAdd(&w.deg[w.e_row[e]], 1); atomicAdd(&w.cdeg[w.e_col[e]], 1); }
+    int32_t *tab = L.parent;                              // [n + m]: rows, then columns
+    if (tid == 0) { L.NA = 0; L.MA = 0; L.C = 0; L.maxr = 0; L.maxc = 0; L.maxe = 0; L.EH = 0; }
+    for (int k = tid; k < n + m; k += nth) tab[k] = 0;
     __syncthreads();
-    // 2. isolated pairs are final; everything else is queued
-    for (int e = tid; e < E; e += nth) {
+    for (int e = tid; e < E; e += nth) { atomicAdd(&tab[w.e_row[e]], 1); atomicAdd(&tab[n + w.e_col[e]], 1); }
+    __syncthreads();
+    for (int e = tid; e < E; e += nth) {                  // isolated pairs are final; the rest is queued
         const int i = w.e_row[e], j = w.e_col[e];
-        if (RLX(&w.deg[i]) == 1 && RLX(&w.cdeg[j]) == 1) { A.x[i] = j; A.y[j] = i; }
-        else w.hard[atomicAdd(&w.hdr[H_NH], 1)] = e;
+        if (tab[i] == 1 && tab[n + j] == 1) { A.x[i] = j; A.y[j] = i; }
+        else { const int h = atomicAdd(&L.EH, 1); if (h < SM_EH) L.he[h] = e; }
     }
     __syncthreads();
-    // (degrees of the isolated pairs go back to zero only now: the test above must see 1 for both ends)
-    for (int e = tid; e < E; e += nth) {
-        const int i = w.e_row[e], j = w.e_col[e];
-        if (A.x[i] == j && RLX(&w.deg[i]) == 1 && RLX(&w.cdeg[j]) == 1) { RST(&w.deg[i], 0); RST(&w.cdeg[j], 0); }
+    const int EH = L.EH;
+    if (EH == 0) return 0;
+    if (EH > SM_EH) return -1;
+    for (int h = tid; h < EH; h += nth) {                 // dense slots; the table entry becomes FIRST | slot
+        const int e = L.he[h], i = w.e_row[e], j = w.e_col[e];
+        if (!(atomicOr(&tab[i], FIRST) & FIRST)) { const int s = atomicAdd(&L.NA, 1); L.arow[s] = i; atomicExch(&tab[i], FIRST | s); }
+        if (!(atomicOr(&tab[n + j], FIRST) & FIRST)) { const int s = atomicAdd(&L.MA, 1); L.acol[s] = j; atomicExch(&tab[n + j], FIRST | s); }
     }
-    const int EH = RLX(&w.hdr[H_NH]);
-    if (EH == 0) return;
+    __syncthreads();
+    const int NA = L.NA, MA = L.MA;
+    for (int h = tid; h < EH; h += nth) { const int e = L.he[h]; L.hr[h] = tab[w.e_row[e]] & ~FIRST; L.hc[h] = tab[n + w.e_col[e]] & ~FIRST; }
+    __syncthreads();                                      // the table is dead from here on
+    for (int s = tid; s < NA; s += nth) { L.parent[s] = s; L.rptr[s] = 0; L.ecnt[s] = 0; }
+    for (int s = tid; s < MA; s += nth) L.parent[SM_EH + s] = SM_EH + s;
+    __syncthreads();
+    for (int h = tid; h < EH; h += nth) { unite(L.parent, L.hr[h], SM_EH + L.hc[h]); atomicAdd(&L.rptr[L.hr[h]], 1); }
+    __syncthreads();
+    for (int s = tid; s < NA; s += nth) {                 // roots (read-only walks) hand out component ids
+        const int r = find_root_lds(L.parent, s);
+        L.comp[s] = r;
+        if (r == s) { const int c = atomicAdd(&L.C, 1); L.cid[s] = c; L.crp[c] = 0; L.ccp[c] = 0; }
+    }
+    for (int s = tid; s < MA; s += nth) L.ccomp[s] = find_root_lds(L.parent, SM_EH + s);
+    __syncthreads();
+    const int C = L.C;
+    for (int s = tid; s < NA; s += nth) { const int c = L.cid[L.comp[s]]; L.comp[s] = c; atomicAdd(&L.crp[c], 1); atomicAdd(&L.ecnt[c], L.rptr[s]); }
+    for (int s = tid; s < MA; s += nth) { const int c = L.cid[L.ccomp[s]]; L.ccomp[s] = c; atomicAdd(&L.ccp[c], 1); }
+    __syncthreads();
+    for (int c = tid; c < C; c += nth) { atomicMax(&L.maxr, L.crp[c]); atomicMax(&L.maxc, L.ccp[c]); atomicMax(&L.maxe, L.ecnt[c]); }
+    __syncthreads();
+    const bool fits = L.maxr <= 64 && L.maxc <= 64 && L.maxe <= SM_EDGES;
+    if (!fits) return -1;
+    block_exscan_plain(L.crp, C, tmp);
+    block_exscan_plain(L.ccp, C, tmp);
+    if (tid == 0) { L.crp[C] = NA; L.ccp[C] = MA; }
+    int32_t *cursor = L.cursor(), *cur_r = L.cur_r(), *cur_c = L.cur_c();
+    for (int c = tid; c < C; c += nth) { cur_r[c] = L.crp[c]; cur_c[c] = L.ccp[c]; }
+    __syncthreads();
+    // rows / columns grouped by component; edge ranges handed out in grouped row order, so that the
+    // edges of one component are one contiguous block
+    for (int s = tid; s < NA; s += nth) { const int pos = atomicAdd(&cur_r[L.comp[s]], 1); L.rpos[s] = pos; L.gstart[pos] = L.rptr[s]; }
+    for (int s = tid; s < MA; s += nth) {
+        const int c = L.ccomp[s], pos = atomicAdd(&cur_c[c], 1);
+        L.lane_of_col[s] = pos - L.ccp[c];
+        w.colid[pos] = L.acol[s];
+    }
+    __syncthreads();
+    block_exscan_plain(L.gstart, NA, tmp);
+    if (tid == 0) L.gstart[NA] = EH;
+    __syncthreads();
+    for (int s = tid; s < NA; s += nth) {
+        const int pos = L.rpos[s], e0 = L.gstart[pos];
+        cursor[s] = e0;
+        w.rowinfo[pos] = make_int4(L.arow[s], e0, e0 + L.rptr[s], 0);
+    }
+    for (int c = tid; c < C; c += nth)
+        w.cdesc[c] = make_int4(L.crp[c], L.ccp[c], (L.crp[c + 1] - L.crp[c]) | ((L.ccp[c + 1] - L.ccp[c]) << 8) | (L.ecnt[c] << 16),
+                               L.gstart[L.crp[c]]);
+    __syncthreads();
+    for (int h = tid; h < EH; h += nth) {
+        const int pos = atomicAdd(&cursor[L.hr[h]], 1);
+        w.csr_lcol[pos] = L.lane_of_col[L.hc[h]];
+        w.csr_cost[pos] = w.e_cost[L.he[h]];
+    }
+    if (tid == 0) { RST(&w.hdr[H_COMPS], C); RST(&w.hdr[H_HARD], C); RST(&w.hdr[H_MODE], 1); RST(&w.hdr[H_NH], EH); }
+    return 0;
+}
+
+// LARGE preparation: global work area, node space (phases as in the LDS form)
+__device__ void large_pipeline(const LapArgs &A, int EH, int32_t *tmp) {
+    const bts_lap_work &w = A.w;
+    const int n = A.dims ? A.dims[0] : A.n_max;
+    const int tid = threadIdx.x, nth = blockDim.x;
     // 3. dense slots for the rows / columns of hard edges, union-find cells
     for (int h = tid; h < EH; h += nth) {
         const int e = w.hard[h], i = w.e_row[e], j = w.e_col[e];
@@ -206,108 +313,156 @@ __global__ __launch_bounds__(1024) void k_prepare(LapArgs A0, LapArgs A1) {
     for (int s = tid; s < MA; s += nth) atomicAdd(&w.ccol_ptr[w.comp_of[w.rootv[n + w.acol[s]]]], 1);
     __syncthreads();
     // 7. pointers
-    block_exscan_plain(w.rptr, NA, tmp);
     block_exscan(w.crow_ptr, C, tmp);
     block_exscan(w.ccol_ptr, C, tmp);
-    if (tid == 0) { w.rptr[NA] = EH; RST(&w.crow_ptr[C], NA); RST(&w.ccol_ptr[C], MA); }
+    if (tid == 0) { RST(&w.crow_ptr[C], NA); RST(&w.ccol_ptr[C], MA); }
     __syncthreads();
-    for (int s = tid; s < NA; s += nth) RST(&w.cursor[s], w.rptr[s]);
     for (int c = tid; c < C; c += nth) { RST(&w.ccur_r[c], RLX(&w.crow_ptr[c])); RST(&w.ccur_c[c], RLX(&w.ccol_ptr[c])); }
     __syncthreads();
-    // 8. fills: CSR by row slot, rows / columns grouped by component; degrees back to zero
+    // 8. rows / columns grouped by component; edge ranges in grouped row order (contiguous per component)
+    for (int s = tid; s < NA; s += nth) {
+        const int i = w.arow[s];
+        const int pos = atomicAdd(&w.ccur_r[w.comp_of[w.rootv[i]]], 1);
+        w.crows[pos] = i; w.rpos[s] = pos; w.gstart[pos] = w.rptr[s];
+    }
+    for (int s = tid; s < MA; s += nth) {
+        const int j = w.acol[s];
+        const int c = w.comp_of[w.rootv[n + j]], pos = atomicAdd(&w.ccur_c[c], 1);
+        w.ccols[pos] = j;
+        w.colid[pos] = j;
+        w.col_local[j] = pos - RLX(&w.ccol_ptr[c]);
+        RST(&w.cdeg[j], 0);
+    }
+    __syncthreads();
+    block_exscan_plain(w.gstart, NA, tmp);
+    if (tid == 0) w.gstart[NA] = EH;
+    __syncthreads();
+    for (int s = tid; s < NA; s += nth) {
+        const int i = w.arow[s], pos = w.rpos[s], e0 = w.gstart[pos], e1 = e0 + w.rptr[s];
+        RST(&w.cursor[s], e0);
+        w.rlo[s] = e0; w.rhi[s] = e1;
+        w.rowinfo[pos] = make_int4(i, e0, e1, 0);
+        RST(&w.deg[i], 0);
+    }
+    for (int c = tid; c < C; c += nth) {
+        const int r0 = RLX(&w.crow_ptr[c]), c0 = RLX(&w.ccol_ptr[c]);
+        const int r = RLX(&w.crow_ptr[c + 1]) - r0, cn = RLX(&w.ccol_ptr[c + 1]) - c0;
+        const int ne = w.gstart[r0 + r] - w.gstart[r0];
+        w.cdesc[c] = make_int4(r0, c0, (r > 255 ? 255 : r) | ((cn > 255 ? 255 : cn) << 8) | ((ne > 0x7fff ? 0x7fff : ne) << 16), w.gstart[r0]);
+    }
+    __syncthreads();
     for (int h = tid; h < EH; h += nth) {
         const int e = w.hard[h];
         const int pos = atomicAdd(&w.cursor[w.slot_of_row[w.e_row[e]]], 1);
         w.csr_col[pos] = w.e_col[e];
+        w.csr_lcol[pos] = w.col_local[w.e_col[e]];
         w.csr_cost[pos] = w.e_cost[e];
     }
-    for (int s = tid; s < NA; s += nth) {
-        const int i = w.arow[s];
-        w.crows[atomicAdd(&w.ccur_r[w.comp_of[w.rootv[i]]], 1)] = i;
-        RST(&w.deg[i], 0);
-    }
-    for (int s = tid; s < MA; s += nth) {
-        const int j = w.acol[s];
-        w.ccols[atomicAdd(&w.ccur_c[w.comp_of[w.rootv[n + j]]], 1)] = j;
-        RST(&w.cdeg[j], 0);
-    }
-    if (tid == 0) RST(&w.hdr[H_HARD], C);                 // every component goes to k_solve
+    if (tid == 0) { RST(&w.hdr[H_HARD], C); RST(&w.hdr[H_MODE], 2); }
 }
 
-// ---- 3. one wavefront per component: shortest augmenting paths ----------------------------------
-// Lanes of the wave exchange state through memory that the same wave wrote earlier in the kernel.
-// Such accesses go straight to L2 (relaxed agent-scope atomics = sc1 loads / write-through stores):
-// a plain load may be served from a vector-L1 line that predates the store.
+// Degrees + isolated pairs; returns the number of hard edges (uniform).
+__device__ int isolated_pairs(const LapArgs &A, int E) {
+    const bts_lap_work &w = A.w;
+    const int tid = threadIdx.x, nth = blockDim.x;
+    for (int e = tid; e < E; e += nth) { atomicAdd(&w.deg[w.e_row[e]], 1); atomicAdd(&w.cdeg[w.e_col[e]], 1); }
+    __syncthreads();
+    for (int e = tid; e < E; e += nth) {
+        const int i = w.e_row[e], j = w.e_col[e];
+        if (RLX(&w.deg[i]) == 1 && RLX(&w.cdeg[j]) == 1) { A.x[i] = j; A.y[j] = i; }
+        else w.hard[atomicAdd(&w.hdr[H_NH], 1)] = e;
+    }
+    __syncthreads();
+    // (degrees of the isolated pairs go back to zero only now: the test above must see 1 for both ends)
+    for (int e = tid; e < E; e += nth) {
+        const int i = w.e_row[e], j = w.e_col[e];
+        if (RLX(&w.deg[i]) == 1 && RLX(&w.cdeg[j]) == 1) { RST(&w.deg[i], 0); RST(&w.cdeg[j], 0); }
+    }
+    return RLX(&w.hdr[H_NH]);
+}
+
+// Lanes of the general solver exchange state through memory that the same wave wrote earlier in the
+// kernel: such accesses go straight to L2 (relaxed agent-scope atomics).
 #define LDG(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define STG(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 
-// order LDS traffic between lanes of one wavefront (DS operations of a wave execute in order; this
-// only stops the compiler from moving accesses across the hand-off)
-__device__ __forceinline__ void lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+// ---- cross-lane helpers for the register solver --------------------------------------------------------
+// ds_bpermute (what __shfl compiles to) costs ~100+ cycles of latency per use; the search below is a
+// chain of such exchanges, so: broadcasts from a wave-uniform lane go through v_readlane (scalar
+// path), and the (distance, column) minimum runs on DPP row operations over the 16 lanes that a
+// component of <= 16 columns occupies (wider components fall back to the xor butterfly).
+__device__ __forceinline__ int bcast_i(int v, int src) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src)); }
+__device__ __forceinline__ double bcast_d(double v, int src) {
+    const int s = __builtin_amdgcn_readfirstlane(src);
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(b & 0xffffffffll), s);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), s);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+template <int CTRL> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL> __device__ __forceinline__ double dpp_d(double v) {
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)dpp_i<CTRL>((int)(b & 0xffffffffll)), hi = (unsigned)dpp_i<CTRL>((int)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// lexicographic (d, col) minimum; `who` = lane that holds it.  All lanes of each 16-lane row end with
+// the row's result; NARROW callers only use row 0.
+template <int CTRL> __device__ __forceinline__ void min_step(double &d, int &col, int &who) {
+    const double od = dpp_d<CTRL>(d);
+    const int oc = dpp_i<CTRL>(col), ow = dpp_i<CTRL>(who);
+    if (od < d || (od == d && oc < col)) { d = od; col = oc; who = ow; }
+}
+__device__ __forceinline__ void min16(double &d, int &col, int &who) {
+    min_step<0xB1>(d, col, who);     // quad_perm [1,0,3,2]  : lane ^ 1
+    min_step<0x4E>(d, col, who);     // quad_perm [2,3,0,1]  : lane ^ 2
+    min_step<0x141>(d, col, who);    // row_half_mirror       : i <-> 7 - i  (pairs the two quads)
+    min_step<0x140>(d, col, who);    // row_mirror            : i <-> 15 - i (pairs the two halves)
 }
 
-constexpr int SM_EDGES = 512;      // edge budget of the register/LDS solver, per wavefront
-struct SmallLds {
+// ---- 3. one wavefront per packed component: shortest augmenting paths ---------------------------------
+struct SmallLds {                    // per-wavefront adjacency copy
     double ecost[SM_EDGES];
-    int32_t ecol[SM_EDGES];
-    int32_t rstart[65];
-    int32_t rows[64];
+    int32_t ecol[SM_EDGES];          // column lane
 };
 
-// Components with <= 64 rows, <= 64 columns and <= SM_EDGES edges (all but pathological crowd
-// clusters): lane k owns local row k (u, its column) AND local column k (v, owner, distance,
-// predecessor, scanned); the adjacency sits in LDS; every step of the Dijkstra search is a handful
-// of __shfl / ds_bpermute operations -- no global memory inside the search.
-__device__ bool solve_small(const LapArgs &A, int c, int lane, SmallLds &L) {
+// Components with <= 64 rows, <= 64 columns and <= SM_EDGES edges: lane k owns local row k (u, its
+// column) AND local column k (v, owner, distance, predecessor, scanned); the adjacency sits in LDS;
+// every step of the Dijkstra search is a handful of __shfl / ds_bpermute operations -- no global
+// memory inside the search.  Returns false if the component does not fit.
+__device__ bool solve_packed(const LapArgs &A, int c, int lane, SmallLds &L) {
     const bts_lap_work &w = A.w;
     const double limit = A.limit, INF = __builtin_huge_val();
-    const int rs = LDG(&w.crow_ptr[c]), r = LDG(&w.crow_ptr[c + 1]) - rs;
-    const int cs = LDG(&w.ccol_ptr[c]), cn = LDG(&w.ccol_ptr[c + 1]) - cs;
-    if (r > 64 || cn > 64) return false;
-    // rows ascending (grouping appended them in arbitrary order)
-    int my_row = lane < r ? LDG(&w.crows[rs + lane]) : 0x7fffffff;
+    const int4 d = w.cdesc[c];
+    const int rs = d.x, cs = d.y, r = d.z & 0xff, cn = (d.z >> 8) & 0xff, ne = d.z >> 16, eb = d.w;
+    if (r > 64 || cn > 64 || ne > SM_EDGES) return false;
+    const int4 ri = lane < r ? w.rowinfo[rs + lane] : make_int4(0x7fffffff, 0, 0, 0);
+    const int my_col = lane < cn ? w.colid[cs + lane] : 0x7fffffff;
+    for (int e = lane; e < ne; e += 64) { L.ecost[e] = w.csr_cost[eb + e]; L.ecol[e] = w.csr_lcol[eb + e]; }   // one contiguous block
+    // rows in ascending id order (the grouping appended them in arbitrary order)
+    int my_row = 0x7fffffff, e_lo = 0, e_hi = 0;
     {
         int rank = 0;
-        for (int q = 0; q < r; ++q) rank += __shfl(my_row, q) < my_row ? 1 : 0;
-        if (lane < r) L.rows[rank] = my_row;
-        lds_sync();
-        my_row = lane < r ? L.rows[lane] : -1;
-    }
-    const int my_col = lane < cn ? LDG(&w.ccols[cs + lane]) : 0x7fffffff;
-    // local CSR
-    const int my_slot = lane < r ? LDG(&w.slot_of_row[my_row]) : 0;
-    const int e_lo = lane < r ? LDG(&w.rptr[my_slot]) : 0, deg = lane < r ? LDG(&w.rptr[my_slot + 1]) - e_lo : 0;
-    int incl = deg;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off); if (lane >= off) incl += t; }
-    const int etot = __shfl(incl, 63);
-    if (etot > SM_EDGES) return false;
-    L.rstart[lane] = incl - deg;
-    if (lane == 63) L.rstart[64] = etot;
-    if (lane < cn) STG(&w.pred[my_col], lane);          // global column id -> local lane (scratch reuse)
-    wave_sync();
-    double u = limit;
-    for (int e = 0; e < deg; ++e) {
-        const double cc = LDG(&w.csr_cost[e_lo + e]);
-        L.ecost[incl - deg + e] = cc;
-        L.ecol[incl - deg + e] = LDG(&w.pred[LDG(&w.csr_col[e_lo + e])]);
-        u = fmin(u, cc);
+        for (int q = 0; q < r; ++q) rank += bcast_i(ri.x, q) < ri.x ? 1 : 0;
+        for (int q = 0; q < r; ++q) {
+            const int rq = bcast_i(rank, q), v0 = bcast_i(ri.x, q), v1 = bcast_i(ri.y, q), v2 = bcast_i(ri.z, q);
+            if (lane == rq) { my_row = v0; e_lo = v1 - eb; e_hi = v2 - eb; }
+        }
     }
     lds_sync();
+    double u = limit;
+    for (int e = e_lo; e < e_hi; ++e) u = fmin(u, L.ecost[e]);
     int xr = -1, yc = -1;       // row -> local column, column -> local row
     double v = 0.0;
     for (int i0 = 0; i0 < r; ++i0) {
         double dist = INF;
         int pred = -1;
         bool scanned = false;
-        double exit_d = limit - __shfl(u, i0);
+        double exit_d = limit - bcast_d(u, i0);
         int exit_row = i0, cur = i0, end_col = -1;
         double dcur = 0.0, mu = 0.0;
         for (;;) {
-            const double ucur = __shfl(u, cur);
-            const int e0 = L.rstart[cur], e1 = L.rstart[cur + 1];
+            const double ucur = bcast_d(u, cur);
+            const int e0 = bcast_i(e_lo, cur), e1 = bcast_i(e_hi, cur);
             for (int e = e0; e < e1; ++e) {
                 if (L.ecol[e] == lane && !scanned) {
                     const double nd = dcur + ((L.ecost[e] - ucur) - v);
@@ -316,18 +471,22 @@ __device__ bool solve_small(const LapArgs &A, int c, int lane, SmallLds &L) {
             }
             double bd = (lane < cn && !scanned) ? dist : INF;
             int bcol = my_col, bl = lane;
+            min16(bd, bcol, bl);
+            if (cn > 16) {
 #pragma unroll
-            for (int off = 32; off; off >>= 1) {
-                const double od = __shfl_xor(bd, off);
-                const int oc = __shfl_xor(bcol, off), ol = __shfl_xor(bl, off);
-                if (od < bd || (od == bd && oc < bcol)) { bd = od; bcol = oc; bl = ol; }
+                for (int off = 32; off >= 16; off >>= 1) {
+                    const double od = __shfl_xor(bd, off);
+                    const int oc = __shfl_xor(bcol, off), ol = __shfl_xor(bl, off);
+                    if (od < bd || (od == bd && oc < bcol)) { bd = od; bcol = oc; bl = ol; }
+                }
             }
+            bd = bcast_d(bd, 0); bl = bcast_i(bl, 0);
             if (!(bd < INF) || exit_d < bd) { mu = exit_d; break; }
-            const int owner = __shfl(yc, bl);
+            const int owner = bcast_i(yc, bl);
             if (owner < 0) { mu = bd; end_col = bl; break; }
             if (lane == bl) scanned = true;
             cur = owner; dcur = bd;
-            const double e2 = bd + (limit - __shfl(u, owner));
+            const double e2 = bd + (limit - bcast_d(u, owner));
             if (e2 < exit_d) { exit_d = e2; exit_row = owner; }
         }
         // duals: every scanned column hands its delta to the row that owns it
@@ -340,12 +499,12 @@ __device__ bool solve_small(const LapArgs &A, int c, int lane, SmallLds &L) {
         int j = end_col;
         if (j < 0) {
             if (exit_row == i0) continue;
-            j = __shfl(xr, exit_row);
+            j = bcast_i(xr, exit_row);
             if (lane == exit_row) xr = -1;
         }
         for (;;) {
-            const int i = __shfl(pred, j);
-            const int jn = __shfl(xr, i);
+            const int i = bcast_i(pred, j);
+            const int jn = bcast_i(xr, i);
             if (lane == i) xr = j;
             if (lane == j) yc = i;
             if (i == i0) break;
@@ -355,6 +514,7 @@ __device__ bool solve_small(const LapArgs &A, int c, int lane, SmallLds &L) {
     const int xcol = __shfl(my_col, xr >= 0 ? xr : 0), yrow = __shfl(my_row, yc >= 0 ? yc : 0);
     if (lane < r) A.x[my_row] = xr >= 0 ? xcol : -1;
     if (lane < cn) A.y[my_col] = yc >= 0 ? yrow : -1;
+    lds_sync();                 // the next component of this wavefront reuses L
     return true;
 }
 
@@ -380,7 +540,7 @@ __device__ void solve_component(const LapArgs &A, int c, int lane) {
         const int i = LDG(&w.crows_s[rs + k]);
         double mn = limit;
         const int sl = LDG(&w.slot_of_row[i]);
-        for (int e = LDG(&w.rptr[sl]); e < LDG(&w.rptr[sl + 1]); ++e) mn = fmin(mn, LDG(&w.csr_cost[e]));
+        for (int e = LDG(&w.rlo[sl]); e < LDG(&w.rhi[sl]); ++e) mn = fmin(mn, LDG(&w.csr_cost[e]));
         STG(&w.u[i], mn);
     }
     wave_sync();
@@ -397,8 +557,8 @@ __device__ void solve_component(const LapArgs &A, int c, int lane) {
         for (;;) {
             const double ucur = LDG(&w.u[cur]);
             const int scur = LDG(&w.slot_of_row[cur]);
-            const int e1 = LDG(&w.rptr[scur + 1]);
-            for (int e = LDG(&w.rptr[scur]) + lane; e < e1; e += 64) {
+            const int e1 = LDG(&w.rhi[scur]);
+            for (int e = LDG(&w.rlo[scur]) + lane; e < e1; e += 64) {
                 const int j = LDG(&w.csr_col[e]);
                 if (!LDG(&w.scanned[j])) {
                     const double nd = dcur + ((LDG(&w.csr_cost[e]) - ucur) - LDG(&w.v[j]));
@@ -463,14 +623,62 @@ __device__ void solve_component(const LapArgs &A, int c, int lane) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_solve(LapArgs A0, LapArgs A1) {
-    __shared__ SmallLds lds[4];
-    const LapArgs &A = blockIdx.y ? A1 : A0;
-    const int C = LDG(&A.w.hdr[H_HARD]);
-    const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwave = (gridDim.x * blockDim.x) >> 6;
-    for (int c = wave; c < C; c += nwave)
-        if (!solve_small(A, c, lane, lds[threadIdx.x >> 6])) solve_component(A, c, lane);
+// ---- the one launch -----------------------------------------------------------------------------------
+// grid = (problems, 1 + helpers); 1024 threads.  Workgroup y = 0 of a problem prepares; the helper
+// workgroups wait for hdr[H_READY] (1 + number of packed components) and share the components.
+constexpr int LAP_HELPERS = 15;    // helper workgroups per problem (16 wavefronts each)
+constexpr unsigned LAP_LDS_BYTES = sizeof(SmallPipe) > 16 * sizeof(SmallLds) ? sizeof(SmallPipe) : 16 * sizeof(SmallLds);
+
+__global__ __launch_bounds__(1024) void k_lap(LapArgs A0, LapArgs A1) {
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    __shared__ int32_t tmp[1024];
+    __shared__ int s_c;
+    const LapArgs &A = blockIdx.x ? A1 : A0;
+    const bts_lap_work &w = A.w;
+    const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63, wid = tid >> 6;
+    int C = 0;
+    if (blockIdx.y == 0) {
+        const int n = A.dims ? A.dims[0] : A.n_max, m = A.dims ? A.dims[1] : A.m_max;
+        int E = RLX(&w.hdr[H_EDGES]);
+        if ((long)E > w.e_cap) E = (int)w.e_cap;
+        if (!A.fresh) {
+            for (int i = tid; i < n; i += nth) { RST(&w.deg[i], 0); A.x[i] = -1; }
+            for (int j = tid; j < m; j += nth) { RST(&w.cdeg[j], 0); A.y[j] = -1; }
+            __syncthreads();
+        }
+        int state = E > 0 ? -1 : 0;
+        if (E > 0 && n + m <= TABLE_CAP) state = small_pipeline(A, *reinterpret_cast<SmallPipe *>(lds_raw), E, n, m, tmp);
+        if (state < 0) {                                  // LARGE form: global degree arrays
+            __syncthreads();
+            const int EH = isolated_pairs(A, E);
+            if (EH > 0) large_pipeline(A, EH, tmp);
+        }
+        __syncthreads();
+        C = RLX(&w.hdr[H_HARD]);
+        // publish (stores -> barrier -> one lane: agent release, drain, relaxed flag)
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            RST(&w.hdr[H_READY], 1 + C);
+        }
+    } else {
+        if (tid == 0) {
+            int v = 0;
+            for (long spins = 0; (v = RLX(&w.hdr[H_READY])) == 0 && spins < (1l << 22); ++spins) __builtin_amdgcn_s_sleep(32);
+            if (v == 0) { RST(&w.hdr[H_ERR], 2); v = 1; }      // give up loudly rather than hang the queue
+            s_c = v - 1;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        C = s_c;
+    }
+    if (C == 0) return;
+    SmallLds *lds = reinterpret_cast<SmallLds *>(lds_raw);
+    const int gw = blockIdx.y * (nth >> 6) + wid, nw = gridDim.y * (nth >> 6);
+    for (int c = gw; c < C; c += nw)
+        if (!solve_packed(A, c, lane, lds[wid])) solve_component(A, c, lane);
+    if (blockIdx.y == 0) { __syncthreads(); TSTAMP(4); }
 }
 
 }  // namespace
@@ -480,7 +688,7 @@ static size_t carve(size_t &off, size_t bytes) { const size_t o = off; off = bts
 
 static void layout(bts_lap_work *w, char *base, size_t &off, int n, int m, int64_t e) {
 #define SLOT(field, type, count) { size_t o = carve(off, sizeof(type) * (size_t)(count)); w->field = base ? (type *)(base + o) : nullptr; }
-    SLOT(hdr, int32_t, 16);
+    SLOT(hdr, int32_t, BTS_LAP_HDR_INTS);
     SLOT(e_row, int32_t, e); SLOT(e_col, int32_t, e); SLOT(e_cost, double, e);
     SLOT(deg, int32_t, n); SLOT(cdeg, int32_t, m); SLOT(rptr, int32_t, n + 1); SLOT(cursor, int32_t, n);
     SLOT(csr_col, int32_t, e); SLOT(csr_cost, double, e);
@@ -488,7 +696,8 @@ static void layout(bts_lap_work *w, char *base, size_t &off, int n, int m, int64
     SLOT(crow_ptr, int32_t, n + 1); SLOT(ccol_ptr, int32_t, n + 1);
     SLOT(ccur_r, int32_t, n + 1); SLOT(ccur_c, int32_t, n + 1);
     SLOT(crows, int32_t, n); SLOT(crows_s, int32_t, n); SLOT(ccols, int32_t, m); SLOT(comp_list, int32_t, n);
-    SLOT(slot_of_row, int32_t, n); SLOT(arow, int32_t, n); SLOT(acol, int32_t, m); SLOT(hard, int32_t, e);
+    SLOT(slot_of_row, int32_t, n); SLOT(slot_of_col, int32_t, m); SLOT(col_local, int32_t, m); SLOT(colid, int32_t, m);
+    SLOT(cdesc, int4, n); SLOT(rowinfo, int4, n); SLOT(rpos, int32_t, n); SLOT(gstart, int32_t, n + 1); SLOT(rlo, int32_t, n); SLOT(rhi, int32_t, n); SLOT(csr_lcol, int32_t, e); SLOT(arow, int32_t, n); SLOT(acol, int32_t, m); SLOT(hard, int32_t, e);
     SLOT(u, double, n); SLOT(v, double, m); SLOT(dist, double, m);
     SLOT(pred, int32_t, m); SLOT(scanned, int32_t, m);
 #undef SLOT
@@ -508,26 +717,22 @@ void bts_lap_work_carve(bts_lap_work *w, void *block, int n_cap, int m_cap, int6
 }
 
 int bts_lap_enqueue_reset(const bts_lap_work *w, hipStream_t stream) {
-    BTS_HIP(hipMemsetAsync(w->hdr, 0, 16 * sizeof(int32_t), stream));
+    BTS_HIP(hipMemsetAsync(w->hdr, 0, BTS_LAP_HDR_INTS * sizeof(int32_t), stream));
     return BTS_OK;
 }
 
 int bts_lap_enqueue(const bts_lap_problem *probs, int count, hipStream_t stream, hipEvent_t *ev) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        BTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lap), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)LAP_LDS_BYTES));
+        attr_set = true;
+    }
     const bts_lap_problem &A = probs[0], &B = probs[count > 1 ? 1 : 0];
     if (ev) (void)hipEventRecord(ev[0], stream);
-    hipLaunchKernelGGL(k_prepare, dim3(count), dim3(1024), 0, stream, A, B);
+    hipLaunchKernelGGL(k_lap, dim3(count, 1 + LAP_HELPERS), dim3(1024), LAP_LDS_BYTES, stream, A, B);
     BTS_LAUNCH_CHECK();
-    if (ev) { (void)hipEventRecord(ev[1], stream); (void)hipEventRecord(ev[2], stream); }
-    int waves = 1;
-    for (int k = 0; k < count; ++k) {
-        const int w_ = probs[k].n_max < probs[k].m_max ? probs[k].n_max : probs[k].m_max;   // #components <= min(n, m)
-        if (w_ > waves) waves = w_;
-    }
-    int blocks = bts_cdiv(waves, 4);
-    if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(k_solve, dim3(blocks, count), dim3(256), 0, stream, A, B);
-    BTS_LAUNCH_CHECK();
-    if (ev) (void)hipEventRecord(ev[3], stream);
+    if (ev) { (void)hipEventRecord(ev[1], stream); (void)hipEventRecord(ev[2], stream); (void)hipEventRecord(ev[3], stream); }
     return BTS_OK;
 }
 

@@ -50,7 +50,7 @@ struct Dev {
     int32_t *x1, *y1, *x2, *y2, *x3, *y3;
     // dedupe
     uint8_t *drop_t, *drop_l;
-    int32_t *lap_hdr;          // 3 x 16 ints: per-stage counters of the assignment solver
+    int32_t *lap_hdr;          // 3 x 64 ints: per-stage counters of the assignment solver (BTS_LAP_HDR_INTS each)
     int record;                // keep dense cost matrices (tests / inspection)
     int filter;                // appearance term by float16-MFMA pre-filter + exact float32 refine
     _Float16 *body_h, *face_h, *det_h, *dface_h;      // float16 shadows of body_curr/face_curr and of the frame's rows
@@ -139,8 +139,8 @@ __device__ __forceinline__ void prep_body(const Dev &d) {
     const int nlo = block_compact(m, tmp, [&](int j) { const double s = (double)d.scores[j]; return s <= d.high && s >= d.low; },
                                   [&](int p, int j) { d.lo_idx[p] = j; });
     __syncthreads();
-    if (tid < 48) d.lap_hdr[tid] = 0;
-    if (tid == 48 && d.filter) *d.cand_n = 0;
+    if (tid < 3 * BTS_LAP_HDR_INTS) d.lap_hdr[tid] = 0;
+    if (tid == 3 * BTS_LAP_HDR_INTS && d.filter) *d.cand_n = 0;
     if (tid == 0) {
         h[H_FRAME] += 1;
         h[H_NPOOL] = N; h[H_NCONF] = nconf; h[H_NUNC] = nunc; h[H_NHI] = nhi; h[H_NLO] = nlo; h[H_NDETS] = m;
@@ -818,7 +818,7 @@ static void tracker_layout(bts_tracker *t, char *base, size_t &off) {
     else { d.cost2 = d.cost1; d.cost3 = d.cost1; }
     SLOT(d.x1, int32_t, T); SLOT(d.y1, int32_t, M); SLOT(d.x2, int32_t, T); SLOT(d.y2, int32_t, M);
     SLOT(d.x3, int32_t, T); SLOT(d.y3, int32_t, M);
-    SLOT(d.drop_t, uint8_t, T); SLOT(d.drop_l, uint8_t, T); SLOT(d.lap_hdr, int32_t, 48);
+    SLOT(d.drop_t, uint8_t, T); SLOT(d.drop_l, uint8_t, T); SLOT(d.lap_hdr, int32_t, 3 * BTS_LAP_HDR_INTS);
     if (d.filter) {
         SLOT(d.body_h, _Float16, T * D); SLOT(d.det_h, _Float16, M * D); SLOT(d.body_n, float, T); SLOT(d.det_n, float, M);
         SLOT(d.face_h, _Float16, T * Df); SLOT(d.dface_h, _Float16, M * Df); SLOT(d.face_n, float, T); SLOT(d.dface_n, float, M);
@@ -975,7 +975,7 @@ int bts_tracker_step(bts_tracker *t, const int32_t *boxes, const float *scores, 
     const dim3 tile_grid(bts_cdiv(mc, CT_COLS), bts_cdiv(T, CT_ROWS));
     const int kf_blocks = bts_cdiv(T * 8 > M ? T * 8 : M, 256);   // 8 lanes per track
     bts_lap_work lap[3] = {t->lap, t->lap, t->lap3};
-    for (int k = 0; k < 3; ++k) lap[k].hdr = d.lap_hdr + 16 * k;
+    for (int k = 0; k < 3; ++k) lap[k].hdr = d.lap_hdr + BTS_LAP_HDR_INTS * k;
     int rc;
 #define LAUNCH(kern, grid, block, ...) hipLaunchKernelGGL(kern, grid, block, 0, s, d, ##__VA_ARGS__); BTS_LAUNCH_CHECK()
 
@@ -1118,6 +1118,14 @@ int bts_tracker_export(bts_tracker *t, int which, int32_t *ints_host, double *me
         BTS_HIP(hipStreamSynchronize(s));
     }
     return n;
+}
+
+int bts_tracker_debug_lap(bts_tracker *t, int stage, int32_t *hdr16_host, bts_stream stream) {
+    BTS_REQUIRE(t && stage >= 1 && stage <= 3 && hdr16_host, "tracker, stage, out");
+    BTS_HIP(hipMemcpyAsync(hdr16_host, t->dv.lap_hdr + BTS_LAP_HDR_INTS * (stage - 1), 64 * sizeof(int32_t), hipMemcpyDeviceToHost,
+                           (hipStream_t)stream));
+    BTS_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return BTS_OK;
 }
 
 int bts_tracker_stage_result(bts_tracker *t, int stage, int32_t *x_host, int32_t *y_host,

@@ -200,6 +200,11 @@ int bts_tracker_export(bts_tracker *trk, int which, int32_t *ints_host, double *
 int bts_tracker_stage_result(bts_tracker *trk, int stage, int32_t *x_host, int32_t *y_host,
                              double *cost_host, int32_t *n_rows, int32_t *n_cols, bts_stream stream);
 
+/* Counters of the assignment solver for stage s of the last step (synchronises): out[0] feasible
+ * edges, [1] components of the non-trivial part, [2] overflow flag, [6] edges that are not isolated
+ * pairs, [8] form used (0 = isolated pairs only, 1 = LDS form, 2 = global form). */
+int bts_tracker_debug_lap(bts_tracker *trk, int stage, int32_t *hdr16_host, bts_stream stream);
+
 /* Measurement hook (bench.py's roofline leg): wrap one kernel group of every following
  * bts_tracker_step in a hipEvent pair recorded on the step's stream.  `capacity` pairs are kept
  * (steps beyond that are not timed); capacity 0 disables.  Events are created here, never in a step. */
