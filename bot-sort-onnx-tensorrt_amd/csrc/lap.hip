@@ -678,7 +678,6 @@ __global__ __launch_bounds__(1024) void k_lap(LapArgs A0, LapArgs A1) {
     const int gw = blockIdx.y * (nth >> 6) + wid, nw = gridDim.y * (nth >> 6);
     for (int c = gw; c < C; c += nw)
         if (!solve_packed(A, c, lane, lds[wid])) solve_component(A, c, lane);
-    if (blockIdx.y == 0) { __syncthreads(); TSTAMP(4); }
 }
 
 }  // namespace
