@@ -41,12 +41,23 @@ __device__ __forceinline__ int compact(int L, int *smem, Pred pred, Emit emit) {
     const int tid = threadIdx.x, nth = blockDim.x;
     const int per = (L + nth - 1) / nth;
     const int lo = min(L, tid * per), hi = min(L, lo + per);
-    int cnt = 0;
-    for (int k = lo; k < hi; ++k) cnt += pred(k) ? 1 : 0;
     int total;
-    int pos = exscan(cnt, smem, &total);
-    for (int k = lo; k < hi; ++k)
-        if (pred(k)) emit(pos++, k);
+    if (per <= 64) {                       // predicate evaluated once: results kept in a bit mask
+        unsigned long long mask = 0;
+        for (int k = lo; k < hi; ++k) mask |= (unsigned long long)(pred(k) ? 1 : 0) << (k - lo);
+        int pos = exscan(__popcll(mask), smem, &total);
+        while (mask) {
+            const int b = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            emit(pos++, lo + b);
+        }
+    } else {
+        int cnt = 0;
+        for (int k = lo; k < hi; ++k) cnt += pred(k) ? 1 : 0;
+        int pos = exscan(cnt, smem, &total);
+        for (int k = lo; k < hi; ++k)
+            if (pred(k)) emit(pos++, k);
+    }
     __syncthreads();
     return total;
 }

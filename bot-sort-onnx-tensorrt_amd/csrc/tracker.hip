@@ -202,15 +202,14 @@ __device__ __forceinline__ float face_fixup(float s) {
 //         k_filter); stage 3 refines the few overlapping pairs with an exact wavefront dot product.
 // MODE 2: record only (dense cost matrix for inspection, no edges).
 template <int STAGE, int MODE>
-__device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w) {
+__device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, int bx, int by) {
     __shared__ double sa[CT_ROWS][4];
     __shared__ double sarea[CT_ROWS];
     __shared__ int sflag[CT_ROWS];
     const int32_t *h = d.hdr;
     const int n = STAGE == 1 ? h[H_NPOOL] : STAGE == 2 ? h[H_NR2] : h[H_NUNC];
     const int m = STAGE == 1 ? h[H_NHI] : STAGE == 2 ? h[H_NLO] : h[H_NLEFT];
-    const int i0 = blockIdx.y * CT_ROWS, q = blockIdx.x * CT_COLS + threadIdx.x;
-    if (i0 >= n || blockIdx.x * CT_COLS >= m) return;
+    const int i0 = by * CT_ROWS, q = bx * CT_COLS + threadIdx.x;
     const double *abox = STAGE == 1 ? d.pool_tlbr : STAGE == 2 ? d.r2_tlbr : d.unc_tlbr;
     if (threadIdx.x < CT_ROWS && i0 + threadIdx.x < n) {
         const int i = i0 + threadIdx.x;
@@ -272,16 +271,28 @@ __device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w) 
         if (MODE == 2 || d.record) cost[o] = c;
         if (MODE == 0 && c <= limit) emit(i0 + r, c);
     }
+    __syncthreads();          // the tile's LDS is reused by the caller's next tile
+}
+
+// Persistent tiles: the live extents are only known on the device, so a fixed grid walks the
+// (column tile, row tile) space of the actual problem instead of launching capacity-sized grids.
+template <int STAGE, int MODE>
+__device__ __forceinline__ void edges_all(const Dev &d, const bts_lap_work &w) {
+    const int32_t *h = d.hdr;
+    const int n = STAGE == 1 ? h[H_NPOOL] : STAGE == 2 ? h[H_NR2] : h[H_NUNC];
+    const int m = STAGE == 1 ? h[H_NHI] : STAGE == 2 ? h[H_NLO] : h[H_NLEFT];
+    const int nct = (m + CT_COLS - 1) / CT_COLS, ntile = nct * ((n + CT_ROWS - 1) / CT_ROWS);
+    for (int t = blockIdx.x; t < ntile; t += gridDim.x) edges_tile<STAGE, MODE>(d, w, t % nct, t / nct);
 }
 
 template <int STAGE, int MODE>
-__global__ __launch_bounds__(CT_COLS) void tk_edges(Dev d, bts_lap_work w) { edges_tile<STAGE, MODE>(d, w); }
+__global__ __launch_bounds__(CT_COLS) void tk_edges(Dev d, bts_lap_work w) { edges_all<STAGE, MODE>(d, w); }
 
-// stages 2 and 3 are independent of each other (disjoint tracks and detections): one launch, z selects
+// stages 2 and 3 are independent of each other (disjoint tracks and detections): one launch, y selects
 template <int MODE3>
 __global__ __launch_bounds__(CT_COLS) void tk_edges23(Dev d, bts_lap_work w2, bts_lap_work w3) {
-    if (blockIdx.z == 0) edges_tile<2, 0>(d, w2);
-    else edges_tile<3, MODE3>(d, w3);
+    if (blockIdx.y == 0) edges_all<2, 0>(d, w2);
+    else edges_all<3, MODE3>(d, w3);
 }
 
 // ---- appearance pre-filter: float16 MFMA GEMM + exact float32 refine ------------------------------------------
@@ -450,20 +461,23 @@ __global__ __launch_bounds__(256) void k_filter(Dev d, bts_lap_work w, int m_max
 template <bool FACE>
 __global__ __launch_bounds__(CT_COLS) void k_filter_scan(Dev d) {
     const int n = d.hdr[H_NPOOL], m = d.hdr[H_NHI];
-    const int i0 = blockIdx.y * CT_ROWS, q = blockIdx.x * CT_COLS + threadIdx.x;
-    if (i0 >= n || q >= m) return;
     const float *na = FACE ? d.face_n : d.body_n, *nb = FACE ? d.dface_n : d.det_n;
     const float eps = FACE ? d.eps_face : d.eps_body, gate = 1.0f - d.app;
-    const float nbq = nb[d.hi_idx[q]];
-    const int rows = min(CT_ROWS, n - i0);
-    for (int r = 0; r < rows; ++r) {
-        const int i = i0 + r;
-        float *p = &d.approx[(long)i * d.Mx + q];
-        const float val = *p;
-        *p = 0.0f;
-        if (is_candidate(val, na[d.pool_slot[i]], nbq, gate, eps)) {
-            const int pos = atomicAdd(d.cand_n, 1);
-            if (pos < d.cand_cap) { d.cand_i[pos] = i; d.cand_q[pos] = q; }
+    const int nct = (m + CT_COLS - 1) / CT_COLS, ntile = nct * ((n + CT_ROWS - 1) / CT_ROWS);
+    for (int t = blockIdx.x; t < ntile; t += gridDim.x) {
+        const int i0 = (t / nct) * CT_ROWS, q = (t % nct) * CT_COLS + threadIdx.x;
+        if (q >= m) continue;
+        const float nbq = nb[d.hi_idx[q]];
+        const int rows = min(CT_ROWS, n - i0);
+        for (int r = 0; r < rows; ++r) {
+            const int i = i0 + r;
+            float *p = &d.approx[(long)i * d.Mx + q];
+            const float val = *p;
+            *p = 0.0f;
+            if (is_candidate(val, na[d.pool_slot[i]], nbq, gate, eps)) {
+                const int pos = atomicAdd(d.cand_n, 1);
+                if (pos < d.cand_cap) { d.cand_i[pos] = i; d.cand_q[pos] = q; }
+            }
         }
     }
 }
@@ -695,36 +709,40 @@ __global__ __launch_bounds__(CT_COLS) void tk_dedupe(Dev d) {
     __shared__ int sflag[CT_ROWS];
     __shared__ int sage[CT_ROWS];
     const int n = d.hdr[H_NT2], m = d.hdr[H_NL2];
-    const int i0 = blockIdx.y * CT_ROWS, j = blockIdx.x * CT_COLS + threadIdx.x;
-    if (i0 >= n || blockIdx.x * CT_COLS >= m) return;
-    if (threadIdx.x < CT_ROWS && i0 + threadIdx.x < n) {
-        const int s = d.tracked2[i0 + threadIdx.x];
-        double box[4];
-        slot_tlbr(d, s, box);
-        const bool f = d.f32[s] != 0;
-        for (int c = 0; c < 4; ++c) sa[threadIdx.x][c] = box[c];
-        sarea[threadIdx.x] = iou::area(box, f);
-        sflag[threadIdx.x] = f;
-        sage[threadIdx.x] = d.frame_id[s] - d.start_frame[s];
-    }
-    __syncthreads();
-    if (j >= m) return;
-    const int sj = d.lost2[j];
-    double bb[4];
-    slot_tlbr(d, sj, bb);
-    const bool bf = d.f32[sj] != 0;
-    const double area_b = iou::area(bb, bf);
-    const int agej = d.frame_id[sj] - d.start_frame[sj];
-    const int rows = min(CT_ROWS, n - i0);
-    bool dropj = false;
-    for (int r = 0; r < rows; ++r) {
-        const double aa[4] = {sa[r][0], sa[r][1], sa[r][2], sa[r][3]};
-        if (iou::cost(aa, sflag[r] != 0, sarea[r], bb, bf, area_b) < d.dedupe_thr) {
-            if (sage[r] > agej) dropj = true;
-            else d.drop_t[i0 + r] = 1;
+    const int nct = (m + CT_COLS - 1) / CT_COLS, ntile = nct * ((n + CT_ROWS - 1) / CT_ROWS);
+    for (int t = blockIdx.x; t < ntile; t += gridDim.x) {
+        const int i0 = (t / nct) * CT_ROWS, j = (t % nct) * CT_COLS + threadIdx.x;
+        if (threadIdx.x < CT_ROWS && i0 + threadIdx.x < n) {
+            const int s = d.tracked2[i0 + threadIdx.x];
+            double box[4];
+            slot_tlbr(d, s, box);
+            const bool f = d.f32[s] != 0;
+            for (int c = 0; c < 4; ++c) sa[threadIdx.x][c] = box[c];
+            sarea[threadIdx.x] = iou::area(box, f);
+            sflag[threadIdx.x] = f;
+            sage[threadIdx.x] = d.frame_id[s] - d.start_frame[s];
         }
+        __syncthreads();
+        if (j < m) {
+            const int sj = d.lost2[j];
+            double bb[4];
+            slot_tlbr(d, sj, bb);
+            const bool bf = d.f32[sj] != 0;
+            const double area_b = iou::area(bb, bf);
+            const int agej = d.frame_id[sj] - d.start_frame[sj];
+            const int rows = min(CT_ROWS, n - i0);
+            bool dropj = false;
+            for (int r = 0; r < rows; ++r) {
+                const double aa[4] = {sa[r][0], sa[r][1], sa[r][2], sa[r][3]};
+                if (iou::cost(aa, sflag[r] != 0, sarea[r], bb, bf, area_b) < d.dedupe_thr) {
+                    if (sage[r] > agej) dropj = true;
+                    else d.drop_t[i0 + r] = 1;
+                }
+            }
+            if (dropj) d.drop_l[j] = 1;
+        }
+        __syncthreads();
     }
-    if (dropj) d.drop_l[j] = 1;
 }
 
 // ---- frame epilogue (1 workgroup): final lists, slot recycling ------------------------------------------------
@@ -972,7 +990,9 @@ int bts_tracker_step(bts_tracker *t, const int32_t *boxes, const float *scores, 
     const int T = d.T, M = d.Mx;
     const int mc = m > 0 ? m : 1;                 // host-known bound on every detection-indexed extent
     const int cos_kernel = t->ctx->cos_kernel;
-    const dim3 tile_grid(bts_cdiv(mc, CT_COLS), bts_cdiv(T, CT_ROWS));
+    int ntile = bts_cdiv(mc, CT_COLS) * bts_cdiv(T, CT_ROWS);
+    if (ntile > 1024) ntile = 1024;
+    const dim3 tile_grid(ntile);               // persistent tiles: the kernels walk the live extents
     const int kf_blocks = bts_cdiv(T * 8 > M ? T * 8 : M, 256);   // 8 lanes per track
     bts_lap_work lap[3] = {t->lap, t->lap, t->lap3};
     for (int k = 0; k < 3; ++k) lap[k].hdr = d.lap_hdr + BTS_LAP_HDR_INTS * k;
@@ -1064,7 +1084,7 @@ int bts_tracker_step(bts_tracker *t, const int32_t *boxes, const float *scores, 
                              d.sim, M, s);
         if (rc) return rc;
     }
-    const dim3 tile_grid2(tile_grid.x, tile_grid.y, 2);
+    const dim3 tile_grid2(tile_grid.x, 2);
     if (d.filter) {
         LAUNCH(tk_edges23<1>, tile_grid2, dim3(CT_COLS), lap[1], lap[2]);
         if (d.record) { LAUNCH((tk_edges<3, 2>), tile_grid, dim3(CT_COLS), lap[2]); }
@@ -1082,7 +1102,10 @@ int bts_tracker_step(bts_tracker *t, const int32_t *boxes, const float *scores, 
     LAUNCH(tk_birth_init, dim3(mc), dim3(256));
     seg_end(BTS_SEG_MERGE);
     seg_begin(BTS_SEG_DEDUPE);
-    LAUNCH(tk_dedupe, dim3(bts_cdiv(T, CT_COLS), bts_cdiv(T, CT_ROWS)), dim3(CT_COLS));
+    {
+        int nd = bts_cdiv(T, CT_COLS) * bts_cdiv(T, CT_ROWS);
+        LAUNCH(tk_dedupe, dim3(nd > 1024 ? 1024 : nd), dim3(CT_COLS));
+    }
     LAUNCH(tk_finalize, dim3(1), dim3(1024));
     seg_end(BTS_SEG_DEDUPE);
     seg_end(BTS_SEG_STEP);
