@@ -44,7 +44,12 @@ __device__ __forceinline__ int compact(int L, int *smem, Pred pred, Emit emit) {
     int total;
     if (per <= 64) {                       // predicate evaluated once: results kept in a bit mask
         unsigned long long mask = 0;
-        for (int k = lo; k < hi; ++k) mask |= (unsigned long long)(pred(k) ? 1 : 0) << (k - lo);
+        int k = lo;
+        for (; k + 3 < hi; k += 4) {       // four independent predicate evaluations: their loads overlap
+            const bool b0 = pred(k), b1 = pred(k + 1), b2 = pred(k + 2), b3 = pred(k + 3);
+            mask |= (unsigned long long)((b0 ? 1 : 0) | (b1 ? 2 : 0) | (b2 ? 4 : 0) | (b3 ? 8 : 0)) << (k - lo);
+        }
+        for (; k < hi; ++k) mask |= (unsigned long long)(pred(k) ? 1 : 0) << (k - lo);
         int pos = exscan(__popcll(mask), smem, &total);
         while (mask) {
             const int b = __ffsll((long long)mask) - 1;

@@ -121,7 +121,19 @@ __device__ __forceinline__ float wave_dot(const float *a, const float *b, int d,
     float acc = 0.0f;
     if (vec4_ok(a, d) && vec4_ok(b, d)) {
         const float4 *a4 = reinterpret_cast<const float4 *>(a), *b4 = reinterpret_cast<const float4 *>(b);
-        for (int k = lane; k < d / 4; k += 64) {
+        const int nv = d / 4;
+        int k = lane;
+        for (; k + 7 * 64 < nv; k += 8 * 64) {          // 16 independent 16-byte loads in flight per lane
+            float4 x[8], y[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) { x[t] = a4[k + t * 64]; y[t] = b4[k + t * 64]; }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                acc = fmaf(x[t].x, y[t].x, acc); acc = fmaf(x[t].y, y[t].y, acc);
+                acc = fmaf(x[t].z, y[t].z, acc); acc = fmaf(x[t].w, y[t].w, acc);
+            }
+        }
+        for (; k < nv; k += 64) {
             const float4 x = a4[k], y = b4[k];
             acc = fmaf(x.x, y.x, acc); acc = fmaf(x.y, y.y, acc); acc = fmaf(x.z, y.z, acc); acc = fmaf(x.w, y.w, acc);
         }

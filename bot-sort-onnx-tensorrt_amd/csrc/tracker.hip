@@ -344,8 +344,8 @@ __device__ __forceinline__ bool is_candidate(float approx, float na, float nb, f
 
 template <bool FACE>
 __global__ __launch_bounds__(256) void k_filter(Dev d, bts_lap_work w, int m_max) {
-    __shared__ __attribute__((aligned(16))) _Float16 As[FBM * FLD];
-    __shared__ __attribute__((aligned(16))) _Float16 Bs[FBN * FLD];
+    __shared__ __attribute__((aligned(16))) _Float16 As2[2][FBM * FLD];     // double-buffered operand tiles
+    __shared__ __attribute__((aligned(16))) _Float16 Bs2[2][FBN * FLD];
     const int n = d.hdr[H_NPOOL], m = d.hdr[H_NHI];
     const int Dd = FACE ? d.Df : d.D;
     const _Float16 *A = FACE ? d.face_h : d.body_h, *B = FACE ? d.dface_h : d.det_h;
@@ -376,11 +376,11 @@ __global__ __launch_bounds__(256) void k_filter(Dev d, bts_lap_work w, int m_max
             rb[s] = (brow[s] && k < Dd) ? *reinterpret_cast<const uint4 *>(brow[s] + k) : make_uint4(0, 0, 0, 0);
         }
     };
-    auto stage_write = [&]() {
+    auto stage_write = [&](int buf) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            *reinterpret_cast<uint4 *>(&As[(srow + 32 * s) * FLD + sk]) = ra[s];
-            *reinterpret_cast<uint4 *>(&Bs[(srow + 32 * s) * FLD + sk]) = rb[s];
+            *reinterpret_cast<uint4 *>(&As2[buf][(srow + 32 * s) * FLD + sk]) = ra[s];
+            *reinterpret_cast<uint4 *>(&Bs2[buf][(srow + 32 * s) * FLD + sk]) = rb[s];
         }
     };
     f32x16 acc[2][2];
@@ -391,12 +391,16 @@ __global__ __launch_bounds__(256) void k_filter(Dev d, bts_lap_work w, int m_max
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
     const int frow = lane & 31, fh = lane >> 5;
+    // One barrier per K step: while tile kt is multiplied out of buffer `cur`, tile kt+1 travels
+    // HBM -> registers, and is written into the other buffer before the barrier.
     stage_load(kt0 * FBK);
+    stage_write(0);
+    __syncthreads();
+    int cur = 0;
     for (int kt = kt0; kt < kt1; ++kt) {
-        __syncthreads();
-        stage_write();
-        __syncthreads();
-        if (kt + 1 < kt1) stage_load((kt + 1) * FBK);
+        const bool more = kt + 1 < kt1;
+        if (more) stage_load((kt + 1) * FBK);
+        const _Float16 *As = As2[cur], *Bs = Bs2[cur];
 #pragma unroll
         for (int t = 0; t < FBK / 16; ++t) {
             half8 fa[2], fb[2];
@@ -412,13 +416,16 @@ __global__ __launch_bounds__(256) void k_filter(Dev d, bts_lap_work w, int m_max
                 for (int ni = 0; ni < 2; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
         }
+        if (more) stage_write(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
     }
     // epilogue: the tile's row/column norms go through LDS (the operand tiles are dead now)
     const float *na = FACE ? d.face_n : d.body_n, *nb = FACE ? d.dface_n : d.det_n;
     const float eps = FACE ? d.eps_face : d.eps_body, gate = 1.0f - d.app;
     const bool split = gridDim.y > 1;
     __syncthreads();
-    float *snorm = reinterpret_cast<float *>(As);          // [0,128): rows, [128,256): columns
+    float *snorm = reinterpret_cast<float *>(As2[0]);      // [0,128): rows, [128,256): columns
     {
         const int g = tid < FBM ? bm * FBM + tid : bn * FBN + (tid - FBM);
         float v = 0.0f;
