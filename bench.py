@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--dense", action="store_true", help="dense float32 appearance path instead of the f16 pre-filter")
+    ap.add_argument("--graph", action="store_true", help="replay each step as one hipGraph (bts_tracker_config.use_graph)")
     ap.add_argument("--breakdown", action="store_true", help="also report the per-segment timing table")
     return ap.parse_args()
 
@@ -137,9 +138,11 @@ def main():
         fr = st.next()
         return (torch.from_numpy(fr.boxes).cuda(), torch.from_numpy(fr.scores).cuda(), torch.from_numpy(fr.feats).cuda())
 
+    stream = torch.cuda.Stream()          # graph replay needs a real (non-legacy) stream
+    torch.cuda.set_stream(stream)
     frames = [next_frame() for _ in range(a.warmup)]
     trk = pkg.DeviceTracker(max_tracks=K + 64, max_dets=max(K, M), feat_dim=D, device=torch.cuda.current_device(),
-                            appearance_mode=1 if a.dense else 0)
+                            appearance_mode=1 if a.dense else 0, use_graph=1 if a.graph else 0)
 
     ms = importlib.import_module("bot-sort-onnx-tensorrt_amd.multistream")
     ddist = dist if world > 1 else None
@@ -156,8 +159,11 @@ def main():
         ms_, n_ = trk.profile_read()
         breakdown[seg] = 1e3 * ms_ / max(n_, 1)
     segment = a.segment if a.segment != "auto" else max(KERNELS, key=lambda k: breakdown[k])
-    trk.profile_enable(segment, a.steps)
+    trk.profile_enable(segment, 0 if a.graph else a.steps)     # graph replay cannot carry per-kernel events
     timed = [next_frame() for _ in range(a.steps)]
+    if a.graph:                                              # capture happens on the first replayed step: keep it untimed
+        trk.step(*next_frame())
+        torch.cuda.synchronize()
 
     ms.barrier(ddist)
     torch.cuda.synchronize()
@@ -167,6 +173,11 @@ def main():
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     ms.barrier(ddist)
+    if a.graph:      # the dominant kernel's duration: same number of further steps, eager, with events
+        trk.profile_enable(segment, a.steps)
+        for _ in range(a.steps):
+            trk.step(*next_frame())
+        torch.cuda.synchronize()
     seg_ms, seg_n = trk.profile_read()
     counts = trk.counts()
     assert counts["errors"] == 0, counts
@@ -191,7 +202,8 @@ def main():
             "dtype": "f64", "data": "synthetic (seeded stream generator, SURVEY.md 8d; frames resident in HBM before the timed region)",
             "config": {"workload": "%s: %d tracks x %d detections/frame x %d-d ReID, IoU+cosine fused cost, "
                                    "3-stage association, one stream per GPU" % (a.workload, K, M, D),
-                       "tracks": K, "dets": M, "feat_dim": D, "streams": world, "parallelism": "1 stream/GPU, no collective"},
+                       "tracks": K, "dets": M, "feat_dim": D, "streams": world, "parallelism": "1 stream/GPU, no collective",
+                       "launch": "hipGraph replay" if a.graph else "eager"},
             "roofline": {"kernel": KERNELS[segment], "bound": bound, "achieved": achieved, "peak": peak, "unit": runit,
                          "frac": achieved / peak, "traffic": None,
                          "avg_us": 1e6 * seg_s, "launches_timed": seg_n,

@@ -134,7 +134,8 @@ struct bts_lap_problem {
     int32_t *x, *y;
     int fresh;
 };
-// Enqueue 1 or 2 independent problems (they share the two launches).
+int bts_lap_init();
+// Enqueue 1 or 2 independent problems (they share one launch).
 // `ev` (nullable): four pre-created events recorded around k_prepare and k_solve (measurement hook).
 int bts_lap_enqueue(const bts_lap_problem *probs, int count, hipStream_t stream, hipEvent_t *ev = nullptr);
 // reset hdr before edges are appended

@@ -720,13 +720,19 @@ int bts_lap_enqueue_reset(const bts_lap_work *w, hipStream_t stream) {
     return BTS_OK;
 }
 
-int bts_lap_enqueue(const bts_lap_problem *probs, int count, hipStream_t stream, hipEvent_t *ev) {
+int bts_lap_init() {      // the solver kernel needs more than the default 64 KiB of dynamic LDS
     static bool attr_set = false;
     if (!attr_set) {
         BTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lap), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)LAP_LDS_BYTES));
         attr_set = true;
     }
+    return BTS_OK;
+}
+
+int bts_lap_enqueue(const bts_lap_problem *probs, int count, hipStream_t stream, hipEvent_t *ev) {
+    int rc0 = bts_lap_init();
+    if (rc0) return rc0;
     const bts_lap_problem &A = probs[0], &B = probs[count > 1 ? 1 : 0];
     if (ev) (void)hipEventRecord(ev[0], stream);
     hipLaunchKernelGGL(k_lap, dim3(count, 1 + LAP_HELPERS), dim3(1024), LAP_LDS_BYTES, stream, A, B);

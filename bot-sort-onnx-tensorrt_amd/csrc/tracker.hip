@@ -25,6 +25,16 @@ enum {   // hdr[] fields
 enum { F_REFIND = 1, F_LOSTNOW = 2, F_REMOVEDNOW = 4 };
 enum { ERR_TRACK_CAPACITY = 1, ERR_LAP_EDGES = 2 };
 
+// The frame's inputs reach the kernels through one small device-resident descriptor, refreshed by
+// a 40-byte async copy per step: kernel arguments then never change, which is what lets a step be
+// captured once as a hipGraph and replayed.
+struct InDesc {
+    const int32_t *boxes;
+    const float *scores;
+    float *feats, *face_feats;
+    int m, pad;
+};
+
 struct Dev {
     int T, Mx, D, Df;
     // thresholds (float64 like the python attributes)
@@ -60,11 +70,7 @@ struct Dev {
     int32_t *cand_i, *cand_q, *cand_n;                 // appearance candidates (pool row, high-det column), count
     int32_t *app_q;                                    // [T] pool row -> column whose stage-1 edge k_refine emitted (-1: none)
     int cand_cap;
-    // inputs of the current step
-    const int32_t *boxes;
-    const float *scores;
-    float *feats, *face_feats;
-    int m;
+    const InDesc *in;          // inputs of the current step
 };
 
 // ---- single-workgroup helpers: bscan::exscan / bscan::compact (block_scan.h) ------------------------
@@ -112,7 +118,7 @@ __device__ __forceinline__ void prep_body(const Dev &d) {
     __shared__ int s_allf32;
     int32_t *h = d.hdr;
     const int tid = threadIdx.x, nth = blockDim.x;
-    const int nt = h[H_NTRACKED], nl = h[H_NLOST], m = d.m;
+    const int nt = h[H_NTRACKED], nl = h[H_NLOST], m = d.in->m;
     if (tid == 0) s_allf32 = 1;
     const int nconf = block_compact(nt, tmp, [&](int k) { return d.is_activated[d.tracked[k]] != 0; },
                                     [&](int p, int k) { d.pool_slot[p] = d.tracked[k]; });
@@ -127,16 +133,16 @@ __device__ __forceinline__ void prep_body(const Dev &d) {
     if (!all32) s_allf32 = 0;
     // detections
     for (int j = tid; j < m; j += nth) {
-        const int x1 = d.boxes[j * 4 + 0], y1 = d.boxes[j * 4 + 1], x2 = d.boxes[j * 4 + 2], y2 = d.boxes[j * 4 + 3];
+        const int x1 = d.in->boxes[j * 4 + 0], y1 = d.in->boxes[j * 4 + 1], x2 = d.in->boxes[j * 4 + 2], y2 = d.in->boxes[j * 4 + 3];
         const float tx = (float)x1, ty = (float)y1, w = (float)(x2 - x1), hh = (float)(y2 - y1);   // _tlwh, D:465
         d.det_tlbr[j * 4 + 0] = (double)tx; d.det_tlbr[j * 4 + 1] = (double)ty;
         d.det_tlbr[j * 4 + 2] = (double)(w + tx); d.det_tlbr[j * 4 + 3] = (double)(hh + ty);         // D:635-642
         d.det_xywh[j * 4 + 0] = tx + w / 2; d.det_xywh[j * 4 + 1] = ty + hh / 2;                     // D:663-670
         d.det_xywh[j * 4 + 2] = w; d.det_xywh[j * 4 + 3] = hh;
     }
-    const int nhi = block_compact(m, tmp, [&](int j) { return (double)d.scores[j] > d.high; },
+    const int nhi = block_compact(m, tmp, [&](int j) { return (double)d.in->scores[j] > d.high; },
                                   [&](int p, int j) { d.hi_idx[p] = j; });
-    const int nlo = block_compact(m, tmp, [&](int j) { const double s = (double)d.scores[j]; return s <= d.high && s >= d.low; },
+    const int nlo = block_compact(m, tmp, [&](int j) { const double s = (double)d.in->scores[j]; return s <= d.high && s >= d.low; },
                                   [&](int p, int j) { d.lo_idx[p] = j; });
     __syncthreads();
     if (tid < 3 * BTS_LAP_HDR_INTS) d.lap_hdr[tid] = 0;
@@ -154,9 +160,9 @@ __device__ __forceinline__ void prep_body(const Dev &d) {
 // ---- K2: STrack.multi_predict over the pool (D:524-536 + D:265-302) ---------------------------------
 // float16 shadows + norms of this frame's (raw) detection rows for the appearance pre-filter
 __device__ __forceinline__ void cvt_body(const Dev &d, long j) {
-    if (j >= d.m) return;
-    feat::to_half_row(d.feats + j * d.D, d.det_h + j * d.D, d.det_n + j, d.D);
-    if (d.Df) feat::to_half_row(d.face_feats + j * d.Df, d.dface_h + j * d.Df, d.dface_n + j, d.Df);
+    if (j >= d.in->m) return;
+    feat::to_half_row(d.in->feats + j * d.D, d.det_h + j * d.D, d.det_n + j, d.D);
+    if (d.Df) feat::to_half_row(d.in->face_feats + j * d.Df, d.dface_h + j * d.Df, d.dface_n + j, d.Df);
 }
 
 // one launch: workgroup 0 builds the frame's lists, the others convert the detection rows
@@ -169,7 +175,7 @@ __global__ __launch_bounds__(256) void tk_predict(Dev d) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     // the three assignment vectors start out "unmatched" (the solver only writes matches)
     if (g < d.T) { d.x1[g] = -1; d.x2[g] = -1; d.x3[g] = -1; if (d.filter) d.app_q[g] = -1; }
-    if (g < d.m) { d.y1[g] = -1; d.y2[g] = -1; d.y3[g] = -1; }
+    if (g < d.in->m) { d.y1[g] = -1; d.y2[g] = -1; d.y3[g] = -1; }
     const int r = g >> 3, i = g & 7;                     // 8 lanes per pool row
     if (r >= d.hdr[H_NPOOL]) return;
     const int s = d.pool_slot[r];
@@ -248,7 +254,7 @@ __device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, 
                     todo &= todo - 1;
                     const long sdet = __shfl(det, src);
                     const long strk = d.unc_slot[i0 + r];
-                    const float sim = fmaxf(0.0f, feat::wave_dot(d.body_curr + strk * d.D, d.feats + sdet * d.D, d.D, lane));
+                    const float sim = fmaxf(0.0f, feat::wave_dot(d.body_curr + strk * d.D, d.in->feats + sdet * d.D, d.D, lane));
                     const float emb = 1.0f - sim;
                     if (lane == src && !(emb > d.app) && (double)emb <= limit) emit(i0 + r, (double)emb);
                 }
@@ -315,10 +321,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // exact gate of one (pool row i, high-detection column q) pair, evaluated by a whole wavefront
 __device__ __forceinline__ void refine_emit1(const Dev &d, const bts_lap_work &w, int i, int q, int lane) {
     const long s = d.pool_slot[i], det = d.hi_idx[q];
-    const float bsim = fmaxf(0.0f, feat::wave_dot(d.body_curr + s * d.D, d.feats + det * d.D, d.D, lane));
+    const float bsim = fmaxf(0.0f, feat::wave_dot(d.body_curr + s * d.D, d.in->feats + det * d.D, d.D, lane));
     const float emb = 1.0f - bsim;
     float face = 1.0f;
-    if (d.Df) face = 1.0f - face_fixup(fmaxf(0.0f, feat::wave_dot(d.face_curr + s * d.Df, d.face_feats + det * d.Df, d.Df, lane)));
+    if (d.Df) face = 1.0f - face_fixup(fmaxf(0.0f, feat::wave_dot(d.face_curr + s * d.Df, d.in->face_feats + det * d.Df, d.Df, lane)));
     if (lane == 0 && !(fminf(emb, face) > d.app) && (double)emb <= d.match1) {
         // One edge per pair where possible: the first appearance partner of a row also carries the
         // pair's IoU cost (np.minimum of D:1554) and the IoU tile kernel, which runs after this
@@ -504,8 +510,8 @@ __device__ __forceinline__ void renorm_body(const Dev &d, int q) {
     const int nhi = h[H_NHI], nlo = h[H_NLO];
     if (q >= nhi + nlo) return;
     const long det = q < nhi ? d.hi_idx[q] : d.lo_idx[q - nhi];
-    feat::renorm_row(d.feats + det * d.D, d.D);
-    if (d.Df) feat::renorm_row(d.face_feats + det * d.Df, d.Df);
+    feat::renorm_row(d.in->feats + det * d.D, d.D);
+    if (d.Df) feat::renorm_row(d.in->face_feats + det * d.Df, d.Df);
 }
 
 // ---- match application (D:570-610).  FEAT=false: Kalman update + lifecycle, one thread per row with
@@ -524,14 +530,14 @@ __device__ __forceinline__ void apply_body(const Dev &d) {
         const int xq = xs[r];
         if (xq < 0) return;
         const long s = rslot[r], det = cdet[xq];
-        feat::ema_row(d.body_curr + s * d.D, d.body_smooth + s * d.D, d.feats + det * d.D, d.D, d.has_body[s] != 0,
+        feat::ema_row(d.body_curr + s * d.D, d.body_smooth + s * d.D, d.in->feats + det * d.D, d.D, d.has_body[s] != 0,
                       d.ema_a, d.ema_b);
         if (d.Df)
-            feat::ema_row(d.face_curr + s * d.Df, d.face_smooth + s * d.Df, d.face_feats + det * d.Df, d.Df,
+            feat::ema_row(d.face_curr + s * d.Df, d.face_smooth + s * d.Df, d.in->face_feats + det * d.Df, d.Df,
                           d.has_face[s] != 0, d.ema_a, d.ema_b);
         if (d.filter) {
-            feat::to_half_row(d.feats + det * d.D, d.body_h + s * d.D, d.body_n + s, d.D);
-            if (d.Df) feat::to_half_row(d.face_feats + det * d.Df, d.face_h + s * d.Df, d.face_n + s, d.Df);
+            feat::to_half_row(d.in->feats + det * d.D, d.body_h + s * d.D, d.body_n + s, d.D);
+            if (d.Df) feat::to_half_row(d.in->face_feats + det * d.Df, d.face_h + s * d.Df, d.face_n + s, d.Df);
         }
         if (threadIdx.x == 0) { d.has_body[s] = 1; if (d.Df) d.has_face[s] = 1; }
         return;
@@ -566,7 +572,7 @@ __device__ __forceinline__ void apply_body(const Dev &d) {
     d.state[s] = BTS_TRACKED;
     d.is_activated[s] = 1;
     d.frame_id[s] = frame;
-    d.score[s] = d.scores[det];
+    d.score[s] = d.in->scores[det];
     d.det_index[s] = det;
 }
 
@@ -623,7 +629,7 @@ __global__ __launch_bounds__(1024) void tk_merge(Dev d) {
     for (int k = tid; k < nleft; k += nth) d.born_slot[k] = -1;
     __syncthreads();
     const int nborn_want = block_compact(
-        nleft, tmp, [&](int k) { return d.y3[k] < 0 && !((double)d.scores[d.left_det[k]] < d.new_thr); },
+        nleft, tmp, [&](int k) { return d.y3[k] < 0 && !((double)d.in->scores[d.left_det[k]] < d.new_thr); },
         [&](int b, int k) {
             if (b >= nfree) return;
             const int s = d.free_list[b], det = d.left_det[k];
@@ -632,7 +638,7 @@ __global__ __launch_bounds__(1024) void tk_merge(Dev d) {
             d.state[s] = BTS_TRACKED;
             d.is_activated[s] = frame == 1 ? 1 : 0;          // D:565-566
             d.frame_id[s] = frame; d.start_frame[s] = frame; d.tracklet_len[s] = 0;
-            d.score[s] = d.scores[det]; d.det_index[s] = det;
+            d.score[s] = d.in->scores[det]; d.det_index[s] = det;
             d.f32[s] = 1; d.in_removed[s] = 0; d.flag[s] = 0;
             d.has_body[s] = 1; d.has_face[s] = d.Df ? 1 : 0;
         });
@@ -696,16 +702,16 @@ __global__ __launch_bounds__(256) void tk_birth_init(Dev d) {
     }
     // the detection row was renormalised in place; curr and smooth alias it in the reference
     for (int c = threadIdx.x; c < d.D; c += blockDim.x) {
-        const float v = d.feats[det * d.D + c];
+        const float v = d.in->feats[det * d.D + c];
         d.body_curr[s * d.D + c] = v; d.body_smooth[s * d.D + c] = v;
     }
     for (int c = threadIdx.x; c < d.Df; c += blockDim.x) {
-        const float v = d.face_feats[det * d.Df + c];
+        const float v = d.in->face_feats[det * d.Df + c];
         d.face_curr[s * d.Df + c] = v; d.face_smooth[s * d.Df + c] = v;
     }
     if (d.filter) {
-        feat::to_half_row(d.feats + det * d.D, d.body_h + s * d.D, d.body_n + s, d.D);
-        if (d.Df) feat::to_half_row(d.face_feats + det * d.Df, d.face_h + s * d.Df, d.face_n + s, d.Df);
+        feat::to_half_row(d.in->feats + det * d.D, d.body_h + s * d.D, d.body_n + s, d.D);
+        if (d.Df) feat::to_half_row(d.in->face_feats + det * d.Df, d.face_h + s * d.Df, d.face_n + s, d.Df);
     }
 }
 
@@ -814,6 +820,17 @@ struct bts_tracker {
     // optional per-segment timing (bts_tracker_profile_*): a ring of hipEvent pairs
     int prof_seg = -1, prof_cap = 0, prof_n = 0;
     hipEvent_t *prof_ev = nullptr;
+    // input descriptors: pinned host ring -> one device descriptor (40-byte async copy per step)
+    static constexpr int RING = 64;
+    InDesc *d_in = nullptr, *h_in = nullptr;
+    hipEvent_t in_ev[RING] = {};
+    bool in_used[RING] = {};
+    unsigned long step_no = 0;
+    // hipGraph replay of a whole step (optional): captured once on private streams with the
+    // independent kernel chains forked onto side streams
+    hipStream_t cs[3] = {};
+    hipEvent_t fev[8] = {};
+    hipGraphExec_t gexec = nullptr;
 };
 
 static size_t take(size_t &off, size_t bytes) { const size_t o = off; off = bts_align(off + bytes); return o; }
@@ -864,7 +881,7 @@ int bts_tracker_default_config(bts_tracker_config *cfg) {
     cfg->track_high_thresh = 0.40; cfg->track_low_thresh = 0.1; cfg->new_track_thresh = 0.9;
     cfg->match_thresh = 0.8; cfg->second_match_thresh = 0.5; cfg->unconfirmed_match_thresh = 0.7;
     cfg->proximity_thresh = 0.5; cfg->appearance_thresh = 0.25; cfg->dedupe_thresh = 0.15;
-    cfg->ema_alpha = 0.9; cfg->record_costs = 0; cfg->appearance_mode = BTS_APPEARANCE_FILTER;
+    cfg->ema_alpha = 0.9; cfg->record_costs = 0; cfg->appearance_mode = BTS_APPEARANCE_FILTER; cfg->use_graph = 0;
     return BTS_OK;
 }
 
@@ -928,6 +945,14 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
         bts_tracker_destroy(t);
         return BTS_EHIP;
     }
+    bool ok = hipMalloc((void **)&t->d_in, sizeof(InDesc)) == hipSuccess &&
+              hipHostMalloc((void **)&t->h_in, sizeof(InDesc) * bts_tracker::RING) == hipSuccess;
+    for (int k = 0; ok && k < bts_tracker::RING; ++k) ok = hipEventCreateWithFlags(&t->in_ev[k], hipEventDisableTiming) == hipSuccess;
+    for (int k = 0; ok && k < 3; ++k) ok = hipStreamCreateWithFlags(&t->cs[k], hipStreamNonBlocking) == hipSuccess;
+    for (int k = 0; ok && k < 8; ++k) ok = hipEventCreateWithFlags(&t->fev[k], hipEventDisableTiming) == hipSuccess;
+    if (!ok) { (void)hipGetLastError(); bts_set_error("stream / event / descriptor allocation failed"); bts_tracker_destroy(t); return BTS_EHIP; }
+    t->dv.in = t->d_in;
+    bts_lap_init();
     int rc = bts_tracker_reset(t, nullptr);
     if (rc == BTS_OK && hipStreamSynchronize(nullptr) != hipSuccess) rc = BTS_EHIP;
     if (rc != BTS_OK) { bts_tracker_destroy(t); return rc; }
@@ -966,6 +991,12 @@ int bts_tracker_destroy(bts_tracker *t) {
     if (!t) return BTS_OK;
     for (int k = 0; t->prof_ev && k < 2 * t->prof_cap + 2; ++k) (void)hipEventDestroy(t->prof_ev[k]);
     delete[] t->prof_ev;
+    if (t->gexec) (void)hipGraphExecDestroy(t->gexec);
+    for (int k = 0; k < bts_tracker::RING; ++k) if (t->in_ev[k]) (void)hipEventDestroy(t->in_ev[k]);
+    for (int k = 0; k < 8; ++k) if (t->fev[k]) (void)hipEventDestroy(t->fev[k]);
+    for (int k = 0; k < 3; ++k) if (t->cs[k]) (void)hipStreamDestroy(t->cs[k]);
+    if (t->d_in) (void)hipFree(t->d_in);
+    if (t->h_in) (void)hipHostFree(t->h_in);
     if (t->block) (void)hipFree(t->block);
     if (t->host_hdr) (void)hipHostFree(t->host_hdr);
     delete t;
@@ -979,23 +1010,17 @@ int bts_tracker_reset(bts_tracker *t, bts_stream stream) {
     return BTS_OK;
 }
 
-int bts_tracker_step(bts_tracker *t, const int32_t *boxes, const float *scores, float *feats,
-                     float *face_feats, int m, bts_stream stream) {
-    BTS_REQUIRE(t && m >= 0, "tracker, m");
-    if (m > t->cfg.max_dets) {
-        bts_set_error("%d detections exceed max_dets=%d", m, t->cfg.max_dets);
-        return BTS_ECAPACITY;
-    }
-    BTS_REQUIRE(m == 0 || (boxes && scores && feats), "null detection arrays");
-    BTS_REQUIRE(t->cfg.face_dim == 0 || m == 0 || face_feats, "face_feats required when face_dim > 0");
-    hipStream_t s = (hipStream_t)stream;
-    const bool prof_room = t->prof_cap > 0 && t->prof_n < t->prof_cap;
+// Enqueue the kernels of one step.  `mc` bounds every detection-indexed grid (the frame's m in eager
+// mode, max_dets under graph capture).  `par`: fork the independent chains onto the side streams.
+static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face_feats, int mc, bool par) {
+    const bool prof_room = !par && t->prof_cap > 0 && t->prof_n < t->prof_cap;
     auto seg_begin = [&](int id) { if (prof_room && t->prof_seg == id) (void)hipEventRecord(t->prof_ev[2 * t->prof_n], s); };
     auto seg_end = [&](int id) { if (prof_room && t->prof_seg == id) { (void)hipEventRecord(t->prof_ev[2 * t->prof_n + 1], s); t->prof_n++; } };
-    Dev d = t->dv;
-    d.boxes = boxes; d.scores = scores; d.feats = feats; d.face_feats = face_feats; d.m = m;
+    hipStream_t s2 = par ? t->cs[1] : s, s3 = par ? t->cs[2] : s;
+    auto fork = [&](hipStream_t to, int e) { if (par) { (void)hipEventRecord(t->fev[e], s); (void)hipStreamWaitEvent(to, t->fev[e], 0); } };
+    auto join = [&](hipStream_t from, int e) { if (par) { (void)hipEventRecord(t->fev[e], from); (void)hipStreamWaitEvent(s, t->fev[e], 0); } };
+    const Dev &d = t->dv;
     const int T = d.T, M = d.Mx;
-    const int mc = m > 0 ? m : 1;                 // host-known bound on every detection-indexed extent
     const int cos_kernel = t->ctx->cos_kernel;
     int ntile = bts_cdiv(mc, CT_COLS) * bts_cdiv(T, CT_ROWS);
     if (ntile > 1024) ntile = 1024;
@@ -1004,14 +1029,16 @@ int bts_tracker_step(bts_tracker *t, const int32_t *boxes, const float *scores, 
     bts_lap_work lap[3] = {t->lap, t->lap, t->lap3};
     for (int k = 0; k < 3; ++k) lap[k].hdr = d.lap_hdr + BTS_LAP_HDR_INTS * k;
     int rc;
-#define LAUNCH(kern, grid, block, ...) hipLaunchKernelGGL(kern, grid, block, 0, s, d, ##__VA_ARGS__); BTS_LAUNCH_CHECK()
+#define LAUNCH_ON(st, kern, grid, block, ...) hipLaunchKernelGGL(kern, grid, block, 0, st, d, ##__VA_ARGS__); BTS_LAUNCH_CHECK()
+#define LAUNCH(kern, grid, block, ...) LAUNCH_ON(s, kern, grid, block, ##__VA_ARGS__)
 
     seg_begin(BTS_SEG_STEP);
     seg_begin(BTS_SEG_PREP);
     LAUNCH(tk_front, dim3(1 + (d.filter ? mc : 0)), dim3(1024));
     seg_end(BTS_SEG_PREP);
     seg_begin(BTS_SEG_PREDICT);
-    LAUNCH(tk_predict, dim3(kf_blocks), dim3(256));
+    fork(s2, 0);                                    // Kalman predict runs next to the appearance pre-filter
+    LAUNCH_ON(s2, tk_predict, dim3(kf_blocks), dim3(256));
     seg_end(BTS_SEG_PREDICT);
     const bool dense = !d.filter || d.record;
     // split-K factor of the pre-filter: small problems have too few 128x128 tiles to fill 256 CUs
@@ -1046,6 +1073,7 @@ int bts_tracker_step(bts_tracker *t, const int32_t *boxes, const float *scores, 
         LAUNCH(k_refine, dim3(bts_cdiv(mc, 2) < 1024 ? bts_cdiv(mc, 2) : 1024), dim3(256), lap[0]);
     }
     seg_end(BTS_SEG_COS1);
+    join(s2, 1);
     seg_begin(BTS_SEG_COST1);
     seg_begin(BTS_SEG_K_EDGES1);
     if (d.filter) {
@@ -1076,11 +1104,15 @@ int bts_tracker_step(bts_tracker *t, const int32_t *boxes, const float *scores, 
     seg_end(BTS_SEG_LAP1);
     seg_begin(BTS_SEG_APPLY1);
     LAUNCH(tk_mid1, dim3(1 + mc), dim3(1024));       // stage-2/3 lists read pre-update states: before tk_apply<1>
+    // the stage-1 Kalman updates, the stage-1 feature bookkeeping and the whole of stages 2+3 touch
+    // disjoint tracks: three independent chains
+    fork(s2, 2);
+    fork(s3, 3);
     seg_begin(BTS_SEG_K_APPLY_KF1);
-    LAUNCH((tk_apply<1, false>), dim3(kf_blocks), dim3(256));
+    LAUNCH_ON(s2, (tk_apply<1, false>), dim3(kf_blocks), dim3(256));
     seg_end(BTS_SEG_K_APPLY_KF1);
     seg_begin(BTS_SEG_K_APPLY_FEAT1);
-    LAUNCH((tk_apply<1, true>), dim3(T), dim3(256));
+    LAUNCH_ON(s3, (tk_apply<1, true>), dim3(T), dim3(256));
     seg_end(BTS_SEG_K_APPLY_FEAT1);
     seg_end(BTS_SEG_APPLY1);
     // ---- second association (remaining tracked rows x low-score detections) and the unconfirmed
@@ -1103,6 +1135,8 @@ int bts_tracker_step(bts_tracker *t, const int32_t *boxes, const float *scores, 
     LAUNCH(tk_apply23<false>, dim3(kf_blocks, 2), dim3(256));
     LAUNCH(tk_apply23<true>, dim3(T, 2), dim3(256));
     seg_end(BTS_SEG_STAGE2);
+    join(s2, 4);
+    join(s3, 5);
     // ---- births, list merge, duplicate removal
     seg_begin(BTS_SEG_MERGE);
     LAUNCH(tk_merge, dim3(1), dim3(1024));
@@ -1117,6 +1151,46 @@ int bts_tracker_step(bts_tracker *t, const int32_t *boxes, const float *scores, 
     seg_end(BTS_SEG_DEDUPE);
     seg_end(BTS_SEG_STEP);
 #undef LAUNCH
+#undef LAUNCH_ON
+    return BTS_OK;
+}
+
+int bts_tracker_step(bts_tracker *t, const int32_t *boxes, const float *scores, float *feats,
+                     float *face_feats, int m, bts_stream stream) {
+    BTS_REQUIRE(t && m >= 0, "tracker, m");
+    if (m > t->cfg.max_dets) {
+        bts_set_error("%d detections exceed max_dets=%d", m, t->cfg.max_dets);
+        return BTS_ECAPACITY;
+    }
+    BTS_REQUIRE(m == 0 || (boxes && scores && feats), "null detection arrays");
+    BTS_REQUIRE(t->cfg.face_dim == 0 || m == 0 || face_feats, "face_feats required when face_dim > 0");
+    hipStream_t s = (hipStream_t)stream;
+    // this frame's descriptor: next slot of the pinned ring (wait if the GPU is a whole ring behind)
+    const int slot = (int)(t->step_no % bts_tracker::RING);
+    if (t->in_used[slot]) BTS_HIP(hipEventSynchronize(t->in_ev[slot]));
+    t->h_in[slot] = InDesc{boxes, scores, feats, face_feats, m, 0};
+    BTS_HIP(hipMemcpyAsync(t->d_in, &t->h_in[slot], sizeof(InDesc), hipMemcpyHostToDevice, s));
+    int rc;
+    const bool graph = t->cfg.use_graph && t->dv.filter && !t->dv.record && t->prof_cap == 0;
+    if (graph) {
+        if (!t->gexec) {       // capture once, with capacity-sized grids, on the private streams
+            hipGraph_t g = nullptr;
+            BTS_HIP(hipStreamBeginCapture(t->cs[0], hipStreamCaptureModeRelaxed));
+            rc = enqueue_step(t, t->cs[0], nullptr, nullptr, t->cfg.max_dets, true);
+            const hipError_t e = hipStreamEndCapture(t->cs[0], &g);
+            if (rc) return rc;
+            if (e != hipSuccess) { bts_set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e)); return BTS_EHIP; }
+            BTS_HIP(hipGraphInstantiate(&t->gexec, g, nullptr, nullptr, 0));
+            BTS_HIP(hipGraphDestroy(g));
+        }
+        BTS_HIP(hipGraphLaunch(t->gexec, s));
+    } else {
+        rc = enqueue_step(t, s, feats, face_feats, m > 0 ? m : 1, false);
+        if (rc) return rc;
+    }
+    BTS_HIP(hipEventRecord(t->in_ev[slot], s));
+    t->in_used[slot] = true;
+    t->step_no++;
     return BTS_OK;
 }
 

@@ -162,6 +162,8 @@ typedef struct bts_tracker_config {
     double ema_alpha;           /* 0.9  D:473 */
     int32_t record_costs;       /* keep the three cost matrices of the last frame for inspection */
     int32_t appearance_mode;    /* enum bts_appearance_mode */
+    int32_t use_graph;          /* replay each step as one hipGraph (captured on the first step; grids sized for
+                                   max_dets; needs appearance_mode FILTER and record_costs 0) */
 } bts_tracker_config;
 
 /* Fill cfg with the reference's hard-coded values (D:1268-1277). */

@@ -187,6 +187,15 @@ def test_appearance_gate_band(bts, mode):
     trk.close()
 
 
+def test_graph_replay_vs_oracle(bts, synth):
+    """bts_tracker_config.use_graph: the step captured once as a hipGraph (capacity-sized grids, forked
+    side streams) and replayed; inputs reach the kernels through the device descriptor."""
+    import torch
+    with torch.cuda.stream(torch.cuda.Stream()):
+        assert _against_oracle(bts, synth, 200, 96, 512, frames=10, churn=0.03, use_graph=1) > 500
+    torch.cuda.synchronize()
+
+
 def test_churn_lifecycle_vs_oracle(bts, synth):
     """births, unconfirmed removal, expiry (frame_rate=3 -> max_time_lost=30), re-finds, dedupe."""
     _against_oracle(bts, synth, 96, 40, 256, frames=70, churn=0.08, frame_rate=3, seed=99)
