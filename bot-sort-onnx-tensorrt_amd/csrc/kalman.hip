@@ -1,10 +1,10 @@
 // kalman.hip -- batched Kalman kernels behind the C ABI (include/botsort_hip.h).
 //
-// One thread owns one track: its 8-vector and 8x8 covariance live in registers for the whole
-// predict / update, so each state element is read from HBM once and written once.  These
-// standalone entry points take the reference's array-of-rows layout (mean[n,8], cov[n,8,8]); the
-// resident tracker (tracker.hip) calls the same kf:: arithmetic on its component-major table,
-// where consecutive lanes touch consecutive addresses.
+// predict / update: eight lanes own one track (lane i = row i of the covariance, kf8:: in
+// kf_math.h), so a wavefront reads and writes 8 contiguous 576-byte state rows -- the reference's
+// own array-of-rows layout (mean[n,8], cov[n,8,8]) is already the coalesced one, and the resident
+// tracker (tracker.hip) keeps its table the same way.  The low-volume kernels (initiate, project,
+// gating) use one thread per track with the state in registers.
 #include "bts_internal.h"
 #include "kf_math.h"
 
@@ -37,22 +37,32 @@ __global__ __launch_bounds__(64) void k_initiate(const float *__restrict__ meas,
     store_state(v, t, m, P);
 }
 
-__global__ __launch_bounds__(64) void k_multi_predict(StateView v, const uint8_t *__restrict__ zero_vel,
-                                                      const uint8_t *__restrict__ row_f32, int n,
-                                                      double *__restrict__ tlbr_out) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void load_row(const StateView &v, long t, int i, double &mi, double Pr[8]) {
+    mi = v.mean[t * v.mean_st + i * v.mean_sc];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) Pr[j] = v.cov[t * v.cov_st + (i * 8 + j) * v.cov_sc];
+}
+__device__ __forceinline__ void store_row(const StateView &v, long t, int i, double mi, const double Pr[8]) {
+    v.mean[t * v.mean_st + i * v.mean_sc] = mi;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v.cov[t * v.cov_st + (i * 8 + j) * v.cov_sc] = Pr[j];
+}
+
+__global__ __launch_bounds__(256) void k_multi_predict(StateView v, const uint8_t *__restrict__ zero_vel,
+                                                       const uint8_t *__restrict__ row_f32, int n,
+                                                       double *__restrict__ tlbr_out) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = g >> 3, i = g & 7;
     if (t >= n) return;
-    double m[8], P[64];
-    load_state(v, t, m, P);
-    if (zero_vel && zero_vel[t]) { m[6] = 0.0; m[7] = 0.0; }   // D:529-532
-    const bool f32 = row_f32 && row_f32[t];
-    kf::predict(m, P, f32);
-    store_state(v, t, m, P);
+    double mi, Pr[8];
+    load_row(v, t, i, mi, Pr);
+    if (i >= 6 && zero_vel && zero_vel[t]) mi = 0.0;           // D:529-532
+    kf8::predict(mi, Pr, i, row_f32 && row_f32[t]);
+    store_row(v, t, i, mi, Pr);
     if (tlbr_out) {
         double b[4];
-        kf::mean_to_tlbr(m, false, b);
-        tlbr_out[t * 4 + 0] = b[0]; tlbr_out[t * 4 + 1] = b[1];
-        tlbr_out[t * 4 + 2] = b[2]; tlbr_out[t * 4 + 3] = b[3];
+        kf8::tlbr(mi, false, b);
+        if (i < 4) tlbr_out[t * 4 + i] = b[i];
     }
 }
 
@@ -69,19 +79,20 @@ __global__ __launch_bounds__(64) void k_project(StateView v, const uint8_t *__re
     for (int c = 0; c < 16; ++c) pcov[t * 16 + c] = S[c];
 }
 
-__global__ __launch_bounds__(64) void k_update(StateView v, const uint8_t *__restrict__ row_f32,
-                                               const int32_t *__restrict__ trk_idx,
-                                               const float *__restrict__ meas,
-                                               const int32_t *__restrict__ meas_idx, int k) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void k_update(StateView v, const uint8_t *__restrict__ row_f32,
+                                                const int32_t *__restrict__ trk_idx,
+                                                const float *__restrict__ meas,
+                                                const int32_t *__restrict__ meas_idx, int k) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int q = g >> 3, i = g & 7;
     if (q >= k) return;
     const int t = trk_idx ? trk_idx[q] : q;
     const int d = meas_idx ? meas_idx[q] : q;
     float z[4] = {meas[d * 4 + 0], meas[d * 4 + 1], meas[d * 4 + 2], meas[d * 4 + 3]};
-    double m[8], P[64];
-    load_state(v, t, m, P);
-    kf::update(m, P, z, row_f32 && row_f32[t]);
-    store_state(v, t, m, P);
+    double mi, Pr[8];
+    load_row(v, t, i, mi, Pr);
+    kf8::update(mi, Pr, i, z, row_f32 && row_f32[t]);
+    store_row(v, t, i, mi, Pr);
 }
 
 // gating_distance for every (track, measurement) pair, D:338-380.  One thread per track keeps
@@ -153,7 +164,7 @@ int bts_kf_multi_predict(bts_context *ctx, double *mean, double *cov, const uint
     BTS_REQUIRE(ctx && n >= 0, "ctx, n");
     if (n == 0) return BTS_OK;
     BTS_REQUIRE(mean && cov, "null pointer");
-    hipLaunchKernelGGL(k_multi_predict, dim3(bts_cdiv(n, 64)), dim3(64), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(k_multi_predict, dim3(bts_cdiv(n * 8, 256)), dim3(256), 0, (hipStream_t)stream,
                        aos(mean, cov), zero_vel, row_f32, n, tlbr_out);
     BTS_LAUNCH_CHECK();
     return BTS_OK;
@@ -176,7 +187,7 @@ int bts_kf_update(bts_context *ctx, double *mean, double *cov, const uint8_t *ro
     BTS_REQUIRE(ctx && k >= 0, "ctx, k");
     if (k == 0) return BTS_OK;
     BTS_REQUIRE(mean && cov && meas_xywh, "null pointer");
-    hipLaunchKernelGGL(k_update, dim3(bts_cdiv(k, 64)), dim3(64), 0, (hipStream_t)stream, aos(mean, cov),
+    hipLaunchKernelGGL(k_update, dim3(bts_cdiv(k * 8, 256)), dim3(256), 0, (hipStream_t)stream, aos(mean, cov),
                        row_f32, trk_idx, meas_xywh, meas_idx, k);
     BTS_LAUNCH_CHECK();
     return BTS_OK;

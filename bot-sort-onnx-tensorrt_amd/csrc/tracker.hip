@@ -682,6 +682,8 @@ __global__ __launch_bounds__(1024) void tk_merge(Dev d) {
         h[H_LASTID] = last_id + nborn;
         h[H_NREMOVED] += tot_expired + tot_removed_unc;
         if (nborn_want > nfree) h[H_ERR] |= ERR_TRACK_CAPACITY;
+        for (int k = 0; k < 3; ++k)                          // assignment solver: edge-list overflow / helper time-out
+            if (d.lap_hdr[BTS_LAP_HDR_INTS * k + 2]) h[H_ERR] |= ERR_LAP_EDGES;
         h[H_DIMSD] = n_keep + n_b + n_rf; h[H_DIMSD + 1] = n_l0 + n_l1;
     }
 }
