@@ -197,10 +197,11 @@ __device__ int small_pipeline(const LapArgs &A, SmallPipe &L, int E, int n, int 
     if (tid == 0) { L.NA = 0; L.MA = 0; L.C = 0; L.maxr = 0; L.maxc = 0; L.maxe = 0; L.EH = 0; }
     for (int k = tid; k < n + m; k += nth) tab[k] = 0;
     __syncthreads();
-    for (int e = tid; e < E; e += nth) { atomicAdd(&tab[w.e_row[e]], 1); atomicAdd(&tab[n + w.e_col[e]], 1); }
+    for (int e = tid; e < E; e += nth) { const int i = w.e_row[e]; if (i >= 0) { atomicAdd(&tab[i], 1); atomicAdd(&tab[n + w.e_col[e]], 1); } }   // (row -1: vacant slot)
     __syncthreads();
     for (int e = tid; e < E; e += nth) {                  // isolated pairs are final; the rest is queued
         const int i = w.e_row[e], j = w.e_col[e];
+        if (i < 0) continue;
         if (tab[i] == 1 && tab[n + j] == 1) { A.x[i] = j; A.y[j] = i; }
         else { const int h = atomicAdd(&L.EH, 1); if (h < SM_EH) L.he[h] = e; }
     }
@@ -365,10 +366,11 @@ __device__ void large_pipeline(const LapArgs &A, int EH, int32_t *tmp) {
 __device__ int isolated_pairs(const LapArgs &A, int E) {
     const bts_lap_work &w = A.w;
     const int tid = threadIdx.x, nth = blockDim.x;
-    for (int e = tid; e < E; e += nth) { atomicAdd(&w.deg[w.e_row[e]], 1); atomicAdd(&w.cdeg[w.e_col[e]], 1); }
+    for (int e = tid; e < E; e += nth) { const int i = w.e_row[e]; if (i >= 0) { atomicAdd(&w.deg[i], 1); atomicAdd(&w.cdeg[w.e_col[e]], 1); } }
     __syncthreads();
     for (int e = tid; e < E; e += nth) {
         const int i = w.e_row[e], j = w.e_col[e];
+        if (i < 0) continue;
         if (RLX(&w.deg[i]) == 1 && RLX(&w.cdeg[j]) == 1) { A.x[i] = j; A.y[j] = i; }
         else w.hard[atomicAdd(&w.hdr[H_NH], 1)] = e;
     }
@@ -376,6 +378,7 @@ __device__ int isolated_pairs(const LapArgs &A, int E) {
     // (degrees of the isolated pairs go back to zero only now: the test above must see 1 for both ends)
     for (int e = tid; e < E; e += nth) {
         const int i = w.e_row[e], j = w.e_col[e];
+        if (i < 0) continue;
         if (RLX(&w.deg[i]) == 1 && RLX(&w.cdeg[j]) == 1) { RST(&w.deg[i], 0); RST(&w.cdeg[j], 0); }
     }
     return RLX(&w.hdr[H_NH]);

@@ -319,12 +319,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 // exact gate of one (pool row i, high-detection column q) pair, evaluated by a whole wavefront
-__device__ __forceinline__ void refine_emit1(const Dev &d, const bts_lap_work &w, int i, int q, int lane) {
+// `pos` = the edge-list slot of this candidate (slots of rejected candidates hold row -1).
+__device__ __forceinline__ void refine_emit1(const Dev &d, const bts_lap_work &w, int i, int q, int lane, int pos) {
     const long s = d.pool_slot[i], det = d.hi_idx[q];
     const float bsim = fmaxf(0.0f, feat::wave_dot(d.body_curr + s * d.D, d.in->feats + det * d.D, d.D, lane));
     const float emb = 1.0f - bsim;
     float face = 1.0f;
     if (d.Df) face = 1.0f - face_fixup(fmaxf(0.0f, feat::wave_dot(d.face_curr + s * d.Df, d.in->face_feats + det * d.Df, d.Df, lane)));
+    if (lane == 0 && (fminf(emb, face) > d.app || !((double)emb <= d.match1))) w.e_row[pos] = -1;
     if (lane == 0 && !(fminf(emb, face) > d.app) && (double)emb <= d.match1) {
         // One edge per pair where possible: the first appearance partner of a row also carries the
         // pair's IoU cost (np.minimum of D:1554) and the IoU tile kernel, which runs after this
@@ -337,9 +339,7 @@ __device__ __forceinline__ void refine_emit1(const Dev &d, const bts_lap_work &w
             const double bb[4] = {d.det_tlbr[det * 4 + 0], d.det_tlbr[det * 4 + 1], d.det_tlbr[det * 4 + 2], d.det_tlbr[det * 4 + 3]};
             c = fmin(c, iou::cost(aa, false, iou::area(aa, false), bb, true, iou::area(bb, true)));
         }
-        const int pos = atomicAdd(&w.hdr[0], 1);
-        if (pos < w.e_cap) { w.e_row[pos] = i; w.e_col[pos] = q; w.e_cost[pos] = c; }
-        else w.hdr[2] = 1;
+        w.e_row[pos] = i; w.e_col[pos] = q; w.e_cost[pos] = c;
     }
 }
 
@@ -501,7 +501,9 @@ __global__ __launch_bounds__(256) void k_refine(Dev d, bts_lap_work w) {
     if (nc > d.cand_cap) { nc = d.cand_cap; if (threadIdx.x == 0 && blockIdx.x == 0) d.hdr[H_ERR] |= ERR_LAP_EDGES; }
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwave = (gridDim.x * blockDim.x) >> 6;
-    for (int k = wave; k < nc; k += nwave) refine_emit1(d, w, d.cand_i[k], d.cand_q[k], lane);
+    // candidate k owns edge slot k (no contended counter); the IoU tiles append behind them
+    if (blockIdx.x == 0 && threadIdx.x == 0) w.hdr[0] = nc;
+    for (int k = wave; k < nc; k += nwave) refine_emit1(d, w, d.cand_i[k], d.cand_q[k], lane, k);
 }
 
 // ---- detection feature rows: in-place renormalisation (quirk Q8) ------------------------------------------
