@@ -44,6 +44,7 @@ SIGNATURES = {
     "bts_kf_multi_predict": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P]),
     "bts_kf_project": (c_int, [_P, _P, _P, _P, c_int, _P, _P, _P]),
     "bts_kf_update": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, _P]),
+    "bts_kf_multi_gmc": (c_int, [_P, _P, _P, c_int, _P, _P]),
     "bts_kf_gating": (c_int, [_P, _P, _P, c_int, _P, c_int, c_int, c_int, _P, _P]),
     "bts_iou_distance": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, _P, c_int, _P]),
     "bts_cos_similarity": (c_int, [_P, _P, c_int, _P, c_int, c_int, _P, c_int, _P]),
@@ -60,6 +61,7 @@ SIGNATURES = {
     "bts_tracker_step": (c_int, [_P, _P, _P, _P, _P, c_int, _P]),
     "bts_tracker_counts": (c_int, [_P, _P, _P]),
     "bts_tracker_export": (c_int, [_P, c_int, _P, _P, _P, _P, _P]),
+    "bts_tracker_gmc": (c_int, [_P, _P, _P]),
     "bts_tracker_debug_lap": (c_int, [_P, c_int, _P, _P]),
     "bts_tracker_profile_enable": (c_int, [_P, c_int, c_int]),
     "bts_tracker_profile_read": (c_int, [_P, POINTER(c_double), POINTER(c_int32)]),

@@ -95,6 +95,17 @@ __global__ __launch_bounds__(256) void k_update(StateView v, const uint8_t *__re
     store_row(v, t, i, mi, Pr);
 }
 
+struct Warp { double h[6]; };
+
+__global__ __launch_bounds__(64) void k_gmc(StateView v, int n, Warp w) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    double m[8], P[64];
+    load_state(v, t, m, P);
+    kf::gmc(m, P, w.h);
+    store_state(v, t, m, P);
+}
+
 // gating_distance for every (track, measurement) pair, D:338-380.  One thread per track keeps
 // the Cholesky factor in registers and walks the measurements; a block shares them through LDS.
 __global__ __launch_bounds__(64) void k_gating(StateView v, int n, const double *__restrict__ meas, int m,
@@ -189,6 +200,17 @@ int bts_kf_update(bts_context *ctx, double *mean, double *cov, const uint8_t *ro
     BTS_REQUIRE(mean && cov && meas_xywh, "null pointer");
     hipLaunchKernelGGL(k_update, dim3(bts_cdiv(k * 8, 256)), dim3(256), 0, (hipStream_t)stream, aos(mean, cov),
                        row_f32, trk_idx, meas_xywh, meas_idx, k);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+
+int bts_kf_multi_gmc(bts_context *ctx, double *mean, double *cov, int n, const double *h2x3_host, bts_stream stream) {
+    BTS_REQUIRE(ctx && n >= 0 && h2x3_host, "ctx, n, H");
+    if (n == 0) return BTS_OK;
+    BTS_REQUIRE(mean && cov, "null pointer");
+    Warp w;
+    for (int k = 0; k < 6; ++k) w.h[k] = h2x3_host[k];
+    hipLaunchKernelGGL(k_gmc, dim3(bts_cdiv(n, 64)), dim3(64), 0, (hipStream_t)stream, aos(mean, cov), n, w);
     BTS_LAUNCH_CHECK();
     return BTS_OK;
 }

@@ -169,6 +169,35 @@ __device__ __forceinline__ void mean_to_tlbr(const double m[8], bool f32, double
     }
 }
 
+// STrack.multi_gmc (D:538-554): camera-motion warp  x <- kron(I4, R) x (+ t on the centre),
+// P <- R8 P R8^T  with R = H[:2,:2], t = H[:2,2].  R8 is block diagonal: pairs (0,1),(2,3),(4,5),(6,7).
+__device__ __forceinline__ void gmc(double m[8], double P[64], const double H[6]) {
+    const double r00 = H[0], r01 = H[1], tx = H[2], r10 = H[3], r11 = H[4], ty = H[5];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const double a = m[2 * p], b = m[2 * p + 1];
+        m[2 * p] = r00 * a + r01 * b;
+        m[2 * p + 1] = r10 * a + r11 * b;
+    }
+    m[0] += tx; m[1] += ty;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)            // rows: (R8 P)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const double a = P[(2 * p) * 8 + j], b = P[(2 * p + 1) * 8 + j];
+            P[(2 * p) * 8 + j] = r00 * a + r01 * b;
+            P[(2 * p + 1) * 8 + j] = r10 * a + r11 * b;
+        }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)            // columns: (.) R8^T
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double a = P[i * 8 + 2 * q], b = P[i * 8 + 2 * q + 1];
+            P[i * 8 + 2 * q] = a * r00 + b * r01;
+            P[i * 8 + 2 * q + 1] = a * r10 + b * r11;
+        }
+}
+
 }  // namespace kf
 
 // ---- eight lanes per track -------------------------------------------------------------------------

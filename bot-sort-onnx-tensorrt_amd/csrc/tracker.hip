@@ -791,6 +791,20 @@ __global__ __launch_bounds__(1024) void tk_reset(Dev d) {
     for (int j = tid; j < d.Mx; j += nth) d.ones[j] = 1;
 }
 
+// ---- camera-motion compensation of every live track (STrack.multi_gmc, D:538-554) -------------------------
+struct Warp6 { double h[6]; };
+__global__ __launch_bounds__(64) void tk_gmc(Dev d, Warp6 w) {
+    const int nt = d.hdr[H_NTRACKED], nl = d.hdr[H_NLOST];
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nt + nl) return;
+    const int s = k < nt ? d.tracked[k] : d.lost[k - nt];
+    double m[8], P[64];
+    load_state(d, s, m, P);
+    kf::gmc(m, P, w.h);
+    store_state(d, s, m, P);
+    d.f32[s] = 0;                                   // R8.dot(mean) is float64 whatever the state was
+}
+
 // ---- export -----------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void tk_export(Dev d, int which, int32_t *ints, double *mean, double *tlbr, float *score) {
     const int n = which == 0 ? d.hdr[H_NTRACKED] : d.hdr[H_NLOST];
@@ -1226,6 +1240,15 @@ int bts_tracker_export(bts_tracker *t, int which, int32_t *ints_host, double *me
         BTS_HIP(hipStreamSynchronize(s));
     }
     return n;
+}
+
+int bts_tracker_gmc(bts_tracker *t, const double *h2x3_host, bts_stream stream) {
+    BTS_REQUIRE(t && h2x3_host, "tracker, H");
+    Warp6 w;
+    for (int k = 0; k < 6; ++k) w.h[k] = h2x3_host[k];
+    hipLaunchKernelGGL(tk_gmc, dim3(bts_cdiv(t->dv.T, 64)), dim3(64), 0, (hipStream_t)stream, t->dv, w);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
 }
 
 int bts_tracker_debug_lap(bts_tracker *t, int stage, int32_t *hdr16_host, bts_stream stream) {

@@ -116,6 +116,17 @@ class KalmanFilter:
                                      _lib.ptr(z), _lib.ptr(mi), k, _lib.current_stream()))
         return m.cpu().numpy(), c.cpu().numpy()
 
+    def multi_gmc(self, mean, covariance, H):
+        """STrack.multi_gmc's arithmetic (D:538-554) on arrays mean[N,8], cov[N,8,8]; H is 2x3."""
+        lib = _lib.load(require_gpu=True)
+        mean = np.asarray(mean)
+        n = len(mean)
+        m = _dev(mean.reshape(n, 8), np.float64)
+        c = _dev(np.asarray(covariance).reshape(n, 8, 8), np.float64)
+        h = np.ascontiguousarray(H, dtype=np.float64).reshape(6)
+        _lib.check(lib.bts_kf_multi_gmc(self.ctx.handle, _lib.ptr(m), _lib.ptr(c), n, h.ctypes.data, _lib.current_stream()))
+        return m.cpu().numpy(), c.cpu().numpy()
+
     # D:338-380
     def gating_distance(self, mean, covariance, measurements, only_position=False, metric="maha"):
         import torch

@@ -137,6 +137,18 @@ class STrack(BaseTrack):
         return ret
 
     @staticmethod
+    def multi_gmc(stracks: "List[STrack]", H=np.eye(2, 3)):
+        """D:538-554 on host mirrors that carry mean AND covariance (API parity).  Tracks owned by a
+        BoTSORT live on the device: use `BoTSORT.apply_gmc(H)` for those."""
+        if len(stracks) == 0:
+            return
+        kf = STrack.shared_kalman or KalmanFilter()
+        STrack.shared_kalman = kf
+        mean, cov = kf.multi_gmc(np.asarray([st.mean for st in stracks]), np.asarray([st.covariance for st in stracks]), H)
+        for i, st in enumerate(stracks):
+            st.mean, st.covariance = mean[i], cov[i]
+
+    @staticmethod
     def multi_predict(stracks: "List[STrack]"):
         """D:524-536 on host mirrors (API parity; the tracker predicts on the device table)."""
         if len(stracks) == 0:
@@ -190,6 +202,11 @@ class DeviceTracker:
         m = int(boxes.shape[0])
         _lib.check(self._lib.bts_tracker_step(self.handle, _lib.ptr(boxes), _lib.ptr(scores), _lib.ptr(feats),
                                               _lib.ptr(face_feats), m, _lib.current_stream()))
+
+    def gmc(self, H):
+        """STrack.multi_gmc (D:538-554) on every live track; H is a 2x3 affine warp."""
+        h = np.ascontiguousarray(H, dtype=np.float64).reshape(6)
+        _lib.check(self._lib.bts_tracker_gmc(self.handle, h.ctypes.data, _lib.current_stream()))
 
     def counts(self) -> dict:
         c = np.zeros(12, dtype=np.int32)
@@ -320,6 +337,10 @@ class BoTSORT:
         if not export:
             return None
         return self._export(bodies)
+
+    def apply_gmc(self, H):
+        """Camera-motion compensation of every tracked / lost track (STrack.multi_gmc, D:538-554)."""
+        self.device_tracker.gmc(H)
 
     def _export(self, bodies=None) -> List[STrack]:
         dt = self.device_tracker

@@ -82,6 +82,10 @@ int bts_kf_update(bts_context *ctx, double *mean, double *cov, const uint8_t *ro
                   const int32_t *trk_idx, const float *meas_xywh, const int32_t *meas_idx, int k,
                   bts_stream stream);
 
+/* STrack.multi_gmc (D:538-554): camera-motion warp of n states in place, H = 2x3 affine (HOST
+ * pointer to 6 doubles, row-major): x <- kron(I4, H[:, :2]) x, centre += H[:, 2], P <- R8 P R8^T. */
+int bts_kf_multi_gmc(bts_context *ctx, double *mean, double *cov, int n, const double *h2x3_host, bts_stream stream);
+
 /* KalmanFilter.gating_distance (D:338-380) for every (track, measurement) pair -> out[n,m].
  * metric: 0 = 'maha', 1 = 'gaussian'.  meas[m,4] float64. */
 int bts_kf_gating(bts_context *ctx, const double *mean, const double *cov, int n, const double *meas,
@@ -201,6 +205,10 @@ int bts_tracker_export(bts_tracker *trk, int which, int32_t *ints_host, double *
  * If record_costs was set, cost_host (nullable) receives rows*cols float64, row-major. */
 int bts_tracker_stage_result(bts_tracker *trk, int stage, int32_t *x_host, int32_t *y_host,
                              double *cost_host, int32_t *n_rows, int32_t *n_cols, bts_stream stream);
+
+/* STrack.multi_gmc applied to every track of the tracked and lost lists (the reference's call
+ * sites D:1534-1536 are commented out; call it between steps when a camera-motion estimate exists). */
+int bts_tracker_gmc(bts_tracker *trk, const double *h2x3_host, bts_stream stream);
 
 /* Counters of the assignment solver for stage s of the last step (synchronises): out[0] feasible
  * edges, [1] components of the non-trivial part, [2] overflow flag, [6] edges that are not isolated

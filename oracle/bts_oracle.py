@@ -333,6 +333,20 @@ class KalmanOracle:
         new_cov = cov - np.linalg.multi_dot((gain, s, gain.T))
         return new_mean, new_cov
 
+    @staticmethod
+    def multi_gmc(mean: np.ndarray, cov: np.ndarray, H: np.ndarray):
+        """STrack.multi_gmc (D:538-554; its call sites are commented out at D:1534-1536): camera-motion
+        warp of a batch of states, x <- kron(I4, R) x (+ t on the centre), P <- R8 P R8^T."""
+        R8 = np.kron(np.eye(4, dtype=float), H[:2, :2])
+        t = H[:2, 2]
+        out_m, out_c = [], []
+        for m, c in zip(mean, cov):
+            m2 = R8.dot(m)
+            m2[:2] += t
+            out_m.append(m2)
+            out_c.append(R8.dot(c).dot(R8.transpose()))
+        return np.asarray(out_m), np.asarray(out_c)
+
     def gating_distance(self, mean, cov, measurements, only_position=False, metric="maha"):
         """D:338-380 (never called by the reference's update loop; API parity only)."""
         zhat, s = self.project(mean, cov)

@@ -297,6 +297,18 @@ def trace(name, K, M, D, frames, seed, churn=0.0, frame_rate=30, face_dim=0, kee
     save(name, **out)
 
 
+# ------------------------------------------------------------------------------------------ G7
+def g7_gmc(mod):
+    """STrack.multi_gmc (D:538-554) on the G1 states, with a rotation+scale+translation warp."""
+    import types
+    g1 = np.load(os.path.join(HERE, "g1_kalman.npz"))
+    ang, sc = 0.03, 1.02
+    H = np.asarray([[sc * np.cos(ang), -sc * np.sin(ang), 3.5], [sc * np.sin(ang), sc * np.cos(ang), -1.25]])
+    tracks = [types.SimpleNamespace(mean=m.copy(), covariance=c.copy()) for m, c in zip(g1["state_mean"], g1["state_cov"])]
+    mod.STrack.multi_gmc(tracks, H)
+    save("g7_gmc.npz", H=H, mean=np.asarray([t.mean for t in tracks]), cov=np.asarray([t.covariance for t in tracks]))
+
+
 def main():
     if not rh.reference_available():
         raise SystemExit("needs /root/reference (build container only)")
@@ -306,6 +318,7 @@ def main():
     g3_fused(mod)
     g4_lap(mod)
     trace("g5_c1_trace.npz", 64, 32, 2048, 100, seed=1234)
+    g7_gmc(mod)
     trace("g6_lifecycle.npz", 64, 32, 128, 120, seed=7, churn=0.1, frame_rate=3, keep_cost=(1, 2, 40))
     trace("g6_faces.npz", 48, 24, 64, 60, seed=9, churn=0.05, frame_rate=3, face_dim=32, keep_cost=(1, 2, 30))
 

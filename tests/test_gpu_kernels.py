@@ -113,6 +113,13 @@ def test_kf_gating(bts):
         kf.gating_distance(g["state_mean"][0], g["state_cov"][0], g["gate_meas"], metric="nope")
 
 
+def test_kf_multi_gmc(bts):
+    g, g1 = golden("g7_gmc.npz"), golden("g1_kalman.npz")
+    m, c = bts.KalmanFilter().multi_gmc(g1["state_mean"], g1["state_cov"], g["H"])
+    close(m, g["mean"], rel=1e-13, abs_=1e-12)
+    close(c, g["cov"], rel=1e-12, abs_=1e-12)
+
+
 # ------------------------------------------------------------------------------------------ IoU
 @pytest.mark.parametrize("tag", ["f64xf32", "f32xf32", "f64xf64", "f32xf64", "f64xg32", "f32xg32"])
 def test_iou_distance_golden(bts, tag):

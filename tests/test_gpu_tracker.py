@@ -246,6 +246,35 @@ def test_edge_frames(bts):
     trk.close()
 
 
+def test_tracker_gmc(bts, synth):
+    """bts_tracker_gmc warps every live track like STrack.multi_gmc (D:538-554) would."""
+    import torch
+    from oracle import bts_oracle as bo
+    st = synth.SyntheticStream(40, 20, 64, seed=3)
+    trk = bts.DeviceTracker(max_tracks=128, max_dets=64, feat_dim=64)
+    ora = bo.TrackerOracle()
+    H = np.asarray([[1.01, -0.02, 4.0], [0.02, 1.01, -2.5]])
+    for f in range(6):
+        fr = st.next()
+        trk.step(torch.from_numpy(fr.boxes).cuda(), torch.from_numpy(fr.scores).cuda(), torch.from_numpy(fr.feats.copy()).cuda())
+        ora.update_arrays(fr.boxes, fr.scores.astype(np.float64), fr.feats.copy())
+        if f in (2, 4):
+            trk.gmc(H)
+            for lst in (ora.tracked, ora.lost):
+                if lst:
+                    m, c = bo.KalmanOracle.multi_gmc(np.asarray([t.mean for t in lst], dtype=np.float64),
+                                                     np.asarray([t.cov for t in lst], dtype=np.float64), H)
+                    for t, mm, cc in zip(lst, m, c):
+                        t.mean, t.cov = mm, cc
+        for which, lst in ((0, ora.tracked), (1, ora.lost)):
+            t = trk.export(which)
+            want = bo.TrackerOracle.table(lst)
+            assert np.array_equal(t["track_id"], want["track_id"])
+            if len(t["mean"]):
+                assert np.abs(t["mean"] - want["mean"]).max() <= 1e-6
+    trk.close()
+
+
 def test_botsort_facade(bts, synth):
     """the drop-in object: BoTSORT.update_arrays returns STrack mirrors like the reference's update()."""
     from oracle import bts_oracle as bo

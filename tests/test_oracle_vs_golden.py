@@ -41,6 +41,12 @@ def test_g1_kalman_bitwise():
     assert bo.CHI2INV95[4] == 9.4877
 
 
+def test_g7_multi_gmc():
+    g, g1 = golden("g7_gmc.npz"), golden("g1_kalman.npz")
+    m, c = bo.KalmanOracle.multi_gmc(g1["state_mean"], g1["state_cov"], g["H"])
+    assert np.array_equal(m, g["mean"]) and np.array_equal(c, g["cov"])
+
+
 # ------------------------------------------------------------------------------------------ G2
 @pytest.mark.parametrize("tag", ["f64xf32", "f32xf32", "f64xf64", "f32xf64", "f64xg32", "f32xg32"])
 def test_g2_iou(tag):
