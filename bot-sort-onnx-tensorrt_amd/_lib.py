@@ -61,6 +61,7 @@ SIGNATURES = {
     "bts_tracker_step": (c_int, [_P, _P, _P, _P, _P, c_int, _P]),
     "bts_tracker_counts": (c_int, [_P, _P, _P]),
     "bts_tracker_export": (c_int, [_P, c_int, _P, _P, _P, _P, _P]),
+    "bts_tracker_export_mot": (c_int, [_P, _P, _P]),
     "bts_tracker_gmc": (c_int, [_P, _P, _P]),
     "bts_tracker_debug_lap": (c_int, [_P, c_int, _P, _P]),
     "bts_tracker_profile_enable": (c_int, [_P, c_int, c_int]),

@@ -821,6 +821,20 @@ __global__ __launch_bounds__(256) void tk_export(Dev d, int which, int32_t *ints
     score[k] = d.score[s];
 }
 
+// MOTChallenge rows of the tracked list: frame, id, left, top, width, height, conf, -1, -1, -1
+__global__ __launch_bounds__(256) void tk_export_mot(Dev d, double *rows) {
+    const int n = d.hdr[H_NTRACKED];
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int s = d.tracked[k];
+    double b[4];
+    slot_tlbr(d, s, b);
+    double *r = rows + (long)k * 10;
+    r[0] = (double)d.hdr[H_FRAME]; r[1] = (double)d.track_id[s];
+    r[2] = b[0]; r[3] = b[1]; r[4] = b[2] - b[0]; r[5] = b[3] - b[1];
+    r[6] = (double)d.score[s]; r[7] = -1.0; r[8] = -1.0; r[9] = -1.0;
+}
+
 }  // namespace
 
 // =========================================================================================== host side
@@ -833,7 +847,7 @@ struct bts_tracker {
     char *block = nullptr;
     size_t bytes = 0;
     // export staging
-    int32_t *x_ints = nullptr; double *x_mean = nullptr, *x_tlbr = nullptr; float *x_score = nullptr;
+    int32_t *x_ints = nullptr; double *x_mean = nullptr, *x_tlbr = nullptr, *x_mot = nullptr; float *x_score = nullptr;
     int32_t *host_hdr = nullptr;   // pinned
     // optional per-segment timing (bts_tracker_profile_*): a ring of hipEvent pairs
     int prof_seg = -1, prof_cap = 0, prof_n = 0;
@@ -885,7 +899,7 @@ static void tracker_layout(bts_tracker *t, char *base, size_t &off) {
         SLOT(d.approx, float, T * M);
         SLOT(d.cand_i, int32_t, T * M); SLOT(d.cand_q, int32_t, T * M); SLOT(d.cand_n, int32_t, 4); SLOT(d.app_q, int32_t, T);
     }
-    SLOT(t->x_ints, int32_t, 8 * T); SLOT(t->x_mean, double, 8 * T); SLOT(t->x_tlbr, double, 4 * T); SLOT(t->x_score, float, T);
+    SLOT(t->x_ints, int32_t, 8 * T); SLOT(t->x_mean, double, 8 * T); SLOT(t->x_tlbr, double, 4 * T); SLOT(t->x_score, float, T); SLOT(t->x_mot, double, 10 * T);
 #undef SLOT
 }
 
@@ -1237,6 +1251,21 @@ int bts_tracker_export(bts_tracker *t, int which, int32_t *ints_host, double *me
         if (mean_host) BTS_HIP(hipMemcpyAsync(mean_host, t->x_mean, sizeof(double) * 8 * n, hipMemcpyDeviceToHost, s));
         if (tlbr_host) BTS_HIP(hipMemcpyAsync(tlbr_host, t->x_tlbr, sizeof(double) * 4 * n, hipMemcpyDeviceToHost, s));
         if (score_host) BTS_HIP(hipMemcpyAsync(score_host, t->x_score, sizeof(float) * n, hipMemcpyDeviceToHost, s));
+        BTS_HIP(hipStreamSynchronize(s));
+    }
+    return n;
+}
+
+int bts_tracker_export_mot(bts_tracker *t, double *rows_host, bts_stream stream) {
+    BTS_REQUIRE(t && rows_host, "tracker, rows");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(tk_export_mot, dim3(bts_cdiv(t->dv.T, 256)), dim3(256), 0, s, t->dv, t->x_mot);
+    BTS_LAUNCH_CHECK();
+    BTS_HIP(hipMemcpyAsync(t->host_hdr, t->dv.hdr, H_SIZE * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    BTS_HIP(hipStreamSynchronize(s));
+    const int n = t->host_hdr[H_NTRACKED];
+    if (n > 0) {
+        BTS_HIP(hipMemcpyAsync(rows_host, t->x_mot, sizeof(double) * 10 * n, hipMemcpyDeviceToHost, s));
         BTS_HIP(hipStreamSynchronize(s));
     }
     return n;

@@ -203,6 +203,12 @@ class DeviceTracker:
         _lib.check(self._lib.bts_tracker_step(self.handle, _lib.ptr(boxes), _lib.ptr(scores), _lib.ptr(feats),
                                               _lib.ptr(face_feats), m, _lib.current_stream()))
 
+    def export_mot(self) -> np.ndarray:
+        """MOTChallenge rows [n,10] of the tracked list: frame, id, left, top, width, height, conf, -1, -1, -1."""
+        buf = np.empty((self.cfg.max_tracks, 10), dtype=np.float64)
+        n = _lib.check(self._lib.bts_tracker_export_mot(self.handle, buf.ctypes.data, _lib.current_stream()))
+        return buf[:n].copy()
+
     def gmc(self, H):
         """STrack.multi_gmc (D:538-554) on every live track; H is a 2x3 affine warp."""
         h = np.ascontiguousarray(H, dtype=np.float64).reshape(6)

@@ -200,6 +200,11 @@ int bts_tracker_counts(bts_tracker *trk, int32_t *counts12_host, bts_stream stre
 int bts_tracker_export(bts_tracker *trk, int which, int32_t *ints_host, double *mean_host,
                        double *tlbr_host, float *score_host, bts_stream stream);
 
+/* Batched consumer format (what the reference's main loop reads per track, D:2135-2185):
+ * one MOTChallenge row per entry of the tracked list -- frame, id, left, top, width, height, conf, -1, -1, -1
+ * (float64 [rows,10], HOST buffer sized for max_tracks rows).  Synchronises.  Returns the row count or <0. */
+int bts_tracker_export_mot(bts_tracker *trk, double *rows_host, bts_stream stream);
+
 /* Last frame's association results to HOST (synchronises): for stage s in {1,2,3}
  * x_host[rows], y_host[cols] (nullable); returns rows via *n_rows, cols via *n_cols.
  * If record_costs was set, cost_host (nullable) receives rows*cols float64, row-major. */

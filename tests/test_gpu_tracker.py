@@ -291,3 +291,8 @@ def test_botsort_facade(bts, synth):
             assert np.abs(a.tlbr - b.tlbr).max() <= 1e-6 and a.is_activated == b.is_activated
             assert a.state == bts.TrackState.Tracked and repr(a).startswith("OT_%d_" % b.track_id)
     assert bot.frame_id == 15
+    mot = bot.device_tracker.export_mot()
+    assert mot.shape == (len(out), 10) and np.all(mot[:, 0] == 15) and np.all(mot[:, 7:] == -1)
+    assert [int(v) for v in mot[:, 1]] == [t.track_id for t in out]
+    tl = np.asarray([t.tlbr for t in out])
+    assert np.abs(mot[:, 2:4] - tl[:, :2]).max() <= 1e-9 and np.abs(mot[:, 4:6] - (tl[:, 2:] - tl[:, :2])).max() <= 1e-9
