@@ -154,3 +154,39 @@ def dedupe_flags(a_items, b_items, age_a: Sequence[int], age_b: Sequence[int], t
                                     _lib.ptr(db), _lib.ptr(dbf), _lib.ptr(gb), m, float(thresh), _lib.ptr(fa),
                                     _lib.ptr(fb), _lib.current_stream()))
     return fa.cpu().numpy().astype(bool), fb.cpu().numpy().astype(bool)
+
+
+def associate_parts(base_boxes, base_centres, target_boxes, target_centres, used=None, picks: int = 1):
+    """The greedy part attachment of D:1379-1411 for a whole frame: find_most_relevant_object
+    (D:1763-1791) for every base box in order, `picks` picks each.  Integer (x1, y1, x2, y2) boxes and
+    (cx, cy) centres; `used` marks targets already taken.  -> (idx[nb, picks] with -1 = none, used[nt])."""
+    import torch
+    bb = np.ascontiguousarray(np.asarray(base_boxes, dtype=np.int32).reshape(-1, 4))
+    tb = np.ascontiguousarray(np.asarray(target_boxes, dtype=np.int32).reshape(-1, 4))
+    nb, nt = len(bb), len(tb)
+    u = np.zeros(nt, dtype=np.uint8) if used is None else np.asarray(used).astype(np.uint8)
+    if nb == 0:
+        return np.zeros((0, picks), dtype=np.int64), u.astype(bool)
+    lib = _lib.load(require_gpu=True)
+    dbb, dbc = _dev(bb, np.int32), _dev(np.asarray(base_centres).reshape(-1, 2), np.int32)
+    dtb, dtc = _dev(tb, np.int32), _dev(np.asarray(target_centres).reshape(-1, 2), np.int32)
+    du = _dev(u, np.uint8)
+    out = torch.empty((nb * picks,), dtype=torch.int32, device="cuda")
+    _lib.check(lib.bts_associate_parts(_lib.default_context().handle, _lib.ptr(dbb), _lib.ptr(dbc), nb, _lib.ptr(dtb),
+                                       _lib.ptr(dtc), nt, _lib.ptr(du), int(picks), _lib.ptr(out), _lib.current_stream()))
+    return out.cpu().numpy().astype(np.int64).reshape(nb, picks), du.cpu().numpy().astype(bool)
+
+
+def find_most_relevant_object(base_obj, target_objs):
+    """D:1763-1791 with the reference's signature: the not-yet-used target (objects with x1, y1, x2, y2,
+    cx, cy, is_used) that overlaps `base_obj` most; it is marked used and returned (None if none overlaps)."""
+    if not target_objs:
+        return None
+    box = lambda o: [o.x1, o.y1, o.x2, o.y2]
+    idx, _ = associate_parts([box(base_obj)], [[base_obj.cx, base_obj.cy]], [box(t) for t in target_objs],
+                             [[t.cx, t.cy] for t in target_objs], used=[bool(t.is_used) for t in target_objs])
+    if idx[0, 0] < 0:
+        return None
+    hit = target_objs[int(idx[0, 0])]
+    hit.is_used = True
+    return hit

@@ -17,8 +17,68 @@ from typing import List, Optional
 
 import numpy as np
 
-from . import _lib
+from . import _lib, matching
 from .kalman_filter import KalmanFilter
+
+
+class Box:                             # D:84-95: what the detector hands over, one per detection
+    def __init__(self, trackid=0, classid=0, score=0.0, x1=0, y1=0, x2=0, y2=0, cx=0, cy=0, is_used=False):
+        self.trackid, self.classid, self.score = trackid, classid, score
+        self.x1, self.y1, self.x2, self.y2, self.cx, self.cy = x1, y1, x2, y2, cx, cy
+        self.is_used = is_used
+
+    @classmethod
+    def of(cls, box, **extra):
+        return cls(trackid=box.trackid, classid=box.classid, score=box.score, x1=box.x1, y1=box.y1, x2=box.x2, y2=box.y2,
+                   cx=box.cx, cy=box.cy, is_used=False, **extra)
+
+
+class Body(Box):                       # D:97-102
+    def __init__(self, head=None, hand1=None, hand2=None, **kw):
+        super().__init__(**kw)
+        self.head, self.hand1, self.hand2 = head, hand1, hand2
+
+
+class Head(Box):                       # D:104-108
+    def __init__(self, face=None, face_landmarks=None, **kw):
+        super().__init__(**kw)
+        self.face, self.face_landmarks = face, face_landmarks
+
+
+class Face(Box):                       # D:110-112
+    pass
+
+
+class Hand(Box):                       # D:114-116
+    pass
+
+
+def attach_parts(detected_boxes):
+    """D:1303-1411: split one frame's detections by class (0 body, 1 head, 2 hand, 3 face) and attach
+    face -> head, head -> body, two hands -> body with the greedy rule of find_most_relevant_object,
+    one device call per pass.  Returns (bodies, heads, hands, faces)."""
+    bodies = [Body.of(b) for b in detected_boxes if b.classid == 0]
+    heads = [Head.of(b) for b in detected_boxes if b.classid == 1]
+    hands = [Hand.of(b) for b in detected_boxes if b.classid == 2]
+    faces = [Face.of(b) for b in detected_boxes if b.classid == 3]
+
+    def attach(bases, targets, picks, setter):
+        if not bases or not targets:
+            return
+        xyxy = lambda L: [[o.x1, o.y1, o.x2, o.y2] for o in L]
+        cen = lambda L: [[o.cx, o.cy] for o in L]
+        idx, used = matching.associate_parts(xyxy(bases), cen(bases), xyxy(targets), cen(targets), picks=picks)
+        for t, u in zip(targets, used):
+            t.is_used = bool(u)
+        for b, row in zip(bases, idx):
+            for p, k in enumerate(row):
+                if k >= 0:
+                    setter(b, p, targets[int(k)])
+
+    attach(heads, faces, 1, lambda h, p, f: setattr(h, "face", f))
+    attach(bodies, heads, 1, lambda b, p, h: setattr(b, "head", h))
+    attach(bodies, hands, 2, lambda b, p, h: setattr(b, "hand1" if p == 0 else "hand2", h))
+    return bodies, heads, hands, faces
 
 
 class TrackState:                      # D:382-387
@@ -161,6 +221,17 @@ class STrack(BaseTrack):
         mean, cov = kf.multi_predict(mean, cov, zero_velocity=zero)
         for i, st in enumerate(stracks):
             st.mean, st.covariance = mean[i], cov[i]
+
+    def propagate_trackid_to_related_objects(self):                      # D:612-622
+        body = self.body
+        if body is None:
+            return
+        parts = [body, getattr(body, "head", None), getattr(body, "hand1", None), getattr(body, "hand2", None)]
+        if parts[1] is not None:
+            parts.append(getattr(parts[1], "face", None))
+        for o in parts:
+            if o is not None and hasattr(o, "trackid"):
+                o.trackid = self.track_id
 
     def __repr__(self):
         return "OT_{}_({}-{})".format(self.track_id, self.start_frame, self.end_frame)   # D:687-688
@@ -373,8 +444,7 @@ class BoTSORT:
                 st.slot = int(tab["slot"][k])
                 if bodies is not None and st.frame_id == self.frame_id and 0 <= st.det_index < len(bodies):
                     st.body = bodies[st.det_index]
-                    if hasattr(st.body, "trackid"):
-                        st.body.trackid = tid                                  # D:612-622 (body only)
+                    st.propagate_trackid_to_related_objects()
                 lst.append(st)
             out.append(lst)
         self.tracked_stracks, self.lost_stracks = out
@@ -387,11 +457,10 @@ class BoTSORT:
 
     # ---- reference signature (detector + encoders are the caller's objects, unchanged)
     def update(self, image: np.ndarray) -> List[STrack]:
-        """D:1291: detect -> encode -> track.  Only the tracking half runs here; detection-side
-        part association (D:1303-1412) is out of scope."""
+        """D:1291: detect -> attach parts (D:1303-1411, on the device) -> encode -> track."""
         if self.detector is None or self.body_encoder is None:
             raise RuntimeError("update(image) needs detector/encoder models; use update_arrays for pre-extracted detections")
-        boxes = [b for b in self.detector(image) if getattr(b, "classid", 0) == 0]
+        boxes, _, _, _ = attach_parts(self.detector(image))
         m = len(boxes)
         arr = np.asarray([[b.x1, b.y1, b.x2, b.y2] for b in boxes], dtype=np.int32).reshape(m, 4)
         scores = np.asarray([b.score for b in boxes], dtype=np.float32)
@@ -402,7 +471,12 @@ class BoTSORT:
             # the encoder's own similarity output is not used: the device computes it (D:1599 form)
             _, feats = self.body_encoder(base_images=crops, target_features=np.zeros((0, self.feat_dim), dtype=np.float32))
             if self.face_dim and self.face_encoder is not None:
-                ffeats, _ = self.face_encoder(base_images=crops, target_features=np.zeros((0, self.face_dim), dtype=np.float32))
+                blank = getattr(self.face_encoder, "blank_image", None)                  # D:1440-1444
+                fcrops = [image[b.head.face.y1:b.head.face.y2, b.head.face.x1:b.head.face.x2, :]
+                          if b.head is not None and b.head.face is not None else
+                          (blank if blank is not None else np.zeros((1, 1, 3), dtype=np.float32)) for b in boxes]
+                ffeats, _ = self.face_encoder(base_images=fcrops,        # features first: D:1478-1480
+                                               target_features=np.zeros((0, self.face_dim), dtype=np.float32))
         if self.face_dim and ffeats is None:
             ffeats = np.zeros((m, self.face_dim), dtype=np.float32)
         return self.update_arrays(arr, scores, np.asarray(feats, dtype=np.float32), ffeats, bodies=boxes)

@@ -138,6 +138,17 @@ int bts_dedupe_pairs(bts_context *ctx, const double *a_tlbr, const uint8_t *a_f3
                      int n, const double *b_tlbr, const uint8_t *b_f32, const int32_t *age_b, int m,
                      double thresh, uint8_t *drop_a, uint8_t *drop_b, bts_stream stream);
 
+/* Detection-side part association: find_most_relevant_object (D:1763-1791, IoU of integer boxes per
+ * bbox_iou_by_box D:1715-1729) applied to each base box in order, `picks` times per base (1 for
+ * head->body / face->head D:1379-1393, 2 for the hand1/hand2 picks D:1401-1409).  Each pick takes the
+ * unused target with the largest IoU (> 0), ties by the smaller centre distance, then by list order,
+ * and marks it in target_used[nt] (uint8, in/out: targets already taken by an earlier pass stay taken).
+ * boxes are int32 (x1, y1, x2, y2) rows, centres int32 (cx, cy) rows (the Box.cx / Box.cy the detector
+ * stored), all 16-/8-byte aligned device arrays; out_idx[nb * picks] = target index or -1. */
+int bts_associate_parts(bts_context *ctx, const int32_t *base_boxes, const int32_t *base_centres, int nb,
+                        const int32_t *target_boxes, const int32_t *target_centres, int nt,
+                        uint8_t *target_used, int picks, int32_t *out_idx, bts_stream stream);
+
 /* -------------------------------------------------- whole-frame tracker, BoTSORT.update D:1414-1639 */
 
 /* How the stage-1/3 appearance term (D:1539-1554, D:1590-1602) is evaluated inside the tracker:

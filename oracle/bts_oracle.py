@@ -223,6 +223,45 @@ def iou_cost(a_boxes: Sequence[np.ndarray], b_boxes: Sequence[np.ndarray], faith
 
 
 # ----------------------------------------------------------------------------------------------
+# detection-side part association (D:1715-1729, D:1763-1791, D:1379-1411)
+# ----------------------------------------------------------------------------------------------
+def box_iou_int(a, b) -> float:
+    """bbox_iou_by_box (D:1715-1729) on integer (x1, y1, x2, y2) boxes."""
+    x_lo, y_lo = max(a[0], b[0]), max(a[1], b[1])
+    x_hi, y_hi = min(a[2], b[2]), min(a[3], b[3])
+    if x_hi <= x_lo or y_hi <= y_lo:
+        return 0.0
+    inter = (x_hi - x_lo) * (y_hi - y_lo)
+    return inter / float((a[2] - a[0]) * (a[3] - a[1]) + (b[2] - b[0]) * (b[3] - b[1]) - inter)
+
+
+def associate_parts(base_boxes, base_centres, target_boxes, target_centres, used=None, picks: int = 1):
+    """Greedy attachment of `target` parts to `base` objects in base order -- what
+    find_most_relevant_object (D:1763-1791) does inside the loops of D:1379-1411: each base takes the
+    unused target with the largest IoU (> 0), ties by the smaller centre distance, then by list
+    order; `picks` = 2 reproduces the hand1 / hand2 double pick.  Returns (idx[nb, picks] (-1 = none), used)."""
+    nb, nt = len(base_boxes), len(target_boxes)
+    used = np.zeros(nt, dtype=bool) if used is None else np.asarray(used, dtype=bool).copy()
+    out = np.full((nb, picks), -1, dtype=np.int64)
+    for b in range(nb):
+        for p in range(picks):
+            best, best_iou, best_d = -1, 0.0, float("inf")
+            for t in range(nt):
+                if used[t]:
+                    continue
+                iou = box_iou_int([int(v) for v in base_boxes[b]], [int(v) for v in target_boxes[t]])
+                d = (int(base_centres[b][0] - target_centres[t][0]) ** 2 + int(base_centres[b][1] - target_centres[t][1]) ** 2) ** 0.5
+                if iou > best_iou:
+                    best, best_iou, best_d = t, iou, d
+                elif iou > 0.0 and iou == best_iou and d < best_d:
+                    best, best_d = t, d
+            if best >= 0:
+                used[best] = True
+            out[b, p] = best
+    return out, used
+
+
+# ----------------------------------------------------------------------------------------------
 # fused costs (A14-A17)
 # ----------------------------------------------------------------------------------------------
 def cosine_similarity(track_feats: np.ndarray, det_feats: np.ndarray) -> np.ndarray:

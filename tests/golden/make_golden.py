@@ -309,6 +309,42 @@ def g7_gmc(mod):
     save("g7_gmc.npz", H=H, mean=np.asarray([t.mean for t in tracks]), cov=np.asarray([t.covariance for t in tracks]))
 
 
+# ------------------------------------------------------------------------------------------ G8
+def g8_parts(mod):
+    """find_most_relevant_object (D:1763-1791) driven like D:1379-1411: heads -> bodies (one pick) and
+    hands -> bodies (two picks per body), on crowded integer boxes with exact IoU / distance ties."""
+    rng = np.random.default_rng(808)
+
+    def boxes(n, wlo, whi, hlo, hhi, span):
+        x1 = rng.integers(0, span, n); y1 = rng.integers(0, span, n)
+        w = rng.integers(wlo, whi, n); h = rng.integers(hlo, hhi, n)
+        return np.stack([x1, y1, x1 + w, y1 + h], 1).astype(np.int64)
+
+    def mk(cls, b):
+        return cls(trackid=0, classid=0, score=0.9, x1=int(b[0]), y1=int(b[1]), x2=int(b[2]), y2=int(b[3]),
+                   cx=int((b[0] + b[2]) // 2), cy=int((b[1] + b[3]) // 2), is_used=False)
+
+    out = {}
+    for tag, nb, nt, picks in (("head", 40, 55, 1), ("hand", 40, 90, 2)):
+        bb = boxes(nb, 40, 90, 90, 200, 500)
+        tb = boxes(nt, 10, 40, 10, 40, 560)
+        tb[:6] = tb[6:12]                        # exact duplicates: IoU and distance ties -> list order decides
+        tb[12:16, :2] = bb[:4, :2]               # parts sitting on body corners
+        tb[12:16, 2:] = bb[:4, :2] + 20
+        bases = [mk(mod.Box, b) for b in bb]
+        targets = [mk(mod.Box, t) for t in tb]
+        idx = np.full((nb, picks), -1, dtype=np.int64)
+        for i, base in enumerate(bases):
+            for p in range(picks):
+                got = mod.find_most_relevant_object(base_obj=base, target_objs=targets)
+                if got is not None:
+                    idx[i, p] = [k for k, t in enumerate(targets) if t is got][0]
+        out[tag + "_base"] = bb; out[tag + "_target"] = tb; out[tag + "_idx"] = idx
+        out[tag + "_used"] = np.asarray([t.is_used for t in targets])
+        out[tag + "_base_c"] = np.asarray([[b.cx, b.cy] for b in bases]); out[tag + "_target_c"] = np.asarray([[t.cx, t.cy] for t in targets])
+    save("g8_parts.npz", **out)
+
+
 def main():
     if not rh.reference_available():
         raise SystemExit("needs /root/reference (build container only)")
@@ -319,6 +355,7 @@ def main():
     g4_lap(mod)
     trace("g5_c1_trace.npz", 64, 32, 2048, 100, seed=1234)
     g7_gmc(mod)
+    g8_parts(mod)
     trace("g6_lifecycle.npz", 64, 32, 128, 120, seed=7, churn=0.1, frame_rate=3, keep_cost=(1, 2, 40))
     trace("g6_faces.npz", 48, 24, 64, 60, seed=9, churn=0.05, frame_rate=3, face_dim=32, keep_cost=(1, 2, 30))
 

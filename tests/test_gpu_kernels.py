@@ -345,6 +345,62 @@ def test_dedupe_pairs(bts):
     assert np.array_equal(da, want_a) and np.array_equal(db, want_b)
 
 
+# ------------------------------------------------------------------------------------------ part association
+def test_associate_parts_golden(bts):
+    g = golden("g8_parts.npz")
+    for tag, picks in (("head", 1), ("hand", 2)):
+        idx, used = bts.associate_parts(g[tag + "_base"], g[tag + "_base_c"], g[tag + "_target"], g[tag + "_target_c"], picks=picks)
+        assert np.array_equal(idx, g[tag + "_idx"]) and np.array_equal(used, g[tag + "_used"])
+
+
+@pytest.mark.parametrize("nb,nt,picks,span", [(1, 1, 1, 50), (7, 0, 1, 50), (64, 300, 2, 400), (30, 500, 3, 60), (300, 120, 1, 900)])
+def test_associate_parts_vs_oracle(bts, nb, nt, picks, span):
+    """Random crowds, incl. a base with > 64 overlapping targets (span 60: everything overlaps), targets
+    taken beforehand and exact IoU / distance ties."""
+    from oracle import bts_oracle as bo
+    rng = np.random.default_rng(nb * 1000 + nt)
+
+    def boxes(n, lo, hi):
+        xy = rng.integers(0, span, (n, 2)); wh = rng.integers(lo, hi, (n, 2))
+        return np.concatenate([xy, xy + wh], 1).astype(np.int64)
+
+    bb, tb = boxes(nb, 30, 120), boxes(nt, 8, 40)
+    if nt > 20:
+        tb[:10] = tb[10:20]
+    bc, tc = (bb[:, :2] + bb[:, 2:]) // 2, (tb[:, :2] + tb[:, 2:]) // 2
+    used0 = rng.random(nt) < 0.1
+    want, wused = bo.associate_parts(bb, bc, tb, tc, used=used0, picks=picks)
+    idx, used = bts.associate_parts(bb, bc, tb, tc, used=used0, picks=picks)
+    assert np.array_equal(idx, want) and np.array_equal(used, wused)
+
+
+def test_find_most_relevant_object_and_attach(bts):
+    """Reference-shaped calls: one-object query (D:1763-1791) and the whole D:1303-1411 block."""
+    from oracle import bts_oracle as bo
+    rng = np.random.default_rng(5)
+    dets = []
+    for cls, n, lo, hi in ((0, 12, 60, 160), (1, 14, 15, 40), (2, 20, 10, 30), (3, 9, 8, 25)):
+        for _ in range(n):
+            x, y = (int(v) for v in rng.integers(0, 300, 2)); w, h = (int(v) for v in rng.integers(lo, hi, 2))
+            dets.append(bts.Box(classid=cls, score=0.9, x1=x, y1=y, x2=x + w, y2=y + h, cx=(2 * x + w) // 2, cy=(2 * y + h) // 2))
+    bodies, heads, hands, faces = bts.attach_parts(dets)
+    arr = lambda L: (np.asarray([[o.x1, o.y1, o.x2, o.y2] for o in L]), np.asarray([[o.cx, o.cy] for o in L]))
+    for bases, targets, picks, get in ((heads, faces, 1, lambda b: [b.face]), (bodies, heads, 1, lambda b: [b.head]),
+                                       (bodies, hands, 2, lambda b: [b.hand1, b.hand2])):
+        want, wused = bo.associate_parts(*arr(bases), *arr(targets), picks=picks)
+        for b, row in zip(bases, want):
+            assert [targets[k] if k >= 0 else None for k in row] == get(b)
+        assert [t.is_used for t in targets] == list(wused)
+    assert any(b.head is not None and b.head.face is not None for b in bodies)
+    # single query, twice: the second call must skip the part taken by the first
+    body, pool = bodies[0], [bts.Hand.of(h) for h in hands]
+    first = bts.find_most_relevant_object(base_obj=body, target_objs=pool)
+    second = bts.find_most_relevant_object(base_obj=body, target_objs=pool)
+    assert first is body.hand1 or (first is not None and (first.x1, first.y1) == (body.hand1.x1, body.hand1.y1))
+    assert second is None or second is not first
+    assert bts.find_most_relevant_object(base_obj=body, target_objs=[]) is None
+
+
 def test_errors_are_loud(bts):
     lib = bts._lib.load(require_gpu=True)
     ctx = bts._lib.default_context()

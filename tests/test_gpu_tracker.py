@@ -296,3 +296,52 @@ def test_botsort_facade(bts, synth):
     assert [int(v) for v in mot[:, 1]] == [t.track_id for t in out]
     tl = np.asarray([t.tlbr for t in out])
     assert np.abs(mot[:, 2:4] - tl[:, :2]).max() <= 1e-9 and np.abs(mot[:, 4:6] - (tl[:, 2:] - tl[:, :2])).max() <= 1e-9
+
+
+def test_botsort_update_image_with_parts(bts):
+    """update(image) as the reference's loop calls it (D:2130): detector -> device part association ->
+    encoders -> device tracker; the strack's body carries head / face / hands and they all get the
+    track id (D:612-622)."""
+    rng = np.random.default_rng(11)
+    D, F = 64, 32
+    people = [(40 + 150 * i, 60, 100, 260) for i in range(4)]           # x, y, w, h
+    base = rng.normal(size=(4, D)).astype(np.float32)
+    fbase = rng.normal(size=(4, F)).astype(np.float32)
+
+    def mk(cls, x, y, w, h):
+        return bts.Box(classid=cls, score=0.95, x1=x, y1=y, x2=x + w, y2=y + h, cx=x + w // 2, cy=y + h // 2)
+
+    class Det:
+        frame = 0
+
+        def __call__(self, image):
+            out, dx = [], 3 * self.frame
+            for (x, y, w, h) in people:
+                out += [mk(0, x + dx, y, w, h), mk(1, x + dx + 30, y + 5, 40, 40), mk(3, x + dx + 38, y + 15, 24, 24),
+                        mk(2, x + dx - 5, y + 120, 25, 25), mk(2, x + dx + 80, y + 125, 25, 25)]
+            self.frame += 1
+            return out
+
+    class Enc:
+        def __init__(self, table, is_face):
+            self.table, self.is_face = table, is_face
+
+        def __call__(self, base_images, target_features):
+            f = np.stack([self.table[int(round(float(im.mean()))) % 4] if im.size > 3 else np.ones_like(self.table[0]) for im in base_images])
+            sim = np.zeros((len(base_images), len(target_features)), dtype=np.float32)
+            return (f, sim) if self.is_face else (sim, f)
+
+    image = np.zeros((400, 800, 3), dtype=np.float32)
+    det = Det()
+    bot = bts.BoTSORT(det, Enc(base, False), Enc(fbase, True), frame_rate=30, max_tracks=64, max_dets=16, feat_dim=D, face_dim=F)
+    for f in range(5):
+        image[:] = 0
+        for i, (x, y, w, h) in enumerate(people):
+            image[y:y + h, x + 3 * f:x + 3 * f + w, :] = i
+        out = bot.update(image)
+    assert len(out) == 4 and sorted(t.track_id for t in out) == [1, 2, 3, 4]
+    for t in out:
+        b = t.body
+        assert b.head is not None and b.head.face is not None and b.hand1 is not None and b.hand2 is not None
+        assert {b.trackid, b.head.trackid, b.head.face.trackid, b.hand1.trackid, b.hand2.trackid} == {t.track_id}
+        assert b.x1 <= b.head.x1 and b.head.x2 <= b.x2 and b.hand1 is not b.hand2

@@ -41,6 +41,14 @@ def test_g1_kalman_bitwise():
     assert bo.CHI2INV95[4] == 9.4877
 
 
+def test_g8_part_association():
+    g = golden("g8_parts.npz")
+    for tag, picks in (("head", 1), ("hand", 2)):
+        idx, used = bo.associate_parts(g[tag + "_base"], g[tag + "_base_c"], g[tag + "_target"], g[tag + "_target_c"], picks=picks)
+        assert np.array_equal(idx, g[tag + "_idx"]) and np.array_equal(used, g[tag + "_used"])
+        assert (idx >= 0).sum() > 10
+
+
 def test_g7_multi_gmc():
     g, g1 = golden("g7_gmc.npz"), golden("g1_kalman.npz")
     m, c = bo.KalmanOracle.multi_gmc(g1["state_mean"], g1["state_cov"], g["H"])
