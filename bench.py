@@ -33,10 +33,10 @@ if REPO not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 F16_MFMA_PEAK_TF = 2500.0      # dense f16/bf16 MFMA peak (not the 2:1-sparse headline)
 F32_MFMA_PEAK_TF = 157.3       # dense f32-input MFMA peak (= f32 vector peak)
-SEGMENTS = ("prep", "predict", "cos1", "cost1", "lap1", "apply1", "stage2", "merge", "dedupe")   # launch groups of a step
+SEGMENTS = ("prep", "cos1", "cost1", "lap1", "apply1", "stage2", "merge", "dedupe")   # launch groups of a step
 KERNELS = {   # single kernels that can dominate a step -> name in the rocprofv3 kernel trace
-    "k_filter": "k_filter<false>", "k_lap_prepare": "k_lap", "k_edges1": "tk_edges<1,*>",
-    "predict": "tk_predict", "k_apply_kf1": "tk_apply<1,false>", "k_apply_feat1": "tk_apply<1,true>",
+    "k_filter": "k_filter<false>", "k_lap": "k_lap", "k_edges1": "tk_edges<1,1>", "k_mid2": "tk_mid2<1>",
+    "k_apply23": "tk_apply23", "prep": "tk_front", "merge": "tk_merge",
 }
 
 
@@ -64,11 +64,13 @@ def kernel_model(kern, K, M, D, dense):
     if kern == "k_filter":     # appearance contraction 2*N*Mh*D flop on the f16 matrix cores
         return "mfma", 2.0 * N * Mh * D, "flop", F16_MFMA_PEAK_TF
     table = {
-        "predict": 2 * N * 72 * 8 + N * 32,                     # each state row read + written once, box written
-        "k_apply_kf1": Km * (2 * 72 + 4) * 8,                   # matched rows read + written, measurement read
-        "k_apply_feat1": Km * D * (4 + 4 + 4 + 4 + 2),          # det row, smooth r+w, curr w, f16 shadow w
-        "k_edges1": (N + Mh) * 32 + E * 16,                     # boxes in, sparse edges out (N*Mh IoU tests are compute)
-        "k_lap_prepare": E * 16 + 8 * Mh,                       # edge list in, assignment vectors out
+        # stage-1 matches: Kalman rows read + written, measurement read; det row, smooth r+w, curr w, f16 shadow w
+        "k_mid2": Km * (2 * 72 + 4) * 8 + Km * D * (4 + 4 + 4 + 4 + 2),
+        "k_apply23": (M // 8) * ((2 * 72 + 4) * 8 + D * 18),    # the low-score matches of stage 2 (stage 3 is empty in steady state)
+        "k_edges1": (N + Mh) * 32 + E * 16 + Mh * 2 * D * 4,    # boxes in, sparse edges out, two feature rows per refined candidate
+        "k_lap": E * 16 + 8 * Mh,                               # edge list in, assignment vectors out
+        "prep": M * D * 6 + M * 48,                             # detection rows read (f32) + f16 shadows written, boxes
+        "merge": (N + M) * 16,                                  # list entries and per-slot flags
     }
     return "hbm", float(table[kern]), "byte", HBM_PEAK_GBS
 

@@ -117,18 +117,20 @@ __device__ __forceinline__ void to_half_row(const float *f, _Float16 *h, float *
 
 // <a, b> over d floats by one wavefront, every lane gets the result.  Fixed evaluation order
 // (lane-strided fma chains, then an xor butterfly), so the value is reproducible.
+// B = 16-byte loads in flight per lane and operand (register footprint 8*B; the value does not depend on it).
+template <int B = 8>
 __device__ __forceinline__ float wave_dot(const float *a, const float *b, int d, int lane) {
     float acc = 0.0f;
     if (vec4_ok(a, d) && vec4_ok(b, d)) {
         const float4 *a4 = reinterpret_cast<const float4 *>(a), *b4 = reinterpret_cast<const float4 *>(b);
         const int nv = d / 4;
         int k = lane;
-        for (; k + 7 * 64 < nv; k += 8 * 64) {          // 16 independent 16-byte loads in flight per lane
-            float4 x[8], y[8];
+        for (; k + (B - 1) * 64 < nv; k += B * 64) {    // 2*B independent 16-byte loads in flight per lane
+            float4 x[B], y[B];
 #pragma unroll
-            for (int t = 0; t < 8; ++t) { x[t] = a4[k + t * 64]; y[t] = b4[k + t * 64]; }
+            for (int t = 0; t < B; ++t) { x[t] = a4[k + t * 64]; y[t] = b4[k + t * 64]; }
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
+            for (int t = 0; t < B; ++t) {
                 acc = fmaf(x[t].x, y[t].x, acc); acc = fmaf(x[t].y, y[t].y, acc);
                 acc = fmaf(x[t].z, y[t].z, acc); acc = fmaf(x[t].w, y[t].w, acc);
             }

@@ -740,7 +740,7 @@ int bts_lap_enqueue(const bts_lap_problem *probs, int count, hipStream_t stream,
     if (ev) (void)hipEventRecord(ev[0], stream);
     hipLaunchKernelGGL(k_lap, dim3(count, 1 + LAP_HELPERS), dim3(1024), LAP_LDS_BYTES, stream, A, B);
     BTS_LAUNCH_CHECK();
-    if (ev) { (void)hipEventRecord(ev[1], stream); (void)hipEventRecord(ev[2], stream); (void)hipEventRecord(ev[3], stream); }
+    if (ev) (void)hipEventRecord(ev[1], stream);
     return BTS_OK;
 }
 

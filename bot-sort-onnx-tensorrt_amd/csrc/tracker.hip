@@ -19,15 +19,15 @@ namespace {
 
 enum {   // hdr[] fields
     H_FRAME = 0, H_NTRACKED, H_NLOST, H_NREMOVED, H_LASTID, H_NPOOL, H_NHI, H_NLO, H_NUNC, H_NR2, H_NLEFT,
-    H_ERR, H_NCONF, H_ALLF32, H_NFREE, H_NDETS, H_NT2, H_NL2, H_NBORN,
-    H_DIMS1 = 24, H_DIMS2 = 26, H_DIMS3 = 28, H_DIMSD = 30, H_SIZE = 32
+    H_ERR, H_NCONF, H_ALLF32, H_NFREE, H_NDETS, H_NKEEP, H_NB, H_NRF, H_NL0, H_NL1, H_NBORN,
+    H_DIMS1 = 24, H_DIMS2 = 26, H_DIMS3 = 28, H_SIZE = 32
 };
 enum { F_REFIND = 1, F_LOSTNOW = 2, F_REMOVEDNOW = 4 };
 enum { ERR_TRACK_CAPACITY = 1, ERR_LAP_EDGES = 2 };
 
-// The frame's inputs reach the kernels through one small device-resident descriptor, refreshed by
-// a 40-byte async copy per step: kernel arguments then never change, which is what lets a step be
-// captured once as a hipGraph and replayed.
+// The frame's inputs: eager steps carry them in the kernel arguments; under hipGraph replay the
+// kernel arguments are frozen at capture, so they come from one small device-resident descriptor
+// refreshed by a 40-byte async copy per step.
 struct InDesc {
     const int32_t *boxes;
     const float *scores;
@@ -65,13 +65,14 @@ struct Dev {
     int filter;                // appearance term by float16-MFMA pre-filter + exact float32 refine
     _Float16 *body_h, *face_h, *det_h, *dface_h;      // float16 shadows of body_curr/face_curr and of the frame's rows
     float *body_n, *face_n, *det_n, *dface_n;         // their float32 L2 norms
-    float *approx;                                     // [T][Mx] split-K accumulation of the pre-filter (self-cleaning)
+    float *approx, *approx_f;                          // [T][Mx] split-K accumulation of the pre-filter, body / face (self-cleaning)
+    uint32_t *cbits;                                   // [T][cb_ld] candidate bitmap of the one-pass pre-filter (self-cleaning)
+    int cb_ld;                                         // 32-bit words per bitmap row
     float eps_body, eps_face;                          // relative error bounds of the float16 dot products
-    int32_t *cand_i, *cand_q, *cand_n;                 // appearance candidates (pool row, high-det column), count
-    int32_t *app_q;                                    // [T] pool row -> column whose stage-1 edge k_refine emitted (-1: none)
-    int cand_cap;
-    const InDesc *in;          // inputs of the current step
+    const InDesc *in;          // inputs of the current step: descriptor in memory (hipGraph replay) ...
+    InDesc iv;                 // ... or by value in the kernel arguments (eager launches, in == nullptr)
 };
+#define IN(d, f) ((d).in ? (d).in->f : (d).iv.f)
 
 // ---- single-workgroup helpers: bscan::exscan / bscan::compact (block_scan.h) ------------------------
 template <class Pred, class Emit>
@@ -110,72 +111,112 @@ __device__ __forceinline__ void slot_tlbr(const Dev &d, int slot, double out[4])
     kf::mean_to_tlbr(m, d.f32[slot] != 0, out);
 }
 
-// ---- K1: frame prologue (1 workgroup) ---------------------------------------------------------------
+// ---- K1: frame prologue: four independent single-workgroup jobs + the detection-row conversion ---------
 // D:1414-1423 (split tracked into confirmed / unconfirmed, pool = confirmed ++ lost) and the
 // detection records of D:1488-1532 (high: score > 0.40, low: 0.1 <= score <= 0.40; float32 boxes).
-__device__ __forceinline__ void prep_body(const Dev &d) {
+// Each job owns its hdr words; the list order is semantics (it defines the row indices).
+__device__ __forceinline__ void prep_pool(const Dev &d) {
     __shared__ int32_t tmp[1024];
     __shared__ int s_allf32;
     int32_t *h = d.hdr;
     const int tid = threadIdx.x, nth = blockDim.x;
-    const int nt = h[H_NTRACKED], nl = h[H_NLOST], m = d.in->m;
+    const int nt = h[H_NTRACKED], nl = h[H_NLOST];
     if (tid == 0) s_allf32 = 1;
     const int nconf = block_compact(nt, tmp, [&](int k) { return d.is_activated[d.tracked[k]] != 0; },
                                     [&](int p, int k) { d.pool_slot[p] = d.tracked[k]; });
-    const int nunc = block_compact(nt, tmp, [&](int k) { return d.is_activated[d.tracked[k]] == 0; },
-                                   [&](int p, int k) { d.unc_slot[p] = d.tracked[k]; });
     for (int k = tid; k < nl; k += nth) d.pool_slot[nconf + k] = d.lost[k];
     const int N = nconf + nl;
     __syncthreads();
     int all32 = 1;
     for (int k = tid; k < N; k += nth) { const int s = d.pool_slot[k]; d.flag[s] = 0; if (!d.f32[s]) all32 = 0; }
-    for (int k = tid; k < nunc; k += nth) d.flag[d.unc_slot[k]] = 0;
     if (!all32) s_allf32 = 0;
-    // detections
+    __syncthreads();
+    if (tid == 0) {
+        h[H_FRAME] += 1;
+        h[H_NPOOL] = N; h[H_NCONF] = nconf;
+        h[H_ALLF32] = (N > 0 && s_allf32) ? 1 : 0;
+        h[H_DIMS1] = N;
+        h[H_NR2] = 0; h[H_DIMS2] = 0;
+    }
+}
+
+__device__ __forceinline__ void prep_unconfirmed(const Dev &d) {
+    __shared__ int32_t tmp[1024];
+    int32_t *h = d.hdr;
+    const int nt = h[H_NTRACKED];
+    const int nunc = block_compact(nt, tmp, [&](int k) { return d.is_activated[d.tracked[k]] == 0; },
+                                   [&](int p, int k) { const int s = d.tracked[k]; d.unc_slot[p] = s; d.flag[s] = 0; });
+    if (threadIdx.x == 0) { h[H_NUNC] = nunc; h[H_DIMS3] = nunc; }
+}
+
+__device__ __forceinline__ void prep_dets(const Dev &d) {
+    __shared__ int32_t tmp[1024];
+    int32_t *h = d.hdr;
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const int m = IN(d, m);
+    const int32_t *boxes = IN(d, boxes);
+    const float *scores = IN(d, scores);
     for (int j = tid; j < m; j += nth) {
-        const int x1 = d.in->boxes[j * 4 + 0], y1 = d.in->boxes[j * 4 + 1], x2 = d.in->boxes[j * 4 + 2], y2 = d.in->boxes[j * 4 + 3];
-        const float tx = (float)x1, ty = (float)y1, w = (float)(x2 - x1), hh = (float)(y2 - y1);   // _tlwh, D:465
+        const int4 b = reinterpret_cast<const int4 *>(boxes)[j];
+        const float tx = (float)b.x, ty = (float)b.y, w = (float)(b.z - b.x), hh = (float)(b.w - b.y);   // _tlwh, D:465
         d.det_tlbr[j * 4 + 0] = (double)tx; d.det_tlbr[j * 4 + 1] = (double)ty;
         d.det_tlbr[j * 4 + 2] = (double)(w + tx); d.det_tlbr[j * 4 + 3] = (double)(hh + ty);         // D:635-642
         d.det_xywh[j * 4 + 0] = tx + w / 2; d.det_xywh[j * 4 + 1] = ty + hh / 2;                     // D:663-670
         d.det_xywh[j * 4 + 2] = w; d.det_xywh[j * 4 + 3] = hh;
     }
-    const int nhi = block_compact(m, tmp, [&](int j) { return (double)d.in->scores[j] > d.high; },
+    const int nhi = block_compact(m, tmp, [&](int j) { return (double)scores[j] > d.high; },
                                   [&](int p, int j) { d.hi_idx[p] = j; });
-    const int nlo = block_compact(m, tmp, [&](int j) { const double s = (double)d.in->scores[j]; return s <= d.high && s >= d.low; },
+    const int nlo = block_compact(m, tmp, [&](int j) { const double s = (double)scores[j]; return s <= d.high && s >= d.low; },
                                   [&](int p, int j) { d.lo_idx[p] = j; });
-    __syncthreads();
     if (tid < 3 * BTS_LAP_HDR_INTS) d.lap_hdr[tid] = 0;
-    if (tid == 3 * BTS_LAP_HDR_INTS && d.filter) *d.cand_n = 0;
     if (tid == 0) {
-        h[H_FRAME] += 1;
-        h[H_NPOOL] = N; h[H_NCONF] = nconf; h[H_NUNC] = nunc; h[H_NHI] = nhi; h[H_NLO] = nlo; h[H_NDETS] = m;
-        h[H_ALLF32] = (N > 0 && s_allf32) ? 1 : 0;
-        h[H_DIMS1] = N; h[H_DIMS1 + 1] = nhi;
-        h[H_NR2] = 0; h[H_NLEFT] = 0; h[H_NBORN] = 0;
-        h[H_DIMS2] = 0; h[H_DIMS2 + 1] = nlo; h[H_DIMS3] = nunc; h[H_DIMS3 + 1] = 0;
+        h[H_NHI] = nhi; h[H_NLO] = nlo; h[H_NDETS] = m;
+        h[H_DIMS1 + 1] = nhi; h[H_DIMS2 + 1] = nlo;
+        h[H_NLEFT] = 0; h[H_NBORN] = 0; h[H_DIMS3 + 1] = 0;
     }
+}
+
+// slot recycling: a slot is free iff it is on neither list (its track was removed, dropped as a
+// duplicate or filtered by quirk Q6).  Rebuilt here, off the critical path: births happen in tk_merge.
+__device__ __forceinline__ void prep_free(const Dev &d) {
+    __shared__ int32_t tmp[1024];
+    int32_t *h = d.hdr;
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const int nt = h[H_NTRACKED], nl = h[H_NLOST];
+    for (int s = tid; s < d.T; s += nth) d.in_use[s] = 0;
+    __syncthreads();
+    for (int k = tid; k < nt; k += nth) d.in_use[d.tracked[k]] = 1;
+    for (int k = tid; k < nl; k += nth) d.in_use[d.lost[k]] = 1;
+    __syncthreads();
+    const int nfree = block_compact(d.T, tmp, [&](int s) { return !d.in_use[s]; }, [&](int p, int s) { d.free_list[p] = s; });
+    if (tid == 0) h[H_NFREE] = nfree;
 }
 
 // ---- K2: STrack.multi_predict over the pool (D:524-536 + D:265-302) ---------------------------------
 // float16 shadows + norms of this frame's (raw) detection rows for the appearance pre-filter
 __device__ __forceinline__ void cvt_body(const Dev &d, long j) {
-    if (j >= d.in->m) return;
-    feat::to_half_row(d.in->feats + j * d.D, d.det_h + j * d.D, d.det_n + j, d.D);
-    if (d.Df) feat::to_half_row(d.in->face_feats + j * d.Df, d.dface_h + j * d.Df, d.dface_n + j, d.Df);
+    if (j >= IN(d, m)) return;
+    feat::to_half_row(IN(d, feats) + j * d.D, d.det_h + j * d.D, d.det_n + j, d.D);
+    if (d.Df) feat::to_half_row(IN(d, face_feats) + j * d.Df, d.dface_h + j * d.Df, d.dface_n + j, d.Df);
 }
 
-// one launch: workgroup 0 builds the frame's lists, the others convert the detection rows
+// one launch: workgroups 0-3 build the frame's lists, the others convert the detection rows
+constexpr int FRONT_JOBS = 4;
 __global__ __launch_bounds__(1024) void tk_front(Dev d) {
-    if (blockIdx.x == 0) prep_body(d);
-    else cvt_body(d, (long)blockIdx.x - 1);
+    switch (blockIdx.x) {
+    case 0: prep_pool(d); break;
+    case 1: prep_unconfirmed(d); break;
+    case 2: prep_dets(d); break;
+    case 3: prep_free(d); break;
+    default: cvt_body(d, (long)blockIdx.x - FRONT_JOBS);
+    }
 }
 
-__global__ __launch_bounds__(256) void tk_predict(Dev d) {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void predict_body(const Dev &d, int bid) {
+    const int g = bid * 256 + threadIdx.x;
     // the three assignment vectors start out "unmatched" (the solver only writes matches)
-    if (g < d.T) { d.x1[g] = -1; d.x2[g] = -1; d.x3[g] = -1; if (d.filter) d.app_q[g] = -1; }
-    if (g < d.in->m) { d.y1[g] = -1; d.y2[g] = -1; d.y3[g] = -1; }
+    if (g < d.T) { d.x1[g] = -1; d.x2[g] = -1; d.x3[g] = -1; }
+    if (g < IN(d, m)) { d.y1[g] = -1; d.y2[g] = -1; d.y3[g] = -1; }
     const int r = g >> 3, i = g & 7;                     // 8 lanes per pool row
     if (r >= d.hdr[H_NPOOL]) return;
     const int s = d.pool_slot[r];
@@ -189,6 +230,7 @@ __global__ __launch_bounds__(256) void tk_predict(Dev d) {
     if (i < 4) d.pool_tlbr[r * 4 + i] = b[i];
     if (i == 0) d.f32[s] = 0;
 }
+__global__ __launch_bounds__(256) void tk_predict(Dev d) { predict_body(d, blockIdx.x); }
 
 // ---- cost tiles ----------------------------------------------------------------------------------------
 constexpr int CT_ROWS = 16, CT_COLS = 256;
@@ -196,6 +238,11 @@ constexpr int CT_ROWS = 16, CT_COLS = 256;
 __device__ __forceinline__ float face_fixup(float s) {
     const double dd = fabs((double)s - 0.9999999);
     return dd <= 1e-08 + 1e-08 * 0.9999999 ? 0.0f : s;
+}
+
+// candidate test: could the exact similarity reach the gate?  (NaN/inf approximations are candidates)
+__device__ __forceinline__ bool is_candidate(float approx, float na, float nb, float gate, float eps_rel) {
+    return !(approx < gate - eps_rel * na * nb - 3e-5f);
 }
 
 // STAGE 1: cost = min(iou_d, emb) with the appearance gate (D:1539-1554)
@@ -208,10 +255,12 @@ __device__ __forceinline__ float face_fixup(float s) {
 //         k_filter); stage 3 refines the few overlapping pairs with an exact wavefront dot product.
 // MODE 2: record only (dense cost matrix for inspection, no edges).
 template <int STAGE, int MODE>
-__device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, int bx, int by) {
+__device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, int bx, int by, int accum) {
     __shared__ double sa[CT_ROWS][4];
     __shared__ double sarea[CT_ROWS];
     __shared__ int sflag[CT_ROWS];
+    __shared__ int sslot[CT_ROWS];
+    __shared__ float sna[CT_ROWS], snf[CT_ROWS];
     const int32_t *h = d.hdr;
     const int n = STAGE == 1 ? h[H_NPOOL] : STAGE == 2 ? h[H_NR2] : h[H_NUNC];
     const int m = STAGE == 1 ? h[H_NHI] : STAGE == 2 ? h[H_NLO] : h[H_NLEFT];
@@ -224,6 +273,12 @@ __device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, 
         for (int c = 0; c < 4; ++c) sa[threadIdx.x][c] = box[c];
         sarea[threadIdx.x] = iou::area(box, f);
         sflag[threadIdx.x] = f;
+        if (STAGE == 1 && MODE == 1) {
+            const int s = d.pool_slot[i];
+            sslot[threadIdx.x] = s;
+            sna[threadIdx.x] = d.body_n[s];
+            snf[threadIdx.x] = d.Df ? d.face_n[s] : 0.0f;
+        }
     }
     __syncthreads();
     const bool live = q < m;
@@ -234,71 +289,137 @@ __device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, 
     const double limit = STAGE == 1 ? d.match1 : STAGE == 2 ? d.match2 : d.match3;
     const int rows = min(CT_ROWS, n - i0);
     const int lane = threadIdx.x & 63;
-    auto emit = [&](int row, double c) {
-        const int pos = atomicAdd(&w.hdr[0], 1);
-        if (pos < w.e_cap) { w.e_row[pos] = row; w.e_col[pos] = q; w.e_cost[pos] = c; }
-        else w.hdr[2] = 1;
+    float nbq = 0.0f, nfq = 0.0f;
+    if (STAGE == 1 && MODE == 1 && accum && live) { nbq = d.det_n[det]; if (d.Df) nfq = d.dface_n[det]; }
+    const float gate = 1.0f - d.app;
+    // Edges are staged per wavefront in LDS (ballot + lane-prefix, no atomics) and appended to the
+    // solver's list with ONE counter bump per flush and coalesced stores: a returning atomic costs a
+    // memory round trip, far too slow to pay per edge.
+    constexpr int EB = 128;
+    __shared__ double wb_c[CT_COLS / 64][EB];
+    __shared__ int32_t wb_r[CT_COLS / 64][EB], wb_q[CT_COLS / 64][EB];
+    const int wid = threadIdx.x >> 6;
+    int wcount = 0;
+    auto flush = [&]() {
+        if (wcount == 0) return;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&w.hdr[0], wcount);
+        base = __shfl(base, 0);
+        for (int k = lane; k < wcount; k += 64) {
+            const int pos = base + k;
+            if (pos < w.e_cap) { w.e_row[pos] = wb_r[wid][k]; w.e_col[pos] = wb_q[wid][k]; w.e_cost[pos] = wb_c[wid][k]; }
+            else w.hdr[2] = 1;
+        }
+        wcount = 0;
     };
+    auto emit = [&](bool pred, int row, double c) {          // convergent: every lane of the wavefront calls it
+        const unsigned long long mk = __ballot(pred);
+        if (!mk) return;
+        if (pred) {
+            const int p = wcount + __popcll(mk & ((1ull << lane) - 1ull));
+            wb_c[wid][p] = c; wb_r[wid][p] = row; wb_q[wid][p] = q;
+        }
+        wcount += __popcll(mk);
+        if (wcount > EB - 64) flush();
+    };
+    // Stage 1, pre-filter form: which pairs of this column could pass the appearance gate was
+    // decided by the float16 contraction (k_filter) -- either its split-K partial sums are complete
+    // in `approx` now, or it left a candidate bitmap.  Both are consumed and cleared here; all 16
+    // rows are fetched up front so that the tile pays one memory latency, not sixteen.
+    uint32_t cmask = 0;
+    if (MODE == 1 && STAGE == 1 && live) {
+        if (accum) {
+            auto scan = [&](float *acc, const float *srow, float ncol, float eps) {
+                float *p = acc + (long)i0 * d.Mx + q;
+                float av[CT_ROWS];
+#pragma unroll
+                for (int r = 0; r < CT_ROWS; ++r) av[r] = r < rows ? p[(long)r * d.Mx] : 0.0f;
+#pragma unroll
+                for (int r = 0; r < CT_ROWS; ++r) {
+                    if (r >= rows) continue;
+                    p[(long)r * d.Mx] = 0.0f;
+                    cmask |= (uint32_t)is_candidate(av[r], srow[r], ncol, gate, eps) << r;
+                }
+            };
+            scan(d.approx, sna, nbq, d.eps_body);
+            if (d.Df) scan(d.approx_f, snf, nfq, d.eps_face);
+        } else {
+            uint32_t wd[CT_ROWS];
+#pragma unroll
+            for (int r = 0; r < CT_ROWS; ++r) wd[r] = r < rows ? d.cbits[(long)(i0 + r) * d.cb_ld + (q >> 5)] : 0u;
+#pragma unroll
+            for (int r = 0; r < CT_ROWS; ++r) {
+                cmask |= ((wd[r] >> (q & 31)) & 1u) << r;
+                if (wd[r] && (q & 31) == 0) d.cbits[(long)(i0 + r) * d.cb_ld + (q >> 5)] = 0u;
+            }
+        }
+    }
+#pragma unroll 1
     for (int r = 0; r < rows; ++r) {
         const double aa[4] = {sa[r][0], sa[r][1], sa[r][2], sa[r][3]};
         const double iou_d = iou::cost(aa, sflag[r] != 0, sarea[r], bb, true, area_b);
         const long o = (long)(i0 + r) * d.Mx + q;
-        if (MODE == 1) {
-            if (live && iou_d <= limit && !(STAGE == 1 && d.app_q[i0 + r] == q)) emit(i0 + r, iou_d);
-            if (STAGE == 3) {
-                // appearance can only lower the cost where the proximity gate is open (D:1600-1601):
-                // those few pairs get an exact float32 dot product computed by the whole wavefront
-                unsigned long long todo = __ballot(live && iou_d <= d.prox);
-                while (todo) {
-                    const int src = __ffsll((long long)todo) - 1;
-                    todo &= todo - 1;
-                    const long sdet = __shfl(det, src);
-                    const long strk = d.unc_slot[i0 + r];
-                    const float sim = fmaxf(0.0f, feat::wave_dot(d.body_curr + strk * d.D, d.in->feats + sdet * d.D, d.D, lane));
-                    const float emb = 1.0f - sim;
-                    if (lane == src && !(emb > d.app) && (double)emb <= limit) emit(i0 + r, (double)emb);
-                }
-            }
-            continue;
-        }
-        if (!live) continue;
         double c = iou_d;
-        if (STAGE == 1) {
-            float emb = 1.0f - d.sim[o];
-            const float face = 1.0f - (d.Df ? face_fixup(d.fsim[o]) : 0.0f);
-            if (fminf(emb, face) > d.app) emb = 1.0f;
-            c = fmin(iou_d, (double)emb);
-        } else if (STAGE == 3) {
-            float emb = 1.0f - d.sim[o];
-            if (emb > d.app) emb = 1.0f;
-            if (iou_d > d.prox) emb = 1.0f;
-            c = fmin(iou_d, (double)emb);
+        if (MODE == 1 && STAGE == 1) {
+            // candidates get the exact float32 dot product, computed by the whole wavefront; the pair's
+            // single edge carries min(iou_d, emb) = np.minimum of D:1554
+            unsigned long long todo = __ballot((cmask >> r) & 1u);
+            while (todo) {
+                const int src = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const long sdet = __shfl(det, src), strk = sslot[r];
+                const float emb = 1.0f - fmaxf(0.0f, feat::wave_dot<4>(d.body_curr + strk * d.D, IN(d, feats) + sdet * d.D, d.D, lane));
+                float face = 1.0f;
+                if (d.Df)
+                    face = 1.0f - face_fixup(fmaxf(0.0f, feat::wave_dot<4>(d.face_curr + strk * d.Df, IN(d, face_feats) + sdet * d.Df, d.Df, lane)));
+                if (lane == src && !(fminf(emb, face) > d.app)) c = fmin(c, (double)emb);
+            }
+        } else if (MODE == 1 && STAGE == 3) {
+            // appearance can only lower the cost where the proximity gate is open (D:1600-1601):
+            // those few pairs get an exact float32 dot product computed by the whole wavefront
+            unsigned long long todo = __ballot(live && iou_d <= d.prox);
+            while (todo) {
+                const int src = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const long sdet = __shfl(det, src);
+                const long strk = d.unc_slot[i0 + r];
+                const float emb = 1.0f - fmaxf(0.0f, feat::wave_dot<4>(d.body_curr + strk * d.D, IN(d, feats) + sdet * d.D, d.D, lane));
+                if (lane == src && !(emb > d.app)) c = fmin(c, (double)emb);
+            }
+        } else if (MODE != 1 && live) {
+            if (STAGE == 1) {
+                float emb = 1.0f - d.sim[o];
+                const float face = 1.0f - (d.Df ? face_fixup(d.fsim[o]) : 0.0f);
+                if (fminf(emb, face) > d.app) emb = 1.0f;
+                c = fmin(iou_d, (double)emb);
+            } else if (STAGE == 3) {
+                float emb = 1.0f - d.sim[o];
+                if (emb > d.app) emb = 1.0f;
+                if (iou_d > d.prox) emb = 1.0f;
+                c = fmin(iou_d, (double)emb);
+            }
+            if (MODE == 2 || d.record) cost[o] = c;
         }
-        if (MODE == 2 || d.record) cost[o] = c;
-        if (MODE == 0 && c <= limit) emit(i0 + r, c);
+        if (MODE != 2) emit(live && c <= limit, i0 + r, c);
     }
+    if (MODE != 2) flush();
     __syncthreads();          // the tile's LDS is reused by the caller's next tile
 }
 
 // Persistent tiles: the live extents are only known on the device, so a fixed grid walks the
 // (column tile, row tile) space of the actual problem instead of launching capacity-sized grids.
 template <int STAGE, int MODE>
-__device__ __forceinline__ void edges_all(const Dev &d, const bts_lap_work &w) {
+__device__ __forceinline__ void edges_all(const Dev &d, const bts_lap_work &w, int bid, int nblk, int accum = 0) {
     const int32_t *h = d.hdr;
     const int n = STAGE == 1 ? h[H_NPOOL] : STAGE == 2 ? h[H_NR2] : h[H_NUNC];
     const int m = STAGE == 1 ? h[H_NHI] : STAGE == 2 ? h[H_NLO] : h[H_NLEFT];
     const int nct = (m + CT_COLS - 1) / CT_COLS, ntile = nct * ((n + CT_ROWS - 1) / CT_ROWS);
-    for (int t = blockIdx.x; t < ntile; t += gridDim.x) edges_tile<STAGE, MODE>(d, w, t % nct, t / nct);
+    for (int t = bid; t < ntile; t += nblk) edges_tile<STAGE, MODE>(d, w, t % nct, t / nct, accum);
 }
 
 template <int STAGE, int MODE>
-__global__ __launch_bounds__(CT_COLS) void tk_edges(Dev d, bts_lap_work w) { edges_all<STAGE, MODE>(d, w); }
-
-// stages 2 and 3 are independent of each other (disjoint tracks and detections): one launch, y selects
-template <int MODE3>
-__global__ __launch_bounds__(CT_COLS) void tk_edges23(Dev d, bts_lap_work w2, bts_lap_work w3) {
-    if (blockIdx.y == 0) edges_all<2, 0>(d, w2);
-    else edges_all<3, MODE3>(d, w3);
+__global__ __launch_bounds__(CT_COLS) void tk_edges(Dev d, bts_lap_work w, int accum) {
+    edges_all<STAGE, MODE>(d, w, blockIdx.x, gridDim.x, accum);
 }
 
 // ---- appearance pre-filter: float16 MFMA GEMM + exact float32 refine ------------------------------------------
@@ -318,51 +439,30 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
 }
 
-// exact gate of one (pool row i, high-detection column q) pair, evaluated by a whole wavefront
-// `pos` = the edge-list slot of this candidate (slots of rejected candidates hold row -1).
-__device__ __forceinline__ void refine_emit1(const Dev &d, const bts_lap_work &w, int i, int q, int lane, int pos) {
-    const long s = d.pool_slot[i], det = d.hi_idx[q];
-    const float bsim = fmaxf(0.0f, feat::wave_dot(d.body_curr + s * d.D, d.in->feats + det * d.D, d.D, lane));
-    const float emb = 1.0f - bsim;
-    float face = 1.0f;
-    if (d.Df) face = 1.0f - face_fixup(fmaxf(0.0f, feat::wave_dot(d.face_curr + s * d.Df, d.in->face_feats + det * d.Df, d.Df, lane)));
-    if (lane == 0 && (fminf(emb, face) > d.app || !((double)emb <= d.match1))) w.e_row[pos] = -1;
-    if (lane == 0 && !(fminf(emb, face) > d.app) && (double)emb <= d.match1) {
-        // One edge per pair where possible: the first appearance partner of a row also carries the
-        // pair's IoU cost (np.minimum of D:1554) and the IoU tile kernel, which runs after this
-        // one, skips that pair.  Further partners of the same row fall back to a second
-        // (harmless) edge for the pair.
-        double c = (double)emb;
-        const int old = atomicCAS(&d.app_q[i], -1, q);
-        if (old == -1 || old == q) {
-            const double aa[4] = {d.pool_tlbr[i * 4 + 0], d.pool_tlbr[i * 4 + 1], d.pool_tlbr[i * 4 + 2], d.pool_tlbr[i * 4 + 3]};
-            const double bb[4] = {d.det_tlbr[det * 4 + 0], d.det_tlbr[det * 4 + 1], d.det_tlbr[det * 4 + 2], d.det_tlbr[det * 4 + 3]};
-            c = fmin(c, iou::cost(aa, false, iou::area(aa, false), bb, true, iou::area(bb, true)));
-        }
-        w.e_row[pos] = i; w.e_col[pos] = q; w.e_cost[pos] = c;
-    }
-}
-
-// candidate test: could the exact similarity reach the gate?  (NaN/inf approximations are candidates)
-__device__ __forceinline__ bool is_candidate(float approx, float na, float nb, float gate, float eps_rel) {
-    return !(approx < gate - eps_rel * na * nb - 3e-5f);
-}
-
+// Grid: ntiles * nsplit GEMM workgroups (tile-major inside a K split), followed -- body pass only --
+// by the workgroups of the Kalman predict, which is independent of the contraction and shares the launch.
+// accum: add the partial products into `approx` (split K; the stage-1 tile kernel applies the
+// candidate test once they are complete); otherwise test here and set bits in `cbits`.
 template <bool FACE>
-__global__ __launch_bounds__(256) void k_filter(Dev d, bts_lap_work w, int m_max) {
+__global__ __launch_bounds__(256) void k_filter(Dev d, int m_max, int ntiles, int nsplit, int accum) {
     __shared__ __attribute__((aligned(16))) _Float16 As2[2][FBM * FLD];     // double-buffered operand tiles
     __shared__ __attribute__((aligned(16))) _Float16 Bs2[2][FBN * FLD];
+    if ((int)blockIdx.x >= ntiles * nsplit) {
+        if (!FACE) predict_body(d, (int)blockIdx.x - ntiles * nsplit);
+        return;
+    }
     const int n = d.hdr[H_NPOOL], m = d.hdr[H_NHI];
     const int Dd = FACE ? d.Df : d.D;
     const _Float16 *A = FACE ? d.face_h : d.body_h, *B = FACE ? d.dface_h : d.det_h;
     const int nbn = (m_max + FBN - 1) / FBN;
-    const int vb = xcd_remap(blockIdx.x, gridDim.x);
+    const int ksplit = blockIdx.x / ntiles;
+    const int vb = xcd_remap(blockIdx.x % ntiles, ntiles);
     const int bm = vb / nbn, bn = vb % nbn;
     if (bm * FBM >= n || bn * FBN >= m) return;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid >> 1, wc = wid & 1;
     // K range of this split
-    const int kt_all = (Dd + FBK - 1) / FBK, kt_per = (kt_all + gridDim.y - 1) / gridDim.y;
-    const int kt0 = blockIdx.y * kt_per, kt1 = min(kt_all, kt0 + kt_per);
+    const int kt_all = (Dd + FBK - 1) / FBK, kt_per = (kt_all + nsplit - 1) / nsplit;
+    const int kt0 = ksplit * kt_per, kt1 = min(kt_all, kt0 + kt_per);
     if (kt0 >= kt1) return;
 
     const int srow = tid >> 3, sk = (tid & 7) * 8;          // 128 rows x 8 chunks of 8 halves
@@ -429,10 +529,10 @@ __global__ __launch_bounds__(256) void k_filter(Dev d, bts_lap_work w, int m_max
     // epilogue: the tile's row/column norms go through LDS (the operand tiles are dead now)
     const float *na = FACE ? d.face_n : d.body_n, *nb = FACE ? d.dface_n : d.det_n;
     const float eps = FACE ? d.eps_face : d.eps_body, gate = 1.0f - d.app;
-    const bool split = gridDim.y > 1;
+    float *approx = FACE ? d.approx_f : d.approx;
     __syncthreads();
     float *snorm = reinterpret_cast<float *>(As2[0]);      // [0,128): rows, [128,256): columns
-    {
+    if (!accum) {
         const int g = tid < FBM ? bm * FBM + tid : bn * FBN + (tid - FBM);
         float v = 0.0f;
         if (tid < FBM) { if (g < n) v = na[d.pool_slot[g]]; }
@@ -440,7 +540,6 @@ __global__ __launch_bounds__(256) void k_filter(Dev d, bts_lap_work w, int m_max
         snorm[tid] = v;
     }
     __syncthreads();
-    unsigned long long cmask = 0;      // bit (mi*2+ni)*16 + r: accumulator element is a candidate
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -450,60 +549,12 @@ __global__ __launch_bounds__(256) void k_filter(Dev d, bts_lap_work w, int m_max
             for (int r = 0; r < 16; ++r) {
                 const int ii = wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh, i = bm * FBM + ii;
                 const float val = acc[mi][ni][r] * feat::HALF_UNSCALE;
-                const bool in = i < n && q < m;
-                if (split) {
-                    if (in) atomicAdd(&d.approx[(long)i * d.Mx + q], val);
-                } else if (in && is_candidate(val, snorm[ii], snorm[FBM + qq], gate, eps)) {
-                    cmask |= 1ull << ((mi * 2 + ni) * 16 + r);
-                }
+                if (!(i < n && q < m)) continue;
+                if (accum) atomicAdd(&approx[(long)i * d.Mx + q], val);
+                else if (is_candidate(val, snorm[ii], snorm[FBM + qq], gate, eps))      // rare: about one per detection column
+                    atomicOr(&d.cbits[(long)i * d.cb_ld + (q >> 5)], 1u << (q & 31));
             }
         }
-    if (split || cmask == 0) return;
-    for (int b = 0; b < 64; ++b) {       // rare: about one candidate per detection column
-        if (!((cmask >> b) & 1)) continue;
-        const int t4 = b >> 4, r = b & 15, mi = t4 >> 1, ni = t4 & 1;
-        const int i = bm * FBM + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-        const int q = bn * FBN + wc * 64 + ni * 32 + frow;
-        const int pos = atomicAdd(d.cand_n, 1);
-        if (pos < d.cand_cap) { d.cand_i[pos] = i; d.cand_q[pos] = q; }
-    }
-}
-
-// split-K form: the partial products were accumulated into `approx`; scan it (and clear it for the
-// next frame), refine the candidates.
-template <bool FACE>
-__global__ __launch_bounds__(CT_COLS) void k_filter_scan(Dev d) {
-    const int n = d.hdr[H_NPOOL], m = d.hdr[H_NHI];
-    const float *na = FACE ? d.face_n : d.body_n, *nb = FACE ? d.dface_n : d.det_n;
-    const float eps = FACE ? d.eps_face : d.eps_body, gate = 1.0f - d.app;
-    const int nct = (m + CT_COLS - 1) / CT_COLS, ntile = nct * ((n + CT_ROWS - 1) / CT_ROWS);
-    for (int t = blockIdx.x; t < ntile; t += gridDim.x) {
-        const int i0 = (t / nct) * CT_ROWS, q = (t % nct) * CT_COLS + threadIdx.x;
-        if (q >= m) continue;
-        const float nbq = nb[d.hi_idx[q]];
-        const int rows = min(CT_ROWS, n - i0);
-        for (int r = 0; r < rows; ++r) {
-            const int i = i0 + r;
-            float *p = &d.approx[(long)i * d.Mx + q];
-            const float val = *p;
-            *p = 0.0f;
-            if (is_candidate(val, na[d.pool_slot[i]], nbq, gate, eps)) {
-                const int pos = atomicAdd(d.cand_n, 1);
-                if (pos < d.cand_cap) { d.cand_i[pos] = i; d.cand_q[pos] = q; }
-            }
-        }
-    }
-}
-
-// one wavefront per candidate: exact float32 similarity, the D:1543-1547 gate, edge emission
-__global__ __launch_bounds__(256) void k_refine(Dev d, bts_lap_work w) {
-    int nc = *d.cand_n;
-    if (nc > d.cand_cap) { nc = d.cand_cap; if (threadIdx.x == 0 && blockIdx.x == 0) d.hdr[H_ERR] |= ERR_LAP_EDGES; }
-    const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwave = (gridDim.x * blockDim.x) >> 6;
-    // candidate k owns edge slot k (no contended counter); the IoU tiles append behind them
-    if (blockIdx.x == 0 && threadIdx.x == 0) w.hdr[0] = nc;
-    for (int k = wave; k < nc; k += nwave) refine_emit1(d, w, d.cand_i[k], d.cand_q[k], lane, k);
 }
 
 // ---- detection feature rows: in-place renormalisation (quirk Q8) ------------------------------------------
@@ -512,39 +563,39 @@ __device__ __forceinline__ void renorm_body(const Dev &d, int q) {
     const int nhi = h[H_NHI], nlo = h[H_NLO];
     if (q >= nhi + nlo) return;
     const long det = q < nhi ? d.hi_idx[q] : d.lo_idx[q - nhi];
-    feat::renorm_row(d.in->feats + det * d.D, d.D);
-    if (d.Df) feat::renorm_row(d.in->face_feats + det * d.Df, d.Df);
+    feat::renorm_row(IN(d, feats) + det * d.D, d.D);
+    if (d.Df) feat::renorm_row(IN(d, face_feats) + det * d.Df, d.Df);
 }
 
 // ---- match application (D:570-610).  FEAT=false: Kalman update + lifecycle, one thread per row with
 // the state in registers.  FEAT=true: ReID feature bookkeeping, one workgroup per row.  (Two launches:
 // the Kalman part needs the whole register file, the feature part wants occupancy.) ---------------------
 template <int STAGE, bool FEAT>
-__device__ __forceinline__ void apply_body(const Dev &d) {
+__device__ __forceinline__ void apply_body(const Dev &d, int bid) {
     const int32_t *h = d.hdr;
     const int n = STAGE == 1 ? h[H_NPOOL] : STAGE == 2 ? h[H_NR2] : h[H_NUNC];
     const int32_t *rslot = STAGE == 1 ? d.pool_slot : STAGE == 2 ? d.r2_slot : d.unc_slot;
     const int32_t *xs = STAGE == 1 ? d.x1 : STAGE == 2 ? d.x2 : d.x3;
     const int32_t *cdet = STAGE == 1 ? d.hi_idx : STAGE == 2 ? d.lo_idx : d.left_det;
     if (FEAT) {                                               // ---- feature rows: one workgroup each
-        const int r = blockIdx.x;
+        const int r = bid;
         if (r >= n) return;
         const int xq = xs[r];
         if (xq < 0) return;
         const long s = rslot[r], det = cdet[xq];
-        feat::ema_row(d.body_curr + s * d.D, d.body_smooth + s * d.D, d.in->feats + det * d.D, d.D, d.has_body[s] != 0,
+        feat::ema_row(d.body_curr + s * d.D, d.body_smooth + s * d.D, IN(d, feats) + det * d.D, d.D, d.has_body[s] != 0,
                       d.ema_a, d.ema_b);
         if (d.Df)
-            feat::ema_row(d.face_curr + s * d.Df, d.face_smooth + s * d.Df, d.in->face_feats + det * d.Df, d.Df,
+            feat::ema_row(d.face_curr + s * d.Df, d.face_smooth + s * d.Df, IN(d, face_feats) + det * d.Df, d.Df,
                           d.has_face[s] != 0, d.ema_a, d.ema_b);
         if (d.filter) {
-            feat::to_half_row(d.in->feats + det * d.D, d.body_h + s * d.D, d.body_n + s, d.D);
-            if (d.Df) feat::to_half_row(d.in->face_feats + det * d.Df, d.face_h + s * d.Df, d.face_n + s, d.Df);
+            feat::to_half_row(IN(d, feats) + det * d.D, d.body_h + s * d.D, d.body_n + s, d.D);
+            if (d.Df) feat::to_half_row(IN(d, face_feats) + det * d.Df, d.face_h + s * d.Df, d.face_n + s, d.Df);
         }
         if (threadIdx.x == 0) { d.has_body[s] = 1; if (d.Df) d.has_face[s] = 1; }
         return;
     }
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;      // ---- Kalman + lifecycle: 8 lanes per row
+    const int g = bid * 256 + threadIdx.x;                    // ---- Kalman + lifecycle: 8 lanes per row
     const int r = g >> 3, i = g & 7;
     if (r >= n) return;
     const int s = rslot[r];
@@ -574,126 +625,167 @@ __device__ __forceinline__ void apply_body(const Dev &d) {
     d.state[s] = BTS_TRACKED;
     d.is_activated[s] = 1;
     d.frame_id[s] = frame;
-    d.score[s] = d.in->scores[det];
+    d.score[s] = IN(d, scores)[det];
     d.det_index[s] = det;
 }
 
-template <int STAGE, bool FEAT>
-__global__ __launch_bounds__(256) void tk_apply(Dev d) { apply_body<STAGE, FEAT>(d); }
-
-template <bool FEAT>
-__global__ __launch_bounds__(256) void tk_apply23(Dev d) {
-    if (blockIdx.y == 0) apply_body<2, FEAT>(d);
-    else apply_body<3, FEAT>(d);
+// One launch after the stage-1 lists are rebuilt (tk_mid1): the stage-1 Kalman updates, the stage-1
+// feature bookkeeping and the cost tiles of stages 2 and 3 touch disjoint tracks, so they share a
+// launch as consecutive workgroup ranges (all 256 threads wide).
+template <int MODE3>
+__global__ __launch_bounds__(256) void tk_mid2(Dev d, bts_lap_work w2, bts_lap_work w3, int kf_blocks, int feat_blocks, int tile_blocks) {
+    int b = blockIdx.x;
+    if (b < kf_blocks) { apply_body<1, false>(d, b); return; }
+    b -= kf_blocks;
+    if (b < feat_blocks) { apply_body<1, true>(d, b); return; }
+    b -= feat_blocks;
+    if (b < tile_blocks) { edges_all<2, 0>(d, w2, b, tile_blocks); return; }
+    edges_all<3, MODE3>(d, w3, b - tile_blocks, tile_blocks);
 }
 
-// ---- after stage 1: rows of stage 2, columns of stage 3 (1 workgroup) ------------------------------------
-__device__ __forceinline__ void after1_body(const Dev &d) {
+// stages 2 and 3 applied together (disjoint tracks and detections): Kalman ranges, then feature rows
+__global__ __launch_bounds__(256) void tk_apply23(Dev d, int kf_blocks, int feat_blocks) {
+    int b = blockIdx.x;
+    if (b < kf_blocks) { apply_body<2, false>(d, b); return; }
+    b -= kf_blocks;
+    if (b < kf_blocks) { apply_body<3, false>(d, b); return; }
+    b -= kf_blocks;
+    if (b < feat_blocks) { apply_body<2, true>(d, b); return; }
+    apply_body<3, true>(d, b - feat_blocks);
+}
+
+// ---- after stage 1: rows of stage 2, columns of stage 3 (three single-workgroup jobs) -------------------
+constexpr int MID1_JOBS = 3;
+__device__ __forceinline__ void after1_body(const Dev &d, int job) {
     __shared__ int32_t tmp[1024];
     int32_t *h = d.hdr;
-    const int N = h[H_NPOOL], nhi = h[H_NHI], nunc = h[H_NUNC];
-    // r_tracked: unmatched pool rows that are still Tracked (D:1569).  Matched rows were set to
-    // Tracked by tk_apply_kf<1>, so the row test is on x1, the state test sees pre-frame state.
-    const int nr2 = block_compact(N, tmp, [&](int r) { return d.x1[r] < 0 && d.state[d.pool_slot[r]] == BTS_TRACKED; },
-                                  [&](int p, int r) {
-                                      d.r2_row[p] = r; d.r2_slot[p] = d.pool_slot[r];
-                                      for (int c = 0; c < 4; ++c) d.r2_tlbr[p * 4 + c] = d.pool_tlbr[r * 4 + c];
-                                  });
-    const int nleft = block_compact(nhi, tmp, [&](int q) { return d.y1[q] < 0; },
-                                    [&](int p, int q) { d.left_hi[p] = q; d.left_det[p] = d.hi_idx[q]; });
-    for (int k = threadIdx.x; k < nunc; k += blockDim.x) {     // unconfirmed boxes (may be float32 state)
-        const int s = d.unc_slot[k];
-        double b[4];
-        slot_tlbr(d, s, b);
-        for (int c = 0; c < 4; ++c) d.unc_tlbr[k * 4 + c] = b[c];
-        d.unc_f32[k] = d.f32[s];
-    }
-    if (threadIdx.x == 0) {
-        h[H_NR2] = nr2; h[H_NLEFT] = nleft;
-        h[H_DIMS2] = nr2; h[H_DIMS3 + 1] = nleft;
+    if (job == 0) {
+        // r_tracked: unmatched pool rows that are still Tracked (D:1569).  Matched rows are set to
+        // Tracked by the stage-1 update, which runs after this launch: the state test sees pre-frame state.
+        const int N = h[H_NPOOL];
+        const int nr2 = block_compact(N, tmp, [&](int r) { return d.x1[r] < 0 && d.state[d.pool_slot[r]] == BTS_TRACKED; },
+                                      [&](int p, int r) {
+                                          d.r2_row[p] = r; d.r2_slot[p] = d.pool_slot[r];
+                                          for (int c = 0; c < 4; ++c) d.r2_tlbr[p * 4 + c] = d.pool_tlbr[r * 4 + c];
+                                      });
+        if (threadIdx.x == 0) { h[H_NR2] = nr2; h[H_DIMS2] = nr2; }
+    } else if (job == 1) {
+        const int nhi = h[H_NHI];
+        const int nleft = block_compact(nhi, tmp, [&](int q) { return d.y1[q] < 0; },
+                                        [&](int p, int q) { d.left_hi[p] = q; d.left_det[p] = d.hi_idx[q]; });
+        if (threadIdx.x == 0) { h[H_NLEFT] = nleft; h[H_DIMS3 + 1] = nleft; }
+    } else {
+        const int nunc = h[H_NUNC];
+        for (int k = threadIdx.x; k < nunc; k += blockDim.x) {     // unconfirmed boxes (may be float32 state)
+            const int s = d.unc_slot[k];
+            double b[4];
+            slot_tlbr(d, s, b);
+            for (int c = 0; c < 4; ++c) d.unc_tlbr[k * 4 + c] = b[c];
+            d.unc_f32[k] = d.f32[s];
+        }
     }
 }
 
-// one launch after the first assignment: workgroup 0 prepares stages 2/3, the others renormalise rows
+// one launch after the first assignment: workgroups 0-2 prepare stages 2/3, the others renormalise rows
 __global__ __launch_bounds__(1024) void tk_mid1(Dev d) {
-    if (blockIdx.x == 0) after1_body(d);
-    else renorm_body(d, (int)blockIdx.x - 1);
+    if (blockIdx.x < MID1_JOBS) after1_body(d, blockIdx.x);
+    else renorm_body(d, (int)blockIdx.x - MID1_JOBS);
 }
 
-// ---- births + list merge (1 workgroup), D:1614-1636 ----------------------------------------------------------
+// ---- births + list merge, D:1614-1636: five independent single-workgroup jobs ----------------------------
+// tracked' = [old tracked still Tracked] ++ births ++ re-found (pool order);
+// lost'    = ([old lost not re-found] ++ newly lost (pool order)) minus ids already in removed (Q6).
+// Each piece is compacted by its own workgroup into its own region of tracked2 / lost2 (T entries
+// apart); tracked2_at / lost2_at read the concatenation.
+constexpr int MERGE_JOBS = 5;
+__device__ __forceinline__ int tracked2_at(const Dev &d, int k) {
+    const int c0 = d.hdr[H_NKEEP], c1 = d.hdr[H_NB];
+    return k < c0 ? d.tracked2[k] : k < c0 + c1 ? d.tracked2[d.T + (k - c0)] : d.tracked2[2 * d.T + (k - c0 - c1)];
+}
+__device__ __forceinline__ int lost2_at(const Dev &d, int k) {
+    const int c0 = d.hdr[H_NL0];
+    return k < c0 ? d.lost2[k] : d.lost2[d.T + (k - c0)];
+}
+
 __global__ __launch_bounds__(1024) void tk_merge(Dev d) {
     __shared__ int32_t tmp[1024];
     int32_t *h = d.hdr;
     const int tid = threadIdx.x, nth = blockDim.x;
-    const int frame = h[H_FRAME], nleft = h[H_NLEFT], nfree = h[H_NFREE], last_id = h[H_LASTID];
-    const int nt = h[H_NTRACKED], nl = h[H_NLOST], N = h[H_NPOOL], nconf = h[H_NCONF], nunc = h[H_NUNC];
-    // births in ascending leftover-detection order (new ids ascending, quirk Q7)
-    for (int k = tid; k < nleft; k += nth) d.born_slot[k] = -1;
-    __syncthreads();
-    const int nborn_want = block_compact(
-        nleft, tmp, [&](int k) { return d.y3[k] < 0 && !((double)d.in->scores[d.left_det[k]] < d.new_thr); },
-        [&](int b, int k) {
-            if (b >= nfree) return;
-            const int s = d.free_list[b], det = d.left_det[k];
-            d.born_slot[k] = s;
-            d.track_id[s] = last_id + 1 + b;
-            d.state[s] = BTS_TRACKED;
-            d.is_activated[s] = frame == 1 ? 1 : 0;          // D:565-566
-            d.frame_id[s] = frame; d.start_frame[s] = frame; d.tracklet_len[s] = 0;
-            d.score[s] = d.in->scores[det]; d.det_index[s] = det;
-            d.f32[s] = 1; d.in_removed[s] = 0; d.flag[s] = 0;
-            d.has_body[s] = 1; d.has_face[s] = d.Df ? 1 : 0;
-        });
-    const int nborn = min(nborn_want, nfree);
-    // expiry of lost tracks (D:1623-1627); re-found ones carry frame_id == frame
-    int expired = 0;
-    for (int k = tid; k < nl; k += nth) {
-        const int s = d.lost[k];
-        if (frame - d.frame_id[s] > d.max_time_lost) { d.state[s] = BTS_REMOVED; d.flag[s] |= F_REMOVEDNOW; ++expired; }
-    }
-    int tot_expired;
-    block_exscan_i(expired, tmp, &tot_expired);
-    int removed_unc = 0;
-    for (int k = tid; k < nunc; k += nth) removed_unc += (d.flag[d.unc_slot[k]] & F_REMOVEDNOW) ? 1 : 0;
-    int tot_removed_unc;
-    block_exscan_i(removed_unc, tmp, &tot_removed_unc);
-    // tracked' = [old tracked still Tracked] ++ births ++ re-found (pool order)
-    const int n_keep = block_compact(nt, tmp, [&](int k) { return d.state[d.tracked[k]] == BTS_TRACKED; },
-                                     [&](int p, int k) { d.tracked2[p] = d.tracked[k]; });
-    const int n_b = block_compact(nleft, tmp, [&](int k) { return d.born_slot[k] >= 0; },
-                                  [&](int p, int k) { d.tracked2[n_keep + p] = d.born_slot[k]; });
-    const int n_rf = block_compact(N, tmp, [&](int r) { return (d.flag[d.pool_slot[r]] & F_REFIND) != 0; },
-                                   [&](int p, int r) { d.tracked2[n_keep + n_b + p] = d.pool_slot[r]; });
-    // lost' = ([old lost not re-found] ++ newly lost (pool order)) minus ids already in removed (Q6)
-    const int n_l0 = block_compact(nl, tmp,
-                                   [&](int k) { const int s = d.lost[k]; return d.state[s] != BTS_TRACKED && !d.in_removed[s]; },
-                                   [&](int p, int k) { d.lost2[p] = d.lost[k]; });
-    const int n_l1 = block_compact(nconf, tmp,
-                                   [&](int r) { const int s = d.pool_slot[r]; return (d.flag[s] & F_LOSTNOW) && !d.in_removed[s]; },
-                                   [&](int p, int r) { d.lost2[n_l0 + p] = d.pool_slot[r]; });
-    __syncthreads();
-    // removed_stracks.extend(removed_now): remember the ids (here: slots) for the next frames
-    for (int k = tid; k < nl; k += nth) { const int s = d.lost[k]; if (d.flag[s] & F_REMOVEDNOW) d.in_removed[s] = 1; }
-    for (int k = tid; k < nunc; k += nth) { const int s = d.unc_slot[k]; if (d.flag[s] & F_REMOVEDNOW) d.in_removed[s] = 1; }
-    for (int k = tid; k < n_keep + n_b + n_rf; k += nth) d.drop_t[k] = 0;
-    for (int k = tid; k < n_l0 + n_l1; k += nth) d.drop_l[k] = 0;
-    if (tid == 0) {
-        h[H_NT2] = n_keep + n_b + n_rf;
-        h[H_NL2] = n_l0 + n_l1;
-        h[H_NBORN] = nborn;
-        h[H_LASTID] = last_id + nborn;
-        h[H_NREMOVED] += tot_expired + tot_removed_unc;
-        if (nborn_want > nfree) h[H_ERR] |= ERR_TRACK_CAPACITY;
-        for (int k = 0; k < 3; ++k)                          // assignment solver: edge-list overflow / helper time-out
-            if (d.lap_hdr[BTS_LAP_HDR_INTS * k + 2]) h[H_ERR] |= ERR_LAP_EDGES;
-        h[H_DIMSD] = n_keep + n_b + n_rf; h[H_DIMSD + 1] = n_l0 + n_l1;
+    const int frame = h[H_FRAME];
+    if (blockIdx.x == 0) {
+        // births in ascending leftover-detection order (new ids ascending, quirk Q7)
+        const int nleft = h[H_NLEFT], nfree = h[H_NFREE], last_id = h[H_LASTID];
+        const float *scores = IN(d, scores);
+        for (int k = tid; k < nleft; k += nth) d.born_slot[k] = -1;
+        __syncthreads();
+        const int nborn_want = block_compact(
+            nleft, tmp, [&](int k) { return d.y3[k] < 0 && !((double)scores[d.left_det[k]] < d.new_thr); },
+            [&](int b, int k) {
+                if (b >= nfree) return;
+                const int s = d.free_list[b], det = d.left_det[k];
+                d.born_slot[k] = s;
+                d.tracked2[d.T + b] = s;                         // births keep detection order
+                d.track_id[s] = last_id + 1 + b;
+                d.state[s] = BTS_TRACKED;
+                d.is_activated[s] = frame == 1 ? 1 : 0;          // D:565-566
+                d.frame_id[s] = frame; d.start_frame[s] = frame; d.tracklet_len[s] = 0;
+                d.score[s] = scores[det]; d.det_index[s] = det;
+                d.f32[s] = 1; d.in_removed[s] = 0; d.flag[s] = 0;
+                d.has_body[s] = 1; d.has_face[s] = d.Df ? 1 : 0;
+                // position half of KalmanFilter.initiate (D:166-197): the duplicate test of this frame reads
+                // it while the rest of the state is still being initialised (tk_tail)
+                for (int c = 0; c < 4; ++c) d.mean[(long)s * 8 + c] = (double)d.det_xywh[det * 4 + c];
+            });
+        if (tid == 0) {
+            const int nborn = min(nborn_want, nfree);
+            h[H_NB] = nborn; h[H_NBORN] = nborn;
+            h[H_LASTID] = last_id + nborn;
+            int err = nborn_want > nfree ? ERR_TRACK_CAPACITY : 0;
+            for (int k = 0; k < 3; ++k)                          // assignment solver: edge-list overflow / helper time-out
+                if (d.lap_hdr[BTS_LAP_HDR_INTS * k + 2]) err |= ERR_LAP_EDGES;
+            if (err) atomicOr(&h[H_ERR], err);
+        }
+    } else if (blockIdx.x == 1) {
+        const int nt = h[H_NTRACKED];
+        const int n_keep = block_compact(nt, tmp, [&](int k) { return d.state[d.tracked[k]] == BTS_TRACKED; },
+                                         [&](int p, int k) { d.tracked2[p] = d.tracked[k]; });
+        if (tid == 0) h[H_NKEEP] = n_keep;
+    } else if (blockIdx.x == 2) {
+        const int N = h[H_NPOOL];
+        const int n_rf = block_compact(N, tmp, [&](int r) { return (d.flag[d.pool_slot[r]] & F_REFIND) != 0; },
+                                       [&](int p, int r) { d.tracked2[2 * d.T + p] = d.pool_slot[r]; });
+        if (tid == 0) h[H_NRF] = n_rf;
+    } else if (blockIdx.x == 3) {
+        const int nl = h[H_NLOST], nunc = h[H_NUNC];
+        const int n_l0 = block_compact(nl, tmp,
+                                       [&](int k) { const int s = d.lost[k]; return d.state[s] != BTS_TRACKED && !d.in_removed[s]; },
+                                       [&](int p, int k) { d.lost2[p] = d.lost[k]; });
+        // expiry of lost tracks (D:1623-1627); re-found ones carry frame_id == frame.  removed_stracks.extend(
+        // removed_now): the ids (here: slots) are remembered for the next frames -- after the filter above (Q6)
+        int gone = 0;
+        for (int k = tid; k < nl; k += nth) {
+            const int s = d.lost[k];
+            if (frame - d.frame_id[s] > d.max_time_lost) { d.state[s] = BTS_REMOVED; d.flag[s] |= F_REMOVEDNOW; d.in_removed[s] = 1; ++gone; }
+        }
+        for (int k = tid; k < nunc; k += nth) {
+            const int s = d.unc_slot[k];
+            if (d.flag[s] & F_REMOVEDNOW) { d.in_removed[s] = 1; ++gone; }
+        }
+        int tot_gone;
+        block_exscan_i(gone, tmp, &tot_gone);
+        if (tid == 0) { h[H_NL0] = n_l0; h[H_NREMOVED] += tot_gone; }
+    } else {
+        const int nconf = h[H_NCONF];
+        const int n_l1 = block_compact(nconf, tmp,
+                                       [&](int r) { const int s = d.pool_slot[r]; return (d.flag[s] & F_LOSTNOW) && !d.in_removed[s]; },
+                                       [&](int p, int r) { d.lost2[d.T + p] = d.pool_slot[r]; });
+        if (tid == 0) h[H_NL1] = n_l1;
     }
 }
 
 // Kalman initiate + feature rows of the newborn tracks (D:556-568, D:492-514): one workgroup per
 // leftover detection.
-__global__ __launch_bounds__(256) void tk_birth_init(Dev d) {
-    const int k = blockIdx.x;
+__device__ __forceinline__ void birth_body(const Dev &d, int k) {
     if (k >= d.hdr[H_NLEFT]) return;
     const long s = d.born_slot[k];
     if (s < 0) return;
@@ -702,35 +794,38 @@ __global__ __launch_bounds__(256) void tk_birth_init(Dev d) {
         const float z[4] = {d.det_xywh[det * 4 + 0], d.det_xywh[det * 4 + 1], d.det_xywh[det * 4 + 2], d.det_xywh[det * 4 + 3]};
         double m[8], P[64];
         kf::initiate(z, m, P);
-        store_state(d, (int)s, m, P);
+        for (int c = 4; c < 8; ++c) d.mean[s * 8 + c] = m[c];          // m[0..3] were written by tk_merge
+        for (int c = 0; c < 64; ++c) d.cov[s * 64 + c] = P[c];
     }
     // the detection row was renormalised in place; curr and smooth alias it in the reference
     for (int c = threadIdx.x; c < d.D; c += blockDim.x) {
-        const float v = d.in->feats[det * d.D + c];
+        const float v = IN(d, feats)[det * d.D + c];
         d.body_curr[s * d.D + c] = v; d.body_smooth[s * d.D + c] = v;
     }
     for (int c = threadIdx.x; c < d.Df; c += blockDim.x) {
-        const float v = d.in->face_feats[det * d.Df + c];
+        const float v = IN(d, face_feats)[det * d.Df + c];
         d.face_curr[s * d.Df + c] = v; d.face_smooth[s * d.Df + c] = v;
     }
     if (d.filter) {
-        feat::to_half_row(d.in->feats + det * d.D, d.body_h + s * d.D, d.body_n + s, d.D);
-        if (d.Df) feat::to_half_row(d.in->face_feats + det * d.Df, d.face_h + s * d.Df, d.face_n + s, d.Df);
+        feat::to_half_row(IN(d, feats) + det * d.D, d.body_h + s * d.D, d.body_n + s, d.D);
+        if (d.Df) feat::to_half_row(IN(d, face_feats) + det * d.Df, d.face_h + s * d.Df, d.face_n + s, d.Df);
     }
 }
 
 // ---- duplicate removal between tracked' and lost' (D:1665-1680): boxes straight from the table ------------
-__global__ __launch_bounds__(CT_COLS) void tk_dedupe(Dev d) {
+// ... in one launch with the initialisation of the newborn tracks (workgroups >= dedupe_blocks)
+__global__ __launch_bounds__(CT_COLS) void tk_tail(Dev d, int dedupe_blocks) {
+    if ((int)blockIdx.x >= dedupe_blocks) { birth_body(d, (int)blockIdx.x - dedupe_blocks); return; }
     __shared__ double sa[CT_ROWS][4];
     __shared__ double sarea[CT_ROWS];
     __shared__ int sflag[CT_ROWS];
     __shared__ int sage[CT_ROWS];
-    const int n = d.hdr[H_NT2], m = d.hdr[H_NL2];
+    const int n = d.hdr[H_NKEEP] + d.hdr[H_NB] + d.hdr[H_NRF], m = d.hdr[H_NL0] + d.hdr[H_NL1];
     const int nct = (m + CT_COLS - 1) / CT_COLS, ntile = nct * ((n + CT_ROWS - 1) / CT_ROWS);
-    for (int t = blockIdx.x; t < ntile; t += gridDim.x) {
+    for (int t = blockIdx.x; t < ntile; t += dedupe_blocks) {
         const int i0 = (t / nct) * CT_ROWS, j = (t % nct) * CT_COLS + threadIdx.x;
         if (threadIdx.x < CT_ROWS && i0 + threadIdx.x < n) {
-            const int s = d.tracked2[i0 + threadIdx.x];
+            const int s = tracked2_at(d, i0 + threadIdx.x);
             double box[4];
             slot_tlbr(d, s, box);
             const bool f = d.f32[s] != 0;
@@ -741,7 +836,7 @@ __global__ __launch_bounds__(CT_COLS) void tk_dedupe(Dev d) {
         }
         __syncthreads();
         if (j < m) {
-            const int sj = d.lost2[j];
+            const int sj = lost2_at(d, j);
             double bb[4];
             slot_tlbr(d, sj, bb);
             const bool bf = d.f32[sj] != 0;
@@ -762,27 +857,29 @@ __global__ __launch_bounds__(CT_COLS) void tk_dedupe(Dev d) {
     }
 }
 
-// ---- frame epilogue (1 workgroup): final lists, slot recycling ------------------------------------------------
+// ---- frame epilogue: final lists (one workgroup each), drop flags cleared for the next frame ------------------
 __global__ __launch_bounds__(1024) void tk_finalize(Dev d) {
     __shared__ int32_t tmp[1024];
     int32_t *h = d.hdr;
     const int tid = threadIdx.x, nth = blockDim.x;
-    const int nt2 = h[H_NT2], nl2 = h[H_NL2];
-    const int nt = block_compact(nt2, tmp, [&](int k) { return !d.drop_t[k]; }, [&](int p, int k) { d.tracked[p] = d.tracked2[k]; });
-    const int nl = block_compact(nl2, tmp, [&](int k) { return !d.drop_l[k]; }, [&](int p, int k) { d.lost[p] = d.lost2[k]; });
-    for (int s = tid; s < d.T; s += nth) d.in_use[s] = 0;
-    __syncthreads();
-    for (int k = tid; k < nt; k += nth) d.in_use[d.tracked[k]] = 1;
-    for (int k = tid; k < nl; k += nth) d.in_use[d.lost[k]] = 1;
-    __syncthreads();
-    const int nfree = block_compact(d.T, tmp, [&](int s) { return !d.in_use[s]; }, [&](int p, int s) { d.free_list[p] = s; });
-    if (tid == 0) { h[H_NTRACKED] = nt; h[H_NLOST] = nl; h[H_NFREE] = nfree; }
+    if (blockIdx.x == 0) {
+        const int nt2 = h[H_NKEEP] + h[H_NB] + h[H_NRF];
+        const int nt = block_compact(nt2, tmp, [&](int k) { return !d.drop_t[k]; }, [&](int p, int k) { d.tracked[p] = tracked2_at(d, k); });
+        for (int k = tid; k < nt2; k += nth) d.drop_t[k] = 0;
+        if (tid == 0) h[H_NTRACKED] = nt;
+    } else {
+        const int nl2 = h[H_NL0] + h[H_NL1];
+        const int nl = block_compact(nl2, tmp, [&](int k) { return !d.drop_l[k]; }, [&](int p, int k) { d.lost[p] = lost2_at(d, k); });
+        for (int k = tid; k < nl2; k += nth) d.drop_l[k] = 0;
+        if (tid == 0) h[H_NLOST] = nl;
+    }
 }
 
 __global__ __launch_bounds__(1024) void tk_reset(Dev d) {
     const int tid = threadIdx.x, nth = blockDim.x;
     for (int s = tid; s < d.T; s += nth) {
         d.free_list[s] = s; d.in_use[s] = 0; d.in_removed[s] = 0; d.flag[s] = 0; d.f32[s] = 0; d.state[s] = BTS_NEW;
+        d.drop_t[s] = 0; d.drop_l[s] = 0;
         d.is_activated[s] = 0; d.track_id[s] = 0; d.has_body[s] = 0; d.has_face[s] = 0;
     }
     for (int k = tid; k < H_SIZE; k += nth) d.hdr[k] = 0;
@@ -858,10 +955,8 @@ struct bts_tracker {
     hipEvent_t in_ev[RING] = {};
     bool in_used[RING] = {};
     unsigned long step_no = 0;
-    // hipGraph replay of a whole step (optional): captured once on private streams with the
-    // independent kernel chains forked onto side streams
-    hipStream_t cs[3] = {};
-    hipEvent_t fev[8] = {};
+    // hipGraph replay of a whole step (optional): captured once on a private stream
+    hipStream_t cs[1] = {};
     hipGraphExec_t gexec = nullptr;
 };
 
@@ -879,7 +974,7 @@ static void tracker_layout(bts_tracker *t, char *base, size_t &off) {
     SLOT(d.det_index, int32_t, T); SLOT(d.score, float, T);
     SLOT(d.body_curr, float, T * D); SLOT(d.body_smooth, float, T * D);
     SLOT(d.face_curr, float, T * Df); SLOT(d.face_smooth, float, T * Df);
-    SLOT(d.tracked, int32_t, T); SLOT(d.lost, int32_t, T); SLOT(d.tracked2, int32_t, T); SLOT(d.lost2, int32_t, T);
+    SLOT(d.tracked, int32_t, T); SLOT(d.lost, int32_t, T); SLOT(d.tracked2, int32_t, 3 * T); SLOT(d.lost2, int32_t, 2 * T);
     SLOT(d.free_list, int32_t, T); SLOT(d.hdr, int32_t, H_SIZE);
     SLOT(d.pool_slot, int32_t, T); SLOT(d.unc_slot, int32_t, T); SLOT(d.hi_idx, int32_t, M); SLOT(d.lo_idx, int32_t, M);
     SLOT(d.r2_row, int32_t, T); SLOT(d.r2_slot, int32_t, T); SLOT(d.left_hi, int32_t, M); SLOT(d.left_det, int32_t, M);
@@ -896,8 +991,9 @@ static void tracker_layout(bts_tracker *t, char *base, size_t &off) {
     if (d.filter) {
         SLOT(d.body_h, _Float16, T * D); SLOT(d.det_h, _Float16, M * D); SLOT(d.body_n, float, T); SLOT(d.det_n, float, M);
         SLOT(d.face_h, _Float16, T * Df); SLOT(d.dface_h, _Float16, M * Df); SLOT(d.face_n, float, T); SLOT(d.dface_n, float, M);
-        SLOT(d.approx, float, T * M);
-        SLOT(d.cand_i, int32_t, T * M); SLOT(d.cand_q, int32_t, T * M); SLOT(d.cand_n, int32_t, 4); SLOT(d.app_q, int32_t, T);
+        SLOT(d.approx, float, T * M); SLOT(d.approx_f, float, d.Df ? T * M : 1);
+        d.cb_ld = (int)((M + 31) / 32);
+        SLOT(d.cbits, uint32_t, T * (size_t)d.cb_ld);
     }
     SLOT(t->x_ints, int32_t, 8 * T); SLOT(t->x_mean, double, 8 * T); SLOT(t->x_tlbr, double, 4 * T); SLOT(t->x_score, float, T); SLOT(t->x_mot, double, 10 * T);
 #undef SLOT
@@ -936,7 +1032,6 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
     d.record = cfg->record_costs ? 1 : 0;
     // the float16 pre-filter needs 16-byte rows of halves; otherwise the dense float32 form is used
     d.filter = (cfg->appearance_mode == BTS_APPEARANCE_FILTER && d.D % 8 == 0 && d.Df % 8 == 0) ? 1 : 0;
-    d.cand_cap = (int)((int64_t)d.T * d.Mx);
     d.eps_body = 1.1f / 1024.0f + (float)d.D / 4194304.0f;
     d.eps_face = 1.1f / 1024.0f + (float)d.Df / 4194304.0f;
     size_t off = 0;
@@ -964,7 +1059,10 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
         delete t;
         return BTS_ENOMEM;
     }
-    if (t->dv.filter && hipMemset(t->dv.approx, 0, sizeof(float) * (size_t)t->dv.T * t->dv.Mx) != hipSuccess) {
+    const size_t tm = (size_t)t->dv.T * t->dv.Mx;      // the pre-filter's accumulators and bitmap are self-cleaning from here on
+    if (t->dv.filter && (hipMemset(t->dv.approx, 0, sizeof(float) * tm) != hipSuccess ||
+                         hipMemset(t->dv.approx_f, 0, sizeof(float) * (t->dv.Df ? tm : 1)) != hipSuccess ||
+                         hipMemset(t->dv.cbits, 0, sizeof(uint32_t) * (size_t)t->dv.T * t->dv.cb_ld) != hipSuccess)) {
         (void)hipGetLastError();
         bts_set_error("hipMemset failed");
         bts_tracker_destroy(t);
@@ -980,10 +1078,9 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
     bool ok = hipMalloc((void **)&t->d_in, sizeof(InDesc)) == hipSuccess &&
               hipHostMalloc((void **)&t->h_in, sizeof(InDesc) * bts_tracker::RING) == hipSuccess;
     for (int k = 0; ok && k < bts_tracker::RING; ++k) ok = hipEventCreateWithFlags(&t->in_ev[k], hipEventDisableTiming) == hipSuccess;
-    for (int k = 0; ok && k < 3; ++k) ok = hipStreamCreateWithFlags(&t->cs[k], hipStreamNonBlocking) == hipSuccess;
-    for (int k = 0; ok && k < 8; ++k) ok = hipEventCreateWithFlags(&t->fev[k], hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&t->cs[0], hipStreamNonBlocking) == hipSuccess;
     if (!ok) { (void)hipGetLastError(); bts_set_error("stream / event / descriptor allocation failed"); bts_tracker_destroy(t); return BTS_EHIP; }
-    t->dv.in = t->d_in;
+    t->dv.in = nullptr;
     bts_lap_init();
     int rc = bts_tracker_reset(t, nullptr);
     if (rc == BTS_OK && hipStreamSynchronize(nullptr) != hipSuccess) rc = BTS_EHIP;
@@ -1025,8 +1122,7 @@ int bts_tracker_destroy(bts_tracker *t) {
     delete[] t->prof_ev;
     if (t->gexec) (void)hipGraphExecDestroy(t->gexec);
     for (int k = 0; k < bts_tracker::RING; ++k) if (t->in_ev[k]) (void)hipEventDestroy(t->in_ev[k]);
-    for (int k = 0; k < 8; ++k) if (t->fev[k]) (void)hipEventDestroy(t->fev[k]);
-    for (int k = 0; k < 3; ++k) if (t->cs[k]) (void)hipStreamDestroy(t->cs[k]);
+    if (t->cs[0]) (void)hipStreamDestroy(t->cs[0]);
     if (t->d_in) (void)hipFree(t->d_in);
     if (t->h_in) (void)hipHostFree(t->h_in);
     if (t->block) (void)hipFree(t->block);
@@ -1043,20 +1139,19 @@ int bts_tracker_reset(bts_tracker *t, bts_stream stream) {
 }
 
 // Enqueue the kernels of one step.  `mc` bounds every detection-indexed grid (the frame's m in eager
-// mode, max_dets under graph capture).  `par`: fork the independent chains onto the side streams.
-static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face_feats, int mc, bool par) {
-    const bool prof_room = !par && t->prof_cap > 0 && t->prof_n < t->prof_cap;
+// mode, max_dets under graph capture; `capturing` = no timing events).
+static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face_feats, int mc, bool capturing) {
+    const bool prof_room = !capturing && t->prof_cap > 0 && t->prof_n < t->prof_cap;
     auto seg_begin = [&](int id) { if (prof_room && t->prof_seg == id) (void)hipEventRecord(t->prof_ev[2 * t->prof_n], s); };
     auto seg_end = [&](int id) { if (prof_room && t->prof_seg == id) { (void)hipEventRecord(t->prof_ev[2 * t->prof_n + 1], s); t->prof_n++; } };
-    hipStream_t s2 = par ? t->cs[1] : s, s3 = par ? t->cs[2] : s;
-    auto fork = [&](hipStream_t to, int e) { if (par) { (void)hipEventRecord(t->fev[e], s); (void)hipStreamWaitEvent(to, t->fev[e], 0); } };
-    auto join = [&](hipStream_t from, int e) { if (par) { (void)hipEventRecord(t->fev[e], from); (void)hipStreamWaitEvent(s, t->fev[e], 0); } };
     const Dev &d = t->dv;
     const int T = d.T, M = d.Mx;
     const int cos_kernel = t->ctx->cos_kernel;
     int ntile = bts_cdiv(mc, CT_COLS) * bts_cdiv(T, CT_ROWS);
     if (ntile > 1024) ntile = 1024;
     const dim3 tile_grid(ntile);               // persistent tiles: the kernels walk the live extents
+    int ntile1 = bts_cdiv(mc, CT_COLS) * bts_cdiv(T, CT_ROWS);      // stage 1 has the big problem: about a tile per workgroup
+    if (ntile1 > 8192) ntile1 = 8192;
     const int kf_blocks = bts_cdiv(T * 8 > M ? T * 8 : M, 256);   // 8 lanes per track
     bts_lap_work lap[3] = {t->lap, t->lap, t->lap3};
     for (int k = 0; k < 3; ++k) lap[k].hdr = d.lap_hdr + BTS_LAP_HDR_INTS * k;
@@ -1066,22 +1161,33 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
 
     seg_begin(BTS_SEG_STEP);
     seg_begin(BTS_SEG_PREP);
-    LAUNCH(tk_front, dim3(1 + (d.filter ? mc : 0)), dim3(1024));
+    LAUNCH(tk_front, dim3(FRONT_JOBS + (d.filter ? mc : 0)), dim3(1024));
     seg_end(BTS_SEG_PREP);
-    seg_begin(BTS_SEG_PREDICT);
-    fork(s2, 0);                                    // Kalman predict runs next to the appearance pre-filter
-    LAUNCH_ON(s2, tk_predict, dim3(kf_blocks), dim3(256));
-    seg_end(BTS_SEG_PREDICT);
     const bool dense = !d.filter || d.record;
     // split-K factor of the pre-filter: small problems have too few 128x128 tiles to fill 256 CUs
     int split = 1;
+    const int ftiles = bts_cdiv(T, FBM) * bts_cdiv(mc, FBN);
     {
-        const int tiles = bts_cdiv(T, FBM) * bts_cdiv(mc, FBN), kt_all = bts_cdiv(d.D, FBK);
-        while (tiles * split < 256 && split * 2 <= kt_all && split < 16) split *= 2;
+        const int kt_all = bts_cdiv(d.D, FBK);
+        while (ftiles * split < 256 && split * 2 <= kt_all && split < 16) split *= 2;
     }
-    const dim3 filt_grid(bts_cdiv(T, FBM) * bts_cdiv(mc, FBN), split);
+    const int accum = split > 1;
     // ---- first association: pool x high-score detections
     seg_begin(BTS_SEG_COS1);
+    if (d.filter) {
+        // Kalman predict rides in the pre-filter's launch (independent work, consecutive workgroups)
+        seg_begin(BTS_SEG_K_FILTER);
+        LAUNCH(k_filter<false>, dim3(ftiles * split + kf_blocks), dim3(256), mc, ftiles, split, accum);
+        seg_end(BTS_SEG_K_FILTER);
+        if (d.Df) {
+            const int fsplit = split < bts_cdiv(d.Df, FBK) ? split : bts_cdiv(d.Df, FBK);
+            LAUNCH(k_filter<true>, dim3(ftiles * fsplit), dim3(256), mc, ftiles, fsplit, accum);
+        }
+    } else {
+        seg_begin(BTS_SEG_PREDICT);
+        LAUNCH(tk_predict, dim3(kf_blocks), dim3(256));
+        seg_end(BTS_SEG_PREDICT);
+    }
     if (dense) {
         rc = bts_cos_enqueue(cos_kernel, d.body_curr, d.pool_slot, d.D, feats, d.hi_idx, d.D, d.D, d.hdr + H_DIMS1, T, mc,
                              d.sim, M, s);
@@ -1092,27 +1198,14 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
             if (rc) return rc;
         }
     }
-    if (d.filter) {
-        seg_begin(BTS_SEG_K_FILTER);
-        LAUNCH(k_filter<false>, filt_grid, dim3(256), lap[0], mc);
-        seg_end(BTS_SEG_K_FILTER);
-        if (split > 1) { LAUNCH(k_filter_scan<false>, tile_grid, dim3(CT_COLS)); }
-        if (d.Df) {
-            const int fsplit = split < bts_cdiv(d.Df, FBK) ? split : bts_cdiv(d.Df, FBK);
-            LAUNCH(k_filter<true>, dim3(filt_grid.x, fsplit), dim3(256), lap[0], mc);
-            if (fsplit > 1) { LAUNCH(k_filter_scan<true>, tile_grid, dim3(CT_COLS)); }
-        }
-        LAUNCH(k_refine, dim3(bts_cdiv(mc, 2) < 1024 ? bts_cdiv(mc, 2) : 1024), dim3(256), lap[0]);
-    }
     seg_end(BTS_SEG_COS1);
-    join(s2, 1);
     seg_begin(BTS_SEG_COST1);
     seg_begin(BTS_SEG_K_EDGES1);
     if (d.filter) {
-        LAUNCH((tk_edges<1, 1>), tile_grid, dim3(CT_COLS), lap[0]);
-        if (d.record) { LAUNCH((tk_edges<1, 2>), tile_grid, dim3(CT_COLS), lap[0]); }
+        LAUNCH((tk_edges<1, 1>), dim3(ntile1), dim3(CT_COLS), lap[0], accum);
+        if (d.record) { LAUNCH((tk_edges<1, 2>), tile_grid, dim3(CT_COLS), lap[0], 0); }
     } else {
-        LAUNCH((tk_edges<1, 0>), tile_grid, dim3(CT_COLS), lap[0]);
+        LAUNCH((tk_edges<1, 0>), tile_grid, dim3(CT_COLS), lap[0], 0);
     }
     seg_end(BTS_SEG_K_EDGES1);
     seg_end(BTS_SEG_COST1);
@@ -1121,65 +1214,51 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
                                {lap[1], d.hdr + H_DIMS2, T, mc, d.match2, d.x2, d.y2, 1},
                                {lap[2], d.hdr + H_DIMS3, T, mc, d.match3, d.x3, d.y3, 1}};
     {
-        hipEvent_t ev4[4];
-        const bool want = prof_room && (t->prof_seg == BTS_SEG_K_LAP_PREPARE || t->prof_seg == BTS_SEG_K_LAP_SOLVE);
-        if (want) {   // only the selected pair is kept; the other two land on a scratch pair at the ring's end
-            hipEvent_t *keep = &t->prof_ev[2 * t->prof_n], *junk = &t->prof_ev[2 * t->prof_cap];
-            const bool prep = t->prof_seg == BTS_SEG_K_LAP_PREPARE;
-            ev4[0] = prep ? keep[0] : junk[0]; ev4[1] = prep ? keep[1] : junk[1];
-            ev4[2] = prep ? junk[0] : keep[0]; ev4[3] = prep ? junk[1] : keep[1];
-        }
-        rc = bts_lap_enqueue(&prob[0], 1, s, want ? ev4 : nullptr);
+        hipEvent_t ev2[2];
+        const bool want = prof_room && t->prof_seg == BTS_SEG_K_LAP;
+        if (want) { ev2[0] = t->prof_ev[2 * t->prof_n]; ev2[1] = t->prof_ev[2 * t->prof_n + 1]; }
+        rc = bts_lap_enqueue(&prob[0], 1, s, want ? ev2 : nullptr);
         if (rc) return rc;
         if (want) t->prof_n++;
     }
     seg_end(BTS_SEG_LAP1);
     seg_begin(BTS_SEG_APPLY1);
-    LAUNCH(tk_mid1, dim3(1 + mc), dim3(1024));       // stage-2/3 lists read pre-update states: before tk_apply<1>
-    // the stage-1 Kalman updates, the stage-1 feature bookkeeping and the whole of stages 2+3 touch
-    // disjoint tracks: three independent chains
-    fork(s2, 2);
-    fork(s3, 3);
-    seg_begin(BTS_SEG_K_APPLY_KF1);
-    LAUNCH_ON(s2, (tk_apply<1, false>), dim3(kf_blocks), dim3(256));
-    seg_end(BTS_SEG_K_APPLY_KF1);
-    seg_begin(BTS_SEG_K_APPLY_FEAT1);
-    LAUNCH_ON(s3, (tk_apply<1, true>), dim3(T), dim3(256));
-    seg_end(BTS_SEG_K_APPLY_FEAT1);
-    seg_end(BTS_SEG_APPLY1);
-    // ---- second association (remaining tracked rows x low-score detections) and the unconfirmed
-    //      tracks (x leftover high-score detections): independent problems, shared launches
-    seg_begin(BTS_SEG_STAGE2);
+    LAUNCH(tk_mid1, dim3(MID1_JOBS + mc), dim3(1024));       // stage-2/3 lists read pre-update states: before the stage-1 updates
     if (dense) {
         rc = bts_cos_enqueue(cos_kernel, d.body_curr, d.unc_slot, d.D, feats, d.left_det, d.D, d.D, d.hdr + H_DIMS3, T, mc,
                              d.sim, M, s);
         if (rc) return rc;
     }
-    const dim3 tile_grid2(tile_grid.x, 2);
-    if (d.filter) {
-        LAUNCH(tk_edges23<1>, tile_grid2, dim3(CT_COLS), lap[1], lap[2]);
-        if (d.record) { LAUNCH((tk_edges<3, 2>), tile_grid, dim3(CT_COLS), lap[2]); }
-    } else {
-        LAUNCH(tk_edges23<0>, tile_grid2, dim3(CT_COLS), lap[1], lap[2]);
+    // stage-1 Kalman updates + stage-1 feature rows + cost tiles of stages 2 and 3: disjoint tracks, one launch
+    seg_begin(BTS_SEG_K_MID2);
+    {
+        const dim3 g(kf_blocks + T + 2 * ntile);
+        if (d.filter) { LAUNCH(tk_mid2<1>, g, dim3(256), lap[1], lap[2], kf_blocks, T, ntile); }
+        else { LAUNCH(tk_mid2<0>, g, dim3(256), lap[1], lap[2], kf_blocks, T, ntile); }
+        if (d.filter && d.record) { LAUNCH((tk_edges<3, 2>), tile_grid, dim3(CT_COLS), lap[2], 0); }
     }
-    rc = bts_lap_enqueue(&prob[1], 2, s);
+    seg_end(BTS_SEG_K_MID2);
+    seg_end(BTS_SEG_APPLY1);
+    // ---- second association (remaining tracked rows x low-score detections) and the unconfirmed
+    //      tracks (x leftover high-score detections): independent problems, shared launches
+    seg_begin(BTS_SEG_STAGE2);
+    rc = bts_lap_enqueue(&prob[1], 2, s, nullptr);
     if (rc) return rc;
-    LAUNCH(tk_apply23<false>, dim3(kf_blocks, 2), dim3(256));
-    LAUNCH(tk_apply23<true>, dim3(T, 2), dim3(256));
+    seg_begin(BTS_SEG_K_APPLY23);
+    LAUNCH(tk_apply23, dim3(2 * kf_blocks + 2 * T), dim3(256), kf_blocks, T);
+    seg_end(BTS_SEG_K_APPLY23);
     seg_end(BTS_SEG_STAGE2);
-    join(s2, 4);
-    join(s3, 5);
     // ---- births, list merge, duplicate removal
     seg_begin(BTS_SEG_MERGE);
-    LAUNCH(tk_merge, dim3(1), dim3(1024));
-    LAUNCH(tk_birth_init, dim3(mc), dim3(256));
+    LAUNCH(tk_merge, dim3(MERGE_JOBS), dim3(1024));
     seg_end(BTS_SEG_MERGE);
     seg_begin(BTS_SEG_DEDUPE);
     {
         int nd = bts_cdiv(T, CT_COLS) * bts_cdiv(T, CT_ROWS);
-        LAUNCH(tk_dedupe, dim3(nd > 1024 ? 1024 : nd), dim3(CT_COLS));
+        if (nd > 1024) nd = 1024;
+        LAUNCH(tk_tail, dim3(nd + mc), dim3(CT_COLS), nd);
     }
-    LAUNCH(tk_finalize, dim3(1), dim3(1024));
+    LAUNCH(tk_finalize, dim3(2), dim3(1024));
     seg_end(BTS_SEG_DEDUPE);
     seg_end(BTS_SEG_STEP);
 #undef LAUNCH
@@ -1197,14 +1276,15 @@ int bts_tracker_step(bts_tracker *t, const int32_t *boxes, const float *scores, 
     BTS_REQUIRE(m == 0 || (boxes && scores && feats), "null detection arrays");
     BTS_REQUIRE(t->cfg.face_dim == 0 || m == 0 || face_feats, "face_feats required when face_dim > 0");
     hipStream_t s = (hipStream_t)stream;
-    // this frame's descriptor: next slot of the pinned ring (wait if the GPU is a whole ring behind)
-    const int slot = (int)(t->step_no % bts_tracker::RING);
-    if (t->in_used[slot]) BTS_HIP(hipEventSynchronize(t->in_ev[slot]));
-    t->h_in[slot] = InDesc{boxes, scores, feats, face_feats, m, 0};
-    BTS_HIP(hipMemcpyAsync(t->d_in, &t->h_in[slot], sizeof(InDesc), hipMemcpyHostToDevice, s));
     int rc;
     const bool graph = t->cfg.use_graph && t->dv.filter && !t->dv.record && t->prof_cap == 0;
     if (graph) {
+        // this frame's descriptor: next slot of the pinned ring (wait if the GPU is a whole ring behind)
+        const int slot = (int)(t->step_no % bts_tracker::RING);
+        if (t->in_used[slot]) BTS_HIP(hipEventSynchronize(t->in_ev[slot]));
+        t->h_in[slot] = InDesc{boxes, scores, feats, face_feats, m, 0};
+        BTS_HIP(hipMemcpyAsync(t->d_in, &t->h_in[slot], sizeof(InDesc), hipMemcpyHostToDevice, s));
+        t->dv.in = t->d_in;
         if (!t->gexec) {       // capture once, with capacity-sized grids, on the private streams
             hipGraph_t g = nullptr;
             BTS_HIP(hipStreamBeginCapture(t->cs[0], hipStreamCaptureModeRelaxed));
@@ -1216,12 +1296,14 @@ int bts_tracker_step(bts_tracker *t, const int32_t *boxes, const float *scores, 
             BTS_HIP(hipGraphDestroy(g));
         }
         BTS_HIP(hipGraphLaunch(t->gexec, s));
+        BTS_HIP(hipEventRecord(t->in_ev[slot], s));
+        t->in_used[slot] = true;
     } else {
+        t->dv.in = nullptr;
+        t->dv.iv = InDesc{boxes, scores, feats, face_feats, m, 0};
         rc = enqueue_step(t, s, feats, face_feats, m > 0 ? m : 1, false);
         if (rc) return rc;
     }
-    BTS_HIP(hipEventRecord(t->in_ev[slot], s));
-    t->in_used[slot] = true;
     t->step_no++;
     return BTS_OK;
 }

@@ -324,8 +324,8 @@ class DeviceTracker:
                 "cost": cost}
 
     SEGMENTS = {"prep": 0, "predict": 1, "cos1": 2, "cost1": 3, "lap1": 4, "apply1": 5, "stage2": 6, "stage3": 7,
-                "merge": 8, "dedupe": 9, "k_filter": 20, "k_lap_prepare": 21, "k_lap_solve": 22, "k_edges1": 23,
-                "k_apply_kf1": 24, "k_apply_feat1": 25, "step": 100}
+                "merge": 8, "dedupe": 9, "k_filter": 20, "k_lap": 21, "k_edges1": 23, "k_mid2": 24, "k_apply23": 25,
+                "step": 100}
 
     def profile_enable(self, segment: str, capacity: int):
         _lib.check(self._lib.bts_tracker_profile_enable(self.handle, self.SEGMENTS[segment], int(capacity)))

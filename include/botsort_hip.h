@@ -238,8 +238,9 @@ enum bts_segment {
     BTS_SEG_PREP = 0, BTS_SEG_PREDICT = 1, BTS_SEG_COS1 = 2, BTS_SEG_COST1 = 3, BTS_SEG_LAP1 = 4, BTS_SEG_APPLY1 = 5,
     BTS_SEG_STAGE2 = 6, BTS_SEG_STAGE3 = 7, BTS_SEG_MERGE = 8, BTS_SEG_DEDUPE = 9,
     /* single kernels */
-    BTS_SEG_K_FILTER = 20, BTS_SEG_K_LAP_PREPARE = 21, BTS_SEG_K_LAP_SOLVE = 22, BTS_SEG_K_EDGES1 = 23,
-    BTS_SEG_K_APPLY_KF1 = 24, BTS_SEG_K_APPLY_FEAT1 = 25,
+    BTS_SEG_K_FILTER = 20 /* pre-filter GEMM + Kalman predict */, BTS_SEG_K_LAP = 21 /* stage-1 assignment */,
+    BTS_SEG_K_EDGES1 = 23 /* stage-1 cost tiles + exact refine */, BTS_SEG_K_MID2 = 24 /* stage-1 updates + stage-2/3 tiles */,
+    BTS_SEG_K_APPLY23 = 25,
     BTS_SEG_STEP = 100
 };
 int bts_tracker_profile_enable(bts_tracker *trk, int segment, int capacity);
