@@ -67,4 +67,55 @@ __device__ __forceinline__ int compact(int L, int *smem, Pred pred, Emit emit) {
     return total;
 }
 
+// Ordered compaction with a payload, wave-strided: wavefront w owns the contiguous index range
+// [w * chunk, (w + 1) * chunk) and walks it 64 indices at a time, lane-strided, so that
+//   * every load of the selection step is coalesced and independent of the others (one memory
+//     latency for the whole pass instead of one per element),
+//   * positions come from ballots (no per-element scan), and the payload `load` fetched travels in
+//     registers to `emit` (no second, dependent read).
+// load(k, v) -> keep?, may set v;  emit(position, k, v).  Up to 16 rounds per wavefront (L <= 16 * 64 *
+// waves, i.e. 16384 at 1024 threads); longer inputs take the chunk-per-thread form above.
+template <int R, class Load, class Emit>
+__device__ __forceinline__ int compact_ws_r(int L, int chunk, int *smem, Load load, Emit emit) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int base = wid * chunk;
+    int val[R];
+    unsigned long long bal[R];
+    int cnt = 0;
+    // no branches around the loads: all R of them are in flight together (out-of-range lanes re-read index 0)
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const int k = base + j * 64 + lane;
+        const bool inb = j * 64 < chunk && k < L;
+        val[j] = 0;
+        const bool keep = load(inb ? k : 0, val[j]);
+        bal[j] = __ballot(inb && keep);
+        cnt += __popcll(bal[j]);
+    }
+    __syncthreads();                       // smem may still be read from a previous call
+    if (lane == 0) smem[wid] = cnt;
+    __syncthreads();
+    int pos = 0, total = 0;
+    for (int w = 0; w < nw; ++w) { const int c = smem[w]; if (w < wid) pos += c; total += c; }
+    const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        if ((bal[j] >> lane) & 1ull) emit(pos + __popcll(bal[j] & below), base + j * 64 + lane, val[j]);
+        pos += __popcll(bal[j]);
+    }
+    __syncthreads();
+    return total;
+}
+
+template <class Load, class Emit>
+__device__ __forceinline__ int compact_ws(int L, int *smem, Load load, Emit emit) {
+    const int nw = blockDim.x >> 6;
+    const int chunk = ((L + nw - 1) / nw + 63) & ~63, rounds = chunk >> 6;
+    if (L <= 0) return 0;
+    if (rounds <= 1) return compact_ws_r<1>(L, chunk, smem, load, emit);
+    if (rounds <= 4) return compact_ws_r<4>(L, chunk, smem, load, emit);
+    if (rounds <= 16) return compact_ws_r<16>(L, chunk, smem, load, emit);
+    return compact(L, smem, [&](int k) { int v = 0; return load(k, v); }, [&](int p, int k) { int v = 0; (void)load(k, v); emit(p, k, v); });
+}
+
 }  // namespace bscan

@@ -75,8 +75,8 @@ struct Dev {
 #define IN(d, f) ((d).in ? (d).in->f : (d).iv.f)
 
 // ---- single-workgroup helpers: bscan::exscan / bscan::compact (block_scan.h) ------------------------
-template <class Pred, class Emit>
-__device__ __forceinline__ int block_compact(int L, int32_t *tmp, Pred pred, Emit emit) { return bscan::compact(L, tmp, pred, emit); }
+template <class Load, class Emit>
+__device__ __forceinline__ int block_compact(int L, int32_t *tmp, Load load, Emit emit) { return bscan::compact_ws(L, tmp, load, emit); }
 __device__ __forceinline__ int block_exscan_i(int v, int32_t *tmp, int *total) { return bscan::exscan(v, tmp, total); }
 
 __device__ __forceinline__ void load_state(const Dev &d, int slot, double m[8], double P[64]) {
@@ -122,8 +122,8 @@ __device__ __forceinline__ void prep_pool(const Dev &d) {
     const int tid = threadIdx.x, nth = blockDim.x;
     const int nt = h[H_NTRACKED], nl = h[H_NLOST];
     if (tid == 0) s_allf32 = 1;
-    const int nconf = block_compact(nt, tmp, [&](int k) { return d.is_activated[d.tracked[k]] != 0; },
-                                    [&](int p, int k) { d.pool_slot[p] = d.tracked[k]; });
+    const int nconf = block_compact(nt, tmp, [&](int k, int &s) { s = d.tracked[k]; return d.is_activated[s] != 0; },
+                                    [&](int p, int k, int s) { d.pool_slot[p] = s; });
     for (int k = tid; k < nl; k += nth) d.pool_slot[nconf + k] = d.lost[k];
     const int N = nconf + nl;
     __syncthreads();
@@ -144,8 +144,8 @@ __device__ __forceinline__ void prep_unconfirmed(const Dev &d) {
     __shared__ int32_t tmp[1024];
     int32_t *h = d.hdr;
     const int nt = h[H_NTRACKED];
-    const int nunc = block_compact(nt, tmp, [&](int k) { return d.is_activated[d.tracked[k]] == 0; },
-                                   [&](int p, int k) { const int s = d.tracked[k]; d.unc_slot[p] = s; d.flag[s] = 0; });
+    const int nunc = block_compact(nt, tmp, [&](int k, int &s) { s = d.tracked[k]; return d.is_activated[s] == 0; },
+                                   [&](int p, int k, int s) { d.unc_slot[p] = s; d.flag[s] = 0; });
     if (threadIdx.x == 0) { h[H_NUNC] = nunc; h[H_DIMS3] = nunc; }
 }
 
@@ -164,10 +164,10 @@ __device__ __forceinline__ void prep_dets(const Dev &d) {
         d.det_xywh[j * 4 + 0] = tx + w / 2; d.det_xywh[j * 4 + 1] = ty + hh / 2;                     // D:663-670
         d.det_xywh[j * 4 + 2] = w; d.det_xywh[j * 4 + 3] = hh;
     }
-    const int nhi = block_compact(m, tmp, [&](int j) { return (double)scores[j] > d.high; },
-                                  [&](int p, int j) { d.hi_idx[p] = j; });
-    const int nlo = block_compact(m, tmp, [&](int j) { const double s = (double)scores[j]; return s <= d.high && s >= d.low; },
-                                  [&](int p, int j) { d.lo_idx[p] = j; });
+    const int nhi = block_compact(m, tmp, [&](int j, int &) { return (double)scores[j] > d.high; },
+                                  [&](int p, int j, int) { d.hi_idx[p] = j; });
+    const int nlo = block_compact(m, tmp, [&](int j, int &) { const double s = (double)scores[j]; return s <= d.high && s >= d.low; },
+                                  [&](int p, int j, int) { d.lo_idx[p] = j; });
     if (tid < 3 * BTS_LAP_HDR_INTS) d.lap_hdr[tid] = 0;
     if (tid == 0) {
         h[H_NHI] = nhi; h[H_NLO] = nlo; h[H_NDETS] = m;
@@ -188,16 +188,17 @@ __device__ __forceinline__ void prep_free(const Dev &d) {
     for (int k = tid; k < nt; k += nth) d.in_use[d.tracked[k]] = 1;
     for (int k = tid; k < nl; k += nth) d.in_use[d.lost[k]] = 1;
     __syncthreads();
-    const int nfree = block_compact(d.T, tmp, [&](int s) { return !d.in_use[s]; }, [&](int p, int s) { d.free_list[p] = s; });
+    const int nfree = block_compact(d.T, tmp, [&](int s, int &) { return !d.in_use[s]; }, [&](int p, int s, int) { d.free_list[p] = s; });
     if (tid == 0) h[H_NFREE] = nfree;
 }
 
 // ---- K2: STrack.multi_predict over the pool (D:524-536 + D:265-302) ---------------------------------
 // float16 shadows + norms of this frame's (raw) detection rows for the appearance pre-filter
-__device__ __forceinline__ void cvt_body(const Dev &d, long j) {
-    if (j >= IN(d, m)) return;
-    feat::to_half_row(IN(d, feats) + j * d.D, d.det_h + j * d.D, d.det_n + j, d.D);
-    if (d.Df) feat::to_half_row(IN(d, face_feats) + j * d.Df, d.dface_h + j * d.Df, d.dface_n + j, d.Df);
+__device__ __forceinline__ void cvt_body(const Dev &d, long blk) {        // four rows per 1024-thread workgroup
+    const long j = blk * 4 + feat::row_group();
+    const bool on = j < IN(d, m);
+    feat::to_half_row(IN(d, feats) + j * d.D, d.det_h + j * d.D, d.det_n + j, d.D, on);
+    if (d.Df) feat::to_half_row(IN(d, face_feats) + j * d.Df, d.dface_h + j * d.Df, d.dface_n + j, d.Df, on);
 }
 
 // one launch: workgroups 0-3 build the frame's lists, the others convert the detection rows
@@ -439,6 +440,41 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
 }
 
+// epilogue of the pre-filter tiles: candidate test (or split-K accumulation) of a 128 x 128 accumulator tile;
+// the tile's row/column norms go through LDS (`snorm`: 256 floats, the operand tiles are dead by now)
+template <bool FACE>
+__device__ __forceinline__ void filter_epilogue(const Dev &d, f32x16 (&acc)[2][2], float *snorm, int bm, int bn, int n, int m, int accum) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid >> 1, wc = wid & 1;
+    const int frow = lane & 31, fh = lane >> 5;
+    const float *na = FACE ? d.face_n : d.body_n, *nb = FACE ? d.dface_n : d.det_n;
+    const float eps = FACE ? d.eps_face : d.eps_body, gate = 1.0f - d.app;
+    float *approx = FACE ? d.approx_f : d.approx;
+    __syncthreads();
+    if (!accum) {
+        const int g = tid < FBM ? bm * FBM + tid : bn * FBN + (tid - FBM);
+        float v = 0.0f;
+        if (tid < FBM) { if (g < n) v = na[d.pool_slot[g]]; }
+        else if (g < m) v = nb[d.hi_idx[g]];
+        snorm[tid] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int qq = wc * 64 + ni * 32 + frow, q = bn * FBN + qq;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ii = wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh, i = bm * FBM + ii;
+                const float val = acc[mi][ni][r] * feat::HALF_UNSCALE;
+                if (!(i < n && q < m)) continue;
+                if (accum) atomicAdd(&approx[(long)i * d.Mx + q], val);
+                else if (is_candidate(val, snorm[ii], snorm[FBM + qq], gate, eps))      // rare: about one per detection column
+                    atomicOr(&d.cbits[(long)i * d.cb_ld + (q >> 5)], 1u << (q & 31));
+            }
+        }
+}
+
 // Grid: ntiles * nsplit GEMM workgroups (tile-major inside a K split), followed -- body pass only --
 // by the workgroups of the Kalman predict, which is independent of the contraction and shares the launch.
 // accum: add the partial products into `approx` (split K; the stage-1 tile kernel applies the
@@ -526,45 +562,144 @@ __global__ __launch_bounds__(256) void k_filter(Dev d, int m_max, int ntiles, in
         __syncthreads();
         cur ^= 1;
     }
-    // epilogue: the tile's row/column norms go through LDS (the operand tiles are dead now)
-    const float *na = FACE ? d.face_n : d.body_n, *nb = FACE ? d.dface_n : d.det_n;
-    const float eps = FACE ? d.eps_face : d.eps_body, gate = 1.0f - d.app;
-    float *approx = FACE ? d.approx_f : d.approx;
-    __syncthreads();
-    float *snorm = reinterpret_cast<float *>(As2[0]);      // [0,128): rows, [128,256): columns
-    if (!accum) {
-        const int g = tid < FBM ? bm * FBM + tid : bn * FBN + (tid - FBM);
-        float v = 0.0f;
-        if (tid < FBM) { if (g < n) v = na[d.pool_slot[g]]; }
-        else if (g < m) v = nb[d.hi_idx[g]];
-        snorm[tid] = v;
+    filter_epilogue<FACE>(d, acc, reinterpret_cast<float *>(&As2[0][0]), bm, bn, n, m, accum);
+}
+
+// The same contraction with the operand tiles travelling HBM -> LDS directly (global_load_lds, 16 B per
+// lane: no staging registers, no ds_write pass) through a ring of DNS stages of DBK = 32 halves, so that
+// DNS - 1 stages (48 KiB per workgroup, two workgroups per CU) are in flight while one is multiplied:
+// a stage needs ~2 us to arrive when part of it misses the L2, a single prefetched stage does not cover that.
+//   * the LDS image of such a load is lane-linear, so a tile is stored as unpadded 64-byte rows and the
+//     bank spread comes from the SOURCE side: lane (row, c) fetches 16-byte chunk c ^ swz(row) of its row
+//     and the fragment reads undo the permutation; swz(row) = (row >> 2) & 3 makes every ds_read_b128
+//     lane group hit 16 distinct 16-byte slots (0 bank conflicts measured);
+//   * one workgroup barrier per stage, preceded by a COUNTED s_waitcnt vmcnt (only the oldest stage has
+//     to have landed) -- __syncthreads would drain the whole ring.
+// Needs feat_dim % 32 == 0 (no K tail); the register-staged k_filter covers the rest.
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+constexpr int DBK = 32, DNS = 4;
+
+template <int N> __device__ __forceinline__ void wait_stage_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+// Fragment reads of the ring are issued as inline assembly: for a ds_read it can see, the compiler
+// drains EVERY outstanding LDS-DMA load first (it cannot tell the ring's stages apart), which would
+// serialise the pipeline.  The explicit lgkmcnt wait below takes the fragments as operands so that no
+// MFMA can be scheduled above it.
+typedef int v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4i lds_read16(unsigned addr) {
+    v4i v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+template <int N> __device__ __forceinline__ void lds_wait(v4i &a, v4i &b, v4i &c, v4i &e) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(e) : "n"(N));
+}
+
+template <bool FACE>
+__global__ __launch_bounds__(256) void k_filter_dma(Dev d, int m_max, int ntiles, int nsplit, int accum) {
+    __shared__ __attribute__((aligned(1024))) _Float16 As2[DNS][FBM * DBK];
+    __shared__ __attribute__((aligned(1024))) _Float16 Bs2[DNS][FBN * DBK];
+    if ((int)blockIdx.x >= ntiles * nsplit) {
+        if (!FACE) predict_body(d, (int)blockIdx.x - ntiles * nsplit);
+        return;
     }
-    __syncthreads();
+    const int n = d.hdr[H_NPOOL], m = d.hdr[H_NHI];
+    const int Dd = FACE ? d.Df : d.D;
+    const _Float16 *A = FACE ? d.face_h : d.body_h, *B = FACE ? d.dface_h : d.det_h;
+    const int nbn = (m_max + FBN - 1) / FBN;
+    const int ksplit = blockIdx.x / ntiles;
+    const int vb = xcd_remap(blockIdx.x % ntiles, ntiles);
+    const int bm = vb / nbn, bn = vb % nbn;
+    if (bm * FBM >= n || bn * FBN >= m) return;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid >> 1, wc = wid & 1;
+    const int kt_all = Dd / DBK, kt_per = (kt_all + nsplit - 1) / nsplit;
+    const int kt0 = ksplit * kt_per, kt1 = min(kt_all, kt0 + kt_per);
+    if (kt0 >= kt1) return;
+
+    // piece s of a stage = rows [(4 s + wid) * 16, +16): one 1-KiB wavefront load, lane -> (row, 16-byte chunk)
+    const int prow = lane >> 2, pchunk = lane & 3;
+    const _Float16 *asrc[2], *bsrc[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int r = (4 * s + wid) * 16 + prow;
+        const int i = bm * FBM + r, j = bn * FBN + r;
+        const int sw = (pchunk ^ ((r >> 2) & 3)) * 8;
+        asrc[s] = A + (long)d.pool_slot[i < n ? i : bm * FBM] * Dd + sw;       // rows past the end: any valid row, ignored later
+        bsrc[s] = B + (long)d.hi_idx[j < m ? j : bn * FBN] * Dd + sw;
+    }
+    auto stage = [&](int buf, int kt) {                  // 4 wavefront loads per stage and wave
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            __builtin_amdgcn_global_load_lds((gbl_void *)(asrc[s] + kt * DBK), (lds_void *)&As2[buf][(4 * s + wid) * 16 * DBK], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void *)(bsrc[s] + kt * DBK), (lds_void *)&Bs2[buf][(4 * s + wid) * 16 * DBK], 16, 0, 0);
+        }
+    };
+    f32x16 acc[2][2];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int qq = wc * 64 + ni * 32 + frow, q = bn * FBN + qq;
+        for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ii = wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh, i = bm * FBM + ii;
-                const float val = acc[mi][ni][r] * feat::HALF_UNSCALE;
-                if (!(i < n && q < m)) continue;
-                if (accum) atomicAdd(&approx[(long)i * d.Mx + q], val);
-                else if (is_candidate(val, snorm[ii], snorm[FBM + qq], gate, eps))      // rare: about one per detection column
-                    atomicOr(&d.cbits[(long)i * d.cb_ld + (q >> 5)], 1u << (q & 31));
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+    const int frow = lane & 31, fh = lane >> 5;
+    const unsigned lds_a = (unsigned)(__UINTPTR_TYPE__)(lds_void *)&As2[0][0], lds_b = (unsigned)(__UINTPTR_TYPE__)(lds_void *)&Bs2[0][0];
+    int aoff[2], boff[2], asw[2], bsw[2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+        const int ra = wr * 64 + x * 32 + frow, rb = wc * 64 + x * 32 + frow;
+        aoff[x] = ra * DBK; asw[x] = (ra >> 2) & 3;
+        boff[x] = rb * DBK; bsw[x] = (rb >> 2) & 3;
+    }
+#pragma unroll
+    for (int s = 0; s < DNS - 1; ++s)
+        if (kt0 + s < kt1) stage(s, kt0 + s);
+    int cur = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        // stage kt has landed once at most the (up to DNS-2) younger stages are still in flight
+        const int younger = min(DNS - 2, kt1 - 1 - kt);
+        if (younger >= 2) wait_stage_barrier<8>();
+        else if (younger == 1) wait_stage_barrier<4>();
+        else wait_stage_barrier<0>();
+        // every wave is past its reads of the buffer of stage kt-1: refill it with stage kt+DNS-1
+        if (kt + DNS - 1 < kt1) stage(cur == 0 ? DNS - 1 : cur - 1, kt + DNS - 1);
+        const unsigned abase = lds_a + cur * (FBM * DBK * 2), bbase = lds_b + cur * (FBN * DBK * 2);
+        v4i fa[DBK / 16][2], fb[DBK / 16][2];
+#pragma unroll
+        for (int t = 0; t < DBK / 16; ++t) {
+            const int c = t * 2 + fh;
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                fa[t][x] = lds_read16(abase + ((aoff[x] + ((c ^ asw[x]) << 3)) << 1));
+                fb[t][x] = lds_read16(bbase + ((boff[x] + ((c ^ bsw[x]) << 3)) << 1));
             }
         }
+#pragma unroll
+        for (int t = 0; t < DBK / 16; ++t) {
+            if (t == 0) lds_wait<4>(fa[t][0], fa[t][1], fb[t][0], fb[t][1]);      // reads retire in order: 4 younger ones may be pending
+            else lds_wait<0>(fa[t][0], fa[t][1], fb[t][0], fb[t][1]);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, fa[t][mi]), __builtin_bit_cast(half8, fb[t][ni]),
+                                                                         acc[mi][ni], 0, 0, 0);
+        }
+        cur = cur + 1 == DNS ? 0 : cur + 1;
+    }
+    filter_epilogue<FACE>(d, acc, reinterpret_cast<float *>(&As2[0][0]), bm, bn, n, m, accum);
 }
 
 // ---- detection feature rows: in-place renormalisation (quirk Q8) ------------------------------------------
-__device__ __forceinline__ void renorm_body(const Dev &d, int q) {
+__device__ __forceinline__ void renorm_body(const Dev &d, int blk) {        // four rows per 1024-thread workgroup
     const int32_t *h = d.hdr;
     const int nhi = h[H_NHI], nlo = h[H_NLO];
-    if (q >= nhi + nlo) return;
-    const long det = q < nhi ? d.hi_idx[q] : d.lo_idx[q - nhi];
-    feat::renorm_row(IN(d, feats) + det * d.D, d.D);
-    if (d.Df) feat::renorm_row(IN(d, face_feats) + det * d.Df, d.Df);
+    const int q = blk * 4 + feat::row_group();
+    const bool on = q < nhi + nlo;
+    const long det = !on ? 0 : q < nhi ? d.hi_idx[q] : d.lo_idx[q - nhi];
+    feat::renorm_row(IN(d, feats) + det * d.D, d.D, on);
+    if (d.Df) feat::renorm_row(IN(d, face_feats) + det * d.Df, d.Df, on);
 }
 
 // ---- match application (D:570-610).  FEAT=false: Kalman update + lifecycle, one thread per row with
@@ -663,16 +798,16 @@ __device__ __forceinline__ void after1_body(const Dev &d, int job) {
         // r_tracked: unmatched pool rows that are still Tracked (D:1569).  Matched rows are set to
         // Tracked by the stage-1 update, which runs after this launch: the state test sees pre-frame state.
         const int N = h[H_NPOOL];
-        const int nr2 = block_compact(N, tmp, [&](int r) { return d.x1[r] < 0 && d.state[d.pool_slot[r]] == BTS_TRACKED; },
-                                      [&](int p, int r) {
-                                          d.r2_row[p] = r; d.r2_slot[p] = d.pool_slot[r];
+        const int nr2 = block_compact(N, tmp, [&](int r, int &s) { s = d.pool_slot[r]; return d.x1[r] < 0 && d.state[s] == BTS_TRACKED; },
+                                      [&](int p, int r, int s) {
+                                          d.r2_row[p] = r; d.r2_slot[p] = s;
                                           for (int c = 0; c < 4; ++c) d.r2_tlbr[p * 4 + c] = d.pool_tlbr[r * 4 + c];
                                       });
         if (threadIdx.x == 0) { h[H_NR2] = nr2; h[H_DIMS2] = nr2; }
     } else if (job == 1) {
         const int nhi = h[H_NHI];
-        const int nleft = block_compact(nhi, tmp, [&](int q) { return d.y1[q] < 0; },
-                                        [&](int p, int q) { d.left_hi[p] = q; d.left_det[p] = d.hi_idx[q]; });
+        const int nleft = block_compact(nhi, tmp, [&](int q, int &det) { det = d.hi_idx[q]; return d.y1[q] < 0; },
+                                        [&](int p, int q, int det) { d.left_hi[p] = q; d.left_det[p] = det; });
         if (threadIdx.x == 0) { h[H_NLEFT] = nleft; h[H_DIMS3 + 1] = nleft; }
     } else {
         const int nunc = h[H_NUNC];
@@ -719,10 +854,10 @@ __global__ __launch_bounds__(1024) void tk_merge(Dev d) {
         for (int k = tid; k < nleft; k += nth) d.born_slot[k] = -1;
         __syncthreads();
         const int nborn_want = block_compact(
-            nleft, tmp, [&](int k) { return d.y3[k] < 0 && !((double)scores[d.left_det[k]] < d.new_thr); },
-            [&](int b, int k) {
+            nleft, tmp, [&](int k, int &det) { det = d.left_det[k]; return d.y3[k] < 0 && !((double)scores[det] < d.new_thr); },
+            [&](int b, int k, int det) {
                 if (b >= nfree) return;
-                const int s = d.free_list[b], det = d.left_det[k];
+                const int s = d.free_list[b];
                 d.born_slot[k] = s;
                 d.tracked2[d.T + b] = s;                         // births keep detection order
                 d.track_id[s] = last_id + 1 + b;
@@ -747,19 +882,19 @@ __global__ __launch_bounds__(1024) void tk_merge(Dev d) {
         }
     } else if (blockIdx.x == 1) {
         const int nt = h[H_NTRACKED];
-        const int n_keep = block_compact(nt, tmp, [&](int k) { return d.state[d.tracked[k]] == BTS_TRACKED; },
-                                         [&](int p, int k) { d.tracked2[p] = d.tracked[k]; });
+        const int n_keep = block_compact(nt, tmp, [&](int k, int &s) { s = d.tracked[k]; return d.state[s] == BTS_TRACKED; },
+                                         [&](int p, int k, int s) { d.tracked2[p] = s; });
         if (tid == 0) h[H_NKEEP] = n_keep;
     } else if (blockIdx.x == 2) {
         const int N = h[H_NPOOL];
-        const int n_rf = block_compact(N, tmp, [&](int r) { return (d.flag[d.pool_slot[r]] & F_REFIND) != 0; },
-                                       [&](int p, int r) { d.tracked2[2 * d.T + p] = d.pool_slot[r]; });
+        const int n_rf = block_compact(N, tmp, [&](int r, int &s) { s = d.pool_slot[r]; return (d.flag[s] & F_REFIND) != 0; },
+                                       [&](int p, int r, int s) { d.tracked2[2 * d.T + p] = s; });
         if (tid == 0) h[H_NRF] = n_rf;
     } else if (blockIdx.x == 3) {
         const int nl = h[H_NLOST], nunc = h[H_NUNC];
         const int n_l0 = block_compact(nl, tmp,
-                                       [&](int k) { const int s = d.lost[k]; return d.state[s] != BTS_TRACKED && !d.in_removed[s]; },
-                                       [&](int p, int k) { d.lost2[p] = d.lost[k]; });
+                                       [&](int k, int &s) { s = d.lost[k]; return d.state[s] != BTS_TRACKED && !d.in_removed[s]; },
+                                       [&](int p, int k, int s) { d.lost2[p] = s; });
         // expiry of lost tracks (D:1623-1627); re-found ones carry frame_id == frame.  removed_stracks.extend(
         // removed_now): the ids (here: slots) are remembered for the next frames -- after the filter above (Q6)
         int gone = 0;
@@ -777,8 +912,8 @@ __global__ __launch_bounds__(1024) void tk_merge(Dev d) {
     } else {
         const int nconf = h[H_NCONF];
         const int n_l1 = block_compact(nconf, tmp,
-                                       [&](int r) { const int s = d.pool_slot[r]; return (d.flag[s] & F_LOSTNOW) && !d.in_removed[s]; },
-                                       [&](int p, int r) { d.lost2[d.T + p] = d.pool_slot[r]; });
+                                       [&](int r, int &s) { s = d.pool_slot[r]; return (d.flag[s] & F_LOSTNOW) && !d.in_removed[s]; },
+                                       [&](int p, int r, int s) { d.lost2[d.T + p] = s; });
         if (tid == 0) h[H_NL1] = n_l1;
     }
 }
@@ -864,12 +999,12 @@ __global__ __launch_bounds__(1024) void tk_finalize(Dev d) {
     const int tid = threadIdx.x, nth = blockDim.x;
     if (blockIdx.x == 0) {
         const int nt2 = h[H_NKEEP] + h[H_NB] + h[H_NRF];
-        const int nt = block_compact(nt2, tmp, [&](int k) { return !d.drop_t[k]; }, [&](int p, int k) { d.tracked[p] = tracked2_at(d, k); });
+        const int nt = block_compact(nt2, tmp, [&](int k, int &s) { s = tracked2_at(d, k); return !d.drop_t[k]; }, [&](int p, int k, int s) { d.tracked[p] = s; });
         for (int k = tid; k < nt2; k += nth) d.drop_t[k] = 0;
         if (tid == 0) h[H_NTRACKED] = nt;
     } else {
         const int nl2 = h[H_NL0] + h[H_NL1];
-        const int nl = block_compact(nl2, tmp, [&](int k) { return !d.drop_l[k]; }, [&](int p, int k) { d.lost[p] = lost2_at(d, k); });
+        const int nl = block_compact(nl2, tmp, [&](int k, int &s) { s = lost2_at(d, k); return !d.drop_l[k]; }, [&](int p, int k, int s) { d.lost[p] = s; });
         for (int k = tid; k < nl2; k += nth) d.drop_l[k] = 0;
         if (tid == 0) h[H_NLOST] = nl;
     }
@@ -1161,7 +1296,7 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
 
     seg_begin(BTS_SEG_STEP);
     seg_begin(BTS_SEG_PREP);
-    LAUNCH(tk_front, dim3(FRONT_JOBS + (d.filter ? mc : 0)), dim3(1024));
+    LAUNCH(tk_front, dim3(FRONT_JOBS + (d.filter ? bts_cdiv(mc, 4) : 0)), dim3(1024));
     seg_end(BTS_SEG_PREP);
     const bool dense = !d.filter || d.record;
     // split-K factor of the pre-filter: small problems have too few 128x128 tiles to fill 256 CUs
@@ -1177,11 +1312,13 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
     if (d.filter) {
         // Kalman predict rides in the pre-filter's launch (independent work, consecutive workgroups)
         seg_begin(BTS_SEG_K_FILTER);
-        LAUNCH(k_filter<false>, dim3(ftiles * split + kf_blocks), dim3(256), mc, ftiles, split, accum);
+        if (d.D % DBK == 0) { LAUNCH(k_filter_dma<false>, dim3(ftiles * split + kf_blocks), dim3(256), mc, ftiles, split, accum); }
+        else { LAUNCH(k_filter<false>, dim3(ftiles * split + kf_blocks), dim3(256), mc, ftiles, split, accum); }
         seg_end(BTS_SEG_K_FILTER);
         if (d.Df) {
             const int fsplit = split < bts_cdiv(d.Df, FBK) ? split : bts_cdiv(d.Df, FBK);
-            LAUNCH(k_filter<true>, dim3(ftiles * fsplit), dim3(256), mc, ftiles, fsplit, accum);
+            if (d.Df % DBK == 0) { LAUNCH(k_filter_dma<true>, dim3(ftiles * fsplit), dim3(256), mc, ftiles, fsplit, accum); }
+            else { LAUNCH(k_filter<true>, dim3(ftiles * fsplit), dim3(256), mc, ftiles, fsplit, accum); }
         }
     } else {
         seg_begin(BTS_SEG_PREDICT);
@@ -1223,7 +1360,7 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
     }
     seg_end(BTS_SEG_LAP1);
     seg_begin(BTS_SEG_APPLY1);
-    LAUNCH(tk_mid1, dim3(MID1_JOBS + mc), dim3(1024));       // stage-2/3 lists read pre-update states: before the stage-1 updates
+    LAUNCH(tk_mid1, dim3(MID1_JOBS + bts_cdiv(mc, 4)), dim3(1024));       // stage-2/3 lists read pre-update states: before the stage-1 updates
     if (dense) {
         rc = bts_cos_enqueue(cos_kernel, d.body_curr, d.unc_slot, d.D, feats, d.left_det, d.D, d.D, d.hdr + H_DIMS3, T, mc,
                              d.sim, M, s);
@@ -1255,7 +1392,7 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
     seg_begin(BTS_SEG_DEDUPE);
     {
         int nd = bts_cdiv(T, CT_COLS) * bts_cdiv(T, CT_ROWS);
-        if (nd > 1024) nd = 1024;
+        if (nd > 8192) nd = 8192;
         LAUNCH(tk_tail, dim3(nd + mc), dim3(CT_COLS), nd);
     }
     LAUNCH(tk_finalize, dim3(2), dim3(1024));
