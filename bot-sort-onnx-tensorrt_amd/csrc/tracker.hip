@@ -255,25 +255,52 @@ __device__ __forceinline__ bool is_candidate(float approx, float na, float nb, f
 // MODE 1: pre-filter form -- stage 1 emits the IoU edges only (appearance edges come from
 //         k_filter); stage 3 refines the few overlapping pairs with an exact wavefront dot product.
 // MODE 2: record only (dense cost matrix for inspection, no edges).
-template <int STAGE, int MODE>
+// ROWS = rows of a tile: 16, or 64 for big stage-1 problems (a tile's fixed cost -- its chains of dependent
+// loads -- dominates, the per-row screening is cheap).
+template <int STAGE, int MODE, int ROWS = CT_ROWS>
 __device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, int bx, int by, int accum) {
-    __shared__ double sa[CT_ROWS][4];
-    __shared__ double sarea[CT_ROWS];
-    __shared__ int sflag[CT_ROWS];
-    __shared__ int sslot[CT_ROWS];
-    __shared__ float sna[CT_ROWS], snf[CT_ROWS];
+    __shared__ double sa[ROWS][4];
+    __shared__ double sarea[ROWS];
+    __shared__ int sflag[ROWS];
+    __shared__ int sslot[ROWS];
+    __shared__ float sna[ROWS], snf[ROWS];
+    __shared__ float4 sboxf[ROWS];       // row boxes rounded OUTWARD to float32 (conservative overlap pre-test)
     const int32_t *h = d.hdr;
     const int n = STAGE == 1 ? h[H_NPOOL] : STAGE == 2 ? h[H_NR2] : h[H_NUNC];
     const int m = STAGE == 1 ? h[H_NHI] : STAGE == 2 ? h[H_NLO] : h[H_NLEFT];
-    const int i0 = by * CT_ROWS, q = bx * CT_COLS + threadIdx.x;
+    const int i0 = by * ROWS, q = bx * CT_COLS + threadIdx.x;
     const double *abox = STAGE == 1 ? d.pool_tlbr : STAGE == 2 ? d.r2_tlbr : d.unc_tlbr;
-    if (threadIdx.x < CT_ROWS && i0 + threadIdx.x < n) {
+    // every chain of dependent loads of the tile starts here, before the barrier, so that they overlap:
+    // (1) this thread's detection column, (2) the row boxes, (3) the wavefront's candidate-bitmap words
+    const bool live = q < m;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int det = !live ? 0 : STAGE == 1 ? d.hi_idx[q] : STAGE == 2 ? d.lo_idx[q] : d.left_det[q];
+    __shared__ unsigned long long scw[CT_COLS / 64][ROWS];      // [wave][row]: candidate lanes of the row (stage 1)
+    if (MODE == 1 && STAGE == 1 && !accum) {
+        // the bitmap row segment of this wavefront's 64 columns is one aligned 8-byte word: lane u fetches
+        // row i0 + u's (64 rows per load instruction); consumed and cleared
+        for (int u = lane; u < ROWS; u += 64) {
+            unsigned long long v = 0;
+            if (i0 + u < n && bx * CT_COLS + wid * 64 < d.Mx) {
+                unsigned long long *pw = reinterpret_cast<unsigned long long *>(
+                    &d.cbits[(long)(i0 + u) * d.cb_ld + ((bx * CT_COLS + wid * 64) >> 5)]);
+                v = *pw;
+                if (v) *pw = 0ull;
+            }
+            scw[wid][u] = v;
+        }
+    }
+    const double bb[4] = {d.det_tlbr[det * 4 + 0], d.det_tlbr[det * 4 + 1], d.det_tlbr[det * 4 + 2], d.det_tlbr[det * 4 + 3]};
+    float nbq = 0.0f, nfq = 0.0f;
+    if (STAGE == 1 && MODE == 1 && accum && live) { nbq = d.det_n[det]; if (d.Df) nfq = d.dface_n[det]; }
+    if (threadIdx.x < ROWS && i0 + threadIdx.x < n) {
         const int i = i0 + threadIdx.x;
         double box[4] = {abox[i * 4 + 0], abox[i * 4 + 1], abox[i * 4 + 2], abox[i * 4 + 3]};
         const bool f = STAGE == 3 ? d.unc_f32[i] != 0 : false;
         for (int c = 0; c < 4; ++c) sa[threadIdx.x][c] = box[c];
         sarea[threadIdx.x] = iou::area(box, f);
         sflag[threadIdx.x] = f;
+        sboxf[threadIdx.x] = make_float4(__double2float_rd(box[0]), __double2float_rd(box[1]), __double2float_ru(box[2]), __double2float_ru(box[3]));
         if (STAGE == 1 && MODE == 1) {
             const int s = d.pool_slot[i];
             sslot[threadIdx.x] = s;
@@ -282,16 +309,13 @@ __device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, 
         }
     }
     __syncthreads();
-    const bool live = q < m;
-    const int det = !live ? 0 : STAGE == 1 ? d.hi_idx[q] : STAGE == 2 ? d.lo_idx[q] : d.left_det[q];
-    const double bb[4] = {d.det_tlbr[det * 4 + 0], d.det_tlbr[det * 4 + 1], d.det_tlbr[det * 4 + 2], d.det_tlbr[det * 4 + 3]};
     const double area_b = iou::area(bb, true);
+    const float4 bf = make_float4(__double2float_rd(bb[0]), __double2float_rd(bb[1]), __double2float_ru(bb[2]), __double2float_ru(bb[3]));
     double *cost = STAGE == 1 ? d.cost1 : STAGE == 2 ? d.cost2 : d.cost3;
     const double limit = STAGE == 1 ? d.match1 : STAGE == 2 ? d.match2 : d.match3;
-    const int rows = min(CT_ROWS, n - i0);
-    const int lane = threadIdx.x & 63;
-    float nbq = 0.0f, nfq = 0.0f;
-    if (STAGE == 1 && MODE == 1 && accum && live) { nbq = d.det_n[det]; if (d.Df) nfq = d.dface_n[det]; }
+    const bool all_rows = MODE == 2 || (MODE == 0 && d.record) || !(limit < 1.0);      // every entry of the matrix is wanted
+    const int rows = min(ROWS, n - i0);
+    const unsigned long long livemask = __ballot(live);
     const float gate = 1.0f - d.app;
     // Edges are staged per wavefront in LDS (ballot + lane-prefix, no atomics) and appended to the
     // solver's list with ONE counter bump per flush and coalesced stores: a returning atomic costs a
@@ -299,19 +323,21 @@ __device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, 
     constexpr int EB = 128;
     __shared__ double wb_c[CT_COLS / 64][EB];
     __shared__ int32_t wb_r[CT_COLS / 64][EB], wb_q[CT_COLS / 64][EB];
-    const int wid = threadIdx.x >> 6;
     int wcount = 0;
-    auto flush = [&]() {
-        if (wcount == 0) return;
-        int base = 0;
-        if (lane == 0) base = atomicAdd(&w.hdr[0], wcount);
-        base = __shfl(base, 0);
+    __shared__ int s_wcnt[CT_COLS / 64], s_base;
+    auto flush_at = [&](int base) {
         for (int k = lane; k < wcount; k += 64) {
             const int pos = base + k;
             if (pos < w.e_cap) { w.e_row[pos] = wb_r[wid][k]; w.e_col[pos] = wb_q[wid][k]; w.e_cost[pos] = wb_c[wid][k]; }
             else w.hdr[2] = 1;
         }
         wcount = 0;
+    };
+    auto flush = [&]() {                                  // mid-tile overflow of the staging buffer (rare)
+        if (wcount == 0) return;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&w.hdr[0], wcount);
+        flush_at(__shfl(base, 0));
     };
     auto emit = [&](bool pred, int row, double c) {          // convergent: every lane of the wavefront calls it
         const unsigned long long mk = __ballot(pred);
@@ -323,40 +349,64 @@ __device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, 
         wcount += __popcll(mk);
         if (wcount > EB - 64) flush();
     };
-    // Stage 1, pre-filter form: which pairs of this column could pass the appearance gate was
-    // decided by the float16 contraction (k_filter) -- either its split-K partial sums are complete
-    // in `approx` now, or it left a candidate bitmap.  Both are consumed and cleared here; all 16
-    // rows are fetched up front so that the tile pays one memory latency, not sixteen.
-    uint32_t cmask = 0;
-    if (MODE == 1 && STAGE == 1 && live) {
-        if (accum) {
+    // Rows are handled in chunks of 16.  Stage 1, pre-filter form: which pairs of this column could pass
+    // the appearance gate was decided by the float16 contraction (k_filter) -- either its split-K partial
+    // sums are complete in `approx` now, or it left a candidate bitmap.  Both are consumed and cleared
+    // here; the 16 rows of a chunk are fetched up front so that they cost one memory latency, not sixteen.
+#pragma unroll 1
+    for (int rc = 0; rc < rows; rc += 16) {
+    const int crows = min(16, rows - rc);
+    // split-K form: the candidate lanes of each row of the chunk, as wave-uniform 64-bit lane masks in LDS
+    if (MODE == 1 && STAGE == 1 && accum) {
+        uint32_t cmask = 0;
+        if (live) {
             auto scan = [&](float *acc, const float *srow, float ncol, float eps) {
-                float *p = acc + (long)i0 * d.Mx + q;
-                float av[CT_ROWS];
+                float *p = acc + (long)(i0 + rc) * d.Mx + q;
+                float av[16];
 #pragma unroll
-                for (int r = 0; r < CT_ROWS; ++r) av[r] = r < rows ? p[(long)r * d.Mx] : 0.0f;
+                for (int u = 0; u < 16; ++u) av[u] = u < crows ? p[(long)u * d.Mx] : 0.0f;
 #pragma unroll
-                for (int r = 0; r < CT_ROWS; ++r) {
-                    if (r >= rows) continue;
-                    p[(long)r * d.Mx] = 0.0f;
-                    cmask |= (uint32_t)is_candidate(av[r], srow[r], ncol, gate, eps) << r;
+                for (int u = 0; u < 16; ++u) {
+                    if (u >= crows) continue;
+                    p[(long)u * d.Mx] = 0.0f;
+                    cmask |= (uint32_t)is_candidate(av[u], srow[rc + u], ncol, gate, eps) << u;
                 }
             };
             scan(d.approx, sna, nbq, d.eps_body);
             if (d.Df) scan(d.approx_f, snf, nfq, d.eps_face);
-        } else {
-            uint32_t wd[CT_ROWS];
-#pragma unroll
-            for (int r = 0; r < CT_ROWS; ++r) wd[r] = r < rows ? d.cbits[(long)(i0 + r) * d.cb_ld + (q >> 5)] : 0u;
-#pragma unroll
-            for (int r = 0; r < CT_ROWS; ++r) {
-                cmask |= ((wd[r] >> (q & 31)) & 1u) << r;
-                if (wd[r] && (q & 31) == 0) d.cbits[(long)(i0 + r) * d.cb_ld + (q >> 5)] = 0u;
-            }
         }
+        unsigned long long mine = 0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const unsigned long long bu = __ballot((cmask >> u) & 1u);
+            if (lane == u) mine = bu;
+        }
+        if (lane < 16) scw[wid][(rc + lane) & (ROWS - 1)] = mine;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
+    // The N x M pair tests are the bulk of this kernel's instructions and nearly all pairs are disjoint
+    // boxes without an appearance candidate (cost exactly 1 > limit: no edge).  Which rows hold anything
+    // else for this wavefront is found first, with the chunk's LDS reads in flight together: four float32
+    // comparisons per row on outward-rounded boxes (disjoint there => disjoint exactly); only those
+    // rows are then evaluated exactly in float64.
+    uint32_t work = 0;                                    // wave-uniform: bit u = some lane needs row rc + u
 #pragma unroll 1
-    for (int r = 0; r < rows; ++r) {
+    for (int u0 = 0; u0 < 16; u0 += 8)
+#pragma unroll
+    for (int uu = 0; uu < 8; ++uu) {
+        const int u = u0 + uu;
+        const float4 af = sboxf[(rc + u) & (ROWS - 1)];
+        const bool apart = (bf.x >= af.z) | (af.x >= bf.z) | (bf.y >= af.w) | (af.y >= bf.w);
+        unsigned long long want = __ballot(live && !apart);
+        if (MODE == 1 && STAGE == 1) want |= scw[wid][(rc + u) & (ROWS - 1)] & livemask;
+        work |= (want != 0ull ? 1u : 0u) << u;
+    }
+    if (all_rows) work = 0xffffu;
+    work &= (1u << crows) - 1u;
+    while (work) {
+        const int ub = __ffs((int)work) - 1, r = rc + ub;
+        work &= work - 1;
         const double aa[4] = {sa[r][0], sa[r][1], sa[r][2], sa[r][3]};
         const double iou_d = iou::cost(aa, sflag[r] != 0, sarea[r], bb, true, area_b);
         const long o = (long)(i0 + r) * d.Mx + q;
@@ -364,7 +414,7 @@ __device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, 
         if (MODE == 1 && STAGE == 1) {
             // candidates get the exact float32 dot product, computed by the whole wavefront; the pair's
             // single edge carries min(iou_d, emb) = np.minimum of D:1554
-            unsigned long long todo = __ballot((cmask >> r) & 1u);
+            unsigned long long todo = scw[wid][r] & livemask;
             while (todo) {
                 const int src = __ffsll((long long)todo) - 1;
                 todo &= todo - 1;
@@ -403,24 +453,39 @@ __device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, 
         }
         if (MODE != 2) emit(live && c <= limit, i0 + r, c);
     }
-    if (MODE != 2) flush();
+    }   // chunk
+    if (MODE != 2) {
+        // end of tile: ONE counter bump for the whole workgroup (every wavefront of the chip hammering the
+        // same counter costs more than the tile itself)
+        if (lane == 0) s_wcnt[wid] = wcount;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int tot = 0;
+            for (int k = 0; k < CT_COLS / 64; ++k) tot += s_wcnt[k];
+            s_base = tot ? atomicAdd(&w.hdr[0], tot) : 0;
+        }
+        __syncthreads();
+        int base = s_base;
+        for (int k = 0; k < wid; ++k) base += s_wcnt[k];
+        flush_at(base);
+    }
     __syncthreads();          // the tile's LDS is reused by the caller's next tile
 }
 
 // Persistent tiles: the live extents are only known on the device, so a fixed grid walks the
 // (column tile, row tile) space of the actual problem instead of launching capacity-sized grids.
-template <int STAGE, int MODE>
+template <int STAGE, int MODE, int ROWS = CT_ROWS>
 __device__ __forceinline__ void edges_all(const Dev &d, const bts_lap_work &w, int bid, int nblk, int accum = 0) {
     const int32_t *h = d.hdr;
     const int n = STAGE == 1 ? h[H_NPOOL] : STAGE == 2 ? h[H_NR2] : h[H_NUNC];
     const int m = STAGE == 1 ? h[H_NHI] : STAGE == 2 ? h[H_NLO] : h[H_NLEFT];
-    const int nct = (m + CT_COLS - 1) / CT_COLS, ntile = nct * ((n + CT_ROWS - 1) / CT_ROWS);
-    for (int t = bid; t < ntile; t += nblk) edges_tile<STAGE, MODE>(d, w, t % nct, t / nct, accum);
+    const int nct = (m + CT_COLS - 1) / CT_COLS, ntile = nct * ((n + ROWS - 1) / ROWS);
+    for (int t = bid; t < ntile; t += nblk) edges_tile<STAGE, MODE, ROWS>(d, w, t % nct, t / nct, accum);
 }
 
-template <int STAGE, int MODE>
-__global__ __launch_bounds__(CT_COLS) void tk_edges(Dev d, bts_lap_work w, int accum) {
-    edges_all<STAGE, MODE>(d, w, blockIdx.x, gridDim.x, accum);
+template <int STAGE, int MODE, int ROWS = CT_ROWS>
+__global__ __launch_bounds__(CT_COLS, 4) void tk_edges(Dev d, bts_lap_work w, int accum) {
+    edges_all<STAGE, MODE, ROWS>(d, w, blockIdx.x, gridDim.x, accum);
 }
 
 // ---- appearance pre-filter: float16 MFMA GEMM + exact float32 refine ------------------------------------------
@@ -1127,7 +1192,7 @@ static void tracker_layout(bts_tracker *t, char *base, size_t &off) {
         SLOT(d.body_h, _Float16, T * D); SLOT(d.det_h, _Float16, M * D); SLOT(d.body_n, float, T); SLOT(d.det_n, float, M);
         SLOT(d.face_h, _Float16, T * Df); SLOT(d.dface_h, _Float16, M * Df); SLOT(d.face_n, float, T); SLOT(d.dface_n, float, M);
         SLOT(d.approx, float, T * M); SLOT(d.approx_f, float, d.Df ? T * M : 1);
-        d.cb_ld = (int)((M + 31) / 32);
+        d.cb_ld = (int)((M + 63) / 64) * 2;        // 64 columns = one aligned 8-byte word
         SLOT(d.cbits, uint32_t, T * (size_t)d.cb_ld);
     }
     SLOT(t->x_ints, int32_t, 8 * T); SLOT(t->x_mean, double, 8 * T); SLOT(t->x_tlbr, double, 4 * T); SLOT(t->x_score, float, T); SLOT(t->x_mot, double, 10 * T);
@@ -1285,7 +1350,9 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
     int ntile = bts_cdiv(mc, CT_COLS) * bts_cdiv(T, CT_ROWS);
     if (ntile > 1024) ntile = 1024;
     const dim3 tile_grid(ntile);               // persistent tiles: the kernels walk the live extents
-    int ntile1 = bts_cdiv(mc, CT_COLS) * bts_cdiv(T, CT_ROWS);      // stage 1 has the big problem: about a tile per workgroup
+    // stage 1 has the big problem: about a tile per workgroup; 64-row tiles once there are thousands of them
+    const bool tall = bts_cdiv(mc, CT_COLS) * bts_cdiv(T, CT_ROWS) > 2048;
+    int ntile1 = bts_cdiv(mc, CT_COLS) * bts_cdiv(T, tall ? 64 : CT_ROWS);
     if (ntile1 > 8192) ntile1 = 8192;
     const int kf_blocks = bts_cdiv(T * 8 > M ? T * 8 : M, 256);   // 8 lanes per track
     bts_lap_work lap[3] = {t->lap, t->lap, t->lap3};
@@ -1339,7 +1406,8 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
     seg_begin(BTS_SEG_COST1);
     seg_begin(BTS_SEG_K_EDGES1);
     if (d.filter) {
-        LAUNCH((tk_edges<1, 1>), dim3(ntile1), dim3(CT_COLS), lap[0], accum);
+        if (tall) { LAUNCH((tk_edges<1, 1, 64>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); }
+        else { LAUNCH((tk_edges<1, 1>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); }
         if (d.record) { LAUNCH((tk_edges<1, 2>), tile_grid, dim3(CT_COLS), lap[0], 0); }
     } else {
         LAUNCH((tk_edges<1, 0>), tile_grid, dim3(CT_COLS), lap[0], 0);
