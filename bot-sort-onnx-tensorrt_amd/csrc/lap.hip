@@ -668,7 +668,7 @@ __global__ __launch_bounds__(1024) void k_lap(LapArgs A0, LapArgs A1) {
     } else {
         if (tid == 0) {
             int v = 0;
-            for (long spins = 0; (v = RLX(&w.hdr[H_READY])) == 0 && spins < (1l << 22); ++spins) __builtin_amdgcn_s_sleep(32);
+            for (long spins = 0; (v = RLX(&w.hdr[H_READY])) == 0 && spins < (1l << 22); ++spins) __builtin_amdgcn_s_sleep(8);
             if (v == 0) { RST(&w.hdr[H_ERR], 2); v = 1; }      // give up loudly rather than hang the queue
             s_c = v - 1;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");

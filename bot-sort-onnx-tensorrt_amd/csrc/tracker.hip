@@ -1014,17 +1014,30 @@ __device__ __forceinline__ void birth_body(const Dev &d, int k) {
 
 // ---- duplicate removal between tracked' and lost' (D:1665-1680): boxes straight from the table ------------
 // ... in one launch with the initialisation of the newborn tracks (workgroups >= dedupe_blocks)
+template <int ROWS>
 __global__ __launch_bounds__(CT_COLS) void tk_tail(Dev d, int dedupe_blocks) {
     if ((int)blockIdx.x >= dedupe_blocks) { birth_body(d, (int)blockIdx.x - dedupe_blocks); return; }
-    __shared__ double sa[CT_ROWS][4];
-    __shared__ double sarea[CT_ROWS];
-    __shared__ int sflag[CT_ROWS];
-    __shared__ int sage[CT_ROWS];
+    __shared__ double sa[ROWS][4];
+    __shared__ double sarea[ROWS];
+    __shared__ int sflag[ROWS];
+    __shared__ int sage[ROWS];
+    __shared__ float4 sboxf[ROWS];            // row boxes rounded outward to float32 (screening, see edges_tile)
     const int n = d.hdr[H_NKEEP] + d.hdr[H_NB] + d.hdr[H_NRF], m = d.hdr[H_NL0] + d.hdr[H_NL1];
-    const int nct = (m + CT_COLS - 1) / CT_COLS, ntile = nct * ((n + CT_ROWS - 1) / CT_ROWS);
+    const int nct = (m + CT_COLS - 1) / CT_COLS, ntile = nct * ((n + ROWS - 1) / ROWS);
     for (int t = blockIdx.x; t < ntile; t += dedupe_blocks) {
-        const int i0 = (t / nct) * CT_ROWS, j = (t % nct) * CT_COLS + threadIdx.x;
-        if (threadIdx.x < CT_ROWS && i0 + threadIdx.x < n) {
+        const int i0 = (t / nct) * ROWS, j = (t % nct) * CT_COLS + threadIdx.x;
+        // both chains of dependent loads (this thread's lost track, the tile's tracked rows) start before the barrier
+        const bool live = j < m;
+        const int sj = live ? lost2_at(d, j) : 0;
+        double bb[4] = {0.0, 0.0, 0.0, 0.0};
+        bool bf = false;
+        int agej = 0;
+        if (live) {
+            slot_tlbr(d, sj, bb);
+            bf = d.f32[sj] != 0;
+            agej = d.frame_id[sj] - d.start_frame[sj];
+        }
+        if (threadIdx.x < ROWS && i0 + threadIdx.x < n) {
             const int s = tracked2_at(d, i0 + threadIdx.x);
             double box[4];
             slot_tlbr(d, s, box);
@@ -1033,26 +1046,34 @@ __global__ __launch_bounds__(CT_COLS) void tk_tail(Dev d, int dedupe_blocks) {
             sarea[threadIdx.x] = iou::area(box, f);
             sflag[threadIdx.x] = f;
             sage[threadIdx.x] = d.frame_id[s] - d.start_frame[s];
+            sboxf[threadIdx.x] = make_float4(__double2float_rd(box[0]), __double2float_rd(box[1]), __double2float_ru(box[2]), __double2float_ru(box[3]));
         }
         __syncthreads();
-        if (j < m) {
-            const int sj = lost2_at(d, j);
-            double bb[4];
-            slot_tlbr(d, sj, bb);
-            const bool bf = d.f32[sj] != 0;
-            const double area_b = iou::area(bb, bf);
-            const int agej = d.frame_id[sj] - d.start_frame[sj];
-            const int rows = min(CT_ROWS, n - i0);
-            bool dropj = false;
-            for (int r = 0; r < rows; ++r) {
+        const double area_b = iou::area(bb, bf);
+        const float4 bq = make_float4(__double2float_rd(bb[0]), __double2float_rd(bb[1]), __double2float_ru(bb[2]), __double2float_ru(bb[3]));
+        const int rows = min(ROWS, n - i0);
+        bool dropj = false;
+#pragma unroll 1
+        for (int rc = 0; rc < rows; rc += 8) {
+            uint32_t work = 0;                    // wave-uniform: rows of this chunk some lane overlaps
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float4 af = sboxf[(rc + u) & (ROWS - 1)];
+                const bool apart = (bq.x >= af.z) | (af.x >= bq.z) | (bq.y >= af.w) | (af.y >= bq.w);
+                work |= (__ballot(live && !apart) != 0ull ? 1u : 0u) << u;
+            }
+            work &= (1u << min(8, rows - rc)) - 1u;
+            while (work) {
+                const int r = rc + __ffs((int)work) - 1;
+                work &= work - 1;
                 const double aa[4] = {sa[r][0], sa[r][1], sa[r][2], sa[r][3]};
-                if (iou::cost(aa, sflag[r] != 0, sarea[r], bb, bf, area_b) < d.dedupe_thr) {
+                if (live && iou::cost(aa, sflag[r] != 0, sarea[r], bb, bf, area_b) < d.dedupe_thr) {
                     if (sage[r] > agej) dropj = true;
                     else d.drop_t[i0 + r] = 1;
                 }
             }
-            if (dropj) d.drop_l[j] = 1;
         }
+        if (dropj) d.drop_l[j] = 1;
         __syncthreads();
     }
 }
@@ -1459,9 +1480,11 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
     seg_end(BTS_SEG_MERGE);
     seg_begin(BTS_SEG_DEDUPE);
     {
-        int nd = bts_cdiv(T, CT_COLS) * bts_cdiv(T, CT_ROWS);
+        const bool big = bts_cdiv(T, CT_COLS) * bts_cdiv(T, CT_ROWS) > 2048;      // 64-row tiles for big tables
+        int nd = bts_cdiv(T, CT_COLS) * bts_cdiv(T, big ? 64 : CT_ROWS);
         if (nd > 8192) nd = 8192;
-        LAUNCH(tk_tail, dim3(nd + mc), dim3(CT_COLS), nd);
+        if (big) { LAUNCH(tk_tail<64>, dim3(nd + mc), dim3(CT_COLS), nd); }
+        else { LAUNCH(tk_tail<CT_ROWS>, dim3(nd + mc), dim3(CT_COLS), nd); }
     }
     LAUNCH(tk_finalize, dim3(2), dim3(1024));
     seg_end(BTS_SEG_DEDUPE);
