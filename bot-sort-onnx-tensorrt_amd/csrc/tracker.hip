@@ -397,7 +397,7 @@ __device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, 
     for (int uu = 0; uu < 8; ++uu) {
         const int u = u0 + uu;
         const float4 af = sboxf[(rc + u) & (ROWS - 1)];
-        const bool apart = (bf.x >= af.z) | (af.x >= bf.z) | (bf.y >= af.w) | (af.y >= bf.w);
+        const bool apart = fmaxf(fmaxf(bf.x - af.z, af.x - bf.z), fmaxf(bf.y - af.w, af.y - bf.w)) >= 0.0f;     // one comparison, no scalar OR chain
         unsigned long long want = __ballot(live && !apart);
         if (MODE == 1 && STAGE == 1) want |= scw[wid][(rc + u) & (ROWS - 1)] & livemask;
         work |= (want != 0ull ? 1u : 0u) << u;
@@ -484,7 +484,7 @@ __device__ __forceinline__ void edges_all(const Dev &d, const bts_lap_work &w, i
 }
 
 template <int STAGE, int MODE, int ROWS = CT_ROWS>
-__global__ __launch_bounds__(CT_COLS, 4) void tk_edges(Dev d, bts_lap_work w, int accum) {
+__global__ __launch_bounds__(CT_COLS, ROWS == CT_ROWS ? 4 : 3) void tk_edges(Dev d, bts_lap_work w, int accum) {
     edges_all<STAGE, MODE, ROWS>(d, w, blockIdx.x, gridDim.x, accum);
 }
 
@@ -1059,7 +1059,7 @@ __global__ __launch_bounds__(CT_COLS) void tk_tail(Dev d, int dedupe_blocks) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const float4 af = sboxf[(rc + u) & (ROWS - 1)];
-                const bool apart = (bq.x >= af.z) | (af.x >= bq.z) | (bq.y >= af.w) | (af.y >= bq.w);
+                const bool apart = fmaxf(fmaxf(bq.x - af.z, af.x - bq.z), fmaxf(bq.y - af.w, af.y - bq.w)) >= 0.0f;
                 work |= (__ballot(live && !apart) != 0ull ? 1u : 0u) << u;
             }
             work &= (1u << min(8, rows - rc)) - 1u;
