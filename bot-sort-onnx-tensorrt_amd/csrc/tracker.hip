@@ -419,10 +419,10 @@ __device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, 
                 const int src = __ffsll((long long)todo) - 1;
                 todo &= todo - 1;
                 const long sdet = __shfl(det, src), strk = sslot[r];
-                const float emb = 1.0f - fmaxf(0.0f, feat::wave_dot<4>(d.body_curr + strk * d.D, IN(d, feats) + sdet * d.D, d.D, lane));
+                const float emb = 1.0f - fmaxf(0.0f, feat::wave_dot<(ROWS == CT_ROWS ? 8 : 4)>(d.body_curr + strk * d.D, IN(d, feats) + sdet * d.D, d.D, lane));
                 float face = 1.0f;
                 if (d.Df)
-                    face = 1.0f - face_fixup(fmaxf(0.0f, feat::wave_dot<4>(d.face_curr + strk * d.Df, IN(d, face_feats) + sdet * d.Df, d.Df, lane)));
+                    face = 1.0f - face_fixup(fmaxf(0.0f, feat::wave_dot<(ROWS == CT_ROWS ? 8 : 4)>(d.face_curr + strk * d.Df, IN(d, face_feats) + sdet * d.Df, d.Df, lane)));
                 if (lane == src && !(fminf(emb, face) > d.app)) c = fmin(c, (double)emb);
             }
         } else if (MODE == 1 && STAGE == 3) {
@@ -434,7 +434,7 @@ __device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, 
                 todo &= todo - 1;
                 const long sdet = __shfl(det, src);
                 const long strk = d.unc_slot[i0 + r];
-                const float emb = 1.0f - fmaxf(0.0f, feat::wave_dot<4>(d.body_curr + strk * d.D, IN(d, feats) + sdet * d.D, d.D, lane));
+                const float emb = 1.0f - fmaxf(0.0f, feat::wave_dot<(ROWS == CT_ROWS ? 8 : 4)>(d.body_curr + strk * d.D, IN(d, feats) + sdet * d.D, d.D, lane));
                 if (lane == src && !(emb > d.app)) c = fmin(c, (double)emb);
             }
         } else if (MODE != 1 && live) {
@@ -484,7 +484,7 @@ __device__ __forceinline__ void edges_all(const Dev &d, const bts_lap_work &w, i
 }
 
 template <int STAGE, int MODE, int ROWS = CT_ROWS>
-__global__ __launch_bounds__(CT_COLS, ROWS == CT_ROWS ? 4 : 3) void tk_edges(Dev d, bts_lap_work w, int accum) {
+__global__ __launch_bounds__(CT_COLS) void tk_edges(Dev d, bts_lap_work w, int accum) {
     edges_all<STAGE, MODE, ROWS>(d, w, blockIdx.x, gridDim.x, accum);
 }
 
