@@ -195,28 +195,55 @@ __device__ int small_pipeline(const LapArgs &A, SmallPipe &L, int E, int n, int 
     const int tid = threadIdx.x, nth = blockDim.x;
     int32_t *tab = L.parent;                              // [n + m]: rows, then columns
     if (tid == 0) { L.NA = 0; L.MA = 0; L.C = 0; L.maxr = 0; L.maxc = 0; L.maxe = 0; L.EH = 0; }
+    // The edge list is read from global memory ONCE: the first two passes walk it with the same
+    // edge -> thread mapping and keep (row, col) in registers (up to EC per thread; longer lists are
+    // re-read), hard edges carry their (row, col) in the LDS queue, and their costs are fetched while
+    // the component phases run (consumed only by the final export).
+    constexpr int EC = 4;
+    int er[EC], ec[EC];
+    const bool cached = E <= EC * nth;
+#pragma unroll
+    for (int k = 0; k < EC; ++k) {
+        const int e = tid + k * nth;
+        er[k] = (cached && e < E) ? w.e_row[e] : -1;
+        ec[k] = (cached && e < E) ? w.e_col[e] : 0;
+    }
     for (int k = tid; k < n + m; k += nth) tab[k] = 0;
     __syncthreads();
-    for (int e = tid; e < E; e += nth) { const int i = w.e_row[e]; if (i >= 0) { atomicAdd(&tab[i], 1); atomicAdd(&tab[n + w.e_col[e]], 1); } }   // (row -1: vacant slot)
+    if (cached) {
+#pragma unroll
+        for (int k = 0; k < EC; ++k) if (er[k] >= 0) { atomicAdd(&tab[er[k]], 1); atomicAdd(&tab[n + ec[k]], 1); }      // (row -1: vacant slot)
+    } else {
+        for (int e = tid; e < E; e += nth) { const int i = w.e_row[e]; if (i >= 0) { atomicAdd(&tab[i], 1); atomicAdd(&tab[n + w.e_col[e]], 1); } }
+    }
     __syncthreads();
-    for (int e = tid; e < E; e += nth) {                  // isolated pairs are final; the rest is queued
-        const int i = w.e_row[e], j = w.e_col[e];
-        if (i < 0) continue;
+    auto classify = [&](int e, int i, int j) {            // isolated pairs are final; the rest is queued
+        if (i < 0) return;
         if (tab[i] == 1 && tab[n + j] == 1) { A.x[i] = j; A.y[j] = i; }
-        else { const int h = atomicAdd(&L.EH, 1); if (h < SM_EH) L.he[h] = e; }
+        else { const int h = atomicAdd(&L.EH, 1); if (h < SM_EH) { L.he[h] = e; L.hr[h] = i; L.hc[h] = j; } }
+    };
+    if (cached) {
+#pragma unroll
+        for (int k = 0; k < EC; ++k) classify(tid + k * nth, er[k], ec[k]);
+    } else {
+        for (int e = tid; e < E; e += nth) classify(e, w.e_row[e], w.e_col[e]);
     }
     __syncthreads();
     const int EH = L.EH;
     if (EH == 0) return 0;
     if (EH > SM_EH) return -1;
+    constexpr int HC = (SM_EH + 1023) / 1024;             // hard edges per thread at 1024 threads (more threads: fewer)
+    double hcost[HC];                                     // prefetched here, stored by the export at the very end
+#pragma unroll
+    for (int k = 0; k < HC; ++k) { const int h = tid + k * nth; hcost[k] = (nth >= 1024 && h < EH) ? w.e_cost[L.he[h]] : 0.0; }
     for (int h = tid; h < EH; h += nth) {                 // dense slots; the table entry becomes FIRST | slot
-        const int e = L.he[h], i = w.e_row[e], j = w.e_col[e];
+        const int i = L.hr[h], j = L.hc[h];
         if (!(atomicOr(&tab[i], FIRST) & FIRST)) { const int s = atomicAdd(&L.NA, 1); L.arow[s] = i; atomicExch(&tab[i], FIRST | s); }
         if (!(atomicOr(&tab[n + j], FIRST) & FIRST)) { const int s = atomicAdd(&L.MA, 1); L.acol[s] = j; atomicExch(&tab[n + j], FIRST | s); }
     }
     __syncthreads();
     const int NA = L.NA, MA = L.MA;
-    for (int h = tid; h < EH; h += nth) { const int e = L.he[h]; L.hr[h] = tab[w.e_row[e]] & ~FIRST; L.hc[h] = tab[n + w.e_col[e]] & ~FIRST; }
+    for (int h = tid; h < EH; h += nth) { L.hr[h] = tab[L.hr[h]] & ~FIRST; L.hc[h] = tab[n + L.hc[h]] & ~FIRST; }      // (row, col) -> slots, in place
     __syncthreads();                                      // the table is dead from here on
     for (int s = tid; s < NA; s += nth) { L.parent[s] = s; L.rptr[s] = 0; L.ecnt[s] = 0; }
     for (int s = tid; s < MA; s += nth) L.parent[SM_EH + s] = SM_EH + s;
@@ -265,10 +292,22 @@ __device__ int small_pipeline(const LapArgs &A, SmallPipe &L, int E, int n, int 
         w.cdesc[c] = make_int4(L.crp[c], L.ccp[c], (L.crp[c + 1] - L.crp[c]) | ((L.ccp[c + 1] - L.ccp[c]) << 8) | (L.ecnt[c] << 16),
                                L.gstart[L.crp[c]]);
     __syncthreads();
-    for (int h = tid; h < EH; h += nth) {
-        const int pos = atomicAdd(&cursor[L.hr[h]], 1);
-        w.csr_lcol[pos] = L.lane_of_col[L.hc[h]];
-        w.csr_cost[pos] = w.e_cost[L.he[h]];
+    if (nth >= 1024) {
+#pragma unroll
+        for (int k = 0; k < HC; ++k) {
+            const int h = tid + k * nth;
+            if (h < EH) {
+                const int pos = atomicAdd(&cursor[L.hr[h]], 1);
+                w.csr_lcol[pos] = L.lane_of_col[L.hc[h]];
+                w.csr_cost[pos] = hcost[k];
+            }
+        }
+    } else {
+        for (int h = tid; h < EH; h += nth) {
+            const int pos = atomicAdd(&cursor[L.hr[h]], 1);
+            w.csr_lcol[pos] = L.lane_of_col[L.hc[h]];
+            w.csr_cost[pos] = w.e_cost[L.he[h]];
+        }
     }
     if (tid == 0) { RST(&w.hdr[H_COMPS], C); RST(&w.hdr[H_HARD], C); RST(&w.hdr[H_MODE], 1); RST(&w.hdr[H_NH], EH); }
     return 0;
@@ -629,7 +668,8 @@ __device__ void solve_component(const LapArgs &A, int c, int lane) {
 // ---- the one launch -----------------------------------------------------------------------------------
 // grid = (problems, 1 + helpers); 1024 threads.  Workgroup y = 0 of a problem prepares; the helper
 // workgroups wait for hdr[H_READY] (1 + number of packed components) and share the components.
-constexpr int LAP_HELPERS = 15;    // helper workgroups per problem (16 wavefronts each)
+constexpr int LAP_SOLO_EDGES = 64;   // edge lists up to this length are solved by the preparing workgroup alone
+constexpr int LAP_HELPERS = 15, LAP_HELPERS_BIG = 63;    // helper workgroups per problem (16 wavefronts each): small / big problems
 constexpr unsigned LAP_LDS_BYTES = sizeof(SmallPipe) > 16 * sizeof(SmallLds) ? sizeof(SmallPipe) : 16 * sizeof(SmallLds);
 
 __global__ __launch_bounds__(1024) void k_lap(LapArgs A0, LapArgs A1) {
@@ -640,10 +680,15 @@ __global__ __launch_bounds__(1024) void k_lap(LapArgs A0, LapArgs A1) {
     const bts_lap_work &w = A.w;
     const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63, wid = tid >> 6;
     int C = 0;
+    bool solo = false;
     if (blockIdx.y == 0) {
         const int n = A.dims ? A.dims[0] : A.n_max, m = A.dims ? A.dims[1] : A.m_max;
         int E = RLX(&w.hdr[H_EDGES]);
         if ((long)E > w.e_cap) E = (int)w.e_cap;
+        // A short edge list means few components: this workgroup's 16 wavefronts solve them straight away
+        // (no release / poll / re-read of the packed problem through memory); the helpers are sent home.
+        solo = E <= LAP_SOLO_EDGES;
+        if (solo && tid == 0) RST(&w.hdr[H_READY], 1);
         if (!A.fresh) {
             for (int i = tid; i < n; i += nth) { RST(&w.deg[i], 0); A.x[i] = -1; }
             for (int j = tid; j < m; j += nth) { RST(&w.cdeg[j], 0); A.y[j] = -1; }
@@ -658,9 +703,8 @@ __global__ __launch_bounds__(1024) void k_lap(LapArgs A0, LapArgs A1) {
         }
         __syncthreads();
         C = RLX(&w.hdr[H_HARD]);
-        // publish (stores -> barrier -> one lane: agent release, drain, relaxed flag)
         __syncthreads();
-        if (tid == 0) {
+        if (!solo && tid == 0) {       // publish (stores -> barrier -> one lane: agent release, drain, relaxed flag)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             RST(&w.hdr[H_READY], 1 + C);
@@ -678,7 +722,7 @@ __global__ __launch_bounds__(1024) void k_lap(LapArgs A0, LapArgs A1) {
     }
     if (C == 0) return;
     SmallLds *lds = reinterpret_cast<SmallLds *>(lds_raw);
-    const int gw = blockIdx.y * (nth >> 6) + wid, nw = gridDim.y * (nth >> 6);
+    const int gw = blockIdx.y * (nth >> 6) + wid, nw = (solo ? 1 : gridDim.y) * (nth >> 6);
     for (int c = gw; c < C; c += nw)
         if (!solve_packed(A, c, lane, lds[wid])) solve_component(A, c, lane);
 }
@@ -738,7 +782,9 @@ int bts_lap_enqueue(const bts_lap_problem *probs, int count, hipStream_t stream,
     if (rc0) return rc0;
     const bts_lap_problem &A = probs[0], &B = probs[count > 1 ? 1 : 0];
     if (ev) (void)hipEventRecord(ev[0], stream);
-    hipLaunchKernelGGL(k_lap, dim3(count, 1 + LAP_HELPERS), dim3(1024), LAP_LDS_BYTES, stream, A, B);
+    // a component is one wavefront's job: big problems (hundreds of components) get more helper workgroups
+    const int helpers = (A.n_max >= 2048 || B.n_max >= 2048) ? LAP_HELPERS_BIG : LAP_HELPERS;
+    hipLaunchKernelGGL(k_lap, dim3(count, 1 + helpers), dim3(1024), LAP_LDS_BYTES, stream, A, B);
     BTS_LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[1], stream);
     return BTS_OK;
