@@ -113,6 +113,20 @@ def cpu_baseline(pkg, K, M, D, seed, budget_s):
                       % (n, n + 1, t_used, os.cpu_count() or 0)}
 
 
+def pmc_traffic(workload, kernel_name):
+    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE,
+    separate runs: scripts/gpu_final.sh -> scripts/pmc_to_json.py).  None when no pass covers this workload."""
+    try:
+        tab = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))["workloads"][workload]
+    except Exception:
+        return None
+    base = kernel_name.split("<")[0]
+    for k, v in tab.items():
+        if k.split("<")[0] == base:
+            return v.get("traffic_bytes")
+    return None
+
+
 def ms_seed(pkg, rank):
     return pkg.multistream.stream_seed(1234, rank)      # one independent video stream per GPU
 
@@ -207,7 +221,8 @@ def main():
                        "tracks": K, "dets": M, "feat_dim": D, "streams": world, "parallelism": "1 stream/GPU, no collective",
                        "launch": "hipGraph replay" if a.graph else "eager"},
             "roofline": {"kernel": KERNELS[segment], "bound": bound, "achieved": achieved, "peak": peak, "unit": runit,
-                         "frac": achieved / peak, "traffic": None,
+                         "frac": achieved / peak, "traffic": pmc_traffic(a.workload, KERNELS[segment]),
+                         "traffic_unit": "bytes per launch (HBM, rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes, profiles/pmc_traffic.json)",
                          "avg_us": 1e6 * seg_s, "launches_timed": seg_n,
                          "algorithmic_per_launch": amount, "algorithmic_unit": unit},
         }
