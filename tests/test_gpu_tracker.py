@@ -345,3 +345,31 @@ def test_botsort_update_image_with_parts(bts):
         assert b.head is not None and b.head.face is not None and b.hand1 is not None and b.hand2 is not None
         assert {b.trackid, b.head.trackid, b.head.face.trackid, b.hand1.trackid, b.hand2.trackid} == {t.track_id}
         assert b.x1 <= b.head.x1 and b.head.x2 <= b.x2 and b.hand1 is not b.hand2
+
+
+def test_full_size_filter_vs_dense_modes(bts, synth):
+    """BASELINE-size crowd (the CPU oracle would need minutes per frame): the default path -- float16 pre-filter,
+    64-row cost tiles and 64-row duplicate tiles, only taken at this size -- must produce the SAME assignments,
+    track ids and lists as the dense float32 path, which forms the full similarity and cost matrices like the
+    reference does (and is itself pinned to the oracle at the smaller sizes above)."""
+    K, M, D = 8192, 1024, 128
+    st = synth.SyntheticStream(K, M, D, seed=21, churn=0.02)
+    a = bts.DeviceTracker(max_tracks=K + 512, max_dets=K, feat_dim=D)
+    b = bts.DeviceTracker(max_tracks=K + 512, max_dets=K, feat_dim=D, appearance_mode=1)
+    for f in range(6):
+        fr = st.next()
+        a.step(*_dev_frame(fr)[:3])
+        b.step(*_dev_frame(fr)[:3])
+        for k in (1, 2, 3):
+            ra, rb = a.stage_result(k), b.stage_result(k)
+            assert np.array_equal(ra["x"], rb["x"]) and np.array_equal(ra["y"], rb["y"]), (f, k)
+        for which in (0, 1):
+            ta, tb = a.export(which), b.export(which)
+            for key in INT_KEYS:
+                assert np.array_equal(ta[key], tb[key]), (f, which, key)
+            if len(ta["mean"]):
+                assert np.abs(ta["mean"] - tb["mean"]).max() <= 1e-9
+        ca, cb = a.counts(), b.counts()
+        assert ca == cb and ca["errors"] == 0
+    assert a.counts()["n_tracked"] > 500 and a.counts()["n_lost"] > 5000      # the duplicate tiles had real work
+    a.close(); b.close()
