@@ -31,7 +31,7 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-F16_MFMA_PEAK_TF = 2500.0      # dense f16/bf16 MFMA peak (not the 2:1-sparse headline)
+F8_MFMA_PEAK_TF = 5000.0       # dense fp8 MFMA peak (not the 2:1-sparse headline): the pre-filter multiplies fp8 shadows
 F32_MFMA_PEAK_TF = 157.3       # dense f32-input MFMA peak (= f32 vector peak)
 SEGMENTS = ("prep", "cos1", "cost1", "lap1", "apply1", "stage2", "merge", "dedupe")   # launch groups of a step
 KERNELS = {   # single kernels that can dominate a step -> name in the rocprofv3 kernel trace
@@ -61,8 +61,8 @@ def kernel_model(kern, K, M, D, dense):
     Formulas: DESIGN.md section 3."""
     N, Mh, Km = K, M - M // 8, M - M // 8
     E = int(1.2 * Mh)
-    if kern == "k_filter":     # appearance contraction 2*N*Mh*D flop on the f16 matrix cores
-        return "mfma", 2.0 * N * Mh * D, "flop", F16_MFMA_PEAK_TF
+    if kern == "k_filter":     # appearance contraction 2*N*Mh*D flop on the fp8 matrix cores
+        return "mfma", 2.0 * N * Mh * D, "flop", F8_MFMA_PEAK_TF
     table = {
         # stage-1 matches: Kalman rows read + written, measurement read; det row, smooth r+w, curr w, f16 shadow w
         "k_mid2": Km * (2 * 72 + 4) * 8 + Km * D * (4 + 4 + 4 + 4 + 2),

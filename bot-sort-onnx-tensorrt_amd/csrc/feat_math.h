@@ -119,36 +119,61 @@ __device__ __forceinline__ void ema_row(float *curr, float *smooth, const float 
         }
 }
 
-// ---- float16 shadow rows for the appearance pre-filter -----------------------------------------------
-// h[k] = half(256 * f[k]) (the power-of-two scale keeps small components of a unit vector out of the
-// float16 subnormal range; it is undone exactly on the accumulated dot product), *norm = ||f||_2.
-constexpr float HALF_SCALE = 256.0f;
-constexpr float HALF_UNSCALE = 1.0f / (256.0f * 256.0f);
+// ---- 8-bit shadow rows for the appearance pre-filter ----------------------------------------------------
+// q[k] = fp8_e4m3(Q8_SCALE * f[k] / ||f||_2), *norm = ||f||_2.  The shadow is the UNIT vector (no component can
+// saturate whatever the norm of the row is; 128 keeps the largest component below the maximum of both e4m3
+// flavours), so the accumulated dot product of two shadows approximates the COSINE; the norms travel separately.
+// Error model of one element x of a unit vector (validated on the device by tests, bts_debug_q8_roundtrip):
+//     |q(x) - x| <= Q8_REL * |x| + Q8_ABS        (round to nearest, 3 mantissa bits; Q8_ABS covers the subnormal
+//                                                 range even if the conversion flushes it to zero)
+// => |cos_q - cos| <= (2 Q8_REL + Q8_REL^2) + 2 (1 + Q8_REL) Q8_ABS sqrt(D) + D Q8_ABS^2   (+ float32 accumulation).
+constexpr float Q8_SCALE = 128.0f;
+constexpr float Q8_UNSCALE = 1.0f / (128.0f * 128.0f);
+constexpr float Q8_REL = 0.0625f;                 // 2^-4
+constexpr float Q8_ABS = 1.0f / 8192.0f;          // 2^-6 (smallest normal of e4m3fn) / 128
+__host__ __device__ inline float q8_cos_error(int d) {
+    return (2.0f * Q8_REL + Q8_REL * Q8_REL) + 2.0f * (1.0f + Q8_REL) * Q8_ABS * sqrtf((float)d) + (float)d * Q8_ABS * Q8_ABS +
+           (float)d / 4194304.0f + 1e-3f;
+}
 
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void to_half_row(const float *f, _Float16 *h, float *norm, int d, bool active = true) {
+__device__ __forceinline__ unsigned q8_pack4(float a, float b, float c, float e) {
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, e, w, true);
+    return (unsigned)w;
+}
+
+__device__ __forceinline__ void to_q8_row(const float *f, uint8_t *h, float *norm, int d, bool active = true) {
     const int t = row_tid();
     float ss = 0.0f;
-    if (active && vec4_ok(f, d) && (uintptr_t)h % 8 == 0) {
+    const bool v4 = active && vec4_ok(f, d) && (uintptr_t)h % 4 == 0;
+    if (v4 && d / 4 <= 2 * ROW_G) {                       // the row stays in registers between the two sweeps
         const float4 *f4 = reinterpret_cast<const float4 *>(f);
-        half4 *h4 = reinterpret_cast<half4 *>(h);
-        for (int k = t; k < d / 4; k += ROW_G) {
-            const float4 v = f4[k];
-            ss += v.x * v.x; ss += v.y * v.y; ss += v.z * v.z; ss += v.w * v.w;
-            half4 o;
-            o.x = (_Float16)(v.x * HALF_SCALE); o.y = (_Float16)(v.y * HALF_SCALE);
-            o.z = (_Float16)(v.z * HALF_SCALE); o.w = (_Float16)(v.w * HALF_SCALE);
-            h4[k] = o;
+        unsigned *h4 = reinterpret_cast<unsigned *>(h);
+        float4 v[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int k = t + u * ROW_G;
+            v[u] = k < d / 4 ? f4[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+            ss += v[u].x * v[u].x; ss += v[u].y * v[u].y; ss += v[u].z * v[u].z; ss += v[u].w * v[u].w;
         }
-    } else if (active) {
-        for (int k = t; k < d; k += ROW_G) {
-            const float v = f[k];
-            ss += v * v;
-            h[k] = (_Float16)(v * HALF_SCALE);
+        const float nrm = sqrtf(block_sum(ss));
+        const float sc = nrm > 0.0f ? Q8_SCALE / nrm : (nrm == 0.0f ? 0.0f : nrm);       // NaN norms poison the row on purpose
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int k = t + u * ROW_G;
+            if (k < d / 4) h4[k] = q8_pack4(v[u].x * sc, v[u].y * sc, v[u].z * sc, v[u].w * sc);
         }
+        if (t == 0) *norm = nrm;
+        return;
     }
-    const float tot = block_sum(ss);
-    if (active && t == 0) *norm = sqrtf(tot);
+    if (active) for (int k = t; k < d; k += ROW_G) ss += f[k] * f[k];
+    const float nrm = sqrtf(block_sum(ss));
+    const float sc = nrm > 0.0f ? Q8_SCALE / nrm : (nrm == 0.0f ? 0.0f : nrm);
+    if (active) {
+        for (int k = t; k < d; k += ROW_G) h[k] = (uint8_t)(q8_pack4(f[k] * sc, 0.f, 0.f, 0.f) & 0xffu);
+        if (t == 0) *norm = nrm;
+    }
 }
 
 // <a, b> over d floats by one wavefront, every lane gets the result.  Fixed evaluation order

@@ -34,9 +34,34 @@ __global__ __launch_bounds__(256) void k_feature_renorm(float *__restrict__ feat
     feat::renorm_row(feats + s * d, d);
 }
 
+// diagnostic: the 8-bit quantiser of the appearance pre-filter, element by element
+__global__ __launch_bounds__(256) void k_q8_roundtrip(const float *__restrict__ x, float *__restrict__ y, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned w = feat::q8_pack4(x[i] * feat::Q8_SCALE, 0.f, 0.f, 0.f);
+    y[i] = __builtin_amdgcn_cvt_f32_fp8((int)w, 0) / feat::Q8_SCALE;
+}
+
 }  // namespace
 
 extern "C" {
+
+int bts_debug_q8_roundtrip(bts_context *ctx, const float *x, float *y, int n, bts_stream stream) {
+    BTS_REQUIRE(ctx && n >= 0, "ctx, n");
+    if (n == 0) return BTS_OK;
+    BTS_REQUIRE(x && y, "null pointer");
+    hipLaunchKernelGGL(k_q8_roundtrip, dim3(bts_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+
+int bts_debug_q8_model(double *rel, double *abs_, double *scale) {
+    if (rel) *rel = feat::Q8_REL;
+    if (abs_) *abs_ = feat::Q8_ABS;
+    if (scale) *scale = feat::Q8_SCALE;
+    return BTS_OK;
+}
+
 
 int bts_feature_ema(bts_context *ctx, float *curr, float *smooth, uint8_t *has_smooth,
                     const int32_t *trk_idx, const float *det_feats, const int32_t *det_idx, int k, int d,

@@ -63,7 +63,7 @@ struct Dev {
     int32_t *lap_hdr;          // 3 x 64 ints: per-stage counters of the assignment solver (BTS_LAP_HDR_INTS each)
     int record;                // keep dense cost matrices (tests / inspection)
     int filter;                // appearance term by float16-MFMA pre-filter + exact float32 refine
-    _Float16 *body_h, *face_h, *det_h, *dface_h;      // float16 shadows of body_curr/face_curr and of the frame's rows
+    uint8_t *body_h, *face_h, *det_h, *dface_h;       // fp8 unit-vector shadows of body_curr/face_curr and of the frame's rows
     float *body_n, *face_n, *det_n, *dface_n;         // their float32 L2 norms
     float *approx, *approx_f;                          // [T][Mx] split-K accumulation of the pre-filter, body / face (self-cleaning)
     uint32_t *cbits;                                   // [T][cb_ld] candidate bitmap of the one-pass pre-filter (self-cleaning)
@@ -197,8 +197,8 @@ __device__ __forceinline__ void prep_free(const Dev &d) {
 __device__ __forceinline__ void cvt_body(const Dev &d, long blk) {        // four rows per 1024-thread workgroup
     const long j = blk * 4 + feat::row_group();
     const bool on = j < IN(d, m);
-    feat::to_half_row(IN(d, feats) + j * d.D, d.det_h + j * d.D, d.det_n + j, d.D, on);
-    if (d.Df) feat::to_half_row(IN(d, face_feats) + j * d.Df, d.dface_h + j * d.Df, d.dface_n + j, d.Df, on);
+    feat::to_q8_row(IN(d, feats) + j * d.D, d.det_h + j * d.D, d.det_n + j, d.D, on);
+    if (d.Df) feat::to_q8_row(IN(d, face_feats) + j * d.Df, d.dface_h + j * d.Df, d.dface_n + j, d.Df, on);
 }
 
 // one launch: workgroups 0-3 build the frame's lists, the others convert the detection rows
@@ -242,8 +242,9 @@ __device__ __forceinline__ float face_fixup(float s) {
 }
 
 // candidate test: could the exact similarity reach the gate?  (NaN/inf approximations are candidates)
-__device__ __forceinline__ bool is_candidate(float approx, float na, float nb, float gate, float eps_rel) {
-    return !(approx < gate - eps_rel * na * nb - 3e-5f);
+// `approx` approximates the COSINE of the pair with absolute error <= err (feat::q8_cos_error); na, nb = the norms.
+__device__ __forceinline__ bool is_candidate(float approx, float na, float nb, float gate, float err) {
+    return !((approx + err) * (na * nb) < gate - 3e-5f);
 }
 
 // STAGE 1: cost = min(iou_d, emb) with the appearance gate (D:1539-1554)
@@ -496,9 +497,9 @@ __global__ __launch_bounds__(CT_COLS) void tk_edges(Dev d, bts_lap_work w, int a
 // recomputed exactly in float32 (same value the dense float32 path produces up to summation order)
 // and appended to the solver's edge list as (row, col, 1 - sim).  A pair may then appear twice (its IoU
 // edge and its appearance edge): the solver's relaxation takes the minimum, which is np.minimum of D:1554.
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int FBM = 128, FBN = 128, FBK = 64, FLD = FBK + 8;   // halves; +8 keeps 16-B rows on distinct LDS slots
+constexpr int FBM = 128, FBN = 128;      // tile of the pre-filter GEMM
+constexpr int DBK = 64;                  // its K step: 64 fp8 elements = one 64-byte LDS row per stage
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, slot = bid / 8;
@@ -531,7 +532,7 @@ __device__ __forceinline__ void filter_epilogue(const Dev &d, f32x16 (&acc)[2][2
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ii = wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh, i = bm * FBM + ii;
-                const float val = acc[mi][ni][r] * feat::HALF_UNSCALE;
+                const float val = acc[mi][ni][r] * feat::Q8_UNSCALE;
                 if (!(i < n && q < m)) continue;
                 if (accum) atomicAdd(&approx[(long)i * d.Mx + q], val);
                 else if (is_candidate(val, snorm[ii], snorm[FBM + qq], gate, eps))      // rare: about one per detection column
@@ -544,106 +545,24 @@ __device__ __forceinline__ void filter_epilogue(const Dev &d, f32x16 (&acc)[2][2
 // by the workgroups of the Kalman predict, which is independent of the contraction and shares the launch.
 // accum: add the partial products into `approx` (split K; the stage-1 tile kernel applies the
 // candidate test once they are complete); otherwise test here and set bits in `cbits`.
-template <bool FACE>
-__global__ __launch_bounds__(256) void k_filter(Dev d, int m_max, int ntiles, int nsplit, int accum) {
-    __shared__ __attribute__((aligned(16))) _Float16 As2[2][FBM * FLD];     // double-buffered operand tiles
-    __shared__ __attribute__((aligned(16))) _Float16 Bs2[2][FBN * FLD];
-    if ((int)blockIdx.x >= ntiles * nsplit) {
-        if (!FACE) predict_body(d, (int)blockIdx.x - ntiles * nsplit);
-        return;
-    }
-    const int n = d.hdr[H_NPOOL], m = d.hdr[H_NHI];
-    const int Dd = FACE ? d.Df : d.D;
-    const _Float16 *A = FACE ? d.face_h : d.body_h, *B = FACE ? d.dface_h : d.det_h;
-    const int nbn = (m_max + FBN - 1) / FBN;
-    const int ksplit = blockIdx.x / ntiles;
-    const int vb = xcd_remap(blockIdx.x % ntiles, ntiles);
-    const int bm = vb / nbn, bn = vb % nbn;
-    if (bm * FBM >= n || bn * FBN >= m) return;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid >> 1, wc = wid & 1;
-    // K range of this split
-    const int kt_all = (Dd + FBK - 1) / FBK, kt_per = (kt_all + nsplit - 1) / nsplit;
-    const int kt0 = ksplit * kt_per, kt1 = min(kt_all, kt0 + kt_per);
-    if (kt0 >= kt1) return;
-
-    const int srow = tid >> 3, sk = (tid & 7) * 8;          // 128 rows x 8 chunks of 8 halves
-    const _Float16 *arow[4], *brow[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const int i = bm * FBM + srow + 32 * s, j = bn * FBN + srow + 32 * s;
-        arow[s] = i < n ? A + (long)d.pool_slot[i] * Dd : nullptr;
-        brow[s] = j < m ? B + (long)d.hi_idx[j] * Dd : nullptr;
-    }
-    uint4 ra[4], rb[4];
-    auto stage_load = [&](int k0) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int k = k0 + sk;
-            ra[s] = (arow[s] && k < Dd) ? *reinterpret_cast<const uint4 *>(arow[s] + k) : make_uint4(0, 0, 0, 0);
-            rb[s] = (brow[s] && k < Dd) ? *reinterpret_cast<const uint4 *>(brow[s] + k) : make_uint4(0, 0, 0, 0);
-        }
-    };
-    auto stage_write = [&](int buf) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            *reinterpret_cast<uint4 *>(&As2[buf][(srow + 32 * s) * FLD + sk]) = ra[s];
-            *reinterpret_cast<uint4 *>(&Bs2[buf][(srow + 32 * s) * FLD + sk]) = rb[s];
-        }
-    };
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
-    const int frow = lane & 31, fh = lane >> 5;
-    // One barrier per K step: while tile kt is multiplied out of buffer `cur`, tile kt+1 travels
-    // HBM -> registers, and is written into the other buffer before the barrier.
-    stage_load(kt0 * FBK);
-    stage_write(0);
-    __syncthreads();
-    int cur = 0;
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const bool more = kt + 1 < kt1;
-        if (more) stage_load((kt + 1) * FBK);
-        const _Float16 *As = As2[cur], *Bs = Bs2[cur];
-#pragma unroll
-        for (int t = 0; t < FBK / 16; ++t) {
-            half8 fa[2], fb[2];
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-                fa[mi] = *reinterpret_cast<const half8 *>(&As[(wr * 64 + mi * 32 + frow) * FLD + t * 16 + fh * 8]);
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-                fb[ni] = *reinterpret_cast<const half8 *>(&Bs[(wc * 64 + ni * 32 + frow) * FLD + t * 16 + fh * 8]);
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
-        }
-        if (more) stage_write(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
-    }
-    filter_epilogue<FACE>(d, acc, reinterpret_cast<float *>(&As2[0][0]), bm, bn, n, m, accum);
-}
-
-// The same contraction with the operand tiles travelling HBM -> LDS directly (global_load_lds, 16 B per
-// lane: no staging registers, no ds_write pass) through a ring of DNS stages of DBK = 32 halves, so that
-// DNS - 1 stages (48 KiB per workgroup, two workgroups per CU) are in flight while one is multiplied:
-// a stage needs ~2 us to arrive when part of it misses the L2, a single prefetched stage does not cover that.
+//
+// 128 x 128 tiles of v_mfma_scale_f32_32x32x64_f8f6f4 (fp8 x fp8, unit block scales) over the 8-bit unit-vector shadows.  What bounds this
+// kernel is neither HBM nor the matrix cores but the CU's fill path (a 128 x 128 tile needs 64 B/clk/CU of
+// operand traffic at full MFMA rate with 2-byte operands) -- hence 1-byte operands -- and how the operands reach LDS:
+//   * straight from memory (global_load_lds, 16 B per lane: no staging registers, no ds_write pass) through
+//     a ring of DNS stages of DBK = 64 elements, so that DNS - 1 stages are in flight while one is multiplied
+//     (a stage needs ~2 us to arrive when part of it misses the L2);
 //   * the LDS image of such a load is lane-linear, so a tile is stored as unpadded 64-byte rows and the
 //     bank spread comes from the SOURCE side: lane (row, c) fetches 16-byte chunk c ^ swz(row) of its row
 //     and the fragment reads undo the permutation; swz(row) = (row >> 2) & 3 makes every ds_read_b128
 //     lane group hit 16 distinct 16-byte slots (0 bank conflicts measured);
 //   * one workgroup barrier per stage, preceded by a COUNTED s_waitcnt vmcnt (only the oldest stage has
-//     to have landed) -- __syncthreads would drain the whole ring.
-// Needs feat_dim % 32 == 0 (no K tail); the register-staged k_filter covers the rest.
+//     to have landed) -- __syncthreads would drain the whole ring;
+//   * a lane's two 16-byte fragment reads are the 32 K values it feeds to ONE K=64 MFMA (which K indices a lane
+//     holds is free as long as both operands agree).
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
-constexpr int DBK = 32, DNS = 4;
+constexpr int DNS = 4;                 // (DBK = 64 elements = 64 bytes per row and stage, defined above)
 
 template <int N> __device__ __forceinline__ void wait_stage_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
@@ -653,6 +572,7 @@ template <int N> __device__ __forceinline__ void wait_stage_barrier() {
 // serialise the pipeline.  The explicit lgkmcnt wait below takes the fragments as operands so that no
 // MFMA can be scheduled above it.
 typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v8i __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ v4i lds_read16(unsigned addr) {
     v4i v;
     asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
@@ -661,18 +581,20 @@ __device__ __forceinline__ v4i lds_read16(unsigned addr) {
 template <int N> __device__ __forceinline__ void lds_wait(v4i &a, v4i &b, v4i &c, v4i &e) {
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(e) : "n"(N));
 }
+__device__ __forceinline__ long lo8(const v4i &v) { return ((long)(unsigned)v.y << 32) | (unsigned)v.x; }
+__device__ __forceinline__ long hi8(const v4i &v) { return ((long)(unsigned)v.w << 32) | (unsigned)v.z; }
 
 template <bool FACE>
 __global__ __launch_bounds__(256) void k_filter_dma(Dev d, int m_max, int ntiles, int nsplit, int accum) {
-    __shared__ __attribute__((aligned(1024))) _Float16 As2[DNS][FBM * DBK];
-    __shared__ __attribute__((aligned(1024))) _Float16 Bs2[DNS][FBN * DBK];
+    __shared__ __attribute__((aligned(1024))) uint8_t As2[DNS][FBM * DBK];
+    __shared__ __attribute__((aligned(1024))) uint8_t Bs2[DNS][FBN * DBK];
     if ((int)blockIdx.x >= ntiles * nsplit) {
         if (!FACE) predict_body(d, (int)blockIdx.x - ntiles * nsplit);
         return;
     }
     const int n = d.hdr[H_NPOOL], m = d.hdr[H_NHI];
     const int Dd = FACE ? d.Df : d.D;
-    const _Float16 *A = FACE ? d.face_h : d.body_h, *B = FACE ? d.dface_h : d.det_h;
+    const uint8_t *A = FACE ? d.face_h : d.body_h, *B = FACE ? d.dface_h : d.det_h;
     const int nbn = (m_max + FBN - 1) / FBN;
     const int ksplit = blockIdx.x / ntiles;
     const int vb = xcd_remap(blockIdx.x % ntiles, ntiles);
@@ -685,12 +607,12 @@ __global__ __launch_bounds__(256) void k_filter_dma(Dev d, int m_max, int ntiles
 
     // piece s of a stage = rows [(4 s + wid) * 16, +16): one 1-KiB wavefront load, lane -> (row, 16-byte chunk)
     const int prow = lane >> 2, pchunk = lane & 3;
-    const _Float16 *asrc[2], *bsrc[2];
+    const uint8_t *asrc[2], *bsrc[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         const int r = (4 * s + wid) * 16 + prow;
         const int i = bm * FBM + r, j = bn * FBN + r;
-        const int sw = (pchunk ^ ((r >> 2) & 3)) * 8;
+        const int sw = (pchunk ^ ((r >> 2) & 3)) * 16;
         asrc[s] = A + (long)d.pool_slot[i < n ? i : bm * FBM] * Dd + sw;       // rows past the end: any valid row, ignored later
         bsrc[s] = B + (long)d.hi_idx[j < m ? j : bn * FBN] * Dd + sw;
     }
@@ -729,28 +651,30 @@ __global__ __launch_bounds__(256) void k_filter_dma(Dev d, int m_max, int ntiles
         else wait_stage_barrier<0>();
         // every wave is past its reads of the buffer of stage kt-1: refill it with stage kt+DNS-1
         if (kt + DNS - 1 < kt1) stage(cur == 0 ? DNS - 1 : cur - 1, kt + DNS - 1);
-        const unsigned abase = lds_a + cur * (FBM * DBK * 2), bbase = lds_b + cur * (FBN * DBK * 2);
-        v4i fa[DBK / 16][2], fb[DBK / 16][2];
+        const unsigned abase = lds_a + cur * (FBM * DBK), bbase = lds_b + cur * (FBN * DBK);
+        v4i fa[2][2], fb[2][2];                          // [t]: lanes < 32 hold K 32 t .. +16 of their row, lanes >= 32 the next 16
 #pragma unroll
-        for (int t = 0; t < DBK / 16; ++t) {
+        for (int t = 0; t < 2; ++t) {
             const int c = t * 2 + fh;
 #pragma unroll
             for (int x = 0; x < 2; ++x) {
-                fa[t][x] = lds_read16(abase + ((aoff[x] + ((c ^ asw[x]) << 3)) << 1));
-                fb[t][x] = lds_read16(bbase + ((boff[x] + ((c ^ bsw[x]) << 3)) << 1));
+                fa[t][x] = lds_read16(abase + aoff[x] + ((c ^ asw[x]) << 4));
+                fb[t][x] = lds_read16(bbase + boff[x] + ((c ^ bsw[x]) << 4));
             }
         }
+        lds_wait<0>(fa[0][0], fa[0][1], fb[0][0], fb[0][1]);
+        lds_wait<0>(fa[1][0], fa[1][1], fb[1][0], fb[1][1]);
+        v8i av[2], bv[2];                               // a lane's 32 K values of the stage: its two 16-byte fragments
 #pragma unroll
-        for (int t = 0; t < DBK / 16; ++t) {
-            if (t == 0) lds_wait<4>(fa[t][0], fa[t][1], fb[t][0], fb[t][1]);      // reads retire in order: 4 younger ones may be pending
-            else lds_wait<0>(fa[t][0], fa[t][1], fb[t][0], fb[t][1]);
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, fa[t][mi]), __builtin_bit_cast(half8, fb[t][ni]),
-                                                                         acc[mi][ni], 0, 0, 0);
+        for (int x = 0; x < 2; ++x) {
+            av[x] = v8i{fa[0][x].x, fa[0][x].y, fa[0][x].z, fa[0][x].w, fa[1][x].x, fa[1][x].y, fa[1][x].z, fa[1][x].w};
+            bv[x] = v8i{fb[0][x].x, fb[0][x].y, fb[0][x].z, fb[0][x].w, fb[1][x].x, fb[1][x].y, fb[1][x].z, fb[1][x].w};
         }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)       // K = 64 per instruction, formats fp8 x fp8, block scales 2^0
+                acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av[mi], bv[ni], acc[mi][ni], 0, 0, 0, 127, 0, 127);
         cur = cur + 1 == DNS ? 0 : cur + 1;
     }
     filter_epilogue<FACE>(d, acc, reinterpret_cast<float *>(&As2[0][0]), bm, bn, n, m, accum);
@@ -789,8 +713,8 @@ __device__ __forceinline__ void apply_body(const Dev &d, int bid) {
             feat::ema_row(d.face_curr + s * d.Df, d.face_smooth + s * d.Df, IN(d, face_feats) + det * d.Df, d.Df,
                           d.has_face[s] != 0, d.ema_a, d.ema_b);
         if (d.filter) {
-            feat::to_half_row(IN(d, feats) + det * d.D, d.body_h + s * d.D, d.body_n + s, d.D);
-            if (d.Df) feat::to_half_row(IN(d, face_feats) + det * d.Df, d.face_h + s * d.Df, d.face_n + s, d.Df);
+            feat::to_q8_row(IN(d, feats) + det * d.D, d.body_h + s * d.D, d.body_n + s, d.D);
+            if (d.Df) feat::to_q8_row(IN(d, face_feats) + det * d.Df, d.face_h + s * d.Df, d.face_n + s, d.Df);
         }
         if (threadIdx.x == 0) { d.has_body[s] = 1; if (d.Df) d.has_face[s] = 1; }
         return;
@@ -1007,8 +931,8 @@ __device__ __forceinline__ void birth_body(const Dev &d, int k) {
         d.face_curr[s * d.Df + c] = v; d.face_smooth[s * d.Df + c] = v;
     }
     if (d.filter) {
-        feat::to_half_row(IN(d, feats) + det * d.D, d.body_h + s * d.D, d.body_n + s, d.D);
-        if (d.Df) feat::to_half_row(IN(d, face_feats) + det * d.Df, d.face_h + s * d.Df, d.face_n + s, d.Df);
+        feat::to_q8_row(IN(d, feats) + det * d.D, d.body_h + s * d.D, d.body_n + s, d.D);
+        if (d.Df) feat::to_q8_row(IN(d, face_feats) + det * d.Df, d.face_h + s * d.Df, d.face_n + s, d.Df);
     }
 }
 
@@ -1210,8 +1134,8 @@ static void tracker_layout(bts_tracker *t, char *base, size_t &off) {
     SLOT(d.x3, int32_t, T); SLOT(d.y3, int32_t, M);
     SLOT(d.drop_t, uint8_t, T); SLOT(d.drop_l, uint8_t, T); SLOT(d.lap_hdr, int32_t, 3 * BTS_LAP_HDR_INTS);
     if (d.filter) {
-        SLOT(d.body_h, _Float16, T * D); SLOT(d.det_h, _Float16, M * D); SLOT(d.body_n, float, T); SLOT(d.det_n, float, M);
-        SLOT(d.face_h, _Float16, T * Df); SLOT(d.dface_h, _Float16, M * Df); SLOT(d.face_n, float, T); SLOT(d.dface_n, float, M);
+        SLOT(d.body_h, uint8_t, T * D); SLOT(d.det_h, uint8_t, M * D); SLOT(d.body_n, float, T); SLOT(d.det_n, float, M);
+        SLOT(d.face_h, uint8_t, T * Df); SLOT(d.dface_h, uint8_t, M * Df); SLOT(d.face_n, float, T); SLOT(d.dface_n, float, M);
         SLOT(d.approx, float, T * M); SLOT(d.approx_f, float, d.Df ? T * M : 1);
         d.cb_ld = (int)((M + 63) / 64) * 2;        // 64 columns = one aligned 8-byte word
         SLOT(d.cbits, uint32_t, T * (size_t)d.cb_ld);
@@ -1252,9 +1176,10 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
     d.max_time_lost = (int)((double)cfg->frame_rate / 30.0 * cfg->track_buffer);    // D:1276-1277
     d.record = cfg->record_costs ? 1 : 0;
     // the float16 pre-filter needs 16-byte rows of halves; otherwise the dense float32 form is used
-    d.filter = (cfg->appearance_mode == BTS_APPEARANCE_FILTER && d.D % 8 == 0 && d.Df % 8 == 0) ? 1 : 0;
-    d.eps_body = 1.1f / 1024.0f + (float)d.D / 4194304.0f;
-    d.eps_face = 1.1f / 1024.0f + (float)d.Df / 4194304.0f;
+    // the pre-filter works on 64-element K steps; other feature widths take the dense float32 path
+    d.filter = (cfg->appearance_mode == BTS_APPEARANCE_FILTER && d.D % DBK == 0 && d.Df % DBK == 0) ? 1 : 0;
+    d.eps_body = feat::q8_cos_error(d.D);
+    d.eps_face = feat::q8_cos_error(d.Df ? d.Df : 1);
     size_t off = 0;
     tracker_layout(t, nullptr, off);
     const int64_t e_cap = (int64_t)d.T * d.Mx;
@@ -1391,7 +1316,7 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
     int split = 1;
     const int ftiles = bts_cdiv(T, FBM) * bts_cdiv(mc, FBN);
     {
-        const int kt_all = bts_cdiv(d.D, FBK);
+        const int kt_all = bts_cdiv(d.D, DBK);
         while (ftiles * split < 256 && split * 2 <= kt_all && split < 16) split *= 2;
     }
     const int accum = split > 1;
@@ -1400,13 +1325,11 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
     if (d.filter) {
         // Kalman predict rides in the pre-filter's launch (independent work, consecutive workgroups)
         seg_begin(BTS_SEG_K_FILTER);
-        if (d.D % DBK == 0) { LAUNCH(k_filter_dma<false>, dim3(ftiles * split + kf_blocks), dim3(256), mc, ftiles, split, accum); }
-        else { LAUNCH(k_filter<false>, dim3(ftiles * split + kf_blocks), dim3(256), mc, ftiles, split, accum); }
+        LAUNCH(k_filter_dma<false>, dim3(ftiles * split + kf_blocks), dim3(256), mc, ftiles, split, accum);
         seg_end(BTS_SEG_K_FILTER);
         if (d.Df) {
-            const int fsplit = split < bts_cdiv(d.Df, FBK) ? split : bts_cdiv(d.Df, FBK);
-            if (d.Df % DBK == 0) { LAUNCH(k_filter_dma<true>, dim3(ftiles * fsplit), dim3(256), mc, ftiles, fsplit, accum); }
-            else { LAUNCH(k_filter<true>, dim3(ftiles * fsplit), dim3(256), mc, ftiles, fsplit, accum); }
+            const int fsplit = split < bts_cdiv(d.Df, DBK) ? split : bts_cdiv(d.Df, DBK);
+            LAUNCH(k_filter_dma<true>, dim3(ftiles * fsplit), dim3(256), mc, ftiles, fsplit, accum);
         }
     } else {
         seg_begin(BTS_SEG_PREDICT);

@@ -138,6 +138,12 @@ int bts_dedupe_pairs(bts_context *ctx, const double *a_tlbr, const uint8_t *a_f3
                      int n, const double *b_tlbr, const uint8_t *b_f32, const int32_t *age_b, int m,
                      double thresh, uint8_t *drop_a, uint8_t *drop_b, bts_stream stream);
 
+/* Diagnostics of the appearance pre-filter's 8-bit quantiser (the pre-filter never decides a cost -- it selects
+ * the pairs that get the exact float32 dot product -- but its error model must hold): y[i] = dequantise(
+ * quantise(x[i])) for n floats, and the model |y - x| <= rel |x| + abs the candidate bound is derived from. */
+int bts_debug_q8_roundtrip(bts_context *ctx, const float *x, float *y, int n, bts_stream stream);
+int bts_debug_q8_model(double *rel, double *abs_, double *scale);
+
 /* Detection-side part association: find_most_relevant_object (D:1763-1791, IoU of integer boxes per
  * bbox_iou_by_box D:1715-1729) applied to each base box in order, `picks` times per base (1 for
  * head->body / face->head D:1379-1393, 2 for the hand1/hand2 picks D:1401-1409).  Each pick takes the

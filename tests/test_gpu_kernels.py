@@ -410,3 +410,29 @@ def test_errors_are_loud(bts):
         bts._lib.check(rc)
     rc = lib.bts_lapjv(ctx.handle, None, 2, 2, 2, float("inf"), None, None, None)
     assert rc == -1
+
+
+def test_prefilter_quantiser_error_model(bts):
+    """The candidate bound of the appearance pre-filter assumes |q(x) - x| <= rel |x| + abs for every component x of
+    a unit vector.  Sweep the whole range on the device: dense log-spaced magnitudes, both signs, exact powers of two,
+    values around every rounding boundary, zero, the largest component (1.0)."""
+    import ctypes, torch
+    lib = bts._lib.load(require_gpu=True)
+    rel, ab, sc = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    bts._lib.check(lib.bts_debug_q8_model(ctypes.byref(rel), ctypes.byref(ab), ctypes.byref(sc)))
+    mags = np.concatenate([np.logspace(-12, 0, 400000), 2.0 ** np.arange(-30, 1), np.linspace(0.0, 1.0, 200001),
+                           (1.0 + np.arange(0, 64) / 64.0)[None, :].repeat(20, 0).ravel() * np.repeat(2.0 ** -np.arange(1, 21), 64)])
+    x = np.concatenate([mags, -mags]).astype(np.float32)
+    x = x[np.abs(x) <= 1.0]
+    dx = torch.from_numpy(x).cuda()
+    dy = torch.empty_like(dx)
+    bts._lib.check(lib.bts_debug_q8_roundtrip(bts._lib.default_context().handle, bts._lib.ptr(dx), bts._lib.ptr(dy), len(x),
+                                              bts._lib.current_stream()))
+    y = dy.cpu().numpy().astype(np.float64)
+    err = np.abs(y - x.astype(np.float64))
+    bound = rel.value * np.abs(x.astype(np.float64)) + ab.value
+    assert np.isfinite(y).all() and (err <= bound).all(), (float((err - bound).max()), float(x[np.argmax(err - bound)]))
+    assert np.abs(y).max() <= 1.0 + rel.value and y[x == 1.0][0] == 1.0          # no saturation at the largest component
+    # the model is not vacuous: the relative term is nearly attained
+    big = np.abs(x) > 0.01
+    assert (err[big] / np.abs(x[big])).max() > 0.8 * rel.value
