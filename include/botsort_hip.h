@@ -158,7 +158,7 @@ int bts_associate_parts(bts_context *ctx, const int32_t *base_boxes, const int32
 /* -------------------------------------------------- whole-frame tracker, BoTSORT.update D:1414-1639 */
 
 /* How the stage-1/3 appearance term (D:1539-1554, D:1590-1602) is evaluated inside the tracker:
- * FILTER: float16-MFMA pre-filter over float16 shadows of the features + exact float32 recomputation
+ * FILTER: fp8-MFMA pre-filter over 8-bit unit-vector shadows of the features + exact float32 recomputation
  *         of every pair that could pass the appearance gate (results identical to DENSE up to float32
  *         summation order; no N x M matrix is materialised);
  * DENSE:  the dense float32 similarity and cost matrices, as the reference forms them. */
