@@ -6,6 +6,11 @@
 
 namespace bscan {
 
+// Workgroup barrier for hand-offs through LDS only: __syncthreads() also waits for every outstanding global
+// store of the wavefront to be acknowledged (a memory round trip, ~1-2 us) -- needed only when global data
+// written before the barrier is read by other threads after it.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // exclusive scan of one int per thread; *total = sum over the workgroup.  smem: >= 17 ints.
 __device__ __forceinline__ int exscan(int v, int *smem, int *total) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -15,9 +20,9 @@ __device__ __forceinline__ int exscan(int v, int *smem, int *total) {
         const int t = __shfl_up(incl, off);
         if (lane >= off) incl += t;
     }
-    __syncthreads();                       // smem may still be read from a previous call
+    lds_barrier();                       // smem may still be read from a previous call
     if (lane == 63) smem[wid] = incl;
-    __syncthreads();
+    lds_barrier();
     if (wid == 0) {
         int w = lane < nw ? smem[lane] : 0;
         int wi = w;
@@ -29,7 +34,7 @@ __device__ __forceinline__ int exscan(int v, int *smem, int *total) {
         if (lane < nw) smem[lane] = wi - w;          // exclusive wave offsets
         if (lane == nw - 1) smem[16] = wi;           // grand total
     }
-    __syncthreads();
+    lds_barrier();
     *total = smem[16];
     return smem[wid] + incl - v;
 }
@@ -63,7 +68,7 @@ __device__ __forceinline__ int compact(int L, int *smem, Pred pred, Emit emit) {
         for (int k = lo; k < hi; ++k)
             if (pred(k)) emit(pos++, k);
     }
-    __syncthreads();
+    lds_barrier();
     return total;
 }
 
@@ -92,9 +97,9 @@ __device__ __forceinline__ int compact_ws_r(int L, int chunk, int *smem, Load lo
         bal[j] = __ballot(inb && keep);
         cnt += __popcll(bal[j]);
     }
-    __syncthreads();                       // smem may still be read from a previous call
+    lds_barrier();                       // smem may still be read from a previous call
     if (lane == 0) smem[wid] = cnt;
-    __syncthreads();
+    lds_barrier();
     int pos = 0, total = 0;
     for (int w = 0; w < nw; ++w) { const int c = smem[w]; if (w < wid) pos += c; total += c; }
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -103,7 +108,7 @@ __device__ __forceinline__ int compact_ws_r(int L, int chunk, int *smem, Load lo
         if ((bal[j] >> lane) & 1ull) emit(pos + __popcll(bal[j] & below), base + j * 64 + lane, val[j]);
         pos += __popcll(bal[j]);
     }
-    __syncthreads();
+    lds_barrier();
     return total;
 }
 

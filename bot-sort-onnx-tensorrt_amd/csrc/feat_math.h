@@ -5,6 +5,7 @@
 // without a row passes active = false (it only takes part in the barriers).
 #pragma once
 #include <hip/hip_runtime.h>
+#include "block_scan.h"
 
 namespace feat {
 
@@ -19,9 +20,9 @@ __device__ __forceinline__ float block_sum(float v) {
 #pragma unroll
     for (int off = 32; off; off >>= 1) v += __shfl_xor(v, off);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    __syncthreads();                      // protects `part` across back-to-back calls
+    bscan::lds_barrier();                 // protects `part` across back-to-back calls (LDS-only hand-off)
     if (lane == 0) part[wid] = v;
-    __syncthreads();
+    bscan::lds_barrier();
     const int w0 = row_group() * (ROW_G / 64);
     return ((part[w0] + part[w0 + 1]) + part[w0 + 2]) + part[w0 + 3];
 }

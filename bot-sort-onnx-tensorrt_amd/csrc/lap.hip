@@ -103,6 +103,20 @@ __device__ int block_exscan_plain(int32_t *arr, int len, int32_t *tmp) {
     return total;
 }
 
+// same for an LDS array (hand-offs through LDS only: no wait for global stores at the barriers)
+__device__ int block_exscan_lds(int32_t *arr, int len, int32_t *tmp) {
+    const int nth = blockDim.x, tid = threadIdx.x;
+    const int per = (len + nth - 1) / nth;
+    const int lo = min(len, tid * per), hi = min(len, lo + per);
+    int s = 0;
+    for (int k = lo; k < hi; ++k) s += arr[k];
+    int total;
+    int run = bscan::exscan(s, tmp, &total);
+    for (int k = lo; k < hi; ++k) { const int v = arr[k]; arr[k] = run; run += v; }
+    bscan::lds_barrier();
+    return total;
+}
+
 // read-only walk to the root: used once every union is done, so that what it returns is final
 // (a compressing find running next to it could still move parent[] entries to non-root ancestors)
 __device__ int find_root_ro(const int32_t *parent, int x) {
@@ -209,14 +223,14 @@ __device__ int small_pipeline(const LapArgs &A, SmallPipe &L, int E, int n, int 
         ec[k] = (cached && e < E) ? w.e_col[e] : 0;
     }
     for (int k = tid; k < n + m; k += nth) tab[k] = 0;
-    __syncthreads();
+    bscan::lds_barrier();
     if (cached) {
 #pragma unroll
         for (int k = 0; k < EC; ++k) if (er[k] >= 0) { atomicAdd(&tab[er[k]], 1); atomicAdd(&tab[n + ec[k]], 1); }      // (row -1: vacant slot)
     } else {
         for (int e = tid; e < E; e += nth) { const int i = w.e_row[e]; if (i >= 0) { atomicAdd(&tab[i], 1); atomicAdd(&tab[n + w.e_col[e]], 1); } }
     }
-    __syncthreads();
+    bscan::lds_barrier();
     auto classify = [&](int e, int i, int j) {            // isolated pairs are final; the rest is queued
         if (i < 0) return;
         if (tab[i] == 1 && tab[n + j] == 1) { A.x[i] = j; A.y[j] = i; }
@@ -228,7 +242,7 @@ __device__ int small_pipeline(const LapArgs &A, SmallPipe &L, int E, int n, int 
     } else {
         for (int e = tid; e < E; e += nth) classify(e, w.e_row[e], w.e_col[e]);
     }
-    __syncthreads();
+    bscan::lds_barrier();
     const int EH = L.EH;
     if (EH == 0) return 0;
     if (EH > SM_EH) return -1;
@@ -241,36 +255,36 @@ __device__ int small_pipeline(const LapArgs &A, SmallPipe &L, int E, int n, int 
         if (!(atomicOr(&tab[i], FIRST) & FIRST)) { const int s = atomicAdd(&L.NA, 1); L.arow[s] = i; atomicExch(&tab[i], FIRST | s); }
         if (!(atomicOr(&tab[n + j], FIRST) & FIRST)) { const int s = atomicAdd(&L.MA, 1); L.acol[s] = j; atomicExch(&tab[n + j], FIRST | s); }
     }
-    __syncthreads();
+    bscan::lds_barrier();
     const int NA = L.NA, MA = L.MA;
     for (int h = tid; h < EH; h += nth) { L.hr[h] = tab[L.hr[h]] & ~FIRST; L.hc[h] = tab[n + L.hc[h]] & ~FIRST; }      // (row, col) -> slots, in place
-    __syncthreads();                                      // the table is dead from here on
+    bscan::lds_barrier();                                      // the table is dead from here on
     for (int s = tid; s < NA; s += nth) { L.parent[s] = s; L.rptr[s] = 0; L.ecnt[s] = 0; }
     for (int s = tid; s < MA; s += nth) L.parent[SM_EH + s] = SM_EH + s;
-    __syncthreads();
+    bscan::lds_barrier();
     for (int h = tid; h < EH; h += nth) { unite(L.parent, L.hr[h], SM_EH + L.hc[h]); atomicAdd(&L.rptr[L.hr[h]], 1); }
-    __syncthreads();
+    bscan::lds_barrier();
     for (int s = tid; s < NA; s += nth) {                 // roots (read-only walks) hand out component ids
         const int r = find_root_lds(L.parent, s);
         L.comp[s] = r;
         if (r == s) { const int c = atomicAdd(&L.C, 1); L.cid[s] = c; L.crp[c] = 0; L.ccp[c] = 0; }
     }
     for (int s = tid; s < MA; s += nth) L.ccomp[s] = find_root_lds(L.parent, SM_EH + s);
-    __syncthreads();
+    bscan::lds_barrier();
     const int C = L.C;
     for (int s = tid; s < NA; s += nth) { const int c = L.cid[L.comp[s]]; L.comp[s] = c; atomicAdd(&L.crp[c], 1); atomicAdd(&L.ecnt[c], L.rptr[s]); }
     for (int s = tid; s < MA; s += nth) { const int c = L.cid[L.ccomp[s]]; L.ccomp[s] = c; atomicAdd(&L.ccp[c], 1); }
-    __syncthreads();
+    bscan::lds_barrier();
     for (int c = tid; c < C; c += nth) { atomicMax(&L.maxr, L.crp[c]); atomicMax(&L.maxc, L.ccp[c]); atomicMax(&L.maxe, L.ecnt[c]); }
-    __syncthreads();
+    bscan::lds_barrier();
     const bool fits = L.maxr <= 64 && L.maxc <= 64 && L.maxe <= SM_EDGES;
     if (!fits) return -1;
-    block_exscan_plain(L.crp, C, tmp);
-    block_exscan_plain(L.ccp, C, tmp);
+    block_exscan_lds(L.crp, C, tmp);
+    block_exscan_lds(L.ccp, C, tmp);
     if (tid == 0) { L.crp[C] = NA; L.ccp[C] = MA; }
     int32_t *cursor = L.cursor(), *cur_r = L.cur_r(), *cur_c = L.cur_c();
     for (int c = tid; c < C; c += nth) { cur_r[c] = L.crp[c]; cur_c[c] = L.ccp[c]; }
-    __syncthreads();
+    bscan::lds_barrier();
     // rows / columns grouped by component; edge ranges handed out in grouped row order, so that the
     // edges of one component are one contiguous block
     for (int s = tid; s < NA; s += nth) { const int pos = atomicAdd(&cur_r[L.comp[s]], 1); L.rpos[s] = pos; L.gstart[pos] = L.rptr[s]; }
@@ -279,10 +293,10 @@ __device__ int small_pipeline(const LapArgs &A, SmallPipe &L, int E, int n, int 
         L.lane_of_col[s] = pos - L.ccp[c];
         w.colid[pos] = L.acol[s];
     }
-    __syncthreads();
-    block_exscan_plain(L.gstart, NA, tmp);
+    bscan::lds_barrier();
+    block_exscan_lds(L.gstart, NA, tmp);
     if (tid == 0) L.gstart[NA] = EH;
-    __syncthreads();
+    bscan::lds_barrier();
     for (int s = tid; s < NA; s += nth) {
         const int pos = L.rpos[s], e0 = L.gstart[pos];
         cursor[s] = e0;
@@ -291,7 +305,7 @@ __device__ int small_pipeline(const LapArgs &A, SmallPipe &L, int E, int n, int 
     for (int c = tid; c < C; c += nth)
         w.cdesc[c] = make_int4(L.crp[c], L.ccp[c], (L.crp[c + 1] - L.crp[c]) | ((L.ccp[c + 1] - L.ccp[c]) << 8) | (L.ecnt[c] << 16),
                                L.gstart[L.crp[c]]);
-    __syncthreads();
+    bscan::lds_barrier();
     if (nth >= 1024) {
 #pragma unroll
         for (int k = 0; k < HC; ++k) {
