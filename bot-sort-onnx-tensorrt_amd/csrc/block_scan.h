@@ -80,24 +80,33 @@ __device__ __forceinline__ int compact(int L, int *smem, Pred pred, Emit emit) {
 //     registers to `emit` (no second, dependent read).
 // load(k, v) -> keep?, may set v;  emit(position, k, v).  Up to 16 rounds per wavefront (L <= 16 * 64 *
 // waves, i.e. 16384 at 1024 threads); longer inputs take the chunk-per-thread form above.
-template <int R, class Load, class Emit>
-__device__ __forceinline__ int compact_ws_r(int L, int chunk, int *smem, Load load, Emit emit) {
+// load(k) -> int: first-level fetch of index k (the payload, e.g. the slot a list entry names);
+// pred(k, v) -> keep?: may fetch through the payload (second level);  emit(position, k, v).
+// The two levels are separate passes over the wavefront's R rounds, so that all first-level loads are in flight
+// together and then all second-level ones: two memory latencies for the whole selection, whatever R is.
+// (A predicate written `a && b` with loads on both sides would serialise them behind branches: use `&`.)
+template <int R, class Load, class Pred, class Emit>
+__device__ __forceinline__ int compact_ws_r(int L, int chunk, int *smem, Load load, Pred pred, Emit emit) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int base = wid * chunk;
     int val[R];
     unsigned long long bal[R];
     int cnt = 0;
-    // no branches around the loads: all R of them are in flight together (out-of-range lanes re-read index 0)
+    // no branches around the loads (out-of-range lanes re-read index 0)
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const int k = base + j * 64 + lane;
+        val[j] = load((j * 64 < chunk && k < L) ? k : 0);
+    }
 #pragma unroll
     for (int j = 0; j < R; ++j) {
         const int k = base + j * 64 + lane;
         const bool inb = j * 64 < chunk && k < L;
-        val[j] = 0;
-        const bool keep = load(inb ? k : 0, val[j]);
+        const bool keep = pred(inb ? k : 0, val[j]);
         bal[j] = __ballot(inb && keep);
         cnt += __popcll(bal[j]);
     }
-    lds_barrier();                       // smem may still be read from a previous call
+    lds_barrier();                         // smem may still be read from a previous call
     if (lane == 0) smem[wid] = cnt;
     lds_barrier();
     int pos = 0, total = 0;
@@ -112,15 +121,28 @@ __device__ __forceinline__ int compact_ws_r(int L, int chunk, int *smem, Load lo
     return total;
 }
 
-template <class Load, class Emit>
-__device__ __forceinline__ int compact_ws(int L, int *smem, Load load, Emit emit) {
+template <class Load, class Pred, class Emit>
+__device__ __forceinline__ int compact_ws(int L, int *smem, Load load, Pred pred, Emit emit) {
     const int nw = blockDim.x >> 6;
     const int chunk = ((L + nw - 1) / nw + 63) & ~63, rounds = chunk >> 6;
     if (L <= 0) return 0;
-    if (rounds <= 1) return compact_ws_r<1>(L, chunk, smem, load, emit);
-    if (rounds <= 4) return compact_ws_r<4>(L, chunk, smem, load, emit);
-    if (rounds <= 16) return compact_ws_r<16>(L, chunk, smem, load, emit);
-    return compact(L, smem, [&](int k) { int v = 0; return load(k, v); }, [&](int p, int k) { int v = 0; (void)load(k, v); emit(p, k, v); });
+    if (rounds <= 1) return compact_ws_r<1>(L, chunk, smem, load, pred, emit);
+    if (rounds <= 4) return compact_ws_r<4>(L, chunk, smem, load, pred, emit);
+    if (rounds <= 16) return compact_ws_r<16>(L, chunk, smem, load, pred, emit);
+    return compact(L, smem, [&](int k) { return pred(k, load(k)); }, [&](int p, int k) { emit(p, k, load(k)); });
+}
+
+// for (k = tid; k < L; k += nth) body(k, load(k)) with the loads of B iterations in flight together
+template <int B, class Load, class Body>
+__device__ __forceinline__ void for_batched(int L, Load load, Body body) {
+    const int tid = threadIdx.x, nth = blockDim.x;
+    for (int k0 = tid; k0 < L; k0 += B * nth) {
+        int v[B];
+#pragma unroll
+        for (int j = 0; j < B; ++j) { const int k = k0 + j * nth; v[j] = load(k < L ? k : 0); }
+#pragma unroll
+        for (int j = 0; j < B; ++j) { const int k = k0 + j * nth; if (k < L) body(k, v[j]); }
+    }
 }
 
 }  // namespace bscan

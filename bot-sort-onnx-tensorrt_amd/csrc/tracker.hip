@@ -22,7 +22,6 @@ enum {   // hdr[] fields
     H_ERR, H_NCONF, H_ALLF32, H_NFREE, H_NDETS, H_NKEEP, H_NB, H_NRF, H_NL0, H_NL1, H_NBORN,
     H_DIMS1 = 24, H_DIMS2 = 26, H_DIMS3 = 28, H_SIZE = 32
 };
-enum { F_REFIND = 1, F_LOSTNOW = 2, F_REMOVEDNOW = 4 };
 enum { ERR_TRACK_CAPACITY = 1, ERR_LAP_EDGES = 2 };
 
 // The frame's inputs: eager steps carry them in the kernel arguments; under hipGraph replay the
@@ -43,7 +42,7 @@ struct Dev {
     int max_time_lost;
     // track table
     double *mean, *cov;
-    uint8_t *f32, *in_removed, *in_use, *flag;
+    uint8_t *f32, *in_removed, *in_use;
     int32_t *state, *is_activated, *track_id, *frame_id, *start_frame, *tracklet_len, *det_index;
     float *score;
     float *body_curr, *body_smooth, *face_curr, *face_smooth;
@@ -75,8 +74,8 @@ struct Dev {
 #define IN(d, f) ((d).in ? (d).in->f : (d).iv.f)
 
 // ---- single-workgroup helpers: bscan::exscan / bscan::compact (block_scan.h) ------------------------
-template <class Load, class Emit>
-__device__ __forceinline__ int block_compact(int L, int32_t *tmp, Load load, Emit emit) { return bscan::compact_ws(L, tmp, load, emit); }
+template <class Load, class Pred, class Emit>
+__device__ __forceinline__ int block_compact(int L, int32_t *tmp, Load load, Pred pred, Emit emit) { return bscan::compact_ws(L, tmp, load, pred, emit); }
 __device__ __forceinline__ int block_exscan_i(int v, int32_t *tmp, int *total) { return bscan::exscan(v, tmp, total); }
 
 __device__ __forceinline__ void load_state(const Dev &d, int slot, double m[8], double P[64]) {
@@ -119,16 +118,19 @@ __device__ __forceinline__ void prep_pool(const Dev &d) {
     __shared__ int32_t tmp[1024];
     __shared__ int s_allf32;
     int32_t *h = d.hdr;
-    const int tid = threadIdx.x, nth = blockDim.x;
+    const int tid = threadIdx.x;
     const int nt = h[H_NTRACKED], nl = h[H_NLOST];
     if (tid == 0) s_allf32 = 1;
-    const int nconf = block_compact(nt, tmp, [&](int k, int &s) { s = d.tracked[k]; return d.is_activated[s] != 0; },
+    const int nconf = block_compact(nt, tmp, [&](int k) { return d.tracked[k]; }, [&](int k, int s) { return d.is_activated[s] != 0; },
                                     [&](int p, int k, int s) { d.pool_slot[p] = s; });
-    for (int k = tid; k < nl; k += nth) d.pool_slot[nconf + k] = d.lost[k];
+    bscan::for_batched<8>(nl, [&](int k) { return d.lost[k]; }, [&](int k, int s) { d.pool_slot[nconf + k] = s; });
     const int N = nconf + nl;
     __syncthreads();
-    int all32 = 1;
-    for (int k = tid; k < N; k += nth) { const int s = d.pool_slot[k]; d.flag[s] = 0; if (!d.f32[s]) all32 = 0; }
+    // "every pool row still holds float32 state" (np.asarray of the batch is then float32, Q10) can only be true on
+    // the frame after the one that activated its births at once (frame 1, D:565-566): later births enter the pool
+    // through an update, which makes their state float64
+    int all32 = h[H_FRAME] == 1 ? 1 : 0;
+    if (all32) bscan::for_batched<8>(N, [&](int k) { return d.pool_slot[k]; }, [&](int k, int s) { if (!d.f32[s]) all32 = 0; });
     if (!all32) s_allf32 = 0;
     __syncthreads();
     if (tid == 0) {
@@ -144,8 +146,8 @@ __device__ __forceinline__ void prep_unconfirmed(const Dev &d) {
     __shared__ int32_t tmp[1024];
     int32_t *h = d.hdr;
     const int nt = h[H_NTRACKED];
-    const int nunc = block_compact(nt, tmp, [&](int k, int &s) { s = d.tracked[k]; return d.is_activated[s] == 0; },
-                                   [&](int p, int k, int s) { d.unc_slot[p] = s; d.flag[s] = 0; });
+    const int nunc = block_compact(nt, tmp, [&](int k) { return d.tracked[k]; }, [&](int k, int s) { return d.is_activated[s] == 0; },
+                                   [&](int p, int k, int s) { d.unc_slot[p] = s; });
     if (threadIdx.x == 0) { h[H_NUNC] = nunc; h[H_DIMS3] = nunc; }
 }
 
@@ -164,9 +166,10 @@ __device__ __forceinline__ void prep_dets(const Dev &d) {
         d.det_xywh[j * 4 + 0] = tx + w / 2; d.det_xywh[j * 4 + 1] = ty + hh / 2;                     // D:663-670
         d.det_xywh[j * 4 + 2] = w; d.det_xywh[j * 4 + 3] = hh;
     }
-    const int nhi = block_compact(m, tmp, [&](int j, int &) { return (double)scores[j] > d.high; },
+    const int nhi = block_compact(m, tmp, [&](int j) { return __float_as_int(scores[j]); }, [&](int j, int v) { return (double)__int_as_float(v) > d.high; },
                                   [&](int p, int j, int) { d.hi_idx[p] = j; });
-    const int nlo = block_compact(m, tmp, [&](int j, int &) { const double s = (double)scores[j]; return s <= d.high && s >= d.low; },
+    const int nlo = block_compact(m, tmp, [&](int j) { return __float_as_int(scores[j]); },
+                                  [&](int j, int v) { const double s = (double)__int_as_float(v); return s <= d.high && s >= d.low; },
                                   [&](int p, int j, int) { d.lo_idx[p] = j; });
     if (tid < 3 * BTS_LAP_HDR_INTS) d.lap_hdr[tid] = 0;
     if (tid == 0) {
@@ -178,17 +181,29 @@ __device__ __forceinline__ void prep_dets(const Dev &d) {
 
 // slot recycling: a slot is free iff it is on neither list (its track was removed, dropped as a
 // duplicate or filtered by quirk Q6).  Rebuilt here, off the critical path: births happen in tk_merge.
+constexpr int FREE_BITS_WORDS = 8192;       // LDS bitmap of the slots in use: tables up to 262144 tracks
 __device__ __forceinline__ void prep_free(const Dev &d) {
     __shared__ int32_t tmp[1024];
+    __shared__ uint32_t used[FREE_BITS_WORDS];
     int32_t *h = d.hdr;
     const int tid = threadIdx.x, nth = blockDim.x;
     const int nt = h[H_NTRACKED], nl = h[H_NLOST];
-    for (int s = tid; s < d.T; s += nth) d.in_use[s] = 0;
-    __syncthreads();
-    for (int k = tid; k < nt; k += nth) d.in_use[d.tracked[k]] = 1;
-    for (int k = tid; k < nl; k += nth) d.in_use[d.lost[k]] = 1;
-    __syncthreads();
-    const int nfree = block_compact(d.T, tmp, [&](int s, int &) { return !d.in_use[s]; }, [&](int p, int s, int) { d.free_list[p] = s; });
+    const bool lds = d.T <= 32 * FREE_BITS_WORDS;
+    if (lds) {                               // marks go to LDS: the lists are read coalesced, nothing is scattered to memory
+        for (int k = tid; k < (d.T + 31) / 32; k += nth) used[k] = 0u;
+        __syncthreads();
+        bscan::for_batched<4>(nt, [&](int k) { return d.tracked[k]; }, [&](int k, int s) { atomicOr(&used[s >> 5], 1u << (s & 31)); });
+        bscan::for_batched<8>(nl, [&](int k) { return d.lost[k]; }, [&](int k, int s) { atomicOr(&used[s >> 5], 1u << (s & 31)); });
+        __syncthreads();
+    } else {
+        for (int s = tid; s < d.T; s += nth) d.in_use[s] = 0;
+        __syncthreads();
+        bscan::for_batched<4>(nt, [&](int k) { return d.tracked[k]; }, [&](int k, int s) { d.in_use[s] = 1; });
+        bscan::for_batched<8>(nl, [&](int k) { return d.lost[k]; }, [&](int k, int s) { d.in_use[s] = 1; });
+        __syncthreads();
+    }
+    const int nfree = block_compact(d.T, tmp, [&](int s) { return lds ? (int)((used[s >> 5] >> (s & 31)) & 1u) : (int)d.in_use[s]; },
+                                    [&](int s, int v) { return v == 0; }, [&](int p, int s, int) { d.free_list[p] = s; });
     if (tid == 0) h[H_NFREE] = nfree;
 }
 
@@ -726,8 +741,8 @@ __device__ __forceinline__ void apply_body(const Dev &d, int bid) {
     const int xq = xs[r];
     if (xq < 0) {
         if (i == 0) {
-            if (STAGE == 2) { d.state[s] = BTS_LOST; d.flag[s] |= F_LOSTNOW; }                 // D:1582-1586
-            if (STAGE == 3) { d.state[s] = BTS_REMOVED; d.flag[s] |= F_REMOVEDNOW; }           // D:1609-1612
+            if (STAGE == 2) d.state[s] = BTS_LOST;                     // D:1582-1586 (tk_merge finds them by x2 < 0)
+            if (STAGE == 3) d.state[s] = BTS_REMOVED;                  // D:1609-1612 (... by x3 < 0)
         }
         return;
     }
@@ -743,8 +758,7 @@ __device__ __forceinline__ void apply_body(const Dev &d, int bid) {
     if (d.state[s] == BTS_TRACKED) {
         d.tracklet_len[s] += 1;                         // STrack.update
     } else {
-        d.tracklet_len[s] = 0;                          // STrack.re_activate (new_id=False)
-        d.flag[s] |= F_REFIND;
+        d.tracklet_len[s] = 0;                          // STrack.re_activate (new_id=False); tk_merge: lost row with x1 >= 0
     }
     d.state[s] = BTS_TRACKED;
     d.is_activated[s] = 1;
@@ -786,8 +800,10 @@ __device__ __forceinline__ void after1_body(const Dev &d, int job) {
     if (job == 0) {
         // r_tracked: unmatched pool rows that are still Tracked (D:1569).  Matched rows are set to
         // Tracked by the stage-1 update, which runs after this launch: the state test sees pre-frame state.
-        const int N = h[H_NPOOL];
-        const int nr2 = block_compact(N, tmp, [&](int r, int &s) { s = d.pool_slot[r]; return d.x1[r] < 0 && d.state[s] == BTS_TRACKED; },
+        // (only the confirmed rows of the pool, [0, nconf), can be Tracked: the rest are the lost tracks)
+        const int N = h[H_NCONF];
+        const int nr2 = block_compact(N, tmp, [&](int r) { return d.pool_slot[r]; },
+                                      [&](int r, int s) { return (d.x1[r] < 0) & (d.state[s] == BTS_TRACKED); },
                                       [&](int p, int r, int s) {
                                           d.r2_row[p] = r; d.r2_slot[p] = s;
                                           for (int c = 0; c < 4; ++c) d.r2_tlbr[p * 4 + c] = d.pool_tlbr[r * 4 + c];
@@ -795,7 +811,7 @@ __device__ __forceinline__ void after1_body(const Dev &d, int job) {
         if (threadIdx.x == 0) { h[H_NR2] = nr2; h[H_DIMS2] = nr2; }
     } else if (job == 1) {
         const int nhi = h[H_NHI];
-        const int nleft = block_compact(nhi, tmp, [&](int q, int &det) { det = d.hi_idx[q]; return d.y1[q] < 0; },
+        const int nleft = block_compact(nhi, tmp, [&](int q) { return d.hi_idx[q]; }, [&](int q, int det) { return d.y1[q] < 0; },
                                         [&](int p, int q, int det) { d.left_hi[p] = q; d.left_det[p] = det; });
         if (threadIdx.x == 0) { h[H_NLEFT] = nleft; h[H_DIMS3 + 1] = nleft; }
     } else {
@@ -843,7 +859,7 @@ __global__ __launch_bounds__(1024) void tk_merge(Dev d) {
         for (int k = tid; k < nleft; k += nth) d.born_slot[k] = -1;
         __syncthreads();
         const int nborn_want = block_compact(
-            nleft, tmp, [&](int k, int &det) { det = d.left_det[k]; return d.y3[k] < 0 && !((double)scores[det] < d.new_thr); },
+            nleft, tmp, [&](int k) { return d.left_det[k]; }, [&](int k, int det) { return (d.y3[k] < 0) & !((double)scores[det] < d.new_thr); },
             [&](int b, int k, int det) {
                 if (b >= nfree) return;
                 const int s = d.free_list[b];
@@ -854,7 +870,7 @@ __global__ __launch_bounds__(1024) void tk_merge(Dev d) {
                 d.is_activated[s] = frame == 1 ? 1 : 0;          // D:565-566
                 d.frame_id[s] = frame; d.start_frame[s] = frame; d.tracklet_len[s] = 0;
                 d.score[s] = scores[det]; d.det_index[s] = det;
-                d.f32[s] = 1; d.in_removed[s] = 0; d.flag[s] = 0;
+                d.f32[s] = 1; d.in_removed[s] = 0;
                 d.has_body[s] = 1; d.has_face[s] = d.Df ? 1 : 0;
                 // position half of KalmanFilter.initiate (D:166-197): the duplicate test of this frame reads
                 // it while the rest of the state is still being initialised (tk_tail)
@@ -871,38 +887,49 @@ __global__ __launch_bounds__(1024) void tk_merge(Dev d) {
         }
     } else if (blockIdx.x == 1) {
         const int nt = h[H_NTRACKED];
-        const int n_keep = block_compact(nt, tmp, [&](int k, int &s) { s = d.tracked[k]; return d.state[s] == BTS_TRACKED; },
+        const int n_keep = block_compact(nt, tmp, [&](int k) { return d.tracked[k]; }, [&](int k, int s) { return d.state[s] == BTS_TRACKED; },
                                          [&](int p, int k, int s) { d.tracked2[p] = s; });
         if (tid == 0) h[H_NKEEP] = n_keep;
     } else if (blockIdx.x == 2) {
-        const int N = h[H_NPOOL];
-        const int n_rf = block_compact(N, tmp, [&](int r, int &s) { s = d.pool_slot[r]; return (d.flag[s] & F_REFIND) != 0; },
-                                       [&](int p, int r, int s) { d.tracked2[2 * d.T + p] = s; });
+        // re-found = lost rows of the pool (rows >= nconf) that stage 1 matched; no per-slot flag needed
+        const int N = h[H_NPOOL], nconf = h[H_NCONF];
+        const int n_rf = block_compact(N - nconf, tmp, [&](int k) { return d.x1[nconf + k]; }, [&](int k, int xq) { return xq >= 0; },
+                                       [&](int p, int k, int) { d.tracked2[2 * d.T + p] = d.pool_slot[nconf + k]; });
         if (tid == 0) h[H_NRF] = n_rf;
     } else if (blockIdx.x == 3) {
-        const int nl = h[H_NLOST], nunc = h[H_NUNC];
-        const int n_l0 = block_compact(nl, tmp,
-                                       [&](int k, int &s) { s = d.lost[k]; return d.state[s] != BTS_TRACKED && !d.in_removed[s]; },
+        const int nl = h[H_NLOST], nunc = h[H_NUNC], nconf = h[H_NCONF];
+        // old lost that were not re-found (x1 of their pool row < 0) and whose id is not in removed (Q6)
+        const int n_l0 = block_compact(nl, tmp, [&](int k) { return d.lost[k]; },
+                                       [&](int k, int s) { return (d.x1[nconf + k] < 0) & !d.in_removed[s]; },
                                        [&](int p, int k, int s) { d.lost2[p] = s; });
         // expiry of lost tracks (D:1623-1627); re-found ones carry frame_id == frame.  removed_stracks.extend(
         // removed_now): the ids (here: slots) are remembered for the next frames -- after the filter above (Q6)
         int gone = 0;
-        for (int k = tid; k < nl; k += nth) {
-            const int s = d.lost[k];
-            if (frame - d.frame_id[s] > d.max_time_lost) { d.state[s] = BTS_REMOVED; d.flag[s] |= F_REMOVEDNOW; d.in_removed[s] = 1; ++gone; }
+        for (int k0 = tid; k0 < nl; k0 += 8 * nth) {          // (two levels of loads, 8 iterations in flight)
+            int sl[8], fid[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const int k = k0 + j * nth; sl[j] = d.lost[k < nl ? k : 0]; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fid[j] = d.frame_id[sl[j]];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = k0 + j * nth, s = sl[j];
+                if (k < nl && frame - fid[j] > d.max_time_lost) { d.state[s] = BTS_REMOVED; d.in_removed[s] = 1; ++gone; }
+            }
         }
-        for (int k = tid; k < nunc; k += nth) {
-            const int s = d.unc_slot[k];
-            if (d.flag[s] & F_REMOVEDNOW) { d.in_removed[s] = 1; ++gone; }
-        }
+        // unconfirmed tracks that stage 3 left unmatched were removed (D:1609-1612)
+        bscan::for_batched<4>(nunc, [&](int k) { return d.x3[k]; }, [&](int k, int xq) {
+            if (xq < 0) { d.in_removed[d.unc_slot[k]] = 1; ++gone; }
+        });
         int tot_gone;
         block_exscan_i(gone, tmp, &tot_gone);
         if (tid == 0) { h[H_NL0] = n_l0; h[H_NREMOVED] += tot_gone; }
     } else {
-        const int nconf = h[H_NCONF];
-        const int n_l1 = block_compact(nconf, tmp,
-                                       [&](int r, int &s) { s = d.pool_slot[r]; return (d.flag[s] & F_LOSTNOW) && !d.in_removed[s]; },
-                                       [&](int p, int r, int s) { d.lost2[d.T + p] = s; });
+        // newly lost = stage-2 rows (the still-Tracked leftovers of stage 1, in pool order) that stage 2 left unmatched
+        const int nr2 = h[H_NR2];
+        const int n_l1 = block_compact(nr2, tmp, [&](int k) { return d.r2_slot[k]; },
+                                       [&](int k, int s) { return (d.x2[k] < 0) & !d.in_removed[s]; },
+                                       [&](int p, int k, int s) { d.lost2[d.T + p] = s; });
         if (tid == 0) h[H_NL1] = n_l1;
     }
 }
@@ -1009,12 +1036,12 @@ __global__ __launch_bounds__(1024) void tk_finalize(Dev d) {
     const int tid = threadIdx.x, nth = blockDim.x;
     if (blockIdx.x == 0) {
         const int nt2 = h[H_NKEEP] + h[H_NB] + h[H_NRF];
-        const int nt = block_compact(nt2, tmp, [&](int k, int &s) { s = tracked2_at(d, k); return !d.drop_t[k]; }, [&](int p, int k, int s) { d.tracked[p] = s; });
+        const int nt = block_compact(nt2, tmp, [&](int k) { return tracked2_at(d, k); }, [&](int k, int s) { return !d.drop_t[k]; }, [&](int p, int k, int s) { d.tracked[p] = s; });
         for (int k = tid; k < nt2; k += nth) d.drop_t[k] = 0;
         if (tid == 0) h[H_NTRACKED] = nt;
     } else {
         const int nl2 = h[H_NL0] + h[H_NL1];
-        const int nl = block_compact(nl2, tmp, [&](int k, int &s) { s = lost2_at(d, k); return !d.drop_l[k]; }, [&](int p, int k, int s) { d.lost[p] = s; });
+        const int nl = block_compact(nl2, tmp, [&](int k) { return lost2_at(d, k); }, [&](int k, int s) { return !d.drop_l[k]; }, [&](int p, int k, int s) { d.lost[p] = s; });
         for (int k = tid; k < nl2; k += nth) d.drop_l[k] = 0;
         if (tid == 0) h[H_NLOST] = nl;
     }
@@ -1023,7 +1050,7 @@ __global__ __launch_bounds__(1024) void tk_finalize(Dev d) {
 __global__ __launch_bounds__(1024) void tk_reset(Dev d) {
     const int tid = threadIdx.x, nth = blockDim.x;
     for (int s = tid; s < d.T; s += nth) {
-        d.free_list[s] = s; d.in_use[s] = 0; d.in_removed[s] = 0; d.flag[s] = 0; d.f32[s] = 0; d.state[s] = BTS_NEW;
+        d.free_list[s] = s; d.in_use[s] = 0; d.in_removed[s] = 0; d.f32[s] = 0; d.state[s] = BTS_NEW;
         d.drop_t[s] = 0; d.drop_l[s] = 0;
         d.is_activated[s] = 0; d.track_id[s] = 0; d.has_body[s] = 0; d.has_face[s] = 0;
     }
@@ -1112,7 +1139,7 @@ static void tracker_layout(bts_tracker *t, char *base, size_t &off) {
     const size_t T = d.T, M = d.Mx, D = d.D, Df = d.Df ? d.Df : 1;
 #define SLOT(ptr, type, count) { size_t o = take(off, sizeof(type) * (size_t)(count)); ptr = base ? (type *)(base + o) : nullptr; }
     SLOT(d.mean, double, 8 * T); SLOT(d.cov, double, 64 * T);
-    SLOT(d.f32, uint8_t, T); SLOT(d.in_removed, uint8_t, T); SLOT(d.in_use, uint8_t, T); SLOT(d.flag, uint8_t, T);
+    SLOT(d.f32, uint8_t, T); SLOT(d.in_removed, uint8_t, T); SLOT(d.in_use, uint8_t, T);
     SLOT(d.has_body, uint8_t, T); SLOT(d.has_face, uint8_t, T);
     SLOT(d.state, int32_t, T); SLOT(d.is_activated, int32_t, T); SLOT(d.track_id, int32_t, T);
     SLOT(d.frame_id, int32_t, T); SLOT(d.start_frame, int32_t, T); SLOT(d.tracklet_len, int32_t, T);
