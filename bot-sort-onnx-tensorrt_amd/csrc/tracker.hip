@@ -397,7 +397,7 @@ __device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, 
             const unsigned long long bu = __ballot((cmask >> u) & 1u);
             if (lane == u) mine = bu;
         }
-        if (lane < 16) scw[wid][(rc + lane) & (ROWS - 1)] = mine;
+        if (lane < 16 && lane < ROWS) scw[wid][(rc + lane) & (ROWS - 1)] = mine;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
@@ -435,10 +435,10 @@ __device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, 
                 const int src = __ffsll((long long)todo) - 1;
                 todo &= todo - 1;
                 const long sdet = __shfl(det, src), strk = sslot[r];
-                const float emb = 1.0f - fmaxf(0.0f, feat::wave_dot<(ROWS == CT_ROWS ? 8 : 4)>(d.body_curr + strk * d.D, IN(d, feats) + sdet * d.D, d.D, lane));
+                const float emb = 1.0f - fmaxf(0.0f, feat::wave_dot<(ROWS <= CT_ROWS ? 8 : 4)>(d.body_curr + strk * d.D, IN(d, feats) + sdet * d.D, d.D, lane));
                 float face = 1.0f;
                 if (d.Df)
-                    face = 1.0f - face_fixup(fmaxf(0.0f, feat::wave_dot<(ROWS == CT_ROWS ? 8 : 4)>(d.face_curr + strk * d.Df, IN(d, face_feats) + sdet * d.Df, d.Df, lane)));
+                    face = 1.0f - face_fixup(fmaxf(0.0f, feat::wave_dot<(ROWS <= CT_ROWS ? 8 : 4)>(d.face_curr + strk * d.Df, IN(d, face_feats) + sdet * d.Df, d.Df, lane)));
                 if (lane == src && !(fminf(emb, face) > d.app)) c = fmin(c, (double)emb);
             }
         } else if (MODE == 1 && STAGE == 3) {
@@ -450,7 +450,7 @@ __device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, 
                 todo &= todo - 1;
                 const long sdet = __shfl(det, src);
                 const long strk = d.unc_slot[i0 + r];
-                const float emb = 1.0f - fmaxf(0.0f, feat::wave_dot<(ROWS == CT_ROWS ? 8 : 4)>(d.body_curr + strk * d.D, IN(d, feats) + sdet * d.D, d.D, lane));
+                const float emb = 1.0f - fmaxf(0.0f, feat::wave_dot<(ROWS <= CT_ROWS ? 8 : 4)>(d.body_curr + strk * d.D, IN(d, feats) + sdet * d.D, d.D, lane));
                 if (lane == src && !(emb > d.app)) c = fmin(c, (double)emb);
             }
         } else if (MODE != 1 && live) {
@@ -1323,10 +1323,12 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
     int ntile = bts_cdiv(mc, CT_COLS) * bts_cdiv(T, CT_ROWS);
     if (ntile > 1024) ntile = 1024;
     const dim3 tile_grid(ntile);               // persistent tiles: the kernels walk the live extents
-    // stage 1 has the big problem: about a tile per workgroup; 64-row tiles once there are thousands of them
-    const bool tall = bts_cdiv(mc, CT_COLS) * bts_cdiv(T, CT_ROWS) > 2048;
-    int ntile1 = bts_cdiv(mc, CT_COLS) * bts_cdiv(T, tall ? 64 : CT_ROWS);
-    if (ntile1 > 8192) ntile1 = 8192;
+    // stage-1 tiles are R x 256 with R chosen for ~TILE_GOAL workgroups: a tile's cost is its chains of dependent loads
+    // plus a serial part per row, so small problems want many small tiles and big ones few tall tiles
+    constexpr int TILE_GOAL = 768;            // (swept on c2 / c3 / target: 256 ... 6144)
+    int trows = 2;
+    while (trows < 64 && bts_cdiv(mc, CT_COLS) * bts_cdiv(T, trows) > TILE_GOAL) trows *= 2;
+    const int ntile1 = bts_cdiv(mc, CT_COLS) * bts_cdiv(T, trows);
     const int kf_blocks = bts_cdiv(T * 8 > M ? T * 8 : M, 256);   // 8 lanes per track
     bts_lap_work lap[3] = {t->lap, t->lap, t->lap3};
     for (int k = 0; k < 3; ++k) lap[k].hdr = d.lap_hdr + BTS_LAP_HDR_INTS * k;
@@ -1377,8 +1379,14 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
     seg_begin(BTS_SEG_COST1);
     seg_begin(BTS_SEG_K_EDGES1);
     if (d.filter) {
-        if (tall) { LAUNCH((tk_edges<1, 1, 64>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); }
-        else { LAUNCH((tk_edges<1, 1>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); }
+        switch (trows) {
+        case 2: LAUNCH((tk_edges<1, 1, 2>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
+        case 4: LAUNCH((tk_edges<1, 1, 4>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
+        case 8: LAUNCH((tk_edges<1, 1, 8>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
+        case 16: LAUNCH((tk_edges<1, 1, 16>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
+        case 32: LAUNCH((tk_edges<1, 1, 32>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
+        default: LAUNCH((tk_edges<1, 1, 64>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
+        }
         if (d.record) { LAUNCH((tk_edges<1, 2>), tile_grid, dim3(CT_COLS), lap[0], 0); }
     } else {
         LAUNCH((tk_edges<1, 0>), tile_grid, dim3(CT_COLS), lap[0], 0);
@@ -1430,11 +1438,17 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
     seg_end(BTS_SEG_MERGE);
     seg_begin(BTS_SEG_DEDUPE);
     {
-        const bool big = bts_cdiv(T, CT_COLS) * bts_cdiv(T, CT_ROWS) > 2048;      // 64-row tiles for big tables
-        int nd = bts_cdiv(T, CT_COLS) * bts_cdiv(T, big ? 64 : CT_ROWS);
-        if (nd > 8192) nd = 8192;
-        if (big) { LAUNCH(tk_tail<64>, dim3(nd + mc), dim3(CT_COLS), nd); }
-        else { LAUNCH(tk_tail<CT_ROWS>, dim3(nd + mc), dim3(CT_COLS), nd); }
+        int drows = 2;                             // same tile-count rule for the duplicate tiles (tracked' x lost')
+        while (drows < 64 && bts_cdiv(T, CT_COLS) * bts_cdiv(T, drows) > TILE_GOAL) drows *= 2;
+        const int nd = bts_cdiv(T, CT_COLS) * bts_cdiv(T, drows);
+        switch (drows) {
+        case 2: LAUNCH(tk_tail<2>, dim3(nd + mc), dim3(CT_COLS), nd); break;
+        case 4: LAUNCH(tk_tail<4>, dim3(nd + mc), dim3(CT_COLS), nd); break;
+        case 8: LAUNCH(tk_tail<8>, dim3(nd + mc), dim3(CT_COLS), nd); break;
+        case 16: LAUNCH(tk_tail<16>, dim3(nd + mc), dim3(CT_COLS), nd); break;
+        case 32: LAUNCH(tk_tail<32>, dim3(nd + mc), dim3(CT_COLS), nd); break;
+        default: LAUNCH(tk_tail<64>, dim3(nd + mc), dim3(CT_COLS), nd); break;
+        }
     }
     LAUNCH(tk_finalize, dim3(2), dim3(1024));
     seg_end(BTS_SEG_DEDUPE);
