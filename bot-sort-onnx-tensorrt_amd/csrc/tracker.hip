@@ -1346,7 +1346,8 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
     const int ftiles = bts_cdiv(T, FBM) * bts_cdiv(mc, FBN);
     {
         const int kt_all = bts_cdiv(d.D, DBK);
-        while (ftiles * split < 256 && split * 2 <= kt_all && split < 16) split *= 2;
+        // at least ~64 workgroups; beyond that only while it shortens a long K loop (every split adds N*M float atomics)
+        while (split * 2 <= kt_all && split < 16 && (ftiles * split < 64 || (ftiles * split < 256 && kt_all / split > 8))) split *= 2;
     }
     const int accum = split > 1;
     // ---- first association: pool x high-score detections
