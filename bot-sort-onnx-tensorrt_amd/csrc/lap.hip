@@ -275,9 +275,10 @@ __device__ int small_pipeline(const LapArgs &A, SmallPipe &L, int E, int n, int 
     for (int s = tid; s < NA; s += nth) { const int c = L.cid[L.comp[s]]; L.comp[s] = c; atomicAdd(&L.crp[c], 1); atomicAdd(&L.ecnt[c], L.rptr[s]); }
     for (int s = tid; s < MA; s += nth) { const int c = L.cid[L.ccomp[s]]; L.ccomp[s] = c; atomicAdd(&L.ccp[c], 1); }
     bscan::lds_barrier();
-    for (int c = tid; c < C; c += nth) { atomicMax(&L.maxr, L.crp[c]); atomicMax(&L.maxc, L.ccp[c]); atomicMax(&L.maxe, L.ecnt[c]); }
+    for (int c = tid; c < C; c += nth)                    // (a plain flag: no contended atomics for the common all-fit case)
+        if (L.crp[c] > 64 || L.ccp[c] > 64 || L.ecnt[c] > SM_EDGES) L.maxr = 65;
     bscan::lds_barrier();
-    const bool fits = L.maxr <= 64 && L.maxc <= 64 && L.maxe <= SM_EDGES;
+    const bool fits = L.maxr <= 64;
     if (!fits) return -1;
     block_exscan_lds(L.crp, C, tmp);
     block_exscan_lds(L.ccp, C, tmp);
