@@ -103,9 +103,27 @@ __device__ int block_exscan_plain(int32_t *arr, int len, int32_t *tmp) {
     return total;
 }
 
-// same for an LDS array (hand-offs through LDS only: no wait for global stores at the barriers)
+// same for an LDS array (hand-offs through LDS only: no wait for global stores at the barriers).  Short arrays
+// (the usual case: a few hundred components / rows) are scanned by ONE wavefront -- lane chunks, a shuffle scan --
+// behind a single workgroup barrier instead of the four of the general form.
 __device__ int block_exscan_lds(int32_t *arr, int len, int32_t *tmp) {
     const int nth = blockDim.x, tid = threadIdx.x;
+    if (len <= 64 * 32) {
+        if (tid < 64) {
+            const int per = (len + 63) / 64;
+            const int lo = min(len, tid * per), hi = min(len, lo + per);
+            int sum = 0;
+            for (int k = lo; k < hi; ++k) sum += arr[k];
+            int incl = sum;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off); if (tid >= off) incl += t; }
+            int run = incl - sum;
+            for (int k = lo; k < hi; ++k) { const int v = arr[k]; arr[k] = run; run += v; }
+            if (tid == 63) tmp[0] = incl;
+        }
+        bscan::lds_barrier();
+        return tmp[0];
+    }
     const int per = (len + nth - 1) / nth;
     const int lo = min(len, tid * per), hi = min(len, lo + per);
     int s = 0;
