@@ -716,11 +716,15 @@ __device__ __forceinline__ void apply_body(const Dev &d, int bid) {
     const int32_t *rslot = STAGE == 1 ? d.pool_slot : STAGE == 2 ? d.r2_slot : d.unc_slot;
     const int32_t *xs = STAGE == 1 ? d.x1 : STAGE == 2 ? d.x2 : d.x3;
     const int32_t *cdet = STAGE == 1 ? d.hi_idx : STAGE == 2 ? d.lo_idx : d.left_det;
-    if (FEAT) {                                               // ---- feature rows: one workgroup each
-        const int r = bid;
-        if (r >= n) return;
-        const int xq = xs[r];
-        if (xq < 0) return;
+    if (FEAT) {                                               // ---- feature rows: one workgroup per matched COLUMN
+        // (a stage matches at most one row per detection column and there are far fewer columns than table rows:
+        // the grid is max_dets workgroups, not max_tracks)
+        const int m = STAGE == 1 ? h[H_NHI] : STAGE == 2 ? h[H_NLO] : h[H_NLEFT];
+        const int32_t *ys = STAGE == 1 ? d.y1 : STAGE == 2 ? d.y2 : d.y3;
+        const int xq = bid;
+        if (xq >= m) return;
+        const int r = ys[xq];
+        if (r < 0 || r >= n) return;
         const long s = rslot[r], det = cdet[xq];
         feat::ema_row(d.body_curr + s * d.D, d.body_smooth + s * d.D, IN(d, feats) + det * d.D, d.D, d.has_body[s] != 0,
                       d.ema_a, d.ema_b);
@@ -1321,7 +1325,7 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
     const int T = d.T, M = d.Mx;
     const int cos_kernel = t->ctx->cos_kernel;
     int ntile = bts_cdiv(mc, CT_COLS) * bts_cdiv(T, CT_ROWS);
-    if (ntile > 1024) ntile = 1024;
+    if (ntile > 256) ntile = 256;               // (stages 2 and 3 are small problems: idle workgroups only cost dispatch time)
     const dim3 tile_grid(ntile);               // persistent tiles: the kernels walk the live extents
     // stage-1 tiles are R x 256 with R chosen for ~TILE_GOAL workgroups: a tile's cost is its chains of dependent loads
     // plus a serial part per row, so small problems want many small tiles and big ones few tall tiles
@@ -1417,9 +1421,9 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
     // stage-1 Kalman updates + stage-1 feature rows + cost tiles of stages 2 and 3: disjoint tracks, one launch
     seg_begin(BTS_SEG_K_MID2);
     {
-        const dim3 g(kf_blocks + T + 2 * ntile);
-        if (d.filter) { LAUNCH(tk_mid2<1>, g, dim3(256), lap[1], lap[2], kf_blocks, T, ntile); }
-        else { LAUNCH(tk_mid2<0>, g, dim3(256), lap[1], lap[2], kf_blocks, T, ntile); }
+        const dim3 g(kf_blocks + mc + 2 * ntile);
+        if (d.filter) { LAUNCH(tk_mid2<1>, g, dim3(256), lap[1], lap[2], kf_blocks, mc, ntile); }
+        else { LAUNCH(tk_mid2<0>, g, dim3(256), lap[1], lap[2], kf_blocks, mc, ntile); }
         if (d.filter && d.record) { LAUNCH((tk_edges<3, 2>), tile_grid, dim3(CT_COLS), lap[2], 0); }
     }
     seg_end(BTS_SEG_K_MID2);
@@ -1430,7 +1434,7 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
     rc = bts_lap_enqueue(&prob[1], 2, s, nullptr);
     if (rc) return rc;
     seg_begin(BTS_SEG_K_APPLY23);
-    LAUNCH(tk_apply23, dim3(2 * kf_blocks + 2 * T), dim3(256), kf_blocks, T);
+    LAUNCH(tk_apply23, dim3(2 * kf_blocks + 2 * mc), dim3(256), kf_blocks, mc);
     seg_end(BTS_SEG_K_APPLY23);
     seg_end(BTS_SEG_STAGE2);
     // ---- births, list merge, duplicate removal
@@ -1441,7 +1445,8 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
     {
         int drows = 2;                             // same tile-count rule for the duplicate tiles (tracked' x lost')
         while (drows < 64 && bts_cdiv(T, CT_COLS) * bts_cdiv(T, drows) > TILE_GOAL) drows *= 2;
-        const int nd = bts_cdiv(T, CT_COLS) * bts_cdiv(T, drows);
+        int nd = bts_cdiv(T, CT_COLS) * bts_cdiv(T, drows);
+        if (nd > 1024) nd = 1024;                  // (tracked' x lost' is far smaller than T x T: persistent tiles walk the rest)
         switch (drows) {
         case 2: LAUNCH(tk_tail<2>, dim3(nd + mc), dim3(CT_COLS), nd); break;
         case 4: LAUNCH(tk_tail<4>, dim3(nd + mc), dim3(CT_COLS), nd); break;
