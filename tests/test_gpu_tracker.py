@@ -373,3 +373,14 @@ def test_full_size_filter_vs_dense_modes(bts, synth):
         assert ca == cb and ca["errors"] == 0
     assert a.counts()["n_tracked"] > 500 and a.counts()["n_lost"] > 5000      # the duplicate tiles had real work
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("K,M,D,churn,face,rate", [
+    (4, 1, 64, 0.0, 0, 30), (5, 2, 64, 0.5, 0, 30), (17, 9, 128, 0.2, 0, 25), (65, 64, 64, 0.1, 64, 30),
+    (130, 100, 192, 0.05, 0, 10), (257, 300, 128, 0.3, 0, 30), (260, 257, 64, 0.4, 0, 60), (300, 33, 128, 0.0, 64, 30),
+])
+def test_ragged_shapes_vs_oracle(bts, synth, K, M, D, churn, face, rate):
+    """Sizes that straddle every tile / wavefront / chunk boundary of the kernels (1, 2, 17, 64 +- 1, 256 +- 1 ...),
+    more detections than tracks and vice versa, heavy churn (births, unconfirmed tracks, stage 3), short track
+    buffers (expiry), with and without face features: full state equality with the oracle on every frame."""
+    _against_oracle(bts, synth, K, M, D, frames=14, churn=churn, frame_rate=rate, seed=K * 1000 + M, face_dim=face)
