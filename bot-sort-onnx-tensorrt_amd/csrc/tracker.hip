@@ -61,13 +61,13 @@ struct Dev {
     uint8_t *drop_t, *drop_l;
     int32_t *lap_hdr;          // 3 x 64 ints: per-stage counters of the assignment solver (BTS_LAP_HDR_INTS each)
     int record;                // keep dense cost matrices (tests / inspection)
-    int filter;                // appearance term by float16-MFMA pre-filter + exact float32 refine
+    int filter;                // appearance term by fp8-MFMA pre-filter + exact float32 refine
     uint8_t *body_h, *face_h, *det_h, *dface_h;       // fp8 unit-vector shadows of body_curr/face_curr and of the frame's rows
     float *body_n, *face_n, *det_n, *dface_n;         // their float32 L2 norms
     float *approx, *approx_f;                          // [T][Mx] split-K accumulation of the pre-filter, body / face (self-cleaning)
     uint32_t *cbits;                                   // [T][cb_ld] candidate bitmap of the one-pass pre-filter (self-cleaning)
     int cb_ld;                                         // 32-bit words per bitmap row
-    float eps_body, eps_face;                          // relative error bounds of the float16 dot products
+    float eps_body, eps_face;                          // absolute error bounds of the approximate cosines (feat::q8_cos_error)
     const InDesc *in;          // inputs of the current step: descriptor in memory (hipGraph replay) ...
     InDesc iv;                 // ... or by value in the kernel arguments (eager launches, in == nullptr)
 };
@@ -208,7 +208,7 @@ __device__ __forceinline__ void prep_free(const Dev &d) {
 }
 
 // ---- K2: STrack.multi_predict over the pool (D:524-536 + D:265-302) ---------------------------------
-// float16 shadows + norms of this frame's (raw) detection rows for the appearance pre-filter
+// fp8 unit-vector shadows + norms of this frame's (raw) detection rows for the appearance pre-filter
 __device__ __forceinline__ void cvt_body(const Dev &d, long blk) {        // four rows per 1024-thread workgroup
     const long j = blk * 4 + feat::row_group();
     const bool on = j < IN(d, m);
@@ -366,7 +366,7 @@ __device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, 
         if (wcount > EB - 64) flush();
     };
     // Rows are handled in chunks of 16.  Stage 1, pre-filter form: which pairs of this column could pass
-    // the appearance gate was decided by the float16 contraction (k_filter) -- either its split-K partial
+    // the appearance gate was decided by the fp8 contraction (k_filter_dma) -- either its split-K partial
     // sums are complete in `approx` now, or it left a candidate bitmap.  Both are consumed and cleared
     // here; the 16 rows of a chunk are fetched up front so that they cost one memory latency, not sixteen.
 #pragma unroll 1
@@ -504,14 +504,13 @@ __global__ __launch_bounds__(CT_COLS) void tk_edges(Dev d, bts_lap_work w, int a
     edges_all<STAGE, MODE, ROWS>(d, w, blockIdx.x, gridDim.x, accum);
 }
 
-// ---- appearance pre-filter: float16 MFMA GEMM + exact float32 refine ------------------------------------------
+// ---- appearance pre-filter: fp8 MFMA GEMM + exact float32 refine ------------------------------------------------
 // Stage-1 appearance can change a cost only where  min(1 - body_sim, 1 - face_sim) <= appearance_thresh
 // (D:1543-1547), i.e. for similarities >= 0.75 -- about one pair per detection out of N*M.  So the
-// N x M x D contraction runs on the float16 matrix cores (16x the float32 rate) over float16 shadows of
-// the features, and only pairs whose *bounded-error* approximation could reach the gate are
-// recomputed exactly in float32 (same value the dense float32 path produces up to summation order)
-// and appended to the solver's edge list as (row, col, 1 - sim).  A pair may then appear twice (its IoU
-// edge and its appearance edge): the solver's relaxation takes the minimum, which is np.minimum of D:1554.
+// N x M x D contraction runs on the fp8 matrix cores over 8-bit unit-vector shadows of the features, and only
+// pairs whose *bounded-error* approximation could reach the gate (feat::q8_cos_error) are recomputed exactly in
+// float32 by the stage-1 tile kernel (same value the dense float32 path produces up to summation order); the
+// pair's single edge then carries min(IoU cost, 1 - sim) = np.minimum of D:1554.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int FBM = 128, FBN = 128;      // tile of the pre-filter GEMM
 constexpr int DBK = 64;                  // its K step: 64 fp8 elements = one 64-byte LDS row per stage
@@ -1206,7 +1205,6 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
     d.ema_a = (float)cfg->ema_alpha; d.ema_b = (float)(1.0 - cfg->ema_alpha);
     d.max_time_lost = (int)((double)cfg->frame_rate / 30.0 * cfg->track_buffer);    // D:1276-1277
     d.record = cfg->record_costs ? 1 : 0;
-    // the float16 pre-filter needs 16-byte rows of halves; otherwise the dense float32 form is used
     // the pre-filter works on 64-element K steps; other feature widths take the dense float32 path
     d.filter = (cfg->appearance_mode == BTS_APPEARANCE_FILTER && d.D % DBK == 0 && d.Df % DBK == 0) ? 1 : 0;
     d.eps_body = feat::q8_cos_error(d.D);
