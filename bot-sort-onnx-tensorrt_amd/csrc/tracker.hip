@@ -329,7 +329,10 @@ __device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, 
     const float4 bf = make_float4(__double2float_rd(bb[0]), __double2float_rd(bb[1]), __double2float_ru(bb[2]), __double2float_ru(bb[3]));
     double *cost = STAGE == 1 ? d.cost1 : STAGE == 2 ? d.cost2 : d.cost3;
     const double limit = STAGE == 1 ? d.match1 : STAGE == 2 ? d.match2 : d.match3;
-    const bool all_rows = MODE == 2 || (MODE == 0 && d.record) || !(limit < 1.0);      // every entry of the matrix is wanted
+    // rows cannot be screened by box overlap when every entry of the matrix is wanted, or in the dense stage-1 form:
+    // there a pair of DISJOINT boxes still yields an edge when its appearance distance passes the gate (the pre-filter
+    // form carries those pairs as candidates instead)
+    const bool all_rows = MODE == 2 || (MODE == 0 && (d.record || STAGE == 1)) || !(limit < 1.0);
     const int rows = min(ROWS, n - i0);
     const unsigned long long livemask = __ballot(live);
     const float gate = 1.0f - d.app;
@@ -513,7 +516,7 @@ __global__ __launch_bounds__(CT_COLS) void tk_edges(Dev d, bts_lap_work w, int a
 // pair's single edge then carries min(IoU cost, 1 - sim) = np.minimum of D:1554.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int FBM = 128, FBN = 128;      // tile of the pre-filter GEMM
-constexpr int DBK = 64;                  // its K step: 64 fp8 elements = one 64-byte LDS row per stage
+constexpr int DBK = 128;                 // its K step: 128 fp8 elements = one full 128-byte line per row and stage
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, slot = bid / 8;
@@ -563,20 +566,20 @@ __device__ __forceinline__ void filter_epilogue(const Dev &d, f32x16 (&acc)[2][2
 // 128 x 128 tiles of v_mfma_scale_f32_32x32x64_f8f6f4 (fp8 x fp8, unit block scales) over the 8-bit unit-vector shadows.  What bounds this
 // kernel is neither HBM nor the matrix cores but the CU's fill path (a 128 x 128 tile needs 64 B/clk/CU of
 // operand traffic at full MFMA rate with 2-byte operands) -- hence 1-byte operands -- and how the operands reach LDS:
-//   * straight from memory (global_load_lds, 16 B per lane: no staging registers, no ds_write pass) through
-//     a ring of DNS stages of DBK = 64 elements, so that DNS - 1 stages are in flight while one is multiplied
-//     (a stage needs ~2 us to arrive when part of it misses the L2);
-//   * the LDS image of such a load is lane-linear, so a tile is stored as unpadded 64-byte rows and the
+//   * straight from memory (global_load_lds, 16 B per lane: no staging registers, no ds_write pass), double-buffered
+//     in stages of DBK = 128 elements: a row of a stage is one FULL 128-byte line (a CU's load path retires about one
+//     line segment per 4 clocks -- with 64-byte half rows the same bytes cost twice the load-path time), and the L2
+//     answers in ~240 clocks, so one stage in flight is enough;
+//   * the LDS image of such a load is lane-linear, so a tile is stored as unpadded 128-byte rows and the
 //     bank spread comes from the SOURCE side: lane (row, c) fetches 16-byte chunk c ^ swz(row) of its row
-//     and the fragment reads undo the permutation; swz(row) = (row >> 2) & 3 makes every ds_read_b128
+//     and the fragment reads undo the permutation; swz(row) = (row >> 1) & 7 makes every ds_read_b128
 //     lane group hit 16 distinct 16-byte slots (0 bank conflicts measured);
-//   * one workgroup barrier per stage, preceded by a COUNTED s_waitcnt vmcnt (only the oldest stage has
-//     to have landed) -- __syncthreads would drain the whole ring;
+//   * one workgroup barrier per stage behind an s_waitcnt vmcnt issued in inline assembly together with it;
 //   * a lane's two 16-byte fragment reads are the 32 K values it feeds to ONE K=64 MFMA (which K indices a lane
 //     holds is free as long as both operands agree).
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
-constexpr int DNS = 4;                 // (DBK = 64 elements = 64 bytes per row and stage, defined above)
+constexpr int DNS = 2;                 // (DBK = 128 elements = 128 bytes per row and stage, defined above)
 
 template <int N> __device__ __forceinline__ void wait_stage_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
@@ -619,22 +622,23 @@ __global__ __launch_bounds__(256) void k_filter_dma(Dev d, int m_max, int ntiles
     const int kt0 = ksplit * kt_per, kt1 = min(kt_all, kt0 + kt_per);
     if (kt0 >= kt1) return;
 
-    // piece s of a stage = rows [(4 s + wid) * 16, +16): one 1-KiB wavefront load, lane -> (row, 16-byte chunk)
-    const int prow = lane >> 2, pchunk = lane & 3;
-    const uint8_t *asrc[2], *bsrc[2];
+    // piece s of a stage = rows [(4 s + wid) * 8, +8): one 1-KiB wavefront load of 8 FULL 128-byte lines,
+    // lane -> (row, 16-byte chunk); swz(row) = (row >> 1) & 7 spreads every ds_read_b128 lane group over 16 slots
+    const int prow = lane >> 3, pchunk = lane & 7;
+    const uint8_t *asrc[4], *bsrc[4];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const int r = (4 * s + wid) * 16 + prow;
+    for (int s = 0; s < 4; ++s) {
+        const int r = (4 * s + wid) * 8 + prow;
         const int i = bm * FBM + r, j = bn * FBN + r;
-        const int sw = (pchunk ^ ((r >> 2) & 3)) * 16;
+        const int sw = (pchunk ^ ((r >> 1) & 7)) * 16;
         asrc[s] = A + (long)d.pool_slot[i < n ? i : bm * FBM] * Dd + sw;       // rows past the end: any valid row, ignored later
         bsrc[s] = B + (long)d.hi_idx[j < m ? j : bn * FBN] * Dd + sw;
     }
-    auto stage = [&](int buf, int kt) {                  // 4 wavefront loads per stage and wave
+    auto stage = [&](int buf, int kt) {                  // 8 wavefront loads per stage and wave
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            __builtin_amdgcn_global_load_lds((gbl_void *)(asrc[s] + kt * DBK), (lds_void *)&As2[buf][(4 * s + wid) * 16 * DBK], 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gbl_void *)(bsrc[s] + kt * DBK), (lds_void *)&Bs2[buf][(4 * s + wid) * 16 * DBK], 16, 0, 0);
+        for (int s = 0; s < 4; ++s) {
+            __builtin_amdgcn_global_load_lds((gbl_void *)(asrc[s] + kt * DBK), (lds_void *)&As2[buf][(4 * s + wid) * 8 * DBK], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void *)(bsrc[s] + kt * DBK), (lds_void *)&Bs2[buf][(4 * s + wid) * 8 * DBK], 16, 0, 0);
         }
     };
     f32x16 acc[2][2];
@@ -650,46 +654,42 @@ __global__ __launch_bounds__(256) void k_filter_dma(Dev d, int m_max, int ntiles
 #pragma unroll
     for (int x = 0; x < 2; ++x) {
         const int ra = wr * 64 + x * 32 + frow, rb = wc * 64 + x * 32 + frow;
-        aoff[x] = ra * DBK; asw[x] = (ra >> 2) & 3;
-        boff[x] = rb * DBK; bsw[x] = (rb >> 2) & 3;
+        aoff[x] = ra * DBK; asw[x] = (ra >> 1) & 7;
+        boff[x] = rb * DBK; bsw[x] = (rb >> 1) & 7;
     }
-#pragma unroll
-    for (int s = 0; s < DNS - 1; ++s)
-        if (kt0 + s < kt1) stage(s, kt0 + s);
+    stage(0, kt0);
     int cur = 0;
     for (int kt = kt0; kt < kt1; ++kt) {
-        // stage kt has landed once at most the (up to DNS-2) younger stages are still in flight
-        const int younger = min(DNS - 2, kt1 - 1 - kt);
-        if (younger >= 2) wait_stage_barrier<8>();
-        else if (younger == 1) wait_stage_barrier<4>();
-        else wait_stage_barrier<0>();
-        // every wave is past its reads of the buffer of stage kt-1: refill it with stage kt+DNS-1
-        if (kt + DNS - 1 < kt1) stage(cur == 0 ? DNS - 1 : cur - 1, kt + DNS - 1);
+        wait_stage_barrier<0>();             // stage kt has landed (the only one in flight); every wave is past its reads of the other buffer
+        if (kt + 1 < kt1) stage(cur ^ 1, kt + 1);
         const unsigned abase = lds_a + cur * (FBM * DBK), bbase = lds_b + cur * (FBN * DBK);
-        v4i fa[2][2], fb[2][2];                          // [t]: lanes < 32 hold K 32 t .. +16 of their row, lanes >= 32 the next 16
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int c = t * 2 + fh;
+        for (int h = 0; h < 2; ++h) {        // the stage's two K = 64 blocks; a lane holds 32 contiguous K values of each
+            v4i fa[2][2], fb[2][2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int u = h * 4 + fh * 2 + t;
+#pragma unroll
+                for (int x = 0; x < 2; ++x) {
+                    fa[t][x] = lds_read16(abase + aoff[x] + ((u ^ asw[x]) << 4));
+                    fb[t][x] = lds_read16(bbase + boff[x] + ((u ^ bsw[x]) << 4));
+                }
+            }
+            lds_wait<0>(fa[0][0], fa[0][1], fb[0][0], fb[0][1]);
+            lds_wait<0>(fa[1][0], fa[1][1], fb[1][0], fb[1][1]);
+            v8i av[2], bv[2];
 #pragma unroll
             for (int x = 0; x < 2; ++x) {
-                fa[t][x] = lds_read16(abase + aoff[x] + ((c ^ asw[x]) << 4));
-                fb[t][x] = lds_read16(bbase + boff[x] + ((c ^ bsw[x]) << 4));
+                av[x] = v8i{fa[0][x].x, fa[0][x].y, fa[0][x].z, fa[0][x].w, fa[1][x].x, fa[1][x].y, fa[1][x].z, fa[1][x].w};
+                bv[x] = v8i{fb[0][x].x, fb[0][x].y, fb[0][x].z, fb[0][x].w, fb[1][x].x, fb[1][x].y, fb[1][x].z, fb[1][x].w};
             }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)       // K = 64 per instruction, formats fp8 x fp8, block scales 2^0
+                    acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av[mi], bv[ni], acc[mi][ni], 0, 0, 0, 127, 0, 127);
         }
-        lds_wait<0>(fa[0][0], fa[0][1], fb[0][0], fb[0][1]);
-        lds_wait<0>(fa[1][0], fa[1][1], fb[1][0], fb[1][1]);
-        v8i av[2], bv[2];                               // a lane's 32 K values of the stage: its two 16-byte fragments
-#pragma unroll
-        for (int x = 0; x < 2; ++x) {
-            av[x] = v8i{fa[0][x].x, fa[0][x].y, fa[0][x].z, fa[0][x].w, fa[1][x].x, fa[1][x].y, fa[1][x].z, fa[1][x].w};
-            bv[x] = v8i{fb[0][x].x, fb[0][x].y, fb[0][x].z, fb[0][x].w, fb[1][x].x, fb[1][x].y, fb[1][x].z, fb[1][x].w};
-        }
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)       // K = 64 per instruction, formats fp8 x fp8, block scales 2^0
-                acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av[mi], bv[ni], acc[mi][ni], 0, 0, 0, 127, 0, 127);
-        cur = cur + 1 == DNS ? 0 : cur + 1;
+        cur ^= 1;
     }
     filter_epilogue<FACE>(d, acc, reinterpret_cast<float *>(&As2[0][0]), bm, bn, n, m, accum);
 }
@@ -1205,7 +1205,7 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
     d.ema_a = (float)cfg->ema_alpha; d.ema_b = (float)(1.0 - cfg->ema_alpha);
     d.max_time_lost = (int)((double)cfg->frame_rate / 30.0 * cfg->track_buffer);    // D:1276-1277
     d.record = cfg->record_costs ? 1 : 0;
-    // the pre-filter works on 64-element K steps; other feature widths take the dense float32 path
+    // the pre-filter works on 128-element K steps; other feature widths take the dense float32 path
     d.filter = (cfg->appearance_mode == BTS_APPEARANCE_FILTER && d.D % DBK == 0 && d.Df % DBK == 0) ? 1 : 0;
     d.eps_body = feat::q8_cos_error(d.D);
     d.eps_face = feat::q8_cos_error(d.Df ? d.Df : 1);

@@ -384,3 +384,10 @@ def test_ragged_shapes_vs_oracle(bts, synth, K, M, D, churn, face, rate):
     more detections than tracks and vice versa, heavy churn (births, unconfirmed tracks, stage 3), short track
     buffers (expiry), with and without face features: full state equality with the oracle on every frame."""
     _against_oracle(bts, synth, K, M, D, frames=14, churn=churn, frame_rate=rate, seed=K * 1000 + M, face_dim=face)
+
+
+@pytest.mark.parametrize("K,M,D,churn,face", [(260, 257, 64, 0.4, 0), (130, 100, 128, 0.3, 64), (512, 256, 256, 0.2, 0)])
+def test_dense_mode_with_churn_vs_oracle(bts, synth, K, M, D, churn, face):
+    """The dense float32 appearance path under churn: re-found tracks whose predicted box no longer overlaps the
+    detection are matched on appearance alone (a row of disjoint boxes must not be skipped)."""
+    _against_oracle(bts, synth, K, M, D, frames=14, churn=churn, frame_rate=60, seed=K * 1000 + M, face_dim=face, appearance_mode=1)
