@@ -346,39 +346,52 @@ __device__ int small_pipeline(const LapArgs &A, SmallPipe &L, int E, int n, int 
     return 0;
 }
 
+// one counter bump per wavefront instead of one contended global atomic per lane: returns this lane's slot (pred lanes)
+__device__ __forceinline__ int wave_alloc(int32_t *counter, bool pred) {
+    const unsigned long long mk = __ballot(pred);
+    if (!mk) return 0;
+    const int lane = threadIdx.x & 63, first = __ffsll((long long)mk) - 1;
+    int base = 0;
+    if (lane == first) base = atomicAdd(counter, __popcll(mk));
+    base = __shfl(base, first);
+    return base + __popcll(mk & ((1ull << lane) - 1ull));
+}
+
 // LARGE preparation: global work area, node space (phases as in the LDS form)
-__device__ void large_pipeline(const LapArgs &A, int EH, int32_t *tmp) {
+__device__ void large_pipeline(const LapArgs &A, int EH, int32_t *tmp, int32_t *lds_nodes, int lds_cap) {
     const bts_lap_work &w = A.w;
-    const int n = A.dims ? A.dims[0] : A.n_max;
+    const int n = A.dims ? A.dims[0] : A.n_max, m = A.dims ? A.dims[1] : A.m_max;
     const int tid = threadIdx.x, nth = blockDim.x;
+    // the union-find forest is the pointer-chasing part: it lives in LDS whenever the node space fits
+    int32_t *parent = n + m <= lds_cap ? lds_nodes : w.parent;
     // 3. dense slots for the rows / columns of hard edges, union-find cells
-    for (int h = tid; h < EH; h += nth) {
-        const int e = w.hard[h], i = w.e_row[e], j = w.e_col[e];
-        if (!(atomicOr(&w.deg[i], FIRST) & FIRST)) {
-            const int s = atomicAdd(&w.hdr[H_NA], 1);
-            w.arow[s] = i; w.slot_of_row[i] = s; RST(&w.parent[i], i);
-        }
-        if (!(atomicOr(&w.cdeg[j], FIRST) & FIRST)) {
-            const int s = atomicAdd(&w.hdr[H_MA], 1);
-            w.acol[s] = j; RST(&w.parent[n + j], n + j); w.v[j] = 0.0;
-        }
+    for (int h0 = 0; h0 < EH; h0 += nth) {                 // (uniform trip count: wave_alloc is convergent)
+        const int h = h0 + tid;
+        const bool on = h < EH;
+        const int e = on ? w.hard[h] : 0, i = on ? w.e_row[e] : 0, j = on ? w.e_col[e] : 0;
+        const bool newr = on && !(atomicOr(&w.deg[i], FIRST) & FIRST);
+        const int sr = wave_alloc(&w.hdr[H_NA], newr);
+        if (newr) { w.arow[sr] = i; w.slot_of_row[i] = sr; RST(&parent[i], i); }
+        const bool newc = on && !(atomicOr(&w.cdeg[j], FIRST) & FIRST);
+        const int sc = wave_alloc(&w.hdr[H_MA], newc);
+        if (newc) { w.acol[sc] = j; RST(&parent[n + j], n + j); w.v[j] = 0.0; }
     }
     __syncthreads();
     // 4. connected components of the hard graph
-    for (int h = tid; h < EH; h += nth) { const int e = w.hard[h]; unite(w.parent, w.e_row[e], n + w.e_col[e]); }
+    for (int h = tid; h < EH; h += nth) { const int e = w.hard[h]; unite(parent, w.e_row[e], n + w.e_col[e]); }
     __syncthreads();
     // 5. final roots (read-only walks: every union is done); the roots hand out component ids
     const int NA = RLX(&w.hdr[H_NA]), MA = RLX(&w.hdr[H_MA]);
-    for (int s = tid; s < NA; s += nth) {
-        const int i = w.arow[s], r = find_root_ro(w.parent, i);
-        w.rootv[i] = r;
-        w.rptr[s] = RLX(&w.deg[i]) & ~FIRST;
-        if (r == i) {                                     // roots are rows: rows have the smaller node ids
-            const int c = atomicAdd(&w.hdr[H_COMPS], 1);
-            w.comp_of[i] = c; RST(&w.crow_ptr[c], 0); RST(&w.ccol_ptr[c], 0);
-        }
+    for (int s0 = 0; s0 < NA; s0 += nth) {
+        const int s = s0 + tid;
+        const bool on = s < NA;
+        const int i = on ? w.arow[s] : 0, r = on ? find_root_ro(parent, i) : -1;
+        if (on) { w.rootv[i] = r; w.rptr[s] = RLX(&w.deg[i]) & ~FIRST; }
+        const bool root = on && r == i;                   // roots are rows: rows have the smaller node ids
+        const int c = wave_alloc(&w.hdr[H_COMPS], root);
+        if (root) { w.comp_of[i] = c; RST(&w.crow_ptr[c], 0); RST(&w.ccol_ptr[c], 0); }
     }
-    for (int s = tid; s < MA; s += nth) { const int j = w.acol[s]; w.rootv[n + j] = find_root_ro(w.parent, n + j); }
+    for (int s = tid; s < MA; s += nth) { const int j = w.acol[s]; w.rootv[n + j] = find_root_ro(parent, n + j); }
     __syncthreads();
     // 6. component sizes
     const int C = RLX(&w.hdr[H_COMPS]);
@@ -440,11 +453,14 @@ __device__ int isolated_pairs(const LapArgs &A, int E) {
     const int tid = threadIdx.x, nth = blockDim.x;
     for (int e = tid; e < E; e += nth) { const int i = w.e_row[e]; if (i >= 0) { atomicAdd(&w.deg[i], 1); atomicAdd(&w.cdeg[w.e_col[e]], 1); } }
     __syncthreads();
-    for (int e = tid; e < E; e += nth) {
-        const int i = w.e_row[e], j = w.e_col[e];
-        if (i < 0) continue;
-        if (RLX(&w.deg[i]) == 1 && RLX(&w.cdeg[j]) == 1) { A.x[i] = j; A.y[j] = i; }
-        else w.hard[atomicAdd(&w.hdr[H_NH], 1)] = e;
+    for (int e0 = 0; e0 < E; e0 += nth) {
+        const int e = e0 + tid;
+        const int i = e < E ? w.e_row[e] : -1, j = e < E ? w.e_col[e] : 0;
+        const bool iso = i >= 0 && RLX(&w.deg[i]) == 1 && RLX(&w.cdeg[j]) == 1;
+        if (iso) { A.x[i] = j; A.y[j] = i; }
+        const bool hardq = i >= 0 && !iso;
+        const int hq = wave_alloc(&w.hdr[H_NH], hardq);
+        if (hardq) w.hard[hq] = e;
     }
     __syncthreads();
     // (degrees of the isolated pairs go back to zero only now: the test above must see 1 for both ends)
@@ -732,7 +748,7 @@ __global__ __launch_bounds__(1024) void k_lap(LapArgs A0, LapArgs A1) {
         if (state < 0) {                                  // LARGE form: global degree arrays
             __syncthreads();
             const int EH = isolated_pairs(A, E);
-            if (EH > 0) large_pipeline(A, EH, tmp);
+            if (EH > 0) large_pipeline(A, EH, tmp, reinterpret_cast<int32_t *>(lds_raw), (int)(LAP_LDS_BYTES / sizeof(int32_t)));
         }
         __syncthreads();
         C = RLX(&w.hdr[H_HARD]);
