@@ -70,14 +70,36 @@ __device__ __forceinline__ void renorm_row(float *row, int d, bool active = true
     }
 }
 
+// (8-bit shadows of the pre-filter: definitions further down)
+constexpr float Q8_SCALE = 128.0f;
+__device__ __forceinline__ unsigned q8_pack4(float a, float b, float c, float e) {
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, e, w, true);
+    return (unsigned)w;
+}
+
 // curr = f ; smooth = normalise(has ? alpha*smooth + beta*f : f)
-__device__ __forceinline__ void ema_row(float *curr, float *smooth, const float *f, int d, bool has, float alpha,
-                                        float beta, bool active = true) {
+// unit_q8 / unit_norm (optional): also write the 8-bit shadow of f for the pre-filter, for rows that are KNOWN to be
+// unit vectors (the detection rows were renormalised in place before any track consumes them): the shadow is then
+// q(128 f) with no second reduction and the stored norm is 1 (the 1e-7 deviation of a renormalised row from unit
+// length is far inside the slack of feat::q8_cos_error).
+__device__ __forceinline__ bool ema_row(float *curr, float *smooth, const float *f, int d, bool has, float alpha,
+                                        float beta, bool active = true, uint8_t *unit_q8 = nullptr, float *unit_norm = nullptr) {
     const int t = row_tid();
     float ss = 0.0f;
     if (active && vec4_ok(curr, d) && vec4_ok(smooth, d) && vec4_ok(f, d) && d / 4 <= 2 * ROW_G) {      // 16 B per lane, values stay in registers
         const float4 *f4 = reinterpret_cast<const float4 *>(f);
         float4 *c4 = reinterpret_cast<float4 *>(curr), *s4 = reinterpret_cast<float4 *>(smooth);
+        if (unit_q8) {
+            unsigned *h4 = reinterpret_cast<unsigned *>(unit_q8);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int k = t + u * ROW_G;
+                if (k < d / 4) { const float4 v = f4[k]; h4[k] = q8_pack4(v.x * Q8_SCALE, v.y * Q8_SCALE, v.z * Q8_SCALE, v.w * Q8_SCALE); }
+            }
+            if (t == 0) *unit_norm = 1.0f;
+        }
         const int nv = d / 4;
         float4 fv[2], sv[2];
 #pragma unroll
@@ -102,7 +124,7 @@ __device__ __forceinline__ void ema_row(float *curr, float *smooth, const float 
                 s4[k] = make_float4(sv[u].x / nrm, sv[u].y / nrm, sv[u].z / nrm, sv[u].w / nrm);
             }
         }
-        return;
+        return unit_q8 != nullptr;          // shadow written
     }
     if (active)
         for (int k = t; k < d; k += ROW_G) {
@@ -118,6 +140,7 @@ __device__ __forceinline__ void ema_row(float *curr, float *smooth, const float 
             curr[k] = fv;
             smooth[k] = s / nrm;
         }
+    return false;
 }
 
 // ---- 8-bit shadow rows for the appearance pre-filter ----------------------------------------------------
@@ -128,7 +151,6 @@ __device__ __forceinline__ void ema_row(float *curr, float *smooth, const float 
 //     |q(x) - x| <= Q8_REL * |x| + Q8_ABS        (round to nearest, 3 mantissa bits; Q8_ABS covers the subnormal
 //                                                 range even if the conversion flushes it to zero)
 // => |cos_q - cos| <= (2 Q8_REL + Q8_REL^2) + 2 (1 + Q8_REL) Q8_ABS sqrt(D) + D Q8_ABS^2   (+ float32 accumulation).
-constexpr float Q8_SCALE = 128.0f;
 constexpr float Q8_UNSCALE = 1.0f / (128.0f * 128.0f);
 constexpr float Q8_REL = 0.0625f;                 // 2^-4
 constexpr float Q8_ABS = 1.0f / 8192.0f;          // 2^-6 (smallest normal of e4m3fn) / 128
@@ -137,12 +159,6 @@ __host__ __device__ inline float q8_cos_error(int d) {
            (float)d / 4194304.0f + 1e-3f;
 }
 
-__device__ __forceinline__ unsigned q8_pack4(float a, float b, float c, float e) {
-    int w = 0;
-    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
-    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, e, w, true);
-    return (unsigned)w;
-}
 
 __device__ __forceinline__ void to_q8_row(const float *f, uint8_t *h, float *norm, int d, bool active = true) {
     const int t = row_tid();

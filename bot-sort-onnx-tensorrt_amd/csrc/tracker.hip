@@ -725,14 +725,17 @@ __device__ __forceinline__ void apply_body(const Dev &d, int bid) {
         const int r = ys[xq];
         if (r < 0 || r >= n) return;
         const long s = rslot[r], det = cdet[xq];
-        feat::ema_row(d.body_curr + s * d.D, d.body_smooth + s * d.D, IN(d, feats) + det * d.D, d.D, d.has_body[s] != 0,
-                      d.ema_a, d.ema_b);
+        // (the detection rows are unit vectors by now -- tk_mid1 renormalised them -- so their 8-bit shadows are written
+        // from the same registers, without a second norm; odd shapes fall back to the two-pass conversion)
+        const bool sb = feat::ema_row(d.body_curr + s * d.D, d.body_smooth + s * d.D, IN(d, feats) + det * d.D, d.D, d.has_body[s] != 0,
+                                      d.ema_a, d.ema_b, true, d.filter ? d.body_h + s * d.D : nullptr, d.body_n + s);
+        bool sf = true;
         if (d.Df)
-            feat::ema_row(d.face_curr + s * d.Df, d.face_smooth + s * d.Df, IN(d, face_feats) + det * d.Df, d.Df,
-                          d.has_face[s] != 0, d.ema_a, d.ema_b);
+            sf = feat::ema_row(d.face_curr + s * d.Df, d.face_smooth + s * d.Df, IN(d, face_feats) + det * d.Df, d.Df,
+                               d.has_face[s] != 0, d.ema_a, d.ema_b, true, d.filter ? d.face_h + s * d.Df : nullptr, d.face_n + s);
         if (d.filter) {
-            feat::to_q8_row(IN(d, feats) + det * d.D, d.body_h + s * d.D, d.body_n + s, d.D);
-            if (d.Df) feat::to_q8_row(IN(d, face_feats) + det * d.Df, d.face_h + s * d.Df, d.face_n + s, d.Df);
+            if (!sb) feat::to_q8_row(IN(d, feats) + det * d.D, d.body_h + s * d.D, d.body_n + s, d.D);
+            if (d.Df && !sf) feat::to_q8_row(IN(d, face_feats) + det * d.Df, d.face_h + s * d.Df, d.face_n + s, d.Df);
         }
         if (threadIdx.x == 0) { d.has_body[s] = 1; if (d.Df) d.has_face[s] = 1; }
         return;
