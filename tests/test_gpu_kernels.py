@@ -436,3 +436,22 @@ def test_prefilter_quantiser_error_model(bts):
     # the model is not vacuous: the relative term is nearly attained
     big = np.abs(x) > 0.01
     assert (err[big] / np.abs(x[big])).max() > 0.8 * rel.value
+
+
+def test_lapjv_global_memory_form(bts):
+    """More than 2048 non-trivial edges: the solver's global-memory form (union-find in LDS, everything else in the
+    work area), chains and small dense blocks included; exact against the dense oracle."""
+    import ctypes, torch
+    from oracle import bts_oracle as bo
+    rng = np.random.default_rng(77)
+    n, m = 3000, 1800
+    c = np.ones((n, m))
+    rows = rng.permutation(n)[:m]
+    for j in range(m):
+        c[rows[j], j] = rng.uniform(0.02, 0.5)
+        for r in rng.integers(0, n, 3):
+            c[r, j] = min(c[r, j], rng.uniform(0.2, 0.79))
+    assert (c <= 0.8).sum() > 5000
+    _, xo, yo = bo.lapjv(c, True, 0.8)
+    _, x, y = bts.lapjv(c, True, 0.8)
+    assert np.array_equal(x, xo) and np.array_equal(y, yo)
