@@ -252,7 +252,11 @@ __device__ int small_pipeline(const LapArgs &A, SmallPipe &L, int E, int n, int 
     auto classify = [&](int e, int i, int j) {            // isolated pairs are final; the rest is queued
         if (i < 0) return;
         if (tab[i] == 1 && tab[n + j] == 1) { A.x[i] = j; A.y[j] = i; }
-        else { const int h = atomicAdd(&L.EH, 1); if (h < SM_EH) { L.he[h] = e; L.hr[h] = i; L.hc[h] = j; } }
+        else {
+            const int h = atomicAdd(&L.EH, 1);
+            if (h < SM_EH) { L.he[h] = e; L.hr[h] = i; L.hc[h] = j; }
+            w.hard[h] = e;                                // (also the queue of the global-memory form, should it take over)
+        }
     };
     if (cached) {
 #pragma unroll
@@ -263,7 +267,23 @@ __device__ int small_pipeline(const LapArgs &A, SmallPipe &L, int E, int n, int 
     bscan::lds_barrier();
     const int EH = L.EH;
     if (EH == 0) return 0;
-    if (EH > SM_EH) return -1;
+    if (EH > SM_EH) {
+        // Too many non-trivial edges for the LDS form: hand over to the global-memory form WITHOUT redoing the degree
+        // count and the isolated pairs there (three passes of global atomics): its queue w.hard[] is filled, and the
+        // degrees of the rows / columns it will touch are copied out of the LDS table.
+        auto publish = [&](int i, int j) {
+            if (i < 0 || (tab[i] == 1 && tab[n + j] == 1)) return;
+            RST(&w.deg[i], tab[i]); RST(&w.cdeg[j], tab[n + j]);
+        };
+        if (cached) {
+#pragma unroll
+            for (int k = 0; k < EC; ++k) publish(er[k], ec[k]);
+        } else {
+            for (int e = tid; e < E; e += nth) publish(w.e_row[e], w.e_col[e]);
+        }
+        if (tid == 0) RST(&w.hdr[H_NH], EH);
+        return -1;
+    }
     constexpr int HC = (SM_EH + 1023) / 1024;             // hard edges per thread at 1024 threads (more threads: fewer)
     double hcost[HC];                                     // prefetched here, stored by the export at the very end
 #pragma unroll
@@ -297,7 +317,7 @@ __device__ int small_pipeline(const LapArgs &A, SmallPipe &L, int E, int n, int 
         if (L.crp[c] > 64 || L.ccp[c] > 64 || L.ecnt[c] > SM_EDGES) L.maxr = 65;
     bscan::lds_barrier();
     const bool fits = L.maxr <= 64;
-    if (!fits) return -1;
+    if (!fits) return -2;                                 // (the table is gone by now: the other form starts over)
     block_exscan_lds(L.crp, C, tmp);
     block_exscan_lds(L.ccp, C, tmp);
     if (tid == 0) { L.crp[C] = NA; L.ccp[C] = MA; }
@@ -743,11 +763,11 @@ __global__ __launch_bounds__(1024) void k_lap(LapArgs A0, LapArgs A1) {
             for (int j = tid; j < m; j += nth) { RST(&w.cdeg[j], 0); A.y[j] = -1; }
             __syncthreads();
         }
-        int state = E > 0 ? -1 : 0;
+        int state = E > 0 ? -2 : 0;
         if (E > 0 && n + m <= TABLE_CAP) state = small_pipeline(A, *reinterpret_cast<SmallPipe *>(lds_raw), E, n, m, tmp);
         if (state < 0) {                                  // LARGE form: global degree arrays
             __syncthreads();
-            const int EH = isolated_pairs(A, E);
+            const int EH = state == -1 && n + m <= TABLE_CAP ? RLX(&w.hdr[H_NH]) : isolated_pairs(A, E);
             if (EH > 0) large_pipeline(A, EH, tmp, reinterpret_cast<int32_t *>(lds_raw), (int)(LAP_LDS_BYTES / sizeof(int32_t)));
         }
         __syncthreads();
