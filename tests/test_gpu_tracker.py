@@ -391,3 +391,25 @@ def test_dense_mode_with_churn_vs_oracle(bts, synth, K, M, D, churn, face):
     """The dense float32 appearance path under churn: re-found tracks whose predicted box no longer overlaps the
     detection are matched on appearance alone (a row of disjoint boxes must not be skipped)."""
     _against_oracle(bts, synth, K, M, D, frames=14, churn=churn, frame_rate=60, seed=K * 1000 + M, face_dim=face, appearance_mode=1)
+
+
+def test_huge_table_capacity(bts, synth):
+    """A track table far larger than the scene (270 000 slots, beyond the LDS free-slot bitmap): the capacity-sized
+    loops, the free-list fallback and the exports must not depend on how full the table is."""
+    from oracle import bts_oracle as bo
+    K, M, D = 40, 24, 128
+    st = synth.SyntheticStream(K, M, D, seed=99, churn=0.2)
+    ora = bo.TrackerOracle()
+    trk = bts.DeviceTracker(max_tracks=270000, max_dets=64, feat_dim=D)
+    for f in range(10):
+        fr = st.next()
+        trk.step(*_dev_frame(fr)[:3])
+        ora.update_arrays(fr.boxes, fr.scores.astype(np.float64), fr.feats.copy(), None)
+        for which, lst in ((0, ora.tracked), (1, ora.lost)):
+            t = trk.export(which)
+            want = bo.TrackerOracle.table(lst)
+            for key in INT_KEYS:
+                assert np.array_equal(t[key], want[key]), (f, which, key)
+        c = trk.counts()
+        assert c["errors"] == 0 and c["last_id"] == ora._count
+    trk.close()
