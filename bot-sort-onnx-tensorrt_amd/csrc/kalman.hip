@@ -106,50 +106,54 @@ __global__ __launch_bounds__(64) void k_gmc(StateView v, int n, Warp w) {
     store_state(v, t, m, P);
 }
 
-// gating_distance for every (track, measurement) pair, D:338-380.  One thread per track keeps
-// the Cholesky factor in registers and walks the measurements; a block shares them through LDS.
-__global__ __launch_bounds__(64) void k_gating(StateView v, int n, const double *__restrict__ meas, int m,
-                                               int only_position, int metric, double *__restrict__ out) {
-    __shared__ double zs[64 * 4];
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    double mu[8], P[64], S[16], L[16];
-    const bool live = t < n;
-    if (live) {
-        load_state(v, t, mu, P);
+// gating_distance for every (track, measurement) pair, D:338-380.  The matrix is written once (8 B per pair: the
+// kernel is HBM-write-bound), so lanes run along the measurements -- consecutive lanes store consecutive elements of
+// one output row -- and a workgroup takes GT tracks x 256 measurements: the first GT threads factor the tracks'
+// innovation covariances (4x4 Cholesky) into LDS, every thread keeps its measurement in registers.
+constexpr int GT = 16;
+__global__ __launch_bounds__(256) void k_gating(StateView v, int n, const double *__restrict__ meas, int m,
+                                                int only_position, int metric, double *__restrict__ out) {
+    __shared__ double sL[GT][16], smu[GT][4];
+    const int t0 = blockIdx.y * GT, j = blockIdx.x * 256 + threadIdx.x;
+    if (threadIdx.x < GT && t0 + threadIdx.x < n) {
+        double mu[8], P[64], S[16], L[16];
+        load_state(v, t0 + threadIdx.x, mu, P);
         kf::project(mu, P, false, S);
         if (only_position) {   // 2x2 problem embedded in the 4x4 routines
             S[2] = S[3] = S[6] = S[7] = S[8] = S[9] = S[12] = S[13] = S[11] = S[14] = 0.0;
             S[10] = 1.0; S[15] = 1.0;
         }
         kf::chol4(S, L);
+        for (int c = 0; c < 16; ++c) sL[threadIdx.x][c] = (c % 5 == 0) ? 1.0 / L[c] : L[c];      // diagonal stored as its reciprocal
+        for (int c = 0; c < 4; ++c) smu[threadIdx.x][c] = mu[c];
     }
-    const int dim = only_position ? 2 : 4;
-    for (int j0 = 0; j0 < m; j0 += 64) {
-        __syncthreads();
-        for (int e = threadIdx.x; e < 64 * 4; e += 64) {
-            const int j = j0 + e / 4;
-            zs[e] = j < m ? meas[j * 4 + (e & 3)] : 0.0;
-        }
-        __syncthreads();
-        if (!live) continue;
-        const int jn = min(64, m - j0);
-        for (int jj = 0; jj < jn; ++jj) {
-            double d[4] = {0, 0, 0, 0};
-            for (int a = 0; a < dim; ++a) d[a] = zs[jj * 4 + a] - mu[a];
-            double r = 0.0;
-            if (metric == 1) {
-                for (int a = 0; a < dim; ++a) r += d[a] * d[a];
-            } else {   // forward substitution L y = d, sum y^2
-                double y[4];
-                for (int i = 0; i < dim; ++i) {
-                    double s = d[i];
-                    for (int kk = 0; kk < i; ++kk) s -= L[i * 4 + kk] * y[kk];
-                    y[i] = s / L[i * 4 + i];
-                }
-                for (int a = 0; a < dim; ++a) r += y[a] * y[a];
+    __syncthreads();
+    if (j >= m) return;
+    double z[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) z[a] = meas[(long)j * 4 + a];
+    const int nt = min(GT, n - t0);
+    for (int tt = 0; tt < nt; ++tt) {
+        // (fully unrolled over the 4 components, the 2-D case masks the last two: no runtime-indexed arrays)
+        double d[4], y[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) d[a] = z[a] - smu[tt][a];
+        double r;
+        if (metric == 1) {
+            r = d[0] * d[0]; r += d[1] * d[1];
+            if (!only_position) { r += d[2] * d[2]; r += d[3] * d[3]; }
+        } else {   // forward substitution L y = d, sum y^2
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                double sm = d[i];
+#pragma unroll
+                for (int kk = 0; kk < i; ++kk) sm -= sL[tt][i * 4 + kk] * y[kk];
+                y[i] = sm * sL[tt][i * 4 + i];            // (diagonal stored as its reciprocal: one division per track, not per pair)
             }
-            out[(long)t * m + j0 + jj] = r;
+            r = y[0] * y[0]; r += y[1] * y[1];
+            if (!only_position) { r += y[2] * y[2]; r += y[3] * y[3]; }
         }
+        out[(long)(t0 + tt) * m + j] = r;
     }
 }
 
@@ -221,7 +225,7 @@ int bts_kf_gating(bts_context *ctx, const double *mean, const double *cov, int n
     BTS_REQUIRE(metric == 0 || metric == 1, "metric must be 0 (maha) or 1 (gaussian)");
     if (n == 0 || m == 0) return BTS_OK;
     BTS_REQUIRE(mean && cov && meas && out, "null pointer");
-    hipLaunchKernelGGL(k_gating, dim3(bts_cdiv(n, 64)), dim3(64), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(k_gating, dim3(bts_cdiv(m, 256), bts_cdiv(n, GT)), dim3(256), 0, (hipStream_t)stream,
                        aos(const_cast<double *>(mean), const_cast<double *>(cov)), n, meas, m,
                        only_position, metric, out);
     BTS_LAUNCH_CHECK();

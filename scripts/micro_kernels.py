@@ -1,0 +1,33 @@
+"""HBM-bound standalone kernels against the 8 TB/s roofline (C ABI, device-resident operands, hipEvent timing):
+batched Kalman predict / update (1152 / 1184 B per track) and the N x M Mahalanobis gating matrix (8 B per pair)."""
+import importlib, sys, os, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pkg = importlib.import_module("bot-sort-onnx-tensorrt_amd")
+lib = pkg._lib.load(require_gpu=True)
+ctx = pkg._lib.default_context().handle
+P = pkg._lib.ptr
+s = pkg._lib.current_stream()
+
+def timed(fn, reps=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) * 1e3 / reps      # us
+
+rng = np.random.default_rng(0)
+for n, m in ((4096, 1024), (10000, 2000), (16384, 4096), (262144, 0)):
+    mean = torch.from_numpy(rng.normal(500, 100, (n, 8))).cuda()
+    A = rng.normal(size=(n, 8, 8)); cov = torch.from_numpy(A @ A.transpose(0, 2, 1) + 10 * np.eye(8)).cuda()
+    z32 = torch.from_numpy(rng.normal(500, 100, (n, 4)).astype(np.float32)).cuda()
+    t = timed(lambda: pkg._lib.check(lib.bts_kf_multi_predict(ctx, P(mean), P(cov), None, None, n, None, s)))
+    print("multi_predict n=%6d  %7.1f us  %6.0f GB/s (%.0f%% of 8 TB/s)" % (n, t, n * 1152 / t / 1e3, n * 1152 / t / 1e3 / 80))
+    t = timed(lambda: pkg._lib.check(lib.bts_kf_update(ctx, P(mean), P(cov), None, None, P(z32), None, n, s)))
+    print("update        n=%6d  %7.1f us  %6.0f GB/s (%.0f%% of 8 TB/s)" % (n, t, n * 1184 / t / 1e3, n * 1184 / t / 1e3 / 80))
+    if m:
+        z = torch.from_numpy(rng.normal(500, 100, (m, 4))).cuda()
+        out = torch.empty((n, m), dtype=torch.float64, device="cuda")
+        t = timed(lambda: pkg._lib.check(lib.bts_kf_gating(ctx, P(mean), P(cov), n, P(z), m, 0, 0, P(out), s)))
+        print("gating  %6d x %4d  %7.1f us  %6.0f GB/s (%.0f%% of 8 TB/s)" % (n, m, t, n * m * 8 / t / 1e3, n * m * 8 / t / 1e3 / 80))
