@@ -31,3 +31,28 @@ for n, m in ((4096, 1024), (10000, 2000), (16384, 4096), (262144, 0)):
         out = torch.empty((n, m), dtype=torch.float64, device="cuda")
         t = timed(lambda: pkg._lib.check(lib.bts_kf_gating(ctx, P(mean), P(cov), n, P(z), m, 0, 0, P(out), s)))
         print("gating  %6d x %4d  %7.1f us  %6.0f GB/s (%.0f%% of 8 TB/s)" % (n, m, t, n * m * 8 / t / 1e3, n * m * 8 / t / 1e3 / 80))
+
+# ---- the dense matrix forms of the standalone API at the target size
+n, m, D = 10000, 2000, 2048
+def boxes(k):
+    x, y = rng.uniform(0, 12000, k), rng.uniform(0, 12000, k)
+    return torch.from_numpy(np.stack([x, y, x + rng.uniform(30, 80, k), y + rng.uniform(60, 160, k)], 1)).cuda()
+a, b = boxes(n), boxes(m)
+cost = torch.empty((n, m), dtype=torch.float64, device="cuda")
+t = timed(lambda: pkg._lib.check(lib.bts_iou_distance(ctx, P(a), None, n, P(b), None, m, P(cost), m, s)))
+print("iou_distance %d x %d  %7.1f us  %6.0f GB/s written (%.0f%% of 8 TB/s)" % (n, m, t, n * m * 8 / t / 1e3, n * m * 8 / t / 1e3 / 80))
+ft = torch.from_numpy(rng.standard_normal((n, D)).astype(np.float32)).cuda(); fd = torch.from_numpy(rng.standard_normal((m, D)).astype(np.float32)).cuda()
+sim = torch.empty((n, m), dtype=torch.float32, device="cuda")
+t = timed(lambda: pkg._lib.check(lib.bts_cos_similarity(ctx, P(ft), n, P(fd), m, D, P(sim), m, s)), reps=5)
+print("cos_similarity %d x %d x %d  %7.1f us  %6.1f TFLOP/s f32 (%.0f%% of 157 TF)" % (n, m, D, t, 2.0 * n * m * D / t / 1e6, 2.0 * n * m * D / t / 1e6 / 1.573))
+out = torch.empty((n, m), dtype=torch.float64, device="cuda")
+t = timed(lambda: pkg._lib.check(lib.bts_fuse_cost_stage1(ctx, P(cost), m, P(sim), None, m, n, m, 0.5, 0.25, P(out), m, s)))
+print("fuse_cost_stage1 %d x %d  %7.1f us  %6.0f GB/s moved (%.0f%% of 8 TB/s)" % (n, m, t, n * m * 20 / t / 1e3, n * m * 20 / t / 1e3 / 80))
+k = 2000
+curr = torch.zeros((n, D), dtype=torch.float32, device="cuda"); smooth = torch.zeros((n, D), dtype=torch.float32, device="cuda")
+has = torch.ones((n,), dtype=torch.uint8, device="cuda")
+ti = torch.from_numpy(rng.permutation(n)[:k].astype(np.int32)).cuda(); di = torch.arange(k, dtype=torch.int32, device="cuda")
+t = timed(lambda: pkg._lib.check(lib.bts_feature_ema(ctx, P(curr), P(smooth), P(has), P(ti), P(fd), P(di), k, D, 0.9, s)))
+print("feature_ema %d rows x %d  %7.1f us  %6.0f GB/s moved (%.0f%% of 8 TB/s)" % (k, D, t, k * D * 16 / t / 1e3, k * D * 16 / t / 1e3 / 80))
+t = timed(lambda: pkg._lib.check(lib.bts_feature_renorm(ctx, P(fd), None, k, D, s)))
+print("feature_renorm %d rows x %d  %7.1f us  %6.0f GB/s moved (%.0f%% of 8 TB/s)" % (k, D, t, k * D * 8 / t / 1e3, k * D * 8 / t / 1e3 / 80))
