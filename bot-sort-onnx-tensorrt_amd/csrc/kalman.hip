@@ -28,24 +28,48 @@ __device__ __forceinline__ void store_state(const StateView &v, long t, const do
     for (int c = 0; c < 64; ++c) v.cov[t * v.cov_st + c * v.cov_sc] = P[c];
 }
 
-__global__ __launch_bounds__(64) void k_initiate(const float *__restrict__ meas, int n, StateView v) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    float z[4] = {meas[t * 4 + 0], meas[t * 4 + 1], meas[t * 4 + 2], meas[t * 4 + 3]};
-    double m[8], P[64];
-    kf::initiate(z, m, P);
-    store_state(v, t, m, P);
-}
-
+// (contiguous rows -- the layout every caller of this file uses -- move as four 16-byte accesses per lane)
 __device__ __forceinline__ void load_row(const StateView &v, long t, int i, double &mi, double Pr[8]) {
     mi = v.mean[t * v.mean_st + i * v.mean_sc];
+    if (v.cov_sc == 1 && (v.cov_st & 1) == 0 && ((uintptr_t)v.cov & 15) == 0) {
+        const double2 *p = reinterpret_cast<const double2 *>(v.cov + t * v.cov_st + i * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const double2 q = p[j]; Pr[2 * j] = q.x; Pr[2 * j + 1] = q.y; }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) Pr[j] = v.cov[t * v.cov_st + (i * 8 + j) * v.cov_sc];
 }
 __device__ __forceinline__ void store_row(const StateView &v, long t, int i, double mi, const double Pr[8]) {
     v.mean[t * v.mean_st + i * v.mean_sc] = mi;
+    if (v.cov_sc == 1 && (v.cov_st & 1) == 0 && ((uintptr_t)v.cov & 15) == 0) {
+        double2 *p = reinterpret_cast<double2 *>(v.cov + t * v.cov_st + i * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p[j] = make_double2(Pr[2 * j], Pr[2 * j + 1]);
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) v.cov[t * v.cov_st + (i * 8 + j) * v.cov_sc] = Pr[j];
+}
+
+// 8 lanes per track like predict / update: lane i stores mean[i] and row i of the (diagonal) covariance, so a
+// wavefront writes 8 contiguous 576-byte states
+__global__ __launch_bounds__(256) void k_initiate(const float *__restrict__ meas, int n, StateView v) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = g >> 3, i = g & 7;
+    if (t >= n) return;
+    float z[4] = {meas[t * 4 + 0], meas[t * 4 + 1], meas[t * 4 + 2], meas[t * 4 + 3]};
+    double m[8], P[64];
+    kf::initiate(z, m, P);                   // (72 values, of which this lane keeps 9: the rest folds away)
+    double mi = 0.0, Pr[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+        if (r == i) {
+            mi = m[r];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) Pr[j] = P[r * 8 + j];
+        }
+    store_row(v, t, i, mi, Pr);
 }
 
 __global__ __launch_bounds__(256) void k_multi_predict(StateView v, const uint8_t *__restrict__ zero_vel,
@@ -168,7 +192,7 @@ int bts_kf_initiate(bts_context *ctx, const float *meas_xywh, int n, double *mea
     BTS_REQUIRE(ctx && n >= 0, "ctx, n");
     if (n == 0) return BTS_OK;
     BTS_REQUIRE(meas_xywh && mean && cov, "null pointer");
-    hipLaunchKernelGGL(k_initiate, dim3(bts_cdiv(n, 64)), dim3(64), 0, (hipStream_t)stream, meas_xywh, n,
+    hipLaunchKernelGGL(k_initiate, dim3(bts_cdiv(n * 8, 256)), dim3(256), 0, (hipStream_t)stream, meas_xywh, n,
                        aos(mean, cov));
     BTS_LAUNCH_CHECK();
     return BTS_OK;

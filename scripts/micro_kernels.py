@@ -56,3 +56,20 @@ t = timed(lambda: pkg._lib.check(lib.bts_feature_ema(ctx, P(curr), P(smooth), P(
 print("feature_ema %d rows x %d  %7.1f us  %6.0f GB/s moved (%.0f%% of 8 TB/s)" % (k, D, t, k * D * 16 / t / 1e3, k * D * 16 / t / 1e3 / 80))
 t = timed(lambda: pkg._lib.check(lib.bts_feature_renorm(ctx, P(fd), None, k, D, s)))
 print("feature_renorm %d rows x %d  %7.1f us  %6.0f GB/s moved (%.0f%% of 8 TB/s)" % (k, D, t, k * D * 8 / t / 1e3, k * D * 8 / t / 1e3 / 80))
+
+# ---- remaining standalone entry points
+nn = 262144
+mean = torch.from_numpy(rng.normal(500, 100, (nn, 8))).cuda()
+A_ = rng.normal(size=(nn, 8, 8)).astype(np.float64); cov = torch.from_numpy(A_ @ A_.transpose(0, 2, 1) + 10 * np.eye(8)).cuda()
+pm = torch.empty((nn, 4), dtype=torch.float64, device="cuda"); pc = torch.empty((nn, 16), dtype=torch.float64, device="cuda")
+t = timed(lambda: pkg._lib.check(lib.bts_kf_project(ctx, P(mean), P(cov), None, nn, P(pm), P(pc), s)))
+print("project       n=%6d  %7.1f us  %6.0f GB/s (%.0f%% of 8 TB/s)" % (nn, t, nn * (576 + 160) / t / 1e3, nn * 736 / t / 1e3 / 80))
+z32 = torch.from_numpy(rng.normal(500, 100, (nn, 4)).astype(np.float32)).cuda()
+t = timed(lambda: pkg._lib.check(lib.bts_kf_initiate(ctx, P(z32), nn, P(mean), P(cov), s)))
+print("initiate      n=%6d  %7.1f us  %6.0f GB/s (%.0f%% of 8 TB/s)" % (nn, t, nn * 592 / t / 1e3, nn * 592 / t / 1e3 / 80))
+na, nb_ = 2000, 8000
+a2, b2 = boxes(na), boxes(nb_)
+ga = torch.zeros((na,), dtype=torch.int32, device="cuda"); gb = torch.zeros((nb_,), dtype=torch.int32, device="cuda")
+fa = torch.zeros((na,), dtype=torch.uint8, device="cuda"); fb = torch.zeros((nb_,), dtype=torch.uint8, device="cuda")
+t = timed(lambda: pkg._lib.check(lib.bts_dedupe_pairs(ctx, P(a2), None, P(ga), na, P(b2), None, P(gb), nb_, 0.15, P(fa), P(fb), s)))
+print("dedupe_pairs %d x %d  %7.1f us  (%.1f G pair tests/s)" % (na, nb_, t, na * nb_ / t / 1e3))
