@@ -228,6 +228,9 @@ def main():
         }
         out["segments_us"] = {k: round(v, 2) for k, v in breakdown.items()}
         if not a.no_cpu:
+            # the dense kernels of the path, standalone, against their rooflines (a few seconds; the step above is
+            # launch-bound at this size, these show what the kernels do when they have work)
+            out["standalone_rooflines"] = importlib.import_module("bot-sort-onnx-tensorrt_amd.microbench").run(full=False)
             out["cpu_baseline"] = cpu_baseline(pkg, K, M, D, 1234, a.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:
