@@ -187,26 +187,31 @@ __device__ int block_exscan(int32_t *arr, int len, int32_t *tmp) {
 // cursor, ccur_*) are only ever touched with agent-scope atomics (RLX / RST / atomicAdd / CAS); the
 // other arrays are written once and read after a workgroup barrier / the publish with plain accesses.
 constexpr int FIRST = 0x40000000;    // "already has a slot" flag inside deg / cdeg
-constexpr int SM_EH = 2048;          // hard-edge budget of the LDS form
+constexpr int SM_EH = 4096;          // hard-edge budget of the LDS form
+constexpr int SM_C = SM_EH / 2;      // components: a hard edge shares its row or its column with another hard edge, so a
+                                     // component has >= 2 edges (and, being connected, at most edges + 1 rows and columns:
+                                     // row slots + column slots <= SM_EH + SM_C)
 constexpr int SM_EDGES = 512;        // edge budget of the register/LDS solver, per wavefront
 
-struct SmallPipe {                   // LDS image of the hard sub-problem (slot space); 68 B per hard edge
-    int32_t he[SM_EH], hr[SM_EH], hc[SM_EH];      // hard edge -> edge index, row slot, column slot
-    int32_t arow[SM_EH], acol[SM_EH];             // slot -> global row / column
-    int32_t parent[2 * SM_EH];                    // union-find: row slots [0,SM_EH), column slots [SM_EH, 2 SM_EH)
-    int32_t rptr[SM_EH + 1];
-    int32_t cid[SM_EH];                           // root row slot -> component
-    int32_t comp[SM_EH], ccomp[SM_EH];            // row slot / column slot -> component
-    int32_t crp[SM_EH + 1], ccp[SM_EH + 1];       // component -> first row / column of its group
-    int32_t ecnt[SM_EH];                          // component -> edges
-    int32_t rpos[SM_EH];                          // row slot -> position in the grouped row list
-    int32_t lane_of_col[SM_EH];                   // column slot -> lane inside its component
-    int32_t gstart[SM_EH + 1];                    // grouped row position -> first edge (edges of a component are contiguous)
-    int32_t NA, MA, C, maxr, maxc, maxe, EH;
+struct SmallPipe {                   // LDS image of the hard sub-problem (slot space); 34 B per hard edge
+    uint16_t hr[SM_EH], hc[SM_EH];                // hard edge -> row, column (global ids first, then slots)
+    uint16_t arow[SM_EH], acol[SM_EH];            // slot -> global row / column
+    int32_t NA, MA, C, maxr, EH, pad_[3];
+    // ---- everything below is dead while the node table is alive: the table borrows it ----
+    int32_t parent[SM_EH + SM_C];                 // union-find: row slots [0,NA), column slots [NA, NA+MA)
+    int32_t rptr[SM_EH + 1];                      // row slot -> edges
+    int32_t cid[SM_EH + 1];                       // root row slot -> component; later gstart
+    int32_t crp[SM_C + 1], ccp[SM_C + 1];         // component -> first row / column of its group
+    int32_t ecnt[SM_C];                           // component -> edges
+    int32_t cur_c_[SM_C];
+    uint16_t comp[SM_EH], ccomp[SM_EH];           // row slot / column slot -> component; later rpos / lane_of_col
     // arrays with disjoint lifetimes share storage
-    __device__ int32_t *cursor() { return parent; }            // (after the roots are known)
-    __device__ int32_t *cur_r() { return parent + SM_EH; }
-    __device__ int32_t *cur_c() { return cid; }                // (after comp / ccomp hold component ids)
+    __device__ int32_t *cursor() { return parent; }            // [NA] (after the roots are known)
+    __device__ int32_t *cur_r() { return parent + SM_EH; }     // [C]
+    __device__ int32_t *cur_c() { return cur_c_; }
+    __device__ int32_t *gstart() { return cid; }               // [NA+1] grouped row position -> first edge (after comp holds component ids)
+    __device__ uint16_t *rpos() { return comp; }               // row slot -> position in the grouped row list (written by the last reader of comp[s])
+    __device__ uint16_t *lane_of_col() { return ccomp; }       // column slot -> lane inside its component (same)
 };
 
 __device__ int find_root_lds(int32_t *parent, int x) {
@@ -220,25 +225,28 @@ __device__ int find_root_lds(int32_t *parent, int x) {
 // come alive after it is dead.  Returns 0 when the problem is fully prepared/solved as far as this
 // workgroup goes, -1 when the LARGE form has to take over (nothing global was changed except x/y of
 // isolated pairs, which the LARGE form rewrites identically).
-constexpr int TABLE_CAP = 12 * SM_EH;      // node-table entries that fit in the borrowed storage
+constexpr int TABLE_CAP = 6 * SM_EH + SM_C;  // node-table entries that fit in the borrowed storage
+static_assert(sizeof(SmallPipe) - offsetof(SmallPipe, parent) >= TABLE_CAP * sizeof(int32_t), "node table does not fit");
+static_assert(TABLE_CAP < 65536, "global ids are kept in 16 bits");
 
-__device__ int small_pipeline(const LapArgs &A, SmallPipe &L, int E, int n, int m, int32_t *tmp) {
+template <int EC> __device__ int small_pipeline(const LapArgs &A, SmallPipe &L, int E, int n, int m, int32_t *tmp) {
     const bts_lap_work &w = A.w;
     const int tid = threadIdx.x, nth = blockDim.x;
     int32_t *tab = L.parent;                              // [n + m]: rows, then columns
-    if (tid == 0) { L.NA = 0; L.MA = 0; L.C = 0; L.maxr = 0; L.maxc = 0; L.maxe = 0; L.EH = 0; }
-    // The edge list is read from global memory ONCE: the first two passes walk it with the same
-    // edge -> thread mapping and keep (row, col) in registers (up to EC per thread; longer lists are
-    // re-read), hard edges carry their (row, col) in the LDS queue, and their costs are fetched while
-    // the component phases run (consumed only by the final export).
-    constexpr int EC = 4;
-    int er[EC], ec[EC];
+    if (tid == 0) { L.NA = 0; L.MA = 0; L.C = 0; L.maxr = 0; L.EH = 0; }
+    // The edge list is read from global memory ONCE: every pass that walks it uses the same edge -> thread mapping
+    // and keeps (row, col) in registers (up to EC per thread; longer lists are re-read).  A thread also remembers
+    // the queue position of each of its hard edges and fetches their costs while the component phases run: the
+    // final export is done in this mapping too, so the costs never pass through LDS.
+    int er[EC], ec[EC], hs[EC];
+    double hcost[EC];
     const bool cached = E <= EC * nth;
 #pragma unroll
     for (int k = 0; k < EC; ++k) {
         const int e = tid + k * nth;
         er[k] = (cached && e < E) ? w.e_row[e] : -1;
         ec[k] = (cached && e < E) ? w.e_col[e] : 0;
+        hs[k] = -1;
     }
     for (int k = tid; k < n + m; k += nth) tab[k] = 0;
     bscan::lds_barrier();
@@ -249,18 +257,17 @@ __device__ int small_pipeline(const LapArgs &A, SmallPipe &L, int E, int n, int 
         for (int e = tid; e < E; e += nth) { const int i = w.e_row[e]; if (i >= 0) { atomicAdd(&tab[i], 1); atomicAdd(&tab[n + w.e_col[e]], 1); } }
     }
     bscan::lds_barrier();
-    auto classify = [&](int e, int i, int j) {            // isolated pairs are final; the rest is queued
-        if (i < 0) return;
-        if (tab[i] == 1 && tab[n + j] == 1) { A.x[i] = j; A.y[j] = i; }
-        else {
-            const int h = atomicAdd(&L.EH, 1);
-            if (h < SM_EH) { L.he[h] = e; L.hr[h] = i; L.hc[h] = j; }
-            w.hard[h] = e;                                // (also the queue of the global-memory form, should it take over)
-        }
+    auto classify = [&](int e, int i, int j) -> int {     // isolated pairs are final; the rest is queued
+        if (i < 0) return -1;
+        if (tab[i] == 1 && tab[n + j] == 1) { A.x[i] = j; A.y[j] = i; return -1; }
+        const int h = atomicAdd(&L.EH, 1);
+        if (h < SM_EH) { L.hr[h] = (uint16_t)i; L.hc[h] = (uint16_t)j; }
+        w.hard[h] = e;                                    // (the queue of the global-memory form, should it take over)
+        return h;
     };
     if (cached) {
 #pragma unroll
-        for (int k = 0; k < EC; ++k) classify(tid + k * nth, er[k], ec[k]);
+        for (int k = 0; k < EC; ++k) hs[k] = classify(tid + k * nth, er[k], ec[k]);
     } else {
         for (int e = tid; e < E; e += nth) classify(e, w.e_row[e], w.e_col[e]);
     }
@@ -284,34 +291,32 @@ __device__ int small_pipeline(const LapArgs &A, SmallPipe &L, int E, int n, int 
         if (tid == 0) RST(&w.hdr[H_NH], EH);
         return -1;
     }
-    constexpr int HC = (SM_EH + 1023) / 1024;             // hard edges per thread at 1024 threads (more threads: fewer)
-    double hcost[HC];                                     // prefetched here, stored by the export at the very end
 #pragma unroll
-    for (int k = 0; k < HC; ++k) { const int h = tid + k * nth; hcost[k] = (nth >= 1024 && h < EH) ? w.e_cost[L.he[h]] : 0.0; }
+    for (int k = 0; k < EC; ++k) hcost[k] = hs[k] >= 0 ? w.e_cost[tid + k * nth] : 0.0;      // consumed by the export at the very end
     for (int h = tid; h < EH; h += nth) {                 // dense slots; the table entry becomes FIRST | slot
         const int i = L.hr[h], j = L.hc[h];
-        if (!(atomicOr(&tab[i], FIRST) & FIRST)) { const int s = atomicAdd(&L.NA, 1); L.arow[s] = i; atomicExch(&tab[i], FIRST | s); }
-        if (!(atomicOr(&tab[n + j], FIRST) & FIRST)) { const int s = atomicAdd(&L.MA, 1); L.acol[s] = j; atomicExch(&tab[n + j], FIRST | s); }
+        if (!(atomicOr(&tab[i], FIRST) & FIRST)) { const int s = atomicAdd(&L.NA, 1); L.arow[s] = (uint16_t)i; atomicExch(&tab[i], FIRST | s); }
+        if (!(atomicOr(&tab[n + j], FIRST) & FIRST)) { const int s = atomicAdd(&L.MA, 1); L.acol[s] = (uint16_t)j; atomicExch(&tab[n + j], FIRST | s); }
     }
     bscan::lds_barrier();
     const int NA = L.NA, MA = L.MA;
-    for (int h = tid; h < EH; h += nth) { L.hr[h] = tab[L.hr[h]] & ~FIRST; L.hc[h] = tab[n + L.hc[h]] & ~FIRST; }      // (row, col) -> slots, in place
+    for (int h = tid; h < EH; h += nth) { L.hr[h] = (uint16_t)(tab[L.hr[h]] & ~FIRST); L.hc[h] = (uint16_t)(tab[n + L.hc[h]] & ~FIRST); }      // (row, col) -> slots, in place
     bscan::lds_barrier();                                      // the table is dead from here on
-    for (int s = tid; s < NA; s += nth) { L.parent[s] = s; L.rptr[s] = 0; L.ecnt[s] = 0; }
-    for (int s = tid; s < MA; s += nth) L.parent[SM_EH + s] = SM_EH + s;
+    for (int s = tid; s < NA; s += nth) { L.parent[s] = s; L.rptr[s] = 0; }
+    for (int s = tid; s < MA; s += nth) L.parent[NA + s] = NA + s;
     bscan::lds_barrier();
-    for (int h = tid; h < EH; h += nth) { unite(L.parent, L.hr[h], SM_EH + L.hc[h]); atomicAdd(&L.rptr[L.hr[h]], 1); }
+    for (int h = tid; h < EH; h += nth) { unite(L.parent, L.hr[h], NA + L.hc[h]); atomicAdd(&L.rptr[L.hr[h]], 1); }
     bscan::lds_barrier();
-    for (int s = tid; s < NA; s += nth) {                 // roots (read-only walks) hand out component ids
+    for (int s = tid; s < NA; s += nth) {                 // roots (read-only walks; always a row slot) hand out component ids
         const int r = find_root_lds(L.parent, s);
-        L.comp[s] = r;
-        if (r == s) { const int c = atomicAdd(&L.C, 1); L.cid[s] = c; L.crp[c] = 0; L.ccp[c] = 0; }
+        L.comp[s] = (uint16_t)r;
+        if (r == s) { const int c = atomicAdd(&L.C, 1); L.cid[s] = c; L.crp[c] = 0; L.ccp[c] = 0; L.ecnt[c] = 0; }
     }
-    for (int s = tid; s < MA; s += nth) L.ccomp[s] = find_root_lds(L.parent, SM_EH + s);
+    for (int s = tid; s < MA; s += nth) L.ccomp[s] = (uint16_t)find_root_lds(L.parent, NA + s);
     bscan::lds_barrier();
     const int C = L.C;
-    for (int s = tid; s < NA; s += nth) { const int c = L.cid[L.comp[s]]; L.comp[s] = c; atomicAdd(&L.crp[c], 1); atomicAdd(&L.ecnt[c], L.rptr[s]); }
-    for (int s = tid; s < MA; s += nth) { const int c = L.cid[L.ccomp[s]]; L.ccomp[s] = c; atomicAdd(&L.ccp[c], 1); }
+    for (int s = tid; s < NA; s += nth) { const int c = L.cid[L.comp[s]]; L.comp[s] = (uint16_t)c; atomicAdd(&L.crp[c], 1); atomicAdd(&L.ecnt[c], L.rptr[s]); }
+    for (int s = tid; s < MA; s += nth) { const int c = L.cid[L.ccomp[s]]; L.ccomp[s] = (uint16_t)c; atomicAdd(&L.ccp[c], 1); }
     bscan::lds_barrier();
     for (int c = tid; c < C; c += nth)                    // (a plain flag: no contended atomics for the common all-fit case)
         if (L.crp[c] > 64 || L.ccp[c] > 64 || L.ecnt[c] > SM_EDGES) L.maxr = 65;
@@ -321,45 +326,45 @@ __device__ int small_pipeline(const LapArgs &A, SmallPipe &L, int E, int n, int 
     block_exscan_lds(L.crp, C, tmp);
     block_exscan_lds(L.ccp, C, tmp);
     if (tid == 0) { L.crp[C] = NA; L.ccp[C] = MA; }
-    int32_t *cursor = L.cursor(), *cur_r = L.cur_r(), *cur_c = L.cur_c();
+    int32_t *cursor = L.cursor(), *cur_r = L.cur_r(), *cur_c = L.cur_c(), *gstart = L.gstart();
+    uint16_t *rpos = L.rpos(), *lane_of_col = L.lane_of_col();
     for (int c = tid; c < C; c += nth) { cur_r[c] = L.crp[c]; cur_c[c] = L.ccp[c]; }
     bscan::lds_barrier();
     // rows / columns grouped by component; edge ranges handed out in grouped row order, so that the
     // edges of one component are one contiguous block
-    for (int s = tid; s < NA; s += nth) { const int pos = atomicAdd(&cur_r[L.comp[s]], 1); L.rpos[s] = pos; L.gstart[pos] = L.rptr[s]; }
+    for (int s = tid; s < NA; s += nth) { const int pos = atomicAdd(&cur_r[L.comp[s]], 1); rpos[s] = (uint16_t)pos; gstart[pos] = L.rptr[s]; }
     for (int s = tid; s < MA; s += nth) {
         const int c = L.ccomp[s], pos = atomicAdd(&cur_c[c], 1);
-        L.lane_of_col[s] = pos - L.ccp[c];
+        lane_of_col[s] = (uint16_t)(pos - L.ccp[c]);
         w.colid[pos] = L.acol[s];
     }
     bscan::lds_barrier();
-    block_exscan_lds(L.gstart, NA, tmp);
-    if (tid == 0) L.gstart[NA] = EH;
+    block_exscan_lds(gstart, NA, tmp);
+    if (tid == 0) gstart[NA] = EH;
     bscan::lds_barrier();
     for (int s = tid; s < NA; s += nth) {
-        const int pos = L.rpos[s], e0 = L.gstart[pos];
+        const int pos = rpos[s], e0 = gstart[pos];
         cursor[s] = e0;
         w.rowinfo[pos] = make_int4(L.arow[s], e0, e0 + L.rptr[s], 0);
     }
     for (int c = tid; c < C; c += nth)
         w.cdesc[c] = make_int4(L.crp[c], L.ccp[c], (L.crp[c + 1] - L.crp[c]) | ((L.ccp[c + 1] - L.ccp[c]) << 8) | (L.ecnt[c] << 16),
-                               L.gstart[L.crp[c]]);
-    bscan::lds_barrier();
-    if (nth >= 1024) {
+                               gstart[L.crp[c]]);
+    if (!cached) __syncthreads();                         // (w.hard[] is read back below: its stores must have landed)
+    else bscan::lds_barrier();
+    if (cached) {
 #pragma unroll
-        for (int k = 0; k < HC; ++k) {
-            const int h = tid + k * nth;
-            if (h < EH) {
-                const int pos = atomicAdd(&cursor[L.hr[h]], 1);
-                w.csr_lcol[pos] = L.lane_of_col[L.hc[h]];
+        for (int k = 0; k < EC; ++k)
+            if (hs[k] >= 0) {
+                const int pos = atomicAdd(&cursor[L.hr[hs[k]]], 1);
+                w.csr_lcol[pos] = lane_of_col[L.hc[hs[k]]];
                 w.csr_cost[pos] = hcost[k];
             }
-        }
     } else {
         for (int h = tid; h < EH; h += nth) {
             const int pos = atomicAdd(&cursor[L.hr[h]], 1);
-            w.csr_lcol[pos] = L.lane_of_col[L.hc[h]];
-            w.csr_cost[pos] = w.e_cost[L.he[h]];
+            w.csr_lcol[pos] = lane_of_col[L.hc[h]];
+            w.csr_cost[pos] = w.e_cost[RLX(&w.hard[h])];
         }
     }
     if (tid == 0) { RST(&w.hdr[H_COMPS], C); RST(&w.hdr[H_HARD], C); RST(&w.hdr[H_MODE], 1); RST(&w.hdr[H_NH], EH); }
@@ -378,7 +383,7 @@ __device__ __forceinline__ int wave_alloc(int32_t *counter, bool pred) {
 }
 
 // LARGE preparation: global work area, node space (phases as in the LDS form)
-__device__ void large_pipeline(const LapArgs &A, int EH, int32_t *tmp, int32_t *lds_nodes, int lds_cap) {
+__device__ __forceinline__ void large_pipeline(const LapArgs &A, int EH, int32_t *tmp, int32_t *lds_nodes, int lds_cap) {
     const bts_lap_work &w = A.w;
     const int n = A.dims ? A.dims[0] : A.n_max, m = A.dims ? A.dims[1] : A.m_max;
     const int tid = threadIdx.x, nth = blockDim.x;
@@ -468,7 +473,7 @@ __device__ void large_pipeline(const LapArgs &A, int EH, int32_t *tmp, int32_t *
 }
 
 // Degrees + isolated pairs; returns the number of hard edges (uniform).
-__device__ int isolated_pairs(const LapArgs &A, int E) {
+__device__ __forceinline__ int isolated_pairs(const LapArgs &A, int E) {
     const bts_lap_work &w = A.w;
     const int tid = threadIdx.x, nth = blockDim.x;
     for (int e = tid; e < E; e += nth) { const int i = w.e_row[e]; if (i >= 0) { atomicAdd(&w.deg[i], 1); atomicAdd(&w.cdeg[w.e_col[e]], 1); } }
@@ -540,7 +545,7 @@ struct SmallLds {                    // per-wavefront adjacency copy
 // column) AND local column k (v, owner, distance, predecessor, scanned); the adjacency sits in LDS;
 // every step of the Dijkstra search is a handful of __shfl / ds_bpermute operations -- no global
 // memory inside the search.  Returns false if the component does not fit.
-__device__ bool solve_packed(const LapArgs &A, int c, int lane, SmallLds &L) {
+__device__ __forceinline__ bool solve_packed(const LapArgs &A, int c, int lane, SmallLds &L) {
     const bts_lap_work &w = A.w;
     const double limit = A.limit, INF = __builtin_huge_val();
     const int4 d = w.cdesc[c];
@@ -630,7 +635,7 @@ __device__ bool solve_packed(const LapArgs &A, int c, int lane, SmallLds &L) {
 }
 
 // General path (any component size): state in global memory.
-__device__ void solve_component(const LapArgs &A, int c, int lane) {
+__device__ __forceinline__ void solve_component(const LapArgs &A, int c, int lane) {
     const bts_lap_work &w = A.w;
     const double limit = A.limit;
     const double INF = __builtin_huge_val();
@@ -741,11 +746,13 @@ constexpr int LAP_SOLO_EDGES = 64;   // edge lists up to this length are solved 
 constexpr int LAP_HELPERS = 15, LAP_HELPERS_BIG = 63;    // helper workgroups per problem (16 wavefronts each): small / big problems
 constexpr unsigned LAP_LDS_BYTES = sizeof(SmallPipe) > 16 * sizeof(SmallLds) ? sizeof(SmallPipe) : 16 * sizeof(SmallLds);
 
-__global__ __launch_bounds__(1024) void k_lap(LapArgs A0, LapArgs A1) {
+struct LapPair { LapArgs p[2]; };     // (indexed by blockIdx.x straight out of the kernel-argument segment)
+
+template <int EC> __global__ __launch_bounds__(1024) void k_lap(LapPair P) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     __shared__ int32_t tmp[1024];
     __shared__ int s_c;
-    const LapArgs &A = blockIdx.x ? A1 : A0;
+    const LapArgs &A = P.p[blockIdx.x];
     const bts_lap_work &w = A.w;
     const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63, wid = tid >> 6;
     int C = 0;
@@ -764,7 +771,7 @@ __global__ __launch_bounds__(1024) void k_lap(LapArgs A0, LapArgs A1) {
             __syncthreads();
         }
         int state = E > 0 ? -2 : 0;
-        if (E > 0 && n + m <= TABLE_CAP) state = small_pipeline(A, *reinterpret_cast<SmallPipe *>(lds_raw), E, n, m, tmp);
+        if (E > 0 && n + m <= TABLE_CAP) state = small_pipeline<EC>(A, *reinterpret_cast<SmallPipe *>(lds_raw), E, n, m, tmp);
         if (state < 0) {                                  // LARGE form: global degree arrays
             __syncthreads();
             const int EH = state == -1 && n + m <= TABLE_CAP ? RLX(&w.hdr[H_NH]) : isolated_pairs(A, E);
@@ -839,7 +846,9 @@ int bts_lap_enqueue_reset(const bts_lap_work *w, hipStream_t stream) {
 int bts_lap_init() {      // the solver kernel needs more than the default 64 KiB of dynamic LDS
     static bool attr_set = false;
     if (!attr_set) {
-        BTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lap), hipFuncAttributeMaxDynamicSharedMemorySize,
+        BTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lap<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)LAP_LDS_BYTES));
+        BTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lap<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)LAP_LDS_BYTES));
         attr_set = true;
     }
@@ -850,10 +859,15 @@ int bts_lap_enqueue(const bts_lap_problem *probs, int count, hipStream_t stream,
     int rc0 = bts_lap_init();
     if (rc0) return rc0;
     const bts_lap_problem &A = probs[0], &B = probs[count > 1 ? 1 : 0];
+    LapPair P;
+    P.p[0] = A; P.p[1] = B;
     if (ev) (void)hipEventRecord(ev[0], stream);
     // a component is one wavefront's job: big problems (hundreds of components) get more helper workgroups
     const int helpers = (A.n_max >= 2048 || B.n_max >= 2048) ? LAP_HELPERS_BIG : LAP_HELPERS;
-    hipLaunchKernelGGL(k_lap, dim3(count, 1 + helpers), dim3(1024), LAP_LDS_BYTES, stream, A, B);
+    // edges a thread keeps in registers across the preparation passes: 4 (lists up to 4096 edges are read once), or 8 for
+    // problems wide enough to produce longer lists (the instantiation costs the short ones a few percent)
+    if (A.m_max > 3072 || B.m_max > 3072) hipLaunchKernelGGL(k_lap<8>, dim3(count, 1 + helpers), dim3(1024), LAP_LDS_BYTES, stream, P);
+    else hipLaunchKernelGGL(k_lap<4>, dim3(count, 1 + helpers), dim3(1024), LAP_LDS_BYTES, stream, P);
     BTS_LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[1], stream);
     return BTS_OK;
