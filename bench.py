@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="c2")
     ap.add_argument("--segment", default="auto", help="kernel timed for the roofline object (auto = the dominant one)")
+    ap.add_argument("--event-stride", type=int, default=8, help="hipEvent pairs around the roofline kernel on every n-th timed step "
+                    "(a pair costs the stream ~4 us: on every launch it inflates a 90 us step by several percent)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--dense", action="store_true", help="dense float32 appearance path instead of the f16 pre-filter")
@@ -175,7 +177,7 @@ def main():
         ms_, n_ = trk.profile_read()
         breakdown[seg] = 1e3 * ms_ / max(n_, 1)
     segment = a.segment if a.segment != "auto" else max(KERNELS, key=lambda k: breakdown[k])
-    trk.profile_enable(segment, 0 if a.graph else a.steps)     # graph replay cannot carry per-kernel events
+    trk.profile_enable(segment, 0 if a.graph else a.steps, max(1, min(a.event_stride, a.steps // 16)))     # (>= 16 samples)     # graph replay cannot carry per-kernel events
     timed = [next_frame() for _ in range(a.steps)]
     if a.graph:                                              # capture happens on the first replayed step: keep it untimed
         trk.step(*next_frame())
@@ -223,7 +225,7 @@ def main():
             "roofline": {"kernel": KERNELS[segment], "bound": bound, "achieved": achieved, "peak": peak, "unit": runit,
                          "frac": achieved / peak, "traffic": pmc_traffic(a.workload, KERNELS[segment]),
                          "traffic_unit": "bytes per launch (HBM, rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes, profiles/pmc_traffic.json)",
-                         "avg_us": 1e6 * seg_s, "launches_timed": seg_n,
+                         "avg_us": 1e6 * seg_s, "launches_timed": seg_n, "event_stride": max(1, min(a.event_stride, a.steps // 16)),
                          "algorithmic_per_launch": amount, "algorithmic_unit": unit},
         }
         out["segments_us"] = {k: round(v, 2) for k, v in breakdown.items()}

@@ -68,6 +68,7 @@ SIGNATURES = {
     "bts_tracker_gmc": (c_int, [_P, _P, _P]),
     "bts_tracker_debug_lap": (c_int, [_P, c_int, _P, _P]),
     "bts_tracker_profile_enable": (c_int, [_P, c_int, c_int]),
+    "bts_tracker_profile_stride": (c_int, [_P, c_int]),
     "bts_tracker_profile_read": (c_int, [_P, POINTER(c_double), POINTER(c_int32)]),
     "bts_tracker_stage_result": (c_int, [_P, c_int, _P, _P, _P, POINTER(c_int32), POINTER(c_int32), _P]),
 }

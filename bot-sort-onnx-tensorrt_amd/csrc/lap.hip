@@ -521,39 +521,45 @@ template <int CTRL> __device__ __forceinline__ double dpp_d(double v) {
     const unsigned lo = (unsigned)dpp_i<CTRL>((int)(b & 0xffffffffll)), hi = (unsigned)dpp_i<CTRL>((int)(b >> 32));
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
-// lexicographic (d, col) minimum; `who` = lane that holds it.  All lanes of each 16-lane row end with
-// the row's result; NARROW callers only use row 0.
-template <int CTRL> __device__ __forceinline__ void min_step(double &d, int &col, int &who) {
-    const double od = dpp_d<CTRL>(d);
-    const int oc = dpp_i<CTRL>(col), ow = dpp_i<CTRL>(who);
-    if (od < d || (od == d && oc < col)) { d = od; col = oc; who = ow; }
-}
-__device__ __forceinline__ void min16(double &d, int &col, int &who) {
-    min_step<0xB1>(d, col, who);     // quad_perm [1,0,3,2]  : lane ^ 1
-    min_step<0x4E>(d, col, who);     // quad_perm [2,3,0,1]  : lane ^ 2
-    min_step<0x141>(d, col, who);    // row_half_mirror       : i <-> 7 - i  (pairs the two quads)
-    min_step<0x140>(d, col, who);    // row_mirror            : i <-> 15 - i (pairs the two halves)
+// minimum over the wavefront's first cn lanes (the others pass +inf), wave-uniform.  Row operations inside the
+// 16-lane DPP rows, the xor butterfly (ds_bpermute) only for components wider than a row.
+__device__ __forceinline__ double wave_min_d(double d, int cn) {
+    d = fmin(d, dpp_d<0xB1>(d));      // quad_perm [1,0,3,2]  : lane ^ 1
+    d = fmin(d, dpp_d<0x4E>(d));      // quad_perm [2,3,0,1]  : lane ^ 2
+    d = fmin(d, dpp_d<0x141>(d));     // row_half_mirror       : i <-> 7 - i  (pairs the two quads)
+    d = fmin(d, dpp_d<0x140>(d));     // row_mirror            : i <-> 15 - i (pairs the two halves)
+    if (cn > 16) d = fmin(d, __shfl_xor(d, 16));
+    if (cn > 32) d = fmin(d, __shfl_xor(d, 32));
+    return bcast_d(d, 0);
 }
 
 // ---- 3. one wavefront per packed component: shortest augmenting paths ---------------------------------
+constexpr int DN_R = 8, DN_C = 32;   // components up to DN_R x DN_C also get a dense cost block
 struct SmallLds {                    // per-wavefront adjacency copy
-    double ecost[SM_EDGES];
+    double ecost[SM_EDGES];          // (dense form: [0, DN_R * DN_C) the block, the edge list behind it)
     int32_t ecol[SM_EDGES];          // column lane
 };
+static_assert(2 * DN_R * DN_C <= SM_EDGES, "dense block + its edge list share ecost[]");
 
 // Components with <= 64 rows, <= 64 columns and <= SM_EDGES edges: lane k owns local row k (u, its
 // column) AND local column k (v, owner, distance, predecessor, scanned); the adjacency sits in LDS;
-// every step of the Dijkstra search is a handful of __shfl / ds_bpermute operations -- no global
-// memory inside the search.  Returns false if the component does not fit.
+// every step of the Dijkstra search is a handful of DPP / v_readlane operations -- no global memory
+// inside the search.  Small components (most of them: a few rows) keep a dense rows x columns cost
+// block, so that relaxing from a row is ONE LDS read per lane instead of a walk over the row's edge list.
+// Returns false if the component does not fit.
 __device__ __forceinline__ bool solve_packed(const LapArgs &A, int c, int lane, SmallLds &L) {
     const bts_lap_work &w = A.w;
     const double limit = A.limit, INF = __builtin_huge_val();
     const int4 d = w.cdesc[c];
     const int rs = d.x, cs = d.y, r = d.z & 0xff, cn = (d.z >> 8) & 0xff, ne = d.z >> 16, eb = d.w;
     if (r > 64 || cn > 64 || ne > SM_EDGES) return false;
+    const bool dense = r <= DN_R && cn <= DN_C && ne <= DN_R * DN_C;
+    double *ecs = dense ? L.ecost + DN_R * DN_C : L.ecost;
     const int4 ri = lane < r ? w.rowinfo[rs + lane] : make_int4(0x7fffffff, 0, 0, 0);
     const int my_col = lane < cn ? w.colid[cs + lane] : 0x7fffffff;
-    for (int e = lane; e < ne; e += 64) { L.ecost[e] = w.csr_cost[eb + e]; L.ecol[e] = w.csr_lcol[eb + e]; }   // one contiguous block
+    for (int e = lane; e < ne; e += 64) { ecs[e] = w.csr_cost[eb + e]; L.ecol[e] = w.csr_lcol[eb + e]; }   // one contiguous block
+    if (dense)
+        for (int k = lane; k < DN_R * DN_C; k += 64) L.ecost[k] = INF;
     // rows in ascending id order (the grouping appended them in arbitrary order)
     int my_row = 0x7fffffff, e_lo = 0, e_hi = 0;
     {
@@ -566,66 +572,83 @@ __device__ __forceinline__ bool solve_packed(const LapArgs &A, int c, int lane, 
     }
     lds_sync();
     double u = limit;
-    for (int e = e_lo; e < e_hi; ++e) u = fmin(u, L.ecost[e]);
+    for (int e = e_lo; e < e_hi; ++e) u = fmin(u, ecs[e]);
+    if (dense) {
+        for (int e = e_lo; e < e_hi; ++e) L.ecost[lane * DN_C + L.ecol[e]] = ecs[e];
+        lds_sync();
+    }
     int xr = -1, yc = -1;       // row -> local column, column -> local row
     double v = 0.0;
-    for (int i0 = 0; i0 < r; ++i0) {
-        double dist = INF;
-        int pred = -1;
-        bool scanned = false;
-        double exit_d = limit - bcast_d(u, i0);
-        int exit_row = i0, cur = i0, end_col = -1;
-        double dcur = 0.0, mu = 0.0;
-        for (;;) {
-            const double ucur = bcast_d(u, cur);
+    // relax(cur, ucur, dcur, dist, pred, scanned): offers every unscanned column the path through row `cur`
+    auto run = [&](auto relax) {
+        for (int i0 = 0; i0 < r; ++i0) {
+            double dist = INF;
+            int pred = -1;
+            bool scanned = false;
+            double exit_d = limit - bcast_d(u, i0);
+            int exit_row = i0, cur = i0, end_col = -1;
+            double dcur = 0.0, mu = 0.0;
+            for (;;) {
+                relax(cur, bcast_d(u, cur), dcur, dist, pred, scanned);
+                const bool cand = lane < cn && !scanned;
+                const double bd = wave_min_d(cand ? dist : INF, cn);
+                if (!(bd < INF) || exit_d < bd) { mu = exit_d; break; }
+                // the column at that distance; several: the smallest column id
+                const unsigned long long tie = __ballot(cand && dist == bd);
+                int bl = __ffsll((long long)tie) - 1;
+                if (tie & (tie - 1)) {
+                    int bc = 0x7fffffff;
+                    for (unsigned long long t = tie; t; t &= t - 1) {
+                        const int l = __ffsll((long long)t) - 1, cc = bcast_i(my_col, l);
+                        if (cc < bc) { bc = cc; bl = l; }
+                    }
+                }
+                const int owner = bcast_i(yc, bl);
+                if (owner < 0) { mu = bd; end_col = bl; break; }
+                if (lane == bl) scanned = true;
+                cur = owner; dcur = bd;
+                const double e2 = bd + (limit - bcast_d(u, owner));
+                if (e2 < exit_d) { exit_d = e2; exit_row = owner; }
+            }
+            // duals: every scanned column hands its delta to the row that owns it
+            const double delta = scanned ? mu - dist : 0.0;
+            if (scanned) v -= delta;
+            const double dfrom = __shfl(delta, xr >= 0 ? xr : 0);
+            if (xr >= 0) u += dfrom;
+            if (lane == i0) u += mu;
+            // augment
+            int j = end_col;
+            if (j < 0) {
+                if (exit_row == i0) continue;
+                j = bcast_i(xr, exit_row);
+                if (lane == exit_row) xr = -1;
+            }
+            for (;;) {
+                const int i = bcast_i(pred, j);
+                const int jn = bcast_i(xr, i);
+                if (lane == i) xr = j;
+                if (lane == j) yc = i;
+                if (i == i0) break;
+                j = jn;
+            }
+        }
+    };
+    if (dense) {
+        run([&](int cur, double ucur, double dcur, double &dist, int &pred, bool scanned) {
+            const double cst = L.ecost[__builtin_amdgcn_readfirstlane(cur) * DN_C + (lane & (DN_C - 1))];
+            const double nd = dcur + ((cst - ucur) - v);       // (absent pair: +inf, never below dist)
+            if (lane < DN_C && !scanned && nd < dist) { dist = nd; pred = cur; }
+        });
+    } else {
+        run([&](int cur, double ucur, double dcur, double &dist, int &pred, bool scanned) {
             const int e0 = bcast_i(e_lo, cur), e1 = bcast_i(e_hi, cur);
             for (int e = e0; e < e1; ++e) {
                 if (L.ecol[e] == lane && !scanned) {
-                    const double nd = dcur + ((L.ecost[e] - ucur) - v);
+                    const double nd = dcur + ((ecs[e] - ucur) - v);
                     if (nd < dist) { dist = nd; pred = cur; }
                 }
             }
-            double bd = (lane < cn && !scanned) ? dist : INF;
-            int bcol = my_col, bl = lane;
-            min16(bd, bcol, bl);
-            if (cn > 16) {
-#pragma unroll
-                for (int off = 32; off >= 16; off >>= 1) {
-                    const double od = __shfl_xor(bd, off);
-                    const int oc = __shfl_xor(bcol, off), ol = __shfl_xor(bl, off);
-                    if (od < bd || (od == bd && oc < bcol)) { bd = od; bcol = oc; bl = ol; }
-                }
-            }
-            bd = bcast_d(bd, 0); bl = bcast_i(bl, 0);
-            if (!(bd < INF) || exit_d < bd) { mu = exit_d; break; }
-            const int owner = bcast_i(yc, bl);
-            if (owner < 0) { mu = bd; end_col = bl; break; }
-            if (lane == bl) scanned = true;
-            cur = owner; dcur = bd;
-            const double e2 = bd + (limit - bcast_d(u, owner));
-            if (e2 < exit_d) { exit_d = e2; exit_row = owner; }
-        }
-        // duals: every scanned column hands its delta to the row that owns it
-        const double delta = scanned ? mu - dist : 0.0;
-        if (scanned) v -= delta;
-        const double dfrom = __shfl(delta, xr >= 0 ? xr : 0);
-        if (xr >= 0) u += dfrom;
-        if (lane == i0) u += mu;
-        // augment
-        int j = end_col;
-        if (j < 0) {
-            if (exit_row == i0) continue;
-            j = bcast_i(xr, exit_row);
-            if (lane == exit_row) xr = -1;
-        }
-        for (;;) {
-            const int i = bcast_i(pred, j);
-            const int jn = bcast_i(xr, i);
-            if (lane == i) xr = j;
-            if (lane == j) yc = i;
-            if (i == i0) break;
-            j = jn;
-        }
+        });
     }
     const int xcol = __shfl(my_col, xr >= 0 ? xr : 0), yrow = __shfl(my_row, yc >= 0 ? yc : 0);
     if (lane < r) A.x[my_row] = xr >= 0 ? xcol : -1;

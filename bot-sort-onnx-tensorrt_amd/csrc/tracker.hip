@@ -1125,7 +1125,7 @@ struct bts_tracker {
     int32_t *x_ints = nullptr; double *x_mean = nullptr, *x_tlbr = nullptr, *x_mot = nullptr; float *x_score = nullptr;
     int32_t *host_hdr = nullptr;   // pinned
     // optional per-segment timing (bts_tracker_profile_*): a ring of hipEvent pairs
-    int prof_seg = -1, prof_cap = 0, prof_n = 0;
+    int prof_seg = -1, prof_cap = 0, prof_n = 0, prof_stride = 1;
     hipEvent_t *prof_ev = nullptr;
     // input descriptors: pinned host ring -> one device descriptor (40-byte async copy per step)
     static constexpr int RING = 64;
@@ -1280,6 +1280,12 @@ int bts_tracker_profile_enable(bts_tracker *t, int segment, int capacity) {
     return BTS_OK;
 }
 
+int bts_tracker_profile_stride(bts_tracker *t, int stride) {
+    BTS_REQUIRE(t && stride >= 1, "tracker, stride");
+    t->prof_stride = stride;
+    return BTS_OK;
+}
+
 int bts_tracker_profile_read(bts_tracker *t, double *total_ms, int32_t *count) {
     BTS_REQUIRE(t && total_ms && count, "null argument");
     double tot = 0.0;
@@ -1319,7 +1325,7 @@ int bts_tracker_reset(bts_tracker *t, bts_stream stream) {
 // Enqueue the kernels of one step.  `mc` bounds every detection-indexed grid (the frame's m in eager
 // mode, max_dets under graph capture; `capturing` = no timing events).
 static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face_feats, int mc, bool capturing) {
-    const bool prof_room = !capturing && t->prof_cap > 0 && t->prof_n < t->prof_cap;
+    const bool prof_room = !capturing && t->prof_cap > 0 && t->prof_n < t->prof_cap && t->step_no % t->prof_stride == 0;
     auto seg_begin = [&](int id) { if (prof_room && t->prof_seg == id) (void)hipEventRecord(t->prof_ev[2 * t->prof_n], s); };
     auto seg_end = [&](int id) { if (prof_room && t->prof_seg == id) { (void)hipEventRecord(t->prof_ev[2 * t->prof_n + 1], s); t->prof_n++; } };
     const Dev &d = t->dv;

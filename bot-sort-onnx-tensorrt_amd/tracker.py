@@ -327,8 +327,10 @@ class DeviceTracker:
                 "merge": 8, "dedupe": 9, "k_filter": 20, "k_lap": 21, "k_edges1": 23, "k_mid2": 24, "k_apply23": 25,
                 "step": 100}
 
-    def profile_enable(self, segment: str, capacity: int):
+    def profile_enable(self, segment: str, capacity: int, stride: int = 1):
+        """hipEvent pairs around `segment` on every `stride`-th step, at most `capacity` of them."""
         _lib.check(self._lib.bts_tracker_profile_enable(self.handle, self.SEGMENTS[segment], int(capacity)))
+        _lib.check(self._lib.bts_tracker_profile_stride(self.handle, int(stride)))
 
     def profile_read(self):
         """-> (total_ms, count) of the hipEvent pairs recorded since the last read."""

@@ -250,6 +250,8 @@ enum bts_segment {
     BTS_SEG_STEP = 100
 };
 int bts_tracker_profile_enable(bts_tracker *trk, int segment, int capacity);
+/* Record events only on every `stride`-th step (default 1): an event pair costs the stream a few microseconds. */
+int bts_tracker_profile_stride(bts_tracker *trk, int stride);
 /* Synchronises on the recorded events; returns their summed duration and count, then clears them. */
 int bts_tracker_profile_read(bts_tracker *trk, double *total_ms, int32_t *count);
 
