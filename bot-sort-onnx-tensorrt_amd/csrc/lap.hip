@@ -34,6 +34,16 @@ enum { H_EDGES = 0, H_COMPS = 1, H_ERR = 2, H_HARD = 3, H_NA = 4, H_MA = 5, H_NH
 
 typedef bts_lap_problem LapArgs;
 
+// Phase timeline of a launch (make TRACE=1, scripts/dbg_laptrace.py): 100 MHz timestamps in hdr[9 + k].
+#ifdef BTS_LAP_TRACE
+#define TR(w, k) do { if (threadIdx.x == 0) RST(&(w).hdr[9 + (k)], (int)__builtin_amdgcn_s_memrealtime()); } while (0)
+#define TRH(w, k) do { if (blockIdx.y == 1 && threadIdx.x == 0) RST(&(w).hdr[9 + (k)], (int)__builtin_amdgcn_s_memrealtime()); } while (0)
+#else
+#define TR(w, k) do { } while (0)
+#define TRH(w, k) do { } while (0)
+#endif
+
+
 
 // Lanes of one wavefront hand values to each other through global memory (lane 0 publishes a
 // decision, every lane reads it back): drain this wave's outstanding stores/loads before going on.
@@ -200,17 +210,17 @@ struct SmallPipe {                   // LDS image of the hard sub-problem (slot 
     // ---- everything below is dead while the node table is alive: the table borrows it ----
     int32_t parent[SM_EH + SM_C];                 // union-find: row slots [0,NA), column slots [NA, NA+MA)
     int32_t rptr[SM_EH + 1];                      // row slot -> edges
-    int32_t cid[SM_EH + 1];                       // root row slot -> component; later gstart
+    int32_t cid[SM_EH + 1];                       // root row slot -> component; later ebase / ecur
     int32_t crp[SM_C + 1], ccp[SM_C + 1];         // component -> first row / column of its group
     int32_t ecnt[SM_C];                           // component -> edges
     int32_t cur_c_[SM_C];
-    uint16_t comp[SM_EH], ccomp[SM_EH];           // row slot / column slot -> component; later rpos / lane_of_col
+    uint16_t comp[SM_EH], ccomp[SM_EH];           // row slot / column slot -> component; ccomp later lane_of_col
     // arrays with disjoint lifetimes share storage
     __device__ int32_t *cursor() { return parent; }            // [NA] (after the roots are known)
     __device__ int32_t *cur_r() { return parent + SM_EH; }     // [C]
     __device__ int32_t *cur_c() { return cur_c_; }
-    __device__ int32_t *gstart() { return cid; }               // [NA+1] grouped row position -> first edge (after comp holds component ids)
-    __device__ uint16_t *rpos() { return comp; }               // row slot -> position in the grouped row list (written by the last reader of comp[s])
+    __device__ int32_t *ebase() { return cid; }                // [C+1] component -> first edge (after comp holds component ids)
+    __device__ int32_t *ecur() { return cid + SM_C + 1; }      // [C]
     __device__ uint16_t *lane_of_col() { return ccomp; }       // column slot -> lane inside its component (same)
 };
 
@@ -228,6 +238,32 @@ __device__ int find_root_lds(int32_t *parent, int x) {
 constexpr int TABLE_CAP = 6 * SM_EH + SM_C;  // node-table entries that fit in the borrowed storage
 static_assert(sizeof(SmallPipe) - offsetof(SmallPipe, parent) >= TABLE_CAP * sizeof(int32_t), "node table does not fit");
 static_assert(TABLE_CAP < 65536, "global ids are kept in 16 bits");
+
+// inclusive prefix sum across the 64 lanes: DPP row shifts, then the row broadcasts (lane 15 -> next row, lane 31 -> rows 2, 3)
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+// ONE wavefront: out_a[k] = out_b[k] = sum of src[0..k) for k < len, out_a[len] = total (src may be out_a).
+// Returns whether any src[k] exceeds `limit` (lane-local; the caller raises a flag).
+__device__ __forceinline__ bool wave_exscan_lds(const int32_t *src, int len, int32_t *out_a, int32_t *out_b, int limit, int lane) {
+    const int per = (len + 63) >> 6;
+    const int lo = min(len, lane * per), hi = min(len, lo + per);
+    int sum = 0;
+    bool over = false;
+    for (int k = lo; k < hi; ++k) { const int v = src[k]; sum += v; over |= v > limit; }
+    const int incl = wave_incl_scan(sum);
+    int run = incl - sum;
+    for (int k = lo; k < hi; ++k) { const int v = src[k]; out_a[k] = run; out_b[k] = run; run += v; }
+    if (lane == 63) out_a[len] = incl;
+    return over;
+}
 
 template <int EC> __device__ int small_pipeline(const LapArgs &A, SmallPipe &L, int E, int n, int m, int32_t *tmp) {
     const bts_lap_work &w = A.w;
@@ -273,6 +309,7 @@ template <int EC> __device__ int small_pipeline(const LapArgs &A, SmallPipe &L, 
     }
     bscan::lds_barrier();
     const int EH = L.EH;
+    TR(w, 2);
     if (EH == 0) return 0;
     if (EH > SM_EH) {
         // Too many non-trivial edges for the LDS form: hand over to the global-memory form WITHOUT redoing the degree
@@ -302,6 +339,7 @@ template <int EC> __device__ int small_pipeline(const LapArgs &A, SmallPipe &L, 
     const int NA = L.NA, MA = L.MA;
     for (int h = tid; h < EH; h += nth) { L.hr[h] = (uint16_t)(tab[L.hr[h]] & ~FIRST); L.hc[h] = (uint16_t)(tab[n + L.hc[h]] & ~FIRST); }      // (row, col) -> slots, in place
     bscan::lds_barrier();                                      // the table is dead from here on
+    TR(w, 3);
     for (int s = tid; s < NA; s += nth) { L.parent[s] = s; L.rptr[s] = 0; }
     for (int s = tid; s < MA; s += nth) L.parent[NA + s] = NA + s;
     bscan::lds_barrier();
@@ -315,41 +353,41 @@ template <int EC> __device__ int small_pipeline(const LapArgs &A, SmallPipe &L, 
     for (int s = tid; s < MA; s += nth) L.ccomp[s] = (uint16_t)find_root_lds(L.parent, NA + s);
     bscan::lds_barrier();
     const int C = L.C;
+    TR(w, 4);
     for (int s = tid; s < NA; s += nth) { const int c = L.cid[L.comp[s]]; L.comp[s] = (uint16_t)c; atomicAdd(&L.crp[c], 1); atomicAdd(&L.ecnt[c], L.rptr[s]); }
     for (int s = tid; s < MA; s += nth) { const int c = L.cid[L.ccomp[s]]; L.ccomp[s] = (uint16_t)c; atomicAdd(&L.ccp[c], 1); }
     bscan::lds_barrier();
-    for (int c = tid; c < C; c += nth)                    // (a plain flag: no contended atomics for the common all-fit case)
-        if (L.crp[c] > 64 || L.ccp[c] > 64 || L.ecnt[c] > SM_EDGES) L.maxr = 65;
+    // Three wavefronts scan the component tables side by side -- rows, columns, edges: group offsets plus the cursors
+    // the grouping pass bumps -- and check them against the solver's limits (a plain flag: no contended atomics).
+    int32_t *cursor = L.cursor(), *cur_r = L.cur_r(), *cur_c = L.cur_c(), *ebase = L.ebase(), *ecur = L.ecur();
+    uint16_t *lane_of_col = L.lane_of_col();
+    if (tid < 192) {
+        const int wv = tid >> 6, ln = tid & 63;
+        const bool over = wv == 0 ? wave_exscan_lds(L.crp, C, L.crp, cur_r, 64, ln)
+                        : wv == 1 ? wave_exscan_lds(L.ccp, C, L.ccp, cur_c, 64, ln)
+                                  : wave_exscan_lds(L.ecnt, C, ebase, ecur, SM_EDGES, ln);
+        if (over) L.maxr = 65;
+    }
     bscan::lds_barrier();
     const bool fits = L.maxr <= 64;
+    TR(w, 5);
     if (!fits) return -2;                                 // (the table is gone by now: the other form starts over)
-    block_exscan_lds(L.crp, C, tmp);
-    block_exscan_lds(L.ccp, C, tmp);
-    if (tid == 0) { L.crp[C] = NA; L.ccp[C] = MA; }
-    int32_t *cursor = L.cursor(), *cur_r = L.cur_r(), *cur_c = L.cur_c(), *gstart = L.gstart();
-    uint16_t *rpos = L.rpos(), *lane_of_col = L.lane_of_col();
-    for (int c = tid; c < C; c += nth) { cur_r[c] = L.crp[c]; cur_c[c] = L.ccp[c]; }
-    bscan::lds_barrier();
-    // rows / columns grouped by component; edge ranges handed out in grouped row order, so that the
-    // edges of one component are one contiguous block
-    for (int s = tid; s < NA; s += nth) { const int pos = atomicAdd(&cur_r[L.comp[s]], 1); rpos[s] = (uint16_t)pos; gstart[pos] = L.rptr[s]; }
+    // rows / columns grouped by component; a row takes its edge range from its component's block, so that the
+    // edges of one component are contiguous (rows and ranges in arbitrary order inside: the solver sorts rows by id)
+    for (int s = tid; s < NA; s += nth) {
+        const int c = L.comp[s], deg = L.rptr[s];
+        const int pos = atomicAdd(&cur_r[c], 1), e0 = atomicAdd(&ecur[c], deg);
+        cursor[s] = e0;
+        w.rowinfo[pos] = make_int4(L.arow[s], e0, e0 + deg, 0);
+    }
     for (int s = tid; s < MA; s += nth) {
         const int c = L.ccomp[s], pos = atomicAdd(&cur_c[c], 1);
         lane_of_col[s] = (uint16_t)(pos - L.ccp[c]);
         w.colid[pos] = L.acol[s];
     }
-    bscan::lds_barrier();
-    block_exscan_lds(gstart, NA, tmp);
-    if (tid == 0) gstart[NA] = EH;
-    bscan::lds_barrier();
-    for (int s = tid; s < NA; s += nth) {
-        const int pos = rpos[s], e0 = gstart[pos];
-        cursor[s] = e0;
-        w.rowinfo[pos] = make_int4(L.arow[s], e0, e0 + L.rptr[s], 0);
-    }
     for (int c = tid; c < C; c += nth)
-        w.cdesc[c] = make_int4(L.crp[c], L.ccp[c], (L.crp[c + 1] - L.crp[c]) | ((L.ccp[c + 1] - L.ccp[c]) << 8) | (L.ecnt[c] << 16),
-                               gstart[L.crp[c]]);
+        w.cdesc[c] = make_int4(L.crp[c], L.ccp[c], (L.crp[c + 1] - L.crp[c]) | ((L.ccp[c + 1] - L.ccp[c]) << 8) | (L.ecnt[c] << 16), ebase[c]);
+    TR(w, 6);
     if (!cached) __syncthreads();                         // (w.hard[] is read back below: its stores must have landed)
     else bscan::lds_barrier();
     if (cached) {
@@ -368,6 +406,7 @@ template <int EC> __device__ int small_pipeline(const LapArgs &A, SmallPipe &L, 
         }
     }
     if (tid == 0) { RST(&w.hdr[H_COMPS], C); RST(&w.hdr[H_HARD], C); RST(&w.hdr[H_MODE], 1); RST(&w.hdr[H_NH], EH); }
+    TR(w, 7);
     return 0;
 }
 
@@ -550,7 +589,12 @@ static_assert(2 * DN_R * DN_C <= SM_EDGES, "dense block + its edge list share ec
 __device__ __forceinline__ bool solve_packed(const LapArgs &A, int c, int lane, SmallLds &L) {
     const bts_lap_work &w = A.w;
     const double limit = A.limit, INF = __builtin_huge_val();
+    TRH(w, 13);
     const int4 d = w.cdesc[c];
+#ifdef BTS_LAP_TRACE
+    if (d.x < 0) return false;
+#endif
+    TRH(w, 14);
     const int rs = d.x, cs = d.y, r = d.z & 0xff, cn = (d.z >> 8) & 0xff, ne = d.z >> 16, eb = d.w;
     if (r > 64 || cn > 64 || ne > SM_EDGES) return false;
     const bool dense = r <= DN_R && cn <= DN_C && ne <= DN_R * DN_C;
@@ -577,6 +621,10 @@ __device__ __forceinline__ bool solve_packed(const LapArgs &A, int c, int lane, 
         for (int e = e_lo; e < e_hi; ++e) L.ecost[lane * DN_C + L.ecol[e]] = ecs[e];
         lds_sync();
     }
+#ifdef BTS_LAP_TRACE
+    if (u < -1e300) return false;
+#endif
+    TRH(w, 15);
     int xr = -1, yc = -1;       // row -> local column, column -> local row
     double v = 0.0;
     // relax(cur, ucur, dcur, dist, pred, scanned): offers every unscanned column the path through row `cur`
@@ -651,6 +699,10 @@ __device__ __forceinline__ bool solve_packed(const LapArgs &A, int c, int lane, 
         });
     }
     const int xcol = __shfl(my_col, xr >= 0 ? xr : 0), yrow = __shfl(my_row, yc >= 0 ? yc : 0);
+#ifdef BTS_LAP_TRACE
+    if (xcol < -12345) return false;
+#endif
+    TRH(w, 16);
     if (lane < r) A.x[my_row] = xr >= 0 ? xcol : -1;
     if (lane < cn) A.y[my_col] = yc >= 0 ? yrow : -1;
     lds_sync();                 // the next component of this wavefront reuses L
@@ -782,7 +834,9 @@ template <int EC> __global__ __launch_bounds__(1024) void k_lap(LapPair P) {
     bool solo = false;
     if (blockIdx.y == 0) {
         const int n = A.dims ? A.dims[0] : A.n_max, m = A.dims ? A.dims[1] : A.m_max;
+        TR(w, 0);
         int E = RLX(&w.hdr[H_EDGES]);
+        TR(w, 1);
         if ((long)E > w.e_cap) E = (int)w.e_cap;
         // A short edge list means few components: this workgroup's 16 wavefronts solve them straight away
         // (no release / poll / re-read of the packed problem through memory); the helpers are sent home.
@@ -808,7 +862,9 @@ template <int EC> __global__ __launch_bounds__(1024) void k_lap(LapPair P) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             RST(&w.hdr[H_READY], 1 + C);
         }
+        TR(w, 8);
     } else {
+        TRH(w, 9);
         if (tid == 0) {
             int v = 0;
             for (long spins = 0; (v = RLX(&w.hdr[H_READY])) == 0 && spins < (1l << 22); ++spins) __builtin_amdgcn_s_sleep(8);
@@ -818,12 +874,17 @@ template <int EC> __global__ __launch_bounds__(1024) void k_lap(LapPair P) {
         }
         __syncthreads();
         C = s_c;
+        TRH(w, 10);
     }
     if (C == 0) return;
     SmallLds *lds = reinterpret_cast<SmallLds *>(lds_raw);
     const int gw = blockIdx.y * (nth >> 6) + wid, nw = (solo ? 1 : gridDim.y) * (nth >> 6);
     for (int c = gw; c < C; c += nw)
         if (!solve_packed(A, c, lane, lds[wid])) solve_component(A, c, lane);
+#ifdef BTS_LAP_TRACE
+    __syncthreads();
+    if (blockIdx.y <= 1) TR(w, 11 + blockIdx.y);
+#endif
 }
 
 }  // namespace
