@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--segment", default="auto", help="kernel timed for the roofline object (auto = the dominant one)")
     ap.add_argument("--event-stride", type=int, default=8, help="hipEvent pairs around the roofline kernel on every n-th timed step "
                     "(a pair costs the stream ~4 us: on every launch it inflates a 90 us step by several percent)")
+    ap.add_argument("--streams-per-gpu", type=int, default=1, help="independent video streams per GPU, each on its own HIP stream and "
+                    "host thread (the headline metric is 1; more shows what a GPU serves when steps are launch-bound)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--dense", action="store_true", help="dense float32 appearance path instead of the f16 pre-filter")
@@ -149,7 +151,8 @@ def main():
     K, M, D = pkg.synth.CONFIGS[a.workload]
     assert a.warmup >= 3, "warmup must cover the two pool-building frames"
 
-    st = pkg.synth.SyntheticStream(K, M, D, seed=ms_seed(pkg, rank))
+    S = max(1, a.streams_per_gpu)
+    st = pkg.synth.SyntheticStream(K, M, D, seed=ms_seed(pkg, rank * S))
     PROBE = 6
 
     def next_frame():
@@ -179,17 +182,36 @@ def main():
     segment = a.segment if a.segment != "auto" else max(KERNELS, key=lambda k: breakdown[k])
     trk.profile_enable(segment, 0 if a.graph else a.steps, max(1, min(a.event_stride, a.steps // 16)))     # (>= 16 samples)     # graph replay cannot carry per-kernel events
     timed = [next_frame() for _ in range(a.steps)]
+    extra = []                       # further streams of this GPU: (tracker, HIP stream, frames), warmed up the same way
+    for k in range(1, S):
+        st_k = pkg.synth.SyntheticStream(K, M, D, seed=ms_seed(pkg, rank * S + k))
+        hs = None
+        with torch.cuda.stream(torch.cuda.default_stream()):      # (set-up on the default stream: see multistream.run_concurrent)
+            tk = pkg.DeviceTracker(max_tracks=K + 64, max_dets=max(K, M), feat_dim=D, device=torch.cuda.current_device(),
+                                   appearance_mode=1 if a.dense else 0, use_graph=1 if a.graph else 0)
+            for _ in range(a.warmup + 6):
+                fr = st_k.next()
+                tk.step(torch.from_numpy(fr.boxes).cuda(), torch.from_numpy(fr.scores).cuda(), torch.from_numpy(fr.feats).cuda())
+            fl = []
+            for _ in range(a.steps):
+                fr = st_k.next()
+                fl.append((torch.from_numpy(fr.boxes).cuda(), torch.from_numpy(fr.scores).cuda(), torch.from_numpy(fr.feats).cuda()))
+        extra.append((tk, hs, fl))
     if a.graph:                                              # capture happens on the first replayed step: keep it untimed
         trk.step(*next_frame())
         torch.cuda.synchronize()
 
     ms.barrier(ddist)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for fr in timed:
-        trk.step(*fr)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
+    if S == 1:
+        t0 = time.perf_counter()
+        for fr in timed:
+            trk.step(*fr)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+    else:
+        t0 = 0.0
+        t1 = ms.run_concurrent([trk] + [e[0] for e in extra], [timed] + [e[2] for e in extra])
     ms.barrier(ddist)
     if a.graph:      # the dominant kernel's duration: same number of further steps, eager, with events
         trk.profile_enable(segment, a.steps)
@@ -199,6 +221,8 @@ def main():
     seg_ms, seg_n = trk.profile_read()
     counts = trk.counts()
     assert counts["errors"] == 0, counts
+    for e in extra:
+        assert e[0].counts()["errors"] == 0
     elapsed = ms.max_over_ranks(t1 - t0, ddist)
     if a.breakdown and rank == 0:
         sys.stderr.write("segment us/step: " + json.dumps({k: round(v, 1) for k, v in breakdown.items()}) + "\n")
@@ -212,15 +236,15 @@ def main():
             achieved, runit = amount / seg_s / 1e9, "GB/s"
         out = {
             "metric": "tracker update-steps/sec (N_tracks x M_dets)",
-            "value": ms.aggregate_throughput(a.steps, elapsed, world),
+            "value": ms.aggregate_throughput(a.steps * S, elapsed, world),
             "unit": "steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": 1e3 * elapsed / a.steps,
+            "ms_per_step": 1e3 * elapsed / a.steps,      # (one step of every stream)
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic (seeded stream generator, SURVEY.md 8d; frames resident in HBM before the timed region)",
             "config": {"workload": "%s: %d tracks x %d detections/frame x %d-d ReID, IoU+cosine fused cost, "
                                    "3-stage association, one stream per GPU" % (a.workload, K, M, D),
-                       "tracks": K, "dets": M, "feat_dim": D, "streams": world, "parallelism": "1 stream/GPU, no collective",
+                       "tracks": K, "dets": M, "feat_dim": D, "streams": world * S, "parallelism": "%d stream%s/GPU, no collective" % (S, "" if S == 1 else "s (own HIP stream + host thread each)"),
                        "launch": "hipGraph replay" if a.graph else "eager"},
             "roofline": {"kernel": KERNELS[segment], "bound": bound, "achieved": achieved, "peak": peak, "unit": runit,
                          "frac": achieved / peak, "traffic": pmc_traffic(a.workload, KERNELS[segment]),

@@ -55,6 +55,7 @@ SIGNATURES = {
     "bts_feature_renorm": (c_int, [_P, _P, _P, c_int, c_int, _P]),
     "bts_debug_q8_roundtrip": (c_int, [_P, _P, _P, c_int, _P]),
     "bts_debug_q8_model": (c_int, [_P, _P, _P]),
+    "bts_debug_launch_floor": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "bts_associate_parts": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, _P, c_int, _P, _P]),
     "bts_dedupe_pairs": (c_int, [_P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_double, _P, _P, _P]),
     "bts_tracker_default_config": (c_int, [POINTER(TrackerConfig)]),

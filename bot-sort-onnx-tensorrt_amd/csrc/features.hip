@@ -63,6 +63,25 @@ int bts_debug_q8_model(double *rel, double *abs_, double *scale) {
 }
 
 
+// Launch-floor probe: `launches` dependent launches of a kernel that follows a chain of `links` dependent loads
+// (each workgroup walks buf[0] -> buf[buf[0]] -> ...; links = 0: an empty kernel).  Timed by the caller.
+__global__ void k_floor_probe(int32_t *buf, int32_t *out, int links) {
+    // chain: buf[0] -> buf[64] -> buf[128] ... (one cache line each), rewritten by every launch so that the next
+    // launch finds the lines freshly produced by another kernel (cold in its L2), like real producer/consumer kernels
+    int v = 0;
+    for (int k = 0; k < links; ++k) v = __hip_atomic_load(&buf[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0 && v == 12345) out[blockIdx.x] = v;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x < 64) buf[threadIdx.x * 64] = (threadIdx.x + 1) * 64;
+}
+int bts_debug_launch_floor(bts_context *ctx, int32_t *buf, int launches, int blocks, int threads, int links, bts_stream stream) {
+    BTS_REQUIRE(ctx && buf && launches >= 0 && blocks > 0 && threads > 0 && links >= 0, "arguments");
+    for (int k = 0; k < launches; ++k) {
+        hipLaunchKernelGGL(k_floor_probe, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, buf, buf + 4096, links);
+        BTS_LAUNCH_CHECK();
+    }
+    return BTS_OK;
+}
+
 int bts_feature_ema(bts_context *ctx, float *curr, float *smooth, uint8_t *has_smooth,
                     const int32_t *trk_idx, const float *det_feats, const int32_t *det_idx, int k, int d,
                     double alpha, bts_stream stream) {

@@ -143,6 +143,9 @@ int bts_dedupe_pairs(bts_context *ctx, const double *a_tlbr, const uint8_t *a_f3
  * quantise(x[i])) for n floats, and the model |y - x| <= rel |x| + abs the candidate bound is derived from. */
 int bts_debug_q8_roundtrip(bts_context *ctx, const float *x, float *y, int n, bts_stream stream);
 int bts_debug_q8_model(double *rel, double *abs_, double *scale);
+/* Launch-floor probe (scripts/launch_floor.py): `launches` back-to-back launches of a kernel whose workgroups follow
+   `links` dependent loads through buf (int32[>= 8192], zero-filled). */
+int bts_debug_launch_floor(bts_context *ctx, int32_t *buf, int launches, int blocks, int threads, int links, bts_stream stream);
 
 /* Detection-side part association: find_most_relevant_object (D:1763-1791, IoU of integer boxes per
  * bbox_iou_by_box D:1715-1729) applied to each base box in order, `picks` times per base (1 for

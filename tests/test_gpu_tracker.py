@@ -413,3 +413,42 @@ def test_huge_table_capacity(bts, synth):
         c = trk.counts()
         assert c["errors"] == 0 and c["last_id"] == ora._count
     trk.close()
+
+
+@pytest.mark.gpu
+def test_concurrent_streams_match_sequential(bts, synth):
+    """Several video streams on one GPU, each on its own HIP stream and host thread (multistream.run_concurrent):
+    every stream's tables must equal what the same stream produces when it runs alone."""
+    import torch
+    ms = importlib.import_module("bot-sort-onnx-tensorrt_amd.multistream")
+    K, M, D, S, F = 96, 48, 256, 4, 24
+    frames = []
+    for k in range(S):
+        st = synth.SyntheticStream(K, M, D, seed=ms.stream_seed(777, k), churn=0.05)
+        frames.append([_dev_frame(st.next())[:3] for _ in range(F)])
+    torch.cuda.synchronize()
+
+    def tables(trk):
+        out = []
+        for which in (0, 1):
+            t = trk.export(which)
+            out.append({key: t[key].copy() for key in INT_KEYS + ("mean",)})
+        return out
+
+    alone = []
+    for k in range(S):
+        trk = bts.DeviceTracker(max_tracks=K + 64, max_dets=K, feat_dim=D)
+        for fr in frames[k]:
+            trk.step(*fr)
+        alone.append(tables(trk))
+        trk.close()
+    trackers = [bts.DeviceTracker(max_tracks=K + 64, max_dets=K, feat_dim=D) for _ in range(S)]
+    ms.run_concurrent(trackers, frames)
+    for k in range(S):
+        got = tables(trackers[k])
+        assert trackers[k].counts()["errors"] == 0
+        for which in (0, 1):
+            for key in INT_KEYS:
+                assert np.array_equal(got[which][key], alone[k][which][key]), (k, which, key)
+            assert np.array_equal(got[which]["mean"], alone[k][which]["mean"]), (k, which)
+        trackers[k].close()
