@@ -55,6 +55,7 @@ SIGNATURES = {
     "bts_feature_renorm": (c_int, [_P, _P, _P, c_int, c_int, _P]),
     "bts_debug_q8_roundtrip": (c_int, [_P, _P, _P, c_int, _P]),
     "bts_debug_q8_model": (c_int, [_P, _P, _P]),
+    "bts_debug_jobtrace": (c_int, [_P]),
     "bts_debug_launch_floor": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "bts_associate_parts": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, _P, c_int, _P, _P]),
     "bts_dedupe_pairs": (c_int, [_P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_double, _P, _P, _P]),
@@ -88,6 +89,8 @@ def load(require_gpu: bool = False) -> ctypes.CDLL:
         import torch  # noqa: F401  (loads the HIP runtime the library binds to)
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
+            if name.startswith("bts_debug_") and not hasattr(lib, name):
+                continue                     # (measurement probes only: older builds in A/B runs lack some)
             fn = getattr(lib, name)          # AttributeError here = header/library mismatch
             fn.restype = res
             fn.argtypes = args

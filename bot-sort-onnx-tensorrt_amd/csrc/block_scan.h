@@ -1,6 +1,7 @@
 // block_scan.h -- workgroup-wide exclusive scan / ordered compaction built from wavefront __shfl
 // scans (64 lanes, no LDS traffic inside a wave) plus one LDS hop across the <=16 waves.
 // All functions must be reached by every thread of the workgroup (blockDim.x multiple of 64).
+#include <cstdint>
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -85,24 +86,26 @@ __device__ __forceinline__ int compact(int L, int *smem, Pred pred, Emit emit) {
 // The two levels are separate passes over the wavefront's R rounds, so that all first-level loads are in flight
 // together and then all second-level ones: two memory latencies for the whole selection, whatever R is.
 // (A predicate written `a && b` with loads on both sides would serialise them behind branches: use `&`.)
-template <int R, class Load, class Pred, class Emit>
-__device__ __forceinline__ int compact_ws_r(int L, int chunk, int *smem, Load load, Pred pred, Emit emit) {
+// k0 / basefn: the compaction may be one CHUNK of a longer one (see Chunk below): indices [k0, L), positions offset by
+// basefn(local total), which every thread calls once between the counting and the emitting pass.
+template <int R, class Load, class Pred, class Emit, class BaseFn>
+__device__ __forceinline__ int compact_ws_r(int k0, int L, int chunk, int *smem, Load load, Pred pred, Emit emit, BaseFn basefn) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const int base = wid * chunk;
+    const int base = k0 + wid * chunk;
     int val[R];
     unsigned long long bal[R];
     int cnt = 0;
-    // no branches around the loads (out-of-range lanes re-read index 0)
+    // no branches around the loads (out-of-range lanes re-read index k0)
 #pragma unroll
     for (int j = 0; j < R; ++j) {
         const int k = base + j * 64 + lane;
-        val[j] = load((j * 64 < chunk && k < L) ? k : 0);
+        val[j] = load((j * 64 < chunk && k < L) ? k : k0);
     }
 #pragma unroll
     for (int j = 0; j < R; ++j) {
         const int k = base + j * 64 + lane;
         const bool inb = j * 64 < chunk && k < L;
-        const bool keep = pred(inb ? k : 0, val[j]);
+        const bool keep = pred(inb ? k : k0, val[j]);
         bal[j] = __ballot(inb && keep);
         cnt += __popcll(bal[j]);
     }
@@ -111,6 +114,8 @@ __device__ __forceinline__ int compact_ws_r(int L, int chunk, int *smem, Load lo
     lds_barrier();
     int pos = 0, total = 0;
     for (int w = 0; w < nw; ++w) { const int c = smem[w]; if (w < wid) pos += c; total += c; }
+    const int off = basefn(total);
+    pos += off;
     const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
     for (int j = 0; j < R; ++j) {
@@ -118,7 +123,7 @@ __device__ __forceinline__ int compact_ws_r(int L, int chunk, int *smem, Load lo
         pos += __popcll(bal[j]);
     }
     lds_barrier();
-    return total;
+    return off + total;
 }
 
 template <class Load, class Pred, class Emit>
@@ -126,10 +131,102 @@ __device__ __forceinline__ int compact_ws(int L, int *smem, Load load, Pred pred
     const int nw = blockDim.x >> 6;
     const int chunk = ((L + nw - 1) / nw + 63) & ~63, rounds = chunk >> 6;
     if (L <= 0) return 0;
-    if (rounds <= 1) return compact_ws_r<1>(L, chunk, smem, load, pred, emit);
-    if (rounds <= 4) return compact_ws_r<4>(L, chunk, smem, load, pred, emit);
-    if (rounds <= 16) return compact_ws_r<16>(L, chunk, smem, load, pred, emit);
+    auto none = [](int) { return 0; };
+    if (rounds <= 1) return compact_ws_r<1>(0, L, chunk, smem, load, pred, emit, none);
+    if (rounds <= 4) return compact_ws_r<4>(0, L, chunk, smem, load, pred, emit, none);
+    if (rounds <= 16) return compact_ws_r<16>(0, L, chunk, smem, load, pred, emit, none);
     return compact(L, smem, [&](int k) { return pred(k, load(k)); }, [&](int p, int k) { emit(p, k, load(k)); });
+}
+
+// ---- one ordered compaction shared by the nch consecutive workgroups of a launch ("chunks") -----------------------
+// Chunk ch handles the indices [ch * CL, (ch + 1) * CL) and offsets its output by the counts of the chunks before it,
+// which each chunk publishes in agg[] (decoupled look-back: a chunk only ever waits for chunks with a LOWER workgroup
+// index, which the dispatcher started first -- the same discipline as k_lap's helper workgroups).  agg[] entries carry
+// the step's epoch in their high half, so they are never cleared.  A single CU gathers only ~1 list element per clock:
+// chunks are how a 10 000-entry list job gets more than one CU's gather rate.
+struct Chunk {
+    unsigned long long *agg;       // [nch]
+    unsigned epoch;                // != 0, different from the previous uses of agg[]
+    int ch, nch;
+    int32_t *err;                  // word that gets `err_bit` OR-ed in if a wait times out (never hangs)
+    int err_bit;
+};
+constexpr int CHUNK_MAX = 16;
+constexpr unsigned CHUNK_FLAG = 0x80000000u;       // a user bit that travels with the count
+
+// Publishes (count | flag) of this chunk; returns the summed counts of the chunks before it.  want_all: waits for
+// EVERY chunk instead and also returns the grand total and the OR of all flags.  smem: >= 40 ints.
+__device__ __forceinline__ int chunk_publish(const Chunk &c, int count, bool flag, int *smem, bool want_all = false,
+                                             int *grand_total = nullptr, bool *any_flag = nullptr) {
+    if (c.nch <= 1) {
+        if (grand_total) *grand_total = count;
+        if (any_flag) *any_flag = flag;
+        return 0;
+    }
+    lds_barrier();                                   // smem may still be read from a previous call
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        if (lane == 0)
+            __hip_atomic_store(&c.agg[c.ch], ((unsigned long long)c.epoch << 32) | (unsigned)count | (flag ? CHUNK_FLAG : 0u),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned v = 0;
+        const bool mine = lane != c.ch && (want_all ? lane < c.nch : lane < c.ch);
+        if (mine) {
+            unsigned long long a = 0;
+            long spins = 0;
+            do {
+                a = __hip_atomic_load(&c.agg[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(a >> 32) == c.epoch) break;
+                __builtin_amdgcn_s_sleep(2);
+            } while (++spins < (1l << 22));
+            if ((unsigned)(a >> 32) == c.epoch) v = (unsigned)a;
+            else atomicOr(c.err, c.err_bit);
+        }
+        if (lane == c.ch) v = (unsigned)count | (flag ? CHUNK_FLAG : 0u);
+        int before = (lane < c.ch) ? (int)(v & ~CHUNK_FLAG) : 0, all = (lane < c.nch) ? (int)(v & ~CHUNK_FLAG) : 0;
+        unsigned long long fl = __ballot((v & CHUNK_FLAG) != 0);
+#pragma unroll
+        for (int off = 1; off < CHUNK_MAX; off <<= 1) { before += __shfl_xor(before, off); all += __shfl_xor(all, off); }
+        if (lane == 0) { smem[32] = before; smem[33] = all; smem[34] = fl != 0; }
+    }
+    lds_barrier();
+    if (grand_total) *grand_total = smem[33];
+    if (any_flag) *any_flag = smem[34] != 0;
+    return smem[32];
+}
+
+// the index range of chunk c of an L-long job
+__device__ __forceinline__ void chunk_range(const Chunk &c, int L, int &lo, int &hi) {
+    const int cl = ((L + c.nch - 1) / c.nch + 63) & ~63;
+    lo = min(L, c.ch * cl); hi = min(L, lo + cl);
+}
+
+// compact_ws over this chunk's share of [0, L): returns the number of items emitted by chunks 0 .. ch (the last chunk's
+// return value is the total).  `flag` / want_all / grand_total / any_flag: see chunk_publish.
+template <class Load, class Pred, class Emit>
+__device__ __forceinline__ int compact_chunk(const Chunk &c, int L, int *smem, Load load, Pred pred, Emit emit, bool flag = false,
+                                             bool want_all = false, int *grand_total = nullptr, bool *any_flag = nullptr) {
+    int lo, hi;
+    chunk_range(c, L, lo, hi);
+    const int nw = blockDim.x >> 6, len = hi - lo;
+    const int chunk = ((len + nw - 1) / nw + 63) & ~63, rounds = chunk >> 6;
+    auto basefn = [&](int total) { return chunk_publish(c, total, flag, smem, want_all, grand_total, any_flag); };
+    if (len <= 0) return basefn(0);                     // an empty chunk touches no list entry, but still publishes
+    if (rounds <= 1) return compact_ws_r<1>(lo, hi, chunk, smem, load, pred, emit, basefn);
+    if (rounds <= 4) return compact_ws_r<4>(lo, hi, chunk, smem, load, pred, emit, basefn);
+    if (rounds <= 16) return compact_ws_r<16>(lo, hi, chunk, smem, load, pred, emit, basefn);
+    // very long chunks: chunk-per-thread form on the sub-range
+    int cnt = 0;
+    const int tid = threadIdx.x, nth = blockDim.x, per = (len + nth - 1) / nth;
+    const int a = min(hi, lo + tid * per), b = min(hi, a + per);
+    for (int k = a; k < b; ++k) cnt += pred(k, load(k)) ? 1 : 0;
+    int total;
+    int pos = exscan(cnt, smem, &total);
+    const int off = basefn(total);
+    pos += off;
+    for (int k = a; k < b; ++k) { const int v = load(k); if (pred(k, v)) emit(pos++, k, v); }
+    lds_barrier();
+    return off + total;
 }
 
 // for (k = tid; k < L; k += nth) body(k, load(k)) with the loads of B iterations in flight together

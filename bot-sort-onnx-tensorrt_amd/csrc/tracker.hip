@@ -22,7 +22,19 @@ enum {   // hdr[] fields
     H_ERR, H_NCONF, H_ALLF32, H_NFREE, H_NDETS, H_NKEEP, H_NB, H_NRF, H_NL0, H_NL1, H_NBORN,
     H_DIMS1 = 24, H_DIMS2 = 26, H_DIMS3 = 28, H_SIZE = 32
 };
-enum { ERR_TRACK_CAPACITY = 1, ERR_LAP_EDGES = 2 };
+enum { ERR_TRACK_CAPACITY = 1, ERR_LAP_EDGES = 2, ERR_CHUNK_WAIT = 4 };
+// list jobs that are split over `Dev::nch` consecutive workgroups (bscan::Chunk): their slices of Dev::agg
+enum { J_POOL = 0, J_UNC, J_R2, J_KEEP, J_RF, J_L0, J_L1, J_FT, J_FL, J_COUNT };
+
+// Per-workgroup durations of the list jobs (make TRACE=1, bts_debug_jobtrace): 100 MHz ticks at g_jobtrace[kernel * 8 + job].
+__device__ int g_jobtrace[64];
+#ifdef BTS_LAP_TRACE
+#define TJ_BEGIN() const unsigned long long tj_t0 = __builtin_amdgcn_s_memrealtime()
+#define TJ_END(kern, job) do { __syncthreads(); if (threadIdx.x == 0) g_jobtrace[(kern) * 8 + (job)] = (int)(__builtin_amdgcn_s_memrealtime() - tj_t0); } while (0)
+#else
+#define TJ_BEGIN() do { } while (0)
+#define TJ_END(kern, job) do { } while (0)
+#endif
 
 // The frame's inputs: eager steps carry them in the kernel arguments; under hipGraph replay the
 // kernel arguments are frozen at capture, so they come from one small device-resident descriptor
@@ -31,7 +43,8 @@ struct InDesc {
     const int32_t *boxes;
     const float *scores;
     float *feats, *face_feats;
-    int m, pad;
+    int m;
+    unsigned epoch;            // step counter (never 0): tags the chunk counts of the split list jobs
 };
 
 struct Dev {
@@ -43,6 +56,8 @@ struct Dev {
     // track table
     double *mean, *cov;
     uint8_t *f32, *in_removed, *in_use;
+    unsigned long long *agg;   // [J_COUNT][CHUNK_MAX] chunk counts of the split list jobs
+    int nch;                   // workgroups per split list job
     int32_t *state, *is_activated, *track_id, *frame_id, *start_frame, *tracklet_len, *det_index;
     float *score;
     float *body_curr, *body_smooth, *face_curr, *face_smooth;
@@ -72,6 +87,29 @@ struct Dev {
     InDesc iv;                 // ... or by value in the kernel arguments (eager launches, in == nullptr)
 };
 #define IN(d, f) ((d).in ? (d).in->f : (d).iv.f)
+
+__device__ __forceinline__ bscan::Chunk chunk_of(const Dev &d, int job, int ch) {
+    return bscan::Chunk{d.agg + job * bscan::CHUNK_MAX, IN(d, epoch), ch, d.nch, d.hdr + H_ERR, ERR_CHUNK_WAIT};
+}
+// The list kernels exist in two instantiations: CH = false is the single-workgroup form of every job (tables up to
+// ~2048 tracks: the chunk machinery only costs there -- code size on a cold instruction cache), CH = true the split form.
+template <bool CH> __device__ __forceinline__ int nchunks(const Dev &d) { return CH ? d.nch : 1; }
+template <bool CH, class Load, class Pred, class Emit>
+__device__ __forceinline__ int job_compact(const bscan::Chunk &cx, int L, int32_t *tmp, Load load, Pred pred, Emit emit, bool flag = false,
+                                           bool want_all = false, int *grand_total = nullptr, bool *any_flag = nullptr) {
+    if constexpr (CH) {
+        return bscan::compact_chunk(cx, L, tmp, load, pred, emit, flag, want_all, grand_total, any_flag);
+    } else {
+        const int n = bscan::compact_ws(L, tmp, load, pred, emit);
+        if (grand_total) *grand_total = n;
+        if (any_flag) *any_flag = flag;
+        return n;
+    }
+}
+template <bool CH> __device__ __forceinline__ void job_range(const bscan::Chunk &cx, int L, int &lo, int &hi) {
+    if constexpr (CH) bscan::chunk_range(cx, L, lo, hi);
+    else { lo = 0; hi = L; }
+}
 
 // ---- single-workgroup helpers: bscan::exscan / bscan::compact (block_scan.h) ------------------------
 template <class Load, class Pred, class Emit>
@@ -114,41 +152,49 @@ __device__ __forceinline__ void slot_tlbr(const Dev &d, int slot, double out[4])
 // D:1414-1423 (split tracked into confirmed / unconfirmed, pool = confirmed ++ lost) and the
 // detection records of D:1488-1532 (high: score > 0.40, low: 0.1 <= score <= 0.40; float32 boxes).
 // Each job owns its hdr words; the list order is semantics (it defines the row indices).
-__device__ __forceinline__ void prep_pool(const Dev &d) {
+template <bool CH> __device__ __forceinline__ void prep_pool(const Dev &d, int ch) {
     __shared__ int32_t tmp[1024];
-    __shared__ int s_allf32;
     int32_t *h = d.hdr;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, nth = blockDim.x;
     const int nt = h[H_NTRACKED], nl = h[H_NLOST];
-    if (tid == 0) s_allf32 = 1;
-    const int nconf = block_compact(nt, tmp, [&](int k) { return d.tracked[k]; }, [&](int k, int s) { return d.is_activated[s] != 0; },
-                                    [&](int p, int k, int s) { d.pool_slot[p] = s; });
-    bscan::for_batched<8>(nl, [&](int k) { return d.lost[k]; }, [&](int k, int s) { d.pool_slot[nconf + k] = s; });
-    const int N = nconf + nl;
-    __syncthreads();
+    const bscan::Chunk cx = chunk_of(d, J_POOL, ch);
+    int lo, hi;
+    job_range<CH>(cx, nl, lo, hi);
     // "every pool row still holds float32 state" (np.asarray of the batch is then float32, Q10) can only be true on
     // the frame after the one that activated its births at once (frame 1, D:565-566): later births enter the pool
-    // through an update, which makes their state float64
-    int all32 = h[H_FRAME] == 1 ? 1 : 0;
-    if (all32) bscan::for_batched<8>(N, [&](int k) { return d.pool_slot[k]; }, [&](int k, int s) { if (!d.f32[s]) all32 = 0; });
-    if (!all32) s_allf32 = 0;
-    __syncthreads();
-    if (tid == 0) {
+    // through an update, which makes their state float64.  Each chunk looks at its own rows; the verdict travels
+    // with the chunk counts.
+    const bool chk = h[H_FRAME] == 1;
+    int f64 = 0;
+    if (chk) {
+        int a, b;
+        job_range<CH>(cx, nt, a, b);
+        for (int k = a + tid; k < b; k += nth) { const int s = d.tracked[k]; if ((d.is_activated[s] != 0) & !d.f32[s]) f64 = 1; }
+        for (int k = lo + tid; k < hi; k += nth) if (!d.f32[d.lost[k]]) f64 = 1;
+        f64 = __syncthreads_or(f64);
+    }
+    int nconf = 0;
+    bool any64 = false;
+    job_compact<CH>(cx, nt, tmp, [&](int k) { return d.tracked[k]; }, [&](int k, int s) { return d.is_activated[s] != 0; },
+                         [&](int p, int k, int s) { d.pool_slot[p] = s; }, f64 != 0, true, &nconf, &any64);
+    for (int k = lo + tid; k < hi; k += nth) d.pool_slot[nconf + k] = d.lost[k];
+    if (ch == 0 && tid == 0) {           // (every chunk has read H_FRAME by now: all of them have published)
+        const int N = nconf + nl;
         h[H_FRAME] += 1;
         h[H_NPOOL] = N; h[H_NCONF] = nconf;
-        h[H_ALLF32] = (N > 0 && s_allf32) ? 1 : 0;
+        h[H_ALLF32] = (N > 0 && chk && !any64) ? 1 : 0;
         h[H_DIMS1] = N;
         h[H_NR2] = 0; h[H_DIMS2] = 0;
     }
 }
 
-__device__ __forceinline__ void prep_unconfirmed(const Dev &d) {
+template <bool CH> __device__ __forceinline__ void prep_unconfirmed(const Dev &d, int ch) {
     __shared__ int32_t tmp[1024];
     int32_t *h = d.hdr;
     const int nt = h[H_NTRACKED];
-    const int nunc = block_compact(nt, tmp, [&](int k) { return d.tracked[k]; }, [&](int k, int s) { return d.is_activated[s] == 0; },
-                                   [&](int p, int k, int s) { d.unc_slot[p] = s; });
-    if (threadIdx.x == 0) { h[H_NUNC] = nunc; h[H_DIMS3] = nunc; }
+    const int nunc = job_compact<CH>(chunk_of(d, J_UNC, ch), nt, tmp, [&](int k) { return d.tracked[k]; },
+                                          [&](int k, int s) { return d.is_activated[s] == 0; }, [&](int p, int k, int s) { d.unc_slot[p] = s; });
+    if (ch == nchunks<CH>(d) - 1 && threadIdx.x == 0) { h[H_NUNC] = nunc; h[H_DIMS3] = nunc; }
 }
 
 __device__ __forceinline__ void prep_dets(const Dev &d) {
@@ -216,16 +262,17 @@ __device__ __forceinline__ void cvt_body(const Dev &d, long blk) {        // fou
     if (d.Df) feat::to_q8_row(IN(d, face_feats) + j * d.Df, d.dface_h + j * d.Df, d.dface_n + j, d.Df, on);
 }
 
-// one launch: workgroups 0-3 build the frame's lists, the others convert the detection rows
-constexpr int FRONT_JOBS = 4;
-__global__ __launch_bounds__(1024) void tk_front(Dev d) {
-    switch (blockIdx.x) {
-    case 0: prep_pool(d); break;
-    case 1: prep_unconfirmed(d); break;
-    case 2: prep_dets(d); break;
-    case 3: prep_free(d); break;
-    default: cvt_body(d, (long)blockIdx.x - FRONT_JOBS);
-    }
+// one launch: the first workgroups build the frame's lists (two jobs of nch chunks each, the detection lists, the free slots),
+// the others convert the detection rows
+__host__ __device__ constexpr int front_jobs(int nch) { return 2 * nch + 2; }
+template <bool CH> __global__ __launch_bounds__(1024) void tk_front(Dev d) {
+    TJ_BEGIN();
+    const int b = blockIdx.x, nch = nchunks<CH>(d);
+    if (b < nch) { prep_pool<CH>(d, b); if (b == 0) TJ_END(0, 0); }
+    else if (b < 2 * nch) { prep_unconfirmed<CH>(d, b - nch); if (b == 2 * nch - 1) TJ_END(0, 1); }
+    else if (b == 2 * nch) { prep_dets(d); TJ_END(0, 2); }
+    else if (b == 2 * nch + 1) { prep_free(d); TJ_END(0, 3); }
+    else { cvt_body(d, (long)b - front_jobs(nch)); if (b == front_jobs(nch)) TJ_END(0, 4); }
 }
 
 __device__ __forceinline__ void predict_body(const Dev &d, int bid) {
@@ -799,8 +846,8 @@ __global__ __launch_bounds__(256) void tk_apply23(Dev d, int kf_blocks, int feat
 }
 
 // ---- after stage 1: rows of stage 2, columns of stage 3 (three single-workgroup jobs) -------------------
-constexpr int MID1_JOBS = 3;
-__device__ __forceinline__ void after1_body(const Dev &d, int job) {
+__host__ __device__ constexpr int mid1_jobs(int nch) { return nch + 2; }
+template <bool CH> __device__ __forceinline__ void after1_body(const Dev &d, int job, int ch) {
     __shared__ int32_t tmp[1024];
     int32_t *h = d.hdr;
     if (job == 0) {
@@ -808,13 +855,13 @@ __device__ __forceinline__ void after1_body(const Dev &d, int job) {
         // Tracked by the stage-1 update, which runs after this launch: the state test sees pre-frame state.
         // (only the confirmed rows of the pool, [0, nconf), can be Tracked: the rest are the lost tracks)
         const int N = h[H_NCONF];
-        const int nr2 = block_compact(N, tmp, [&](int r) { return d.pool_slot[r]; },
-                                      [&](int r, int s) { return (d.x1[r] < 0) & (d.state[s] == BTS_TRACKED); },
-                                      [&](int p, int r, int s) {
-                                          d.r2_row[p] = r; d.r2_slot[p] = s;
-                                          for (int c = 0; c < 4; ++c) d.r2_tlbr[p * 4 + c] = d.pool_tlbr[r * 4 + c];
-                                      });
-        if (threadIdx.x == 0) { h[H_NR2] = nr2; h[H_DIMS2] = nr2; }
+        const int nr2 = job_compact<CH>(chunk_of(d, J_R2, ch), N, tmp, [&](int r) { return d.pool_slot[r]; },
+                                             [&](int r, int s) { return (d.x1[r] < 0) & (d.state[s] == BTS_TRACKED); },
+                                             [&](int p, int r, int s) {
+                                                 d.r2_row[p] = r; d.r2_slot[p] = s;
+                                                 for (int c = 0; c < 4; ++c) d.r2_tlbr[p * 4 + c] = d.pool_tlbr[r * 4 + c];
+                                             });
+        if (ch == nchunks<CH>(d) - 1 && threadIdx.x == 0) { h[H_NR2] = nr2; h[H_DIMS2] = nr2; }
     } else if (job == 1) {
         const int nhi = h[H_NHI];
         const int nleft = block_compact(nhi, tmp, [&](int q) { return d.hi_idx[q]; }, [&](int q, int det) { return d.y1[q] < 0; },
@@ -833,9 +880,12 @@ __device__ __forceinline__ void after1_body(const Dev &d, int job) {
 }
 
 // one launch after the first assignment: workgroups 0-2 prepare stages 2/3, the others renormalise rows
-__global__ __launch_bounds__(1024) void tk_mid1(Dev d) {
-    if (blockIdx.x < MID1_JOBS) after1_body(d, blockIdx.x);
-    else renorm_body(d, (int)blockIdx.x - MID1_JOBS);
+template <bool CH> __global__ __launch_bounds__(1024) void tk_mid1(Dev d) {
+    TJ_BEGIN();
+    const int b = blockIdx.x, nch = nchunks<CH>(d);
+    if (b < nch) { after1_body<CH>(d, 0, b); if (b == nch - 1) TJ_END(1, 0); }
+    else if (b < nch + 2) { after1_body<CH>(d, 1 + (b - nch), 0); TJ_END(1, 1 + (b - nch)); }
+    else { renorm_body(d, b - mid1_jobs(nch)); if (b == mid1_jobs(nch)) TJ_END(1, 3); }
 }
 
 // ---- births + list merge, D:1614-1636: five independent single-workgroup jobs ----------------------------
@@ -843,7 +893,7 @@ __global__ __launch_bounds__(1024) void tk_mid1(Dev d) {
 // lost'    = ([old lost not re-found] ++ newly lost (pool order)) minus ids already in removed (Q6).
 // Each piece is compacted by its own workgroup into its own region of tracked2 / lost2 (T entries
 // apart); tracked2_at / lost2_at read the concatenation.
-constexpr int MERGE_JOBS = 5;
+__host__ __device__ constexpr int merge_jobs(int nch) { return 1 + 4 * nch; }      // births + four chunked jobs
 __device__ __forceinline__ int tracked2_at(const Dev &d, int k) {
     const int c0 = d.hdr[H_NKEEP], c1 = d.hdr[H_NB];
     return k < c0 ? d.tracked2[k] : k < c0 + c1 ? d.tracked2[d.T + (k - c0)] : d.tracked2[2 * d.T + (k - c0 - c1)];
@@ -853,12 +903,15 @@ __device__ __forceinline__ int lost2_at(const Dev &d, int k) {
     return k < c0 ? d.lost2[k] : d.lost2[d.T + (k - c0)];
 }
 
-__global__ __launch_bounds__(1024) void tk_merge(Dev d) {
+template <bool CH> __global__ __launch_bounds__(1024) void tk_merge(Dev d) {
     __shared__ int32_t tmp[1024];
     int32_t *h = d.hdr;
     const int tid = threadIdx.x, nth = blockDim.x;
     const int frame = h[H_FRAME];
-    if (blockIdx.x == 0) {
+    TJ_BEGIN();
+    const int nch = nchunks<CH>(d), job = blockIdx.x == 0 ? 0 : 1 + ((int)blockIdx.x - 1) / nch, ch = blockIdx.x == 0 ? 0 : ((int)blockIdx.x - 1) % nch;
+    const bool last = ch == nch - 1;
+    if (job == 0) {
         // births in ascending leftover-detection order (new ids ascending, quirk Q7)
         const int nleft = h[H_NLEFT], nfree = h[H_NFREE], last_id = h[H_LASTID];
         const float *scores = IN(d, scores);
@@ -891,53 +944,62 @@ __global__ __launch_bounds__(1024) void tk_merge(Dev d) {
                 if (d.lap_hdr[BTS_LAP_HDR_INTS * k + 2]) err |= ERR_LAP_EDGES;
             if (err) atomicOr(&h[H_ERR], err);
         }
-    } else if (blockIdx.x == 1) {
+    } else if (job == 1) {
         const int nt = h[H_NTRACKED];
-        const int n_keep = block_compact(nt, tmp, [&](int k) { return d.tracked[k]; }, [&](int k, int s) { return d.state[s] == BTS_TRACKED; },
-                                         [&](int p, int k, int s) { d.tracked2[p] = s; });
-        if (tid == 0) h[H_NKEEP] = n_keep;
-    } else if (blockIdx.x == 2) {
+        const int n_keep = job_compact<CH>(chunk_of(d, J_KEEP, ch), nt, tmp, [&](int k) { return d.tracked[k]; },
+                                                [&](int k, int s) { return d.state[s] == BTS_TRACKED; }, [&](int p, int k, int s) { d.tracked2[p] = s; });
+        if (last && tid == 0) h[H_NKEEP] = n_keep;
+    } else if (job == 2) {
         // re-found = lost rows of the pool (rows >= nconf) that stage 1 matched; no per-slot flag needed
         const int N = h[H_NPOOL], nconf = h[H_NCONF];
-        const int n_rf = block_compact(N - nconf, tmp, [&](int k) { return d.x1[nconf + k]; }, [&](int k, int xq) { return xq >= 0; },
-                                       [&](int p, int k, int) { d.tracked2[2 * d.T + p] = d.pool_slot[nconf + k]; });
-        if (tid == 0) h[H_NRF] = n_rf;
-    } else if (blockIdx.x == 3) {
+        const int n_rf = job_compact<CH>(chunk_of(d, J_RF, ch), N - nconf, tmp, [&](int k) { return d.x1[nconf + k]; },
+                                              [&](int k, int xq) { return xq >= 0; },
+                                              [&](int p, int k, int) { d.tracked2[2 * d.T + p] = d.pool_slot[nconf + k]; });
+        if (last && tid == 0) h[H_NRF] = n_rf;
+    } else if (job == 3) {
         const int nl = h[H_NLOST], nunc = h[H_NUNC], nconf = h[H_NCONF];
         // old lost that were not re-found (x1 of their pool row < 0) and whose id is not in removed (Q6)
-        const int n_l0 = block_compact(nl, tmp, [&](int k) { return d.lost[k]; },
-                                       [&](int k, int s) { return (d.x1[nconf + k] < 0) & !d.in_removed[s]; },
-                                       [&](int p, int k, int s) { d.lost2[p] = s; });
+        const bscan::Chunk cx = chunk_of(d, J_L0, ch);
+        const int n_l0 = job_compact<CH>(cx, nl, tmp, [&](int k) { return d.lost[k]; },
+                                              [&](int k, int s) { return (d.x1[nconf + k] < 0) & !d.in_removed[s]; },
+                                              [&](int p, int k, int s) { d.lost2[p] = s; });
+        int lo, hi;
+        job_range<CH>(cx, nl, lo, hi);
         // expiry of lost tracks (D:1623-1627); re-found ones carry frame_id == frame.  removed_stracks.extend(
         // removed_now): the ids (here: slots) are remembered for the next frames -- after the filter above (Q6)
         int gone = 0;
-        for (int k0 = tid; k0 < nl; k0 += 8 * nth) {          // (two levels of loads, 8 iterations in flight)
-            int sl[8], fid[8];
+        for (int k0 = lo + tid; k0 < hi; k0 += 4 * nth) {     // (this chunk's share; two levels of loads, 4 iterations in flight)
+            int sl[4], fid[4];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { const int k = k0 + j * nth; sl[j] = d.lost[k < nl ? k : 0]; }
+            for (int j = 0; j < 4; ++j) { const int k = k0 + j * nth; sl[j] = d.lost[k < hi ? k : lo]; }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) fid[j] = d.frame_id[sl[j]];
+            for (int j = 0; j < 4; ++j) fid[j] = d.frame_id[sl[j]];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < 4; ++j) {
                 const int k = k0 + j * nth, s = sl[j];
-                if (k < nl && frame - fid[j] > d.max_time_lost) { d.state[s] = BTS_REMOVED; d.in_removed[s] = 1; ++gone; }
+                if (k < hi && frame - fid[j] > d.max_time_lost) { d.state[s] = BTS_REMOVED; d.in_removed[s] = 1; ++gone; }
             }
         }
         // unconfirmed tracks that stage 3 left unmatched were removed (D:1609-1612)
-        bscan::for_batched<4>(nunc, [&](int k) { return d.x3[k]; }, [&](int k, int xq) {
-            if (xq < 0) { d.in_removed[d.unc_slot[k]] = 1; ++gone; }
-        });
+        if (ch == 0)
+            bscan::for_batched<4>(nunc, [&](int k) { return d.x3[k]; }, [&](int k, int xq) {
+                if (xq < 0) { d.in_removed[d.unc_slot[k]] = 1; ++gone; }
+            });
         int tot_gone;
         block_exscan_i(gone, tmp, &tot_gone);
-        if (tid == 0) { h[H_NL0] = n_l0; h[H_NREMOVED] += tot_gone; }
+        if (tid == 0) {
+            if (last) h[H_NL0] = n_l0;
+            if (tot_gone) atomicAdd(&h[H_NREMOVED], tot_gone);
+        }
     } else {
         // newly lost = stage-2 rows (the still-Tracked leftovers of stage 1, in pool order) that stage 2 left unmatched
         const int nr2 = h[H_NR2];
-        const int n_l1 = block_compact(nr2, tmp, [&](int k) { return d.r2_slot[k]; },
-                                       [&](int k, int s) { return (d.x2[k] < 0) & !d.in_removed[s]; },
-                                       [&](int p, int k, int s) { d.lost2[d.T + p] = s; });
-        if (tid == 0) h[H_NL1] = n_l1;
+        const int n_l1 = job_compact<CH>(chunk_of(d, J_L1, ch), nr2, tmp, [&](int k) { return d.r2_slot[k]; },
+                                              [&](int k, int s) { return (d.x2[k] < 0) & !d.in_removed[s]; },
+                                              [&](int p, int k, int s) { d.lost2[d.T + p] = s; });
+        if (last && tid == 0) h[H_NL1] = n_l1;
     }
+    if (last) TJ_END(2, job);
 }
 
 // Kalman initiate + feature rows of the newborn tracks (D:556-568, D:492-514): one workgroup per
@@ -1036,21 +1098,31 @@ __global__ __launch_bounds__(CT_COLS) void tk_tail(Dev d, int dedupe_blocks) {
 }
 
 // ---- frame epilogue: final lists (one workgroup each), drop flags cleared for the next frame ------------------
-__global__ __launch_bounds__(1024) void tk_finalize(Dev d) {
+template <bool CH> __global__ __launch_bounds__(1024) void tk_finalize(Dev d) {
     __shared__ int32_t tmp[1024];
     int32_t *h = d.hdr;
     const int tid = threadIdx.x, nth = blockDim.x;
-    if (blockIdx.x == 0) {
+    TJ_BEGIN();
+    const int nch = nchunks<CH>(d), job = (int)blockIdx.x / nch, ch = (int)blockIdx.x % nch;
+    int lo, hi;
+    if (job == 0) {
         const int nt2 = h[H_NKEEP] + h[H_NB] + h[H_NRF];
-        const int nt = block_compact(nt2, tmp, [&](int k) { return tracked2_at(d, k); }, [&](int k, int s) { return !d.drop_t[k]; }, [&](int p, int k, int s) { d.tracked[p] = s; });
-        for (int k = tid; k < nt2; k += nth) d.drop_t[k] = 0;
-        if (tid == 0) h[H_NTRACKED] = nt;
+        const bscan::Chunk cx = chunk_of(d, J_FT, ch);
+        const int nt = job_compact<CH>(cx, nt2, tmp, [&](int k) { return tracked2_at(d, k); }, [&](int k, int s) { return !d.drop_t[k]; },
+                                            [&](int p, int k, int s) { d.tracked[p] = s; });
+        job_range<CH>(cx, nt2, lo, hi);
+        for (int k = lo + tid; k < hi; k += nth) d.drop_t[k] = 0;
+        if (ch == nch - 1 && tid == 0) h[H_NTRACKED] = nt;
     } else {
         const int nl2 = h[H_NL0] + h[H_NL1];
-        const int nl = block_compact(nl2, tmp, [&](int k) { return lost2_at(d, k); }, [&](int k, int s) { return !d.drop_l[k]; }, [&](int p, int k, int s) { d.lost[p] = s; });
-        for (int k = tid; k < nl2; k += nth) d.drop_l[k] = 0;
-        if (tid == 0) h[H_NLOST] = nl;
+        const bscan::Chunk cx = chunk_of(d, J_FL, ch);
+        const int nl = job_compact<CH>(cx, nl2, tmp, [&](int k) { return lost2_at(d, k); }, [&](int k, int s) { return !d.drop_l[k]; },
+                                            [&](int p, int k, int s) { d.lost[p] = s; });
+        job_range<CH>(cx, nl2, lo, hi);
+        for (int k = lo + tid; k < hi; k += nth) d.drop_l[k] = 0;
+        if (ch == nch - 1 && tid == 0) h[H_NLOST] = nl;
     }
+    if (ch == nch - 1) TJ_END(3, job);
 }
 
 __global__ __launch_bounds__(1024) void tk_reset(Dev d) {
@@ -1061,6 +1133,7 @@ __global__ __launch_bounds__(1024) void tk_reset(Dev d) {
         d.is_activated[s] = 0; d.track_id[s] = 0; d.has_body[s] = 0; d.has_face[s] = 0;
     }
     for (int k = tid; k < H_SIZE; k += nth) d.hdr[k] = 0;
+    for (int k = tid; k < J_COUNT * bscan::CHUNK_MAX; k += nth) d.agg[k] = 0ull;
     __syncthreads();
     if (tid == 0) d.hdr[H_NFREE] = d.T;
     for (int j = tid; j < d.Mx; j += nth) d.ones[j] = 1;
@@ -1146,6 +1219,7 @@ static void tracker_layout(bts_tracker *t, char *base, size_t &off) {
 #define SLOT(ptr, type, count) { size_t o = take(off, sizeof(type) * (size_t)(count)); ptr = base ? (type *)(base + o) : nullptr; }
     SLOT(d.mean, double, 8 * T); SLOT(d.cov, double, 64 * T);
     SLOT(d.f32, uint8_t, T); SLOT(d.in_removed, uint8_t, T); SLOT(d.in_use, uint8_t, T);
+    SLOT(d.agg, unsigned long long, J_COUNT * bscan::CHUNK_MAX);
     SLOT(d.has_body, uint8_t, T); SLOT(d.has_face, uint8_t, T);
     SLOT(d.state, int32_t, T); SLOT(d.is_activated, int32_t, T); SLOT(d.track_id, int32_t, T);
     SLOT(d.frame_id, int32_t, T); SLOT(d.start_frame, int32_t, T); SLOT(d.tracklet_len, int32_t, T);
@@ -1208,6 +1282,13 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
     d.ema_a = (float)cfg->ema_alpha; d.ema_b = (float)(1.0 - cfg->ema_alpha);
     d.max_time_lost = (int)((double)cfg->frame_rate / 30.0 * cfg->track_buffer);    // D:1276-1277
     d.record = cfg->record_costs ? 1 : 0;
+    {   // list jobs over tables beyond ~6000 tracks are split into chunks of ~2048 entries, one workgroup each
+        // (measured: 4096 tracks slightly better unsplit, 10 000 +3.5 %, 16 384 +6.5 %); BTS_CHUNK_ROWS forces a chunk size
+        const char *e = getenv("BTS_CHUNK_ROWS");
+        const int rows = e && atoi(e) > 0 ? atoi(e) : 2048;
+        d.nch = (!e && d.T <= 6144) ? 1 : bts_cdiv(d.T, rows);
+        d.nch = d.nch < 1 ? 1 : d.nch > 8 ? 8 : d.nch;
+    }
     // the pre-filter works on 128-element K steps; other feature widths take the dense float32 path
     d.filter = (cfg->appearance_mode == BTS_APPEARANCE_FILTER && d.D % DBK == 0 && d.Df % DBK == 0) ? 1 : 0;
     d.eps_body = feat::q8_cos_error(d.D);
@@ -1349,7 +1430,8 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
 
     seg_begin(BTS_SEG_STEP);
     seg_begin(BTS_SEG_PREP);
-    LAUNCH(tk_front, dim3(FRONT_JOBS + (d.filter ? bts_cdiv(mc, 4) : 0)), dim3(1024));
+    if (d.nch > 1) { LAUNCH(tk_front<true>, dim3(front_jobs(d.nch) + (d.filter ? bts_cdiv(mc, 4) : 0)), dim3(1024)); }
+    else { LAUNCH(tk_front<false>, dim3(front_jobs(1) + (d.filter ? bts_cdiv(mc, 4) : 0)), dim3(1024)); }
     seg_end(BTS_SEG_PREP);
     const bool dense = !d.filter || d.record;
     // split-K factor of the pre-filter: small problems have too few 128x128 tiles to fill 256 CUs
@@ -1419,7 +1501,8 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
     }
     seg_end(BTS_SEG_LAP1);
     seg_begin(BTS_SEG_APPLY1);
-    LAUNCH(tk_mid1, dim3(MID1_JOBS + bts_cdiv(mc, 4)), dim3(1024));       // stage-2/3 lists read pre-update states: before the stage-1 updates
+    if (d.nch > 1) { LAUNCH(tk_mid1<true>, dim3(mid1_jobs(d.nch) + bts_cdiv(mc, 4)), dim3(1024)); }
+    else { LAUNCH(tk_mid1<false>, dim3(mid1_jobs(1) + bts_cdiv(mc, 4)), dim3(1024)); }       // stage-2/3 lists read pre-update states: before the stage-1 updates
     if (dense) {
         rc = bts_cos_enqueue(cos_kernel, d.body_curr, d.unc_slot, d.D, feats, d.left_det, d.D, d.D, d.hdr + H_DIMS3, T, mc,
                              d.sim, M, s);
@@ -1446,7 +1529,8 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
     seg_end(BTS_SEG_STAGE2);
     // ---- births, list merge, duplicate removal
     seg_begin(BTS_SEG_MERGE);
-    LAUNCH(tk_merge, dim3(MERGE_JOBS), dim3(1024));
+    if (d.nch > 1) { LAUNCH(tk_merge<true>, dim3(merge_jobs(d.nch)), dim3(1024)); }
+    else { LAUNCH(tk_merge<false>, dim3(merge_jobs(1)), dim3(1024)); }
     seg_end(BTS_SEG_MERGE);
     seg_begin(BTS_SEG_DEDUPE);
     {
@@ -1463,7 +1547,8 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
         default: LAUNCH(tk_tail<64>, dim3(nd + mc), dim3(CT_COLS), nd); break;
         }
     }
-    LAUNCH(tk_finalize, dim3(2), dim3(1024));
+    if (d.nch > 1) { LAUNCH(tk_finalize<true>, dim3(2 * d.nch), dim3(1024)); }
+    else { LAUNCH(tk_finalize<false>, dim3(2), dim3(1024)); }
     seg_end(BTS_SEG_DEDUPE);
     seg_end(BTS_SEG_STEP);
 #undef LAUNCH
@@ -1487,7 +1572,7 @@ int bts_tracker_step(bts_tracker *t, const int32_t *boxes, const float *scores, 
         // this frame's descriptor: next slot of the pinned ring (wait if the GPU is a whole ring behind)
         const int slot = (int)(t->step_no % bts_tracker::RING);
         if (t->in_used[slot]) BTS_HIP(hipEventSynchronize(t->in_ev[slot]));
-        t->h_in[slot] = InDesc{boxes, scores, feats, face_feats, m, 0};
+        t->h_in[slot] = InDesc{boxes, scores, feats, face_feats, m, (unsigned)(t->step_no + 1)};
         BTS_HIP(hipMemcpyAsync(t->d_in, &t->h_in[slot], sizeof(InDesc), hipMemcpyHostToDevice, s));
         t->dv.in = t->d_in;
         if (!t->gexec) {       // capture once, with capacity-sized grids, on the private streams
@@ -1505,7 +1590,7 @@ int bts_tracker_step(bts_tracker *t, const int32_t *boxes, const float *scores, 
         t->in_used[slot] = true;
     } else {
         t->dv.in = nullptr;
-        t->dv.iv = InDesc{boxes, scores, feats, face_feats, m, 0};
+        t->dv.iv = InDesc{boxes, scores, feats, face_feats, m, (unsigned)(t->step_no + 1)};
         rc = enqueue_step(t, s, feats, face_feats, m > 0 ? m : 1, false);
         if (rc) return rc;
     }
@@ -1564,6 +1649,12 @@ int bts_tracker_gmc(bts_tracker *t, const double *h2x3_host, bts_stream stream) 
     for (int k = 0; k < 6; ++k) w.h[k] = h2x3_host[k];
     hipLaunchKernelGGL(tk_gmc, dim3(bts_cdiv(t->dv.T, 64)), dim3(64), 0, (hipStream_t)stream, t->dv, w);
     BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+
+int bts_debug_jobtrace(int32_t *out64_host) {
+    BTS_REQUIRE(out64_host, "out");
+    BTS_HIP(hipMemcpyFromSymbol(out64_host, HIP_SYMBOL(g_jobtrace), 64 * sizeof(int32_t)));
     return BTS_OK;
 }
 

@@ -145,6 +145,9 @@ int bts_debug_q8_roundtrip(bts_context *ctx, const float *x, float *y, int n, bt
 int bts_debug_q8_model(double *rel, double *abs_, double *scale);
 /* Launch-floor probe (scripts/launch_floor.py): `launches` back-to-back launches of a kernel whose workgroups follow
    `links` dependent loads through buf (int32[>= 8192], zero-filled). */
+/* Durations of the tracker's single-workgroup list jobs (library built with `make TRACE=1`; zeros otherwise):
+   100 MHz ticks at out[kernel * 8 + job], kernels 0..3 = tk_front, tk_mid1, tk_merge, tk_finalize. */
+int bts_debug_jobtrace(int32_t *out64_host);
 int bts_debug_launch_floor(bts_context *ctx, int32_t *buf, int launches, int blocks, int threads, int links, bts_stream stream);
 
 /* Detection-side part association: find_most_relevant_object (D:1763-1791, IoU of integer boxes per

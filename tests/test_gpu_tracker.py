@@ -452,3 +452,14 @@ def test_concurrent_streams_match_sequential(bts, synth):
                 assert np.array_equal(got[which][key], alone[k][which][key]), (k, which, key)
             assert np.array_equal(got[which]["mean"], alone[k][which]["mean"]), (k, which)
         trackers[k].close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows", [16, 100, 1000])
+def test_chunked_list_jobs_vs_oracle(bts, synth, monkeypatch, rows):
+    """The list jobs over the track table (pool, unconfirmed, free slots, stage-2 rows, kept / re-found / lost pieces,
+    final lists) split over several workgroups (BTS_CHUNK_ROWS entries each, read at create): same tables as the oracle,
+    with churn (births, removals, re-finds, duplicates) so that every piece is non-trivial and chunks are ragged/empty."""
+    monkeypatch.setenv("BTS_CHUNK_ROWS", str(rows))
+    assert _against_oracle(bts, synth, 120, 60, 128, frames=40, churn=0.15, frame_rate=2, seed=77) > 500
+    assert _against_oracle(bts, synth, 300, 200, 256, frames=16, churn=0.05, seed=78) > 1000
