@@ -41,4 +41,28 @@ __device__ __forceinline__ double cost(const double a[4], bool a32, double area_
     return 1.0 - q;
 }
 
+// ---- conservative overlap pre-test on 16-bit pixel boxes -------------------------------------------------------
+// The N x M pair tests are instruction-bound (nearly all pairs are disjoint), so the screening box is two packed
+// dwords -- lo = (floor x1, floor y1), hi = (ceil x2 - 1, ceil y2 - 1) -- and a pair costs v_pk_max_i16, v_pk_min_i16,
+// v_pk_sub_i16 and one sign test.  Never misses an overlap: floor(a.x1) <= a.x1 < b.x2 <= ceil(b.x2), and the clamps
+// (lo to [-16000, 15999], hi to [-15999, 16000]) keep lo < hi for every pair that satisfied it before clamping, so
+// boxes beyond the 16-bit range only make the test say "maybe".  (The exact float64 IoU decides afterwards.)
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+struct ScreenBox { s16x2 lo, hi; };
+
+__device__ __forceinline__ ScreenBox screen_box(const double b[4]) {
+    auto lo = [](double v) { const int i = __double2int_rd(v); return (short)(i < -16000 ? -16000 : i > 15999 ? 15999 : i); };
+    auto hi = [](double v) { const int i = __double2int_ru(v); return (short)((i < -15999 ? -15999 : i > 16000 ? 16000 : i) - 1); };
+    ScreenBox s;
+    s.lo = s16x2{lo(b[0]), lo(b[1])};
+    s.hi = s16x2{hi(b[2]), hi(b[3])};
+    return s;
+}
+
+__device__ __forceinline__ bool screen_overlap(const ScreenBox &a, const ScreenBox &b) {
+    const s16x2 lo = __builtin_elementwise_max(a.lo, b.lo), hi = __builtin_elementwise_min(a.hi, b.hi);
+    const s16x2 dd = hi - lo;                      // both halves >= 0 <=> lo < hi + 1 in x and in y
+    return (__builtin_bit_cast(unsigned, dd) & 0x80008000u) == 0u;
+}
+
 }  // namespace iou

@@ -327,7 +327,7 @@ __device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, 
     __shared__ int sflag[ROWS];
     __shared__ int sslot[ROWS];
     __shared__ float sna[ROWS], snf[ROWS];
-    __shared__ float4 sboxf[ROWS];       // row boxes rounded OUTWARD to float32 (conservative overlap pre-test)
+    __shared__ iou::ScreenBox sboxf[ROWS];       // row boxes rounded OUTWARD to 16-bit pixels (conservative overlap pre-test)
     const int32_t *h = d.hdr;
     const int n = STAGE == 1 ? h[H_NPOOL] : STAGE == 2 ? h[H_NR2] : h[H_NUNC];
     const int m = STAGE == 1 ? h[H_NHI] : STAGE == 2 ? h[H_NLO] : h[H_NLEFT];
@@ -363,7 +363,7 @@ __device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, 
         for (int c = 0; c < 4; ++c) sa[threadIdx.x][c] = box[c];
         sarea[threadIdx.x] = iou::area(box, f);
         sflag[threadIdx.x] = f;
-        sboxf[threadIdx.x] = make_float4(__double2float_rd(box[0]), __double2float_rd(box[1]), __double2float_ru(box[2]), __double2float_ru(box[3]));
+        sboxf[threadIdx.x] = iou::screen_box(box);
         if (STAGE == 1 && MODE == 1) {
             const int s = d.pool_slot[i];
             sslot[threadIdx.x] = s;
@@ -373,7 +373,7 @@ __device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, 
     }
     __syncthreads();
     const double area_b = iou::area(bb, true);
-    const float4 bf = make_float4(__double2float_rd(bb[0]), __double2float_rd(bb[1]), __double2float_ru(bb[2]), __double2float_ru(bb[3]));
+    const iou::ScreenBox bf = iou::screen_box(bb);
     double *cost = STAGE == 1 ? d.cost1 : STAGE == 2 ? d.cost2 : d.cost3;
     const double limit = STAGE == 1 ? d.match1 : STAGE == 2 ? d.match2 : d.match3;
     // rows cannot be screened by box overlap when every entry of the matrix is wanted, or in the dense stage-1 form:
@@ -462,8 +462,7 @@ __device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, 
 #pragma unroll
     for (int uu = 0; uu < 8; ++uu) {
         const int u = u0 + uu;
-        const float4 af = sboxf[(rc + u) & (ROWS - 1)];
-        const bool apart = fmaxf(fmaxf(bf.x - af.z, af.x - bf.z), fmaxf(bf.y - af.w, af.y - bf.w)) >= 0.0f;     // one comparison, no scalar OR chain
+        const bool apart = !iou::screen_overlap(sboxf[(rc + u) & (ROWS - 1)], bf);     // three packed 16-bit operations + one test
         unsigned long long want = __ballot(live && !apart);
         if (MODE == 1 && STAGE == 1) want |= scw[wid][(rc + u) & (ROWS - 1)] & livemask;
         work |= (want != 0ull ? 1u : 0u) << u;
@@ -1040,7 +1039,7 @@ __global__ __launch_bounds__(CT_COLS) void tk_tail(Dev d, int dedupe_blocks) {
     __shared__ double sarea[ROWS];
     __shared__ int sflag[ROWS];
     __shared__ int sage[ROWS];
-    __shared__ float4 sboxf[ROWS];            // row boxes rounded outward to float32 (screening, see edges_tile)
+    __shared__ iou::ScreenBox sboxf[ROWS];    // row boxes rounded outward to 16-bit pixels (screening, see edges_tile)
     const int n = d.hdr[H_NKEEP] + d.hdr[H_NB] + d.hdr[H_NRF], m = d.hdr[H_NL0] + d.hdr[H_NL1];
     const int nct = (m + CT_COLS - 1) / CT_COLS, ntile = nct * ((n + ROWS - 1) / ROWS);
     for (int t = blockIdx.x; t < ntile; t += dedupe_blocks) {
@@ -1065,11 +1064,11 @@ __global__ __launch_bounds__(CT_COLS) void tk_tail(Dev d, int dedupe_blocks) {
             sarea[threadIdx.x] = iou::area(box, f);
             sflag[threadIdx.x] = f;
             sage[threadIdx.x] = d.frame_id[s] - d.start_frame[s];
-            sboxf[threadIdx.x] = make_float4(__double2float_rd(box[0]), __double2float_rd(box[1]), __double2float_ru(box[2]), __double2float_ru(box[3]));
+            sboxf[threadIdx.x] = iou::screen_box(box);
         }
         __syncthreads();
         const double area_b = iou::area(bb, bf);
-        const float4 bq = make_float4(__double2float_rd(bb[0]), __double2float_rd(bb[1]), __double2float_ru(bb[2]), __double2float_ru(bb[3]));
+        const iou::ScreenBox bq = iou::screen_box(bb);
         const int rows = min(ROWS, n - i0);
         bool dropj = false;
 #pragma unroll 1
@@ -1077,8 +1076,7 @@ __global__ __launch_bounds__(CT_COLS) void tk_tail(Dev d, int dedupe_blocks) {
             uint32_t work = 0;                    // wave-uniform: rows of this chunk some lane overlaps
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const float4 af = sboxf[(rc + u) & (ROWS - 1)];
-                const bool apart = fmaxf(fmaxf(bq.x - af.z, af.x - bq.z), fmaxf(bq.y - af.w, af.y - bq.w)) >= 0.0f;
+                const bool apart = !iou::screen_overlap(sboxf[(rc + u) & (ROWS - 1)], bq);
                 work |= (__ballot(live && !apart) != 0ull ? 1u : 0u) << u;
             }
             work &= (1u << min(8, rows - rc)) - 1u;
