@@ -59,6 +59,9 @@ __device__ __forceinline__ ScreenBox screen_box(const double b[4]) {
     return s;
 }
 
+// a box that overlaps nothing (lo beyond every hi)
+__device__ __forceinline__ ScreenBox screen_none() { ScreenBox s; s.lo = s16x2{16001, 16001}; s.hi = s16x2{-16001, -16001}; return s; }
+
 __device__ __forceinline__ bool screen_overlap(const ScreenBox &a, const ScreenBox &b) {
     const s16x2 lo = __builtin_elementwise_max(a.lo, b.lo), hi = __builtin_elementwise_min(a.hi, b.hi);
     const s16x2 dd = hi - lo;                      // both halves >= 0 <=> lo < hi + 1 in x and in y

@@ -373,7 +373,7 @@ __device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, 
     }
     __syncthreads();
     const double area_b = iou::area(bb, true);
-    const iou::ScreenBox bf = iou::screen_box(bb);
+    const iou::ScreenBox bf = live ? iou::screen_box(bb) : iou::screen_none();      // (a dead column overlaps nothing)
     double *cost = STAGE == 1 ? d.cost1 : STAGE == 2 ? d.cost2 : d.cost3;
     const double limit = STAGE == 1 ? d.match1 : STAGE == 2 ? d.match2 : d.match3;
     // rows cannot be screened by box overlap when every entry of the matrix is wanted, or in the dense stage-1 form:
@@ -457,15 +457,17 @@ __device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, 
     // comparisons per row on outward-rounded boxes (disjoint there => disjoint exactly); only those
     // rows are then evaluated exactly in float64.
     uint32_t work = 0;                                    // wave-uniform: bit u = some lane needs row rc + u
+    if (MODE == 1 && STAGE == 1) {                        // rows with an appearance candidate in this wavefront's columns: one pass, lane u = row u
+        const unsigned long long cw = lane < 16 ? scw[wid][(rc + lane) & (ROWS - 1)] & livemask : 0ull;
+        work = (uint32_t)__ballot(cw != 0ull) & 0xffffu;
+    }
 #pragma unroll 1
     for (int u0 = 0; u0 < 16; u0 += 8)
 #pragma unroll
     for (int uu = 0; uu < 8; ++uu) {
         const int u = u0 + uu;
-        const bool apart = !iou::screen_overlap(sboxf[(rc + u) & (ROWS - 1)], bf);     // three packed 16-bit operations + one test
-        unsigned long long want = __ballot(live && !apart);
-        if (MODE == 1 && STAGE == 1) want |= scw[wid][(rc + u) & (ROWS - 1)] & livemask;
-        work |= (want != 0ull ? 1u : 0u) << u;
+        // three packed 16-bit operations + one test per pair; the verdict stays on the scalar side
+        work |= (__ballot(iou::screen_overlap(sboxf[(rc + u) & (ROWS - 1)], bf)) != 0ull ? 1u : 0u) << u;
     }
     if (all_rows) work = 0xffffu;
     work &= (1u << crows) - 1u;
@@ -1068,7 +1070,7 @@ __global__ __launch_bounds__(CT_COLS) void tk_tail(Dev d, int dedupe_blocks) {
         }
         __syncthreads();
         const double area_b = iou::area(bb, bf);
-        const iou::ScreenBox bq = iou::screen_box(bb);
+        const iou::ScreenBox bq = live ? iou::screen_box(bb) : iou::screen_none();
         const int rows = min(ROWS, n - i0);
         bool dropj = false;
 #pragma unroll 1
@@ -1076,8 +1078,7 @@ __global__ __launch_bounds__(CT_COLS) void tk_tail(Dev d, int dedupe_blocks) {
             uint32_t work = 0;                    // wave-uniform: rows of this chunk some lane overlaps
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const bool apart = !iou::screen_overlap(sboxf[(rc + u) & (ROWS - 1)], bq);
-                work |= (__ballot(live && !apart) != 0ull ? 1u : 0u) << u;
+                work |= (__ballot(iou::screen_overlap(sboxf[(rc + u) & (ROWS - 1)], bq)) != 0ull ? 1u : 0u) << u;
             }
             work &= (1u << min(8, rows - rc)) - 1u;
             while (work) {
