@@ -554,6 +554,13 @@ template <int STAGE, int MODE, int ROWS = CT_ROWS>
 __global__ __launch_bounds__(CT_COLS) void tk_edges(Dev d, bts_lap_work w, int accum) {
     edges_all<STAGE, MODE, ROWS>(d, w, blockIdx.x, gridDim.x, accum);
 }
+// the tall stage-1 tiles of big problems are throughput-bound on their screening loop (59 % of the wave cycles waiting
+// at 3 wavefronts per SIMD): capped at 128 registers they run 4 per SIMD (no spills at 32 / 64 rows; the short tiles
+// would spill, and any scratch costs a launch ~2 us)
+template <int ROWS>
+__global__ __launch_bounds__(CT_COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) void tk_edges_tall(Dev d, bts_lap_work w, int accum) {
+    edges_all<1, 1, ROWS>(d, w, blockIdx.x, gridDim.x, accum);
+}
 
 // ---- appearance pre-filter: fp8 MFMA GEMM + exact float32 refine ------------------------------------------------
 // Stage-1 appearance can change a cost only where  min(1 - body_sim, 1 - face_sim) <= appearance_thresh
@@ -1477,8 +1484,8 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
         case 4: LAUNCH((tk_edges<1, 1, 4>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
         case 8: LAUNCH((tk_edges<1, 1, 8>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
         case 16: LAUNCH((tk_edges<1, 1, 16>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
-        case 32: LAUNCH((tk_edges<1, 1, 32>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
-        default: LAUNCH((tk_edges<1, 1, 64>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
+        case 32: LAUNCH(tk_edges_tall<32>, dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
+        default: LAUNCH(tk_edges_tall<64>, dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
         }
         if (d.record) { LAUNCH((tk_edges<1, 2>), tile_grid, dim3(CT_COLS), lap[0], 0); }
     } else {
