@@ -463,3 +463,24 @@ def test_chunked_list_jobs_vs_oracle(bts, synth, monkeypatch, rows):
     monkeypatch.setenv("BTS_CHUNK_ROWS", str(rows))
     assert _against_oracle(bts, synth, 120, 60, 128, frames=40, churn=0.15, frame_rate=2, seed=77) > 500
     assert _against_oracle(bts, synth, 300, 200, 256, frames=16, churn=0.05, seed=78) > 1000
+
+
+@pytest.mark.gpu
+def test_profile_stride(bts, synth):
+    """bts_tracker_profile_stride: event pairs only on every n-th step (bench.py's roofline timing)."""
+    K, M, D = 64, 32, 128
+    st = synth.SyntheticStream(K, M, D, seed=5)
+    trk = bts.DeviceTracker(max_tracks=K + 64, max_dets=K, feat_dim=D)
+    for _ in range(3):
+        trk.step(*_dev_frame(st.next())[:3])
+    trk.profile_enable("k_lap", 64, 4)
+    for _ in range(16):
+        trk.step(*_dev_frame(st.next())[:3])
+    ms, n = trk.profile_read()
+    assert n == 4 and ms > 0.0
+    trk.profile_enable("step", 64)
+    for _ in range(5):
+        trk.step(*_dev_frame(st.next())[:3])
+    ms, n = trk.profile_read()
+    assert n == 5 and ms > 0.0
+    trk.close()
