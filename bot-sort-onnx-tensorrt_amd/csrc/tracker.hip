@@ -581,20 +581,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // epilogue of the pre-filter tiles: candidate test (or split-K accumulation) of a 128 x 128 accumulator tile;
 // the tile's row/column norms go through LDS (`snorm`: 256 floats, the operand tiles are dead by now)
 template <bool FACE>
-__device__ __forceinline__ void filter_epilogue(const Dev &d, f32x16 (&acc)[2][2], float *snorm, int bm, int bn, int n, int m, int accum) {
+__device__ __forceinline__ void filter_epilogue(const Dev &d, f32x16 (&acc)[2][2], float *snorm, float my_norm, int bm, int bn, int n, int m, int accum) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid >> 1, wc = wid & 1;
     const int frow = lane & 31, fh = lane >> 5;
-    const float *na = FACE ? d.face_n : d.body_n, *nb = FACE ? d.dface_n : d.det_n;
     const float eps = FACE ? d.eps_face : d.eps_body, gate = 1.0f - d.app;
     float *approx = FACE ? d.approx_f : d.approx;
     __syncthreads();
-    if (!accum) {
-        const int g = tid < FBM ? bm * FBM + tid : bn * FBN + (tid - FBM);
-        float v = 0.0f;
-        if (tid < FBM) { if (g < n) v = na[d.pool_slot[g]]; }
-        else if (g < m) v = nb[d.hi_idx[g]];
-        snorm[tid] = v;
-    }
+    if (!accum) snorm[tid] = my_norm;            // (fetched in the prologue: two dependent loads that ride under the K loop)
     __syncthreads();
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
@@ -689,6 +682,14 @@ __global__ __launch_bounds__(256) void k_filter_dma(Dev d, int m_max, int ntiles
         asrc[s] = A + (long)d.pool_slot[i < n ? i : bm * FBM] * Dd + sw;       // rows past the end: any valid row, ignored later
         bsrc[s] = B + (long)d.hi_idx[j < m ? j : bn * FBN] * Dd + sw;
     }
+    // this thread's row (threads 0-127) or column (128-255) norm for the epilogue's candidate test
+    float my_norm = 0.0f;
+    if (!accum) {
+        const float *na = FACE ? d.face_n : d.body_n, *nb = FACE ? d.dface_n : d.det_n;
+        const int g = tid < FBM ? bm * FBM + tid : bn * FBN + (tid - FBM);
+        if (tid < FBM) { if (g < n) my_norm = na[d.pool_slot[g]]; }
+        else if (g < m) my_norm = nb[d.hi_idx[g]];
+    }
     auto stage = [&](int buf, int kt) {                  // 8 wavefront loads per stage and wave
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -746,7 +747,7 @@ __global__ __launch_bounds__(256) void k_filter_dma(Dev d, int m_max, int ntiles
         }
         cur ^= 1;
     }
-    filter_epilogue<FACE>(d, acc, reinterpret_cast<float *>(&As2[0][0]), bm, bn, n, m, accum);
+    filter_epilogue<FACE>(d, acc, reinterpret_cast<float *>(&As2[0][0]), my_norm, bm, bn, n, m, accum);
 }
 
 // ---- detection feature rows: in-place renormalisation (quirk Q8) ------------------------------------------
