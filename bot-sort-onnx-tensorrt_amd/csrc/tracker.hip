@@ -750,6 +750,162 @@ __global__ __launch_bounds__(256) void k_filter_dma(Dev d, int m_max, int ntiles
     filter_epilogue<FACE>(d, acc, reinterpret_cast<float *>(&As2[0][0]), my_norm, bm, bn, n, m, accum);
 }
 
+// Persistent form for problems with more tiles than resident workgroups (no split-K): FILTER_PW workgroups walk the
+// tiles, and the chain of dependent loads that opens a tile (index lists -> row pointers -> first stage) is taken off
+// the tile's critical path: the NEXT tile's indices are fetched while the current K loop runs, and its first stage is
+// issued before the current tile's epilogue (both operand buffers are idle then; the norms sit in their own LDS words).
+constexpr int FILTER_PW = 512;       // 2 resident workgroups per CU (64 KiB of operand stages each)
+template <bool FACE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_filter_dma_p(Dev d, int m_max, int ntiles) {
+    __shared__ __attribute__((aligned(1024))) uint8_t As2[DNS][FBM * DBK];
+    __shared__ __attribute__((aligned(1024))) uint8_t Bs2[DNS][FBN * DBK];
+    __shared__ float snorm[FBM + FBN];
+    if ((int)blockIdx.x >= FILTER_PW) {
+        if (!FACE) predict_body(d, (int)blockIdx.x - FILTER_PW);
+        return;
+    }
+    const int n = d.hdr[H_NPOOL], m = d.hdr[H_NHI];
+    const int Dd = FACE ? d.Df : d.D;
+    const uint8_t *A = FACE ? d.face_h : d.body_h, *B = FACE ? d.dface_h : d.det_h;
+    const float *na = FACE ? d.face_n : d.body_n, *nb = FACE ? d.dface_n : d.det_n;
+    const int nbn = (m_max + FBN - 1) / FBN;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid >> 1, wc = wid & 1;
+    const int kt_all = Dd / DBK;
+    const int prow = lane >> 3, pchunk = lane & 7;
+    const int frow = lane & 31, fh = lane >> 5;
+    const unsigned lds_a = (unsigned)(__UINTPTR_TYPE__)(lds_void *)&As2[0][0], lds_b = (unsigned)(__UINTPTR_TYPE__)(lds_void *)&Bs2[0][0];
+    int aoff[2], boff[2], asw[2], bsw[2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+        const int ra = wr * 64 + x * 32 + frow, rb = wc * 64 + x * 32 + frow;
+        aoff[x] = ra * DBK; asw[x] = (ra >> 1) & 7;
+        boff[x] = rb * DBK; bsw[x] = (rb >> 1) & 7;
+    }
+    // live tiles of this workgroup, in order: vt = blockIdx.x, + FILTER_PW, ... (tiles past the live extents are skipped)
+    auto next_live = [&](int vt, int &bm, int &bn) {
+        for (; vt < ntiles; vt += FILTER_PW) {
+            const int vb = xcd_remap(vt, ntiles);
+            bm = vb / nbn; bn = vb % nbn;
+            if (bm * FBM < n && bn * FBN < m) return vt;
+        }
+        return ntiles;
+    };
+    // index fetch of a tile: the table slots / detection indices of this lane's four A rows and four B rows, and of the
+    // row (threads 0-127) or column (128-255) whose norm this thread carries into the epilogue
+    auto fetch_idx = [&](int bm, int bn, int (&ia)[4], int (&ib)[4], int &inorm) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int r = (4 * s + wid) * 8 + prow;
+            const int i = bm * FBM + r, j = bn * FBN + r;
+            ia[s] = d.pool_slot[i < n ? i : bm * FBM];       // rows past the end: any valid row, ignored later
+            ib[s] = d.hi_idx[j < m ? j : bn * FBN];
+        }
+        const int g = tid < FBM ? bm * FBM + tid : bn * FBN + (tid - FBM);
+        inorm = tid < FBM ? (g < n ? d.pool_slot[g] : -1) : (g < m ? d.hi_idx[g] : -1);
+    };
+    const uint8_t *asrc[4], *bsrc[4];
+    auto set_src = [&](const int (&ia)[4], const int (&ib)[4]) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int r = (4 * s + wid) * 8 + prow;
+            const int sw = (pchunk ^ ((r >> 1) & 7)) * 16;
+            asrc[s] = A + (long)ia[s] * Dd + sw;
+            bsrc[s] = B + (long)ib[s] * Dd + sw;
+        }
+    };
+    auto stage = [&](int buf, int kt) {                  // 8 wavefront loads per stage and wave
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            __builtin_amdgcn_global_load_lds((gbl_void *)(asrc[s] + kt * DBK), (lds_void *)&As2[buf][(4 * s + wid) * 8 * DBK], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void *)(bsrc[s] + kt * DBK), (lds_void *)&Bs2[buf][(4 * s + wid) * 8 * DBK], 16, 0, 0);
+        }
+    };
+    int bm, bn;
+    int vt = next_live((int)blockIdx.x, bm, bn);
+    if (vt >= ntiles) return;
+    int ia[4], ib[4], inorm;
+    fetch_idx(bm, bn, ia, ib, inorm);
+    set_src(ia, ib);
+    float my_norm = inorm < 0 ? 0.0f : (tid < FBM ? na[inorm] : nb[inorm]);
+    stage(0, 0);
+    int cur = 0;
+    for (;;) {
+        // the next tile's indices travel while this tile's K loop runs
+        int nbm = 0, nbnn = 0;
+        const int nvt = next_live(vt + FILTER_PW, nbm, nbnn);
+        if (nvt < ntiles) fetch_idx(nbm, nbnn, ia, ib, inorm);
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+        for (int kt = 0; kt < kt_all; ++kt) {
+            wait_stage_barrier<0>();             // stage kt has landed (the only one in flight); every wave is past its reads of the other buffer
+            if (kt + 1 < kt_all) stage(cur ^ 1, kt + 1);
+            const unsigned abase = lds_a + cur * (FBM * DBK), bbase = lds_b + cur * (FBN * DBK);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {        // the stage's two K = 64 blocks; a lane holds 32 contiguous K values of each
+                v4i fa[2][2], fb[2][2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int u = h * 4 + fh * 2 + t;
+#pragma unroll
+                    for (int x = 0; x < 2; ++x) {
+                        fa[t][x] = lds_read16(abase + aoff[x] + ((u ^ asw[x]) << 4));
+                        fb[t][x] = lds_read16(bbase + boff[x] + ((u ^ bsw[x]) << 4));
+                    }
+                }
+                lds_wait<0>(fa[0][0], fa[0][1], fb[0][0], fb[0][1]);
+                lds_wait<0>(fa[1][0], fa[1][1], fb[1][0], fb[1][1]);
+                v8i av[2], bv[2];
+#pragma unroll
+                for (int x = 0; x < 2; ++x) {
+                    av[x] = v8i{fa[0][x].x, fa[0][x].y, fa[0][x].z, fa[0][x].w, fa[1][x].x, fa[1][x].y, fa[1][x].z, fa[1][x].w};
+                    bv[x] = v8i{fb[0][x].x, fb[0][x].y, fb[0][x].z, fb[0][x].w, fb[1][x].x, fb[1][x].y, fb[1][x].z, fb[1][x].w};
+                }
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)       // K = 64 per instruction, formats fp8 x fp8, block scales 2^0
+                        acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av[mi], bv[ni], acc[mi][ni], 0, 0, 0, 127, 0, 127);
+            }
+            cur ^= 1;
+        }
+        // epilogue of this tile; its first barrier also says every wave is done reading the operand buffers, so the next
+        // tile's first stage goes out right behind it and lands while the candidate tests run
+        const float norm_now = my_norm;
+        __syncthreads();
+        snorm[tid] = norm_now;
+        if (nvt < ntiles) {
+            set_src(ia, ib);
+            my_norm = inorm < 0 ? 0.0f : (tid < FBM ? na[inorm] : nb[inorm]);
+            stage(cur, 0);
+        }
+        __syncthreads();
+        {
+            const float eps = FACE ? d.eps_face : d.eps_body, gate = 1.0f - d.app;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const int qq = wc * 64 + ni * 32 + frow, q = bn * FBN + qq;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ii = wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh, i = bm * FBM + ii;
+                        const float val = acc[mi][ni][r] * feat::Q8_UNSCALE;
+                        if (!(i < n && q < m)) continue;
+                        if (is_candidate(val, snorm[ii], snorm[FBM + qq], gate, eps))      // rare: about one per detection column
+                            atomicOr(&d.cbits[(long)i * d.cb_ld + (q >> 5)], 1u << (q & 31));
+                    }
+                }
+        }
+        if (nvt >= ntiles) break;
+        vt = nvt; bm = nbm; bn = nbnn;
+    }
+}
+
 // ---- detection feature rows: in-place renormalisation (quirk Q8) ------------------------------------------
 __device__ __forceinline__ void renorm_body(const Dev &d, int blk) {        // four rows per 1024-thread workgroup
     const int32_t *h = d.hdr;
@@ -1455,11 +1611,14 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
     if (d.filter) {
         // Kalman predict rides in the pre-filter's launch (independent work, consecutive workgroups)
         seg_begin(BTS_SEG_K_FILTER);
-        LAUNCH(k_filter_dma<false>, dim3(ftiles * split + kf_blocks), dim3(256), mc, ftiles, split, accum);
+        const bool persistent = split == 1 && ftiles > FILTER_PW;      // more tiles than resident workgroups: walk them (k_filter_dma_p)
+        if (persistent) { LAUNCH(k_filter_dma_p<false>, dim3(FILTER_PW + kf_blocks), dim3(256), mc, ftiles); }
+        else { LAUNCH(k_filter_dma<false>, dim3(ftiles * split + kf_blocks), dim3(256), mc, ftiles, split, accum); }
         seg_end(BTS_SEG_K_FILTER);
         if (d.Df) {
             const int fsplit = split < bts_cdiv(d.Df, DBK) ? split : bts_cdiv(d.Df, DBK);
-            LAUNCH(k_filter_dma<true>, dim3(ftiles * fsplit), dim3(256), mc, ftiles, fsplit, accum);
+            if (persistent) { LAUNCH(k_filter_dma_p<true>, dim3(FILTER_PW), dim3(256), mc, ftiles); }
+            else { LAUNCH(k_filter_dma<true>, dim3(ftiles * fsplit), dim3(256), mc, ftiles, fsplit, accum); }
         }
     } else {
         seg_begin(BTS_SEG_PREDICT);

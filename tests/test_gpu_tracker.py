@@ -484,3 +484,50 @@ def test_profile_stride(bts, synth):
     ms, n = trk.profile_read()
     assert n == 5 and ms > 0.0
     trk.close()
+
+
+@pytest.mark.gpu
+def test_persistent_prefilter_gate_band_vs_dense(bts):
+    """More pre-filter tiles than resident workgroups (33 x 16 = 528 > 512, two K stages): the persistent form of the
+    fp8 contraction (k_filter_dma_p, tiles pipelined across each other) must hand the solver exactly the pairs the
+    dense float32 path finds -- appearance-only re-association (boxes teleport) with cosines within +-0.01 of the gate."""
+    import torch
+    rng = np.random.default_rng(77)
+    K, D = 2048, 256
+    proto = rng.standard_normal((K, D))
+    proto /= np.linalg.norm(proto, axis=1, keepdims=True)
+    a = bts.DeviceTracker(max_tracks=4224, max_dets=K, feat_dim=D)
+    b = bts.DeviceTracker(max_tracks=4224, max_dets=K, feat_dim=D, appearance_mode=1)
+    matched1 = 0
+    for f in range(4):
+        cx = rng.permutation(K) * 7 + 10
+        cy = rng.integers(100, 8000, K)
+        boxes = np.stack([cx, cy, cx + 5, cy + 9], 1).astype(np.int32)
+        # (after the first frame: high-score detections that may match but are never born, so the table does not overflow)
+        scores = (rng.uniform(0.91, 0.99, K) if f == 0 else rng.uniform(0.5, 0.85, K)).astype(np.float32)
+        c = 0.75 + rng.uniform(3e-5, 0.01, K) * rng.choice([-1.0, 1.0], K)
+        if f == 0:
+            c[:] = 1.0
+        noise = rng.standard_normal((K, D))
+        noise -= (noise * proto).sum(1, keepdims=True) * proto
+        noise /= np.linalg.norm(noise, axis=1, keepdims=True)
+        feats = (c[:, None] * proto + np.sqrt(1 - c[:, None] ** 2) * noise).astype(np.float32)
+        proto = feats.astype(np.float64) / np.linalg.norm(feats.astype(np.float64), axis=1, keepdims=True)
+        perm = rng.permutation(K)
+        boxes, scores, feats = boxes[perm], scores[perm], np.ascontiguousarray(feats[perm])
+        proto = proto[perm]
+        fr = (torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda())
+        a.step(*fr, torch.from_numpy(feats.copy()).cuda())
+        b.step(*fr, torch.from_numpy(feats.copy()).cuda())
+        for k in (1, 2, 3):
+            ra, rb = a.stage_result(k), b.stage_result(k)
+            assert np.array_equal(ra["x"], rb["x"]) and np.array_equal(ra["y"], rb["y"]), (f, k)
+        if f == 1:
+            matched1 = len(a.stage_result(1)["m"])
+        for which in (0, 1):
+            ta, tb = a.export(which), b.export(which)
+            for key in INT_KEYS:
+                assert np.array_equal(ta[key], tb[key]), (f, which, key)
+        assert a.counts() == b.counts() and a.counts()["errors"] == 0
+    assert matched1 > K // 4          # about half of the cosines sit inside the gate
+    a.close(); b.close()
