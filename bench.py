@@ -124,11 +124,12 @@ def pmc_traffic(workload, kernel_name):
         tab = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))["workloads"][workload]
     except Exception:
         return None
-    base = kernel_name.split("<")[0]
+    bases = [alt.strip().split("<")[0] for alt in kernel_name.split("|")]      # (a kernel may have several forms)
+    best = None
     for k, v in tab.items():
-        if k.split("<")[0] == base:
-            return v.get("traffic_bytes")
-    return None
+        if k.split("<")[0] in bases and v.get("traffic_bytes") is not None:
+            best = max(best or 0.0, v["traffic_bytes"])       # the form that ran (the others are absent or tiny)
+    return best
 
 
 def ms_seed(pkg, rank):
