@@ -1580,9 +1580,10 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
     const dim3 tile_grid(ntile);               // persistent tiles: the kernels walk the live extents
     // stage-1 tiles are R x 256 with R chosen for ~TILE_GOAL workgroups: a tile's cost is its chains of dependent loads
     // plus a serial part per row, so small problems want many small tiles and big ones few tall tiles
-    constexpr int TILE_GOAL = 768;            // (swept on c2 / c3 / target: 256 ... 6144)
+    constexpr int TILE_GOAL = 768;            // (swept on c2 / c3 / target: 256 ... 6144; heights up to 256 rows: 10000 x 2000 runs
+                                              //  128-row tiles (632 of them: one resident round), 16384 x 4096 256-row tiles)
     int trows = 2;
-    while (trows < 64 && bts_cdiv(mc, CT_COLS) * bts_cdiv(T, trows) > TILE_GOAL) trows *= 2;
+    while (trows < 256 && bts_cdiv(mc, CT_COLS) * bts_cdiv(T, trows) > TILE_GOAL) trows *= 2;
     const int ntile1 = bts_cdiv(mc, CT_COLS) * bts_cdiv(T, trows);
     const int kf_blocks = bts_cdiv(T * 8 > M ? T * 8 : M, 256);   // 8 lanes per track
     bts_lap_work lap[3] = {t->lap, t->lap, t->lap3};
@@ -1645,7 +1646,9 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
         case 8: LAUNCH((tk_edges<1, 1, 8>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
         case 16: LAUNCH((tk_edges<1, 1, 16>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
         case 32: LAUNCH(tk_edges_tall<32>, dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
-        default: LAUNCH(tk_edges_tall<64>, dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
+        case 64: LAUNCH(tk_edges_tall<64>, dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
+        case 128: LAUNCH(tk_edges_tall<128>, dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
+        default: LAUNCH(tk_edges_tall<256>, dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
         }
         if (d.record) { LAUNCH((tk_edges<1, 2>), tile_grid, dim3(CT_COLS), lap[0], 0); }
     } else {

@@ -347,12 +347,13 @@ def test_botsort_update_image_with_parts(bts):
         assert b.x1 <= b.head.x1 and b.head.x2 <= b.x2 and b.hand1 is not b.hand2
 
 
-def test_full_size_filter_vs_dense_modes(bts, synth):
-    """BASELINE-size crowd (the CPU oracle would need minutes per frame): the default path -- float16 pre-filter,
-    64-row cost tiles and 64-row duplicate tiles, only taken at this size -- must produce the SAME assignments,
-    track ids and lists as the dense float32 path, which forms the full similarity and cost matrices like the
-    reference does (and is itself pinned to the oracle at the smaller sizes above)."""
-    K, M, D = 8192, 1024, 128
+@pytest.mark.parametrize("M", [1024, 2048, 4096])
+def test_full_size_filter_vs_dense_modes(bts, synth, M):
+    """BASELINE-size crowd (the CPU oracle would need minutes per frame): the default path -- fp8 pre-filter (persistent
+    tiles), 64- / 128- / 256-row cost tiles (M = 1024 / 2048 / 4096) and 64-row duplicate tiles, only taken at these
+    sizes -- must produce the SAME assignments, track ids and lists as the dense float32 path, which forms the full
+    similarity and cost matrices like the reference does (and is itself pinned to the oracle at the smaller sizes above)."""
+    K, D = 8192, 128
     st = synth.SyntheticStream(K, M, D, seed=21, churn=0.02)
     a = bts.DeviceTracker(max_tracks=K + 512, max_dets=K, feat_dim=D)
     b = bts.DeviceTracker(max_tracks=K + 512, max_dets=K, feat_dim=D, appearance_mode=1)
@@ -371,7 +372,7 @@ def test_full_size_filter_vs_dense_modes(bts, synth):
                 assert np.abs(ta["mean"] - tb["mean"]).max() <= 1e-9
         ca, cb = a.counts(), b.counts()
         assert ca == cb and ca["errors"] == 0
-    assert a.counts()["n_tracked"] > 500 and a.counts()["n_lost"] > 5000      # the duplicate tiles had real work
+    assert a.counts()["n_tracked"] > 500 and a.counts()["n_lost"] > 4000      # the duplicate tiles had real work
     a.close(); b.close()
 
 
