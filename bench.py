@@ -132,6 +132,24 @@ def pmc_traffic(workload, kernel_name):
     return best
 
 
+def several_streams(a, counts):
+    """Aggregate steps/s of n concurrent streams on this GPU, n in `counts`: `bench.py --streams-per-gpu n`, each in a
+    fresh process (the runtime binds HIP streams to its hardware queues at first use; a process that has already used
+    other streams gets less regular bindings)."""
+    import subprocess
+    out = []
+    for n in counts:
+        cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--workload", a.workload, "--steps", str(min(a.steps, 200)),
+               "--warmup", str(a.warmup), "--no-cpu", "--streams-per-gpu", str(n)] + (["--dense"] if a.dense else [])
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            out.append({"streams": n, "value": d["value"], "unit": d["unit"], "steps_per_stream": d["steps"]})
+        except Exception as e:          # a reported extra, never fatal for the headline line
+            out.append({"streams": n, "value": None, "error": str(e)[:200]})
+    return out
+
+
 def ms_seed(pkg, rank):
     return pkg.multistream.stream_seed(1234, rank)      # one independent video stream per GPU
 
@@ -258,6 +276,10 @@ def main():
             # the dense kernels of the path, standalone, against their rooflines (a few seconds; the step above is
             # launch-bound at this size, these show what the kernels do when they have work)
             out["standalone_rooflines"] = importlib.import_module("bot-sort-onnx-tensorrt_amd.microbench").run(full=False)
+            if world == 1 and S == 1 and not a.graph:
+                # what ONE GPU serves when it is given several independent streams of this workload (own handle, HIP stream
+                # and host thread each: multistream.run_concurrent); not the headline configuration (1 stream per GPU)
+                out["several_streams_one_gpu"] = several_streams(a, (4, 8))
             out["cpu_baseline"] = cpu_baseline(pkg, K, M, D, 1234, a.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:
