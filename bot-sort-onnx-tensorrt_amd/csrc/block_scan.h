@@ -138,6 +138,59 @@ __device__ __forceinline__ int compact_ws(int L, int *smem, Load load, Pred pred
     return compact(L, smem, [&](int k) { return pred(k, load(k)); }, [&](int p, int k) { emit(p, k, load(k)); });
 }
 
+// Two ordered compactions of the same index range in ONE pass (one fetch of the payload, one round of barriers):
+// items with predA go to emitA, items with predB to emitB (an item may be in both or neither).  Returns both totals.
+template <int R, class Load, class PredA, class PredB, class EmitA, class EmitB>
+__device__ __forceinline__ int2 compact2_ws_r(int L, int chunk, int *smem, Load load, PredA predA, PredB predB, EmitA emitA, EmitB emitB) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int base = wid * chunk;
+    int val[R];
+    unsigned long long ba[R], bb[R];
+    int ca = 0, cb = 0;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const int k = base + j * 64 + lane;
+        val[j] = load((j * 64 < chunk && k < L) ? k : 0);
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const int k = base + j * 64 + lane;
+        const bool inb = j * 64 < chunk && k < L;
+        ba[j] = __ballot(inb && predA(inb ? k : 0, val[j]));
+        bb[j] = __ballot(inb && predB(inb ? k : 0, val[j]));
+        ca += __popcll(ba[j]); cb += __popcll(bb[j]);
+    }
+    lds_barrier();                         // smem may still be read from a previous call
+    if (lane == 0) { smem[wid] = ca; smem[16 + wid] = cb; }
+    lds_barrier();
+    int pa = 0, pb = 0, ta = 0, tb = 0;
+    for (int w = 0; w < nw; ++w) { const int x = smem[w], y = smem[16 + w]; if (w < wid) { pa += x; pb += y; } ta += x; tb += y; }
+    const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const int k = base + j * 64 + lane;
+        if ((ba[j] >> lane) & 1ull) emitA(pa + __popcll(ba[j] & below), k, val[j]);
+        if ((bb[j] >> lane) & 1ull) emitB(pb + __popcll(bb[j] & below), k, val[j]);
+        pa += __popcll(ba[j]); pb += __popcll(bb[j]);
+    }
+    lds_barrier();
+    return make_int2(ta, tb);
+}
+
+template <class Load, class PredA, class PredB, class EmitA, class EmitB>
+__device__ __forceinline__ int2 compact2_ws(int L, int *smem, Load load, PredA predA, PredB predB, EmitA emitA, EmitB emitB) {
+    const int nw = blockDim.x >> 6;
+    const int chunk = ((L + nw - 1) / nw + 63) & ~63, rounds = chunk >> 6;
+    if (L <= 0) return make_int2(0, 0);
+    if (rounds <= 1) return compact2_ws_r<1>(L, chunk, smem, load, predA, predB, emitA, emitB);
+    if (rounds <= 4) return compact2_ws_r<4>(L, chunk, smem, load, predA, predB, emitA, emitB);
+    if (rounds <= 16) return compact2_ws_r<16>(L, chunk, smem, load, predA, predB, emitA, emitB);
+    // very long inputs: two plain passes
+    const int a = compact(L, smem, [&](int k) { return predA(k, load(k)); }, [&](int p, int k) { emitA(p, k, load(k)); });
+    const int b = compact(L, smem, [&](int k) { return predB(k, load(k)); }, [&](int p, int k) { emitB(p, k, load(k)); });
+    return make_int2(a, b);
+}
+
 // ---- one ordered compaction shared by the nch consecutive workgroups of a launch ("chunks") -----------------------
 // Chunk ch handles the indices [ch * CL, (ch + 1) * CL) and offsets its output by the counts of the chunks before it,
 // which each chunk publishes in agg[] (decoupled look-back: a chunk only ever waits for chunks with a LOWER workgroup

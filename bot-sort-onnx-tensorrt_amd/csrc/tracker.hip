@@ -212,11 +212,12 @@ __device__ __forceinline__ void prep_dets(const Dev &d) {
         d.det_xywh[j * 4 + 0] = tx + w / 2; d.det_xywh[j * 4 + 1] = ty + hh / 2;                     // D:663-670
         d.det_xywh[j * 4 + 2] = w; d.det_xywh[j * 4 + 3] = hh;
     }
-    const int nhi = block_compact(m, tmp, [&](int j) { return __float_as_int(scores[j]); }, [&](int j, int v) { return (double)__int_as_float(v) > d.high; },
-                                  [&](int p, int j, int) { d.hi_idx[p] = j; });
-    const int nlo = block_compact(m, tmp, [&](int j) { return __float_as_int(scores[j]); },
-                                  [&](int j, int v) { const double s = (double)__int_as_float(v); return s <= d.high && s >= d.low; },
-                                  [&](int p, int j, int) { d.lo_idx[p] = j; });
+    // high- and low-score lists in one pass over the scores
+    const int2 nn = bscan::compact2_ws(m, tmp, [&](int j) { return __float_as_int(scores[j]); },
+                                       [&](int j, int v) { return (double)__int_as_float(v) > d.high; },
+                                       [&](int j, int v) { const double s = (double)__int_as_float(v); return (s <= d.high) & (s >= d.low); },
+                                       [&](int p, int j, int) { d.hi_idx[p] = j; }, [&](int p, int j, int) { d.lo_idx[p] = j; });
+    const int nhi = nn.x, nlo = nn.y;
     if (tid < 3 * BTS_LAP_HDR_INTS) d.lap_hdr[tid] = 0;
     if (tid == 0) {
         h[H_NHI] = nhi; h[H_NLO] = nlo; h[H_NDETS] = m;
