@@ -990,14 +990,24 @@ __device__ __forceinline__ void apply_body(const Dev &d, int bid) {
 // feature bookkeeping and the cost tiles of stages 2 and 3 touch disjoint tracks, so they share a
 // launch as consecutive workgroup ranges (all 256 threads wide).
 template <int MODE3>
-__global__ __launch_bounds__(256) void tk_mid2(Dev d, bts_lap_work w2, bts_lap_work w3, int kf_blocks, int feat_blocks, int tile_blocks) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void tk_mid2(Dev d, bts_lap_work w2, bts_lap_work w3, int kf_blocks, int feat_blocks, int tile_blocks) {
     int b = blockIdx.x;
-    if (b < kf_blocks) { apply_body<1, false>(d, b); return; }
-    b -= kf_blocks;
-    if (b < feat_blocks) { apply_body<1, true>(d, b); return; }
-    b -= feat_blocks;
-    if (b < tile_blocks) { edges_all<2, 0>(d, w2, b, tile_blocks); return; }
-    edges_all<3, MODE3>(d, w3, b - tile_blocks, tile_blocks);
+#ifdef BTS_LAP_TRACE
+    // role timeline (kernel 4 of g_jobtrace): [0] first workgroup's start, [1..4] latest end of the Kalman / feature /
+    // stage-2 tile / stage-3 tile workgroups (low 32 bits of the 100 MHz clock)
+    if (b == 0 && threadIdx.x == 0) g_jobtrace[32] = (int)__builtin_amdgcn_s_memrealtime();
+    const int role = b < tile_blocks ? 3 : b < 2 * tile_blocks ? 4 : b < 2 * tile_blocks + kf_blocks ? 1 : 2;
+#endif
+    // the (few, latency-bound) tile workgroups first: dispatched behind the bulk of the Kalman / feature workgroups they
+    // started late and ended the kernel
+    if (b < tile_blocks) edges_all<2, 0>(d, w2, b, tile_blocks);
+    else if ((b -= tile_blocks) < tile_blocks) edges_all<3, MODE3>(d, w3, b, tile_blocks);
+    else if ((b -= tile_blocks) < kf_blocks) apply_body<1, false>(d, b);
+    else apply_body<1, true>(d, b - kf_blocks);
+#ifdef BTS_LAP_TRACE
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(&g_jobtrace[32 + role], (int)__builtin_amdgcn_s_memrealtime());
+#endif
 }
 
 // stages 2 and 3 applied together (disjoint tracks and detections): Kalman ranges, then feature rows
