@@ -13,6 +13,9 @@ extra objects:
   cpu_baseline  the CPU oracle (structure-faithful port of the reference: per-pair Python IoU,
                 scalar Kalman updates, dense extended-matrix JV) on the same stream, 1 core,
                 bounded to ~15 s.
+  id_match      the metric's "assignment ID match vs ref": a second tracker handle stepped on the
+                frames of the cpu_baseline sample, compared with the oracle frame by frame
+                (assignment pairs of the three stages, ordered track ids / states, Kalman means).
 For N > 1 launch with torch.distributed.run; ranks only meet at barriers (gloo control plane).
 """
 from __future__ import annotations
@@ -79,7 +82,55 @@ def kernel_model(kern, K, M, D, dense):
     return "hbm", float(table[kern]), "byte", HBM_PEAK_GBS
 
 
-def cpu_baseline(pkg, K, M, D, seed, budget_s):
+class IdMatch:
+    """Checker beside the CPU-baseline leg (the metric's "assignment ID match vs ref"): a second tracker handle is
+    stepped on the very frames the oracle is timed on (outside the oracle's timed bracket) and, per frame, the three
+    stages' assignment indices, the ordered track ids / states of the tracked and lost lists and the Kalman means are
+    compared with the oracle's."""
+    INT_KEYS = ("track_id", "state", "is_activated", "frame_id", "start_frame", "tracklet_len")
+
+    def __init__(self, pkg, K, M, D):
+        import torch
+        self.torch = torch
+        self.trk = pkg.DeviceTracker(max_tracks=K + 64, max_dets=max(K, M), feat_dim=D, device=torch.cuda.current_device())
+        self.frames = self.pairs = self.pairs_equal = self.ids = self.ids_equal = 0
+        self.frames_identical = 0
+        self.kalman_err = 0.0
+
+    def frame(self, fr, feats, ora, table):
+        t = self.torch
+        self.trk.step(t.from_numpy(fr.boxes).cuda(), t.from_numpy(fr.scores).cuda(), t.from_numpy(feats).cuda())
+        same = True
+        for k in (1, 2, 3):
+            got, want = self.trk.stage_result(k)["m"], np.asarray(ora.trace["m%d" % k]).reshape(-1, 2)
+            got = np.asarray(got).reshape(-1, 2)
+            eq = int((got == want).all(axis=1).sum()) if got.shape == want.shape else len(set(map(tuple, got)) & set(map(tuple, want)))
+            self.pairs += len(want)
+            self.pairs_equal += eq
+            same &= got.shape == want.shape and eq == len(want)
+        for which, lst in ((0, ora.tracked), (1, ora.lost)):
+            g, w = self.trk.export(which), table(lst)
+            ok = all(np.array_equal(g[key], w[key]) for key in self.INT_KEYS)
+            self.ids += len(w["track_id"])
+            self.ids_equal += len(w["track_id"]) if ok else int(np.sum(g["track_id"][:len(w["track_id"])] == w["track_id"][:len(g["track_id"])]))
+            same &= ok
+            if ok and len(w["track_id"]):
+                self.kalman_err = max(self.kalman_err, float(np.abs(g["mean"] - w["mean"]).max()))
+        self.frames += 1
+        self.frames_identical += int(same)
+
+    def result(self):
+        errors = self.trk.counts()["errors"]
+        self.trk.close()
+        return {"frames": self.frames, "frames_identical": self.frames_identical,
+                "assignment_pairs": self.pairs, "assignment_pairs_equal": self.pairs_equal,
+                "track_ids": self.ids, "track_ids_equal": self.ids_equal,
+                "kalman_mean_max_abs_err": self.kalman_err, "kalman_tolerance": 1e-4, "device_errors": errors,
+                "against": "CPU oracle (pinned to the reference's golden vectors), every frame of the cpu_baseline sample incl. "
+                           "the two pool-building frames; tracked + lost lists in order, stages 1-3 (row, column) pairs"}
+
+
+def cpu_baseline(pkg, K, M, D, seed, budget_s, checker=None):
     """The oracle timed on this box's host cores: 1 process, 1 core (the reference is
     single-threaded Python).  Only this leg may touch oracle/."""
     from oracle import bts_oracle as bo
@@ -94,9 +145,12 @@ def cpu_baseline(pkg, K, M, D, seed, budget_s):
     f = 0
     while True:
         fr = st.next()
+        feats0 = fr.feats.copy() if checker is not None else None     # (the oracle, like the reference, renormalises rows of its input in place: Q8)
         t0 = time.perf_counter()
         ora.update_arrays(fr.boxes, fr.scores.astype(np.float64), fr.feats, None)
         dt = time.perf_counter() - t0
+        if checker is not None:
+            checker.frame(fr, feats0, ora, bo.TrackerOracle.table)
         f += 1
         if f <= 2:          # frames 0-1 build the track pool: not steady state
             if dt > budget_s * 4:
@@ -280,7 +334,10 @@ def main():
                 # what ONE GPU serves when it is given several independent streams of this workload (own handle, HIP stream
                 # and host thread each: multistream.run_concurrent); not the headline configuration (1 stream per GPU)
                 out["several_streams_one_gpu"] = several_streams(a, (4, 8))
-            out["cpu_baseline"] = cpu_baseline(pkg, K, M, D, 1234, a.cpu_seconds)
+            checker = IdMatch(pkg, K, M, D) if (S == 1 and not a.dense) else None
+            out["cpu_baseline"] = cpu_baseline(pkg, K, M, D, ms_seed(pkg, 0), a.cpu_seconds, checker)
+            if checker is not None:
+                out["id_match"] = checker.result()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
