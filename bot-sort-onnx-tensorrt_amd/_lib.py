@@ -28,6 +28,7 @@ class TrackerConfig(ctypes.Structure):
         ("match_thresh", c_double), ("second_match_thresh", c_double), ("unconfirmed_match_thresh", c_double),
         ("proximity_thresh", c_double), ("appearance_thresh", c_double), ("dedupe_thresh", c_double),
         ("ema_alpha", c_double), ("record_costs", c_int32), ("appearance_mode", c_int32), ("use_graph", c_int32),
+        ("motion_gate", c_int32),
     ]
 
 

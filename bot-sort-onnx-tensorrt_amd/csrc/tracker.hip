@@ -76,6 +76,8 @@ struct Dev {
     uint8_t *drop_t, *drop_l;
     int32_t *lap_hdr;          // 3 x 64 ints: per-stage counters of the assignment solver (BTS_LAP_HDR_INTS each)
     int record;                // keep dense cost matrices (tests / inspection)
+    int motion_gate;           // optional Mahalanobis gate on the stage-1 edges (tk_gate_edges)
+    double gate_thr;           // chi2inv95[4], D:139-149
     int filter;                // appearance term by fp8-MFMA pre-filter + exact float32 refine
     uint8_t *body_h, *face_h, *det_h, *dface_h;       // fp8 unit-vector shadows of body_curr/face_curr and of the frame's rows
     float *body_n, *face_n, *det_n, *dface_n;         // their float32 L2 norms
@@ -561,6 +563,69 @@ __global__ __launch_bounds__(CT_COLS) void tk_edges(Dev d, bts_lap_work w, int a
 template <int ROWS>
 __global__ __launch_bounds__(CT_COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) void tk_edges_tall(Dev d, bts_lap_work w, int accum) {
     edges_all<1, 1, ROWS>(d, w, blockIdx.x, gridDim.x, accum);
+}
+
+// ---- optional motion gate on the stage-1 edges -------------------------------------------------------------------
+// KalmanFilter.gating_distance (D:338-380, metric 'maha', all four coordinates) is defined by the reference but never
+// called from its update loop; with bts_tracker_config.motion_gate the cascade applies it the way
+// upstream BoT-SORT's gate_cost_matrix does: a stage-1 pair whose squared Mahalanobis distance between the track's
+// predicted state and the detection's (cx, cy, w, h) exceeds chi2inv95[4] gets cost +inf, i.e. its edge leaves the
+// solver's list.  Only pairs that ARE edges (cost <= match threshold) can be affected, so the N x M distance matrix is
+// never formed: one thread per edge projects its track (4x4 block of the covariance + measurement noise), factors it
+// and solves L y = z - H m in float64, then the list is compacted in place (chunks of 1024, in order; a chunk is read
+// completely before any of it is overwritten).  One workgroup: the list holds a few thousand edges.
+__global__ __launch_bounds__(1024) void tk_gate_edges(Dev d, bts_lap_work w) {
+    __shared__ int s_w[16];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const long e_all = w.hdr[0];
+    const int E = (int)(e_all < w.e_cap ? e_all : w.e_cap);
+    int kept = 0;                                         // uniform over the workgroup
+    for (int e0 = 0; e0 < E; e0 += 1024) {
+        const int e = e0 + threadIdx.x;
+        bool keep = false;
+        int r = 0, q = 0;
+        double c = 0.0;
+        if (e < E) {
+            r = w.e_row[e]; q = w.e_col[e]; c = w.e_cost[e];
+            const long s = d.pool_slot[r];
+            const int det = d.hi_idx[q];
+            const bool f = d.f32[s] != 0;
+            double mu[4], S[16], L[16], y[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) mu[a] = d.mean[s * 8 + a];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) S[i * 4 + j] = d.cov[s * 64 + i * 8 + j];
+            const double r_w = kf::sq_scaled(kf::W_POS, mu[2], f), r_h = kf::sq_scaled(kf::W_POS, mu[3], f);      // D:236-263
+            S[0] += r_w; S[5] += r_h; S[10] += r_w; S[15] += r_h;
+            kf::chol4(S, L);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) y[a] = (double)d.det_xywh[det * 4 + a] - mu[a];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {                 // forward substitution L y = d (solve_triangular, D:374-376)
+                double t = y[i];
+#pragma unroll
+                for (int k = 0; k < i; ++k) t -= L[i * 4 + k] * y[k];
+                y[i] = t / L[i * 4 + i];
+            }
+            double g = y[0] * y[0]; g += y[1] * y[1]; g += y[2] * y[2]; g += y[3] * y[3];
+            keep = !(g > d.gate_thr);                     // (a NaN distance is not "greater": the pair stays, like cost[d2 > thr] = inf)
+        }
+        const unsigned long long mk = __ballot(keep);
+        if (lane == 0) s_w[wid] = __popcll(mk);
+        __syncthreads();                                  // every read of the chunk is done: its head may be overwritten
+        int base = kept, tot = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const int v = s_w[k]; base += k < wid ? v : 0; tot += v; }
+        if (keep) {
+            const int p = base + __popcll(mk & ((1ull << lane) - 1ull));
+            w.e_row[p] = r; w.e_col[p] = q; w.e_cost[p] = c;
+        }
+        kept += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && kept != E) atomicExch(&w.hdr[0], kept);      // (a word that atomics target: no plain store)
 }
 
 // ---- appearance pre-filter: fp8 MFMA GEMM + exact float32 refine ------------------------------------------------
@@ -1436,6 +1501,7 @@ int bts_tracker_default_config(bts_tracker_config *cfg) {
     cfg->match_thresh = 0.8; cfg->second_match_thresh = 0.5; cfg->unconfirmed_match_thresh = 0.7;
     cfg->proximity_thresh = 0.5; cfg->appearance_thresh = 0.25; cfg->dedupe_thresh = 0.15;
     cfg->ema_alpha = 0.9; cfg->record_costs = 0; cfg->appearance_mode = BTS_APPEARANCE_FILTER; cfg->use_graph = 0;
+    cfg->motion_gate = 0;      // the reference's loop never gates on motion (A6): off keeps parity
     return BTS_OK;
 }
 
@@ -1456,6 +1522,8 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
     d.ema_a = (float)cfg->ema_alpha; d.ema_b = (float)(1.0 - cfg->ema_alpha);
     d.max_time_lost = (int)((double)cfg->frame_rate / 30.0 * cfg->track_buffer);    // D:1276-1277
     d.record = cfg->record_costs ? 1 : 0;
+    d.motion_gate = cfg->motion_gate ? 1 : 0;
+    d.gate_thr = 9.4877;       // chi2inv95[4], D:139-149
     {   // list jobs over tables beyond ~6000 tracks are split into chunks of ~2048 entries, one workgroup each
         // (measured: 4096 tracks slightly better unsplit, 10 000 +3.5 %, 16 384 +6.5 %); BTS_CHUNK_ROWS forces a chunk size
         const char *e = getenv("BTS_CHUNK_ROWS");
@@ -1666,6 +1734,7 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
         LAUNCH((tk_edges<1, 0>), tile_grid, dim3(CT_COLS), lap[0], 0);
     }
     seg_end(BTS_SEG_K_EDGES1);
+    if (d.motion_gate) { LAUNCH(tk_gate_edges, dim3(1), dim3(1024), lap[0]); }
     seg_end(BTS_SEG_COST1);
     seg_begin(BTS_SEG_LAP1);
     bts_lap_problem prob[3] = {{lap[0], d.hdr + H_DIMS1, T, mc, d.match1, d.x1, d.y1, 1},

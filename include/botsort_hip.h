@@ -191,6 +191,12 @@ typedef struct bts_tracker_config {
     int32_t appearance_mode;    /* enum bts_appearance_mode */
     int32_t use_graph;          /* replay each step as one hipGraph (captured on the first step; grids sized for
                                    max_dets; needs appearance_mode FILTER and record_costs 0) */
+    int32_t motion_gate;        /* 0 (default, = the reference: KalmanFilter.gating_distance D:338-380 is never called by
+                                   its update loop) | 1: stage-1 pairs whose squared Mahalanobis distance between the
+                                   track's predicted state and the detection's (cx,cy,w,h) exceeds chi2inv95[4] = 9.4877
+                                   (D:139-149) cannot be matched (cost = +inf, upstream BoT-SORT's gate_cost_matrix);
+                                   applied to the sparse edge list, the N x M distance matrix is never formed
+                                   (record_costs shows the cost matrix before the gate) */
 } bts_tracker_config;
 
 /* Fill cfg with the reference's hard-coded values (D:1268-1277). */

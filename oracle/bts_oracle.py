@@ -543,7 +543,8 @@ class TrackerOracle:
     same IDs).
     """
 
-    def __init__(self, frame_rate: int = 30, faithful_iou: bool = False):
+    def __init__(self, frame_rate: int = 30, faithful_iou: bool = False, motion_gate: bool = False):
+        self.motion_gate = motion_gate      # NOT in the reference's loop (A6): see _gate_stage1
         self.tracked: List[TrackRec] = []
         self.lost: List[TrackRec] = []
         self.removed: List[TrackRec] = []
@@ -569,6 +570,20 @@ class TrackerOracle:
 
     def _iou(self, a: List[TrackRec], b: List[TrackRec]):
         return iou_cost([t.tlbr for t in a], [t.tlbr for t in b], faithful=self.faithful_iou)
+
+    def _gate_stage1(self, dists, pool: List[TrackRec], dets: List[TrackRec]):
+        """Optional extension (bts_tracker_config.motion_gate): upstream BoT-SORT's `gate_cost_matrix` on the stage-1
+        costs, built from the reference's own KalmanFilter.gating_distance (D:338-380, 'maha', 4 dof) and
+        chi2inv95[4] (D:139-149) -- the reference defines both and never calls them.  Gated entries get a cost
+        no assignment can use (+inf upstream; a finite 1e9 here so that the dense JV's arithmetic stays finite)."""
+        if not self.motion_gate or dists.size == 0:
+            return dists
+        meas = np.asarray([TrackRec.tlwh_to_xywh(t.tlwh0) for t in dets])
+        dists = np.array(dists, dtype=np.float64)
+        for i, t in enumerate(pool):
+            d2 = self.kf.gating_distance(t.mean, t.cov, meas)
+            dists[i, d2 > CHI2INV95[4]] = 1e9
+        return dists
 
     def _multi_predict(self, pool: List[TrackRec]):          # D:524-536
         if not pool:
@@ -639,6 +654,7 @@ class TrackerOracle:
         else:
             dists = fuse_cost_stage1(iou_d, body_sim[:, hi_idx], face_sim[:, hi_idx],
                                      self.proximity_thresh, self.appearance_thresh)
+        dists = self._gate_stage1(dists, pool, dets_hi)
         m1, u_trk, u_det = linear_assignment(dists, self.match_thresh)
         tr["cost1"] = dists
         tr["m1"] = np.asarray(m1, dtype=np.int64).reshape(-1, 2)

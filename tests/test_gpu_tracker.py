@@ -532,3 +532,55 @@ def test_persistent_prefilter_gate_band_vs_dense(bts):
         assert a.counts() == b.counts() and a.counts()["errors"] == 0
     assert matched1 > K // 4          # about half of the cosines sit inside the gate
     a.close(); b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,M,D,mode", [(256, 128, 256, 0), (256, 128, 256, 1), (1500, 700, 128, 0)])
+def test_motion_gate_vs_oracle(bts, synth, K, M, D, mode):
+    """bts_tracker_config.motion_gate (KalmanFilter.gating_distance D:338-380 + chi2inv95[4] D:139-149 applied
+    to the stage-1 costs the way upstream's gate_cost_matrix does; default off = the reference).  A few detections per
+    frame are teleported 300 px away: their appearance still matches, so the ungated cascade keeps their identity and the
+    gated one must not.  The device path (gate on the sparse edge list) is compared with the oracle's dense gate frame by
+    frame, and the gate has to change outcomes relative to the ungated oracle."""
+    from oracle import bts_oracle as bo
+    frames = 14
+    st = synth.SyntheticStream(K, M, D, seed=777, churn=0.02)
+    rng = np.random.default_rng(5)
+    gated, plain = bo.TrackerOracle(motion_gate=True), bo.TrackerOracle()
+    trk = bts.DeviceTracker(max_tracks=3 * K + 64, max_dets=max(K, M), feat_dim=D, appearance_mode=mode, motion_gate=1)
+    differs = 0
+    for f in range(frames):
+        fr = st.next()
+        boxes = fr.boxes.copy()
+        if f >= 3:
+            jump = rng.choice(len(boxes), size=max(2, len(boxes) // 25), replace=False)
+            boxes[jump] += np.asarray([300, 300, 300, 300], dtype=boxes.dtype)
+        trk.step(torch_i32(boxes), torch_f32(fr.scores), torch_f32(fr.feats.copy()))
+        gated.update_arrays(boxes, fr.scores.astype(np.float64), fr.feats.copy())
+        plain.update_arrays(boxes, fr.scores.astype(np.float64), fr.feats.copy())
+        for k in (1, 2, 3):
+            r = trk.stage_result(k)
+            assert np.array_equal(r["m"], gated.trace["m%d" % k]), (f, k)
+            assert np.array_equal(r["u_trk"], gated.trace["u_trk%d" % k]), (f, k)
+            assert np.array_equal(r["u_det"], gated.trace["u_det%d" % k]), (f, k)
+        for which, lst in ((0, gated.tracked), (1, gated.lost)):
+            t = trk.export(which)
+            want = bo.TrackerOracle.table(lst)
+            for key in INT_KEYS:
+                assert np.array_equal(t[key], want[key]), (f, which, key)
+            if len(t["mean"]):
+                assert np.abs(t["mean"] - want["mean"]).max() <= 1e-6, (f, which)
+        differs += int(gated._count != plain._count or len(gated.trace["m1"]) != len(plain.trace["m1"]))
+    assert trk.counts()["errors"] == 0
+    assert differs >= frames - 4, differs           # the gate changed the cascade on (nearly) every teleport frame
+    trk.close()
+
+
+def torch_i32(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).cuda()
+
+
+def torch_f32(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()

@@ -187,3 +187,28 @@ def test_g6_lifecycle(synth):
 
 def test_g6_faces(synth):
     _replay("g6_faces.npz", synth)
+
+
+def test_motion_gate_extension_of_the_oracle(synth):
+    """The optional motion gate (not in the reference's loop) is built from pieces the golden vectors pin
+    (gating_distance: G1; chi2inv95[4] = 9.4877, D:139-149).  Off it changes nothing; on, a detection teleported 300 px
+    keeps its appearance match in the plain cascade and loses it in the gated one."""
+    from oracle import bts_oracle as bo
+    assert bo.CHI2INV95[4] == 9.4877
+    st = synth.SyntheticStream(48, 40, 64, seed=11)
+    plain, gated = bo.TrackerOracle(), bo.TrackerOracle(motion_gate=True)
+    for f in range(6):
+        fr = st.next()
+        boxes = fr.boxes.copy()
+        if f == 5:
+            boxes[3] += 300
+        for o in (plain, gated):
+            o.update_arrays(boxes, fr.scores.astype(np.float64), fr.feats.copy())
+        if f < 5:
+            for k in ("m1", "m2", "m3"):
+                assert np.array_equal(plain.trace[k], gated.trace[k])
+    hi = list(plain.trace["hi_idx"])
+    assert 3 in hi
+    col = hi.index(3)
+    assert col in set(plain.trace["m1"][:, 1]) and col not in set(gated.trace["m1"][:, 1])
+    assert gated._count == plain._count + (1 if fr.scores[3] >= 0.9 else 0)
