@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--dense", action="store_true", help="dense float32 appearance path instead of the f16 pre-filter")
     ap.add_argument("--graph", action="store_true", help="replay each step as one hipGraph (bts_tracker_config.use_graph)")
     ap.add_argument("--breakdown", action="store_true", help="also report the per-segment timing table")
+    ap.add_argument("--motion-gate", action="store_true", help="Mahalanobis gate on the stage-1 pairs (bts_tracker_config.motion_gate; "
+                    "BASELINE config 3 names it; off = the reference's cascade)")
     return ap.parse_args()
 
 
@@ -194,7 +196,7 @@ def several_streams(a, counts):
     out = []
     for n in counts:
         cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--workload", a.workload, "--steps", str(min(a.steps, 200)),
-               "--warmup", str(a.warmup), "--no-cpu", "--streams-per-gpu", str(n)] + (["--dense"] if a.dense else [])
+               "--warmup", str(a.warmup), "--no-cpu", "--streams-per-gpu", str(n)] + (["--dense"] if a.dense else []) + (["--motion-gate"] if a.motion_gate else [])
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
             d = json.loads(r.stdout.strip().splitlines()[-1])
@@ -236,7 +238,7 @@ def main():
     torch.cuda.set_stream(stream)
     frames = [next_frame() for _ in range(a.warmup)]
     trk = pkg.DeviceTracker(max_tracks=K + 64, max_dets=max(K, M), feat_dim=D, device=torch.cuda.current_device(),
-                            appearance_mode=1 if a.dense else 0, use_graph=1 if a.graph else 0)
+                            appearance_mode=1 if a.dense else 0, use_graph=1 if a.graph else 0, motion_gate=1 if a.motion_gate else 0)
 
     ms = importlib.import_module("bot-sort-onnx-tensorrt_amd.multistream")
     ddist = dist if world > 1 else None
@@ -261,7 +263,7 @@ def main():
         hs = None
         with torch.cuda.stream(torch.cuda.default_stream()):      # (set-up on the default stream: see multistream.run_concurrent)
             tk = pkg.DeviceTracker(max_tracks=K + 64, max_dets=max(K, M), feat_dim=D, device=torch.cuda.current_device(),
-                                   appearance_mode=1 if a.dense else 0, use_graph=1 if a.graph else 0)
+                                   appearance_mode=1 if a.dense else 0, use_graph=1 if a.graph else 0, motion_gate=1 if a.motion_gate else 0)
             for _ in range(a.warmup + 6):
                 fr = st_k.next()
                 tk.step(torch.from_numpy(fr.boxes).cuda(), torch.from_numpy(fr.scores).cuda(), torch.from_numpy(fr.feats).cuda())
@@ -318,7 +320,7 @@ def main():
             "config": {"workload": "%s: %d tracks x %d detections/frame x %d-d ReID, IoU+cosine fused cost, "
                                    "3-stage association, one stream per GPU" % (a.workload, K, M, D),
                        "tracks": K, "dets": M, "feat_dim": D, "streams": world * S, "parallelism": "%d stream%s/GPU, no collective" % (S, "" if S == 1 else "s (own HIP stream + host thread each)"),
-                       "launch": "hipGraph replay" if a.graph else "eager"},
+                       "launch": "hipGraph replay" if a.graph else "eager", "motion_gate": bool(a.motion_gate)},
             "roofline": {"kernel": KERNELS[segment], "bound": bound, "achieved": achieved, "peak": peak, "unit": runit,
                          "frac": achieved / peak, "traffic": pmc_traffic(a.workload, KERNELS[segment]),
                          "traffic_unit": "bytes per launch (HBM, rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes, profiles/pmc_traffic.json)",
@@ -334,7 +336,7 @@ def main():
                 # what ONE GPU serves when it is given several independent streams of this workload (own handle, HIP stream
                 # and host thread each: multistream.run_concurrent); not the headline configuration (1 stream per GPU)
                 out["several_streams_one_gpu"] = several_streams(a, (4, 8))
-            checker = IdMatch(pkg, K, M, D) if (S == 1 and not a.dense) else None
+            checker = IdMatch(pkg, K, M, D) if (S == 1 and not a.dense and not a.motion_gate) else None
             out["cpu_baseline"] = cpu_baseline(pkg, K, M, D, ms_seed(pkg, 0), a.cpu_seconds, checker)
             if checker is not None:
                 out["id_match"] = checker.result()

@@ -312,6 +312,42 @@ __device__ __forceinline__ bool is_candidate(float approx, float na, float nb, f
     return !((approx + err) * (na * nb) < gate - 3e-5f);
 }
 
+// ---- optional motion gate on the stage-1 pairs --------------------------------------------------------------------
+// KalmanFilter.gating_distance (D:338-380, metric 'maha', all four coordinates) is defined by the reference but never
+// called from its update loop (SURVEY.md A6); with bts_tracker_config.motion_gate the cascade applies it the way
+// upstream BoT-SORT's gate_cost_matrix does: a stage-1 pair whose squared Mahalanobis distance between the track's
+// predicted state and the detection's (cx, cy, w, h) exceeds chi2inv95[4] gets cost +inf, i.e. it never becomes an
+// edge of the solver's list.  Only pairs that WOULD be edges (cost <= match threshold; about one per detection) can be
+// affected, so the test runs inside the stage-1 tile kernel on exactly those lanes, right before the edge is staged
+// (GATE instantiations of tk_edges / tk_edges_tall, launched only when the option is on): the N x M distance matrix is
+// never formed and the step keeps its 11 launches.  (A separate pass over the edge list was measured first: +12 us at
+// 4096x1024 and +15..24 us at 10000x2000 -- a launch boundary plus a chain of float64 divisions and square roots that
+// one or a few workgroups execute; spread over the tiles the same arithmetic disappears in the tile kernel's time.)
+__device__ __forceinline__ bool motion_gate_open(const Dev &d, long s, int det) {
+    const bool f = d.f32[s] != 0;
+    double mu[4], S[16], L[16], y[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) mu[a] = d.mean[s * 8 + a];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) S[i * 4 + j] = d.cov[s * 64 + i * 8 + j];      // (cho_factor reads the lower triangle)
+    const double r_w = kf::sq_scaled(kf::W_POS, mu[2], f), r_h = kf::sq_scaled(kf::W_POS, mu[3], f);      // D:236-263
+    S[0] += r_w; S[5] += r_h; S[10] += r_w; S[15] += r_h;
+    kf::chol4(S, L);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) y[a] = (double)d.det_xywh[det * 4 + a] - mu[a];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                         // forward substitution L y = z - H m (solve_triangular, D:374-376)
+        double t = y[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) t -= L[i * 4 + k] * y[k];
+        y[i] = t / L[i * 4 + i];
+    }
+    double g = y[0] * y[0]; g += y[1] * y[1]; g += y[2] * y[2]; g += y[3] * y[3];
+    return !(g > d.gate_thr);                             // (a NaN distance is not "greater": the pair stays, like cost[d2 > thr] = inf)
+}
+
 // STAGE 1: cost = min(iou_d, emb) with the appearance gate (D:1539-1554)
 // STAGE 2: cost = iou_d (D:1570)      STAGE 3: D:1590-1602
 // The same tile also feeds the assignment solver directly: every entry <= the stage's match
@@ -323,7 +359,7 @@ __device__ __forceinline__ bool is_candidate(float approx, float na, float nb, f
 // MODE 2: record only (dense cost matrix for inspection, no edges).
 // ROWS = rows of a tile: 16, or 64 for big stage-1 problems (a tile's fixed cost -- its chains of dependent
 // loads -- dominates, the per-row screening is cheap).
-template <int STAGE, int MODE, int ROWS = CT_ROWS>
+template <int STAGE, int MODE, int ROWS = CT_ROWS, bool GATE = false>
 __device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, int bx, int by, int accum) {
     __shared__ double sa[ROWS][4];
     __shared__ double sarea[ROWS];
@@ -521,7 +557,9 @@ __device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, 
             }
             if (MODE == 2 || d.record) cost[o] = c;
         }
-        if (MODE != 2) emit(live && c <= limit, i0 + r, c);
+        bool edge = live && c <= limit;
+        if (GATE && STAGE == 1 && edge) edge = motion_gate_open(d, d.pool_slot[i0 + r], det);
+        if (MODE != 2) emit(edge, i0 + r, c);
     }
     }   // chunk
     if (MODE != 2) {
@@ -544,18 +582,18 @@ __device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, 
 
 // Persistent tiles: the live extents are only known on the device, so a fixed grid walks the
 // (column tile, row tile) space of the actual problem instead of launching capacity-sized grids.
-template <int STAGE, int MODE, int ROWS = CT_ROWS>
+template <int STAGE, int MODE, int ROWS = CT_ROWS, bool GATE = false>
 __device__ __forceinline__ void edges_all(const Dev &d, const bts_lap_work &w, int bid, int nblk, int accum = 0) {
     const int32_t *h = d.hdr;
     const int n = STAGE == 1 ? h[H_NPOOL] : STAGE == 2 ? h[H_NR2] : h[H_NUNC];
     const int m = STAGE == 1 ? h[H_NHI] : STAGE == 2 ? h[H_NLO] : h[H_NLEFT];
     const int nct = (m + CT_COLS - 1) / CT_COLS, ntile = nct * ((n + ROWS - 1) / ROWS);
-    for (int t = bid; t < ntile; t += nblk) edges_tile<STAGE, MODE, ROWS>(d, w, t % nct, t / nct, accum);
+    for (int t = bid; t < ntile; t += nblk) edges_tile<STAGE, MODE, ROWS, GATE>(d, w, t % nct, t / nct, accum);
 }
 
-template <int STAGE, int MODE, int ROWS = CT_ROWS>
+template <int STAGE, int MODE, int ROWS = CT_ROWS, bool GATE = false>
 __global__ __launch_bounds__(CT_COLS) void tk_edges(Dev d, bts_lap_work w, int accum) {
-    edges_all<STAGE, MODE, ROWS>(d, w, blockIdx.x, gridDim.x, accum);
+    edges_all<STAGE, MODE, ROWS, GATE>(d, w, blockIdx.x, gridDim.x, accum);
 }
 // the tall stage-1 tiles of big problems are throughput-bound on their screening loop (59 % of the wave cycles waiting
 // at 3 wavefronts per SIMD): capped at 128 registers they run 4 per SIMD (no spills at 32 / 64 rows; the short tiles
@@ -564,68 +602,11 @@ template <int ROWS>
 __global__ __launch_bounds__(CT_COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) void tk_edges_tall(Dev d, bts_lap_work w, int accum) {
     edges_all<1, 1, ROWS>(d, w, blockIdx.x, gridDim.x, accum);
 }
-
-// ---- optional motion gate on the stage-1 edges -------------------------------------------------------------------
-// KalmanFilter.gating_distance (D:338-380, metric 'maha', all four coordinates) is defined by the reference but never
-// called from its update loop (SURVEY.md A6); with bts_tracker_config.motion_gate the cascade applies it the way
-// upstream BoT-SORT's gate_cost_matrix does: a stage-1 pair whose squared Mahalanobis distance between the track's
-// predicted state and the detection's (cx, cy, w, h) exceeds chi2inv95[4] gets cost +inf, i.e. its edge leaves the
-// solver's list.  Only pairs that ARE edges (cost <= match threshold) can be affected, so the N x M distance matrix is
-// never formed: one thread per edge projects its track (4x4 block of the covariance + measurement noise), factors it
-// and solves L y = z - H m in float64, then the list is compacted in place (chunks of 1024, in order; a chunk is read
-// completely before any of it is overwritten).  One workgroup: the list holds a few thousand edges.
-__global__ __launch_bounds__(1024) void tk_gate_edges(Dev d, bts_lap_work w) {
-    __shared__ int s_w[16];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const long e_all = w.hdr[0];
-    const int E = (int)(e_all < w.e_cap ? e_all : w.e_cap);
-    int kept = 0;                                         // uniform over the workgroup
-    for (int e0 = 0; e0 < E; e0 += 1024) {
-        const int e = e0 + threadIdx.x;
-        bool keep = false;
-        int r = 0, q = 0;
-        double c = 0.0;
-        if (e < E) {
-            r = w.e_row[e]; q = w.e_col[e]; c = w.e_cost[e];
-            const long s = d.pool_slot[r];
-            const int det = d.hi_idx[q];
-            const bool f = d.f32[s] != 0;
-            double mu[4], S[16], L[16], y[4];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) mu[a] = d.mean[s * 8 + a];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) S[i * 4 + j] = d.cov[s * 64 + i * 8 + j];
-            const double r_w = kf::sq_scaled(kf::W_POS, mu[2], f), r_h = kf::sq_scaled(kf::W_POS, mu[3], f);      // D:236-263
-            S[0] += r_w; S[5] += r_h; S[10] += r_w; S[15] += r_h;
-            kf::chol4(S, L);
-#pragma unroll
-            for (int a = 0; a < 4; ++a) y[a] = (double)d.det_xywh[det * 4 + a] - mu[a];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {                 // forward substitution L y = d (solve_triangular, D:374-376)
-                double t = y[i];
-#pragma unroll
-                for (int k = 0; k < i; ++k) t -= L[i * 4 + k] * y[k];
-                y[i] = t / L[i * 4 + i];
-            }
-            double g = y[0] * y[0]; g += y[1] * y[1]; g += y[2] * y[2]; g += y[3] * y[3];
-            keep = !(g > d.gate_thr);                     // (a NaN distance is not "greater": the pair stays, like cost[d2 > thr] = inf)
-        }
-        const unsigned long long mk = __ballot(keep);
-        if (lane == 0) s_w[wid] = __popcll(mk);
-        __syncthreads();                                  // every read of the chunk is done: its head may be overwritten
-        int base = kept, tot = 0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) { const int v = s_w[k]; base += k < wid ? v : 0; tot += v; }
-        if (keep) {
-            const int p = base + __popcll(mk & ((1ull << lane) - 1ull));
-            w.e_row[p] = r; w.e_col[p] = q; w.e_cost[p] = c;
-        }
-        kept += tot;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0 && kept != E) atomicExch(&w.hdr[0], kept);      // (a word that atomics target: no plain store)
+// the motion-gate form of the tall tiles: no register cap (under it the gate's float64 factorisation spilled 8-12 bytes
+// per lane, and any scratch costs a launch ~2 us)
+template <int ROWS>
+__global__ __launch_bounds__(CT_COLS) void tk_edges_tall_gate(Dev d, bts_lap_work w, int accum) {
+    edges_all<1, 1, ROWS, true>(d, w, blockIdx.x, gridDim.x, accum);
 }
 
 // ---- appearance pre-filter: fp8 MFMA GEMM + exact float32 refine ------------------------------------------------
@@ -1718,7 +1699,19 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
     seg_end(BTS_SEG_COS1);
     seg_begin(BTS_SEG_COST1);
     seg_begin(BTS_SEG_K_EDGES1);
-    if (d.filter) {
+    if (d.filter && d.motion_gate) {
+        switch (trows) {
+        case 2: LAUNCH((tk_edges<1, 1, 2, true>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
+        case 4: LAUNCH((tk_edges<1, 1, 4, true>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
+        case 8: LAUNCH((tk_edges<1, 1, 8, true>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
+        case 16: LAUNCH((tk_edges<1, 1, 16, true>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
+        case 32: LAUNCH(tk_edges_tall_gate<32>, dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
+        case 64: LAUNCH(tk_edges_tall_gate<64>, dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
+        case 128: LAUNCH(tk_edges_tall_gate<128>, dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
+        default: LAUNCH(tk_edges_tall_gate<256>, dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
+        }
+        if (d.record) { LAUNCH((tk_edges<1, 2>), tile_grid, dim3(CT_COLS), lap[0], 0); }
+    } else if (d.filter) {
         switch (trows) {
         case 2: LAUNCH((tk_edges<1, 1, 2>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
         case 4: LAUNCH((tk_edges<1, 1, 4>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
@@ -1730,11 +1723,12 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
         default: LAUNCH(tk_edges_tall<256>, dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
         }
         if (d.record) { LAUNCH((tk_edges<1, 2>), tile_grid, dim3(CT_COLS), lap[0], 0); }
+    } else if (d.motion_gate) {
+        LAUNCH((tk_edges<1, 0, CT_ROWS, true>), tile_grid, dim3(CT_COLS), lap[0], 0);
     } else {
         LAUNCH((tk_edges<1, 0>), tile_grid, dim3(CT_COLS), lap[0], 0);
     }
     seg_end(BTS_SEG_K_EDGES1);
-    if (d.motion_gate) { LAUNCH(tk_gate_edges, dim3(1), dim3(1024), lap[0]); }
     seg_end(BTS_SEG_COST1);
     seg_begin(BTS_SEG_LAP1);
     bts_lap_problem prob[3] = {{lap[0], d.hdr + H_DIMS1, T, mc, d.match1, d.x1, d.y1, 1},
