@@ -132,7 +132,7 @@ class IdMatch:
                            "the two pool-building frames; tracked + lost lists in order, stages 1-3 (row, column) pairs"}
 
 
-def cpu_baseline(pkg, K, M, D, seed, budget_s, checker=None):
+def cpu_baseline(pkg, K, M, D, seed, budget_s, checker=None, faithful=True, max_frames=200):
     """The oracle timed on this box's host cores: 1 process, 1 core (the reference is
     single-threaded Python).  Only this leg may touch oracle/."""
     from oracle import bts_oracle as bo
@@ -142,7 +142,7 @@ def cpu_baseline(pkg, K, M, D, seed, budget_s, checker=None):
     except Exception:
         limit = None
     st = pkg.synth.SyntheticStream(K, M, D, seed=seed)
-    ora = bo.TrackerOracle(faithful_iou=True)
+    ora = bo.TrackerOracle(faithful_iou=faithful)
     t_used, n = 0.0, 0
     f = 0
     while True:
@@ -160,7 +160,7 @@ def cpu_baseline(pkg, K, M, D, seed, budget_s, checker=None):
             continue
         t_used += dt
         n += 1
-        if t_used >= budget_s or n >= 200:
+        if t_used >= budget_s or n >= max_frames:
             break
     if limit is not None:
         limit.unregister() if hasattr(limit, "unregister") else None
@@ -302,6 +302,15 @@ def main():
     if a.breakdown and rank == 0:
         sys.stderr.write("segment us/step: " + json.dumps({k: round(v, 1) for k, v in breakdown.items()}) + "\n")
 
+    id_multi = None
+    if world > 1 and not a.no_cpu and S == 1 and not a.dense and not a.motion_gate:
+        # ID match of EVERY rank's stream (N > 1: no CPU baseline, that is the N = 1 line's): 24 steady-state frames of this
+        # rank's stream through a second handle and the oracle (vectorised IoU form: the checker, not a timing), gathered
+        chk = IdMatch(pkg, K, M, D)
+        cpu_baseline(pkg, K, M, D, ms_seed(pkg, rank), 60.0, chk, faithful=False, max_frames=24)
+        id_multi = [None] * world
+        dist.all_gather_object(id_multi, chk.result())
+
     if rank == 0:
         bound, amount, unit, peak = kernel_model(segment, K, M, D, a.dense)
         seg_s = (seg_ms / 1e3) / max(seg_n, 1)
@@ -328,7 +337,13 @@ def main():
                          "algorithmic_per_launch": amount, "algorithmic_unit": unit},
         }
         out["segments_us"] = {k: round(v, 2) for k, v in breakdown.items()}
-        if not a.no_cpu:
+        if id_multi is not None:
+            keys = ("frames", "frames_identical", "assignment_pairs", "assignment_pairs_equal", "track_ids", "track_ids_equal", "device_errors")
+            out["id_match"] = {k: sum(r[k] for r in id_multi) for k in keys}
+            out["id_match"].update({"kalman_mean_max_abs_err": max(r["kalman_mean_max_abs_err"] for r in id_multi), "kalman_tolerance": 1e-4,
+                                    "streams": world, "frames_identical_per_stream": [r["frames_identical"] for r in id_multi],
+                                    "against": "CPU oracle, the first 26 frames of every rank's own stream"})
+        if not a.no_cpu and world == 1:
             # the dense kernels of the path, standalone, against their rooflines (a few seconds; the step above is
             # launch-bound at this size, these show what the kernels do when they have work)
             out["standalone_rooflines"] = importlib.import_module("bot-sort-onnx-tensorrt_amd.microbench").run(full=False)
