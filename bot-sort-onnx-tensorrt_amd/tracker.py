@@ -357,7 +357,8 @@ class BoTSORT:
     def __init__(self, object_detection_model=None, body_feature_extractor_model=None,
                  face_feature_extractor_model=None, frame_rate: int = 30, *, max_tracks: int = 4096,
                  max_dets: int = 1024, feat_dim: Optional[int] = None, face_dim: Optional[int] = None,
-                 record_costs: bool = False, device: int = 0):
+                 record_costs: bool = False, device: int = 0, **tracker_options):
+        """`tracker_options`: further `bts_tracker_config` fields by name (`motion_gate=1`, `appearance_mode=1`, ...)."""
         self.tracked_stracks: List[STrack] = []
         self.lost_stracks: List[STrack] = []
         self.removed_stracks: List[STrack] = []
@@ -383,7 +384,7 @@ class BoTSORT:
             face_dim = 0
         self.feat_dim, self.face_dim = int(feat_dim), int(face_dim)
         self.device_tracker = DeviceTracker(max_tracks, max_dets, self.feat_dim, self.face_dim, frame_rate,
-                                            record_costs=record_costs, device=device)
+                                            record_costs=record_costs, device=device, **tracker_options)
         self._mirror = {}          # track_id -> STrack
         self._last_dets = None
 

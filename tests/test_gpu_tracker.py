@@ -584,3 +584,23 @@ def torch_i32(a):
 def torch_f32(a):
     import torch
     return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def test_botsort_facade_options(bts, synth):
+    """tracker options reach the handle through the façade (`BoTSORT(..., motion_gate=1)`); unknown ones are refused."""
+    from oracle import bts_oracle as bo
+    st = synth.SyntheticStream(48, 24, 128, seed=9)
+    bot = bts.BoTSORT(frame_rate=30, max_tracks=256, max_dets=64, feat_dim=128, motion_gate=1)
+    ora = bo.TrackerOracle(motion_gate=True)
+    for f in range(8):
+        fr = st.next()
+        boxes = fr.boxes.copy()
+        if f == 6:
+            boxes[:3] += 300
+        out = bot.update_arrays(boxes, fr.scores, fr.feats.copy())
+        ora.update_arrays(boxes, fr.scores.astype(np.float64), fr.feats.copy())
+        assert [t.track_id for t in out] == [t.track_id for t in ora.tracked]
+        assert [t.track_id for t in bot.lost_stracks] == [t.track_id for t in ora.lost]
+    assert bot.device_tracker.cfg.motion_gate == 1
+    with pytest.raises(TypeError):
+        bts.BoTSORT(frame_rate=30, max_tracks=64, max_dets=64, feat_dim=128, no_such_option=1)
