@@ -602,10 +602,16 @@ template <int ROWS>
 __global__ __launch_bounds__(CT_COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) void tk_edges_tall(Dev d, bts_lap_work w, int accum) {
     edges_all<1, 1, ROWS>(d, w, blockIdx.x, gridDim.x, accum);
 }
-// the motion-gate form of the tall tiles: no register cap (under it the gate's float64 factorisation spilled 8-12 bytes
-// per lane, and any scratch costs a launch ~2 us)
+// the motion-gate form of the tall tiles: no register cap up to 128 rows (under it the gate's float64 factorisation
+// spills 8-12 bytes per lane, and any scratch costs a launch ~2 us); the 256-row tiles of the biggest problems keep the
+// cap (tk_edges_tall_gate_c): there the fourth wavefront per SIMD is worth more than the spill costs (16384x4096 with
+// the gate: 52 us capped, 65 us uncapped, 43 us without the gate; 10000x2000, 128 rows: 34-35 us either way)
 template <int ROWS>
 __global__ __launch_bounds__(CT_COLS) void tk_edges_tall_gate(Dev d, bts_lap_work w, int accum) {
+    edges_all<1, 1, ROWS, true>(d, w, blockIdx.x, gridDim.x, accum);
+}
+template <int ROWS>
+__global__ __launch_bounds__(CT_COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) void tk_edges_tall_gate_c(Dev d, bts_lap_work w, int accum) {
     edges_all<1, 1, ROWS, true>(d, w, blockIdx.x, gridDim.x, accum);
 }
 
@@ -1708,7 +1714,7 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
         case 32: LAUNCH(tk_edges_tall_gate<32>, dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
         case 64: LAUNCH(tk_edges_tall_gate<64>, dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
         case 128: LAUNCH(tk_edges_tall_gate<128>, dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
-        default: LAUNCH(tk_edges_tall_gate<256>, dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
+        default: LAUNCH(tk_edges_tall_gate_c<256>, dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
         }
         if (d.record) { LAUNCH((tk_edges<1, 2>), tile_grid, dim3(CT_COLS), lap[0], 0); }
     } else if (d.filter) {

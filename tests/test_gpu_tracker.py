@@ -604,3 +604,35 @@ def test_botsort_facade_options(bts, synth):
     assert bot.device_tracker.cfg.motion_gate == 1
     with pytest.raises(TypeError):
         bts.BoTSORT(frame_rate=30, max_tracks=64, max_dets=64, feat_dim=128, no_such_option=1)
+
+
+@pytest.mark.parametrize("M", [1024, 4096])
+def test_full_size_motion_gate_filter_vs_dense(bts, synth, M):
+    """the motion gate at BASELINE sizes, where the oracle is out of reach: the 64- and 256-row gated tile kernels
+    (`tk_edges_tall_gate`, and the register-capped `tk_edges_tall_gate_c<256>` that only the biggest problems take) must
+    agree with the gated dense form (`tk_edges<1,0,16,true>`, pinned to the oracle at the smaller sizes), with teleported
+    detections in every frame so that the gate decides matches; and the gate must change the outcome w.r.t. no gate."""
+    K, D = 8192, 128
+    st = synth.SyntheticStream(K, M, D, seed=33, churn=0.02)
+    rng = np.random.default_rng(3)
+    a = bts.DeviceTracker(max_tracks=K + 2048, max_dets=K, feat_dim=D, motion_gate=1)
+    b = bts.DeviceTracker(max_tracks=K + 2048, max_dets=K, feat_dim=D, motion_gate=1, appearance_mode=1)
+    c = bts.DeviceTracker(max_tracks=K + 2048, max_dets=K, feat_dim=D)
+    for f in range(6):
+        fr = st.next()
+        boxes = fr.boxes.copy()
+        if f >= 2:
+            boxes[rng.choice(len(boxes), size=len(boxes) // 20, replace=False)] += 400
+        for t in (a, b, c):
+            t.step(torch_i32(boxes), torch_f32(fr.scores), torch_f32(fr.feats.copy()))
+        for k in (1, 2, 3):
+            ra, rb = a.stage_result(k), b.stage_result(k)
+            assert np.array_equal(ra["x"], rb["x"]) and np.array_equal(ra["y"], rb["y"]), (f, k)
+        for which in (0, 1):
+            ta, tb = a.export(which), b.export(which)
+            for key in INT_KEYS:
+                assert np.array_equal(ta[key], tb[key]), (f, which, key)
+        assert a.counts() == b.counts() and a.counts()["errors"] == 0
+    assert a.counts()["last_id"] > c.counts()["last_id"]      # gated teleports were re-born as new identities
+    for t in (a, b, c):
+        t.close()
