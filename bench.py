@@ -60,7 +60,8 @@ def parse():
     ap.add_argument("--graph", action="store_true", help="replay each step as one hipGraph (bts_tracker_config.use_graph)")
     ap.add_argument("--breakdown", action="store_true", help="also report the per-segment timing table")
     ap.add_argument("--motion-gate", action="store_true", help="Mahalanobis gate on the stage-1 pairs (bts_tracker_config.motion_gate; "
-                    "BASELINE config 3 names it; off = the reference's cascade)")
+                    "off = the reference's cascade).  BASELINE config 3 is stated with the gate on: --workload c3 implies it")
+    ap.add_argument("--no-motion-gate", action="store_true", help="c3 without the gate")
     return ap.parse_args()
 
 
@@ -91,10 +92,11 @@ class IdMatch:
     compared with the oracle's."""
     INT_KEYS = ("track_id", "state", "is_activated", "frame_id", "start_frame", "tracklet_len")
 
-    def __init__(self, pkg, K, M, D):
+    def __init__(self, pkg, K, M, D, motion_gate=False):
         import torch
         self.torch = torch
-        self.trk = pkg.DeviceTracker(max_tracks=K + 64, max_dets=max(K, M), feat_dim=D, device=torch.cuda.current_device())
+        self.trk = pkg.DeviceTracker(max_tracks=K + 64, max_dets=max(K, M), feat_dim=D, device=torch.cuda.current_device(),
+                                     motion_gate=1 if motion_gate else 0)
         self.frames = self.pairs = self.pairs_equal = self.ids = self.ids_equal = 0
         self.frames_identical = 0
         self.kalman_err = 0.0
@@ -132,7 +134,7 @@ class IdMatch:
                            "the two pool-building frames; tracked + lost lists in order, stages 1-3 (row, column) pairs"}
 
 
-def cpu_baseline(pkg, K, M, D, seed, budget_s, checker=None, faithful=True, max_frames=200):
+def cpu_baseline(pkg, K, M, D, seed, budget_s, checker=None, faithful=True, max_frames=200, motion_gate=False):
     """The oracle timed on this box's host cores: 1 process, 1 core (the reference is
     single-threaded Python).  Only this leg may touch oracle/."""
     from oracle import bts_oracle as bo
@@ -142,7 +144,7 @@ def cpu_baseline(pkg, K, M, D, seed, budget_s, checker=None, faithful=True, max_
     except Exception:
         limit = None
     st = pkg.synth.SyntheticStream(K, M, D, seed=seed)
-    ora = bo.TrackerOracle(faithful_iou=faithful)
+    ora = bo.TrackerOracle(faithful_iou=faithful, motion_gate=motion_gate)
     t_used, n = 0.0, 0
     f = 0
     while True:
@@ -196,7 +198,7 @@ def several_streams(a, counts):
     out = []
     for n in counts:
         cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--workload", a.workload, "--steps", str(min(a.steps, 200)),
-               "--warmup", str(a.warmup), "--no-cpu", "--streams-per-gpu", str(n)] + (["--dense"] if a.dense else []) + (["--motion-gate"] if a.motion_gate else [])
+               "--warmup", str(a.warmup), "--no-cpu", "--streams-per-gpu", str(n)] + (["--dense"] if a.dense else []) + (["--motion-gate"] if a.motion_gate else ["--no-motion-gate"])
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
             d = json.loads(r.stdout.strip().splitlines()[-1])
@@ -224,6 +226,7 @@ def main():
     torch.cuda.set_device(local % torch.cuda.device_count())
     pkg = importlib.import_module("bot-sort-onnx-tensorrt_amd")
     K, M, D = pkg.synth.CONFIGS[a.workload]
+    a.motion_gate = (a.motion_gate or a.workload == "c3") and not a.no_motion_gate
     a.warmup = max(a.warmup, 3)          # (frames 0-1 build the track pool, frame 2 is the first steady-state one: never timed)
 
     S = max(1, a.streams_per_gpu)
@@ -303,11 +306,11 @@ def main():
         sys.stderr.write("segment us/step: " + json.dumps({k: round(v, 1) for k, v in breakdown.items()}) + "\n")
 
     id_multi = None
-    if world > 1 and not a.no_cpu and S == 1 and not a.dense and not a.motion_gate:
+    if world > 1 and not a.no_cpu and S == 1 and not a.dense:
         # ID match of EVERY rank's stream (N > 1: no CPU baseline, that is the N = 1 line's): 24 steady-state frames of this
         # rank's stream through a second handle and the oracle (vectorised IoU form: the checker, not a timing), gathered
-        chk = IdMatch(pkg, K, M, D)
-        cpu_baseline(pkg, K, M, D, ms_seed(pkg, rank), 60.0, chk, faithful=False, max_frames=24)
+        chk = IdMatch(pkg, K, M, D, a.motion_gate)
+        cpu_baseline(pkg, K, M, D, ms_seed(pkg, rank), 60.0, chk, faithful=False, max_frames=24, motion_gate=a.motion_gate)
         id_multi = [None] * world
         dist.all_gather_object(id_multi, chk.result())
 
@@ -327,7 +330,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic (seeded stream generator, SURVEY.md 8d; frames resident in HBM before the timed region)",
             "config": {"workload": "%s: %d tracks x %d detections/frame x %d-d ReID, IoU+cosine fused cost, "
-                                   "3-stage association, one stream per GPU" % (a.workload, K, M, D),
+                                   "3-stage association%s, one stream per GPU" % (a.workload, K, M, D, ", Mahalanobis gate on" if a.motion_gate else ""),
                        "tracks": K, "dets": M, "feat_dim": D, "streams": world * S, "parallelism": "%d stream%s/GPU, no collective" % (S, "" if S == 1 else "s (own HIP stream + host thread each)"),
                        "launch": "hipGraph replay" if a.graph else "eager", "motion_gate": bool(a.motion_gate)},
             "roofline": {"kernel": KERNELS[segment], "bound": bound, "achieved": achieved, "peak": peak, "unit": runit,
@@ -351,8 +354,15 @@ def main():
                 # what ONE GPU serves when it is given several independent streams of this workload (own handle, HIP stream
                 # and host thread each: multistream.run_concurrent); not the headline configuration (1 stream per GPU)
                 out["several_streams_one_gpu"] = several_streams(a, (4, 8))
-            checker = IdMatch(pkg, K, M, D) if (S == 1 and not a.dense and not a.motion_gate) else None
-            out["cpu_baseline"] = cpu_baseline(pkg, K, M, D, ms_seed(pkg, 0), a.cpu_seconds, checker)
+            checker = IdMatch(pkg, K, M, D, a.motion_gate) if (S == 1 and not a.dense) else None
+            if K <= 1024:
+                out["cpu_baseline"] = cpu_baseline(pkg, K, M, D, ms_seed(pkg, 0), a.cpu_seconds, checker, motion_gate=a.motion_gate)
+            else:
+                # big tables: the structure-faithful oracle takes seconds to minutes per frame -- it is timed alone on what
+                # fits the budget, and the ID match runs on 6 steady-state frames of the vectorised form of the same oracle
+                out["cpu_baseline"] = cpu_baseline(pkg, K, M, D, ms_seed(pkg, 0), a.cpu_seconds, None, motion_gate=a.motion_gate)
+                if checker is not None:
+                    cpu_baseline(pkg, K, M, D, ms_seed(pkg, 0), 120.0, checker, faithful=False, max_frames=6, motion_gate=a.motion_gate)
             if checker is not None:
                 out["id_match"] = checker.result()
         print(json.dumps(out), flush=True)

@@ -4,7 +4,7 @@ mkdir -p gpurun_out/final
 R=$GRAFT_REPO_ROOT
 timeout 900 python bench.py > gpurun_out/final/bench_c2.json 2> gpurun_out/final/bench_c2.err
 for w in c3 target c5; do
-  timeout 900 python bench.py --workload $w --steps 100 --no-cpu > gpurun_out/final/bench_$w.json 2> gpurun_out/final/bench_$w.err
+  timeout 900 python bench.py --workload $w --steps 100 --no-cpu > gpurun_out/final/bench_$w.json      # (c3 runs with the motion gate, as BASELINE states it) 2> gpurun_out/final/bench_$w.err
 done
 cd /tmp && export TMPDIR=/tmp
 for w in c2 target; do
