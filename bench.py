@@ -38,7 +38,7 @@ F8_MFMA_PEAK_TF = 5000.0       # dense fp8 MFMA peak (not the 2:1-sparse headlin
 F32_MFMA_PEAK_TF = 157.3       # dense f32-input MFMA peak (= f32 vector peak)
 SEGMENTS = ("prep", "cos1", "cost1", "lap1", "apply1", "stage2", "merge", "dedupe")   # launch groups of a step
 KERNELS = {   # single kernels that can dominate a step -> name in the rocprofv3 kernel trace
-    "k_filter": "k_filter_dma<false> | k_filter_dma_p<false>", "k_lap": "k_lap<4|8>", "k_edges1": "tk_edges<1,1,*> | tk_edges_tall<*>", "k_mid2": "tk_mid2<1>",
+    "k_filter": "k_filter_dma<false> | k_filter_dma_p<false>", "k_lap": "k_lap<4|8>", "k_edges1": "tk_edges<1,1,*> | tk_edges_tall<*> | tk_edges_tall_gate<*> | tk_edges_tall_gate_c<*>", "k_mid2": "tk_mid2<1>",
     "k_apply23": "tk_apply23", "prep": "tk_front", "merge": "tk_merge",
 }
 
