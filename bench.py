@@ -168,7 +168,7 @@ def cpu_baseline(pkg, K, M, D, seed, budget_s, checker=None, faithful=True, max_
         limit.unregister() if hasattr(limit, "unregister") else None
     if n == 0:
         return {"value": None, "unit": "steps/s", "cores": 1, "kind": "port",
-                "sample": "frame 1 alone exceeded the time budget at this size"}
+                "sample": "not timed (--cpu-seconds 0)" if budget_s <= 0 else "frame 1 alone exceeded the time budget at this size"}
     return {"value": n / t_used, "unit": "steps/s", "cores": 1, "kind": "port",
             "sample": "%d steady-state frames (frames 2..%d) of the same seeded stream, %.1f s, structure-faithful oracle "
                       "(per-pair Python IoU, scalar Kalman update, dense JV on the (N+M)^2 matrix); host has %d cores"
