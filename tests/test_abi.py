@@ -41,6 +41,22 @@ def test_default_config_matches_reference_constants():
     assert (cfg.match_thresh, cfg.second_match_thresh, cfg.unconfirmed_match_thresh) == (0.8, 0.5, 0.7)
     assert (cfg.proximity_thresh, cfg.appearance_thresh, cfg.dedupe_thresh) == (0.5, 0.25, 0.15)
     assert cfg.track_buffer == 300 and cfg.frame_rate == 30 and cfg.ema_alpha == 0.9
+    # extensions are opt-in: the default cascade is the reference's (no motion gate, D:1534-1556 never calls gating_distance)
+    assert cfg.motion_gate == 0 and cfg.use_graph == 0 and cfg.record_costs == 0 and cfg.appearance_mode == 0
+
+
+def test_config_struct_layout_matches_the_header():
+    """the ctypes mirror and include/botsort_hip.h declare the same fields in the same order (a field added on one side
+    only would silently shift every threshold)."""
+    import re
+    lib_mod = importlib.import_module("bot-sort-onnx-tensorrt_amd._lib")
+    hdr = open(os.path.join(REPO, "include", "botsort_hip.h")).read()
+    body = re.search(r"typedef struct bts_tracker_config \{(.*?)\} bts_tracker_config;", hdr, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    decl = re.findall(r"(int32_t|double)\s+(\w+)\s*;", body)
+    want = [(n, {"int32_t": ctypes.c_int32, "double": ctypes.c_double}[t]) for t, n in decl]
+    assert want == list(lib_mod.TrackerConfig._fields_)
+    assert ctypes.sizeof(lib_mod.TrackerConfig) == 6 * 4 + 10 * 8 + 4 * 4
 
 
 def test_product_path_never_imports_the_oracle():
