@@ -2,21 +2,30 @@
 """Tracker-only benchmark: BoT-SORT update steps / second on pre-extracted detections
 (BASELINE.json metric), one independent video stream per GPU (no data-path collective).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c1|c3|target|c5]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload target|c1|c2|c3|c5|crowd|hard-reid]
 
-A "step" is one whole BoTSORT.update (tracking half) = one `bts_tracker_step` on one frame of the
-seeded synthetic stream.  Frames are generated on the host and uploaded to HBM
-before the timed region.  Rank 0 prints ONE JSON line (contract in the task statement) with two
-extra objects:
-  roofline      the dominant kernel group of the step, timed live with hipEvents on the step's
-                stream inside the timed region (C ABI bts_tracker_profile_*), against its bound
-  cpu_baseline  the CPU oracle (structure-faithful port of the reference: per-pair Python IoU,
-                scalar Kalman updates, dense extended-matrix JV) on the same stream, 1 core,
-                bounded to ~15 s.
-  id_match      the metric's "assignment ID match vs ref": a second tracker handle stepped on the
-                frames of the cpu_baseline sample, compared with the oracle frame by frame
-                (assignment pairs of the three stages, ordered track ids / states, Kalman means).
-For N > 1 launch with torch.distributed.run; ranks only meet at barriers (gloo control plane).
+A "step" is one whole BoTSORT.update (tracking half, reference D:2129-2133 / D:1414-1639) = one
+`bts_tracker_step` on one frame of the seeded synthetic stream.  Frames are generated on the
+host and uploaded to HBM before the timed region.  The default workload is the metric's headline size,
+10 000 tracks x 2 000 detections x 2048-d.
+
+`--gpus N` without a torch.distributed environment spawns N ranks itself (one process per GPU, one video
+stream each, gloo control plane on 127.0.0.1: start/stop barriers and the max-over-ranks time -- no collective
+on the data path); under `python -m torch.distributed.run` the environment's RANK / WORLD_SIZE are used.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
+  roofline          .kernel: the dominant kernel of the step, timed with hipEvents on the step's stream in a
+                    SEPARATE pass after the timed region (an event pair costs the stream ~4 us), against its
+                    bound (bound type explicit); .step: the whole step against the 8 TB/s HBM roofline, with
+                    SURVEY.md 8(d)'s algorithmic-bytes formula and the as-built variant
+  export_inclusive  steps/s when every frame's result also leaves the device (MOT rows of the tracked list
+                    written into a ring of pinned host buffers, bts_tracker_export_mot_async + one event per
+                    frame, read one ring turn late), and with a host synchronisation per frame
+  cpu_baseline      the CPU oracle (structure-faithful port of the reference: per-pair Python IoU, scalar Kalman
+                    updates, dense extended-matrix JV) on the same stream, 1 core, bounded
+  id_match          the metric's "assignment ID match vs ref": a second tracker handle stepped on the frames of
+                    the oracle sample, compared frame by frame (assignment pairs of the three stages, ordered
+                    track ids / states, Kalman means)
 """
 from __future__ import annotations
 
@@ -24,6 +33,8 @@ import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -48,23 +59,54 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="c2")
-    ap.add_argument("--segment", default="auto", help="kernel timed for the roofline object (auto = the dominant one)")
-    ap.add_argument("--event-stride", type=int, default=8, help="hipEvent pairs around the roofline kernel on every n-th timed step "
-                    "(a pair costs the stream ~4 us: on every launch it inflates a 90 us step by several percent)")
+    ap.add_argument("--workload", default="target")
+    ap.add_argument("--segment", default="auto", help="kernel timed for roofline.kernel (auto = the dominant one)")
+    ap.add_argument("--roofline-steps", type=int, default=48, help="steps of the separate event pass behind the timed region")
     ap.add_argument("--streams-per-gpu", type=int, default=1, help="independent video streams per GPU, each on its own HIP stream and "
                     "host thread (the headline metric is 1; more shows what a GPU serves when steps are launch-bound)")
+    ap.add_argument("--several-streams", action="store_true", help="also report 4 and 8 concurrent streams on this GPU (fresh processes)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--dense", action="store_true", help="dense float32 appearance path instead of the f16 pre-filter")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline, the ID match and the standalone kernels")
+    ap.add_argument("--no-export", action="store_true", help="skip the export-inclusive legs")
+    ap.add_argument("--dense", action="store_true", help="dense float32 appearance path instead of the fp8 pre-filter")
     ap.add_argument("--graph", action="store_true", help="replay each step as one hipGraph (bts_tracker_config.use_graph)")
-    ap.add_argument("--breakdown", action="store_true", help="also report the per-segment timing table")
+    ap.add_argument("--breakdown", action="store_true", help="also print the per-segment timing table to stderr")
     ap.add_argument("--motion-gate", action="store_true", help="Mahalanobis gate on the stage-1 pairs (bts_tracker_config.motion_gate; "
                     "off = the reference's cascade).  BASELINE config 3 is stated with the gate on: --workload c3 implies it")
     ap.add_argument("--no-motion-gate", action="store_true", help="c3 without the gate")
+    ap.add_argument("--oversubscribe", action="store_true", help="allow --gpus N on a box with fewer GPUs (ranks share devices; "
+                    "for testing the launch path only -- the line says so)")
     return ap.parse_args()
 
 
+# ------------------------------------------------------------------------------------------- launch
+def self_spawn(a) -> int:
+    """`--gpus N` without a distributed environment: N ranks of this script, one per GPU (reference deployment:
+    one process per video stream, D:390 / D:1264).  Rank 0's stdout (the JSON line) is passed through."""
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < a.gpus and not a.oversubscribe:
+        sys.stderr.write("bench.py: --gpus %d but %d GPU(s) visible (use --oversubscribe to share devices for a launch-path test)\n"
+                         % (a.gpus, have))
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), BTS_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
+# ------------------------------------------------------------------------------------------- models
 def kernel_model(kern, K, M, D, dense):
     """Algorithmic work of ONE launch of a kernel in a steady-state frame (pool N = K rows, M detections,
     7/8 of them high-score, ~M matches, ~1.2 feasible edges per detection): (bound, amount, unit, peak).
@@ -74,15 +116,30 @@ def kernel_model(kern, K, M, D, dense):
     if kern == "k_filter":     # appearance contraction 2*N*Mh*D flop on the fp8 matrix cores
         return "mfma", 2.0 * N * Mh * D, "flop", F8_MFMA_PEAK_TF
     table = {
-        # stage-1 matches: Kalman rows read + written, measurement read; det row, smooth r+w, curr w, f16 shadow w
+        # stage-1 matches: Kalman rows read + written, measurement read; det row, smooth r+w, curr w, fp8 shadow w
         "k_mid2": Km * (2 * 72 + 4) * 8 + Km * D * (4 + 4 + 4 + 4 + 2),
         "k_apply23": (M // 8) * ((2 * 72 + 4) * 8 + D * 18),    # the low-score matches of stage 2 (stage 3 is empty in steady state)
         "k_edges1": (N + Mh) * 32 + E * 16 + Mh * 2 * D * 4,    # boxes in, sparse edges out, two feature rows per refined candidate
         "k_lap": E * 16 + 8 * Mh,                               # edge list in, assignment vectors out
-        "prep": M * D * 6 + M * 48,                             # detection rows read (f32) + f16 shadows written, boxes
+        "prep": M * D * 6 + M * 48,                             # detection rows read (f32) + fp8 shadows written, boxes
         "merge": (N + M) * 16,                                  # list entries and per-slot flags
     }
     return "hbm", float(table[kern]), "byte", HBM_PEAK_GBS
+
+
+def step_bytes(K, M, D):
+    """Algorithmic HBM bytes of ONE step, two ways (both stated in DESIGN.md section 3):
+    survey   SURVEY.md 8(d)'s formula with its fp32 element sizes (s_k = s_f = s_c = 4), K_matches = M:
+             2 N 72 s_k + K (2 72 + 4) s_k + (N + M) 16 + (N + M) D s_f + 2 N M s_c + 4 K D s_f + 4 (N + M)
+    as_built what this implementation has to move: float64 Kalman rows (s_k = 8), no N x M matrix at all (the 2 N M s_c
+             term is gone), each track / high-score detection feature row read once as its 1-byte fp8 shadow by the
+             pre-filter, detection rows read once in float32 and their shadows written, exact float32 refinement of one
+             candidate per high-score detection (two rows), feature write-back 18 D bytes per match."""
+    N, Km, Mh = K, M, M - M // 8
+    survey = 2 * N * 72 * 4 + Km * (2 * 72 + 4) * 4 + (N + M) * 16 + (N + M) * D * 4 + 2 * N * M * 4 + 4 * Km * D * 4 + 4 * (N + M)
+    as_built = (2 * N * 72 * 8 + Km * (2 * 72 + 4) * 8 + (N + M) * 48 + (N + Mh) * D * 1 + M * D * (4 + 1)
+                + Mh * 2 * D * 4 + Km * D * 18 + 16 * int(1.2 * Mh) + 4 * (N + M) * 3)
+    return float(survey), float(as_built)
 
 
 class IdMatch:
@@ -92,11 +149,11 @@ class IdMatch:
     compared with the oracle's."""
     INT_KEYS = ("track_id", "state", "is_activated", "frame_id", "start_frame", "tracklet_len")
 
-    def __init__(self, pkg, K, M, D, motion_gate=False):
+    def __init__(self, pkg, K, M, D, motion_gate=False, **opts):
         import torch
         self.torch = torch
         self.trk = pkg.DeviceTracker(max_tracks=K + 64, max_dets=max(K, M), feat_dim=D, device=torch.cuda.current_device(),
-                                     motion_gate=1 if motion_gate else 0)
+                                     motion_gate=1 if motion_gate else 0, **opts)
         self.frames = self.pairs = self.pairs_equal = self.ids = self.ids_equal = 0
         self.frames_identical = 0
         self.kalman_err = 0.0
@@ -130,11 +187,11 @@ class IdMatch:
                 "assignment_pairs": self.pairs, "assignment_pairs_equal": self.pairs_equal,
                 "track_ids": self.ids, "track_ids_equal": self.ids_equal,
                 "kalman_mean_max_abs_err": self.kalman_err, "kalman_tolerance": 1e-4, "device_errors": errors,
-                "against": "CPU oracle (pinned to the reference's golden vectors), every frame of the cpu_baseline sample incl. "
+                "against": "CPU oracle (pinned to the reference's golden vectors), every frame of the sample incl. "
                            "the two pool-building frames; tracked + lost lists in order, stages 1-3 (row, column) pairs"}
 
 
-def cpu_baseline(pkg, K, M, D, seed, budget_s, checker=None, faithful=True, max_frames=200, motion_gate=False):
+def cpu_baseline(pkg, wl, seed, budget_s, checker=None, faithful=True, max_frames=200, motion_gate=False):
     """The oracle timed on this box's host cores: 1 process, 1 core (the reference is
     single-threaded Python).  Only this leg may touch oracle/."""
     from oracle import bts_oracle as bo
@@ -143,7 +200,7 @@ def cpu_baseline(pkg, K, M, D, seed, budget_s, checker=None, faithful=True, max_
         limit = threadpool_limits(limits=1)
     except Exception:
         limit = None
-    st = pkg.synth.SyntheticStream(K, M, D, seed=seed)
+    st = pkg.synth.make_workload(wl, seed=seed)
     ora = bo.TrackerOracle(faithful_iou=faithful, motion_gate=motion_gate)
     t_used, n = 0.0, 0
     f = 0
@@ -177,7 +234,7 @@ def cpu_baseline(pkg, K, M, D, seed, budget_s, checker=None, faithful=True, max_
 
 def pmc_traffic(workload, kernel_name):
     """HBM bytes per launch of the roofline kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE,
-    separate runs: scripts/gpu_final.sh -> scripts/pmc_to_json.py).  None when no pass covers this workload."""
+    separate runs: scripts/gpu_pmc_traffic.sh -> scripts/pmc_to_json.py).  None when no pass covers this workload."""
     try:
         tab = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))["workloads"][workload]
     except Exception:
@@ -194,13 +251,12 @@ def several_streams(a, counts):
     """Aggregate steps/s of n concurrent streams on this GPU, n in `counts`: `bench.py --streams-per-gpu n`, each in a
     fresh process (the runtime binds HIP streams to its hardware queues at first use; a process that has already used
     other streams gets less regular bindings)."""
-    import subprocess
     out = []
     for n in counts:
         cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--workload", a.workload, "--steps", str(min(a.steps, 200)),
-               "--warmup", str(a.warmup), "--no-cpu", "--streams-per-gpu", str(n)] + (["--dense"] if a.dense else []) + (["--motion-gate"] if a.motion_gate else ["--no-motion-gate"])
+               "--warmup", str(a.warmup), "--no-cpu", "--no-export", "--streams-per-gpu", str(n)] + (["--dense"] if a.dense else []) + (["--motion-gate"] if a.motion_gate else ["--no-motion-gate"])
         try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
             d = json.loads(r.stdout.strip().splitlines()[-1])
             out.append({"streams": n, "value": d["value"], "unit": d["unit"], "steps_per_stream": d["steps"]})
         except Exception as e:          # a reported extra, never fatal for the headline line
@@ -212,8 +268,57 @@ def ms_seed(pkg, rank):
     return pkg.multistream.stream_seed(1234, rank)      # one independent video stream per GPU
 
 
+def export_legs(pkg, trk, frames, torch):
+    """What a per-frame consumer (D:2135-2185) sees.  (a) asynchronous: every step is followed by
+    bts_tracker_export_mot_async into the next buffer of a ring of pinned host buffers and an event; the host reads a
+    buffer one ring turn later (waits on that frame's event only).  (b) synchronous: bts_tracker_export_mot (stream
+    synchronisation + copy) after every step."""
+    RING = 4
+    T = trk.cfg.max_tracks
+    ring = [pkg.PinnedMot(T) for _ in range(RING)]
+    events = [torch.cuda.Event() for _ in range(RING)]
+    used = [False] * RING
+    rows_seen = 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k, fr in enumerate(frames):
+        slot = k % RING
+        if used[slot]:
+            events[slot].synchronize()
+            rows_seen += ring[slot].count()                      # the consumer's read of that frame
+        trk.step(*fr)
+        trk.export_mot_async(ring[slot])
+        events[slot].record()
+        used[slot] = True
+    for slot in range(RING):
+        if used[slot]:
+            events[slot].synchronize()
+            rows_seen += ring[slot].count()
+    t1 = time.perf_counter()
+    n_async = len(frames)
+    dt_async = t1 - t0
+    for r in ring:
+        r.close()
+    half = frames[: max(8, len(frames) // 4)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rows_sync = 0
+    for fr in half:
+        trk.step(*fr)
+        rows_sync += len(trk.export_mot())
+    t1 = time.perf_counter()
+    return {"async_steps_per_s": n_async / dt_async, "async_us_per_step": 1e6 * dt_async / n_async,
+            "async_mean_rows_per_frame": rows_seen / max(n_async, 1), "ring": RING,
+            "sync_steps_per_s": len(half) / (t1 - t0), "sync_us_per_step": 1e6 * (t1 - t0) / len(half),
+            "sync_frames": len(half), "sync_mean_rows_per_frame": rows_sync / len(half),
+            "what": "async: bts_tracker_export_mot_async (MOT rows written by the export kernel into pinned host memory, one event "
+                    "per frame, read one ring turn late); sync: bts_tracker_export_mot (stream sync + copy) after every step"}
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_spawn(a))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -223,15 +328,18 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
     assert torch.cuda.is_available(), "bench.py measures the HIP path: a GPU is required (no CPU fallback)"
-    torch.cuda.set_device(local % torch.cuda.device_count())
+    ndev = torch.cuda.device_count()
+    if world > ndev and not a.oversubscribe:
+        raise SystemExit("bench.py: %d ranks but %d GPU(s) visible" % (world, ndev))
+    torch.cuda.set_device(local % ndev)
     pkg = importlib.import_module("bot-sort-onnx-tensorrt_amd")
-    K, M, D = pkg.synth.CONFIGS[a.workload]
+    K, M, D = pkg.synth.workload_dims(a.workload)
     a.motion_gate = (a.motion_gate or a.workload == "c3") and not a.no_motion_gate
     a.warmup = max(a.warmup, 3)          # (frames 0-1 build the track pool, frame 2 is the first steady-state one: never timed)
 
     S = max(1, a.streams_per_gpu)
-    st = pkg.synth.SyntheticStream(K, M, D, seed=ms_seed(pkg, rank * S))
-    PROBE = 6
+    st = pkg.synth.make_workload(a.workload, seed=ms_seed(pkg, rank * S))
+    PROBE = 4
 
     def next_frame():
         fr = st.next()
@@ -240,8 +348,8 @@ def main():
     stream = torch.cuda.Stream()          # graph replay needs a real (non-legacy) stream
     torch.cuda.set_stream(stream)
     frames = [next_frame() for _ in range(a.warmup)]
-    trk = pkg.DeviceTracker(max_tracks=K + 64, max_dets=max(K, M), feat_dim=D, device=torch.cuda.current_device(),
-                            appearance_mode=1 if a.dense else 0, use_graph=1 if a.graph else 0, motion_gate=1 if a.motion_gate else 0)
+    opts = dict(appearance_mode=1 if a.dense else 0, use_graph=1 if a.graph else 0, motion_gate=1 if a.motion_gate else 0)
+    trk = pkg.DeviceTracker(max_tracks=K + 64, max_dets=max(K, M), feat_dim=D, device=torch.cuda.current_device(), **opts)
 
     ms = importlib.import_module("bot-sort-onnx-tensorrt_amd.multistream")
     ddist = dist if world > 1 else None
@@ -249,24 +357,12 @@ def main():
     for k in range(a.warmup):
         trk.step(*frames[k])
     torch.cuda.synchronize()
-    # untimed probe (more warm-up): which kernel group dominates a step?
-    breakdown = {}
-    for seg in SEGMENTS + tuple(k for k in KERNELS if k not in SEGMENTS) + ("step",):
-        trk.profile_enable(seg, PROBE)
-        for _ in range(PROBE):
-            trk.step(*next_frame())
-        ms_, n_ = trk.profile_read()
-        breakdown[seg] = 1e3 * ms_ / max(n_, 1)
-    segment = a.segment if a.segment != "auto" else max(KERNELS, key=lambda k: breakdown[k])
-    trk.profile_enable(segment, 0 if a.graph else a.steps, max(1, min(a.event_stride, a.steps // 16)))     # (>= 16 samples)     # graph replay cannot carry per-kernel events
     timed = [next_frame() for _ in range(a.steps)]
     extra = []                       # further streams of this GPU: (tracker, HIP stream, frames), warmed up the same way
     for k in range(1, S):
-        st_k = pkg.synth.SyntheticStream(K, M, D, seed=ms_seed(pkg, rank * S + k))
-        hs = None
+        st_k = pkg.synth.make_workload(a.workload, seed=ms_seed(pkg, rank * S + k))
         with torch.cuda.stream(torch.cuda.default_stream()):      # (set-up on the default stream: see multistream.run_concurrent)
-            tk = pkg.DeviceTracker(max_tracks=K + 64, max_dets=max(K, M), feat_dim=D, device=torch.cuda.current_device(),
-                                   appearance_mode=1 if a.dense else 0, use_graph=1 if a.graph else 0, motion_gate=1 if a.motion_gate else 0)
+            tk = pkg.DeviceTracker(max_tracks=K + 64, max_dets=max(K, M), feat_dim=D, device=torch.cuda.current_device(), **opts)
             for _ in range(a.warmup + 6):
                 fr = st_k.next()
                 tk.step(torch.from_numpy(fr.boxes).cuda(), torch.from_numpy(fr.scores).cuda(), torch.from_numpy(fr.feats).cuda())
@@ -274,11 +370,12 @@ def main():
             for _ in range(a.steps):
                 fr = st_k.next()
                 fl.append((torch.from_numpy(fr.boxes).cuda(), torch.from_numpy(fr.scores).cuda(), torch.from_numpy(fr.feats).cuda()))
-        extra.append((tk, hs, fl))
+        extra.append((tk, None, fl))
     if a.graph:                                              # capture happens on the first replayed step: keep it untimed
         trk.step(*next_frame())
         torch.cuda.synchronize()
 
+    # ---- the timed region: K steps, nothing else on the stream (no events, no read-backs)
     ms.barrier(ddist)
     torch.cuda.synchronize()
     if S == 1:
@@ -291,26 +388,45 @@ def main():
         t0 = 0.0
         t1 = ms.run_concurrent([trk] + [e[0] for e in extra], [timed] + [e[2] for e in extra])
     ms.barrier(ddist)
-    if a.graph:      # the dominant kernel's duration: same number of further steps, eager, with events
-        trk.profile_enable(segment, a.steps)
-        for _ in range(a.steps):
-            trk.step(*next_frame())
-        torch.cuda.synchronize()
-    seg_ms, seg_n = trk.profile_read()
     counts = trk.counts()
     assert counts["errors"] == 0, counts
     for e in extra:
         assert e[0].counts()["errors"] == 0
     elapsed = ms.max_over_ranks(t1 - t0, ddist)
+
+    # ---- behind the timed region: which kernel dominates a step, and its duration (separate event passes)
+    breakdown = {}
+    more = [next_frame() for _ in range(PROBE)]
+    for seg in SEGMENTS + tuple(k for k in KERNELS if k not in SEGMENTS) + ("step",):
+        trk.profile_enable(seg, PROBE)
+        for fr in more:
+            trk.step(*fr)
+        ms_, n_ = trk.profile_read()
+        breakdown[seg] = 1e3 * ms_ / max(n_, 1)
+    segment = a.segment if a.segment != "auto" else max(KERNELS, key=lambda k: breakdown[k])
+    roof_frames = (timed + more)[: a.roofline_steps] if len(timed) + len(more) >= a.roofline_steps else timed + more
+    trk.profile_enable(segment, len(roof_frames))
+    for fr in roof_frames:
+        trk.step(*fr)
+    torch.cuda.synchronize()
+    seg_ms, seg_n = trk.profile_read()
+    trk.profile_enable("step", 0)
+    assert trk.counts()["errors"] == 0
     if a.breakdown and rank == 0:
         sys.stderr.write("segment us/step: " + json.dumps({k: round(v, 1) for k, v in breakdown.items()}) + "\n")
 
+    export = None
+    if rank == 0 and S == 1 and not a.no_export and not a.graph:
+        export = export_legs(pkg, trk, timed, torch)
+        assert trk.counts()["errors"] == 0
+
+    big = K > 1024
     id_multi = None
     if world > 1 and not a.no_cpu and S == 1 and not a.dense:
-        # ID match of EVERY rank's stream (N > 1: no CPU baseline, that is the N = 1 line's): 24 steady-state frames of this
+        # ID match of EVERY rank's stream (N > 1: no CPU baseline, that is the N = 1 line's): steady-state frames of this
         # rank's stream through a second handle and the oracle (vectorised IoU form: the checker, not a timing), gathered
         chk = IdMatch(pkg, K, M, D, a.motion_gate)
-        cpu_baseline(pkg, K, M, D, ms_seed(pkg, rank), 60.0, chk, faithful=False, max_frames=24, motion_gate=a.motion_gate)
+        cpu_baseline(pkg, a.workload, ms_seed(pkg, rank), 120.0, chk, faithful=False, max_frames=4 if big else 24, motion_gate=a.motion_gate)
         id_multi = [None] * world
         dist.all_gather_object(id_multi, chk.result())
 
@@ -321,6 +437,16 @@ def main():
             achieved, runit = amount / seg_s / 1e12, "TFLOP/s"
         else:
             achieved, runit = amount / seg_s / 1e9, "GB/s"
+        step_s = elapsed / a.steps
+        b_survey, b_built = step_bytes(K, M, D)
+        kern_roof = {"kernel": KERNELS[segment], "bound": bound,
+                     "bound_peak": "dense fp8 MFMA 5 PFLOP/s" if bound == "mfma" else "HBM3E 8 TB/s",
+                     "achieved": achieved, "peak": peak, "unit": runit, "frac": achieved / peak,
+                     "traffic": pmc_traffic(a.workload, KERNELS[segment]),
+                     "traffic_unit": "bytes per launch (HBM, rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes, profiles/pmc_traffic.json)",
+                     "avg_us": 1e6 * seg_s, "launches_timed": seg_n,
+                     "timed_in": "separate pass of %d steps behind the timed region, one hipEvent pair per launch on the step's stream" % seg_n,
+                     "algorithmic_per_launch": amount, "algorithmic_unit": unit}
         out = {
             "metric": "tracker update-steps/sec (N_tracks x M_dets)",
             "value": ms.aggregate_throughput(a.steps * S, elapsed, world),
@@ -329,40 +455,50 @@ def main():
             "ms_per_step": 1e3 * elapsed / a.steps,      # (one step of every stream)
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic (seeded stream generator, SURVEY.md 8d; frames resident in HBM before the timed region)",
-            "config": {"workload": "%s: %d tracks x %d detections/frame x %d-d ReID, IoU+cosine fused cost, "
-                                   "3-stage association%s, one stream per GPU" % (a.workload, K, M, D, ", Mahalanobis gate on" if a.motion_gate else ""),
+            "config": {"workload": "%s: %s" % (a.workload, pkg.synth.workload_text(a.workload)) + (", Mahalanobis gate on" if a.motion_gate else "")
+                                   + ", IoU+cosine fused cost, 3-stage association, one stream per GPU",
                        "tracks": K, "dets": M, "feat_dim": D, "streams": world * S, "parallelism": "%d stream%s/GPU, no collective" % (S, "" if S == 1 else "s (own HIP stream + host thread each)"),
-                       "launch": "hipGraph replay" if a.graph else "eager", "motion_gate": bool(a.motion_gate)},
-            "roofline": {"kernel": KERNELS[segment], "bound": bound, "achieved": achieved, "peak": peak, "unit": runit,
-                         "frac": achieved / peak, "traffic": pmc_traffic(a.workload, KERNELS[segment]),
-                         "traffic_unit": "bytes per launch (HBM, rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes, profiles/pmc_traffic.json)",
-                         "avg_us": 1e6 * seg_s, "launches_timed": seg_n, "event_stride": max(1, min(a.event_stride, a.steps // 16)),
-                         "algorithmic_per_launch": amount, "algorithmic_unit": unit},
+                       "launch": "hipGraph replay" if a.graph else "eager", "motion_gate": bool(a.motion_gate),
+                       "spawn": "self-spawned ranks" if os.environ.get("BTS_BENCH_SPAWNED") else ("torch.distributed.run" if world > 1 else "single process"),
+                       "oversubscribed": bool(world > ndev)},
+            # flat fields = the dominant kernel (contract); .kernel repeats it with its bound type, .step is the whole step
+            "roofline": dict(kern_roof, kernel_detail=None),
         }
+        out["roofline"].pop("kernel_detail")
+        out["roofline"]["step"] = {
+            "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "us_per_step": 1e6 * step_s,
+            "algorithmic_bytes_survey_formula": b_survey, "achieved_survey": b_survey / step_s / 1e9, "frac_survey": b_survey / step_s / 1e9 / HBM_PEAK_GBS,
+            "algorithmic_bytes_as_built": b_built, "achieved_as_built": b_built / step_s / 1e9, "frac_as_built": b_built / step_s / 1e9 / HBM_PEAK_GBS,
+            "formula": "SURVEY.md 8(d) with fp32 element sizes (survey) / float64 Kalman rows, no N x M matrix, fp8 shadows (as built): bench.py step_bytes()"}
         out["segments_us"] = {k: round(v, 2) for k, v in breakdown.items()}
+        out["lap"] = {"stage%d" % s: dict(zip(("edges", "components", "overflow", "hard_edges", "form"),
+                                               (lambda h: (int(h[0]), int(h[1]), int(h[2]), int(h[6]), int(h[8])))(trk.debug_lap(s)))) for s in (1, 2, 3)}
+        if export is not None:
+            out["export_inclusive"] = export
         if id_multi is not None:
             keys = ("frames", "frames_identical", "assignment_pairs", "assignment_pairs_equal", "track_ids", "track_ids_equal", "device_errors")
             out["id_match"] = {k: sum(r[k] for r in id_multi) for k in keys}
             out["id_match"].update({"kalman_mean_max_abs_err": max(r["kalman_mean_max_abs_err"] for r in id_multi), "kalman_tolerance": 1e-4,
                                     "streams": world, "frames_identical_per_stream": [r["frames_identical"] for r in id_multi],
-                                    "against": "CPU oracle, the first 26 frames of every rank's own stream"})
+                                    "against": "CPU oracle, the first frames of every rank's own stream"})
         if not a.no_cpu and world == 1:
-            # the dense kernels of the path, standalone, against their rooflines (a few seconds; the step above is
-            # launch-bound at this size, these show what the kernels do when they have work)
-            out["standalone_rooflines"] = importlib.import_module("bot-sort-onnx-tensorrt_amd.microbench").run(full=False)
-            if world == 1 and S == 1 and not a.graph:
+            if not big:
+                # the dense kernels of the path, standalone, against their rooflines (a few seconds; at small sizes the
+                # step above is launch-bound, these show what the kernels do when they have work)
+                out["standalone_rooflines"] = importlib.import_module("bot-sort-onnx-tensorrt_amd.microbench").run(full=False)
+            if a.several_streams and S == 1 and not a.graph:
                 # what ONE GPU serves when it is given several independent streams of this workload (own handle, HIP stream
                 # and host thread each: multistream.run_concurrent); not the headline configuration (1 stream per GPU)
                 out["several_streams_one_gpu"] = several_streams(a, (4, 8))
             checker = IdMatch(pkg, K, M, D, a.motion_gate) if (S == 1 and not a.dense) else None
-            if K <= 1024:
-                out["cpu_baseline"] = cpu_baseline(pkg, K, M, D, ms_seed(pkg, 0), a.cpu_seconds, checker, motion_gate=a.motion_gate)
+            if not big:
+                out["cpu_baseline"] = cpu_baseline(pkg, a.workload, ms_seed(pkg, 0), a.cpu_seconds, checker, motion_gate=a.motion_gate)
             else:
                 # big tables: the structure-faithful oracle takes seconds to minutes per frame -- it is timed alone on what
-                # fits the budget, and the ID match runs on 6 steady-state frames of the vectorised form of the same oracle
-                out["cpu_baseline"] = cpu_baseline(pkg, K, M, D, ms_seed(pkg, 0), a.cpu_seconds, None, motion_gate=a.motion_gate)
+                # fits the budget, and the ID match runs on 4 steady-state frames of the vectorised form of the same oracle
+                out["cpu_baseline"] = cpu_baseline(pkg, a.workload, ms_seed(pkg, 0), a.cpu_seconds, None, motion_gate=a.motion_gate)
                 if checker is not None:
-                    cpu_baseline(pkg, K, M, D, ms_seed(pkg, 0), 120.0, checker, faithful=False, max_frames=6, motion_gate=a.motion_gate)
+                    cpu_baseline(pkg, a.workload, ms_seed(pkg, 0), 120.0, checker, faithful=False, max_frames=4, motion_gate=a.motion_gate)
             if checker is not None:
                 out["id_match"] = checker.result()
         print(json.dumps(out), flush=True)

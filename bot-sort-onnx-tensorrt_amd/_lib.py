@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbotsort_hip.so")
@@ -28,7 +28,7 @@ class TrackerConfig(ctypes.Structure):
         ("match_thresh", c_double), ("second_match_thresh", c_double), ("unconfirmed_match_thresh", c_double),
         ("proximity_thresh", c_double), ("appearance_thresh", c_double), ("dedupe_thresh", c_double),
         ("ema_alpha", c_double), ("record_costs", c_int32), ("appearance_mode", c_int32), ("use_graph", c_int32),
-        ("motion_gate", c_int32),
+        ("motion_gate", c_int32), ("max_edges", c_int32),
     ]
 
 
@@ -68,6 +68,11 @@ SIGNATURES = {
     "bts_tracker_counts": (c_int, [_P, _P, _P]),
     "bts_tracker_export": (c_int, [_P, c_int, _P, _P, _P, _P, _P]),
     "bts_tracker_export_mot": (c_int, [_P, _P, _P]),
+    "bts_tracker_export_mot_async": (c_int, [_P, _P, _P, _P]),
+    "bts_tracker_export_state": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P]),
+    "bts_tracker_read_slot": (c_int, [_P, c_int, c_int, _P, _P]),
+    "bts_pinned_alloc": (c_int, [POINTER(c_void_p), c_size_t]),
+    "bts_pinned_free": (c_int, [_P]),
     "bts_tracker_gmc": (c_int, [_P, _P, _P]),
     "bts_tracker_debug_lap": (c_int, [_P, c_int, _P, _P]),
     "bts_tracker_profile_enable": (c_int, [_P, c_int, c_int]),
@@ -151,7 +156,12 @@ class Context:
 _default_ctx = {}
 
 
-def default_context(device: int = 0) -> Context:
+def default_context(device: int = None) -> Context:
+    """The context of `device` (default: torch's current device -- a rank with LOCAL_RANK != 0 must not land on GPU 0)."""
+    if device is None:
+        import torch
+        device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+    device = int(device)
     if device not in _default_ctx:
         _default_ctx[device] = Context(device)
     return _default_ctx[device]

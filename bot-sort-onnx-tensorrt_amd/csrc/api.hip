@@ -14,7 +14,8 @@ void bts_set_error(const char *fmt, ...) {
 
 int bts_arena::ensure(size_t bytes) {
     if (bytes <= cap) return BTS_OK;
-    if (base) { (void)hipFree(base); base = nullptr; cap = 0; }
+    // growing replaces the block: everything enqueued on the old one (any stream of this device) must have finished
+    if (base) { (void)hipDeviceSynchronize(); (void)hipFree(base); base = nullptr; cap = 0; }
     const size_t want = bts_align(bytes + bytes / 4, 1 << 20);
     if (hipMalloc((void **)&base, want) != hipSuccess) {
         (void)hipGetLastError();
@@ -65,7 +66,7 @@ int bts_context_create(bts_context **out, int device_ordinal) {
         bts_set_error("device %d is %s; this library carries gfx950 code only", device_ordinal, prop.gcnArchName);
         return BTS_ENODEVICE;
     }
-    BTS_HIP(hipSetDevice(device_ordinal));
+    // (the caller's current device is left alone: every entry point selects ctx->device itself, BTS_ON_DEVICE)
     bts_context *ctx = new (std::nothrow) bts_context();
     if (!ctx) { bts_set_error("host allocation failed"); return BTS_ENOMEM; }
     ctx->device = device_ordinal;
@@ -76,8 +77,25 @@ int bts_context_create(bts_context **out, int device_ordinal) {
 
 int bts_context_destroy(bts_context *ctx) {
     if (!ctx) return BTS_OK;
+    BTS_ON_DEVICE(ctx);
     ctx->scratch.release();
     delete ctx;
+    return BTS_OK;
+}
+
+int bts_pinned_alloc(void **out, size_t bytes) {
+    BTS_REQUIRE(out && bytes > 0, "out, bytes");
+    *out = nullptr;
+    if (hipHostMalloc(out, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        bts_set_error("pinned host allocation of %zu bytes failed", bytes);
+        return BTS_ENOMEM;
+    }
+    return BTS_OK;
+}
+
+int bts_pinned_free(void *p) {
+    if (p) BTS_HIP(hipHostFree(p));
     return BTS_OK;
 }
 

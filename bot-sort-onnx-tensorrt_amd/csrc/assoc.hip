@@ -142,6 +142,7 @@ int bts_iou_distance(bts_context *ctx, const double *a_tlbr, const uint8_t *a_f3
                      const double *b_tlbr, const uint8_t *b_f32, int m, double *cost, int ld,
                      bts_stream stream) {
     BTS_REQUIRE(ctx && n >= 0 && m >= 0, "ctx, n, m");
+    BTS_ON_DEVICE(ctx);
     if (n == 0 || m == 0) return BTS_OK;
     BTS_REQUIRE(a_tlbr && b_tlbr && cost && ld >= m, "null pointer / ld < m");
     hipLaunchKernelGGL(k_iou_distance, dim3(bts_cdiv(m, TILE_COLS), bts_cdiv(n, TILE_ROWS)), dim3(TILE_COLS), 0,
@@ -154,6 +155,7 @@ int bts_fuse_cost_stage1(bts_context *ctx, const double *iou_d, int ld_iou, cons
                          const float *face_sim, int ld_sim, int n, int m, double proximity_thresh,
                          double appearance_thresh, double *cost, int ld_cost, bts_stream stream) {
     BTS_REQUIRE(ctx && n >= 0 && m >= 0, "ctx, n, m");
+    BTS_ON_DEVICE(ctx);
     if (n == 0 || m == 0) return BTS_OK;
     BTS_REQUIRE(iou_d && body_sim && cost && ld_iou >= m && ld_sim >= m && ld_cost >= m, "null pointer / ld < m");
     hipLaunchKernelGGL(k_fuse1, dim3(bts_cdiv(m, 256), bts_cdiv(n, TILE_ROWS)), dim3(256), 0, (hipStream_t)stream,
@@ -167,6 +169,7 @@ int bts_fuse_cost_stage3(bts_context *ctx, const double *iou_d, int ld_iou, cons
                          int ld_sim, int n, int m, double proximity_thresh, double appearance_thresh,
                          double *cost, int ld_cost, bts_stream stream) {
     BTS_REQUIRE(ctx && n >= 0 && m >= 0, "ctx, n, m");
+    BTS_ON_DEVICE(ctx);
     if (n == 0 || m == 0) return BTS_OK;
     BTS_REQUIRE(iou_d && body_sim && cost && ld_iou >= m && ld_sim >= m && ld_cost >= m, "null pointer / ld < m");
     hipLaunchKernelGGL(k_fuse3, dim3(bts_cdiv(m, 256), bts_cdiv(n, TILE_ROWS)), dim3(256), 0, (hipStream_t)stream,
@@ -180,6 +183,7 @@ int bts_dedupe_pairs(bts_context *ctx, const double *a_tlbr, const uint8_t *a_f3
                      int n, const double *b_tlbr, const uint8_t *b_f32, const int32_t *age_b, int m,
                      double thresh, uint8_t *drop_a, uint8_t *drop_b, bts_stream stream) {
     BTS_REQUIRE(ctx && n >= 0 && m >= 0, "ctx, n, m");
+    BTS_ON_DEVICE(ctx);
     if (n > 0) { BTS_REQUIRE(drop_a, "drop_a"); BTS_HIP(hipMemsetAsync(drop_a, 0, n, (hipStream_t)stream)); }
     if (m > 0) { BTS_REQUIRE(drop_b, "drop_b"); BTS_HIP(hipMemsetAsync(drop_b, 0, m, (hipStream_t)stream)); }
     if (n == 0 || m == 0) return BTS_OK;

@@ -57,6 +57,20 @@ struct bts_arena {
     void release();
 };
 
+// Every entry point runs on its context's device and leaves the caller's current device as it found it
+// (a rank with LOCAL_RANK != 0 may call in with another device current).
+struct bts_device_guard {
+    int prev = -1, want;
+    explicit bts_device_guard(int dev) : want(dev) {
+        if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; }
+        if (prev != dev) (void)hipSetDevice(dev);
+    }
+    ~bts_device_guard() { if (prev >= 0 && prev != want) (void)hipSetDevice(prev); }
+    bts_device_guard(const bts_device_guard &) = delete;
+    bts_device_guard &operator=(const bts_device_guard &) = delete;
+};
+#define BTS_ON_DEVICE(ctx) bts_device_guard dev_guard_((ctx)->device)
+
 struct bts_context {
     int device = 0;
     int cos_kernel = BTS_COS_MFMA_F32;

@@ -187,6 +187,7 @@ int bts_cos_enqueue(int which, const float *a, const int32_t *a_idx, int lda, co
 extern "C" int bts_cos_similarity(bts_context *ctx, const float *trk_feats, int n, const float *det_feats, int m,
                                   int d, float *sim, int ld, bts_stream stream) {
     BTS_REQUIRE(ctx && n >= 0 && m >= 0 && d >= 0, "ctx, n, m, d");
+    BTS_ON_DEVICE(ctx);
     if (n == 0 || m == 0) return BTS_OK;
     BTS_REQUIRE(trk_feats && det_feats && sim && ld >= m, "null pointer / ld < m");
     return bts_cos_enqueue(ctx->cos_kernel, trk_feats, nullptr, d, det_feats, nullptr, d, d, nullptr, n, m, sim, ld,

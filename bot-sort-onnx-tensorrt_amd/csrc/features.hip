@@ -48,6 +48,7 @@ extern "C" {
 
 int bts_debug_q8_roundtrip(bts_context *ctx, const float *x, float *y, int n, bts_stream stream) {
     BTS_REQUIRE(ctx && n >= 0, "ctx, n");
+    BTS_ON_DEVICE(ctx);
     if (n == 0) return BTS_OK;
     BTS_REQUIRE(x && y, "null pointer");
     hipLaunchKernelGGL(k_q8_roundtrip, dim3(bts_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n);
@@ -75,6 +76,7 @@ __global__ void k_floor_probe(int32_t *buf, int32_t *out, int links) {
 }
 int bts_debug_launch_floor(bts_context *ctx, int32_t *buf, int launches, int blocks, int threads, int links, bts_stream stream) {
     BTS_REQUIRE(ctx && buf && launches >= 0 && blocks > 0 && threads > 0 && links >= 0, "arguments");
+    BTS_ON_DEVICE(ctx);
     for (int k = 0; k < launches; ++k) {
         hipLaunchKernelGGL(k_floor_probe, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, buf, buf + 4096, links);
         BTS_LAUNCH_CHECK();
@@ -86,6 +88,7 @@ int bts_feature_ema(bts_context *ctx, float *curr, float *smooth, uint8_t *has_s
                     const int32_t *trk_idx, const float *det_feats, const int32_t *det_idx, int k, int d,
                     double alpha, bts_stream stream) {
     BTS_REQUIRE(ctx && k >= 0 && d > 0, "ctx, k, d");
+    BTS_ON_DEVICE(ctx);
     if (k == 0) return BTS_OK;
     BTS_REQUIRE(curr && smooth && has_smooth && det_feats, "null pointer");
     // alpha and (1 - alpha) are python floats in the reference, demoted to float32 by the array
@@ -98,6 +101,7 @@ int bts_feature_ema(bts_context *ctx, float *curr, float *smooth, uint8_t *has_s
 
 int bts_feature_renorm(bts_context *ctx, float *feats, const int32_t *idx, int k, int d, bts_stream stream) {
     BTS_REQUIRE(ctx && k >= 0 && d > 0, "ctx, k, d");
+    BTS_ON_DEVICE(ctx);
     if (k == 0) return BTS_OK;
     BTS_REQUIRE(feats, "null pointer");
     hipLaunchKernelGGL(k_feature_renorm, dim3(k), dim3(256), 0, (hipStream_t)stream, feats, idx, k, d);

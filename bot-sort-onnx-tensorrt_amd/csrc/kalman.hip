@@ -190,6 +190,7 @@ extern "C" {
 int bts_kf_initiate(bts_context *ctx, const float *meas_xywh, int n, double *mean, double *cov,
                     bts_stream stream) {
     BTS_REQUIRE(ctx && n >= 0, "ctx, n");
+    BTS_ON_DEVICE(ctx);
     if (n == 0) return BTS_OK;
     BTS_REQUIRE(meas_xywh && mean && cov, "null pointer");
     hipLaunchKernelGGL(k_initiate, dim3(bts_cdiv(n * 8, 256)), dim3(256), 0, (hipStream_t)stream, meas_xywh, n,
@@ -201,6 +202,7 @@ int bts_kf_initiate(bts_context *ctx, const float *meas_xywh, int n, double *mea
 int bts_kf_multi_predict(bts_context *ctx, double *mean, double *cov, const uint8_t *zero_vel,
                          const uint8_t *row_f32, int n, double *tlbr_out, bts_stream stream) {
     BTS_REQUIRE(ctx && n >= 0, "ctx, n");
+    BTS_ON_DEVICE(ctx);
     if (n == 0) return BTS_OK;
     BTS_REQUIRE(mean && cov, "null pointer");
     hipLaunchKernelGGL(k_multi_predict, dim3(bts_cdiv(n * 8, 256)), dim3(256), 0, (hipStream_t)stream,
@@ -212,6 +214,7 @@ int bts_kf_multi_predict(bts_context *ctx, double *mean, double *cov, const uint
 int bts_kf_project(bts_context *ctx, const double *mean, const double *cov, const uint8_t *row_f32,
                    int n, double *pmean, double *pcov, bts_stream stream) {
     BTS_REQUIRE(ctx && n >= 0, "ctx, n");
+    BTS_ON_DEVICE(ctx);
     if (n == 0) return BTS_OK;
     BTS_REQUIRE(mean && cov && pmean && pcov, "null pointer");
     hipLaunchKernelGGL(k_project, dim3(bts_cdiv(n, 64)), dim3(64), 0, (hipStream_t)stream,
@@ -224,6 +227,7 @@ int bts_kf_update(bts_context *ctx, double *mean, double *cov, const uint8_t *ro
                   const int32_t *trk_idx, const float *meas_xywh, const int32_t *meas_idx, int k,
                   bts_stream stream) {
     BTS_REQUIRE(ctx && k >= 0, "ctx, k");
+    BTS_ON_DEVICE(ctx);
     if (k == 0) return BTS_OK;
     BTS_REQUIRE(mean && cov && meas_xywh, "null pointer");
     hipLaunchKernelGGL(k_update, dim3(bts_cdiv(k * 8, 256)), dim3(256), 0, (hipStream_t)stream, aos(mean, cov),
@@ -234,6 +238,7 @@ int bts_kf_update(bts_context *ctx, double *mean, double *cov, const uint8_t *ro
 
 int bts_kf_multi_gmc(bts_context *ctx, double *mean, double *cov, int n, const double *h2x3_host, bts_stream stream) {
     BTS_REQUIRE(ctx && n >= 0 && h2x3_host, "ctx, n, H");
+    BTS_ON_DEVICE(ctx);
     if (n == 0) return BTS_OK;
     BTS_REQUIRE(mean && cov, "null pointer");
     Warp w;
@@ -246,6 +251,7 @@ int bts_kf_multi_gmc(bts_context *ctx, double *mean, double *cov, int n, const d
 int bts_kf_gating(bts_context *ctx, const double *mean, const double *cov, int n, const double *meas,
                   int m, int only_position, int metric, double *out, bts_stream stream) {
     BTS_REQUIRE(ctx && n >= 0 && m >= 0, "ctx, n, m");
+    BTS_ON_DEVICE(ctx);
     BTS_REQUIRE(metric == 0 || metric == 1, "metric must be 0 (maha) or 1 (gaussian)");
     if (n == 0 || m == 0) return BTS_OK;
     BTS_REQUIRE(mean && cov && meas && out, "null pointer");

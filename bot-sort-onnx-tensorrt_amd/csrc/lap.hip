@@ -976,6 +976,7 @@ int bts_lap_enqueue_dense(const bts_lap_work *w, const double *cost, int ld, con
 extern "C" int bts_lapjv(bts_context *ctx, const double *cost, int n, int m, int ld, double cost_limit,
                          int32_t *x, int32_t *y, bts_stream stream) {
     BTS_REQUIRE(ctx && n >= 0 && m >= 0, "ctx, n, m");
+    BTS_ON_DEVICE(ctx);
     BTS_REQUIRE(cost_limit == cost_limit && cost_limit < 1e300, "cost_limit must be finite");
     if (n == 0 && m == 0) return BTS_OK;
     BTS_REQUIRE((n == 0 || x) && (m == 0 || y), "null x / y");
@@ -983,8 +984,8 @@ extern "C" int bts_lapjv(bts_context *ctx, const double *cost, int n, int m, int
     const int64_t e_cap = (int64_t)n * m;
     BTS_REQUIRE(e_cap < (1ll << 31), "n*m must fit int32");
     const size_t bytes = bts_lap_work_bytes(n, m, e_cap);
-    // the arena is reused across calls on one context: order reuse after earlier work on it
-    if (bytes > ctx->scratch.cap) BTS_HIP(hipDeviceSynchronize());
+    // the arena is reused across calls on one context (bts_arena::ensure synchronises the device before it grows);
+    // calls that share a context must be issued on ONE stream (botsort_hip.h, conventions)
     int rc = ctx->scratch.ensure(bytes);
     if (rc) return rc;
     bts_lap_work w;

@@ -136,11 +136,14 @@ extern "C" int bts_associate_parts(bts_context *ctx, const int32_t *base_boxes, 
                                    const int32_t *target_boxes, const int32_t *target_centres, int nt,
                                    uint8_t *target_used, int picks, int32_t *out_idx, bts_stream stream) {
     BTS_REQUIRE(ctx && nb >= 0 && nt >= 0, "ctx, nb, nt");
+    BTS_ON_DEVICE(ctx);
     BTS_REQUIRE(picks >= 1 && picks <= 8, "picks must be in 1..8");
     BTS_REQUIRE(nt <= 65536, "at most 65536 target boxes");
     if (nb == 0) return BTS_OK;
     BTS_REQUIRE(base_boxes && base_centres && out_idx, "null pointer");
     BTS_REQUIRE(nt == 0 || (target_boxes && target_centres && target_used), "null pointer");
+    BTS_REQUIRE((uintptr_t)base_boxes % 16 == 0 && (uintptr_t)target_boxes % 16 == 0, "box arrays must be 16-byte aligned");
+    BTS_REQUIRE((uintptr_t)base_centres % 8 == 0 && (uintptr_t)target_centres % 8 == 0, "centre arrays must be 8-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const size_t per = bts_align((size_t)nb * PARTS_CAND * 8);
     const size_t need = bts_align((size_t)nb * 4) + bts_align((size_t)nb * PARTS_CAND * 4) + 2 * per;

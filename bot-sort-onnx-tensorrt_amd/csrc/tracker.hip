@@ -1409,6 +1409,40 @@ __global__ __launch_bounds__(256) void tk_export_mot(Dev d, double *rows) {
     r[6] = (double)d.score[s]; r[7] = -1.0; r[8] = -1.0; r[9] = -1.0;
 }
 
+// the same rows written where the consumer reads them (pinned, device-mapped host memory) together with their count:
+// no staging copy and no host synchronisation -- the caller waits on an event of its own when it wants the frame
+__global__ __launch_bounds__(256) void tk_export_mot_direct(Dev d, double *rows, int32_t *n_out) {
+    const int n = d.hdr[H_NTRACKED];
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k == 0) { n_out[0] = n; n_out[1] = d.hdr[H_FRAME]; n_out[2] = d.hdr[H_ERR]; }
+    if (k >= n) return;
+    const int s = d.tracked[k];
+    double b[4];
+    slot_tlbr(d, s, b);
+    double *r = rows + (long)k * 10;
+    r[0] = (double)d.hdr[H_FRAME]; r[1] = (double)d.track_id[s];
+    r[2] = b[0]; r[3] = b[1]; r[4] = b[2] - b[0]; r[5] = b[3] - b[1];
+    r[6] = (double)d.score[s]; r[7] = -1.0; r[8] = -1.0; r[9] = -1.0;
+}
+
+// rows [first, first + count) of a list, one table field, gathered into `out` (row-major, `width` elements per row):
+// field 0 covariance (64 doubles), 1 / 2 body curr / smooth, 3 / 4 face curr / smooth (floats)
+__global__ __launch_bounds__(256) void tk_gather_state(Dev d, int which, int field, int first, int count, void *out) {
+    const int n = which == 0 ? d.hdr[H_NTRACKED] : d.hdr[H_NLOST];
+    const int k = first + (int)blockIdx.x;
+    if ((int)blockIdx.x >= count || k >= n) return;
+    const long s = which == 0 ? d.tracked[k] : d.lost[k];
+    if (field == 0) {
+        double *o = (double *)out + (long)blockIdx.x * 64;
+        for (int c = threadIdx.x; c < 64; c += blockDim.x) o[c] = d.cov[s * 64 + c];
+        return;
+    }
+    const int w = field <= 2 ? d.D : d.Df;
+    const float *src = field == 1 ? d.body_curr : field == 2 ? d.body_smooth : field == 3 ? d.face_curr : d.face_smooth;
+    float *o = (float *)out + (long)blockIdx.x * w;
+    for (int c = threadIdx.x; c < w; c += blockDim.x) o[c] = src[s * w + c];
+}
+
 }  // namespace
 
 // =========================================================================================== host side
@@ -1437,6 +1471,8 @@ struct bts_tracker {
     hipGraphExec_t gexec = nullptr;
 };
 
+constexpr size_t SPLITK_MAX_ENTRIES = (size_t)8 << 20;     // T x M entries up to which the split-K accumulators are allocated
+
 static size_t take(size_t &off, size_t bytes) { const size_t o = off; off = bts_align(off + bytes); return o; }
 
 static void tracker_layout(bts_tracker *t, char *base, size_t &off) {
@@ -1459,8 +1495,11 @@ static void tracker_layout(bts_tracker *t, char *base, size_t &off) {
     SLOT(d.born_slot, int32_t, M);
     SLOT(d.pool_tlbr, double, 4 * T); SLOT(d.unc_tlbr, double, 4 * T); SLOT(d.det_tlbr, double, 4 * M);
     SLOT(d.r2_tlbr, double, 4 * T); SLOT(d.unc_f32, uint8_t, T); SLOT(d.ones, uint8_t, M); SLOT(d.det_xywh, float, 4 * M);
-    SLOT(d.sim, float, T * M); SLOT(d.fsim, float, d.Df ? T * M : 1);
-    SLOT(d.cost1, double, T * M);
+    // the dense N x M matrices exist only where they are read: similarities in the DENSE appearance mode (and for
+    // cost recording), cost matrices for cost recording alone
+    const bool dense_sim = !d.filter || t->cfg.record_costs;
+    SLOT(d.sim, float, dense_sim ? T * M : 1); SLOT(d.fsim, float, dense_sim && d.Df ? T * M : 1);
+    SLOT(d.cost1, double, t->cfg.record_costs ? T * M : 1);
     if (t->cfg.record_costs) { SLOT(d.cost2, double, T * M); SLOT(d.cost3, double, T * M); }
     else { d.cost2 = d.cost1; d.cost3 = d.cost1; }
     SLOT(d.x1, int32_t, T); SLOT(d.y1, int32_t, M); SLOT(d.x2, int32_t, T); SLOT(d.y2, int32_t, M);
@@ -1469,7 +1508,9 @@ static void tracker_layout(bts_tracker *t, char *base, size_t &off) {
     if (d.filter) {
         SLOT(d.body_h, uint8_t, T * D); SLOT(d.det_h, uint8_t, M * D); SLOT(d.body_n, float, T); SLOT(d.det_n, float, M);
         SLOT(d.face_h, uint8_t, T * Df); SLOT(d.dface_h, uint8_t, M * Df); SLOT(d.face_n, float, T); SLOT(d.dface_n, float, M);
-        SLOT(d.approx, float, T * M); SLOT(d.approx_f, float, d.Df ? T * M : 1);
+        // split-K accumulators: only tables small enough to ever need split K (< 256 tiles of 128 x 128) carry them
+        if (T * M <= SPLITK_MAX_ENTRIES) { SLOT(d.approx, float, T * M); SLOT(d.approx_f, float, d.Df ? T * M : 1); }
+        else { d.approx = nullptr; d.approx_f = nullptr; }
         d.cb_ld = (int)((M + 63) / 64) * 2;        // 64 columns = one aligned 8-byte word
         SLOT(d.cbits, uint32_t, T * (size_t)d.cb_ld);
     }
@@ -1489,14 +1530,17 @@ int bts_tracker_default_config(bts_tracker_config *cfg) {
     cfg->proximity_thresh = 0.5; cfg->appearance_thresh = 0.25; cfg->dedupe_thresh = 0.15;
     cfg->ema_alpha = 0.9; cfg->record_costs = 0; cfg->appearance_mode = BTS_APPEARANCE_FILTER; cfg->use_graph = 0;
     cfg->motion_gate = 0;      // the reference's loop never gates on motion (A6): off keeps parity
+    cfg->max_edges = 0;        // automatic
     return BTS_OK;
 }
 
 int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_tracker **out) {
     BTS_REQUIRE(ctx && cfg && out, "null argument");
+    BTS_ON_DEVICE(ctx);
     *out = nullptr;
     BTS_REQUIRE(cfg->max_tracks > 0 && cfg->max_dets > 0 && cfg->feat_dim > 0 && cfg->face_dim >= 0, "capacities");
     BTS_REQUIRE((int64_t)cfg->max_tracks * cfg->max_dets < (1ll << 31), "max_tracks * max_dets must fit int32");
+    BTS_REQUIRE(cfg->max_edges >= 0, "max_edges");
     bts_tracker *t = new (std::nothrow) bts_tracker();
     if (!t) { bts_set_error("host allocation failed"); return BTS_ENOMEM; }
     t->ctx = ctx; t->cfg = *cfg;
@@ -1524,7 +1568,12 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
     d.eps_face = feat::q8_cos_error(d.Df ? d.Df : 1);
     size_t off = 0;
     tracker_layout(t, nullptr, off);
-    const int64_t e_cap = (int64_t)d.T * d.Mx;
+    // capacity of the solver's edge lists: the feasible pairs (cost <= match threshold) are O(detections) in any scene
+    // a tracker can follow; overflow raises the error flag (BTS_ECAPACITY from the next export)
+    int64_t e_cap = (int64_t)d.T * d.Mx;
+    const int64_t e_auto = 64ll * ((int64_t)d.T + d.Mx);
+    if (cfg->max_edges > 0) e_cap = e_cap < cfg->max_edges ? e_cap : cfg->max_edges;
+    else if (e_cap > e_auto) e_cap = e_auto;
     const size_t lap_off = off;
     off += bts_lap_work_bytes(d.T, d.Mx, e_cap);
     const size_t lap3_off = off;
@@ -1548,8 +1597,8 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
         return BTS_ENOMEM;
     }
     const size_t tm = (size_t)t->dv.T * t->dv.Mx;      // the pre-filter's accumulators and bitmap are self-cleaning from here on
-    if (t->dv.filter && (hipMemset(t->dv.approx, 0, sizeof(float) * tm) != hipSuccess ||
-                         hipMemset(t->dv.approx_f, 0, sizeof(float) * (t->dv.Df ? tm : 1)) != hipSuccess ||
+    if (t->dv.filter && ((t->dv.approx && (hipMemset(t->dv.approx, 0, sizeof(float) * tm) != hipSuccess ||
+                                           hipMemset(t->dv.approx_f, 0, sizeof(float) * (t->dv.Df ? tm : 1)) != hipSuccess)) ||
                          hipMemset(t->dv.cbits, 0, sizeof(uint32_t) * (size_t)t->dv.T * t->dv.cb_ld) != hipSuccess)) {
         (void)hipGetLastError();
         bts_set_error("hipMemset failed");
@@ -1579,25 +1628,37 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
 
 int bts_tracker_profile_enable(bts_tracker *t, int segment, int capacity) {
     BTS_REQUIRE(t && capacity >= 0, "tracker, capacity");
+    BTS_ON_DEVICE(t->ctx);
     for (int k = 0; t->prof_ev && k < 2 * t->prof_cap + 2; ++k) (void)hipEventDestroy(t->prof_ev[k]);
     delete[] t->prof_ev;
     t->prof_ev = nullptr; t->prof_cap = 0; t->prof_n = 0; t->prof_seg = segment;
     if (capacity == 0) return BTS_OK;
-    t->prof_ev = new (std::nothrow) hipEvent_t[2 * capacity + 2];
-    if (!t->prof_ev) { bts_set_error("host allocation failed"); return BTS_ENOMEM; }
-    for (int k = 0; k < 2 * capacity + 2; ++k) BTS_HIP(hipEventCreate(&t->prof_ev[k]));
+    hipEvent_t *ev = new (std::nothrow) hipEvent_t[2 * capacity + 2]();
+    if (!ev) { bts_set_error("host allocation failed"); return BTS_ENOMEM; }
+    for (int k = 0; k < 2 * capacity + 2; ++k) {
+        const hipError_t e = hipEventCreate(&ev[k]);
+        if (e != hipSuccess) {                  // nothing half-built is kept
+            for (int q = 0; q < k; ++q) (void)hipEventDestroy(ev[q]);
+            delete[] ev;
+            bts_set_error("hipEventCreate failed: %s", hipGetErrorString(e));
+            return BTS_EHIP;
+        }
+    }
+    t->prof_ev = ev;
     t->prof_cap = capacity;
     return BTS_OK;
 }
 
 int bts_tracker_profile_stride(bts_tracker *t, int stride) {
     BTS_REQUIRE(t && stride >= 1, "tracker, stride");
+    BTS_ON_DEVICE(t->ctx);
     t->prof_stride = stride;
     return BTS_OK;
 }
 
 int bts_tracker_profile_read(bts_tracker *t, double *total_ms, int32_t *count) {
     BTS_REQUIRE(t && total_ms && count, "null argument");
+    BTS_ON_DEVICE(t->ctx);
     double tot = 0.0;
     for (int k = 0; k < t->prof_n; ++k) {
         BTS_HIP(hipEventSynchronize(t->prof_ev[2 * k + 1]));
@@ -1612,6 +1673,7 @@ int bts_tracker_profile_read(bts_tracker *t, double *total_ms, int32_t *count) {
 
 int bts_tracker_destroy(bts_tracker *t) {
     if (!t) return BTS_OK;
+    BTS_ON_DEVICE(t->ctx);
     for (int k = 0; t->prof_ev && k < 2 * t->prof_cap + 2; ++k) (void)hipEventDestroy(t->prof_ev[k]);
     delete[] t->prof_ev;
     if (t->gexec) (void)hipGraphExecDestroy(t->gexec);
@@ -1627,6 +1689,7 @@ int bts_tracker_destroy(bts_tracker *t) {
 
 int bts_tracker_reset(bts_tracker *t, bts_stream stream) {
     BTS_REQUIRE(t, "tracker");
+    BTS_ON_DEVICE(t->ctx);
     hipLaunchKernelGGL(tk_reset, dim3(1), dim3(1024), 0, (hipStream_t)stream, t->dv);
     BTS_LAUNCH_CHECK();
     return BTS_OK;
@@ -1670,7 +1733,7 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
     {
         const int kt_all = bts_cdiv(d.D, DBK);
         // at least ~64 workgroups; beyond that only while it shortens a long K loop (every split adds N*M float atomics)
-        while (split * 2 <= kt_all && split < 16 && (ftiles * split < 64 || (ftiles * split < 256 && kt_all / split > 8))) split *= 2;
+        while (d.approx && split * 2 <= kt_all && split < 16 && (ftiles * split < 64 || (ftiles * split < 256 && kt_all / split > 8))) split *= 2;
     }
     const int accum = split > 1;
     // ---- first association: pool x high-score detections
@@ -1808,11 +1871,13 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
 int bts_tracker_step(bts_tracker *t, const int32_t *boxes, const float *scores, float *feats,
                      float *face_feats, int m, bts_stream stream) {
     BTS_REQUIRE(t && m >= 0, "tracker, m");
+    BTS_ON_DEVICE(t->ctx);
     if (m > t->cfg.max_dets) {
         bts_set_error("%d detections exceed max_dets=%d", m, t->cfg.max_dets);
         return BTS_ECAPACITY;
     }
     BTS_REQUIRE(m == 0 || (boxes && scores && feats), "null detection arrays");
+    BTS_REQUIRE((uintptr_t)boxes % 16 == 0 && (uintptr_t)feats % 16 == 0, "boxes / feats must be 16-byte aligned");
     BTS_REQUIRE(t->cfg.face_dim == 0 || m == 0 || face_feats, "face_feats required when face_dim > 0");
     hipStream_t s = (hipStream_t)stream;
     int rc;
@@ -1829,8 +1894,8 @@ int bts_tracker_step(bts_tracker *t, const int32_t *boxes, const float *scores, 
             BTS_HIP(hipStreamBeginCapture(t->cs[0], hipStreamCaptureModeRelaxed));
             rc = enqueue_step(t, t->cs[0], nullptr, nullptr, t->cfg.max_dets, true);
             const hipError_t e = hipStreamEndCapture(t->cs[0], &g);
-            if (rc) return rc;
-            if (e != hipSuccess) { bts_set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e)); return BTS_EHIP; }
+            if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+            if (e != hipSuccess) { if (g) (void)hipGraphDestroy(g); bts_set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e)); return BTS_EHIP; }
             BTS_HIP(hipGraphInstantiate(&t->gexec, g, nullptr, nullptr, 0));
             BTS_HIP(hipGraphDestroy(g));
         }
@@ -1847,8 +1912,28 @@ int bts_tracker_step(bts_tracker *t, const int32_t *boxes, const float *scores, 
     return BTS_OK;
 }
 
+// The device raises H_ERR instead of stopping (a step never synchronises): every call that already has the header on
+// the host turns a raised flag into a status, so a drop-in caller cannot miss a truncated frame.
+static int device_error_status(const bts_tracker *t) {
+    const int e = t->host_hdr[H_ERR];
+    if (!e) return BTS_OK;
+    if (e & ERR_TRACK_CAPACITY) {
+        bts_set_error("track table full (max_tracks = %d): births were dropped at or before frame %d; results diverge from "
+                      "the reference from there on", t->cfg.max_tracks, t->host_hdr[H_FRAME]);
+        return BTS_ECAPACITY;
+    }
+    if (e & ERR_LAP_EDGES) {
+        bts_set_error("assignment solver: edge list overflow (max_edges) or helper time-out at or before frame %d; the "
+                      "assignment of that frame is incomplete", t->host_hdr[H_FRAME]);
+        return BTS_ECAPACITY;
+    }
+    bts_set_error("device-side wait timed out (flags 0x%x) at or before frame %d", e, t->host_hdr[H_FRAME]);
+    return BTS_EHIP;
+}
+
 int bts_tracker_counts(bts_tracker *t, int32_t *counts12_host, bts_stream stream) {
     BTS_REQUIRE(t && counts12_host, "null argument");
+    BTS_ON_DEVICE(t->ctx);
     BTS_HIP(hipMemcpyAsync(t->host_hdr, t->dv.hdr, H_SIZE * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
     BTS_HIP(hipStreamSynchronize((hipStream_t)stream));
     const int32_t *h = t->host_hdr;
@@ -1860,12 +1945,14 @@ int bts_tracker_counts(bts_tracker *t, int32_t *counts12_host, bts_stream stream
 int bts_tracker_export(bts_tracker *t, int which, int32_t *ints_host, double *mean_host,
                        double *tlbr_host, float *score_host, bts_stream stream) {
     BTS_REQUIRE(t && (which == 0 || which == 1), "tracker, which");
+    BTS_ON_DEVICE(t->ctx);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(tk_export, dim3(bts_cdiv(t->dv.T, 256)), dim3(256), 0, s, t->dv, which, t->x_ints, t->x_mean,
                        t->x_tlbr, t->x_score);
     BTS_LAUNCH_CHECK();
     BTS_HIP(hipMemcpyAsync(t->host_hdr, t->dv.hdr, H_SIZE * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     BTS_HIP(hipStreamSynchronize(s));
+    if (int rc = device_error_status(t)) return rc;
     const int n = which == 0 ? t->host_hdr[H_NTRACKED] : t->host_hdr[H_NLOST];
     if (n > 0) {
         if (ints_host) BTS_HIP(hipMemcpyAsync(ints_host, t->x_ints, sizeof(int32_t) * 8 * n, hipMemcpyDeviceToHost, s));
@@ -1879,11 +1966,13 @@ int bts_tracker_export(bts_tracker *t, int which, int32_t *ints_host, double *me
 
 int bts_tracker_export_mot(bts_tracker *t, double *rows_host, bts_stream stream) {
     BTS_REQUIRE(t && rows_host, "tracker, rows");
+    BTS_ON_DEVICE(t->ctx);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(tk_export_mot, dim3(bts_cdiv(t->dv.T, 256)), dim3(256), 0, s, t->dv, t->x_mot);
     BTS_LAUNCH_CHECK();
     BTS_HIP(hipMemcpyAsync(t->host_hdr, t->dv.hdr, H_SIZE * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     BTS_HIP(hipStreamSynchronize(s));
+    if (int rc = device_error_status(t)) return rc;
     const int n = t->host_hdr[H_NTRACKED];
     if (n > 0) {
         BTS_HIP(hipMemcpyAsync(rows_host, t->x_mot, sizeof(double) * 10 * n, hipMemcpyDeviceToHost, s));
@@ -1892,8 +1981,61 @@ int bts_tracker_export_mot(bts_tracker *t, double *rows_host, bts_stream stream)
     return n;
 }
 
+int bts_tracker_export_mot_async(bts_tracker *t, double *rows_pinned, int32_t *n_pinned, bts_stream stream) {
+    BTS_REQUIRE(t && rows_pinned && n_pinned, "tracker, rows, n");
+    BTS_ON_DEVICE(t->ctx);
+    hipLaunchKernelGGL(tk_export_mot_direct, dim3(bts_cdiv(t->dv.T, 256)), dim3(256), 0, (hipStream_t)stream, t->dv, rows_pinned, n_pinned);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+
+int bts_tracker_export_state(bts_tracker *t, int which, double *cov_host, float *body_curr_host, float *body_smooth_host,
+                             float *face_curr_host, float *face_smooth_host, bts_stream stream) {
+    BTS_REQUIRE(t && (which == 0 || which == 1), "tracker, which");
+    BTS_ON_DEVICE(t->ctx);
+    hipStream_t s = (hipStream_t)stream;
+    BTS_HIP(hipMemcpyAsync(t->host_hdr, t->dv.hdr, H_SIZE * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    BTS_HIP(hipStreamSynchronize(s));
+    if (int rc = device_error_status(t)) return rc;
+    const int n = which == 0 ? t->host_hdr[H_NTRACKED] : t->host_hdr[H_NLOST];
+    void *dst[5] = {cov_host, body_curr_host, body_smooth_host, face_curr_host, face_smooth_host};
+    const size_t row_bytes[5] = {64 * sizeof(double), sizeof(float) * (size_t)t->dv.D, sizeof(float) * (size_t)t->dv.D,
+                                 sizeof(float) * (size_t)t->dv.Df, sizeof(float) * (size_t)t->dv.Df};
+    // gathered through the context's scratch arena in batches of at most 64 MiB (one field at a time)
+    for (int f = 0; f < 5 && n > 0; ++f) {
+        if (!dst[f] || row_bytes[f] == 0) continue;
+        int batch = (int)(((size_t)64 << 20) / row_bytes[f]);
+        batch = batch < 1 ? 1 : batch > n ? n : batch;
+        if (int rc = t->ctx->scratch.ensure(row_bytes[f] * (size_t)batch)) return rc;
+        for (int first = 0; first < n; first += batch) {
+            const int cnt = n - first < batch ? n - first : batch;
+            hipLaunchKernelGGL(tk_gather_state, dim3(cnt), dim3(256), 0, s, t->dv, which, f, first, cnt, (void *)t->ctx->scratch.base);
+            BTS_LAUNCH_CHECK();
+            BTS_HIP(hipMemcpyAsync((char *)dst[f] + row_bytes[f] * (size_t)first, t->ctx->scratch.base, row_bytes[f] * (size_t)cnt,
+                                   hipMemcpyDeviceToHost, s));
+            BTS_HIP(hipStreamSynchronize(s));
+        }
+    }
+    return n;
+}
+
+int bts_tracker_read_slot(bts_tracker *t, int slot, int field, void *out_host, bts_stream stream) {
+    BTS_REQUIRE(t && out_host && slot >= 0 && slot < t->dv.T && field >= 0 && field <= 5, "tracker, slot, field, out");
+    BTS_ON_DEVICE(t->ctx);
+    const Dev &d = t->dv;
+    BTS_REQUIRE(field < 4 || d.Df > 0, "the tracker carries no face features");
+    const void *src = field == 0 ? (const void *)(d.mean + (size_t)slot * 8) : field == 1 ? (const void *)(d.cov + (size_t)slot * 64)
+                    : field == 2 ? (const void *)(d.body_curr + (size_t)slot * d.D) : field == 3 ? (const void *)(d.body_smooth + (size_t)slot * d.D)
+                    : field == 4 ? (const void *)(d.face_curr + (size_t)slot * d.Df) : (const void *)(d.face_smooth + (size_t)slot * d.Df);
+    const size_t bytes = field == 0 ? 8 * sizeof(double) : field == 1 ? 64 * sizeof(double) : sizeof(float) * (size_t)(field <= 3 ? d.D : d.Df);
+    BTS_HIP(hipMemcpyAsync(out_host, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    BTS_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return BTS_OK;
+}
+
 int bts_tracker_gmc(bts_tracker *t, const double *h2x3_host, bts_stream stream) {
     BTS_REQUIRE(t && h2x3_host, "tracker, H");
+    BTS_ON_DEVICE(t->ctx);
     Warp6 w;
     for (int k = 0; k < 6; ++k) w.h[k] = h2x3_host[k];
     hipLaunchKernelGGL(tk_gmc, dim3(bts_cdiv(t->dv.T, 64)), dim3(64), 0, (hipStream_t)stream, t->dv, w);
@@ -1909,6 +2051,7 @@ int bts_debug_jobtrace(int32_t *out64_host) {
 
 int bts_tracker_debug_lap(bts_tracker *t, int stage, int32_t *hdr16_host, bts_stream stream) {
     BTS_REQUIRE(t && stage >= 1 && stage <= 3 && hdr16_host, "tracker, stage, out");
+    BTS_ON_DEVICE(t->ctx);
     BTS_HIP(hipMemcpyAsync(hdr16_host, t->dv.lap_hdr + BTS_LAP_HDR_INTS * (stage - 1), 64 * sizeof(int32_t), hipMemcpyDeviceToHost,
                            (hipStream_t)stream));
     BTS_HIP(hipStreamSynchronize((hipStream_t)stream));
@@ -1918,9 +2061,11 @@ int bts_tracker_debug_lap(bts_tracker *t, int stage, int32_t *hdr16_host, bts_st
 int bts_tracker_stage_result(bts_tracker *t, int stage, int32_t *x_host, int32_t *y_host,
                              double *cost_host, int32_t *n_rows, int32_t *n_cols, bts_stream stream) {
     BTS_REQUIRE(t && stage >= 1 && stage <= 3, "tracker, stage");
+    BTS_ON_DEVICE(t->ctx);
     hipStream_t s = (hipStream_t)stream;
     BTS_HIP(hipMemcpyAsync(t->host_hdr, t->dv.hdr, H_SIZE * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     BTS_HIP(hipStreamSynchronize(s));
+    if (int rc = device_error_status(t)) return rc;
     const int32_t *h = t->host_hdr;
     const int rows = stage == 1 ? h[H_NPOOL] : stage == 2 ? h[H_NR2] : h[H_NUNC];
     const int cols = stage == 1 ? h[H_NHI] : stage == 2 ? h[H_NLO] : h[H_NLEFT];

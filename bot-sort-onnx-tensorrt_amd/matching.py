@@ -137,6 +137,28 @@ def linear_assignment(cost_matrix: np.ndarray, thresh: float):
     return matches, np.where(x < 0)[0], np.where(y < 0)[0]
 
 
+def feature_ema(smooth, feature: np.ndarray, alpha: float = 0.9):
+    """One STrack.update_body_features / update_face_features step (D:492-514) through the C-ABI kernels ->
+    (smooth', feature).  First call (smooth is None): the reference aliases smooth = feature and normalises IN PLACE
+    (quirk Q8) -- `feature` (a writable float32 array) is overwritten with its renormalised self and returned as both.
+    Later calls: smooth' = normalise(alpha * smooth + (1 - alpha) * feature), a new array; feature untouched."""
+    import torch
+    lib = _lib.load(require_gpu=True)
+    ctx = _lib.default_context().handle
+    d = int(feature.shape[-1])
+    f = _dev(feature.reshape(1, d), np.float32)
+    if smooth is None:
+        _lib.check(lib.bts_feature_renorm(ctx, _lib.ptr(f), None, 1, d, _lib.current_stream()))
+        feature[...] = f.cpu().numpy().reshape(feature.shape)
+        return feature, feature
+    s = _dev(np.asarray(smooth, dtype=np.float32).reshape(1, d), np.float32)
+    curr = torch.empty_like(f)
+    has = torch.ones((1,), dtype=torch.uint8, device="cuda")
+    _lib.check(lib.bts_feature_ema(ctx, _lib.ptr(curr), _lib.ptr(s), _lib.ptr(has), None, _lib.ptr(f), None, 1, d,
+                                   float(alpha), _lib.current_stream()))
+    return s.cpu().numpy().reshape(feature.shape), feature
+
+
 def dedupe_flags(a_items, b_items, age_a: Sequence[int], age_b: Sequence[int], thresh: float = 0.15):
     """The pair test of remove_duplicate_stracks (D:1665-1680) -> (drop_a[n], drop_b[m]) bool."""
     import torch

@@ -15,6 +15,12 @@ term of the fused cost is actually exercised at every D):
     ~U(0.12,0.38) (second association), the rest ~U(0.9,1); optional churn replaces a fraction
     of the detections with brand-new identities (births / unconfirmed-track stage);
   * detection feature = normalise(prototype + (0.3/sqrt(D)) * N(0,1)), float32.
+
+Adversarial variants (bench.py --workload crowd | hard-reid, tests): `side_scale` shrinks the canvas (40 instead of
+125 px per sqrt(identity): boxes overlap 5-10 deep, the IoU graph gets large connected components); `clusters` draws
+the prototypes around that many shared centres with per-identity spreads so that impostor cosines of 0.5-0.8 are
+commonplace (what post-ReLU ReID embeddings look like), instead of the near-orthogonal i.i.d. prototypes.  Both draw
+their extra randomness from a generator of their own: the streams of the plain configurations are unchanged.
 """
 from __future__ import annotations
 
@@ -46,7 +52,7 @@ class Frame:
 class SyntheticStream:
     def __init__(self, n_ids: int, n_dets: int, feat_dim: int, seed: int = 1234,
                  churn: float = 0.0, low_frac: float = 0.125, face_dim: int = 0,
-                 feat_noise: float = 0.3):
+                 feat_noise: float = 0.3, side_scale: float = 125.0, clusters: int = 0):
         self.rng = np.random.default_rng(seed)
         self.K0 = n_ids
         self.M = n_dets
@@ -55,7 +61,10 @@ class SyntheticStream:
         self.churn = churn
         self.low_frac = low_frac
         self.feat_noise = feat_noise
-        self.side = int(math.ceil(125.0 * math.sqrt(n_ids)))
+        self.side = int(math.ceil(side_scale * math.sqrt(n_ids)))
+        self.clusters = int(clusters)
+        self._xr = np.random.default_rng([int(seed), 0x5eed]) if clusters else None      # (never touches self.rng)
+        self._centres = None
         self.cx = np.empty(0)
         self.cy = np.empty(0)
         self.w = np.empty(0)
@@ -67,14 +76,25 @@ class SyntheticStream:
 
     def _spawn(self, k: int):
         r = self.rng
-        margin = 100.0
+        margin = min(100.0, self.side / 8.0)
         self.cx = np.concatenate([self.cx, r.uniform(margin, self.side - margin, k)])
         self.cy = np.concatenate([self.cy, r.uniform(margin, self.side - margin, k)])
         self.w = np.concatenate([self.w, r.uniform(30.0, 80.0, k)])
         self.h = np.concatenate([self.h, r.uniform(60.0, 160.0, k)])
         p = r.standard_normal((k, self.D)).astype(np.float32)
         p /= np.linalg.norm(p, axis=1, keepdims=True)
-        self.proto = np.concatenate([self.proto, p])
+        if self.clusters:
+            # prototype = normalise(centre + s * unit noise), s ~ U(0.5, 1): cos(i, j) = 1 / sqrt((1 + s_i^2)(1 + s_j^2))
+            # in [0.5, 0.8] for two identities of one cluster
+            x = self._xr
+            if self._centres is None:
+                c = x.standard_normal((self.clusters, self.D)).astype(np.float32)
+                self._centres = c / np.linalg.norm(c, axis=1, keepdims=True)
+            which = x.integers(0, self.clusters, k)
+            spread = x.uniform(0.5, 1.0, (k, 1)).astype(np.float32)
+            p = self._centres[which] + spread * p
+            p /= np.linalg.norm(p, axis=1, keepdims=True)
+        self.proto = np.concatenate([self.proto, p.astype(np.float32)])
         if self.Df:
             q = r.standard_normal((k, self.Df)).astype(np.float32)
             q /= np.linalg.norm(q, axis=1, keepdims=True)
@@ -127,3 +147,40 @@ class SyntheticStream:
 def make_stream(config: str, seed: int = 1234, **kw) -> SyntheticStream:
     k, m, d = CONFIGS[config]
     return SyntheticStream(k, m, d, seed=seed, **kw)
+
+
+# bench / test workloads: the BASELINE configurations plus the adversarial scenes.  "name@config" runs an adversarial
+# scene at another configuration's size (e.g. crowd@target).
+ADVERSARIAL = {
+    "crowd": dict(side_scale=40.0),          # boxes overlap 5-10 deep
+    "hard-reid": dict(clusters=32),          # impostor cosines 0.5-0.8
+    "crowd-hard-reid": dict(side_scale=40.0, clusters=32),
+}
+
+
+def _split(name: str):
+    base, _, at = name.partition("@")
+    if base in ADVERSARIAL:
+        return base, CONFIGS[at or "c3"]
+    return None, CONFIGS[base]
+
+
+def workload_dims(name: str):
+    return _split(name)[1]
+
+
+def workload_text(name: str) -> str:
+    adv, (k, m, d) = _split(name)
+    txt = "%d tracks x %d detections/frame x %d-d ReID" % (k, m, d)
+    if adv == "crowd" or adv == "crowd-hard-reid":
+        txt += ", dense crowd (canvas 40 px per sqrt(identity): boxes overlap 5-10 deep)"
+    if adv == "hard-reid" or adv == "crowd-hard-reid":
+        txt += ", clustered embeddings (32 centres, impostor cosines 0.5-0.8)"
+    return txt
+
+
+def make_workload(name: str, seed: int = 1234, **kw) -> SyntheticStream:
+    adv, (k, m, d) = _split(name)
+    opts = dict(ADVERSARIAL[adv]) if adv else {}
+    opts.update(kw)
+    return SyntheticStream(k, m, d, seed=seed, **opts)

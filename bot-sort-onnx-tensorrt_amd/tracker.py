@@ -121,29 +121,138 @@ class BaseTrack:                       # D:389-437 (the ID counter lives in the 
         self.state = TrackState.Removed
 
 
+def _lazy(field, name):
+    """A per-track array that lives in the device table of the owning BoTSORT (covariance, ReID feature rows): a mirror
+    fetches it on first access after a frame (bts_tracker_read_slot) and caches it until the next frame; standalone
+    STracks (detection records, tracks driven by hand through activate / update) simply hold their own value."""
+    attr = "_" + name
+
+    def get(self):
+        own = self._owner
+        if own is not None and self.slot >= 0 and self._fresh.get(name) != own.frame_id and self._live:
+            setattr(self, attr, own.device_tracker.read_slot(self.slot, field))
+            self._fresh[name] = own.frame_id
+        return getattr(self, attr)
+
+    def set(self, value):
+        setattr(self, attr, value)
+        if self._owner is not None:
+            self._fresh[name] = self._owner.frame_id
+
+    return property(get, set)
+
+
 class STrack(BaseTrack):
-    """Host mirror of one track (or one detection record).  Kalman state and ReID features live
-    in the device track table; `mean` is refreshed from it after every frame."""
+    """One track or one detection record, D:439-688.
+
+    Two lives.  (1) Mirror of a track owned by a `BoTSORT`: Kalman state and ReID features live in the device track
+    table; the integer fields, `mean` and `tlbr` are refreshed after every frame, `covariance` and the feature rows are
+    read from the table on access.  (2) Standalone object driven by hand exactly like the reference's
+    (`STrack(tlwh, score, ...)`, `activate`, `predict`, `update`, `re_activate`, `update_*_features`): the arithmetic
+    runs through the standalone C-ABI kernels (`KalmanFilter`, `bts_feature_ema`) on the arrays the object holds."""
     shared_kalman = None
 
     def __init__(self, tlwh, score, feature_history=300, body=None, body_feature=None, face_feature=None):
+        self._owner, self._live, self._fresh = None, True, {}
         self._tlwh = np.asarray(tlwh, dtype=np.float32)            # D:465
         self.kalman_filter = None
-        self.mean, self.covariance = None, None
+        self.mean, self._covariance = None, None
         self.is_activated = False
         self.score = score
         self.tracklet_len = 0
         self.alpha = 0.9                                           # D:473
         self.body = body
-        self.body_curr_feature = body_feature
-        self.body_smooth_feature = None
-        self.face_curr_feature = face_feature
-        self.face_smooth_feature = None
+        self._body_curr_feature = None                             # D:475-490
+        self._body_smooth_feature = None
+        self._face_curr_feature = None
+        self._face_smooth_feature = None
         self.body_features = deque([], maxlen=feature_history)
         self.face_features = deque([], maxlen=feature_history)
         self.det_index = -1
         self.slot = -1
         self._dev_tlbr = None       # STrack.tlbr as evaluated on the device (float32 flow for fresh tracks)
+        if body_feature is not None:
+            self.update_body_features(body_feature)                # D:477-478
+        if face_feature is not None:
+            self.update_face_features(face_feature)                # D:484-485
+
+    covariance = _lazy(1, "covariance")
+    body_curr_feature = _lazy(2, "body_curr_feature")
+    body_smooth_feature = _lazy(3, "body_smooth_feature")
+    face_curr_feature = _lazy(4, "face_curr_feature")
+    face_smooth_feature = _lazy(5, "face_smooth_feature")
+
+    # ---- ReID feature bookkeeping, D:492-514 (quirk Q8: the first call aliases smooth = feature and normalises IN PLACE)
+    def _update_features(self, which, feature):
+        feature = np.asarray(feature)
+        if not (feature.dtype == np.float32 and feature.flags.c_contiguous and feature.flags.writeable):
+            feature = np.array(feature, dtype=np.float32)          # (a private copy: nothing of the caller's to alias)
+        smooth = getattr(self, which + "_smooth_feature")
+        new_smooth, feature = matching.feature_ema(smooth, feature, self.alpha)
+        setattr(self, which + "_curr_feature", feature)
+        setattr(self, which + "_smooth_feature", new_smooth)
+        getattr(self, which + "_features").append(feature)
+
+    def update_body_features(self, feature):
+        self._update_features("body", feature)
+
+    def update_face_features(self, feature):
+        self._update_features("face", feature)
+
+    # ---- Kalman life cycle, D:516-610
+    def predict(self):
+        """D:516-522 (dead code in the reference's loop, kept for API parity)."""
+        mean_state = self.mean.copy()
+        if self.state != TrackState.Tracked:
+            mean_state[6] = 0
+            mean_state[7] = 0
+        self.mean, self.covariance = self.kalman_filter.predict(mean_state, self.covariance)
+
+    def activate(self, kalman_filter, frame_id):
+        """D:556-568: start a new tracklet."""
+        self.kalman_filter = kalman_filter
+        self.track_id = self.next_id()
+        self.mean, self.covariance = self.kalman_filter.initiate(self.tlwh_to_xywh(self._tlwh))
+        self._dev_tlbr = None
+        self.tracklet_len = 0
+        self.state = TrackState.Tracked
+        if frame_id == 1:
+            self.is_activated = True
+        self.frame_id = frame_id
+        self.start_frame = frame_id
+
+    def re_activate(self, new_track, frame_id, new_id=False):
+        """D:570-584."""
+        self.mean, self.covariance = self.kalman_filter.update(self.mean, self.covariance, self.tlwh_to_xywh(new_track.tlwh))
+        self._dev_tlbr = None
+        if new_track.body_curr_feature is not None:
+            self.update_body_features(new_track.body_curr_feature)
+        if new_track.face_curr_feature is not None:
+            self.update_face_features(new_track.face_curr_feature)
+        self.tracklet_len = 0
+        self.state = TrackState.Tracked
+        self.is_activated = True
+        self.frame_id = frame_id
+        if new_id:
+            self.track_id = self.next_id()
+        self.score = new_track.score
+        self.body = new_track.body
+
+    def update(self, new_track, frame_id):
+        """D:586-610: update a matched track."""
+        self.frame_id = frame_id
+        self.tracklet_len += 1
+        new_tlwh = new_track.tlwh
+        self.mean, self.covariance = self.kalman_filter.update(self.mean, self.covariance, self.tlwh_to_xywh(new_tlwh))
+        self._dev_tlbr = None
+        if new_track.body_curr_feature is not None:
+            self.update_body_features(new_track.body_curr_feature)
+        if new_track.face_curr_feature is not None:
+            self.update_face_features(new_track.face_curr_feature)
+        self.state = TrackState.Tracked
+        self.is_activated = True
+        self.score = new_track.score
+        self.body = new_track.body
 
     # ---- box formats, D:624-685
     @property
@@ -241,7 +350,7 @@ class DeviceTracker:
     """Thin owner of a `bts_tracker` handle."""
 
     def __init__(self, max_tracks: int, max_dets: int, feat_dim: int, face_dim: int = 0, frame_rate: int = 30,
-                 record_costs: bool = False, device: int = 0, context: Optional[_lib.Context] = None, **thresholds):
+                 record_costs: bool = False, device: Optional[int] = None, context: Optional[_lib.Context] = None, **thresholds):
         lib = _lib.load(require_gpu=True)
         self.ctx = context or _lib.default_context(device)
         cfg = _lib.TrackerConfig()
@@ -279,6 +388,40 @@ class DeviceTracker:
         buf = np.empty((self.cfg.max_tracks, 10), dtype=np.float64)
         n = _lib.check(self._lib.bts_tracker_export_mot(self.handle, buf.ctypes.data, _lib.current_stream()))
         return buf[:n].copy()
+
+    def export_mot_async(self, buf: "PinnedMot"):
+        """Enqueue the MOT rows of the tracked list into `buf` (pinned host memory) behind the steps already on the
+        current stream -- no host synchronisation; read `buf.rows()` after an event / sync of your own."""
+        _lib.check(self._lib.bts_tracker_export_mot_async(self.handle, buf.rows_ptr, buf.n_ptr, _lib.current_stream()))
+
+    def export_state(self, which: int, cov=True, body=True, face=False) -> dict:
+        """covariance [n,8,8] / body_curr, body_smooth [n,D] / face_* [n,Df] of the tracked (0) or lost (1) list, list order."""
+        t, D, Df = self.cfg.max_tracks, self.cfg.feat_dim, self.cfg.face_dim
+        n = self.counts()["n_tracked" if which == 0 else "n_lost"]
+        bufs = [np.empty((n, 64), np.float64) if cov else None,
+                np.empty((n, D), np.float32) if body else None, np.empty((n, D), np.float32) if body else None,
+                np.empty((n, Df), np.float32) if face and Df else None, np.empty((n, Df), np.float32) if face and Df else None]
+        got = _lib.check(self._lib.bts_tracker_export_state(self.handle, which, *[b.ctypes.data if b is not None and b.size else None for b in bufs],
+                                                            _lib.current_stream()))
+        assert got == n
+        keys = ("covariance", "body_curr_feature", "body_smooth_feature", "face_curr_feature", "face_smooth_feature")
+        out = {k: b for k, b in zip(keys, bufs) if b is not None}
+        if "covariance" in out:
+            out["covariance"] = out["covariance"].reshape(n, 8, 8)
+        return out
+
+    def read_slot(self, slot: int, field: int) -> np.ndarray:
+        """One table row: field 0 mean, 1 covariance [8,8], 2/3 body curr/smooth, 4/5 face curr/smooth."""
+        D, Df = self.cfg.feat_dim, self.cfg.face_dim
+        out = np.empty(8 if field == 0 else 64 if field == 1 else D if field <= 3 else Df, np.float64 if field <= 1 else np.float32)
+        _lib.check(self._lib.bts_tracker_read_slot(self.handle, int(slot), int(field), out.ctypes.data, _lib.current_stream()))
+        return out.reshape(8, 8) if field == 1 else out
+
+    def debug_lap(self, stage: int) -> np.ndarray:
+        """Counters of the assignment solver for stage 1..3 of the last step (bts_tracker_debug_lap)."""
+        h = np.zeros(64, dtype=np.int32)
+        _lib.check(self._lib.bts_tracker_debug_lap(self.handle, int(stage), h.ctypes.data, _lib.current_stream()))
+        return h
 
     def gmc(self, H):
         """STrack.multi_gmc (D:538-554) on every live track; H is a 2x3 affine warp."""
@@ -350,6 +493,48 @@ class DeviceTracker:
             pass
 
 
+class PinnedMot:
+    """A pinned (device-mapped) host buffer for `DeviceTracker.export_mot_async`: max_tracks x 10 float64 rows + counters."""
+
+    def __init__(self, max_tracks: int):
+        lib = _lib.load(require_gpu=True)
+        self._lib = lib
+        self.max_tracks = int(max_tracks)
+        pr, pn = ctypes.c_void_p(), ctypes.c_void_p()
+        _lib.check(lib.bts_pinned_alloc(ctypes.byref(pr), self.max_tracks * 10 * 8))
+        _lib.check(lib.bts_pinned_alloc(ctypes.byref(pn), 16))
+        self.rows_ptr, self.n_ptr = pr, pn
+        self._rows = np.ctypeslib.as_array(ctypes.cast(pr, ctypes.POINTER(ctypes.c_double)), shape=(self.max_tracks, 10))
+        self._n = np.ctypeslib.as_array(ctypes.cast(pn, ctypes.POINTER(ctypes.c_int32)), shape=(4,))
+        self._n[:] = 0
+
+    def count(self) -> int:
+        return int(self._n[0])
+
+    def frame_id(self) -> int:
+        return int(self._n[1])
+
+    def errors(self) -> int:
+        return int(self._n[2])
+
+    def rows(self) -> np.ndarray:
+        """The frame's rows (a view into the pinned buffer: copy before the buffer is reused)."""
+        return self._rows[: self.count()]
+
+    def close(self):
+        if getattr(self, "rows_ptr", None):
+            self._lib.bts_pinned_free(self.rows_ptr)
+            self._lib.bts_pinned_free(self.n_ptr)
+            self.rows_ptr = self.n_ptr = None
+            self._rows = self._n = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class BoTSORT:
     """D:1252-1639.  `update(image)` keeps the reference signature; `update_arrays` is the
     tracker-only entry point fed with pre-extracted detections (BASELINE.json north_star)."""
@@ -357,7 +542,7 @@ class BoTSORT:
     def __init__(self, object_detection_model=None, body_feature_extractor_model=None,
                  face_feature_extractor_model=None, frame_rate: int = 30, *, max_tracks: int = 4096,
                  max_dets: int = 1024, feat_dim: Optional[int] = None, face_dim: Optional[int] = None,
-                 record_costs: bool = False, device: int = 0, **tracker_options):
+                 record_costs: bool = False, device: Optional[int] = None, **tracker_options):
         """`tracker_options`: further `bts_tracker_config` fields by name (`motion_gate=1`, `appearance_mode=1`, ...)."""
         self.tracked_stracks: List[STrack] = []
         self.lost_stracks: List[STrack] = []
@@ -423,6 +608,9 @@ class BoTSORT:
         self.device_tracker.gmc(H)
 
     def _export(self, bodies=None) -> List[STrack]:
+        """Mirror the device lists.  Raises BtsError when the device flagged a truncated frame (track table full, solver
+        edge list overflow): bts_tracker_export turns the sticky flag into a status.  With export=False nothing is read
+        back -- poll `device_tracker.counts()['errors']`."""
         dt = self.device_tracker
         out = []
         for which in (0, 1):
@@ -434,6 +622,8 @@ class BoTSORT:
                 if st is None:
                     st = STrack(np.zeros(4, dtype=np.float32), 0.0, self.feature_history)
                     st.track_id = tid
+                    st._owner = self
+                    st.kalman_filter = self.kalman_filter
                     self._mirror[tid] = st
                 st.mean = tab["mean"][k]
                 st._dev_tlbr = tab["tlbr"][k]
@@ -454,6 +644,7 @@ class BoTSORT:
         live = {t.track_id for t in self.tracked_stracks} | {t.track_id for t in self.lost_stracks}
         for tid in [t for t in self._mirror if t not in live]:
             st = self._mirror.pop(tid)
+            st._live = False            # its table slot may be recycled: the cached arrays are what is left of it
             st.state = TrackState.Removed
             self.removed_stracks.append(st)
         return self.tracked_stracks

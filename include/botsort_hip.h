@@ -19,11 +19,21 @@
  *     reference (never-predicted tracks, detections): the kernels then evaluate the same
  *     sub-expressions in float32 that NumPy scalar arithmetic does, so results are bit-identical.
  *   - one bts_context per (GPU, host thread); one bts_tracker per video stream. Neither is
- *     thread-safe; different objects are independent.
+ *     thread-safe; different objects are independent.  A context's scratch arena is shared by the
+ *     standalone calls made on it (bts_lapjv, bts_associate_parts, bts_tracker_export_state): issue
+ *     them on ONE stream (or synchronise between streams).
+ *   - every call runs on its context's device and restores the caller's current device on return.
+ *   - int32 box arrays are read as 16-byte rows and feature rows as float4: 16-byte alignment is
+ *     required (checked; any hipMalloc / PyTorch allocation satisfies it).
+ *   - device-side failures of an enqueued step (track table full, solver edge-list overflow, an
+ *     in-kernel wait that timed out) cannot stop the stream; they raise a sticky flag that every
+ *     synchronising call (bts_tracker_export*, _stage_result) returns as BTS_ECAPACITY / BTS_EHIP and
+ *     bts_tracker_counts reports in counts[11].  Callers that never export must poll counts.
  */
 #ifndef BOTSORT_HIP_H
 #define BOTSORT_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -56,6 +66,10 @@ const char *bts_status_string(int status);
 int bts_context_create(bts_context **out, int device_ordinal);
 int bts_context_destroy(bts_context *ctx);
 int bts_context_set_cos_kernel(bts_context *ctx, int which);
+
+/* Pinned (page-locked, device-mapped) host memory for the asynchronous export below. */
+int bts_pinned_alloc(void **out, size_t bytes);
+int bts_pinned_free(void *p);
 
 /* ------------------------------------------------------------------ Kalman filter (D:118-380) */
 
@@ -197,6 +211,9 @@ typedef struct bts_tracker_config {
                                    (D:139-149) cannot be matched (cost = +inf, upstream BoT-SORT's gate_cost_matrix);
                                    applied to the sparse edge list, the N x M distance matrix is never formed
                                    (record_costs shows the cost matrix before the gate) */
+    int32_t max_edges;          /* capacity of the assignment solver's edge lists (pairs with cost <= the stage's match
+                                   threshold); 0 = automatic: min(max_tracks * max_dets, 64 * (max_tracks + max_dets)).
+                                   Overflow raises the sticky error flag (BTS_ECAPACITY) */
 } bts_tracker_config;
 
 /* Fill cfg with the reference's hard-coded values (D:1268-1277). */
@@ -233,6 +250,23 @@ int bts_tracker_export(bts_tracker *trk, int which, int32_t *ints_host, double *
  * one MOTChallenge row per entry of the tracked list -- frame, id, left, top, width, height, conf, -1, -1, -1
  * (float64 [rows,10], HOST buffer sized for max_tracks rows).  Synchronises.  Returns the row count or <0. */
 int bts_tracker_export_mot(bts_tracker *trk, double *rows_host, bts_stream stream);
+
+/* The same rows without any host synchronisation: written by the export kernel straight into PINNED host memory
+ * (bts_pinned_alloc: rows_pinned sized for max_tracks x 10 doubles, n_pinned for 4 int32) behind the steps already
+ * enqueued on `stream`.  n_pinned[0] = row count, [1] = frame id, [2] = error flags.  The caller orders its read with
+ * an event / stream wait of its own (e.g. a ring of buffers read one frame late): a D:2135-2185 consumer does not have
+ * to stall the stream per frame. */
+int bts_tracker_export_mot_async(bts_tracker *trk, double *rows_pinned, int32_t *n_pinned, bts_stream stream);
+
+/* The rest of the per-track state a caller of the reference can read (STrack.covariance D:467, body/face curr and smooth
+ * features D:475-490), rows in the order of the tracked (which=0) / lost (which=1) list, to HOST buffers (each nullable;
+ * sized for the list's rows x 64 doubles / x feat_dim / x face_dim floats).  Synchronises.  Returns the row count or <0. */
+int bts_tracker_export_state(bts_tracker *trk, int which, double *cov_host, float *body_curr_host, float *body_smooth_host,
+                             float *face_curr_host, float *face_smooth_host, bts_stream stream);
+
+/* One table slot's row of one field to HOST (slot = ints[row,7] of bts_tracker_export; synchronises):
+ * field 0 mean[8] f64, 1 covariance[64] f64, 2 body_curr[D] f32, 3 body_smooth[D], 4 face_curr[Df], 5 face_smooth[Df]. */
+int bts_tracker_read_slot(bts_tracker *trk, int slot, int field, void *out_host, bts_stream stream);
 
 /* Last frame's association results to HOST (synchronises): for stage s in {1,2,3}
  * x_host[rows], y_host[cols] (nullable); returns rows via *n_rows, cols via *n_cols.

@@ -23,7 +23,7 @@
  *
  * PARITY STATUS: "parity unpinned" for tie-breaking -- there is no lap binary or
  * golden vector in the reference to pin against.  What IS pinned (tests/
- * test_oracle_lapjv.py): optimal objective and, on tie-free inputs, the visible
+ * test_oracle_vs_golden.py, tests/test_lap_ties.py): optimal objective and, on tie-free inputs, the visible
  * matching, against scipy.optimize.linear_sum_assignment on the same extended matrix.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.

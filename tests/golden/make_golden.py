@@ -12,6 +12,10 @@ G4 linear_assignment wrapper cases     (D:1682-1693; lap.lapjv served by the ora
                                         cross-checked with scipy.optimize.linear_sum_assignment)
 G5 end-to-end config-1 trace, 100 frames (64 tracks x 32 dets x 2048-d)
 G6 lifecycle traces (frame_rate=3 => max_time_lost=30, identity churn, low-score dets, faces)
+G9  crowd size (BASELINE config 3: 4096 tracks x 1024 dets x 2048-d), 7 frames   } `--big`: the reference needs
+G10 north-star size (10 000 tracks x 2 000 dets x 2048-d), 6 frames             } ~9 s / ~40 s per frame
+    (light traces: indices, ordered ids / states / counters of every frame; Kalman means of the last frame
+     and their per-frame sums -- no cost matrices)
 """
 from __future__ import annotations
 
@@ -262,7 +266,7 @@ def g4_lap(mod):
 
 
 # ------------------------------------------------------------------------------------ G5 / G6
-def trace(name, K, M, D, frames, seed, churn=0.0, frame_rate=30, face_dim=0, keep_cost=(1, 2, 50)):
+def trace(name, K, M, D, frames, seed, churn=0.0, frame_rate=30, face_dim=0, keep_cost=(1, 2, 50), light=False):
     st = synth.SyntheticStream(K, M, D, seed=seed, churn=churn, face_dim=face_dim)
     ref = rh.ReferenceRunner(D, face_dim=face_dim, frame_rate=frame_rate)
     out = {"K": K, "M": M, "D": D, "frames": frames, "seed": seed, "churn": churn,
@@ -284,13 +288,19 @@ def trace(name, K, M, D, frames, seed, churn=0.0, frame_rate=30, face_dim=0, kee
             out[p + "u_det"] = s["u_det"].astype(np.int32)
             out[p + "cost_sum"] = np.asarray(s["cost"].sum())
             out[p + "cost_shape"] = np.asarray(s["cost"].shape)
-            if f in keep_cost:
+            if f in keep_cost and not light:
                 out[p + "cost"] = s["cost"]
         for nm, lst in (("trk", ref.bot.tracked_stracks), ("lost", ref.bot.lost_stracks)):
             t = rh.table(lst)
             p = "f%d_%s_" % (f, nm)
             for key, v in t.items():
+                if key == "mean" and light:
+                    out[p + "mean_sum"] = np.asarray([v.sum(), np.abs(v).sum()])
+                    if f < frames - 1:
+                        continue
                 out[p + key] = v.astype(np.int32) if key != "mean" else v
+        if light:
+            print("  %s frame %d done" % (name, f), flush=True)
         out["f%d_n_removed" % f] = np.asarray(len(ref.bot.removed_stracks))
     out["input_sha256"] = np.asarray(h.hexdigest())
     out["last_id"] = np.asarray(ref.mod.BaseTrack._count)
@@ -349,6 +359,12 @@ def main():
     if not rh.reference_available():
         raise SystemExit("needs /root/reference (build container only)")
     mod = rh.load_reference()
+    if "--big" in sys.argv:
+        if "--only-g10" not in sys.argv:
+            trace("g9_c3_trace.npz", 4096, 1024, 2048, 7, seed=1234, light=True)
+        if "--only-g9" not in sys.argv:
+            trace("g10_target_trace.npz", 10000, 2000, 2048, 6, seed=1234, light=True)
+        return
     g1_kalman(mod)
     g2_iou(mod)
     g3_fused(mod)

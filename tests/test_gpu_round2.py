@@ -1,0 +1,372 @@
+"""GPU parity, second batch:
+  * G9 / G10: replays of traces the REFERENCE ITSELF produced at the crowd size (4096 x 1024 x 2048) and the north-star
+    size (10 000 x 2 000 x 2048) -- tests/golden/make_golden.py --big;
+  * BASELINE config 3 as stated (Mahalanobis gate on, full size) and config 5 (16384 x 4096 x 384) against the oracle;
+  * the drop-in boundary: BoTSORT.update(image) driven by re-declared fakes of the detector / encoders replays G5 and
+    G6-faces; STrack.activate / predict / update / re_activate / update_*_features against the oracle's TrackRec;
+    state read-back (covariance, feature rows), asynchronous MOT export, error propagation, device selection;
+  * adversarial scenes (dense crowd, clustered embeddings) against the oracle.
+"""
+import hashlib
+import importlib
+
+import numpy as np
+import pytest
+
+from tests.conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+INT_KEYS = ("track_id", "state", "is_activated", "frame_id", "start_frame", "tracklet_len")
+
+
+@pytest.fixture(scope="module")
+def bts():
+    pkg = importlib.import_module("bot-sort-onnx-tensorrt_amd")
+    pkg._lib.load(require_gpu=True)
+    return pkg
+
+
+def _dev_frame(fr):
+    import torch
+    b = torch.from_numpy(fr.boxes.astype(np.int32)).cuda()
+    s = torch.from_numpy(fr.scores.astype(np.float32)).cuda()
+    f = torch.from_numpy(fr.feats.copy()).cuda()
+    ff = None if fr.face_feats is None else torch.from_numpy(fr.face_feats.copy()).cuda()
+    return b, s, f, ff
+
+
+# ------------------------------------------------------------------------------- G9 / G10: the reference at size
+def _replay_light(bts, synth, name, **opts):
+    g = golden(name)
+    K, M, D, frames = int(g["K"]), int(g["M"]), int(g["D"]), int(g["frames"])
+    st = synth.SyntheticStream(K, M, D, seed=int(g["seed"]))
+    trk = bts.DeviceTracker(max_tracks=K + 64, max_dets=max(K, M), feat_dim=D, **opts)
+    h = hashlib.sha256()
+    pairs = 0
+    for f in range(frames):
+        fr = st.next()
+        h.update(fr.boxes.tobytes()); h.update(fr.scores.tobytes()); h.update(fr.feats.tobytes())
+        trk.step(*_dev_frame(fr))
+        for k in (1, 2, 3):
+            p = "f%d_s%d_" % (f, k)
+            r = trk.stage_result(k)
+            assert tuple(g[p + "cost_shape"]) == (len(r["x"]), len(r["y"])), (f, k)
+            assert np.array_equal(r["m"], g[p + "m"].reshape(-1, 2)), (f, k)
+            assert np.array_equal(r["u_trk"], g[p + "u_trk"]), (f, k)
+            assert np.array_equal(r["u_det"], g[p + "u_det"]), (f, k)
+            pairs += len(r["m"])
+        for which, nm in ((0, "trk"), (1, "lost")):
+            t = trk.export(which)
+            p = "f%d_%s_" % (f, nm)
+            for key in INT_KEYS:
+                assert np.array_equal(t[key], g[p + key]), (f, nm, key)
+            want = g[p + "mean_sum"]
+            got = np.asarray([t["mean"].sum(), np.abs(t["mean"]).sum()])
+            assert np.abs(got - want).max() <= 1e-6 * max(1.0, np.abs(want).max()), (f, nm)
+            if (p + "mean") in g.files and len(t["mean"]):
+                assert np.abs(t["mean"] - g[p + "mean"]).max() <= 1e-6, (f, nm)
+        c = trk.counts()
+        assert c["n_removed"] == int(g["f%d_n_removed" % f]) and c["errors"] == 0
+    assert h.hexdigest() == str(g["input_sha256"])
+    assert trk.counts()["last_id"] == int(g["last_id"])
+    trk.close()
+    return pairs
+
+
+def test_golden_c3_size_trace_from_the_reference(bts, synth):
+    """G9: 4096 tracks x 1024 detections x 2048-d, 7 frames recorded by running the reference itself."""
+    assert _replay_light(bts, synth, "g9_c3_trace.npz") > 4000
+
+
+def test_golden_target_size_trace_from_the_reference(bts, synth):
+    """G10: the metric's headline size, 10 000 x 2 000 x 2048-d, 6 frames recorded by running the reference itself."""
+    assert _replay_light(bts, synth, "g10_target_trace.npz") > 7000
+
+
+def test_golden_c3_size_trace_dense_mode(bts, synth):
+    assert _replay_light(bts, synth, "g9_c3_trace.npz", appearance_mode=1) > 4000
+
+
+# ------------------------------------------------------------------------------- configs 3 and 5 as stated
+def _against_vector_oracle(bts, st, K, M, D, frames, motion_gate=False, **opts):
+    from oracle import bts_oracle as bo
+    ora = bo.TrackerOracle(faithful_iou=False, motion_gate=motion_gate)
+    trk = bts.DeviceTracker(max_tracks=K + 256, max_dets=max(K, M), feat_dim=D, motion_gate=1 if motion_gate else 0, **opts)
+    matched = 0
+    for f in range(frames):
+        fr = st.next()
+        trk.step(*_dev_frame(fr))
+        ora.update_arrays(fr.boxes, fr.scores.astype(np.float64), fr.feats.copy(), None)
+        for k in (1, 2, 3):
+            r = trk.stage_result(k)
+            assert np.array_equal(r["m"], np.asarray(ora.trace["m%d" % k]).reshape(-1, 2)), (f, k)
+            matched += len(r["m"])
+        for which, lst in ((0, ora.tracked), (1, ora.lost)):
+            t = trk.export(which)
+            want = bo.TrackerOracle.table(lst)
+            for key in INT_KEYS:
+                assert np.array_equal(t[key], want[key]), (f, which, key)
+            if len(t["mean"]):
+                assert np.abs(t["mean"] - want["mean"]).max() <= 1e-6, (f, which)
+        c = trk.counts()
+        assert c["errors"] == 0 and c["last_id"] == ora._count
+    lap = [trk.debug_lap(s) for s in (1, 2, 3)]
+    trk.close()
+    return matched, lap
+
+
+def test_config3_as_stated_gate_on_full_size(bts, synth):
+    """BASELINE config 3: crowd scene 4096 x 1024 x 2048-d WITH the Mahalanobis gate, vs TrackerOracle(motion_gate=True)."""
+    st = synth.SyntheticStream(4096, 1024, 2048, seed=1234)
+    matched, _ = _against_vector_oracle(bts, st, 4096, 1024, 2048, frames=4, motion_gate=True)
+    assert matched > 2000
+
+
+def test_config5_stress_size_vs_oracle(bts, synth):
+    """BASELINE config 5 size: 16384 tracks x 4096 detections x 384-d (float64 Kalman / no cost matrix: DESIGN.md section 4
+    records the precision deviation from the config's 'fp32 Kalman / fp16 cost' wording)."""
+    st = synth.SyntheticStream(16384, 4096, 384, seed=1234)
+    matched, _ = _against_vector_oracle(bts, st, 16384, 4096, 384, frames=3)
+    assert matched > 3500
+
+
+@pytest.mark.parametrize("name", ["crowd@c2", "hard-reid@c2", "crowd-hard-reid@c2", "crowd", "hard-reid"])
+def test_adversarial_scenes_vs_oracle(bts, synth, name):
+    """Dense crowds (boxes 5-10 deep: large connected components for the solver) and clustered embeddings (impostor
+    cosines 0.5-0.8: many pre-filter candidates) -- results must still be the oracle's."""
+    K, M, D = synth.workload_dims(name)
+    st = synth.make_workload(name, seed=77)
+    matched, lap = _against_vector_oracle(bts, st, K, M, D, frames=6 if K <= 512 else 4)
+    assert matched > 2 * M
+    assert int(lap[0][2]) == 0      # no edge-list overflow
+
+
+# ------------------------------------------------------------------------------- the drop-in boundary
+class _FakeDetector:
+    """What BoTSORT.update(image) asks of the detector (D:1301): a callable returning Box records."""
+
+    def __init__(self, pkg):
+        self.pkg, self.boxes, self.scores = pkg, None, None
+
+    def __call__(self, image):
+        out = []
+        for b, s in zip(self.boxes, self.scores):
+            x1, y1, x2, y2 = (int(v) for v in b)
+            out.append(self.pkg.Box(trackid=0, classid=0, score=float(s), x1=x1, y1=y1, x2=x2, y2=y2,
+                                    cx=(x1 + x2) // 2, cy=(y1 + y2) // 2, is_used=False))
+        return out
+
+
+class _FakeBody:
+    """(similarities[Ndet, Ntrk], features[Ndet, D]), D:1453-1460."""
+
+    def __init__(self, dim):
+        self.feature_size, self.feats = dim, None
+
+    def __call__(self, *, base_images, target_features):
+        return np.zeros((len(base_images), len(target_features)), dtype=np.float32), self.feats
+
+
+class _FakeFace:
+    """(features, similarities) -- swapped order, D:1478-1480."""
+
+    def __init__(self, dim):
+        self.feature_size, self._input_shapes, self.feats = dim, [["N", 3, 8, 8]], None
+
+    def __call__(self, *, base_images, target_features):
+        return self.feats, np.zeros((len(base_images), len(target_features)), dtype=np.float32)
+
+
+@pytest.mark.parametrize("name", ["g5_c1_trace.npz", "g6_faces.npz", "g6_lifecycle.npz"])
+def test_update_image_replays_the_reference_traces(bts, synth, name):
+    """BoTSORT.update(image) -- the D:2130 seam -- fed through fakes of the detector / encoders (re-declared here; the
+    reference is not imported) must reproduce what the reference's own BoTSORT.update produced on the same stream."""
+    g = golden(name)
+    K, M, D, frames, fd = int(g["K"]), int(g["M"]), int(g["D"]), int(g["frames"]), int(g["face_dim"])
+    st = synth.SyntheticStream(K, M, D, seed=int(g["seed"]), churn=float(g["churn"]), face_dim=fd)
+    det, body, face = _FakeDetector(bts), _FakeBody(D), _FakeFace(fd if fd else 8)
+    bot = bts.BoTSORT(det, body, face, frame_rate=int(g["frame_rate"]), max_tracks=4 * K + 64, max_dets=max(K, M) + 8,
+                      feat_dim=D, face_dim=fd)
+    image = np.zeros((1, 1, 3), dtype=np.uint8)
+    for f in range(frames):
+        fr = st.next()
+        det.boxes, det.scores = fr.boxes, fr.scores
+        body.feats = fr.feats.copy()
+        face.feats = None if fr.face_feats is None else fr.face_feats.copy()
+        out = bot.update(image)
+        assert out is bot.tracked_stracks and bot.frame_id == f + 1
+        for k in (1, 2, 3):
+            r = bot.device_tracker.stage_result(k)
+            assert np.array_equal(r["m"], g["f%d_s%d_m" % (f, k)].reshape(-1, 2)), (f, k)
+        for lst, nm in ((bot.tracked_stracks, "trk"), (bot.lost_stracks, "lost")):
+            p = "f%d_%s_" % (f, nm)
+            assert [t.track_id for t in lst] == list(g[p + "track_id"]), (f, nm)
+            assert [int(t.state) for t in lst] == list(g[p + "state"]), (f, nm)
+            assert [int(t.is_activated) for t in lst] == list(g[p + "is_activated"]), (f, nm)
+            assert [t.frame_id for t in lst] == list(g[p + "frame_id"]) and [t.start_frame for t in lst] == list(g[p + "start_frame"])
+            assert [t.tracklet_len for t in lst] == list(g[p + "tracklet_len"]), (f, nm)
+            if lst:
+                assert np.abs(np.asarray([t.mean for t in lst]) - g[p + "mean"]).max() <= 1e-6, (f, nm)
+        assert len(bot.removed_stracks) <= int(g["f%d_n_removed" % f])     # (the reference's list can hold duplicates, Q6)
+    assert bot.device_tracker.counts()["last_id"] == int(g["last_id"])
+
+
+def test_strack_lifecycle_methods_vs_oracle(bts):
+    """STrack.activate / predict / update / re_activate / update_*_features with the reference's signatures (D:492-610)
+    on hand-driven objects, next to the oracle's TrackRec driven the same way."""
+    from oracle import bts_oracle as bo
+    rng = np.random.default_rng(5)
+    D = 96
+    kf, okf = bts.KalmanFilter(), bo.KalmanOracle()
+
+    def feat():
+        f = rng.standard_normal(D).astype(np.float32)
+        return f / np.linalg.norm(f)
+
+    bts.BaseTrack.clear_count()
+    f0 = feat()
+    mine = bts.STrack(np.asarray([100.0, 50.0, 40.0, 90.0]), 0.93, 300, None, f0.copy())
+    ref = bo.TrackRec(np.asarray([100.0, 50.0, 40.0, 90.0], dtype=np.float32), 0.93, f0.copy())
+    # first feature call: curr and smooth alias the (renormalised) input row (Q8)
+    assert mine.body_curr_feature is mine.body_smooth_feature
+    assert np.abs(mine.body_smooth_feature - ref.body_smooth).max() <= 2e-7
+    mine.activate(kf, 1)
+    assert mine.track_id == 1 and mine.is_activated and mine.state == bts.TrackState.Tracked and mine.start_frame == 1
+    m0, c0 = okf.initiate(bo.TrackRec.tlwh_to_xywh(ref.tlwh0))
+    assert np.array_equal(np.asarray(mine.mean, dtype=np.float64), np.asarray(m0, dtype=np.float64))
+    assert np.array_equal(np.asarray(mine.covariance, dtype=np.float64), np.asarray(c0, dtype=np.float64))
+    late = bts.STrack(np.asarray([300.0, 80.0, 50.0, 120.0]), 0.95, 300, None, feat())
+    late.activate(kf, 7)
+    assert late.track_id == 2 and not late.is_activated            # D:565-566: confirmed at birth only on frame 1
+    mean, cov = m0, c0            # (float32 until the first predict, Q10)
+    for frame in range(2, 8):
+        # predict (D:516-522) then update with a new detection record (D:586-610)
+        mine.predict()
+        mean, cov = okf.predict(mean, cov)
+        assert np.array_equal(mine.mean, mean) and np.array_equal(mine.covariance, cov)
+        z = np.asarray([100.0 + 3 * frame, 50.0 + frame, 41.0, 91.0])
+        fz = feat()
+        new = bts.STrack(z, 0.9 + 0.01 * frame, 300, "body%d" % frame, fz.copy())
+        ref.push_body(fz.copy())
+        if frame == 5:
+            mine.mark_lost()
+            mine.re_activate(new, frame, new_id=False)
+            assert mine.tracklet_len == 0 and mine.track_id == 1
+        else:
+            before = mine.tracklet_len
+            mine.update(new, frame)
+            assert mine.tracklet_len == before + 1
+        mean, cov = okf.update(mean, cov, bo.TrackRec.tlwh_to_xywh(np.asarray(z, dtype=np.float32)))
+        assert np.abs(mine.mean - mean).max() <= 1e-9 * max(1.0, np.abs(mean).max())
+        assert np.abs(mine.covariance - cov).max() <= 1e-9 * max(1.0, np.abs(cov).max())
+        assert mine.state == bts.TrackState.Tracked and mine.is_activated and mine.frame_id == frame
+        assert mine.score == new.score and mine.body == "body%d" % frame
+        assert np.array_equal(mine.body_curr_feature, new.body_curr_feature)
+        assert abs(float(np.linalg.norm(mine.body_smooth_feature)) - 1.0) <= 1e-6
+        assert np.abs(mine.body_smooth_feature - ref.body_smooth).max() <= 4e-7      # the EMA chain (alpha = 0.9, D:473)
+        assert len(mine.body_features) == frame
+    assert mine.body_smooth_feature.dtype == np.float32
+    mine.mark_removed()
+    assert mine.state == bts.TrackState.Removed and repr(mine) == "OT_1_(1-7)"
+
+
+def test_mirror_state_readback_and_async_export(bts, synth):
+    """covariance / feature rows of mirrored tracks (lazy per-track reads and the bulk bts_tracker_export_state) equal the
+    oracle's; bts_tracker_export_mot_async delivers the same rows as the synchronous export, without a stream sync."""
+    import torch
+    from oracle import bts_oracle as bo
+    K, M, D = 96, 48, 128
+    st = synth.SyntheticStream(K, M, D, seed=21, churn=0.05)
+    bot = bts.BoTSORT(max_tracks=512, max_dets=K, feat_dim=D)
+    ora = bo.TrackerOracle()
+    ring = [bts.PinnedMot(512) for _ in range(2)]
+    evs = [torch.cuda.Event() for _ in range(2)]
+    for f in range(8):
+        fr = st.next()
+        out = bot.update_arrays(fr.boxes, fr.scores, fr.feats.copy())
+        ora.update_arrays(fr.boxes, fr.scores.astype(np.float64), fr.feats.copy())
+        buf = ring[f % 2]
+        bot.device_tracker.export_mot_async(buf)
+        evs[f % 2].record()
+        assert [t.track_id for t in out] == [t.track_id for t in ora.tracked]
+        for mine, want in list(zip(out, ora.tracked))[::7]:
+            assert np.abs(mine.covariance - want.cov).max() <= 1e-9 * max(1.0, np.abs(want.cov).max())
+            assert np.abs(mine.body_curr_feature - want.body_curr).max() <= 2e-7
+            assert np.abs(mine.body_smooth_feature - want.body_smooth).max() <= 4e-7
+        bulk = bot.device_tracker.export_state(0)
+        assert bulk["covariance"].shape == (len(out), 8, 8)
+        assert np.abs(bulk["covariance"] - np.asarray([t.cov for t in ora.tracked])).max() <= 1e-6
+        assert np.abs(bulk["body_curr_feature"] - np.asarray([t.body_curr for t in ora.tracked])).max() <= 2e-7
+        evs[f % 2].synchronize()
+        rows = buf.rows().copy()
+        assert buf.frame_id() == f + 1 and buf.errors() == 0
+        assert np.array_equal(rows, bot.device_tracker.export_mot())
+    gone = [t for t in bot.removed_stracks]
+    for t in gone:
+        assert t.state == bts.TrackState.Removed
+    for r in ring:
+        r.close()
+
+
+def test_device_errors_reach_the_caller(bts, synth):
+    """A full track table truncates births on the device; the next export must say so (BTS_ECAPACITY), not mirror a
+    silently diverged list."""
+    st = synth.SyntheticStream(64, 32, 64, seed=3)
+    bot = bts.BoTSORT(max_tracks=40, max_dets=64, feat_dim=64)           # 64 identities do not fit 40 slots
+    fr = st.next()
+    with pytest.raises(bts.BtsError, match="track table full"):
+        bot.update_arrays(fr.boxes, fr.scores, fr.feats.copy())
+    assert bot.device_tracker.counts()["errors"] != 0
+    # the solver's edge list: capacity 8 edges cannot hold a 64 x 32 frame's feasible pairs
+    trk = bts.DeviceTracker(max_tracks=256, max_dets=64, feat_dim=64, max_edges=8)
+    st = synth.SyntheticStream(64, 32, 64, seed=3)
+    trk.step(*_dev_frame(st.next()))
+    trk.export(0)                                                        # frame 0: no pool, no edges
+    trk.step(*_dev_frame(st.next()))
+    with pytest.raises(bts.BtsError, match="edge list overflow"):
+        trk.export(0)
+    trk.close()
+
+
+def test_contexts_follow_the_current_device(bts):
+    """module-level functions use the context of torch's CURRENT device and leave the caller's device selection alone."""
+    import torch
+    before = torch.cuda.current_device()
+    c = bts.iou_distance([[0, 0, 10, 10]], [[5, 5, 15, 15]])
+    assert abs(float(c[0, 0]) - (1 - 25 / 175)) < 1e-12
+    assert torch.cuda.current_device() == before
+    assert bts._lib.default_context().device == before
+    if torch.cuda.device_count() > 1:
+        with torch.cuda.device(1):
+            c1 = bts.iou_distance([[0, 0, 10, 10]], [[5, 5, 15, 15]])
+            assert bts._lib.default_context().device == 1 and torch.cuda.current_device() == 1
+        assert np.array_equal(c, c1)
+
+
+def test_lap_ties_documented_behaviour(bts):
+    """Exact cost ties: lap.lapjv's choice among equal optima is unpinned in the reference (package source absent); the
+    device solver must still return AN optimum of the extend_cost/cost_limit problem (same objective as the dense JV
+    restatement) -- scripts/tie_survey.py reports where the two pick different optima."""
+    from oracle import bts_oracle as bo
+    rng = np.random.default_rng(0)
+    L = 0.8
+
+    def objective(c, x, y):
+        rows = np.nonzero(x >= 0)[0]
+        return float(c[rows, x[rows]].sum()) + L / 2 * ((x < 0).sum() + (y < 0).sum())
+
+    cases = [np.full((1, 2), 0.3), np.full((2, 1), 0.3), np.full((4, 4), 0.25), np.full((3, 5), 0.25), np.array([[L, 0.2], [0.3, L]])]
+    for _ in range(60):
+        n, m = rng.integers(2, 9, 2)
+        cases.append(rng.integers(1, 5, (n, m)) / 5.0)
+    for c in cases:
+        c = np.ascontiguousarray(c, dtype=np.float64)
+        _, xd, yd = bts.lapjv(c, extend_cost=True, cost_limit=L)
+        _, xo, yo = bo.lapjv(c, extend_cost=True, cost_limit=L)
+        # a valid matching ...
+        rows = np.nonzero(xd >= 0)[0]
+        assert len(set(xd[rows])) == len(rows) and all(yd[xd[r]] == r for r in rows)
+        assert all(c[r, xd[r]] <= L for r in rows)
+        # ... with the optimal objective
+        assert abs(objective(c, xd, yd) - objective(c, np.asarray(xo), np.asarray(yo))) <= 1e-9, c
