@@ -45,11 +45,11 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-F8_MFMA_PEAK_TF = 5000.0       # dense fp8 MFMA peak (not the 2:1-sparse headline): the pre-filter multiplies fp8 shadows
+I8_MFMA_PEAK_TF = 5000.0       # dense int8 MFMA peak (the same 5 P(FL)OP/s as fp8; not the 2:1-sparse headline): the pre-filter multiplies int8 shadows
 F32_MFMA_PEAK_TF = 157.3       # dense f32-input MFMA peak (= f32 vector peak)
 SEGMENTS = ("prep", "cos1", "cost1", "lap1", "apply1", "stage2", "merge", "dedupe")   # launch groups of a step
 KERNELS = {   # single kernels that can dominate a step -> name in the rocprofv3 kernel trace
-    "k_filter": "k_filter_dma<false> | k_filter_dma_p<false>", "k_lap": "k_lap<4|8>", "k_edges1": "tk_edges<1,1,*> | tk_edges_tall<*> | tk_edges_tall_gate<*> | tk_edges_tall_gate_c<*>", "k_mid2": "tk_mid2<1>",
+    "k_filter": "k_filter_i8<false> | k_filter_splitk<false>", "k_lap": "k_lap<4|8>", "k_edges1": "tk_edges<1,1,*> | tk_edges_tall<*> | tk_edges_tall_gate<*> | tk_edges_tall_gate_c<*>", "k_mid2": "tk_mid2<1>",
     "k_apply23": "tk_apply23", "prep": "tk_front", "merge": "tk_merge",
 }
 
@@ -101,20 +101,25 @@ def self_spawn(a) -> int:
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
     out, _ = procs[0].communicate()
     rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    out = "".join(ln + "\n" for ln in out.splitlines() if ln.startswith("{"))        # the JSON line, nothing else
     sys.stdout.write(out)
     sys.stdout.flush()
     return max(abs(rc) for rc in rcs)
 
 
 # ------------------------------------------------------------------------------------------- models
-def kernel_model(kern, K, M, D, dense):
+def kernel_model(kern, K, M, D, dense, filt=None):
     """Algorithmic work of ONE launch of a kernel in a steady-state frame (pool N = K rows, M detections,
     7/8 of them high-score, ~M matches, ~1.2 feasible edges per detection): (bound, amount, unit, peak).
     Formulas: DESIGN.md section 3."""
     N, Mh, Km = K, M - M // 8, M - M // 8
     E = int(1.2 * Mh)
-    if kern == "k_filter":     # appearance contraction 2*N*Mh*D flop on the fp8 matrix cores
-        return "mfma", 2.0 * N * Mh * D, "flop", F8_MFMA_PEAK_TF
+    if kern == "k_filter":
+        # appearance contraction on the int8 matrix cores: the multiply-adds the kernel EXECUTED (tiles stop at a prefix of K
+        # once nothing in them can reach the gate: counted on the device, 128 x 128 x 128 per tile stage), not 2 N Mh D
+        if filt and filt.get("k_stages"):
+            return "mfma", 2.0 * 128 * 128 * 128 * filt["k_stages"], "op", I8_MFMA_PEAK_TF
+        return "mfma", 2.0 * N * Mh * D, "op", I8_MFMA_PEAK_TF
     table = {
         # stage-1 matches: Kalman rows read + written, measurement read; det row, smooth r+w, curr w, fp8 shadow w
         "k_mid2": Km * (2 * 72 + 4) * 8 + Km * D * (4 + 4 + 4 + 4 + 2),
@@ -142,6 +147,13 @@ def step_bytes(K, M, D):
     return float(survey), float(as_built)
 
 
+def table_rows(K):
+    """Track-table capacity for a stream of K identities: the live tracks plus room for the duplicates a long run
+    accumulates (with the motion gate a re-appearing identity whose prediction drifted is born again while its old
+    track waits out the 300-frame lost buffer; the reference's lists are unbounded)."""
+    return K + max(64, K // 8)
+
+
 class IdMatch:
     """Checker beside the CPU-baseline leg (the metric's "assignment ID match vs ref"): a second tracker handle is
     stepped on the very frames the oracle is timed on (outside the oracle's timed bracket) and, per frame, the three
@@ -152,7 +164,7 @@ class IdMatch:
     def __init__(self, pkg, K, M, D, motion_gate=False, **opts):
         import torch
         self.torch = torch
-        self.trk = pkg.DeviceTracker(max_tracks=K + 64, max_dets=max(K, M), feat_dim=D, device=torch.cuda.current_device(),
+        self.trk = pkg.DeviceTracker(max_tracks=table_rows(K), max_dets=max(K, M), feat_dim=D, device=torch.cuda.current_device(),
                                      motion_gate=1 if motion_gate else 0, **opts)
         self.frames = self.pairs = self.pairs_equal = self.ids = self.ids_equal = 0
         self.frames_identical = 0
@@ -326,7 +338,17 @@ def main():
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        # (gloo announces its connections on stdout; rank 0's stdout carries the ONE JSON line only)
+        sys.stdout.flush()
+        keep = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(keep, 1)
+            os.close(keep)
     assert torch.cuda.is_available(), "bench.py measures the HIP path: a GPU is required (no CPU fallback)"
     ndev = torch.cuda.device_count()
     if world > ndev and not a.oversubscribe:
@@ -349,7 +371,7 @@ def main():
     torch.cuda.set_stream(stream)
     frames = [next_frame() for _ in range(a.warmup)]
     opts = dict(appearance_mode=1 if a.dense else 0, use_graph=1 if a.graph else 0, motion_gate=1 if a.motion_gate else 0)
-    trk = pkg.DeviceTracker(max_tracks=K + 64, max_dets=max(K, M), feat_dim=D, device=torch.cuda.current_device(), **opts)
+    trk = pkg.DeviceTracker(max_tracks=table_rows(K), max_dets=max(K, M), feat_dim=D, device=torch.cuda.current_device(), **opts)
 
     ms = importlib.import_module("bot-sort-onnx-tensorrt_amd.multistream")
     ddist = dist if world > 1 else None
@@ -362,7 +384,7 @@ def main():
     for k in range(1, S):
         st_k = pkg.synth.make_workload(a.workload, seed=ms_seed(pkg, rank * S + k))
         with torch.cuda.stream(torch.cuda.default_stream()):      # (set-up on the default stream: see multistream.run_concurrent)
-            tk = pkg.DeviceTracker(max_tracks=K + 64, max_dets=max(K, M), feat_dim=D, device=torch.cuda.current_device(), **opts)
+            tk = pkg.DeviceTracker(max_tracks=table_rows(K), max_dets=max(K, M), feat_dim=D, device=torch.cuda.current_device(), **opts)
             for _ in range(a.warmup + 6):
                 fr = st_k.next()
                 tk.step(torch.from_numpy(fr.boxes).cuda(), torch.from_numpy(fr.scores).cuda(), torch.from_numpy(fr.feats).cuda())
@@ -389,7 +411,8 @@ def main():
         t1 = ms.run_concurrent([trk] + [e[0] for e in extra], [timed] + [e[2] for e in extra])
     ms.barrier(ddist)
     counts = trk.counts()
-    assert counts["errors"] == 0, counts
+    IGNORE = bool(os.environ.get("BTS_BENCH_IGNORE_ERRORS"))       # (kernel timing experiments whose results are meaningless)
+    assert counts["errors"] == 0 or IGNORE, counts
     for e in extra:
         assert e[0].counts()["errors"] == 0
     elapsed = ms.max_over_ranks(t1 - t0, ddist)
@@ -411,7 +434,8 @@ def main():
     torch.cuda.synchronize()
     seg_ms, seg_n = trk.profile_read()
     trk.profile_enable("step", 0)
-    assert trk.counts()["errors"] == 0
+    if trk.counts()["errors"] != 0 and not IGNORE:
+        trk.export(0)            # (raises with the device's own account of what overflowed, and when)
     if a.breakdown and rank == 0:
         sys.stderr.write("segment us/step: " + json.dumps({k: round(v, 1) for k, v in breakdown.items()}) + "\n")
 
@@ -431,16 +455,17 @@ def main():
         dist.all_gather_object(id_multi, chk.result())
 
     if rank == 0:
-        bound, amount, unit, peak = kernel_model(segment, K, M, D, a.dense)
+        filt = trk.debug_filter()
+        bound, amount, unit, peak = kernel_model(segment, K, M, D, a.dense, filt)
         seg_s = (seg_ms / 1e3) / max(seg_n, 1)
         if bound == "mfma":
-            achieved, runit = amount / seg_s / 1e12, "TFLOP/s"
+            achieved, runit = amount / seg_s / 1e12, "TOP/s"
         else:
             achieved, runit = amount / seg_s / 1e9, "GB/s"
         step_s = elapsed / a.steps
         b_survey, b_built = step_bytes(K, M, D)
         kern_roof = {"kernel": KERNELS[segment], "bound": bound,
-                     "bound_peak": "dense fp8 MFMA 5 PFLOP/s" if bound == "mfma" else "HBM3E 8 TB/s",
+                     "bound_peak": "dense int8 MFMA 5 POP/s" if bound == "mfma" else "HBM3E 8 TB/s",
                      "achieved": achieved, "peak": peak, "unit": runit, "frac": achieved / peak,
                      "traffic": pmc_traffic(a.workload, KERNELS[segment]),
                      "traffic_unit": "bytes per launch (HBM, rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes, profiles/pmc_traffic.json)",
@@ -471,6 +496,13 @@ def main():
             "algorithmic_bytes_as_built": b_built, "achieved_as_built": b_built / step_s / 1e9, "frac_as_built": b_built / step_s / 1e9 / HBM_PEAK_GBS,
             "formula": "SURVEY.md 8(d) with fp32 element sizes (survey) / float64 Kalman rows, no N x M matrix, fp8 shadows (as built): bench.py step_bytes()"}
         out["segments_us"] = {k: round(v, 2) for k, v in breakdown.items()}
+        Mh = max(1, counts.get("n_hi", M) or M)
+        if hasattr(trk, "_filter_raw") and os.environ.get("BTS_BENCH_IGNORE_ERRORS"):
+            filt = dict(filt, raw=[int(v) for v in trk._filter_raw])
+        out["prefilter"] = dict(filt, full_k_stages_equivalent=int(-(-K // 128) * -(-Mh // 128) * (D // 128)),
+                                candidates_per_high_detection=filt["candidates"] / Mh,
+                                what="last step: K stages of 128 elements run over all 128 x 128 tiles, tiles that stopped at a prefix "
+                                     "checkpoint, pairs handed to the exact float32 refinement")
         out["lap"] = {"stage%d" % s: dict(zip(("edges", "components", "overflow", "hard_edges", "form"),
                                                (lambda h: (int(h[0]), int(h[1]), int(h[2]), int(h[6]), int(h[8])))(trk.debug_lap(s)))) for s in (1, 2, 3)}
         if export is not None:

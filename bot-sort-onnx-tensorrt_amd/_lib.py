@@ -54,8 +54,10 @@ SIGNATURES = {
     "bts_lapjv": (c_int, [_P, _P, c_int, c_int, c_int, c_double, _P, _P, _P]),
     "bts_feature_ema": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_double, _P]),
     "bts_feature_renorm": (c_int, [_P, _P, _P, c_int, c_int, _P]),
-    "bts_debug_q8_roundtrip": (c_int, [_P, _P, _P, c_int, _P]),
-    "bts_debug_q8_model": (c_int, [_P, _P, _P]),
+    "bts_debug_i8_rows": (c_int, [_P, _P, c_int, c_int, c_double, _P, _P, _P]),
+    "bts_debug_i8_pairs": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P]),
+    "bts_debug_i8_layout": (c_int, [c_int, _P]),
+    "bts_tracker_debug_filter": (c_int, [_P, _P, _P]),
     "bts_debug_jobtrace": (c_int, [_P]),
     "bts_debug_launch_floor": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "bts_associate_parts": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, _P, c_int, _P, _P]),

@@ -70,36 +70,14 @@ __device__ __forceinline__ void renorm_row(float *row, int d, bool active = true
     }
 }
 
-// (8-bit shadows of the pre-filter: definitions further down)
-constexpr float Q8_SCALE = 128.0f;
-__device__ __forceinline__ unsigned q8_pack4(float a, float b, float c, float e) {
-    int w = 0;
-    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
-    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, e, w, true);
-    return (unsigned)w;
-}
-
 // curr = f ; smooth = normalise(has ? alpha*smooth + beta*f : f)
-// unit_q8 / unit_norm (optional): also write the 8-bit shadow of f for the pre-filter, for rows that are KNOWN to be
-// unit vectors (the detection rows were renormalised in place before any track consumes them): the shadow is then
-// q(128 f) with no second reduction and the stored norm is 1 (the 1e-7 deviation of a renormalised row from unit
-// length is far inside the slack of feat::q8_cos_error).
-__device__ __forceinline__ bool ema_row(float *curr, float *smooth, const float *f, int d, bool has, float alpha,
-                                        float beta, bool active = true, uint8_t *unit_q8 = nullptr, float *unit_norm = nullptr) {
+__device__ __forceinline__ void ema_row(float *curr, float *smooth, const float *f, int d, bool has, float alpha,
+                                        float beta, bool active = true) {
     const int t = row_tid();
     float ss = 0.0f;
     if (active && vec4_ok(curr, d) && vec4_ok(smooth, d) && vec4_ok(f, d) && d / 4 <= 2 * ROW_G) {      // 16 B per lane, values stay in registers
         const float4 *f4 = reinterpret_cast<const float4 *>(f);
         float4 *c4 = reinterpret_cast<float4 *>(curr), *s4 = reinterpret_cast<float4 *>(smooth);
-        if (unit_q8) {
-            unsigned *h4 = reinterpret_cast<unsigned *>(unit_q8);
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int k = t + u * ROW_G;
-                if (k < d / 4) { const float4 v = f4[k]; h4[k] = q8_pack4(v.x * Q8_SCALE, v.y * Q8_SCALE, v.z * Q8_SCALE, v.w * Q8_SCALE); }
-            }
-            if (t == 0) *unit_norm = 1.0f;
-        }
         const int nv = d / 4;
         float4 fv[2], sv[2];
 #pragma unroll
@@ -124,7 +102,7 @@ __device__ __forceinline__ bool ema_row(float *curr, float *smooth, const float 
                 s4[k] = make_float4(sv[u].x / nrm, sv[u].y / nrm, sv[u].z / nrm, sv[u].w / nrm);
             }
         }
-        return unit_q8 != nullptr;          // shadow written
+        return;
     }
     if (active)
         for (int k = t; k < d; k += ROW_G) {
@@ -140,58 +118,176 @@ __device__ __forceinline__ bool ema_row(float *curr, float *smooth, const float 
             curr[k] = fv;
             smooth[k] = s / nrm;
         }
-    return false;
 }
 
-// ---- 8-bit shadow rows for the appearance pre-filter ----------------------------------------------------
-// q[k] = fp8_e4m3(Q8_SCALE * f[k] / ||f||_2), *norm = ||f||_2.  The shadow is the UNIT vector (no component can
-// saturate whatever the norm of the row is; 128 keeps the largest component below the maximum of both e4m3
-// flavours), so the accumulated dot product of two shadows approximates the COSINE; the norms travel separately.
-// Error model of one element x of a unit vector (validated on the device by tests, bts_debug_q8_roundtrip):
-//     |q(x) - x| <= Q8_REL * |x| + Q8_ABS        (round to nearest, 3 mantissa bits; Q8_ABS covers the subnormal
-//                                                 range even if the conversion flushes it to zero)
-// => |cos_q - cos| <= (2 Q8_REL + Q8_REL^2) + 2 (1 + Q8_REL) Q8_ABS sqrt(D) + D Q8_ABS^2   (+ float32 accumulation).
-constexpr float Q8_UNSCALE = 1.0f / (128.0f * 128.0f);
-constexpr float Q8_REL = 0.0625f;                 // 2^-4
-constexpr float Q8_ABS = 1.0f / 8192.0f;          // 2^-6 (smallest normal of e4m3fn) / 128
-__host__ __device__ inline float q8_cos_error(int d) {
-    return (2.0f * Q8_REL + Q8_REL * Q8_REL) + 2.0f * (1.0f + Q8_REL) * Q8_ABS * sqrtf((float)d) + (float)d * Q8_ABS * Q8_ABS +
-           (float)d / 4194304.0f + 1e-3f;
+// ---- 8-bit integer shadow rows for the appearance pre-filter ------------------------------------------------
+// A float32 feature row x gets the shadow  q[k] = clamp(round(x[k] * s), +-127)  (int8, symmetric; ONE scale s for every row of
+// a given dimension: 127 at I8_CLIP standard deviations of a unit vector's components, so that an integer dot product means
+// the same cosine for every pair and the candidate test can compare accumulators with integer thresholds; a component
+// beyond the clip saturates and shows up in the row's measured residual; qd = q / s is the dequantised row) and an
+// 80-byte record of what the pre-filter's candidate test needs.  The test is a
+// RIGOROUS upper bound on the exact dot product <a, b> from integer arithmetic on a PREFIX of the rows:
+//     <a, b> = (|a|^2 + |b|^2 - |a - b|^2) / 2                      (any vectors)
+//     |a - b| >= |a_k - b_k| >= |qd_a,k - qd_b,k| - r_a - r_b       (prefix of k elements; r = |x - qd| over the WHOLE row,
+//                                                                     measured when the row is quantised -- no error model)
+//     |qd_a,k - qd_b,k|^2 = A_k + B_k - 2 <q_a,k, q_b,k> / (s_a s_b)  (A_k = |qd_a,k|^2; the integer dot product is exact)
+// so  <a, b> >= gate  is impossible once  |qd_a,k - qd_b,k| > r_a + r_b + sqrt(|a|^2 + |b|^2 - 2 gate).  Evaluated without
+// a square root per pair: the square of the right-hand side is bounded by a ROW part plus a COLUMN part (to_i8_row), so a
+// pair is excluded when  c < uh_i + uh_j  with c = <q_a,k, q_b,k> / (s_a s_b); on the full row the direct form
+// <a, b> <= c + |qd_a| r_b + |b| r_a is used (the same expression with cross terms alpha * r: i8_excluded).
+// At k = D the bound is the quantised dot product plus the measured residuals (a band of ~0.02 for well-spread rows,
+// against 0.14 of a worst-case element model of an 8-bit float format); at a prefix it lets a tile STOP the K loop as
+// soon as (nearly) nothing in it can still reach the gate.  Non-finite rows get r = +inf: every pair with them is a
+// candidate and the exact float32 dot product decides.
+constexpr float I8_CLIP = 6.0f;               // int8 full scale, in units of 1 / sqrt(D) (the component RMS of a unit vector)
+__host__ __device__ inline float i8_scale(int d) { return 127.0f * sqrtf((float)d) / I8_CLIP; }
+constexpr int I8_NCHK = 4;                    // prefix checkpoints of the K loop (stages of I8_STAGE elements) besides the full row
+constexpr int I8_STAGE = 128;                 // elements per K stage of the pre-filter GEMM
+constexpr int I8_META = 4 * (I8_NCHK + 1);    // floats per row record
+// record layout: five float4 {1/s, r, alpha_c, uh_c}, c = 0 .. I8_NCHK (the last: full row) -- the float4 of a checkpoint is what
+// a candidate test reads, and one 16-byte global -> LDS transfer per row brings it there
+__host__ __device__ inline void i8_checkpoints(int kt_all, int (&c)[I8_NCHK]) {
+    // stages after which a tile may stop: ~5/16, 7/16, 10/16, 13/16 of the row (strictly increasing, at least 3 stages --
+    // shorter prefixes are statistically useless --, unused ones = kt_all)
+    const int num[I8_NCHK] = {5, 7, 10, 13};
+    int prev = 2;
+    for (int j = 0; j < I8_NCHK; ++j) {
+        int v = (kt_all * num[j] + 15) / 16;
+        if (v <= prev) v = prev + 1;
+        if (v >= kt_all) v = kt_all;
+        c[j] = v;
+        prev = v < kt_all ? v : kt_all;
+    }
 }
 
+// sum and maximum over the row group in one pass of barriers
+__device__ __forceinline__ void block_sum_max(float &sum, float &mx) {
+    __shared__ float part[2][16];
+#pragma unroll
+    for (int off = 32; off; off >>= 1) { sum += __shfl_xor(sum, off); mx = fmaxf(mx, __shfl_xor(mx, off)); }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    bscan::lds_barrier();
+    if (lane == 0) { part[0][wid] = sum; part[1][wid] = mx; }
+    bscan::lds_barrier();
+    const int w0 = row_group() * (ROW_G / 64);
+    sum = ((part[0][w0] + part[0][w0 + 1]) + part[0][w0 + 2]) + part[0][w0 + 3];
+    mx = fmaxf(fmaxf(part[1][w0], part[1][w0 + 1]), fmaxf(part[1][w0 + 2], part[1][w0 + 3]));
+}
+// six sums at once (the residual and the five prefix buckets of the squared quantised row)
+__device__ __forceinline__ void block_sum6(float (&v)[6]) {
+    __shared__ float part[6][16];
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int off = 32; off; off >>= 1) v[q] += __shfl_xor(v[q], off);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    bscan::lds_barrier();
+    if (lane == 0)
+#pragma unroll
+        for (int q = 0; q < 6; ++q) part[q][wid] = v[q];
+    bscan::lds_barrier();
+    const int w0 = row_group() * (ROW_G / 64);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) v[q] = ((part[q][w0] + part[q][w0 + 1]) + part[q][w0 + 2]) + part[q][w0 + 3];
+}
 
-__device__ __forceinline__ void to_q8_row(const float *f, uint8_t *h, float *norm, int d, bool active = true) {
+__device__ __forceinline__ int i8_round(float v) { return (int)__builtin_rintf(fminf(fmaxf(v, -127.0f), 127.0f)); }
+
+// x[d] -> q[d] (int8), meta[I8_META].  `gate` = the similarity the appearance term must reach (1 - appearance_thresh).
+// Called by all threads of the row group; inactive groups only take part in the barriers.
+__device__ __forceinline__ void to_i8_row(const float *x, int8_t *q, float *meta, int d, float gate, bool active = true) {
     const int t = row_tid();
-    float ss = 0.0f;
-    const bool v4 = active && vec4_ok(f, d) && (uintptr_t)h % 4 == 0;
-    if (v4 && d / 4 <= 2 * ROW_G) {                       // the row stays in registers between the two sweeps
-        const float4 *f4 = reinterpret_cast<const float4 *>(f);
-        unsigned *h4 = reinterpret_cast<unsigned *>(h);
-        float4 v[2];
+    int cst[I8_NCHK];
+    i8_checkpoints(d / I8_STAGE, cst);
+    float ss = 0.0f, mx = 0.0f;
+    const bool v4 = active && vec4_ok(x, d) && (uintptr_t)q % 4 == 0 && d / 4 <= 2 * ROW_G;
+    float4 v[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    if (v4) {
+        const float4 *x4 = reinterpret_cast<const float4 *>(x);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int k = t + u * ROW_G;
-            v[u] = k < d / 4 ? f4[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < d / 4) v[u] = x4[k];
             ss += v[u].x * v[u].x; ss += v[u].y * v[u].y; ss += v[u].z * v[u].z; ss += v[u].w * v[u].w;
+            mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[u].x), fabsf(v[u].y)), fmaxf(fabsf(v[u].z), fabsf(v[u].w))));
         }
-        const float nrm = sqrtf(block_sum(ss));
-        const float sc = nrm > 0.0f ? Q8_SCALE / nrm : (nrm == 0.0f ? 0.0f : nrm);       // NaN norms poison the row on purpose
+    } else if (active) {
+        for (int k = t; k < d; k += ROW_G) { const float e = x[k]; ss += e * e; mx = fmaxf(mx, fabsf(e)); }
+    }
+    block_sum_max(ss, mx);
+    const bool finite = ss == ss && ss < 3.0e38f;            // (NaN / inf rows: every pair with them stays a candidate)
+    const float s = i8_scale(d), inv = 1.0f / s;
+    (void)mx;
+    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};          // [0] residual^2, [1..5] squared quantised elements per prefix bucket
+    auto bucket = [&](int elem) { const int st = elem / I8_STAGE; int b = 0;
+#pragma unroll
+        for (int j = 0; j < I8_NCHK; ++j) b += st >= cst[j] ? 1 : 0;
+        return b; };
+    auto add = [&](int b, float qq) { acc[1] += b == 0 ? qq : 0.f; acc[2] += b == 1 ? qq : 0.f; acc[3] += b == 2 ? qq : 0.f;
+                                      acc[4] += b == 3 ? qq : 0.f; acc[5] += b == 4 ? qq : 0.f; };
+    if (v4) {
+        unsigned *q4 = reinterpret_cast<unsigned *>(q);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int k = t + u * ROW_G;
-            if (k < d / 4) h4[k] = q8_pack4(v[u].x * sc, v[u].y * sc, v[u].z * sc, v[u].w * sc);
+            if (k >= d / 4) continue;
+            const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+            unsigned w = 0;
+            const int b = bucket(4 * k);                      // (a float4 never straddles a stage)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int qi = finite ? i8_round(e[c] * s) : 0;
+                const float dq = (float)qi * inv, res = e[c] - dq;
+                acc[0] += res * res;
+                add(b, dq * dq);
+                w |= (unsigned)(qi & 0xff) << (8 * c);
+            }
+            q4[k] = w;
         }
-        if (t == 0) *norm = nrm;
-        return;
+    } else if (active) {
+        for (int k = t; k < d; k += ROW_G) {
+            const float e = x[k];
+            const int qi = finite ? i8_round(e * s) : 0;
+            const float dq = (float)qi * inv, res = e - dq;
+            acc[0] += res * res;
+            add(bucket(k), dq * dq);
+            q[k] = (int8_t)qi;
+        }
     }
-    if (active) for (int k = t; k < d; k += ROW_G) ss += f[k] * f[k];
-    const float nrm = sqrtf(block_sum(ss));
-    const float sc = nrm > 0.0f ? Q8_SCALE / nrm : (nrm == 0.0f ? 0.0f : nrm);
-    if (active) {
-        for (int k = t; k < d; k += ROW_G) h[k] = (uint8_t)(q8_pack4(f[k] * sc, 0.f, 0.f, 0.f) & 0xffu);
-        if (t == 0) *norm = nrm;
+    block_sum6(acc);
+    if (active && t == 0) {
+        const float inf = __builtin_huge_valf();
+        // slack: float32 evaluation of the sums above and of the test (~1e-6 relative), the 1e-7 difference between a raw
+        // detection row and its in-place renormalised self (the track rows are copies of the latter, D:492-502 / Q8)
+        const float r = finite ? sqrtf(acc[0]) * 1.0001f + 1e-5f : inf;
+        float run = 0.0f;
+#pragma unroll
+        for (int c = 0; c <= I8_NCHK; ++c) {
+            run += acc[1 + c];
+            const float a_k = c == I8_NCHK ? ((acc[1] + acc[2]) + (acc[3] + acc[4])) + acc[5] : run;
+            // Prefix records: (tau + r_a + r_b)^2 <= (1 + e) tau^2 + (1 + 1/e) (r_a + r_b)^2 <= 1.03 tau^2 + 68.7 (r_a^2 + r_b^2)  with
+            // e = 0.03 (tight where r ~ 0.02 tau, which is where prefix exits happen) and tau^2 = (|a|^2 - gate) + (|b|^2 - gate):
+            // the right-hand side splits into a row part and a column part, so the pair is excluded when
+            //     c < uh_a + uh_b,   uh = (A_k - 1.03 (|x|^2 - gate) - 68.7 r^2) / 2     (alpha = 0: no cross terms).
+            // Full row: the direct form  <a, b> <= c + |qd_a| r_b + |b| r_a,  same arithmetic with alpha = max(|x|, |qd|)
+            // and uh = gate / 2.
+            const float alpha = c == I8_NCHK ? fmaxf(sqrtf(a_k), sqrtf(ss)) * 1.00001f : 0.0f;
+            const float uh = c == I8_NCHK ? 0.5f * gate : 0.5f * (a_k - 1.03f * (ss - gate) - 68.7f * r * r);
+            meta[4 * c + 0] = inv; meta[4 * c + 1] = r;
+            meta[4 * c + 2] = alpha;
+            meta[4 * c + 3] = finite ? uh - 1e-4f * (1.0f + ss) : -inf;
+        }
     }
 }
+
+// "no pair of these two rows can reach the gate", from the accumulated integer dot product of the prefix the records'
+// checkpoint c describes: ra / rb = float4 {1/s, r, alpha_c, uh_c} of the row / column.  NaN-safe: anything that does not
+// compare stays a candidate.
+__device__ __forceinline__ bool i8_excluded(int dot, const float4 &ra, const float4 &rb) {
+    const float lhs = fmaf((float)dot * ra.x, rb.x, fmaf(ra.z, rb.y, rb.z * ra.y));
+    return lhs < ra.w + rb.w;
+}
+__device__ __forceinline__ float4 i8_rec(const float *meta, int c) { return *reinterpret_cast<const float4 *>(meta + 4 * c); }
 
 // <a, b> over d floats by one wavefront, every lane gets the result.  Fixed evaluation order
 // (lane-strided fma chains, then an xor butterfly), so the value is reproducible.

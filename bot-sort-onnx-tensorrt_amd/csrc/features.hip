@@ -34,32 +34,64 @@ __global__ __launch_bounds__(256) void k_feature_renorm(float *__restrict__ feat
     feat::renorm_row(feats + s * d, d);
 }
 
-// diagnostic: the 8-bit quantiser of the appearance pre-filter, element by element
-__global__ __launch_bounds__(256) void k_q8_roundtrip(const float *__restrict__ x, float *__restrict__ y, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const unsigned w = feat::q8_pack4(x[i] * feat::Q8_SCALE, 0.f, 0.f, 0.f);
-    y[i] = __builtin_amdgcn_cvt_f32_fp8((int)w, 0) / feat::Q8_SCALE;
+// diagnostics of the appearance pre-filter's int8 shadows (feat::to_i8_row / feat::i8_excluded), exposed for the tests
+__global__ __launch_bounds__(256) void k_i8_rows(const float *__restrict__ x, int n, int d, float gate, int8_t *__restrict__ q,
+                                                 float *__restrict__ meta) {
+    const long j = blockIdx.x;
+    feat::to_i8_row(x + j * d, q + j * d, meta + j * feat::I8_META, d, gate, j < n);
+}
+// pair p = (ia[p], ib[p]): for every checkpoint c (the last = full row) out[p][c] = 1 when the prefix's integer dot
+// product excludes the pair (feat::i8_excluded), dots[p][c] = that integer dot product
+__global__ __launch_bounds__(64) void k_i8_pairs(const int8_t *__restrict__ qa, const float *__restrict__ ma, const int8_t *__restrict__ qb,
+                                                 const float *__restrict__ mb, const int32_t *__restrict__ ia, const int32_t *__restrict__ ib,
+                                                 int np, int d, uint8_t *__restrict__ out, int32_t *__restrict__ dots) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= np) return;
+    int chk[feat::I8_NCHK];
+    feat::i8_checkpoints(d / feat::I8_STAGE, chk);
+    const int8_t *a = qa + (long)ia[p] * d, *b = qb + (long)ib[p] * d;
+    const float *ra = ma + (long)ia[p] * feat::I8_META, *rb = mb + (long)ib[p] * feat::I8_META;
+    int dot = 0, k = 0;
+    for (int c = 0; c <= feat::I8_NCHK; ++c) {
+        const int upto = c == feat::I8_NCHK ? d : (chk[c] < d / feat::I8_STAGE ? chk[c] * feat::I8_STAGE : d);
+        for (; k < upto; ++k) dot += (int)a[k] * (int)b[k];
+        out[p * (feat::I8_NCHK + 1) + c] = feat::i8_excluded(dot, feat::i8_rec(ra, c), feat::i8_rec(rb, c)) ? 1 : 0;
+        dots[p * (feat::I8_NCHK + 1) + c] = dot;
+    }
 }
 
 }  // namespace
 
 extern "C" {
 
-int bts_debug_q8_roundtrip(bts_context *ctx, const float *x, float *y, int n, bts_stream stream) {
-    BTS_REQUIRE(ctx && n >= 0, "ctx, n");
+int bts_debug_i8_rows(bts_context *ctx, const float *x, int n, int d, double gate, int8_t *q, float *meta, bts_stream stream) {
+    BTS_REQUIRE(ctx && n >= 0 && d > 0, "ctx, n, d");
     BTS_ON_DEVICE(ctx);
     if (n == 0) return BTS_OK;
-    BTS_REQUIRE(x && y, "null pointer");
-    hipLaunchKernelGGL(k_q8_roundtrip, dim3(bts_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n);
+    BTS_REQUIRE(x && q && meta, "null pointer");
+    hipLaunchKernelGGL(k_i8_rows, dim3(n), dim3(256), 0, (hipStream_t)stream, x, n, d, (float)gate, q, meta);
     BTS_LAUNCH_CHECK();
     return BTS_OK;
 }
 
-int bts_debug_q8_model(double *rel, double *abs_, double *scale) {
-    if (rel) *rel = feat::Q8_REL;
-    if (abs_) *abs_ = feat::Q8_ABS;
-    if (scale) *scale = feat::Q8_SCALE;
+int bts_debug_i8_pairs(bts_context *ctx, const int8_t *qa, const float *meta_a, const int8_t *qb, const float *meta_b,
+                       const int32_t *ia, const int32_t *ib, int n_pairs, int d, uint8_t *excluded, int32_t *dots, bts_stream stream) {
+    BTS_REQUIRE(ctx && n_pairs >= 0 && d > 0, "ctx, n_pairs, d");
+    BTS_ON_DEVICE(ctx);
+    if (n_pairs == 0) return BTS_OK;
+    BTS_REQUIRE(qa && meta_a && qb && meta_b && ia && ib && excluded && dots, "null pointer");
+    hipLaunchKernelGGL(k_i8_pairs, dim3(bts_cdiv(n_pairs, 64)), dim3(64), 0, (hipStream_t)stream, qa, meta_a, qb, meta_b, ia, ib, n_pairs, d,
+                       excluded, dots);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+
+int bts_debug_i8_layout(int d, int32_t *out8) {
+    BTS_REQUIRE(d > 0 && out8, "d, out");
+    int chk[feat::I8_NCHK];
+    feat::i8_checkpoints(d / feat::I8_STAGE, chk);
+    for (int c = 0; c < feat::I8_NCHK; ++c) out8[c] = chk[c];
+    out8[4] = d / feat::I8_STAGE; out8[5] = feat::I8_STAGE; out8[6] = feat::I8_META; out8[7] = feat::I8_NCHK;
     return BTS_OK;
 }
 

@@ -202,6 +202,8 @@ constexpr int SM_C = SM_EH / 2;      // components: a hard edge shares its row o
                                      // component has >= 2 edges (and, being connected, at most edges + 1 rows and columns:
                                      // row slots + column slots <= SM_EH + SM_C)
 constexpr int SM_EDGES = 512;        // edge budget of the register/LDS solver, per wavefront
+constexpr int TALL_S = 4, TALL_R = 254;       // rows of a component the register solvers take (solve_packed: 64, solve_packed_tall: TALL_S row
+                                              // slots per lane; the packed descriptor keeps the row count in 8 bits, 255 = "255 or more")
 
 struct SmallPipe {                   // LDS image of the hard sub-problem (slot space); 34 B per hard edge
     uint16_t hr[SM_EH], hc[SM_EH];                // hard edge -> row, column (global ids first, then slots)
@@ -363,7 +365,7 @@ template <int EC> __device__ int small_pipeline(const LapArgs &A, SmallPipe &L, 
     uint16_t *lane_of_col = L.lane_of_col();
     if (tid < 192) {
         const int wv = tid >> 6, ln = tid & 63;
-        const bool over = wv == 0 ? wave_exscan_lds(L.crp, C, L.crp, cur_r, 64, ln)
+        const bool over = wv == 0 ? wave_exscan_lds(L.crp, C, L.crp, cur_r, TALL_R, ln)      // (TALL_R rows: solve_packed_tall)
                         : wv == 1 ? wave_exscan_lds(L.ccp, C, L.ccp, cur_c, 64, ln)
                                   : wave_exscan_lds(L.ecnt, C, ebase, ecur, SM_EDGES, ln);
         if (over) L.maxr = 65;
@@ -709,6 +711,130 @@ __device__ __forceinline__ bool solve_packed(const LapArgs &A, int c, int lane, 
     return true;
 }
 
+// Tall components (dense crowds: a detection column overlapped by many track rows): up to TALL_R rows, <= 64 columns,
+// <= SM_EDGES edges.  Same search as solve_packed with the row state spread over TALL_S slots per lane (local row
+// i lives in lane i & 63, slot i >> 6); the column state stays one per lane.  Slots are selected with wave-uniform
+// indices through unrolled selects (a runtime-indexed register array would go to scratch).
+template <class T> __device__ __forceinline__ T sel4(const T (&a)[TALL_S], int s) { return s == 0 ? a[0] : s == 1 ? a[1] : s == 2 ? a[2] : a[3]; }
+__device__ __forceinline__ bool solve_packed_tall(const LapArgs &A, int c, int lane, SmallLds &L) {
+    const bts_lap_work &w = A.w;
+    const double limit = A.limit, INF = __builtin_huge_val();
+    const int4 d = w.cdesc[c];
+    const int rs = d.x, cs = d.y, r = d.z & 0xff, cn = (d.z >> 8) & 0xff, ne = d.z >> 16, eb = d.w;
+    if (r >= TALL_R + 1 || cn > 64 || ne > SM_EDGES) return false;
+    int4 ri[TALL_S];
+#pragma unroll
+    for (int s = 0; s < TALL_S; ++s) ri[s] = lane + 64 * s < r ? w.rowinfo[rs + lane + 64 * s] : make_int4(0x7fffffff, 0, 0, 0);
+    const int my_col = lane < cn ? w.colid[cs + lane] : 0x7fffffff;
+    for (int e = lane; e < ne; e += 64) { L.ecost[e] = w.csr_cost[eb + e]; L.ecol[e] = w.csr_lcol[eb + e]; }
+    // rows in ascending id order: rank = number of rows with a smaller id, then every row moves to (rank & 63, rank >> 6)
+    int my_row[TALL_S], e_lo[TALL_S], e_hi[TALL_S], rank[TALL_S];
+#pragma unroll
+    for (int s = 0; s < TALL_S; ++s) { my_row[s] = 0x7fffffff; e_lo[s] = 0; e_hi[s] = 0; rank[s] = 0; }
+    for (int q = 0; q < r; ++q) {
+        const int idq = bcast_i(q < 64 ? ri[0].x : q < 128 ? ri[1].x : q < 192 ? ri[2].x : ri[3].x, q & 63);
+#pragma unroll
+        for (int s = 0; s < TALL_S; ++s) rank[s] += idq < ri[s].x ? 1 : 0;
+    }
+    for (int q = 0; q < r; ++q) {
+        const int qs = q >> 6, ql = q & 63;
+        const int4 rq = make_int4(bcast_i(qs == 0 ? ri[0].x : qs == 1 ? ri[1].x : qs == 2 ? ri[2].x : ri[3].x, ql),
+                                  bcast_i(qs == 0 ? ri[0].y : qs == 1 ? ri[1].y : qs == 2 ? ri[2].y : ri[3].y, ql),
+                                  bcast_i(qs == 0 ? ri[0].z : qs == 1 ? ri[1].z : qs == 2 ? ri[2].z : ri[3].z, ql), 0);
+        const int rk = bcast_i(sel4(rank, qs), ql);
+#pragma unroll
+        for (int s = 0; s < TALL_S; ++s)
+            if (lane == (rk & 63) && s == (rk >> 6)) { my_row[s] = rq.x; e_lo[s] = rq.y - eb; e_hi[s] = rq.z - eb; }
+    }
+    lds_sync();
+    double u[TALL_S];
+    int xr[TALL_S];
+#pragma unroll
+    for (int s = 0; s < TALL_S; ++s) {
+        u[s] = limit; xr[s] = -1;
+        for (int e = e_lo[s]; e < e_hi[s]; ++e) u[s] = fmin(u[s], L.ecost[e]);
+    }
+    int yc = -1;                 // column -> local row
+    double v = 0.0;
+    for (int i0 = 0; i0 < r; ++i0) {
+        double dist = INF;
+        int pred = -1;
+        bool scanned = false;
+        double exit_d = limit - bcast_d(sel4(u, i0 >> 6), i0 & 63);
+        int exit_row = i0, cur = i0, end_col = -1;
+        double dcur = 0.0, mu = 0.0;
+        for (;;) {
+            const int cs_ = cur >> 6, cl = cur & 63;
+            const double ucur = bcast_d(sel4(u, cs_), cl);
+            const int e0 = bcast_i(sel4(e_lo, cs_), cl), e1 = bcast_i(sel4(e_hi, cs_), cl);
+            for (int e = e0; e < e1; ++e) {
+                if (L.ecol[e] == lane && !scanned) {
+                    const double nd = dcur + ((L.ecost[e] - ucur) - v);
+                    if (nd < dist) { dist = nd; pred = cur; }
+                }
+            }
+            const bool cand = lane < cn && !scanned;
+            const double bd = wave_min_d(cand ? dist : INF, cn);
+            if (!(bd < INF) || exit_d < bd) { mu = exit_d; break; }
+            const unsigned long long tie = __ballot(cand && dist == bd);
+            int bl = __ffsll((long long)tie) - 1;
+            if (tie & (tie - 1)) {
+                int bc = 0x7fffffff;
+                for (unsigned long long t = tie; t; t &= t - 1) {
+                    const int l = __ffsll((long long)t) - 1, cc = bcast_i(my_col, l);
+                    if (cc < bc) { bc = cc; bl = l; }
+                }
+            }
+            const int owner = bcast_i(yc, bl);
+            if (owner < 0) { mu = bd; end_col = bl; break; }
+            if (lane == bl) scanned = true;
+            cur = owner; dcur = bd;
+            const double e2 = bd + (limit - bcast_d(sel4(u, owner >> 6), owner & 63));
+            if (e2 < exit_d) { exit_d = e2; exit_row = owner; }
+        }
+        // duals: every scanned column hands its delta to the row that owns it
+        const double delta = scanned ? mu - dist : 0.0;
+        if (scanned) v -= delta;
+#pragma unroll
+        for (int s = 0; s < TALL_S; ++s) {
+            const double dfrom = __shfl(delta, xr[s] >= 0 ? xr[s] : 0);
+            if (xr[s] >= 0) u[s] += dfrom;
+            if (lane == (i0 & 63) && s == (i0 >> 6)) u[s] += mu;
+        }
+        // augment
+        int j = end_col;
+        if (j < 0) {
+            if (exit_row == i0) continue;
+            j = bcast_i(sel4(xr, exit_row >> 6), exit_row & 63);
+#pragma unroll
+            for (int s = 0; s < TALL_S; ++s) if (lane == (exit_row & 63) && s == (exit_row >> 6)) xr[s] = -1;
+        }
+        for (;;) {
+            const int i = bcast_i(pred, j);
+            const int jn = bcast_i(sel4(xr, i >> 6), i & 63);
+#pragma unroll
+            for (int s = 0; s < TALL_S; ++s) if (lane == (i & 63) && s == (i >> 6)) xr[s] = j;
+            if (lane == j) yc = i;
+            if (i == i0) break;
+            j = jn;
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < TALL_S; ++s) {
+        const int xcol = __shfl(my_col, xr[s] >= 0 ? xr[s] : 0);
+        if (lane + 64 * s < r) A.x[my_row[s]] = xr[s] >= 0 ? xcol : -1;
+    }
+    {
+        const int ys = yc >= 0 ? yc >> 6 : 0, yl = yc >= 0 ? yc & 63 : 0;
+        int yrow = 0;
+#pragma unroll
+        for (int s = 0; s < TALL_S; ++s) { const int t = __shfl(my_row[s], yl); if (ys == s) yrow = t; }
+        if (lane < cn) A.y[my_col] = yc >= 0 ? yrow : -1;
+    }
+    lds_sync();                 // the next component of this wavefront reuses L
+    return true;
+}
+
 // General path (any component size): state in global memory.
 __device__ __forceinline__ void solve_component(const LapArgs &A, int c, int lane) {
     const bts_lap_work &w = A.w;
@@ -880,7 +1006,7 @@ template <int EC> __global__ __launch_bounds__(1024) void k_lap(LapPair P) {
     SmallLds *lds = reinterpret_cast<SmallLds *>(lds_raw);
     const int gw = blockIdx.y * (nth >> 6) + wid, nw = (solo ? 1 : gridDim.y) * (nth >> 6);
     for (int c = gw; c < C; c += nw)
-        if (!solve_packed(A, c, lane, lds[wid])) solve_component(A, c, lane);
+        if (!solve_packed(A, c, lane, lds[wid]) && !solve_packed_tall(A, c, lane, lds[wid])) solve_component(A, c, lane);
 #ifdef BTS_LAP_TRACE
     __syncthreads();
     if (blockIdx.y <= 1) TR(w, 11 + blockIdx.y);

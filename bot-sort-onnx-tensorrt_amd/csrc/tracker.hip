@@ -78,13 +78,14 @@ struct Dev {
     int record;                // keep dense cost matrices (tests / inspection)
     int motion_gate;           // optional Mahalanobis gate on the stage-1 edges (tk_gate_edges)
     double gate_thr;           // chi2inv95[4], D:139-149
-    int filter;                // appearance term by fp8-MFMA pre-filter + exact float32 refine
-    uint8_t *body_h, *face_h, *det_h, *dface_h;       // fp8 unit-vector shadows of body_curr/face_curr and of the frame's rows
-    float *body_n, *face_n, *det_n, *dface_n;         // their float32 L2 norms
-    float *approx, *approx_f;                          // [T][Mx] split-K accumulation of the pre-filter, body / face (self-cleaning)
+    int filter;                // appearance term by int8-MFMA pre-filter + exact float32 refine
+    int8_t *body_h, *face_h, *det_h, *dface_h;        // int8 shadows of body_curr/face_curr and of the frame's rows (feat::to_i8_row)
+    float *body_m, *face_m, *det_m, *dface_m;         // their records [rows][feat::I8_META]: scale, residual, prefix norms
+    int32_t *approx, *approx_f;                        // [T][Mx] split-K accumulation of the pre-filter, body / face (self-cleaning; exact integers)
     uint32_t *cbits;                                   // [T][cb_ld] candidate bitmap of the one-pass pre-filter (self-cleaning)
     int cb_ld;                                         // 32-bit words per bitmap row
-    float eps_body, eps_face;                          // absolute error bounds of the approximate cosines (feat::q8_cos_error)
+    float gate_sim;                                    // the similarity the appearance term must reach: 1 - appearance_thresh
+    int32_t *fstat;                                    // [8] pre-filter counters of the frame: K stages run, tiles, prefix exits, candidates
     const InDesc *in;          // inputs of the current step: descriptor in memory (hipGraph replay) ...
     InDesc iv;                 // ... or by value in the kernel arguments (eager launches, in == nullptr)
 };
@@ -221,6 +222,7 @@ __device__ __forceinline__ void prep_dets(const Dev &d) {
                                        [&](int p, int j, int) { d.hi_idx[p] = j; }, [&](int p, int j, int) { d.lo_idx[p] = j; });
     const int nhi = nn.x, nlo = nn.y;
     if (tid < 3 * BTS_LAP_HDR_INTS) d.lap_hdr[tid] = 0;
+    if (tid < 16 && d.filter) d.fstat[tid] = tid == 8 || tid == 12 ? 0x7fffffff : 0;
     if (tid == 0) {
         h[H_NHI] = nhi; h[H_NLO] = nlo; h[H_NDETS] = m;
         h[H_DIMS1 + 1] = nhi; h[H_DIMS2 + 1] = nlo;
@@ -257,12 +259,26 @@ __device__ __forceinline__ void prep_free(const Dev &d) {
 }
 
 // ---- K2: STrack.multi_predict over the pool (D:524-536 + D:265-302) ---------------------------------
-// fp8 unit-vector shadows + norms of this frame's (raw) detection rows for the appearance pre-filter
+// int8 shadows + records of this frame's (raw) detection rows for the appearance pre-filter
 __device__ __forceinline__ void cvt_body(const Dev &d, long blk) {        // four rows per 1024-thread workgroup
     const long j = blk * 4 + feat::row_group();
     const bool on = j < IN(d, m);
-    feat::to_q8_row(IN(d, feats) + j * d.D, d.det_h + j * d.D, d.det_n + j, d.D, on);
-    if (d.Df) feat::to_q8_row(IN(d, face_feats) + j * d.Df, d.dface_h + j * d.Df, d.dface_n + j, d.Df, on);
+    feat::to_i8_row(IN(d, feats) + j * d.D, d.det_h + j * d.D, d.det_m + j * feat::I8_META, d.D, d.gate_sim, on);
+    if (d.Df) feat::to_i8_row(IN(d, face_feats) + j * d.Df, d.dface_h + j * d.Df, d.dface_m + j * feat::I8_META, d.Df, d.gate_sim, on);
+}
+// A track's latest feature IS a detection row (curr = the matched / born detection's renormalised row, D:492-502): its
+// shadow and record are that detection's, copied (the record's slack covers the 1e-7 between a raw row and its in-place
+// renormalised self).  Called by the 256 threads that handle the row.
+__device__ __forceinline__ void copy_shadow(const int8_t *src_q, const float *src_m, int8_t *dst_q, float *dst_m, int dim) {
+    const int t = feat::row_tid();
+    if (dim % 16 == 0) {
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(src_q);
+        uint4 *d4 = reinterpret_cast<uint4 *>(dst_q);
+        for (int k = t; k < dim / 16; k += feat::ROW_G) d4[k] = s4[k];
+    } else {
+        for (int k = t; k < dim; k += feat::ROW_G) dst_q[k] = src_q[k];
+    }
+    if (t < feat::I8_META) dst_m[t] = src_m[t];
 }
 
 // one launch: the first workgroups build the frame's lists (two jobs of nch chunks each, the detection lists, the free slots),
@@ -304,12 +320,6 @@ constexpr int CT_ROWS = 16, CT_COLS = 256;
 __device__ __forceinline__ float face_fixup(float s) {
     const double dd = fabs((double)s - 0.9999999);
     return dd <= 1e-08 + 1e-08 * 0.9999999 ? 0.0f : s;
-}
-
-// candidate test: could the exact similarity reach the gate?  (NaN/inf approximations are candidates)
-// `approx` approximates the COSINE of the pair with absolute error <= err (feat::q8_cos_error); na, nb = the norms.
-__device__ __forceinline__ bool is_candidate(float approx, float na, float nb, float gate, float err) {
-    return !((approx + err) * (na * nb) < gate - 3e-5f);
 }
 
 // ---- optional motion gate on the stage-1 pairs --------------------------------------------------------------------
@@ -365,7 +375,7 @@ __device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, 
     __shared__ double sarea[ROWS];
     __shared__ int sflag[ROWS];
     __shared__ int sslot[ROWS];
-    __shared__ float sna[ROWS], snf[ROWS];
+    __shared__ float4 srec[ROWS], srec_f[ROWS];       // full-row records of the tile's tracks (split-K form of the pre-filter)
     __shared__ iou::ScreenBox sboxf[ROWS];       // row boxes rounded OUTWARD to 16-bit pixels (conservative overlap pre-test)
     const int32_t *h = d.hdr;
     const int n = STAGE == 1 ? h[H_NPOOL] : STAGE == 2 ? h[H_NR2] : h[H_NUNC];
@@ -393,8 +403,11 @@ __device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, 
         }
     }
     const double bb[4] = {d.det_tlbr[det * 4 + 0], d.det_tlbr[det * 4 + 1], d.det_tlbr[det * 4 + 2], d.det_tlbr[det * 4 + 3]};
-    float nbq = 0.0f, nfq = 0.0f;
-    if (STAGE == 1 && MODE == 1 && accum && live) { nbq = d.det_n[det]; if (d.Df) nfq = d.dface_n[det]; }
+    float4 crec = make_float4(0.f, 0.f, 0.f, 0.f), crec_f = crec;
+    if (STAGE == 1 && MODE == 1 && accum && live) {
+        crec = feat::i8_rec(d.det_m + (long)det * feat::I8_META, feat::I8_NCHK);
+        if (d.Df) crec_f = feat::i8_rec(d.dface_m + (long)det * feat::I8_META, feat::I8_NCHK);
+    }
     if (threadIdx.x < ROWS && i0 + threadIdx.x < n) {
         const int i = i0 + threadIdx.x;
         double box[4] = {abox[i * 4 + 0], abox[i * 4 + 1], abox[i * 4 + 2], abox[i * 4 + 3]};
@@ -406,8 +419,10 @@ __device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, 
         if (STAGE == 1 && MODE == 1) {
             const int s = d.pool_slot[i];
             sslot[threadIdx.x] = s;
-            sna[threadIdx.x] = d.body_n[s];
-            snf[threadIdx.x] = d.Df ? d.face_n[s] : 0.0f;
+            if (accum) {
+                srec[threadIdx.x] = feat::i8_rec(d.body_m + (long)s * feat::I8_META, feat::I8_NCHK);
+                if (d.Df) srec_f[threadIdx.x] = feat::i8_rec(d.face_m + (long)s * feat::I8_META, feat::I8_NCHK);
+            }
         }
     }
     __syncthreads();
@@ -421,7 +436,6 @@ __device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, 
     const bool all_rows = MODE == 2 || (MODE == 0 && (d.record || STAGE == 1)) || !(limit < 1.0);
     const int rows = min(ROWS, n - i0);
     const unsigned long long livemask = __ballot(live);
-    const float gate = 1.0f - d.app;
     // Edges are staged per wavefront in LDS (ballot + lane-prefix, no atomics) and appended to the
     // solver's list with ONE counter bump per flush and coalesced stores: a returning atomic costs a
     // memory round trip, far too slow to pay per edge.
@@ -465,20 +479,20 @@ __device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, 
     if (MODE == 1 && STAGE == 1 && accum) {
         uint32_t cmask = 0;
         if (live) {
-            auto scan = [&](float *acc, const float *srow, float ncol, float eps) {
-                float *p = acc + (long)(i0 + rc) * d.Mx + q;
-                float av[16];
+            auto scan = [&](int32_t *acc, const float4 *srow, const float4 &col) {
+                int32_t *p = acc + (long)(i0 + rc) * d.Mx + q;
+                int32_t av[16];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) av[u] = u < crows ? p[(long)u * d.Mx] : 0.0f;
+                for (int u = 0; u < 16; ++u) av[u] = u < crows ? p[(long)u * d.Mx] : 0;
 #pragma unroll
                 for (int u = 0; u < 16; ++u) {
                     if (u >= crows) continue;
-                    p[(long)u * d.Mx] = 0.0f;
-                    cmask |= (uint32_t)is_candidate(av[u], srow[rc + u], ncol, gate, eps) << u;
+                    p[(long)u * d.Mx] = 0;
+                    cmask |= (uint32_t)!feat::i8_excluded(av[u], srow[rc + u], col) << u;
                 }
             };
-            scan(d.approx, sna, nbq, d.eps_body);
-            if (d.Df) scan(d.approx_f, snf, nfq, d.eps_face);
+            scan(d.approx, srec, crec);
+            if (d.Df) scan(d.approx_f, srec_f, crec_f);
         }
         unsigned long long mine = 0;
 #pragma unroll
@@ -615,58 +629,29 @@ __global__ __launch_bounds__(CT_COLS) __attribute__((amdgpu_waves_per_eu(4, 8)))
     edges_all<1, 1, ROWS, true>(d, w, blockIdx.x, gridDim.x, accum);
 }
 
-// ---- appearance pre-filter: fp8 MFMA GEMM + exact float32 refine ------------------------------------------------
+// ---- appearance pre-filter: int8 MFMA GEMM with prefix exits + exact float32 refine -----------------------------
 // Stage-1 appearance can change a cost only where  min(1 - body_sim, 1 - face_sim) <= appearance_thresh
 // (D:1543-1547), i.e. for similarities >= 0.75 -- about one pair per detection out of N*M.  So the
-// N x M x D contraction runs on the fp8 matrix cores over 8-bit unit-vector shadows of the features, and only
-// pairs whose *bounded-error* approximation could reach the gate (feat::q8_cos_error) are recomputed exactly in
-// float32 by the stage-1 tile kernel (same value the dense float32 path produces up to summation order); the
+// N x M x D contraction runs on the matrix cores over int8 shadows of the feature rows (feat::to_i8_row), and only
+// pairs that a RIGOROUS upper bound on the exact dot product cannot exclude (feat::i8_excluded) are recomputed exactly
+// in float32 by the stage-1 tile kernel (same value the dense float32 path produces up to summation order); the
 // pair's single edge then carries min(IoU cost, 1 - sim) = np.minimum of D:1554.
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+// The bound works on any PREFIX of the rows (squared distances only grow with more elements), so a tile walks K in
+// stages and stops at the first checkpoint where (nearly) nothing in it can still reach the gate: on embeddings whose
+// non-matching pairs are far from the gate that is after ~5/16 of K; the survivors of an early stop are candidates
+// like the others (a superset -- the exact refinement decides).
+typedef int i32x16 __attribute__((ext_vector_type(16)));
 constexpr int FBM = 128, FBN = 128;      // tile of the pre-filter GEMM
-constexpr int DBK = 128;                 // its K step: 128 fp8 elements = one full 128-byte line per row and stage
+constexpr int DBK = feat::I8_STAGE;      // its K step: 128 int8 elements = one full 128-byte line per row and stage
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, slot = bid / 8;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
 }
 
-// epilogue of the pre-filter tiles: candidate test (or split-K accumulation) of a 128 x 128 accumulator tile;
-// the tile's row/column norms go through LDS (`snorm`: 256 floats, the operand tiles are dead by now)
-template <bool FACE>
-__device__ __forceinline__ void filter_epilogue(const Dev &d, f32x16 (&acc)[2][2], float *snorm, float my_norm, int bm, int bn, int n, int m, int accum) {
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid >> 1, wc = wid & 1;
-    const int frow = lane & 31, fh = lane >> 5;
-    const float eps = FACE ? d.eps_face : d.eps_body, gate = 1.0f - d.app;
-    float *approx = FACE ? d.approx_f : d.approx;
-    __syncthreads();
-    if (!accum) snorm[tid] = my_norm;            // (fetched in the prologue: two dependent loads that ride under the K loop)
-    __syncthreads();
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int qq = wc * 64 + ni * 32 + frow, q = bn * FBN + qq;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ii = wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh, i = bm * FBM + ii;
-                const float val = acc[mi][ni][r] * feat::Q8_UNSCALE;
-                if (!(i < n && q < m)) continue;
-                if (accum) atomicAdd(&approx[(long)i * d.Mx + q], val);
-                else if (is_candidate(val, snorm[ii], snorm[FBM + qq], gate, eps))      // rare: about one per detection column
-                    atomicOr(&d.cbits[(long)i * d.cb_ld + (q >> 5)], 1u << (q & 31));
-            }
-        }
-}
-
-// Grid: ntiles * nsplit GEMM workgroups (tile-major inside a K split), followed -- body pass only --
-// by the workgroups of the Kalman predict, which is independent of the contraction and shares the launch.
-// accum: add the partial products into `approx` (split K; the stage-1 tile kernel applies the
-// candidate test once they are complete); otherwise test here and set bits in `cbits`.
-//
-// 128 x 128 tiles of v_mfma_scale_f32_32x32x64_f8f6f4 (fp8 x fp8, unit block scales) over the 8-bit unit-vector shadows.  What bounds this
-// kernel is neither HBM nor the matrix cores but the CU's fill path (a 128 x 128 tile needs 64 B/clk/CU of
-// operand traffic at full MFMA rate with 2-byte operands) -- hence 1-byte operands -- and how the operands reach LDS:
+// 128 x 128 tiles of v_mfma_i32_32x32x32_i8 over the int8 shadows.  What bounds this kernel is neither HBM nor the
+// matrix cores but the CU's fill path (a 128 x 128 tile needs 64 B/clk/CU of operand traffic at full MFMA rate with
+// 2-byte operands) -- hence 1-byte operands -- and how the operands reach LDS:
 //   * straight from memory (global_load_lds, 16 B per lane: no staging registers, no ds_write pass), double-buffered
 //     in stages of DBK = 128 elements: a row of a stage is one FULL 128-byte line (a CU's load path retires about one
 //     line segment per 4 clocks -- with 64-byte half rows the same bytes cost twice the load-path time), and the L2
@@ -676,7 +661,7 @@ __device__ __forceinline__ void filter_epilogue(const Dev &d, f32x16 (&acc)[2][2
 //     and the fragment reads undo the permutation; swz(row) = (row >> 1) & 7 makes every ds_read_b128
 //     lane group hit 16 distinct 16-byte slots (0 bank conflicts measured);
 //   * one workgroup barrier per stage behind an s_waitcnt vmcnt issued in inline assembly together with it;
-//   * a lane's two 16-byte fragment reads are the 32 K values it feeds to ONE K=64 MFMA (which K indices a lane
+//   * a lane's 16-byte fragment read is the 16 K values it feeds to ONE K = 32 MFMA (which K indices a lane
 //     holds is free as long as both operands agree).
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
@@ -690,7 +675,6 @@ template <int N> __device__ __forceinline__ void wait_stage_barrier() {
 // serialise the pipeline.  The explicit lgkmcnt wait below takes the fragments as operands so that no
 // MFMA can be scheduled above it.
 typedef int v4i __attribute__((ext_vector_type(4)));
-typedef int v8i __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ v4i lds_read16(unsigned addr) {
     v4i v;
     asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
@@ -699,20 +683,111 @@ __device__ __forceinline__ v4i lds_read16(unsigned addr) {
 template <int N> __device__ __forceinline__ void lds_wait(v4i &a, v4i &b, v4i &c, v4i &e) {
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(e) : "n"(N));
 }
-__device__ __forceinline__ long lo8(const v4i &v) { return ((long)(unsigned)v.y << 32) | (unsigned)v.x; }
-__device__ __forceinline__ long hi8(const v4i &v) { return ((long)(unsigned)v.w << 32) | (unsigned)v.z; }
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 lds_read16f(unsigned addr) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+// (every operand of a wait must be a DIFFERENT variable: naming one twice makes the compiler copy it -- before the wait)
+__device__ __forceinline__ void lds_wait_f(f32x4 &a, f32x4 &b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void lds_wait_i(v4i &a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a)); }
+__device__ __forceinline__ void lds_wait_f1(f32x4 &a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a)); }
+__device__ __forceinline__ void lds_write8(unsigned addr, float x, float y) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 v = {x, y};
+    asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_write16(unsigned addr, f32x4 v) { asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_write4(unsigned addr, int v) { asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
 
+// minimum / maximum over a wavefront, returned to every lane: DPP steps inside the 16-lane rows, then the four rows through the scalar side
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float rdlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ float wave_min_f(float v) {
+    v = fminf(v, dpp_f<0xB1>(v)); v = fminf(v, dpp_f<0x4E>(v)); v = fminf(v, dpp_f<0x141>(v)); v = fminf(v, dpp_f<0x140>(v));
+    return fminf(fminf(rdlane_f(v, 0), rdlane_f(v, 16)), fminf(rdlane_f(v, 32), rdlane_f(v, 48)));
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+    v = fmaxf(v, dpp_f<0xB1>(v)); v = fmaxf(v, dpp_f<0x4E>(v)); v = fmaxf(v, dpp_f<0x141>(v)); v = fmaxf(v, dpp_f<0x140>(v));
+    return fmaxf(fmaxf(rdlane_f(v, 0), rdlane_f(v, 16)), fmaxf(rdlane_f(v, 32), rdlane_f(v, 48)));
+}
+
+// the per-thread view of a 128 x 128 tile's operands in LDS: wave (wr, wc) owns the 64 x 64 quadrant, as 2 x 2 MFMA blocks
+struct FragMap {
+    int aoff[2], boff[2], asw[2], bsw[2];
+    __device__ __forceinline__ void init(int wr, int wc, int frow) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const int ra = wr * 64 + x * 32 + frow, rb = wc * 64 + x * 32 + frow;
+            aoff[x] = ra * DBK; asw[x] = (ra >> 1) & 7;
+            boff[x] = rb * DBK; bsw[x] = (rb >> 1) & 7;
+        }
+    }
+};
+// one K stage (128 int8 per row) of a wave's quadrant: four K = 32 steps, two per batch of LDS reads
+// (VAR 1: timing experiment only -- the same operand bytes through the fp8 K = 64 instruction; results are meaningless)
+typedef int v8i_ __attribute__((ext_vector_type(8)));
+typedef float f32x16_ __attribute__((ext_vector_type(16)));
+template <int VAR = 0>
+__device__ __forceinline__ void stage_mfma(unsigned abase, unsigned bbase, const FragMap &fm, int fh, i32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        v4i fa[2][2], fb[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int u = (h * 2 + t) * 2 + fh;          // K step (2 h + t): bytes [32 (2 h + t), +32), this lane half takes 16 of them
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                fa[t][x] = lds_read16(abase + fm.aoff[x] + ((u ^ fm.asw[x]) << 4));
+                fb[t][x] = lds_read16(bbase + fm.boff[x] + ((u ^ fm.bsw[x]) << 4));
+            }
+        }
+        lds_wait<0>(fa[0][0], fa[0][1], fb[0][0], fb[0][1]);
+        lds_wait<0>(fa[1][0], fa[1][1], fb[1][0], fb[1][1]);
+        if constexpr (VAR == 1) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const v8i_ av = {fa[0][mi].x, fa[0][mi].y, fa[0][mi].z, fa[0][mi].w, fa[1][mi].x, fa[1][mi].y, fa[1][mi].z, fa[1][mi].w};
+                    const v8i_ bv = {fb[0][ni].x, fb[0][ni].y, fb[0][ni].z, fb[0][ni].w, fb[1][ni].x, fb[1][ni].y, fb[1][ni].z, fb[1][ni].w};
+                    f32x16_ c;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) c[r] = __int_as_float(acc[mi][ni][r]);
+                    c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, c, 0, 0, 0, 127, 0, 127);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] = __float_as_int(c[r]);
+                }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[t][mi], fb[t][ni], acc[mi][ni], 0, 0, 0);
+        }
+    }
+}
+
+// Split-K form for SMALL problems (too few tiles to fill the chip): ntiles * nsplit GEMM workgroups (tile-major inside
+// a K split) add their exact integer partial products into `approx`; the stage-1 tile kernel applies the candidate test
+// once they are complete (and clears them).  Body pass only: followed by the workgroups of the Kalman predict, which is
+// independent of the contraction and shares the launch.
 template <bool FACE>
-__global__ __launch_bounds__(256) void k_filter_dma(Dev d, int m_max, int ntiles, int nsplit, int accum) {
-    __shared__ __attribute__((aligned(1024))) uint8_t As2[DNS][FBM * DBK];
-    __shared__ __attribute__((aligned(1024))) uint8_t Bs2[DNS][FBN * DBK];
+__global__ __launch_bounds__(256) void k_filter_splitk(Dev d, int m_max, int ntiles, int nsplit) {
+    __shared__ __attribute__((aligned(1024))) int8_t As2[DNS][FBM * DBK];
+    __shared__ __attribute__((aligned(1024))) int8_t Bs2[DNS][FBN * DBK];
     if ((int)blockIdx.x >= ntiles * nsplit) {
         if (!FACE) predict_body(d, (int)blockIdx.x - ntiles * nsplit);
         return;
     }
     const int n = d.hdr[H_NPOOL], m = d.hdr[H_NHI];
     const int Dd = FACE ? d.Df : d.D;
-    const uint8_t *A = FACE ? d.face_h : d.body_h, *B = FACE ? d.dface_h : d.det_h;
+    const int8_t *A = FACE ? d.face_h : d.body_h, *B = FACE ? d.dface_h : d.det_h;
     const int nbn = (m_max + FBN - 1) / FBN;
     const int ksplit = blockIdx.x / ntiles;
     const int vb = xcd_remap(blockIdx.x % ntiles, ntiles);
@@ -726,7 +801,7 @@ __global__ __launch_bounds__(256) void k_filter_dma(Dev d, int m_max, int ntiles
     // piece s of a stage = rows [(4 s + wid) * 8, +8): one 1-KiB wavefront load of 8 FULL 128-byte lines,
     // lane -> (row, 16-byte chunk); swz(row) = (row >> 1) & 7 spreads every ds_read_b128 lane group over 16 slots
     const int prow = lane >> 3, pchunk = lane & 7;
-    const uint8_t *asrc[4], *bsrc[4];
+    const int8_t *asrc[4], *bsrc[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const int r = (4 * s + wid) * 8 + prow;
@@ -735,14 +810,6 @@ __global__ __launch_bounds__(256) void k_filter_dma(Dev d, int m_max, int ntiles
         asrc[s] = A + (long)d.pool_slot[i < n ? i : bm * FBM] * Dd + sw;       // rows past the end: any valid row, ignored later
         bsrc[s] = B + (long)d.hi_idx[j < m ? j : bn * FBN] * Dd + sw;
     }
-    // this thread's row (threads 0-127) or column (128-255) norm for the epilogue's candidate test
-    float my_norm = 0.0f;
-    if (!accum) {
-        const float *na = FACE ? d.face_n : d.body_n, *nb = FACE ? d.dface_n : d.det_n;
-        const int g = tid < FBM ? bm * FBM + tid : bn * FBN + (tid - FBM);
-        if (tid < FBM) { if (g < n) my_norm = na[d.pool_slot[g]]; }
-        else if (g < m) my_norm = nb[d.hi_idx[g]];
-    }
     auto stage = [&](int buf, int kt) {                  // 8 wavefront loads per stage and wave
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -750,93 +817,86 @@ __global__ __launch_bounds__(256) void k_filter_dma(Dev d, int m_max, int ntiles
             __builtin_amdgcn_global_load_lds((gbl_void *)(bsrc[s] + kt * DBK), (lds_void *)&Bs2[buf][(4 * s + wid) * 8 * DBK], 16, 0, 0);
         }
     };
-    f32x16 acc[2][2];
+    i32x16 acc[2][2];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0;
     const int frow = lane & 31, fh = lane >> 5;
     const unsigned lds_a = (unsigned)(__UINTPTR_TYPE__)(lds_void *)&As2[0][0], lds_b = (unsigned)(__UINTPTR_TYPE__)(lds_void *)&Bs2[0][0];
-    int aoff[2], boff[2], asw[2], bsw[2];
-#pragma unroll
-    for (int x = 0; x < 2; ++x) {
-        const int ra = wr * 64 + x * 32 + frow, rb = wc * 64 + x * 32 + frow;
-        aoff[x] = ra * DBK; asw[x] = (ra >> 1) & 7;
-        boff[x] = rb * DBK; bsw[x] = (rb >> 1) & 7;
-    }
+    FragMap fm;
+    fm.init(wr, wc, frow);
     stage(0, kt0);
     int cur = 0;
     for (int kt = kt0; kt < kt1; ++kt) {
         wait_stage_barrier<0>();             // stage kt has landed (the only one in flight); every wave is past its reads of the other buffer
         if (kt + 1 < kt1) stage(cur ^ 1, kt + 1);
-        const unsigned abase = lds_a + cur * (FBM * DBK), bbase = lds_b + cur * (FBN * DBK);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {        // the stage's two K = 64 blocks; a lane holds 32 contiguous K values of each
-            v4i fa[2][2], fb[2][2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int u = h * 4 + fh * 2 + t;
-#pragma unroll
-                for (int x = 0; x < 2; ++x) {
-                    fa[t][x] = lds_read16(abase + aoff[x] + ((u ^ asw[x]) << 4));
-                    fb[t][x] = lds_read16(bbase + boff[x] + ((u ^ bsw[x]) << 4));
-                }
-            }
-            lds_wait<0>(fa[0][0], fa[0][1], fb[0][0], fb[0][1]);
-            lds_wait<0>(fa[1][0], fa[1][1], fb[1][0], fb[1][1]);
-            v8i av[2], bv[2];
-#pragma unroll
-            for (int x = 0; x < 2; ++x) {
-                av[x] = v8i{fa[0][x].x, fa[0][x].y, fa[0][x].z, fa[0][x].w, fa[1][x].x, fa[1][x].y, fa[1][x].z, fa[1][x].w};
-                bv[x] = v8i{fb[0][x].x, fb[0][x].y, fb[0][x].z, fb[0][x].w, fb[1][x].x, fb[1][x].y, fb[1][x].z, fb[1][x].w};
-            }
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)       // K = 64 per instruction, formats fp8 x fp8, block scales 2^0
-                    acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av[mi], bv[ni], acc[mi][ni], 0, 0, 0, 127, 0, 127);
-        }
+        stage_mfma(lds_a + cur * (FBM * DBK), lds_b + cur * (FBN * DBK), fm, fh, acc);
         cur ^= 1;
     }
-    filter_epilogue<FACE>(d, acc, reinterpret_cast<float *>(&As2[0][0]), my_norm, bm, bn, n, m, accum);
+    int32_t *approx = FACE ? d.approx_f : d.approx;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int q = bn * FBN + wc * 64 + ni * 32 + frow;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = bm * FBM + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (i < n && q < m) atomicAdd(&approx[(long)i * d.Mx + q], acc[mi][ni][r]);
+            }
+        }
 }
 
-// Persistent form for problems with more tiles than resident workgroups (no split-K): FILTER_PW workgroups walk the
-// tiles, and the chain of dependent loads that opens a tile (index lists -> row pointers -> first stage) is taken off
-// the tile's critical path: the NEXT tile's indices are fetched while the current K loop runs, and its first stage is
-// issued before the current tile's epilogue (both operand buffers are idle then; the norms sit in their own LDS words).
+// The one-pass form: FILTER_PW persistent workgroups walk the tiles (2 resident per CU), each tile runs its K loop up to the
+// first checkpoint that lets it stop (or to the end) and sets the candidate bits itself.  The chain of dependent loads
+// that opens a tile (index lists -> row pointers -> first stage) is taken off the tile's critical path: the NEXT tile's
+// indices are fetched while the current K loop runs, and its first stage is issued before the current tile's last
+// candidate test (the operand buffer it lands in is idle then).
 constexpr int FILTER_PW = 512;       // 2 resident workgroups per CU (64 KiB of operand stages each)
-template <bool FACE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_filter_dma_p(Dev d, int m_max, int ntiles) {
-    __shared__ __attribute__((aligned(1024))) uint8_t As2[DNS][FBM * DBK];
-    __shared__ __attribute__((aligned(1024))) uint8_t Bs2[DNS][FBN * DBK];
-    __shared__ float snorm[FBM + FBN];
-    if ((int)blockIdx.x >= FILTER_PW) {
-        if (!FACE) predict_body(d, (int)blockIdx.x - FILTER_PW);
+enum { FS_STAGES = 0, FS_TILES, FS_EARLY, FS_CAND, FS_CHECKS };     // ([5..7]: clock cycles / 64 in candidate tests, stage waits, in total, summed over the workgroups)
+template <bool FACE, int VAR = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_filter_i8(Dev d, int m_max, int ntiles, int gemm_blocks) {
+    __shared__ __attribute__((aligned(1024))) int8_t As2[DNS][FBM * DBK];
+    __shared__ __attribute__((aligned(1024))) int8_t Bs2[DNS][FBN * DBK];
+    __shared__ float4 srec2[2][FBM + FBN];       // records of the tile's rows / columns for the checkpoint being tested (two
+                                                 // images: a test never waits for the readers of the previous one)
+    __shared__ __attribute__((aligned(16))) int s_cnt[2][4];     // survivors per wavefront
+    __shared__ __attribute__((aligned(16))) float sred[2][8];    // {min uh, max alpha, max r, -} of the rows' records, per row wavefront
+    if ((int)blockIdx.x >= gemm_blocks) {
+#ifdef BTS_FILTER_TRACE
+        const int p_beg = (int)(((long long)__builtin_amdgcn_s_memrealtime()) & 0x3fffffff);
+#endif
+        if (!FACE) predict_body(d, (int)blockIdx.x - gemm_blocks);
+#ifdef BTS_FILTER_TRACE
+        if (threadIdx.x == 0) { atomicMin(&d.fstat[12], p_beg); atomicMax(&d.fstat[13], (int)(((long long)__builtin_amdgcn_s_memrealtime()) & 0x3fffffff)); }
+#endif
         return;
     }
-    const int n = d.hdr[H_NPOOL], m = d.hdr[H_NHI];
+    const int n = __builtin_amdgcn_readfirstlane(d.hdr[H_NPOOL]), m = __builtin_amdgcn_readfirstlane(d.hdr[H_NHI]);     // (scalar registers)
     const int Dd = FACE ? d.Df : d.D;
-    const uint8_t *A = FACE ? d.face_h : d.body_h, *B = FACE ? d.dface_h : d.det_h;
-    const float *na = FACE ? d.face_n : d.body_n, *nb = FACE ? d.dface_n : d.det_n;
+    const int8_t *A = FACE ? d.face_h : d.body_h, *B = FACE ? d.dface_h : d.det_h;
+    const float *ma = FACE ? d.face_m : d.body_m, *mb = FACE ? d.dface_m : d.det_m;
     const int nbn = (m_max + FBN - 1) / FBN;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid >> 1, wc = wid & 1;
     const int kt_all = Dd / DBK;
+    int chk[feat::I8_NCHK];
+    feat::i8_checkpoints(kt_all, chk);
+    static_assert(feat::I8_NCHK == 4, "chk_at selects by hand (a runtime-indexed register array would go to scratch)");
+    auto chk_at = [&](int j) { return j == 0 ? chk[0] : j == 1 ? chk[1] : j == 2 ? chk[2] : chk[3]; };
+    auto skip_unused = [&](int j) { return (j < feat::I8_NCHK && chk_at(j) >= kt_all) ? (int)feat::I8_NCHK : j; };
     const int prow = lane >> 3, pchunk = lane & 7;
     const int frow = lane & 31, fh = lane >> 5;
     const unsigned lds_a = (unsigned)(__UINTPTR_TYPE__)(lds_void *)&As2[0][0], lds_b = (unsigned)(__UINTPTR_TYPE__)(lds_void *)&Bs2[0][0];
-    int aoff[2], boff[2], asw[2], bsw[2];
-#pragma unroll
-    for (int x = 0; x < 2; ++x) {
-        const int ra = wr * 64 + x * 32 + frow, rb = wc * 64 + x * 32 + frow;
-        aoff[x] = ra * DBK; asw[x] = (ra >> 1) & 7;
-        boff[x] = rb * DBK; bsw[x] = (rb >> 1) & 7;
-    }
-    // live tiles of this workgroup, in order: vt = blockIdx.x, + FILTER_PW, ... (tiles past the live extents are skipped)
+    FragMap fm;
+    fm.init(wr, wc, frow);
+    const unsigned lds_rec = (unsigned)(__UINTPTR_TYPE__)(lds_void *)&srec2[0][0], lds_cnt = (unsigned)(__UINTPTR_TYPE__)(lds_void *)&s_cnt[0][0],
+                   lds_red = (unsigned)(__UINTPTR_TYPE__)(lds_void *)&sred[0][0];
+    // live tiles of this workgroup, in order: vt = blockIdx.x, + gemm_blocks, ... (tiles past the live extents are skipped)
     auto next_live = [&](int vt, int &bm, int &bn) {
-        for (; vt < ntiles; vt += FILTER_PW) {
+        for (; vt < ntiles; vt += gemm_blocks) {
             const int vb = xcd_remap(vt, ntiles);
             bm = vb / nbn; bn = vb % nbn;
             if (bm * FBM < n && bn * FBN < m) return vt;
@@ -844,8 +904,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         return ntiles;
     };
     // index fetch of a tile: the table slots / detection indices of this lane's four A rows and four B rows, and of the
-    // row (threads 0-127) or column (128-255) whose norm this thread carries into the epilogue
-    auto fetch_idx = [&](int bm, int bn, int (&ia)[4], int (&ib)[4], int &inorm) {
+    // row (threads 0-127) or column (128-255) whose record this thread carries into the candidate tests
+    auto fetch_idx = [&](int bm, int bn, int (&ia)[4], int (&ib)[4], int &irec) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int r = (4 * s + wid) * 8 + prow;
@@ -854,109 +914,266 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             ib[s] = d.hi_idx[j < m ? j : bn * FBN];
         }
         const int g = tid < FBM ? bm * FBM + tid : bn * FBN + (tid - FBM);
-        inorm = tid < FBM ? (g < n ? d.pool_slot[g] : -1) : (g < m ? d.hi_idx[g] : -1);
+        irec = tid < FBM ? d.pool_slot[g < n ? g : bm * FBM] : d.hi_idx[g < m ? g : bn * FBN];
     };
-    const uint8_t *asrc[4], *bsrc[4];
+    unsigned asrc[4], bsrc[4];                           // byte offsets into A / B (tables up to 4 GiB of shadows)
     auto set_src = [&](const int (&ia)[4], const int (&ib)[4]) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int r = (4 * s + wid) * 8 + prow;
-            const int sw = (pchunk ^ ((r >> 1) & 7)) * 16;
-            asrc[s] = A + (long)ia[s] * Dd + sw;
-            bsrc[s] = B + (long)ib[s] * Dd + sw;
+            const unsigned sw = (unsigned)((pchunk ^ ((r >> 1) & 7)) * 16);
+            asrc[s] = (unsigned)ia[s] * (unsigned)Dd + sw;
+            bsrc[s] = (unsigned)ib[s] * (unsigned)Dd + sw;
         }
     };
     auto stage = [&](int buf, int kt) {                  // 8 wavefront loads per stage and wave
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            __builtin_amdgcn_global_load_lds((gbl_void *)(asrc[s] + kt * DBK), (lds_void *)&As2[buf][(4 * s + wid) * 8 * DBK], 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gbl_void *)(bsrc[s] + kt * DBK), (lds_void *)&Bs2[buf][(4 * s + wid) * 8 * DBK], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void *)(A + ((size_t)asrc[s] + (size_t)(kt * DBK))), (lds_void *)&As2[buf][(4 * s + wid) * 8 * DBK], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void *)(B + ((size_t)bsrc[s] + (size_t)(kt * DBK))), (lds_void *)&Bs2[buf][(4 * s + wid) * 8 * DBK], 16, 0, 0);
         }
     };
+    // the NEXT tile's first stage (its offsets are derived from the prefetched indices on the spot: the current tile's stay intact)
+    auto stage_next = [&](int buf, const int (&ia)[4], const int (&ib)[4]) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int r = (4 * s + wid) * 8 + prow;
+            const size_t sw = (size_t)((pchunk ^ ((r >> 1) & 7)) * 16);
+            __builtin_amdgcn_global_load_lds((gbl_void *)(A + ((size_t)((unsigned)ia[s] * (unsigned)Dd) + sw)), (lds_void *)&As2[buf][(4 * s + wid) * 8 * DBK], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void *)(B + ((size_t)((unsigned)ib[s] * (unsigned)Dd) + sw)), (lds_void *)&Bs2[buf][(4 * s + wid) * 8 * DBK], 16, 0, 0);
+        }
+    };
+    // survivors a tile may hand to the exact refinement when it stops at a prefix: the true matches it holds anyway
+    // (~ columns x rows / pool rows) plus a few -- an exact float32 dot product costs about one K stage of a tile
+    const int stop_thr = 6 + (3 * FBM * FBN) / (2 * (n > 0 ? n : 1));
+    const float i8_s2 = feat::i8_scale(Dd) * feat::i8_scale(Dd) * 0.99999f;        // integer dot products per unit of dequantised dot product
     int bm, bn;
     int vt = next_live((int)blockIdx.x, bm, bn);
     if (vt >= ntiles) return;
-    int ia[4], ib[4], inorm;
-    fetch_idx(bm, bn, ia, ib, inorm);
+    int ia[4], ib[4], irec;
+    fetch_idx(bm, bn, ia, ib, irec);
     set_src(ia, ib);
-    float my_norm = inorm < 0 ? 0.0f : (tid < FBM ? na[inorm] : nb[inorm]);
+    const float *mbase = tid < FBM ? ma : mb;
+    unsigned my_meta_o = (unsigned)irec * feat::I8_META;                             // this thread's row / column record (element offset)
+    // The records a candidate test needs ({1/s, r, alpha_c, uh_c} of the tile's 128 rows and 128 columns for checkpoint c) go
+    // straight from memory into an LDS image, one 16-byte transfer per thread, at least one K stage ahead of the test:
+    // the stage barrier in between waits for them like for the operands.  Nothing of it passes through registers, so
+    // the compiler has no load result to wait for inside the K loop (its wait would drain the operand stage in flight).
+    auto stage_rec = [&](int img, int c) {
+        __builtin_amdgcn_global_load_lds((gbl_void *)(mbase + ((size_t)my_meta_o + (size_t)(4 * c))), (lds_void *)&srec2[img][wid * 64], 16, 0, 0);
+    };
+    int rimg = 0;                                // image the NEXT test's records are in (or on their way to)
     stage(0, 0);
-    int cur = 0;
+    int cur = 0, flip = 0;
+    // Where this workgroup's tiles have been stopping: `last_exit` = the stage count of the predicted stop (-1: none yet).
+    // The prediction moves up at once and down only after three earlier stops in a row (a stop before the predicted one
+    // costs a cold first stage of the next tile, a stop after it a cold K stage: late is the cheaper mistake); tests at
+    // checkpoints before the predicted one are skipped except on every fourth tile (the probe that lets it move down).
+    int last_exit = -1, early_run = 0, tile_no = 0;
+    int st_stages = 0, st_early = 0, st_cand = 0;
+#ifdef BTS_FILTER_TRACE
+    long long tm_check = 0, tm_wait = 0, tm_all = 0, tm_first = 0, tm_pro = 0;      // clock cycles of this workgroup: candidate tests, stage waits, total, first test, prologue
+    const long long tm_begin = (long long)__builtin_amdgcn_s_memrealtime();
+#define FT_BEGIN(v) const long long v = (long long)__builtin_amdgcn_s_memrealtime()
+#define FT_ADD(acc, v) acc += (long long)__builtin_amdgcn_s_memrealtime() - v
+#else
+#define FT_BEGIN(v) do { } while (0)
+#define FT_ADD(acc, v) do { } while (0)
+#endif
     for (;;) {
         // the next tile's indices travel while this tile's K loop runs
         int nbm = 0, nbnn = 0;
-        const int nvt = next_live(vt + FILTER_PW, nbm, nbnn);
-        if (nvt < ntiles) fetch_idx(nbm, nbnn, ia, ib, inorm);
-        f32x16 acc[2][2];
+        const int nvt = next_live(vt + gemm_blocks, nbm, nbnn);
+        if (nvt < ntiles) fetch_idx(nbm, nbnn, ia, ib, irec);
+        i32x16 acc[2][2];
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
-        for (int kt = 0; kt < kt_all; ++kt) {
-            wait_stage_barrier<0>();             // stage kt has landed (the only one in flight); every wave is past its reads of the other buffer
-            if (kt + 1 < kt_all) stage(cur ^ 1, kt + 1);
-            const unsigned abase = lds_a + cur * (FBM * DBK), bbase = lds_b + cur * (FBN * DBK);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {        // the stage's two K = 64 blocks; a lane holds 32 contiguous K values of each
-                v4i fa[2][2], fb[2][2];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int u = h * 4 + fh * 2 + t;
-#pragma unroll
-                    for (int x = 0; x < 2; ++x) {
-                        fa[t][x] = lds_read16(abase + aoff[x] + ((u ^ asw[x]) << 4));
-                        fb[t][x] = lds_read16(bbase + boff[x] + ((u ^ bsw[x]) << 4));
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0;
+        int ci = VAR == 2 ? (int)feat::I8_NCHK : skip_unused(0);     // next checkpoint (feat::I8_NCHK = the full row)
+        // checkpoints before the predicted stop are not tested, except on every fourth tile (the probe that lets the
+        // prediction move down)
+        if ((tile_no & 3) != 3)
+            while (ci < feat::I8_NCHK && chk_at(ci) < last_exit) ci = skip_unused(ci + 1);
+        stage_rec(rimg, ci);
+        int issued = 1;                              // stages whose loads have been issued
+        int kt = 0;
+        bool next_staged = false;                    // the next tile's first stage is already on its way
+        for (;;) {
+            const bool at_end = kt == kt_all;
+            if (at_end || (VAR != 2 && ci < feat::I8_NCHK && kt == chk_at(ci))) {
+                FT_BEGIN(tc0);
+                // ---- candidate test on the prefix of kt stages (checkpoint ci; at the end: the full-row records)
+                if (at_end && nvt < ntiles && !next_staged) {
+                    // every wave is past its reads of buffer `cur` (the barrier of the last stage): the next tile's first
+                    // stage goes there now and lands while the test runs
+                    stage_next(cur, ia, ib);
+                    next_staged = true;
+                }
+                // Every LDS access of the test is inline assembly: for an LDS access it can see, the compiler first drains ALL
+                // outstanding LDS-DMA loads (s_waitcnt vmcnt(0)) -- the operand stage that is landing under this test.
+                // The records are in image `rimg` since the last stage barrier at the latest.
+                const unsigned srec_a = lds_rec + (unsigned)rimg * (unsigned)((FBM + FBN) * 16);
+                const unsigned scnt_a = lds_cnt + (unsigned)flip * 16u, sred_a = lds_red + (unsigned)flip * 32u;
+                // survivors of this lane: sv[mi] bit ni * 16 + r.  All shadows share one scale, so "excluded" (feat::i8_excluded:
+                //     dot / s^2 + alpha_i r_j + alpha_j r_i  <  uh_i + uh_j)
+                // becomes ONE integer compare per accumulator against a per-column threshold once the tile's rows are
+                // summarised by {min uh, max alpha, max r}:
+                //     dot < ((min uh_rows + uh_j) - (max alpha_rows r_j + alpha_j max r_rows)) s^2      =>  excluded
+                // (prefix records have alpha = 0; looser than pair by pair only by the spread of the rows' records).
+                unsigned sv[2] = {0u, 0u};
+                {
+                    f32x4 mine = lds_read16f(srec_a + (unsigned)tid * 16u);
+                    lds_wait_f1(mine);
+                    if (wid < 2) {                   // wavefronts 0-1 hold the rows
+                        const float m_u = wave_min_f(mine.w), m_a = wave_max_f(mine.z), m_r = wave_max_f(mine.y);
+                        if (lane == 0) lds_write16(sred_a + (unsigned)wid * 16u, f32x4{m_u, m_a, m_r, 0.0f});
                     }
+                    bscan::lds_barrier();
+                    f32x4 ra = lds_read16f(sred_a), rb = lds_read16f(sred_a + 16u);
+                    f32x4 c0 = lds_read16f(srec_a + (unsigned)(FBM + wc * 64 + frow) * 16u), c1 = lds_read16f(srec_a + (unsigned)(FBM + wc * 64 + 32 + frow) * 16u);
+                    lds_wait_f(ra, rb);
+                    lds_wait_f(c0, c1);
+                    const float u_min = fminf(ra.x, rb.x), a_max = fmaxf(ra.y, rb.y), r_max = fmaxf(ra.z, rb.z);
+                    const float s2 = i8_s2;
+                    const float t0 = ((u_min + c0.w) - (a_max * c0.y + c0.z * r_max)) * s2;
+                    const float t1 = ((u_min + c1.w) - (a_max * c1.y + c1.z * r_max)) * s2;
+                    // (NaN / non-positive bounds: nothing is excluded)
+                    const int ti0 = t0 > 0.0f ? (int)fminf(t0 * 0.999999f, 2.0e9f) - 1 : (int)0x80000000;
+                    const int ti1 = t1 > 0.0f ? (int)fminf(t1 * 0.999999f, 2.0e9f) - 1 : (int)0x80000000;
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            sv[mi] |= (acc[mi][0][r] >= ti0 ? 1u : 0u) << r;
+                            sv[mi] |= (acc[mi][1][r] >= ti1 ? 1u : 0u) << (16 + r);
+                        }
                 }
-                lds_wait<0>(fa[0][0], fa[0][1], fb[0][0], fb[0][1]);
-                lds_wait<0>(fa[1][0], fa[1][1], fb[1][0], fb[1][1]);
-                v8i av[2], bv[2];
+                {
+                    // which of this lane's 64 accumulators lie inside the live extents (edge tiles)
+                    unsigned vmask0, vmask1;
+                    {
+                        const int lim = n - bm * FBM - (wr * 64 + 4 * fh);       // local row (mi * 32 + 8 g + u) is live iff < lim
+                        unsigned rv0 = 0u, rv1 = 0u;
 #pragma unroll
-                for (int x = 0; x < 2; ++x) {
-                    av[x] = v8i{fa[0][x].x, fa[0][x].y, fa[0][x].z, fa[0][x].w, fa[1][x].x, fa[1][x].y, fa[1][x].z, fa[1][x].w};
-                    bv[x] = v8i{fb[0][x].x, fb[0][x].y, fb[0][x].z, fb[0][x].w, fb[1][x].x, fb[1][x].y, fb[1][x].z, fb[1][x].w};
+                        for (int r = 0; r < 16; ++r) {
+                            const int lr = (r & 3) + 8 * (r >> 2);
+                            rv0 |= (lr < lim ? 1u : 0u) << r;
+                            rv1 |= (32 + lr < lim ? 1u : 0u) << r;
+                        }
+                        const int q0 = bn * FBN + wc * 64 + frow;
+                        const unsigned m0 = q0 < m ? 0xffffu : 0u, m1 = q0 + 32 < m ? 0xffff0000u : 0u;
+                        vmask0 = (rv0 | (rv0 << 16)) & (m0 | m1);
+                        vmask1 = (rv1 | (rv1 << 16)) & (m0 | m1);
+                    }
+                    sv[0] &= vmask0; sv[1] &= vmask1;            // rows / columns past the live extents
                 }
+                int cnt = __popc(sv[0]) + __popc(sv[1]);
+                bool stop = at_end;
+                if (!at_end) {
+                    // the workgroup's survivors: every wavefront leaves its count, everybody adds the four up
+                    int wcnt = cnt;
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
+                    for (int off = 32; off; off >>= 1) wcnt += __shfl_xor(wcnt, off);
+                    if (lane == 0) lds_write4(scnt_a + (unsigned)wid * 4u, wcnt);
+                    bscan::lds_barrier();
+                    v4i c4 = lds_read16(scnt_a);
+                    lds_wait_i(c4);
+                    // (wave-uniform by construction; saying so keeps the whole K loop's control flow -- stage counters, buffer
+                    //  indices, the stop decision -- on the scalar side instead of exec-masked vector code)
+                    const int total = __builtin_amdgcn_readfirstlane((c4.x + c4.y) + (c4.z + c4.w));
+                    flip ^= 1;
+                    // an exact refinement costs about what a K stage of this tile costs: stop when the survivors are
+                    // fewer than the stages that are left (plus the handful of true matches a tile holds anyway)
+                    stop = total <= stop_thr;
+                }
+                if (stop) {
 #pragma unroll
-                    for (int ni = 0; ni < 2; ++ni)       // K = 64 per instruction, formats fp8 x fp8, block scales 2^0
-                        acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av[mi], bv[ni], acc[mi][ni], 0, 0, 0, 127, 0, 127);
-            }
-            cur ^= 1;
-        }
-        // epilogue of this tile; its first barrier also says every wave is done reading the operand buffers, so the next
-        // tile's first stage goes out right behind it and lands while the candidate tests run
-        const float norm_now = my_norm;
-        __syncthreads();
-        snorm[tid] = norm_now;
-        if (nvt < ntiles) {
-            set_src(ia, ib);
-            my_norm = inorm < 0 ? 0.0f : (tid < FBM ? na[inorm] : nb[inorm]);
-            stage(cur, 0);
-        }
-        __syncthreads();
-        {
-            const float eps = FACE ? d.eps_face : d.eps_body, gate = 1.0f - d.app;
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    const int qq = wc * 64 + ni * 32 + frow, q = bn * FBN + qq;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int ii = wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh, i = bm * FBM + ii;
-                        const float val = acc[mi][ni][r] * feat::Q8_UNSCALE;
-                        if (!(i < n && q < m)) continue;
-                        if (is_candidate(val, snorm[ii], snorm[FBM + qq], gate, eps))      // rare: about one per detection column
+                    for (int mi = 0; mi < 2; ++mi) {
+                        unsigned bits = sv[mi];
+                        while (bits) {                           // (rare: about one survivor per detection column)
+                            const int b = __ffs((int)bits) - 1, r = b & 15;
+                            bits &= bits - 1;
+                            const int q = bn * FBN + wc * 64 + (b >> 4) * 32 + frow;
+                            const int i = bm * FBM + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
                             atomicOr(&d.cbits[(long)i * d.cb_ld + (q >> 5)], 1u << (q & 31));
+                        }
                     }
+                    st_cand += cnt;
+                    if (!at_end) ++st_early;
+                    const int here = at_end ? kt_all : kt;
+                    if (here >= last_exit) { last_exit = here; early_run = 0; }
+                    else if (++early_run >= 3) { last_exit = here; early_run = 0; }
+#ifdef BTS_FILTER_TRACE
+                    if (tm_first == 0) tm_first = (long long)__builtin_amdgcn_s_memrealtime() - tc0; else
+#endif
+                    FT_ADD(tm_check, tc0);
+                    break;
                 }
+                ci = skip_unused(ci + 1);
+                rimg ^= 1;                           // (the image just tested may still be read by the slower wavefronts)
+                stage_rec(rimg, ci);
+#ifdef BTS_FILTER_TRACE
+                if (tm_first == 0) tm_first = (long long)__builtin_amdgcn_s_memrealtime() - tc0; else
+#endif
+                FT_ADD(tm_check, tc0);
+            }
+            // ---- K stage kt
+            if (issued <= kt) {                  // its prefetch was skipped (an exit was predicted here and did not happen): the
+                stage(cur, kt);                  // speculative first stage of the next tile sits in this buffer -- overwritten
+                issued = kt + 1;
+                next_staged = false;
+            }
+            {
+                FT_BEGIN(tw0);
+                wait_stage_barrier<0>();         // stage kt has landed; every wave is past its reads of the other buffer
+                FT_ADD(tm_wait, tw0);
+#ifdef BTS_FILTER_TRACE
+                if (tm_pro == 0) tm_pro = (long long)__builtin_amdgcn_s_memrealtime() - tm_begin;
+#endif
+            }
+            // Prefetch the next stage into the other buffer -- unless this workgroup's previous tile stopped right there: then
+            // this one most likely will, and the buffer takes the NEXT TILE's first stage instead (it lands under this stage
+            // and the candidate test, so the next K loop starts without a cold load)
+            if (kt + 1 < kt_all && issued == kt + 1) {
+                if (kt + 1 != last_exit) { stage(cur ^ 1, kt + 1); issued = kt + 2; }
+                else if (nvt < ntiles && !next_staged) { stage_next(cur ^ 1, ia, ib); next_staged = true; }
+            }
+            stage_mfma<VAR == 1 ? 1 : 0>(lds_a + cur * (FBM * DBK), lds_b + cur * (FBN * DBK), fm, fh, acc);
+            cur ^= 1;
+            ++kt;
+            ++st_stages;
         }
+        ++tile_no;
         if (nvt >= ntiles) break;
         vt = nvt; bm = nbm; bn = nbnn;
+        my_meta_o = (unsigned)irec * feat::I8_META;
+        rimg ^= 1;
+        if (!next_staged) {
+            // stopped at an unpredicted checkpoint: a prefetched stage of the OLD tile may still be landing in buffer `cur`;
+            // the new tile starts in the other one (the test's barriers put every wave past its reads of it) and the
+            // first stage barrier waits for both
+            cur ^= 1;
+            stage_next(cur, ia, ib);
+        }
+        set_src(ia, ib);
     }
+    if (tid == 0) {
+        atomicAdd(&d.fstat[FS_STAGES], st_stages); atomicAdd(&d.fstat[FS_EARLY], st_early); atomicAdd(&d.fstat[FS_TILES], tile_no);
+#ifdef BTS_FILTER_TRACE
+        tm_all = (long long)__builtin_amdgcn_s_memrealtime() - tm_begin;
+        atomicAdd(&d.fstat[5], (int)tm_check); atomicAdd(&d.fstat[6], (int)tm_wait); atomicAdd(&d.fstat[7], (int)tm_all);
+        atomicAdd(&d.fstat[3], (int)tm_first); atomicAdd(&d.fstat[4], (int)tm_pro);      // (trace build: [3] is NOT the candidate count)
+        const int t_beg = (int)(tm_begin & 0x3fffffff), t_end = (int)(((long long)__builtin_amdgcn_s_memrealtime()) & 0x3fffffff);
+        atomicMin(&d.fstat[8], t_beg); atomicMax(&d.fstat[9], t_end); atomicMax(&d.fstat[10], (int)tm_all); atomicMax(&d.fstat[11], t_beg);
+#endif
+    }
+    // candidates: every lane counted its own
+#pragma unroll
+    for (int off = 32; off; off >>= 1) st_cand += __shfl_xor(st_cand, off);
+    if (lane == 0 && st_cand) atomicAdd(&d.fstat[FS_CAND], st_cand);
 }
 
 // ---- detection feature rows: in-place renormalisation (quirk Q8) ------------------------------------------
@@ -990,17 +1207,12 @@ __device__ __forceinline__ void apply_body(const Dev &d, int bid) {
         const int r = ys[xq];
         if (r < 0 || r >= n) return;
         const long s = rslot[r], det = cdet[xq];
-        // (the detection rows are unit vectors by now -- tk_mid1 renormalised them -- so their 8-bit shadows are written
-        // from the same registers, without a second norm; odd shapes fall back to the two-pass conversion)
-        const bool sb = feat::ema_row(d.body_curr + s * d.D, d.body_smooth + s * d.D, IN(d, feats) + det * d.D, d.D, d.has_body[s] != 0,
-                                      d.ema_a, d.ema_b, true, d.filter ? d.body_h + s * d.D : nullptr, d.body_n + s);
-        bool sf = true;
+        feat::ema_row(d.body_curr + s * d.D, d.body_smooth + s * d.D, IN(d, feats) + det * d.D, d.D, d.has_body[s] != 0, d.ema_a, d.ema_b);
         if (d.Df)
-            sf = feat::ema_row(d.face_curr + s * d.Df, d.face_smooth + s * d.Df, IN(d, face_feats) + det * d.Df, d.Df,
-                               d.has_face[s] != 0, d.ema_a, d.ema_b, true, d.filter ? d.face_h + s * d.Df : nullptr, d.face_n + s);
-        if (d.filter) {
-            if (!sb) feat::to_q8_row(IN(d, feats) + det * d.D, d.body_h + s * d.D, d.body_n + s, d.D);
-            if (d.Df && !sf) feat::to_q8_row(IN(d, face_feats) + det * d.Df, d.face_h + s * d.Df, d.face_n + s, d.Df);
+            feat::ema_row(d.face_curr + s * d.Df, d.face_smooth + s * d.Df, IN(d, face_feats) + det * d.Df, d.Df, d.has_face[s] != 0, d.ema_a, d.ema_b);
+        if (d.filter) {        // the track's latest feature is this detection's row: so is its shadow
+            copy_shadow(d.det_h + det * d.D, d.det_m + det * feat::I8_META, d.body_h + s * d.D, d.body_m + s * feat::I8_META, d.D);
+            if (d.Df) copy_shadow(d.dface_h + det * d.Df, d.dface_m + det * feat::I8_META, d.face_h + s * d.Df, d.face_m + s * feat::I8_META, d.Df);
         }
         if (threadIdx.x == 0) { d.has_body[s] = 1; if (d.Df) d.has_face[s] = 1; }
         return;
@@ -1168,6 +1380,7 @@ template <bool CH> __global__ __launch_bounds__(1024) void tk_merge(Dev d) {
             h[H_NB] = nborn; h[H_NBORN] = nborn;
             h[H_LASTID] = last_id + nborn;
             int err = nborn_want > nfree ? ERR_TRACK_CAPACITY : 0;
+            if (err && !(h[H_ERR] & ERR_TRACK_CAPACITY)) { h[30] = frame; h[31] = nborn_want - nfree; }      // (first occurrence, for the error message)
             for (int k = 0; k < 3; ++k)                          // assignment solver: edge-list overflow / helper time-out
                 if (d.lap_hdr[BTS_LAP_HDR_INTS * k + 2]) err |= ERR_LAP_EDGES;
             if (err) atomicOr(&h[H_ERR], err);
@@ -1254,8 +1467,8 @@ __device__ __forceinline__ void birth_body(const Dev &d, int k) {
         d.face_curr[s * d.Df + c] = v; d.face_smooth[s * d.Df + c] = v;
     }
     if (d.filter) {
-        feat::to_q8_row(IN(d, feats) + det * d.D, d.body_h + s * d.D, d.body_n + s, d.D);
-        if (d.Df) feat::to_q8_row(IN(d, face_feats) + det * d.Df, d.face_h + s * d.Df, d.face_n + s, d.Df);
+        copy_shadow(d.det_h + det * d.D, d.det_m + det * feat::I8_META, d.body_h + s * d.D, d.body_m + s * feat::I8_META, d.D);
+        if (d.Df) copy_shadow(d.dface_h + det * d.Df, d.dface_m + det * feat::I8_META, d.face_h + s * d.Df, d.face_m + s * feat::I8_META, d.Df);
     }
 }
 
@@ -1506,10 +1719,11 @@ static void tracker_layout(bts_tracker *t, char *base, size_t &off) {
     SLOT(d.x3, int32_t, T); SLOT(d.y3, int32_t, M);
     SLOT(d.drop_t, uint8_t, T); SLOT(d.drop_l, uint8_t, T); SLOT(d.lap_hdr, int32_t, 3 * BTS_LAP_HDR_INTS);
     if (d.filter) {
-        SLOT(d.body_h, uint8_t, T * D); SLOT(d.det_h, uint8_t, M * D); SLOT(d.body_n, float, T); SLOT(d.det_n, float, M);
-        SLOT(d.face_h, uint8_t, T * Df); SLOT(d.dface_h, uint8_t, M * Df); SLOT(d.face_n, float, T); SLOT(d.dface_n, float, M);
+        SLOT(d.body_h, int8_t, T * D); SLOT(d.det_h, int8_t, M * D); SLOT(d.body_m, float, T * feat::I8_META); SLOT(d.det_m, float, M * feat::I8_META);
+        SLOT(d.face_h, int8_t, T * Df); SLOT(d.dface_h, int8_t, M * Df); SLOT(d.face_m, float, T * feat::I8_META); SLOT(d.dface_m, float, M * feat::I8_META);
+        SLOT(d.fstat, int32_t, 16);
         // split-K accumulators: only tables small enough to ever need split K (< 256 tiles of 128 x 128) carry them
-        if (T * M <= SPLITK_MAX_ENTRIES) { SLOT(d.approx, float, T * M); SLOT(d.approx_f, float, d.Df ? T * M : 1); }
+        if (T * M <= SPLITK_MAX_ENTRIES) { SLOT(d.approx, int32_t, T * M); SLOT(d.approx_f, int32_t, d.Df ? T * M : 1); }
         else { d.approx = nullptr; d.approx_f = nullptr; }
         d.cb_ld = (int)((M + 63) / 64) * 2;        // 64 columns = one aligned 8-byte word
         SLOT(d.cbits, uint32_t, T * (size_t)d.cb_ld);
@@ -1564,8 +1778,7 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
     }
     // the pre-filter works on 128-element K steps; other feature widths take the dense float32 path
     d.filter = (cfg->appearance_mode == BTS_APPEARANCE_FILTER && d.D % DBK == 0 && d.Df % DBK == 0) ? 1 : 0;
-    d.eps_body = feat::q8_cos_error(d.D);
-    d.eps_face = feat::q8_cos_error(d.Df ? d.Df : 1);
+    d.gate_sim = 1.0f - d.app;
     size_t off = 0;
     tracker_layout(t, nullptr, off);
     // capacity of the solver's edge lists: the feasible pairs (cost <= match threshold) are O(detections) in any scene
@@ -1597,8 +1810,9 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
         return BTS_ENOMEM;
     }
     const size_t tm = (size_t)t->dv.T * t->dv.Mx;      // the pre-filter's accumulators and bitmap are self-cleaning from here on
-    if (t->dv.filter && ((t->dv.approx && (hipMemset(t->dv.approx, 0, sizeof(float) * tm) != hipSuccess ||
-                                           hipMemset(t->dv.approx_f, 0, sizeof(float) * (t->dv.Df ? tm : 1)) != hipSuccess)) ||
+    if (t->dv.filter && ((t->dv.approx && (hipMemset(t->dv.approx, 0, sizeof(int32_t) * tm) != hipSuccess ||
+                                           hipMemset(t->dv.approx_f, 0, sizeof(int32_t) * (t->dv.Df ? tm : 1)) != hipSuccess)) ||
+                         hipMemset(t->dv.fstat, 0, sizeof(int32_t) * 16) != hipSuccess ||
                          hipMemset(t->dv.cbits, 0, sizeof(uint32_t) * (size_t)t->dv.T * t->dv.cb_ld) != hipSuccess)) {
         (void)hipGetLastError();
         bts_set_error("hipMemset failed");
@@ -1741,14 +1955,16 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
     if (d.filter) {
         // Kalman predict rides in the pre-filter's launch (independent work, consecutive workgroups)
         seg_begin(BTS_SEG_K_FILTER);
-        const bool persistent = split == 1 && ftiles > FILTER_PW;      // more tiles than resident workgroups: walk them (k_filter_dma_p)
-        if (persistent) { LAUNCH(k_filter_dma_p<false>, dim3(FILTER_PW + kf_blocks), dim3(256), mc, ftiles); }
-        else { LAUNCH(k_filter_dma<false>, dim3(ftiles * split + kf_blocks), dim3(256), mc, ftiles, split, accum); }
+        // one-pass form (candidate bitmap, prefix exits): up to FILTER_PW persistent workgroups walk the tiles;
+        // small problems add split-K partial products instead (k_filter_splitk)
+        const int gemm_blocks = ftiles < FILTER_PW ? ftiles : FILTER_PW;
+        if (!accum) { LAUNCH(k_filter_i8<false>, dim3(gemm_blocks + kf_blocks), dim3(256), mc, ftiles, gemm_blocks); }
+        else { LAUNCH(k_filter_splitk<false>, dim3(ftiles * split + kf_blocks), dim3(256), mc, ftiles, split); }
         seg_end(BTS_SEG_K_FILTER);
         if (d.Df) {
             const int fsplit = split < bts_cdiv(d.Df, DBK) ? split : bts_cdiv(d.Df, DBK);
-            if (persistent) { LAUNCH(k_filter_dma_p<true>, dim3(FILTER_PW), dim3(256), mc, ftiles); }
-            else { LAUNCH(k_filter_dma<true>, dim3(ftiles * fsplit), dim3(256), mc, ftiles, fsplit, accum); }
+            if (!accum) { LAUNCH(k_filter_i8<true>, dim3(gemm_blocks), dim3(256), mc, ftiles, gemm_blocks); }
+            else { LAUNCH(k_filter_splitk<true>, dim3(ftiles * fsplit), dim3(256), mc, ftiles, fsplit); }
         }
     } else {
         seg_begin(BTS_SEG_PREDICT);
@@ -1918,8 +2134,8 @@ static int device_error_status(const bts_tracker *t) {
     const int e = t->host_hdr[H_ERR];
     if (!e) return BTS_OK;
     if (e & ERR_TRACK_CAPACITY) {
-        bts_set_error("track table full (max_tracks = %d): births were dropped at or before frame %d; results diverge from "
-                      "the reference from there on", t->cfg.max_tracks, t->host_hdr[H_FRAME]);
+        bts_set_error("track table full (max_tracks = %d): %d births were dropped at frame %d (now at frame %d); results diverge "
+                      "from the reference from there on", t->cfg.max_tracks, t->host_hdr[31], t->host_hdr[30], t->host_hdr[H_FRAME]);
         return BTS_ECAPACITY;
     }
     if (e & ERR_LAP_EDGES) {
@@ -2020,9 +2236,16 @@ int bts_tracker_export_state(bts_tracker *t, int which, double *cov_host, float 
 }
 
 int bts_tracker_read_slot(bts_tracker *t, int slot, int field, void *out_host, bts_stream stream) {
-    BTS_REQUIRE(t && out_host && slot >= 0 && slot < t->dv.T && field >= 0 && field <= 5, "tracker, slot, field, out");
+    BTS_REQUIRE(t && out_host && slot >= 0 && slot < t->dv.T && field >= 0 && field <= 6, "tracker, slot, field, out");
     BTS_ON_DEVICE(t->ctx);
     const Dev &d = t->dv;
+    if (field == 6) {          // {track_id, state}: what became of a track that left both lists (removed vs dropped as a duplicate)
+        int32_t *o = (int32_t *)out_host;
+        BTS_HIP(hipMemcpyAsync(o, d.track_id + slot, sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+        BTS_HIP(hipMemcpyAsync(o + 1, d.state + slot, sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+        BTS_HIP(hipStreamSynchronize((hipStream_t)stream));
+        return BTS_OK;
+    }
     BTS_REQUIRE(field < 4 || d.Df > 0, "the tracker carries no face features");
     const void *src = field == 0 ? (const void *)(d.mean + (size_t)slot * 8) : field == 1 ? (const void *)(d.cov + (size_t)slot * 64)
                     : field == 2 ? (const void *)(d.body_curr + (size_t)slot * d.D) : field == 3 ? (const void *)(d.body_smooth + (size_t)slot * d.D)
@@ -2046,6 +2269,16 @@ int bts_tracker_gmc(bts_tracker *t, const double *h2x3_host, bts_stream stream) 
 int bts_debug_jobtrace(int32_t *out64_host) {
     BTS_REQUIRE(out64_host, "out");
     BTS_HIP(hipMemcpyFromSymbol(out64_host, HIP_SYMBOL(g_jobtrace), 64 * sizeof(int32_t)));
+    return BTS_OK;
+}
+
+int bts_tracker_debug_filter(bts_tracker *t, int32_t *out8_host, bts_stream stream) {
+    BTS_REQUIRE(t && out8_host, "tracker, out");
+    BTS_ON_DEVICE(t->ctx);
+    for (int k = 0; k < 16; ++k) out8_host[k] = 0;
+    if (!t->dv.filter) return BTS_OK;
+    BTS_HIP(hipMemcpyAsync(out8_host, t->dv.fstat, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    BTS_HIP(hipStreamSynchronize((hipStream_t)stream));
     return BTS_OK;
 }
 

@@ -413,9 +413,22 @@ class DeviceTracker:
     def read_slot(self, slot: int, field: int) -> np.ndarray:
         """One table row: field 0 mean, 1 covariance [8,8], 2/3 body curr/smooth, 4/5 face curr/smooth."""
         D, Df = self.cfg.feat_dim, self.cfg.face_dim
+        if field == 6:
+            out = np.empty(2, np.int32)
+            _lib.check(self._lib.bts_tracker_read_slot(self.handle, int(slot), 6, out.ctypes.data, _lib.current_stream()))
+            return out
         out = np.empty(8 if field == 0 else 64 if field == 1 else D if field <= 3 else Df, np.float64 if field <= 1 else np.float32)
         _lib.check(self._lib.bts_tracker_read_slot(self.handle, int(slot), int(field), out.ctypes.data, _lib.current_stream()))
         return out.reshape(8, 8) if field == 1 else out
+
+    def debug_filter(self) -> dict:
+        """Counters of the appearance pre-filter for the last step (bts_tracker_debug_filter)."""
+        h = np.zeros(16, dtype=np.int32)
+        _lib.check(self._lib.bts_tracker_debug_filter(self.handle, h.ctypes.data, _lib.current_stream()))
+        self._filter_raw = h
+        return {"k_stages": int(h[0]), "tiles": int(h[1]), "prefix_exits": int(h[2]), "candidates": int(h[3]), "tests": int(h[4]),
+                # clock cycles summed over the persistent workgroups (one wave's view): candidate tests, waits for operand stages, total
+                "cycles_tests": int(h[5]) * 64, "cycles_stage_waits": int(h[6]) * 64, "cycles_total": int(h[7]) * 64}
 
     def debug_lap(self, stage: int) -> np.ndarray:
         """Counters of the assignment solver for stage 1..3 of the last step (bts_tracker_debug_lap)."""
@@ -644,9 +657,13 @@ class BoTSORT:
         live = {t.track_id for t in self.tracked_stracks} | {t.track_id for t in self.lost_stracks}
         for tid in [t for t in self._mirror if t not in live]:
             st = self._mirror.pop(tid)
+            # removed (D:1609-1612, D:1623-1627: goes to removed_stracks) or dropped by remove_duplicate_stracks (D:1637: just
+            # leaves the lists)?  The slot still holds the track this frame.
+            dev_id, dev_state = (int(v) for v in dt.read_slot(st.slot, 6)) if st.slot >= 0 else (tid, TrackState.Removed)
             st._live = False            # its table slot may be recycled: the cached arrays are what is left of it
-            st.state = TrackState.Removed
-            self.removed_stracks.append(st)
+            if dev_id == tid and dev_state == TrackState.Removed:
+                st.state = TrackState.Removed
+                self.removed_stracks.append(st)
         return self.tracked_stracks
 
     # ---- reference signature (detector + encoders are the caller's objects, unchanged)

@@ -152,11 +152,18 @@ int bts_dedupe_pairs(bts_context *ctx, const double *a_tlbr, const uint8_t *a_f3
                      int n, const double *b_tlbr, const uint8_t *b_f32, const int32_t *age_b, int m,
                      double thresh, uint8_t *drop_a, uint8_t *drop_b, bts_stream stream);
 
-/* Diagnostics of the appearance pre-filter's 8-bit quantiser (the pre-filter never decides a cost -- it selects
- * the pairs that get the exact float32 dot product -- but its error model must hold): y[i] = dequantise(
- * quantise(x[i])) for n floats, and the model |y - x| <= rel |x| + abs the candidate bound is derived from. */
-int bts_debug_q8_roundtrip(bts_context *ctx, const float *x, float *y, int n, bts_stream stream);
-int bts_debug_q8_model(double *rel, double *abs_, double *scale);
+/* Diagnostics of the appearance pre-filter's int8 shadows (the pre-filter never decides a cost -- it selects the pairs
+ * that get the exact float32 dot product -- but its bound must hold; tests/test_gpu_kernels.py):
+ * bts_debug_i8_rows: x[n,d] float32 -> q[n,d] int8 shadows and meta[n,20] records (scale, measured residual, prefix norms:
+ *   csrc/feat_math.h) for the similarity `gate` (= 1 - appearance_thresh);
+ * bts_debug_i8_pairs: for pair p = (ia[p], ib[p]) and every checkpoint c of the K loop (the last = the full row)
+ *   excluded[p,5] = 1 when the prefix's integer dot product proves <a, b> < gate, dots[p,5] = that dot product;
+ * bts_debug_i8_layout: out[0..3] checkpoint stages for dimension d, [4] stages, [5] elements per stage, [6] floats per
+ *   record, [7] checkpoints. */
+int bts_debug_i8_rows(bts_context *ctx, const float *x, int n, int d, double gate, int8_t *q, float *meta, bts_stream stream);
+int bts_debug_i8_pairs(bts_context *ctx, const int8_t *qa, const float *meta_a, const int8_t *qb, const float *meta_b,
+                       const int32_t *ia, const int32_t *ib, int n_pairs, int d, uint8_t *excluded, int32_t *dots, bts_stream stream);
+int bts_debug_i8_layout(int d, int32_t *out8);
 /* Launch-floor probe (scripts/launch_floor.py): `launches` back-to-back launches of a kernel whose workgroups follow
    `links` dependent loads through buf (int32[>= 8192], zero-filled). */
 /* Durations of the tracker's single-workgroup list jobs (library built with `make TRACE=1`; zeros otherwise):
@@ -178,9 +185,10 @@ int bts_associate_parts(bts_context *ctx, const int32_t *base_boxes, const int32
 /* -------------------------------------------------- whole-frame tracker, BoTSORT.update D:1414-1639 */
 
 /* How the stage-1/3 appearance term (D:1539-1554, D:1590-1602) is evaluated inside the tracker:
- * FILTER: fp8-MFMA pre-filter over 8-bit unit-vector shadows of the features + exact float32 recomputation
- *         of every pair that could pass the appearance gate (results identical to DENSE up to float32
- *         summation order; no N x M matrix is materialised);
+ * FILTER: int8-MFMA pre-filter over 8-bit shadows of the features (a rigorous upper bound on every pair's dot product,
+ *         evaluated on a prefix of the rows where that already decides) + exact float32 recomputation of every pair
+ *         that could pass the appearance gate (results identical to DENSE up to float32 summation order; no
+ *         N x M matrix is materialised);
  * DENSE:  the dense float32 similarity and cost matrices, as the reference forms them. */
 enum bts_appearance_mode { BTS_APPEARANCE_FILTER = 0, BTS_APPEARANCE_DENSE = 1 };
 
@@ -265,7 +273,8 @@ int bts_tracker_export_state(bts_tracker *trk, int which, double *cov_host, floa
                              float *face_curr_host, float *face_smooth_host, bts_stream stream);
 
 /* One table slot's row of one field to HOST (slot = ints[row,7] of bts_tracker_export; synchronises):
- * field 0 mean[8] f64, 1 covariance[64] f64, 2 body_curr[D] f32, 3 body_smooth[D], 4 face_curr[Df], 5 face_smooth[Df]. */
+ * field 0 mean[8] f64, 1 covariance[64] f64, 2 body_curr[D] f32, 3 body_smooth[D], 4 face_curr[Df], 5 face_smooth[Df],
+ * 6 {track_id, state} int32[2]. */
 int bts_tracker_read_slot(bts_tracker *trk, int slot, int field, void *out_host, bts_stream stream);
 
 /* Last frame's association results to HOST (synchronises): for stage s in {1,2,3}
@@ -277,6 +286,11 @@ int bts_tracker_stage_result(bts_tracker *trk, int stage, int32_t *x_host, int32
 /* STrack.multi_gmc applied to every track of the tracked and lost lists (the reference's call
  * sites D:1534-1536 are commented out; call it between steps when a camera-motion estimate exists). */
 int bts_tracker_gmc(bts_tracker *trk, const double *h2x3_host, bts_stream stream);
+
+/* Counters of the appearance pre-filter for the last step (synchronises): out[0] K stages (128 elements) run over all
+ * tiles, [1] tiles, [2] tiles that stopped at a prefix checkpoint, [3] candidate pairs handed to the exact refinement,
+ * [5..7] clock cycles / 64 summed over the kernel's workgroups: in candidate tests, waiting for operand stages, in total. */
+int bts_tracker_debug_filter(bts_tracker *trk, int32_t *out16_host, bts_stream stream);
 
 /* Counters of the assignment solver for stage s of the last step (synchronises): out[0] feasible
  * edges, [1] components of the non-trivial part, [2] overflow flag, [6] edges that are not isolated
