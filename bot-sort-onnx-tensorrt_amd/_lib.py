@@ -12,7 +12,7 @@ import os
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbotsort_hip.so")
+LIB_PATH = os.environ.get("BTS_LIB_PATH") or os.path.join(_HERE, "libbotsort_hip.so")      # (override: A/B runs of two builds on one box)
 
 
 class BtsError(RuntimeError):
