@@ -147,11 +147,12 @@ def step_bytes(K, M, D):
     return float(survey), float(as_built)
 
 
-def table_rows(K):
+def table_rows(K, motion_gate=False):
     """Track-table capacity for a stream of K identities: the live tracks plus room for the duplicates a long run
     accumulates (with the motion gate a re-appearing identity whose prediction drifted is born again while its old
-    track waits out the 300-frame lost buffer; the reference's lists are unbounded)."""
-    return K + max(64, K // 8)
+    track waits out the 300-frame lost buffer, so a few hundred frames pile up some 0.15 K of them; the reference's
+    lists are unbounded, a table that fills up is reported as a device error and voids the run)."""
+    return K + (K // 2 if motion_gate else max(64, K // 8))
 
 
 class IdMatch:
@@ -164,7 +165,7 @@ class IdMatch:
     def __init__(self, pkg, K, M, D, motion_gate=False, **opts):
         import torch
         self.torch = torch
-        self.trk = pkg.DeviceTracker(max_tracks=table_rows(K), max_dets=max(K, M), feat_dim=D, device=torch.cuda.current_device(),
+        self.trk = pkg.DeviceTracker(max_tracks=table_rows(K, motion_gate), max_dets=max(K, M), feat_dim=D, device=torch.cuda.current_device(),
                                      motion_gate=1 if motion_gate else 0, **opts)
         self.frames = self.pairs = self.pairs_equal = self.ids = self.ids_equal = 0
         self.frames_identical = 0
@@ -371,7 +372,7 @@ def main():
     torch.cuda.set_stream(stream)
     frames = [next_frame() for _ in range(a.warmup)]
     opts = dict(appearance_mode=1 if a.dense else 0, use_graph=1 if a.graph else 0, motion_gate=1 if a.motion_gate else 0)
-    trk = pkg.DeviceTracker(max_tracks=table_rows(K), max_dets=max(K, M), feat_dim=D, device=torch.cuda.current_device(), **opts)
+    trk = pkg.DeviceTracker(max_tracks=table_rows(K, a.motion_gate), max_dets=max(K, M), feat_dim=D, device=torch.cuda.current_device(), **opts)
 
     ms = importlib.import_module("bot-sort-onnx-tensorrt_amd.multistream")
     ddist = dist if world > 1 else None
@@ -384,7 +385,7 @@ def main():
     for k in range(1, S):
         st_k = pkg.synth.make_workload(a.workload, seed=ms_seed(pkg, rank * S + k))
         with torch.cuda.stream(torch.cuda.default_stream()):      # (set-up on the default stream: see multistream.run_concurrent)
-            tk = pkg.DeviceTracker(max_tracks=table_rows(K), max_dets=max(K, M), feat_dim=D, device=torch.cuda.current_device(), **opts)
+            tk = pkg.DeviceTracker(max_tracks=table_rows(K, a.motion_gate), max_dets=max(K, M), feat_dim=D, device=torch.cuda.current_device(), **opts)
             for _ in range(a.warmup + 6):
                 fr = st_k.next()
                 tk.step(torch.from_numpy(fr.boxes).cuda(), torch.from_numpy(fr.scores).cuda(), torch.from_numpy(fr.feats).cuda())

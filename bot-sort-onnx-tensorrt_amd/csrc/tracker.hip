@@ -85,6 +85,8 @@ struct Dev {
     uint32_t *cbits;                                   // [T][cb_ld] candidate bitmap of the one-pass pre-filter (self-cleaning)
     int cb_ld;                                         // 32-bit words per bitmap row
     float gate_sim;                                    // the similarity the appearance term must reach: 1 - appearance_thresh
+    int32_t use_grid;                                   // BTS_EDGES_GRID=1 at create: stage-1 edges by neighbour search (experimental; wins only for very large frames)
+    int32_t *grid_hdr, *cell_start, *cell_items;       // uniform grid over the frame's high-score detections (prep_dets -> tk_edges_grid)
     int32_t *fstat;                                    // [8] pre-filter counters of the frame: K stages run, tiles, prefix exits, candidates
     const InDesc *in;          // inputs of the current step: descriptor in memory (hipGraph replay) ...
     InDesc iv;                 // ... or by value in the kernel arguments (eager launches, in == nullptr)
@@ -200,6 +202,71 @@ template <bool CH> __device__ __forceinline__ void prep_unconfirmed(const Dev &d
     if (ch == nchunks<CH>(d) - 1 && threadIdx.x == 0) { h[H_NUNC] = nunc; h[H_DIMS3] = nunc; }
 }
 
+// ---- uniform grid over the high-score detections, for the stage-1 neighbour search (tk_edges_grid) ---------------------
+// A pair (track, detection) can only get an IoU edge when the boxes overlap, i.e. when the detection's CENTRE lies inside
+// the track's box widened by half the detection's size.  The detections are binned by centre into square cells at least
+// as large as the largest detection of the frame, so a track looks at the few cells its widened box touches (3 x 3 for
+// boxes of similar size) instead of at every detection.  Coordinates are DOUBLED integers (2 cx = x1 + x2: no halves).
+// Built by the workgroup that has just compacted the high-score list: reductions, counts (LDS atomics), scan, scatter.
+constexpr int GRID_MAX = 128, GRID_CELLS = GRID_MAX * GRID_MAX;
+enum { G_OX = 0, G_OY, G_CS, G_GX, G_GY, G_MAXW, G_MAXH, G_NCELL };
+__device__ __forceinline__ void build_grid(const Dev &d, int nhi, int32_t *tmp) {
+    __shared__ int gcnt[GRID_CELLS];
+    __shared__ int gred[8];
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const int4 *boxes = reinterpret_cast<const int4 *>(IN(d, boxes));
+    if (tid < 8) gred[tid] = tid < 2 ? 0x7fffffff : tid < 4 ? (int)0x80000000 : 0;
+    __syncthreads();                                   // (also: the high-score list written above is visible to the whole workgroup)
+    int mnx = 0x7fffffff, mny = 0x7fffffff, mxx = (int)0x80000000, mxy = (int)0x80000000, mw = 0, mh = 0;
+    for (int p = tid; p < nhi; p += nth) {
+        const int4 b = boxes[d.hi_idx[p]];
+        const int cx2 = b.x + b.z, cy2 = b.y + b.w;
+        mnx = min(mnx, cx2); mny = min(mny, cy2); mxx = max(mxx, cx2); mxy = max(mxy, cy2);
+        mw = max(mw, b.z - b.x); mh = max(mh, b.w - b.y);
+    }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) {
+        mnx = min(mnx, __shfl_xor(mnx, off)); mny = min(mny, __shfl_xor(mny, off));
+        mxx = max(mxx, __shfl_xor(mxx, off)); mxy = max(mxy, __shfl_xor(mxy, off));
+        mw = max(mw, __shfl_xor(mw, off)); mh = max(mh, __shfl_xor(mh, off));
+    }
+    if ((tid & 63) == 0) {
+        atomicMin(&gred[0], mnx); atomicMin(&gred[1], mny); atomicMax(&gred[2], mxx); atomicMax(&gred[3], mxy);
+        atomicMax(&gred[4], mw); atomicMax(&gred[5], mh);
+    }
+    __syncthreads();
+    const int ox = gred[0], oy = gred[1], maxw = max(gred[4], 0), maxh = max(gred[5], 0);
+    const long spanx = nhi ? (long)gred[2] - ox : 0, spany = nhi ? (long)gred[3] - oy : 0;
+    long cs = 2L * max(max(maxw, maxh), 1);            // cell side (doubled coordinates) >= the largest detection
+    cs = max(cs, max(spanx, spany) / GRID_MAX + 1);    // ... and no more than GRID_MAX cells per axis
+    const int gx = (int)(spanx / cs) + 1, gy = (int)(spany / cs) + 1, ncell = gx * gy;
+    for (int c = tid; c < ncell; c += nth) gcnt[c] = 0;
+    __syncthreads();
+    auto cell_of = [&](int p) {
+        const int4 b = boxes[d.hi_idx[p]];
+        return (int)(((long)(b.y + b.w) - oy) / cs) * gx + (int)(((long)(b.x + b.z) - ox) / cs);
+    };
+    for (int p = tid; p < nhi; p += nth) atomicAdd(&gcnt[cell_of(p)], 1);
+    __syncthreads();
+    {   // exclusive scan of the counts: every thread owns a contiguous run of cells
+        const int per = (ncell + nth - 1) / nth, lo = min(ncell, tid * per), hi = min(ncell, lo + per);
+        int sum = 0;
+        for (int c = lo; c < hi; ++c) sum += gcnt[c];
+        int total;
+        int run = bscan::exscan(sum, tmp, &total);
+        for (int c = lo; c < hi; ++c) { const int v = gcnt[c]; gcnt[c] = run; d.cell_start[c] = run; run += v; }
+        if (tid == 0) d.cell_start[ncell] = nhi;
+    }
+    __syncthreads();
+    for (int p = tid; p < nhi; p += nth) d.cell_items[atomicAdd(&gcnt[cell_of(p)], 1)] = p;
+    if (tid == 0) {
+        int32_t *g = d.grid_hdr;
+        g[G_OX] = ox; g[G_OY] = oy; g[G_CS] = (int)min(cs, 0x7fffffffL); g[G_GX] = gx; g[G_GY] = gy;
+        g[G_MAXW] = maxw; g[G_MAXH] = maxh; g[G_NCELL] = ncell;
+    }
+    __syncthreads();
+}
+
 __device__ __forceinline__ void prep_dets(const Dev &d) {
     __shared__ int32_t tmp[1024];
     int32_t *h = d.hdr;
@@ -221,6 +288,7 @@ __device__ __forceinline__ void prep_dets(const Dev &d) {
                                        [&](int j, int v) { const double s = (double)__int_as_float(v); return (s <= d.high) & (s >= d.low); },
                                        [&](int p, int j, int) { d.hi_idx[p] = j; }, [&](int p, int j, int) { d.lo_idx[p] = j; });
     const int nhi = nn.x, nlo = nn.y;
+    if (d.filter && d.use_grid) build_grid(d, nhi, tmp);
     if (tid < 3 * BTS_LAP_HDR_INTS) d.lap_hdr[tid] = 0;
     if (tid < 16 && d.filter) d.fstat[tid] = tid == 8 || tid == 12 ? 0x7fffffff : 0;
     if (tid == 0) {
@@ -627,6 +695,149 @@ __global__ __launch_bounds__(CT_COLS) void tk_edges_tall_gate(Dev d, bts_lap_wor
 template <int ROWS>
 __global__ __launch_bounds__(CT_COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) void tk_edges_tall_gate_c(Dev d, bts_lap_work w, int accum) {
     edges_all<1, 1, ROWS, true>(d, w, blockIdx.x, gridDim.x, accum);
+}
+
+// ---- stage-1 cost edges by neighbour search (the default when the pre-filter left a candidate bitmap) -------------------
+// One wavefront per 64 pool rows.  (1) Geometry: lane = row; the row's predicted box is looked up in the detections' grid
+// (build_grid) and the few detections found get the exact float64 IoU cost (pairs that are appearance candidates are
+// left to (2)).  (2) Appearance: the rows' words of the candidate bitmap are swept 64 at a time (coalesced); every
+// candidate pair gets the exact float32 dot product from the whole wavefront and ONE edge with min(IoU cost, 1 - sim)
+// (np.minimum of D:1554) when that is within the match threshold.  Edges are staged in LDS and appended
+// with one counter bump per wavefront.  Same edges as the tile form (tk_edges<1,1,R>), in another order -- the solver
+// does not depend on the order.
+template <bool GATE>
+__global__ __launch_bounds__(64) void tk_edges_grid(Dev d, bts_lap_work w) {
+    constexpr int EB = 512;
+    __shared__ double wb_c[EB];
+    __shared__ int32_t wb_r[EB], wb_q[EB];
+    const int32_t *h = d.hdr;
+    const int n = h[H_NPOOL], m = h[H_NHI];
+    const int lane = threadIdx.x;
+    const double limit = d.match1;
+    const int32_t *g = d.grid_hdr;
+    const int ox = g[G_OX], oy = g[G_OY], cs = g[G_CS], gx = g[G_GX], gy = g[G_GY], maxw = g[G_MAXW], maxh = g[G_MAXH];
+    int wcount = 0;
+    auto flush = [&]() {
+        if (wcount == 0) return;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&w.hdr[0], wcount);
+        base = __shfl(base, 0);
+        for (int k = lane; k < wcount; k += 64) {
+            const int pos = base + k;
+            if (pos < w.e_cap) { w.e_row[pos] = wb_r[k]; w.e_col[pos] = wb_q[k]; w.e_cost[pos] = wb_c[k]; }
+            else w.hdr[2] = 1;
+        }
+        wcount = 0;
+    };
+    auto emit = [&](bool pred, int row, int q, double c) {          // convergent: every lane of the wavefront calls it
+        const unsigned long long mk = __ballot(pred);
+        if (!mk) return;
+        if (wcount + __popcll(mk) > EB) flush();
+        if (pred) {
+            const int p = wcount + __popcll(mk & ((1ull << lane) - 1ull));
+            wb_c[p] = c; wb_r[p] = row; wb_q[p] = q;
+        }
+        wcount += __popcll(mk);
+    };
+    const int words = (m + 31) >> 5;                    // live words of a bitmap row
+    // RPW rows per wavefront (many wavefronts: every step below is a chain of dependent loads, and the exact dot products
+    // of the candidates want to be spread thin); LPR lanes share a row in the neighbour search (cells dealt round-robin)
+    constexpr int RPW = 16, LPR = 64 / RPW;
+    for (int base = (int)blockIdx.x * RPW; base < n; base += (int)gridDim.x * RPW) {
+        const int rows = min(RPW, n - base);
+        const int i = base + lane / LPR, sub = lane % LPR;
+        const bool live = i < n;
+        // this lane's row
+        double aa[4] = {0.0, 0.0, 0.0, 0.0};
+        if (live) { aa[0] = d.pool_tlbr[i * 4 + 0]; aa[1] = d.pool_tlbr[i * 4 + 1]; aa[2] = d.pool_tlbr[i * 4 + 2]; aa[3] = d.pool_tlbr[i * 4 + 3]; }
+        const double area_a = iou::area(aa, false);
+        // ---- (1) geometric neighbours: walk the cells the row's widened box touches (pairs that are appearance
+        //      candidates are left to (2), which gives them their one edge)
+        int cx0 = 0, ncx = 0, cy0 = 0, ncell_r = 0;
+        if (live && m > 0) {
+            // detection centres (doubled) that can belong to an overlapping box: (2 x1 - maxw, 2 x2 + maxw) x (2 y1 - maxh, 2 y2 + maxh)
+            const double lx = 2.0 * aa[0] - (double)maxw - (double)ox, hx = 2.0 * aa[2] + (double)maxw - (double)ox;
+            const double ly = 2.0 * aa[1] - (double)maxh - (double)oy, hy = 2.0 * aa[3] + (double)maxh - (double)oy;
+            const double span_x = (double)gx * (double)cs, span_y = (double)gy * (double)cs;
+            if (hx >= 0.0 && lx < span_x && hy >= 0.0 && ly < span_y && hx >= lx && hy >= ly) {
+                cx0 = lx <= 0.0 ? 0 : (int)(lx / (double)cs);
+                cy0 = ly <= 0.0 ? 0 : (int)(ly / (double)cs);
+                const int cx1 = min(hx >= span_x ? gx - 1 : (int)(hx / (double)cs), gx - 1);
+                const int cy1 = min(hy >= span_y ? gy - 1 : (int)(hy / (double)cs), gy - 1);
+                ncx = cx1 - cx0 + 1;
+                ncell_r = ncx > 0 && cy1 >= cy0 ? ncx * (cy1 - cy0 + 1) : 0;
+            }
+        }
+        int ck = sub, it = 0, it_end = 0;               // this lane's next cell (linear index in the row's range), item cursor
+        bool more = ck < ncell_r;
+        if (more) { const int c = (cy0 + ck / ncx) * gx + cx0 + ck % ncx; it = d.cell_start[c]; it_end = d.cell_start[c + 1]; }
+        while (__any(more)) {
+            bool have = false;
+            int q = 0;
+            if (more) {
+                while (it >= it_end) {                   // next non-empty cell of this lane's share
+                    ck += LPR;
+                    if (ck >= ncell_r) { more = false; break; }
+                    const int c = (cy0 + ck / ncx) * gx + cx0 + ck % ncx;
+                    it = d.cell_start[c]; it_end = d.cell_start[c + 1];
+                }
+                if (more) { q = d.cell_items[it++]; have = true; }
+            }
+            if (have && ((d.cbits[(long)i * d.cb_ld + (q >> 5)] >> (q & 31)) & 1u)) have = false;
+            double c = 1.0;
+            bool edge = false;
+            if (have) {
+                const int det = d.hi_idx[q];
+                const double bb[4] = {d.det_tlbr[det * 4 + 0], d.det_tlbr[det * 4 + 1], d.det_tlbr[det * 4 + 2], d.det_tlbr[det * 4 + 3]};
+                c = iou::cost(aa, false, area_a, bb, true, iou::area(bb, true));
+                edge = c <= limit;
+                if (GATE && edge) edge = motion_gate_open(d, d.pool_slot[i], det);
+            }
+            emit(edge, i, q, c);
+        }
+        // ---- (2) appearance candidates: lane = bitmap word, one row per step (the words are consumed: this wavefront's rows only)
+        for (int w0 = 0; w0 < words; w0 += 64) {
+            const int wl = w0 + lane;
+            for (int r0 = 0; r0 < rows; r0 += 8) {
+                uint32_t wv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    wv[u] = (r0 + u < rows && wl < words) ? d.cbits[(long)(base + r0 + u) * d.cb_ld + wl] : 0u;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    unsigned long long any = __ballot(wv[u] != 0u);
+                    if (!any) continue;
+                    const int row = base + r0 + u;
+                    if (wv[u]) d.cbits[(long)row * d.cb_ld + wl] = 0u;              // consumed
+                    const long strk = d.pool_slot[row];
+                    const double ra[4] = {d.pool_tlbr[row * 4 + 0], d.pool_tlbr[row * 4 + 1], d.pool_tlbr[row * 4 + 2], d.pool_tlbr[row * 4 + 3]};
+                    const double rarea = iou::area(ra, false);
+                    while (any) {
+                        const int src = __ffsll((long long)any) - 1;
+                        any &= any - 1;
+                        uint32_t bits = __shfl(wv[u], src);
+                        while (bits) {
+                            const int q = (w0 + src) * 32 + (__ffs((int)bits) - 1);
+                            bits &= bits - 1;
+                            if (q >= m) continue;
+                            const long det = d.hi_idx[q];
+                            const float emb = 1.0f - fmaxf(0.0f, feat::wave_dot<8>(d.body_curr + strk * d.D, IN(d, feats) + det * d.D, d.D, lane));
+                            float face = 1.0f;
+                            if (d.Df)
+                                face = 1.0f - face_fixup(fmaxf(0.0f, feat::wave_dot<8>(d.face_curr + strk * d.Df, IN(d, face_feats) + det * d.Df, d.Df, lane)));
+                            const double bb[4] = {d.det_tlbr[det * 4 + 0], d.det_tlbr[det * 4 + 1], d.det_tlbr[det * 4 + 2], d.det_tlbr[det * 4 + 3]};
+                            double c = iou::cost(ra, false, rarea, bb, true, iou::area(bb, true));
+                            if (!(fminf(emb, face) > d.app)) c = fmin(c, (double)emb);
+                            bool edge = lane == 0 && c <= limit;
+                            if (GATE && edge) edge = motion_gate_open(d, strk, (int)det);
+                            emit(edge, row, q, c);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    flush();
 }
 
 // ---- appearance pre-filter: int8 MFMA GEMM with prefix exits + exact float32 refine -----------------------------
@@ -1722,6 +1933,7 @@ static void tracker_layout(bts_tracker *t, char *base, size_t &off) {
         SLOT(d.body_h, int8_t, T * D); SLOT(d.det_h, int8_t, M * D); SLOT(d.body_m, float, T * feat::I8_META); SLOT(d.det_m, float, M * feat::I8_META);
         SLOT(d.face_h, int8_t, T * Df); SLOT(d.dface_h, int8_t, M * Df); SLOT(d.face_m, float, T * feat::I8_META); SLOT(d.dface_m, float, M * feat::I8_META);
         SLOT(d.fstat, int32_t, 16);
+        SLOT(d.grid_hdr, int32_t, 8); SLOT(d.cell_start, int32_t, GRID_CELLS + 1); SLOT(d.cell_items, int32_t, M);
         // split-K accumulators: only tables small enough to ever need split K (< 256 tiles of 128 x 128) carry them
         if (T * M <= SPLITK_MAX_ENTRIES) { SLOT(d.approx, int32_t, T * M); SLOT(d.approx_f, int32_t, d.Df ? T * M : 1); }
         else { d.approx = nullptr; d.approx_f = nullptr; }
@@ -1778,6 +1990,7 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
     }
     // the pre-filter works on 128-element K steps; other feature widths take the dense float32 path
     d.filter = (cfg->appearance_mode == BTS_APPEARANCE_FILTER && d.D % DBK == 0 && d.Df % DBK == 0) ? 1 : 0;
+    d.use_grid = getenv("BTS_EDGES_GRID") != nullptr ? 1 : 0;
     d.gate_sim = 1.0f - d.app;
     size_t off = 0;
     tracker_layout(t, nullptr, off);
@@ -1984,7 +2197,10 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
     seg_end(BTS_SEG_COS1);
     seg_begin(BTS_SEG_COST1);
     seg_begin(BTS_SEG_K_EDGES1);
-    if (d.filter && d.motion_gate) {
+    const bool grid_form = d.use_grid && d.filter && !accum && !d.record;
+    if (grid_form && d.motion_gate) {
+        LAUNCH(tk_edges_grid<true>, dim3(bts_cdiv(T, 16)), dim3(64), lap[0]);
+    } else if (d.filter && d.motion_gate) {
         switch (trows) {
         case 2: LAUNCH((tk_edges<1, 1, 2, true>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
         case 4: LAUNCH((tk_edges<1, 1, 4, true>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
@@ -1996,6 +2212,10 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
         default: LAUNCH(tk_edges_tall_gate_c<256>, dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
         }
         if (d.record) { LAUNCH((tk_edges<1, 2>), tile_grid, dim3(CT_COLS), lap[0], 0); }
+    } else if (grid_form) {
+        // neighbour search on the detections' grid: opt-in (BTS_EDGES_GRID=1 when the tracker is created).  Measured on
+        // MI355X it only beats the tile forms below at 20 000 x 5 000 (34 vs 40 us); at the headline size it is 2 us slower.
+        LAUNCH(tk_edges_grid<false>, dim3(bts_cdiv(T, 16)), dim3(64), lap[0]);
     } else if (d.filter) {
         switch (trows) {
         case 2: LAUNCH((tk_edges<1, 1, 2>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;

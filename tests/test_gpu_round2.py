@@ -142,6 +142,17 @@ def test_adversarial_scenes_vs_oracle(bts, synth, name):
     assert int(lap[0][2]) == 0      # no edge-list overflow
 
 
+def test_edges_by_neighbour_search_opt_in(bts, synth, monkeypatch):
+    """BTS_EDGES_GRID=1 (read when the tracker is created) builds the stage-1 edge list by a neighbour search on a grid
+    over the detections instead of by tiles: the reference's G9 trace and the c3 gate run must come out the same."""
+    monkeypatch.setenv("BTS_EDGES_GRID", "1")
+    assert _replay_light(bts, synth, "g9_c3_trace.npz") > 0
+    K, M, D = 1024, 256, 512
+    st = synth.SyntheticStream(K, M, D, seed=5)
+    matched, lap = _against_vector_oracle(bts, st, K, M, D, frames=5, motion_gate=True)
+    assert matched > 2 * M
+
+
 # ------------------------------------------------------------------------------- the drop-in boundary
 class _FakeDetector:
     """What BoTSORT.update(image) asks of the detector (D:1301): a callable returning Box records."""
