@@ -6,8 +6,8 @@ pkg = importlib.import_module("bot-sort-onnx-tensorrt_amd")
 names = {0: ["prep_pool", "prep_unconfirmed", "prep_dets", "prep_free", "cvt(first)"], 1: ["r2 rows", "left dets", "unc boxes", "renorm(first)"],
          2: ["births", "keep", "re-found", "old lost+expiry", "newly lost"], 3: ["tracked", "lost"]}
 for wl in sys.argv[1:]:
-    K, M, D = pkg.synth.CONFIGS[wl]
-    st = pkg.synth.SyntheticStream(K, M, D, seed=1234)
+    K, M, D = pkg.synth.workload_dims(wl)
+    st = pkg.synth.make_workload(wl, seed=1234)
     trk = pkg.DeviceTracker(max_tracks=K + 64, max_dets=max(K, M), feat_dim=D)
     acc = []
     for f in range(24):

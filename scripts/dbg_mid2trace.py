@@ -5,8 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 pkg = importlib.import_module("bot-sort-onnx-tensorrt_amd")
 for wl in sys.argv[1:]:
-    K, M, D = pkg.synth.CONFIGS[wl]
-    st = pkg.synth.SyntheticStream(K, M, D, seed=1234)
+    K, M, D = pkg.synth.workload_dims(wl)
+    st = pkg.synth.make_workload(wl, seed=1234)
     trk = pkg.DeviceTracker(max_tracks=K + 64, max_dets=max(K, M), feat_dim=D)
     acc = []
     for f in range(24):
