@@ -68,7 +68,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline, the ID match and the standalone kernels")
     ap.add_argument("--no-export", action="store_true", help="skip the export-inclusive legs")
-    ap.add_argument("--dense", action="store_true", help="dense float32 appearance path instead of the fp8 pre-filter")
+    ap.add_argument("--dense", action="store_true", help="dense float32 appearance path instead of the int8 pre-filter")
     ap.add_argument("--graph", action="store_true", help="replay each step as one hipGraph (bts_tracker_config.use_graph)")
     ap.add_argument("--breakdown", action="store_true", help="also print the per-segment timing table to stderr")
     ap.add_argument("--motion-gate", action="store_true", help="Mahalanobis gate on the stage-1 pairs (bts_tracker_config.motion_gate; "
@@ -137,7 +137,7 @@ def step_bytes(K, M, D):
     survey   SURVEY.md 8(d)'s formula with its fp32 element sizes (s_k = s_f = s_c = 4), K_matches = M:
              2 N 72 s_k + K (2 72 + 4) s_k + (N + M) 16 + (N + M) D s_f + 2 N M s_c + 4 K D s_f + 4 (N + M)
     as_built what this implementation has to move: float64 Kalman rows (s_k = 8), no N x M matrix at all (the 2 N M s_c
-             term is gone), each track / high-score detection feature row read once as its 1-byte fp8 shadow by the
+             term is gone), each track / high-score detection feature row read once as its 1-byte int8 shadow by the
              pre-filter, detection rows read once in float32 and their shadows written, exact float32 refinement of one
              candidate per high-score detection (two rows), feature write-back 18 D bytes per match."""
     N, Km, Mh = K, M, M - M // 8
