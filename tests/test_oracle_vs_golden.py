@@ -189,6 +189,50 @@ def test_g6_faces(synth):
     _replay("g6_faces.npz", synth)
 
 
+def _replay_big(name, synth, faithful_iou):
+    """G9 / G10 hold what make_golden.py --big recorded from the REFERENCE at 4096 x 1024 and 10 000 x 2 000: assignment
+    indices, ordered id / state tables, checksums of the means (and the means themselves where they were kept)."""
+    g = golden(name)
+    K, M, D, frames = int(g["K"]), int(g["M"]), int(g["D"]), int(g["frames"])
+    st = synth.SyntheticStream(K, M, D, seed=int(g["seed"]))
+    trk = bo.TrackerOracle(faithful_iou=faithful_iou)
+    h = hashlib.sha256()
+    for f in range(frames):
+        fr = st.next()
+        h.update(fr.boxes.tobytes()); h.update(fr.scores.tobytes()); h.update(fr.feats.tobytes())
+        trk.update_arrays(fr.boxes, fr.scores.astype(np.float64), fr.feats.copy(), None)
+        for k in (1, 2, 3):
+            p = "f%d_s%d_" % (f, k)
+            assert np.array_equal(np.asarray(trk.trace["m%d" % k]).reshape(-1, 2), g[p + "m"].reshape(-1, 2)), (f, k)
+            assert np.array_equal(trk.trace["u_trk%d" % k], g[p + "u_trk"]), (f, k)
+            assert np.array_equal(trk.trace["u_det%d" % k], g[p + "u_det"]), (f, k)
+        for nm, lst in (("trk", trk.tracked), ("lost", trk.lost)):
+            t = bo.TrackerOracle.table(lst)
+            p = "f%d_%s_" % (f, nm)
+            for key in ("track_id", "state", "is_activated", "frame_id", "start_frame", "tracklet_len"):
+                assert np.array_equal(t[key], g[p + key]), (f, nm, key)
+            want = g[p + "mean_sum"]
+            got = np.asarray([t["mean"].sum(), np.abs(t["mean"]).sum()])
+            assert np.abs(got - want).max() <= 1e-9 * max(1.0, np.abs(want).max()), (f, nm)
+            if (p + "mean") in g.files and len(t["mean"]):
+                assert np.abs(t["mean"] - g[p + "mean"]).max() <= 1e-9, (f, nm)
+        assert len(trk.removed) == int(g["f%d_n_removed" % f])
+    assert h.hexdigest() == str(g["input_sha256"])
+    assert trk._count == int(g["last_id"])
+
+
+def test_g9_vectorised_oracle_vs_the_reference_at_c3_size(synth):
+    """The GPU tests and bench.py's id_match at the big sizes check the device against the VECTORISED form of the oracle
+    (faithful_iou=False: same arithmetic, array IoU instead of the per-pair Python loop).  This pins that form to the
+    reference itself at 4096 x 1024 x 2048."""
+    _replay_big("g9_c3_trace.npz", synth, faithful_iou=False)
+
+
+def test_g10_vectorised_oracle_vs_the_reference_at_the_headline_size(synth):
+    """Same at 10 000 x 2 000 x 2048 (four frames; the dense JV runs on the 12 000 x 12 000 extended matrix)."""
+    _replay_big("g10_target_trace.npz", synth, faithful_iou=False)
+
+
 def test_motion_gate_extension_of_the_oracle(synth):
     """The optional motion gate (not in the reference's loop) is built from pieces the golden vectors pin
     (gating_distance: G1; chi2inv95[4] = 9.4877, D:139-149).  Off it changes nothing; on, a detection teleported 300 px
