@@ -63,6 +63,7 @@ SIGNATURES = {
     "bts_associate_parts": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, _P, c_int, _P, _P]),
     "bts_dedupe_pairs": (c_int, [_P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_double, _P, _P, _P]),
     "bts_tracker_default_config": (c_int, [POINTER(TrackerConfig)]),
+    "bts_tracker_memory_bytes": (c_int, [POINTER(TrackerConfig), POINTER(ctypes.c_uint64)]),
     "bts_tracker_create": (c_int, [_P, POINTER(TrackerConfig), POINTER(c_void_p)]),
     "bts_tracker_destroy": (c_int, [_P]),
     "bts_tracker_reset": (c_int, [_P, _P]),

@@ -1960,6 +1960,32 @@ int bts_tracker_default_config(bts_tracker_config *cfg) {
     return BTS_OK;
 }
 
+int bts_tracker_memory_bytes(const bts_tracker_config *cfg, uint64_t *out_bytes) {
+    BTS_REQUIRE(cfg && out_bytes, "null argument");
+    BTS_REQUIRE(cfg->max_tracks > 0 && cfg->max_dets > 0 && cfg->feat_dim > 0 && cfg->face_dim >= 0, "capacities");
+    BTS_REQUIRE((int64_t)cfg->max_tracks * cfg->max_dets < (1ll << 31), "max_tracks * max_dets must fit int32");
+    BTS_REQUIRE(cfg->max_edges >= 0, "max_edges");
+    // the sizes bts_tracker_create derives from cfg, then the same layout walk with no base address
+    bts_tracker *t = new (std::nothrow) bts_tracker();
+    if (!t) { bts_set_error("host allocation failed"); return BTS_ENOMEM; }
+    t->cfg = *cfg;
+    Dev &d = t->dv;
+    memset(&d, 0, sizeof(d));
+    d.T = cfg->max_tracks; d.Mx = cfg->max_dets; d.D = cfg->feat_dim; d.Df = cfg->face_dim;
+    d.record = cfg->record_costs ? 1 : 0;
+    d.filter = (cfg->appearance_mode == BTS_APPEARANCE_FILTER && d.D % DBK == 0 && d.Df % DBK == 0) ? 1 : 0;
+    size_t off = 0;
+    tracker_layout(t, nullptr, off);
+    int64_t e_cap = (int64_t)d.T * d.Mx;
+    const int64_t e_auto = 64ll * ((int64_t)d.T + d.Mx);
+    if (cfg->max_edges > 0) e_cap = e_cap < cfg->max_edges ? e_cap : cfg->max_edges;
+    else if (e_cap > e_auto) e_cap = e_auto;
+    off += 2 * bts_lap_work_bytes(d.T, d.Mx, e_cap);
+    *out_bytes = (uint64_t)off;
+    delete t;
+    return BTS_OK;
+}
+
 int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_tracker **out) {
     BTS_REQUIRE(ctx && cfg && out, "null argument");
     BTS_ON_DEVICE(ctx);

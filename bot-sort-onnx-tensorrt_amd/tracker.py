@@ -346,6 +346,22 @@ class STrack(BaseTrack):
         return "OT_{}_({}-{})".format(self.track_id, self.start_frame, self.end_frame)   # D:687-688
 
 
+def tracker_memory_bytes(max_tracks: int, max_dets: int, feat_dim: int, face_dim: int = 0, record_costs: bool = False, **options) -> int:
+    """Device bytes a DeviceTracker with these capacities allocates (bts_tracker_memory_bytes: host-only, no GPU needed)."""
+    lib = _lib.load()
+    cfg = _lib.TrackerConfig()
+    _lib.check(lib.bts_tracker_default_config(ctypes.byref(cfg)))
+    cfg.max_tracks, cfg.max_dets, cfg.feat_dim, cfg.face_dim = max_tracks, max_dets, feat_dim, face_dim
+    cfg.record_costs = 1 if record_costs else 0
+    for k, v in options.items():
+        if not hasattr(cfg, k):
+            raise TypeError("unknown tracker option %r" % k)
+        setattr(cfg, k, v)
+    out = ctypes.c_uint64()
+    _lib.check(lib.bts_tracker_memory_bytes(ctypes.byref(cfg), ctypes.byref(out)))
+    return int(out.value)
+
+
 class DeviceTracker:
     """Thin owner of a `bts_tracker` handle."""
 

@@ -227,6 +227,11 @@ typedef struct bts_tracker_config {
 /* Fill cfg with the reference's hard-coded values (D:1268-1277). */
 int bts_tracker_default_config(bts_tracker_config *cfg);
 
+/* Device bytes bts_tracker_create(cfg) allocates for the track table and its per-frame work arrays (one block; the
+   shared scratch arena of the context is not included).  Host-only: needs no GPU and no context -- for sizing how many
+   streams fit one GPU's 288 GB.  Reads the same environment switches as create. */
+int bts_tracker_memory_bytes(const bts_tracker_config *cfg, uint64_t *out_bytes);
+
 int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_tracker **out);
 int bts_tracker_destroy(bts_tracker *trk);
 /* Back to frame 0, no tracks, ID counter 0 (what constructing a new BoTSORT does, D:1261-1266). */

@@ -78,3 +78,19 @@ def test_no_gpu_means_loud_failure():
     pkg = importlib.import_module("bot-sort-onnx-tensorrt_amd")
     with pytest.raises(pkg.BtsError):
         pkg.iou_distance([[0, 0, 1, 1]], [[0, 0, 1, 1]])
+
+
+def test_tracker_memory_is_linear_in_the_capacities():
+    """bts_tracker_memory_bytes (host-only): nothing in the default mode is O(T * M) except the candidate bitmap -- the
+    round-1 layout allocated 5.9 GB for 16384 x 4096 x 2048 (ADVICE), DESIGN.md section 2 quotes this function's figure."""
+    pkg = importlib.import_module("bot-sort-onnx-tensorrt_amd")
+    f = pkg.tracker_memory_bytes
+    big = f(16384, 4096, 2048)
+    assert 400e6 < big < 480e6
+    feature_tables = 2 * 16384 * 2048 * 4 + 16384 * 2048
+    assert big > feature_tables and big - feature_tables < 150e6            # everything else: < 150 MB
+    assert f(16384, 4096, 2048, appearance_mode=1) - big > 16384 * 4096 * 4 * 0.7   # DENSE mode: + the similarity matrix (- the int8 shadows)
+    assert f(4096, 1024, 2048, record_costs=True) - f(4096, 1024, 2048) > 3 * 4096 * 1024 * 8
+    assert f(16384, 4096, 2048, max_edges=100000) < big
+    with pytest.raises(pkg.BtsError):
+        f(0, 10, 128)
