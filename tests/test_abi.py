@@ -94,3 +94,28 @@ def test_tracker_memory_is_linear_in_the_capacities():
     assert f(16384, 4096, 2048, max_edges=100000) < big
     with pytest.raises(pkg.BtsError):
         f(0, 10, 128)
+
+
+def test_binding_argument_counts_match_the_header():
+    """Every prototype of include/botsort_hip.h against the ctypes signature table: same number of parameters, pointer
+    parameters bound as pointers (a drifted binding would pass garbage through the C ABI without any error)."""
+    import ctypes
+    lib_mod = importlib.import_module("bot-sort-onnx-tensorrt_amd._lib")
+    text = open(os.path.join(REPO, "include", "botsort_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    protos = re.findall(r"\b(?:int|const char \*|void)\s*\*?\s*(bts_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S)
+    seen = {}
+    for name, params in protos:
+        params = " ".join(params.split())
+        plist = [] if params in ("", "void") else [q.strip() for q in params.split(",")]
+        seen[name] = plist
+    assert set(seen) == set(lib_mod.SIGNATURES), set(seen) ^ set(lib_mod.SIGNATURES)
+    pointer_types = (ctypes.c_void_p, ctypes.c_char_p)
+    for name, plist in seen.items():
+        _, argtypes = lib_mod.SIGNATURES[name]
+        assert len(argtypes) == len(plist), (name, plist, argtypes)
+        for decl, at in zip(plist, argtypes):
+            is_ptr_c = "*" in decl or decl.startswith("bts_stream ")      # (typedef void *bts_stream)
+            is_ptr_py = at in pointer_types or hasattr(at, "contents") or at is lib_mod._P
+            assert is_ptr_c == is_ptr_py, (name, decl, at)
