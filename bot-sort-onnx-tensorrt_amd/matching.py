@@ -55,9 +55,9 @@ def iou_distance(atracks, btracks) -> np.ndarray:
     return _iou_cost(atracks, btracks)
 
 
-def bbox_iou(box1, box2) -> float:
+def bbox_iou(atlbr, btlbr) -> float:
     """D:1695-1713 (one pair; goes through the same kernel)."""
-    return float(1 - _iou_cost([np.asarray(box1)], [np.asarray(box2)])[0, 0])
+    return float(1 - _iou_cost([np.asarray(atlbr)], [np.asarray(btlbr)])[0, 0])
 
 
 def cosine_similarity(track_feats, det_feats) -> np.ndarray:

@@ -12,7 +12,7 @@ run on the MI355X with no host round trip; this module only
 from __future__ import annotations
 
 import ctypes
-from collections import deque
+from collections import OrderedDict, deque
 from typing import List, Optional
 
 import numpy as np
@@ -94,9 +94,13 @@ class BaseTrack:                       # D:389-437 (the ID counter lives in the 
     track_id = 0
     is_activated = False
     state = TrackState.New
+    history = OrderedDict()
+    features = []
     score = 0
     start_frame = 0
     frame_id = 0
+    time_since_update = 0
+    location = (np.inf, np.inf)           # (multi-camera field of the reference; never read by the tracker)
 
     @property
     def end_frame(self):
@@ -110,6 +114,15 @@ class BaseTrack:                       # D:389-437 (the ID counter lives in the 
     @staticmethod
     def clear_count():
         BaseTrack._count = 0
+
+    def activate(self, *args):             # abstract in the reference too (D:389-437): STrack overrides all three
+        raise NotImplementedError
+
+    def predict(self):
+        raise NotImplementedError
+
+    def update(self, *args, **kwargs):
+        raise NotImplementedError
 
     def mark_lost(self):
         self.state = TrackState.Lost
@@ -166,6 +179,7 @@ class STrack(BaseTrack):
         self._body_smooth_feature = None
         self._face_curr_feature = None
         self._face_smooth_feature = None
+        self.feature_history = feature_history
         self.body_features = deque([], maxlen=feature_history)
         self.face_features = deque([], maxlen=feature_history)
         self.det_index = -1
@@ -584,6 +598,8 @@ class BoTSORT:
         self.match_thresh = 0.8
         self.track_buffer = 300
         self.feature_history = 300
+        self.body_strack_features = []      # (D:1285, D:1289: set once, never updated by the reference -- the update
+        self.face_strack_features = []      #  loop's lists of the same name are locals; the tracks' features live on the device)
         self.proximity_thresh = 0.5
         self.appearance_thresh = 0.25
         self.buffer_size = int(frame_rate / 30.0 * self.track_buffer)
