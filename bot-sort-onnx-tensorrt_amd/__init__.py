@@ -11,7 +11,7 @@ from . import _lib
 from ._lib import BtsError, Context, LIB_PATH
 from .kalman_filter import KalmanFilter
 from .matching import (bbox_iou, bbox_ious, cosine_similarity, fuse_cost_stage1, fuse_cost_stage3, iou_distance,
-                       lapjv, linear_assignment, associate_parts, find_most_relevant_object)
+                       lapjv, linear_assignment, associate_parts, find_most_relevant_object, bbox_iou_by_box)
 from .tracker import (Box, Body, Head, Face, Hand, attach_parts, BaseTrack, BoTSORT, DeviceTracker, tracker_memory_bytes, PinnedMot, STrack, TrackState, joint_stracks, remove_duplicate_stracks,
                       sub_stracks)
 from . import multistream, synth
@@ -20,5 +20,5 @@ __all__ = [
     "BtsError", "Context", "LIB_PATH", "KalmanFilter", "TrackState", "BaseTrack", "STrack", "BoTSORT", "DeviceTracker", "tracker_memory_bytes",
     "linear_assignment", "lapjv", "iou_distance", "bbox_ious", "bbox_iou", "cosine_similarity", "fuse_cost_stage1",
     "fuse_cost_stage3", "joint_stracks", "sub_stracks", "remove_duplicate_stracks", "synth", "multistream",
-    "PinnedMot", "Box", "Body", "Head", "Face", "Hand", "attach_parts", "associate_parts", "find_most_relevant_object",
+    "PinnedMot", "Box", "Body", "Head", "Face", "Hand", "attach_parts", "associate_parts", "find_most_relevant_object", "bbox_iou_by_box",
 ]

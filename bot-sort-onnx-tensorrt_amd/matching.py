@@ -199,6 +199,13 @@ def associate_parts(base_boxes, base_centres, target_boxes, target_centres, used
     return out.cpu().numpy().astype(np.int64).reshape(nb, picks), du.cpu().numpy().astype(bool)
 
 
+def bbox_iou_by_box(base_obj, target_obj) -> float:
+    """D:1715-1729: IoU of two detector boxes (objects with integer x1, y1, x2, y2); 0.0 when they do not overlap.
+    Goes through the IoU kernel on float64 copies of the pixel coordinates (exact there)."""
+    box = lambda o: np.asarray([o.x1, o.y1, o.x2, o.y2], dtype=np.float64)
+    return bbox_iou(box(base_obj), box(target_obj))
+
+
 def find_most_relevant_object(base_obj, target_objs):
     """D:1763-1791 with the reference's signature: the not-yet-used target (objects with x1, y1, x2, y2,
     cx, cy, is_used) that overlaps `base_obj` most; it is marked used and returned (None if none overlaps)."""

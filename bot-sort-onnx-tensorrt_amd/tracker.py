@@ -33,15 +33,17 @@ class Box:                             # D:84-95: what the detector hands over, 
                    cx=box.cx, cy=box.cy, is_used=False, **extra)
 
 
-class Body(Box):                       # D:97-102
-    def __init__(self, head=None, hand1=None, hand2=None, **kw):
-        super().__init__(**kw)
+class Body(Box):                       # D:97-102 (parameter order as in the reference: the ten Box fields first)
+    def __init__(self, trackid=0, classid=0, score=0.0, x1=0, y1=0, x2=0, y2=0, cx=0, cy=0, is_used=False,
+                 head=None, hand1=None, hand2=None):
+        super().__init__(trackid, classid, score, x1, y1, x2, y2, cx, cy, is_used)
         self.head, self.hand1, self.hand2 = head, hand1, hand2
 
 
 class Head(Box):                       # D:104-108
-    def __init__(self, face=None, face_landmarks=None, **kw):
-        super().__init__(**kw)
+    def __init__(self, trackid=0, classid=0, score=0.0, x1=0, y1=0, x2=0, y2=0, cx=0, cy=0, is_used=False,
+                 face=None, face_landmarks=None):
+        super().__init__(trackid, classid, score, x1, y1, x2, y2, cx, cy, is_used)
         self.face, self.face_landmarks = face, face_landmarks
 
 

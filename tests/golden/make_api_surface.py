@@ -51,6 +51,13 @@ def main():
         out["classes"][cname] = members(cls, [n for n in names if hasattr(cls, n)])
     for f in ("linear_assignment", "iou_distance", "bbox_ious", "bbox_iou", "joint_stracks", "sub_stracks", "remove_duplicate_stracks"):
         out["functions"][f] = sig(getattr(mod, f))
+    out["records"] = {}        # the detector's box records (D:84-116): constructor parameters and base classes
+    for cname in ("Box", "Body", "Head", "Face", "Hand"):
+        cls = getattr(mod, cname)
+        out["records"][cname] = {"params": sig(cls)[0:], "bases": [b.__name__ for b in cls.__mro__[1:] if b.__name__ not in ("ABC", "object")]}
+    for f in ("find_most_relevant_object", "bbox_iou_by_box"):
+        if hasattr(mod, f):
+            out["functions"][f] = sig(getattr(mod, f))
     out["TrackState"] = {k: int(v) for k, v in vars(mod.TrackState).items() if not k.startswith("_") and isinstance(v, int)}
     out["chi2inv95"] = {str(k): float(v) for k, v in mod.KalmanFilter.chi2inv95.items()} if hasattr(mod.KalmanFilter, "chi2inv95") else \
         {str(k): float(v) for k, v in mod.chi2inv95.items()}

@@ -52,6 +52,19 @@ def test_module_functions(pkg, fname):
     _check_params(fname, getattr(pkg, fname), REF["functions"][fname])
 
 
+@pytest.mark.parametrize("cname", sorted(REF["records"]))
+def test_detector_box_records(pkg, cname):
+    cls = getattr(pkg, cname)
+    ref = REF["records"][cname]
+    ours = list(inspect.signature(cls).parameters.values())
+    assert [p.name for p in ours][:len(ref["params"])] == [p["name"] for p in ref["params"]], cname     # positional order kept
+    assert all(p.default is not inspect._empty for p in ours[len(ref["params"]):])
+    assert [b.__name__ for b in cls.__mro__[1:] if b.__name__ not in ("ABC", "object")] == ref["bases"]
+    obj = cls(*range(len(ref["params"])))                                                                # positional call works
+    for k, p in enumerate(ref["params"]):
+        assert getattr(obj, p["name"]) == k, (cname, p["name"])
+
+
 def test_constants(pkg):
     for k, v in REF["TrackState"].items():
         assert getattr(pkg.TrackState, k) == v

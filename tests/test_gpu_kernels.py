@@ -401,6 +401,21 @@ def test_find_most_relevant_object_and_attach(bts):
     assert bts.find_most_relevant_object(base_obj=body, target_objs=[]) is None
 
 
+def test_bbox_iou_by_box_vs_oracle(bts):
+    """D:1715-1729 on detector records, positional construction as the reference's callers do it (D:1303-1411)."""
+    from oracle import bts_oracle as bo
+    rng = np.random.default_rng(9)
+    for _ in range(40):
+        x, y, u, v = (int(t) for t in rng.integers(0, 120, 4)); w, h, p, q = (int(t) for t in rng.integers(5, 90, 4))
+        a = bts.Body(0, 0, 0.9, x, y, x + w, y + h, x + w // 2, y + h // 2, False, None, None, None)
+        b = bts.Head(0, 1, 0.8, u, v, u + p, v + q, u + p // 2, v + q // 2, False)
+        got = bts.bbox_iou_by_box(a, b)
+        want = bo.box_iou_int([a.x1, a.y1, a.x2, a.y2], [b.x1, b.y1, b.x2, b.y2])
+        assert abs(got - want) <= 1e-12, (got, want)
+        if want == 0.0:
+            assert got == 0.0
+
+
 def test_errors_are_loud(bts):
     lib = bts._lib.load(require_gpu=True)
     ctx = bts._lib.default_context()
