@@ -74,3 +74,41 @@ print("host-only ok")
 def test_host_code_under_asan_ubsan_cpu_paths():
     _build()
     assert "host-only ok" in _run_child(HOST_ONLY)
+
+
+ORACLE_JV = r"""
+import ctypes, sys, numpy as np
+lib = ctypes.CDLL(sys.argv[1])
+lib.bts_oracle_lapjv_extended.restype = ctypes.c_int
+lib.bts_oracle_lapjv_extended.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+rng = np.random.default_rng(0)
+shapes = [(1, 1), (1, 7), (9, 1), (5, 5), (17, 40), (64, 33), (200, 120)]
+for n, m in shapes:
+    for kind in range(4):
+        c = rng.uniform(0.0, 1.0, (n, m))
+        if kind == 1: c = np.round(c * 4) / 4            # many exact ties
+        if kind == 2: c[:] = 0.25                        # all equal
+        if kind == 3: c[rng.random((n, m)) < 0.8] = 1.0  # mostly infeasible
+        c = np.ascontiguousarray(c)
+        x = np.empty(n, np.int32); y = np.empty(m, np.int32); opt = ctypes.c_double()
+        assert lib.bts_oracle_lapjv_extended(n, m, c.ctypes.data, 0.8, x.ctypes.data, y.ctypes.data, ctypes.byref(opt)) == 0
+        for i in range(n):
+            assert -1 <= x[i] < m and (x[i] < 0 or y[x[i]] == i)
+print("oracle jv ok")
+"""
+
+
+def test_oracle_lapjv_under_gcc_asan_ubsan(tmp_path):
+    """The checker's C helper (oracle/lapjv_oracle.c: the dense JV every assignment is compared with) compiled with gcc's
+    AddressSanitizer + UBSan and driven over ragged / degenerate shapes, tie-heavy and mostly infeasible matrices."""
+    import shutil
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    so = str(tmp_path / "liboracle_lapjv_san.so")
+    subprocess.check_call(["gcc", "-O1", "-g", "-fPIC", "-shared", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                           "-fno-omit-frame-pointer", "-o", so, os.path.join(REPO, "oracle", "lapjv_oracle.c")])
+    rt = subprocess.check_output(["gcc", "-print-file-name=libasan.so"], text=True).strip()
+    env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:exitcode=23", UBSAN_OPTIONS="halt_on_error=1:exitcode=24")
+    p = subprocess.run([sys.executable, "-c", ORACLE_JV, so], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "oracle jv ok" in p.stdout, (p.returncode, p.stderr[-3000:])
+    assert "ERROR: AddressSanitizer" not in p.stderr and "runtime error:" not in p.stderr, p.stderr[-3000:]
