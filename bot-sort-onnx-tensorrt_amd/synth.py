@@ -19,8 +19,10 @@ term of the fused cost is actually exercised at every D):
 Adversarial variants (bench.py --workload crowd | hard-reid, tests): `side_scale` shrinks the canvas (40 instead of
 125 px per sqrt(identity): boxes overlap 5-10 deep, the IoU graph gets large connected components); `clusters` draws
 the prototypes around that many shared centres with per-identity spreads so that impostor cosines of 0.5-0.8 are
-commonplace (what post-ReLU ReID embeddings look like), instead of the near-orthogonal i.i.d. prototypes.  Both draw
-their extra randomness from a generator of their own: the streams of the plain configurations are unchanged.
+commonplace (what post-ReLU ReID embeddings look like), instead of the near-orthogonal i.i.d. prototypes.  `clusters` draws
+its extra randomness from a generator of its own and the reduced canvas margin applies only when `side_scale != 125`, so the
+streams of the plain configurations are bit-identical to round 1's (tests/test_fixtures_regenerate.py regenerates the fixtures
+and compares).
 """
 from __future__ import annotations
 
@@ -61,6 +63,7 @@ class SyntheticStream:
         self.churn = churn
         self.low_frac = low_frac
         self.feat_noise = feat_noise
+        self.side_scale = float(side_scale)
         self.side = int(math.ceil(side_scale * math.sqrt(n_ids)))
         self.clusters = int(clusters)
         self._xr = np.random.default_rng([int(seed), 0x5eed]) if clusters else None      # (never touches self.rng)
@@ -76,7 +79,10 @@ class SyntheticStream:
 
     def _spawn(self, k: int):
         r = self.rng
-        margin = min(100.0, self.side / 8.0)
+        # 100 px as in every fixture of rounds 1-2; only a shrunken canvas (the crowd scene, side_scale != 125) takes a
+        # margin that still leaves room when the canvas is small (side/8 < 100 px also happens on PLAIN streams with
+        # fewer than 41 identities: they keep the 100 px their fixtures were recorded with)
+        margin = 100.0 if self.side_scale == 125.0 else min(100.0, self.side / 8.0)
         self.cx = np.concatenate([self.cx, r.uniform(margin, self.side - margin, k)])
         self.cy = np.concatenate([self.cy, r.uniform(margin, self.side - margin, k)])
         self.w = np.concatenate([self.w, r.uniform(30.0, 80.0, k)])

@@ -45,8 +45,11 @@ def checksum(*arrays) -> str:
     return h.hexdigest()
 
 
+OUT_DIR = os.environ.get("BTS_GOLDEN_OUT", HERE)      # tests/test_fixtures_regenerate.py writes into a temp dir
+
+
 def save(name, **kw):
-    path = os.path.join(HERE, name)
+    path = os.path.join(OUT_DIR, name)
     np.savez_compressed(path, versions=VERS, **kw)
     print("wrote", name, "%.1f KB" % (os.path.getsize(path) / 1024))
 
@@ -369,9 +372,11 @@ def main():
     g2_iou(mod)
     g3_fused(mod)
     g4_lap(mod)
-    trace("g5_c1_trace.npz", 64, 32, 2048, 100, seed=1234)
     g7_gmc(mod)
     g8_parts(mod)
+    if "--small-only" in sys.argv:           # G1-G4, G7, G8: seconds (the regeneration test)
+        return
+    trace("g5_c1_trace.npz", 64, 32, 2048, 100, seed=1234)
     trace("g6_lifecycle.npz", 64, 32, 128, 120, seed=7, churn=0.1, frame_rate=3, keep_cost=(1, 2, 40))
     trace("g6_faces.npz", 48, 24, 64, 60, seed=9, churn=0.05, frame_rate=3, face_dim=32, keep_cost=(1, 2, 30))
 
