@@ -437,8 +437,11 @@ __device__ __forceinline__ bool motion_gate_open(const Dev &d, long s, int det) 
 // MODE 2: record only (dense cost matrix for inspection, no edges).
 // ROWS = rows of a tile: 16, or 64 for big stage-1 problems (a tile's fixed cost -- its chains of dependent
 // loads -- dominates, the per-row screening is cheap).
-template <int STAGE, int MODE, int ROWS = CT_ROWS, bool GATE = false>
-__device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, int bx, int by, int accum) {
+// ACC = false compiles the split-K form of the pre-filter out (the tall tiles: the column records it keeps in registers
+// across the row loop pushed them over their 128-register cap -- 12-20 B of scratch, ~2 us per launch)
+template <int STAGE, int MODE, int ROWS = CT_ROWS, bool GATE = false, bool ACC = true>
+__device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, int bx, int by, int accum_rt) {
+    const int accum = ACC ? accum_rt : 0;
     __shared__ double sa[ROWS][4];
     __shared__ double sarea[ROWS];
     __shared__ int sflag[ROWS];
@@ -664,13 +667,13 @@ __device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, 
 
 // Persistent tiles: the live extents are only known on the device, so a fixed grid walks the
 // (column tile, row tile) space of the actual problem instead of launching capacity-sized grids.
-template <int STAGE, int MODE, int ROWS = CT_ROWS, bool GATE = false>
+template <int STAGE, int MODE, int ROWS = CT_ROWS, bool GATE = false, bool ACC = true>
 __device__ __forceinline__ void edges_all(const Dev &d, const bts_lap_work &w, int bid, int nblk, int accum = 0) {
     const int32_t *h = d.hdr;
     const int n = STAGE == 1 ? h[H_NPOOL] : STAGE == 2 ? h[H_NR2] : h[H_NUNC];
     const int m = STAGE == 1 ? h[H_NHI] : STAGE == 2 ? h[H_NLO] : h[H_NLEFT];
     const int nct = (m + CT_COLS - 1) / CT_COLS, ntile = nct * ((n + ROWS - 1) / ROWS);
-    for (int t = bid; t < ntile; t += nblk) edges_tile<STAGE, MODE, ROWS, GATE>(d, w, t % nct, t / nct, accum);
+    for (int t = bid; t < ntile; t += nblk) edges_tile<STAGE, MODE, ROWS, GATE, ACC>(d, w, t % nct, t / nct, accum);
 }
 
 template <int STAGE, int MODE, int ROWS = CT_ROWS, bool GATE = false>
@@ -682,7 +685,7 @@ __global__ __launch_bounds__(CT_COLS) void tk_edges(Dev d, bts_lap_work w, int a
 // would spill, and any scratch costs a launch ~2 us)
 template <int ROWS>
 __global__ __launch_bounds__(CT_COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) void tk_edges_tall(Dev d, bts_lap_work w, int accum) {
-    edges_all<1, 1, ROWS>(d, w, blockIdx.x, gridDim.x, accum);
+    edges_all<1, 1, ROWS, false, false>(d, w, blockIdx.x, gridDim.x, 0);      // (launched for the bitmap form only)
 }
 // the motion-gate form of the tall tiles: no register cap up to 128 rows (under it the gate's float64 factorisation
 // spills 8-12 bytes per lane, and any scratch costs a launch ~2 us); the 256-row tiles of the biggest problems keep the
@@ -690,11 +693,11 @@ __global__ __launch_bounds__(CT_COLS) __attribute__((amdgpu_waves_per_eu(4, 8)))
 // the gate: 52 us capped, 65 us uncapped, 43 us without the gate; 10000x2000, 128 rows: 34-35 us either way)
 template <int ROWS>
 __global__ __launch_bounds__(CT_COLS) void tk_edges_tall_gate(Dev d, bts_lap_work w, int accum) {
-    edges_all<1, 1, ROWS, true>(d, w, blockIdx.x, gridDim.x, accum);
+    edges_all<1, 1, ROWS, true, false>(d, w, blockIdx.x, gridDim.x, 0);
 }
 template <int ROWS>
 __global__ __launch_bounds__(CT_COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) void tk_edges_tall_gate_c(Dev d, bts_lap_work w, int accum) {
-    edges_all<1, 1, ROWS, true>(d, w, blockIdx.x, gridDim.x, accum);
+    edges_all<1, 1, ROWS, true, false>(d, w, blockIdx.x, gridDim.x, 0);
 }
 
 // ---- stage-1 cost edges by neighbour search (the default when the pre-filter left a candidate bitmap) -------------------
@@ -2232,10 +2235,10 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
         case 4: LAUNCH((tk_edges<1, 1, 4, true>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
         case 8: LAUNCH((tk_edges<1, 1, 8, true>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
         case 16: LAUNCH((tk_edges<1, 1, 16, true>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
-        case 32: LAUNCH(tk_edges_tall_gate<32>, dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
-        case 64: LAUNCH(tk_edges_tall_gate<64>, dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
-        case 128: LAUNCH(tk_edges_tall_gate<128>, dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
-        default: LAUNCH(tk_edges_tall_gate_c<256>, dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
+        case 32: if (accum) { LAUNCH((tk_edges<1, 1, 32, true>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); } else { LAUNCH(tk_edges_tall_gate<32>, dim3(ntile1), dim3(CT_COLS), lap[0], 0); } break;
+        case 64: if (accum) { LAUNCH((tk_edges<1, 1, 64, true>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); } else { LAUNCH(tk_edges_tall_gate<64>, dim3(ntile1), dim3(CT_COLS), lap[0], 0); } break;
+        case 128: if (accum) { LAUNCH((tk_edges<1, 1, 128, true>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); } else { LAUNCH(tk_edges_tall_gate<128>, dim3(ntile1), dim3(CT_COLS), lap[0], 0); } break;
+        default: if (accum) { LAUNCH((tk_edges<1, 1, 256, true>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); } else { LAUNCH(tk_edges_tall_gate_c<256>, dim3(ntile1), dim3(CT_COLS), lap[0], 0); } break;
         }
         if (d.record) { LAUNCH((tk_edges<1, 2>), tile_grid, dim3(CT_COLS), lap[0], 0); }
     } else if (grid_form) {
@@ -2248,10 +2251,10 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
         case 4: LAUNCH((tk_edges<1, 1, 4>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
         case 8: LAUNCH((tk_edges<1, 1, 8>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
         case 16: LAUNCH((tk_edges<1, 1, 16>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
-        case 32: LAUNCH(tk_edges_tall<32>, dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
-        case 64: LAUNCH(tk_edges_tall<64>, dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
-        case 128: LAUNCH(tk_edges_tall<128>, dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
-        default: LAUNCH(tk_edges_tall<256>, dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
+        case 32: if (accum) { LAUNCH((tk_edges<1, 1, 32>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); } else { LAUNCH(tk_edges_tall<32>, dim3(ntile1), dim3(CT_COLS), lap[0], 0); } break;
+        case 64: if (accum) { LAUNCH((tk_edges<1, 1, 64>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); } else { LAUNCH(tk_edges_tall<64>, dim3(ntile1), dim3(CT_COLS), lap[0], 0); } break;
+        case 128: if (accum) { LAUNCH((tk_edges<1, 1, 128>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); } else { LAUNCH(tk_edges_tall<128>, dim3(ntile1), dim3(CT_COLS), lap[0], 0); } break;
+        default: if (accum) { LAUNCH((tk_edges<1, 1, 256>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); } else { LAUNCH(tk_edges_tall<256>, dim3(ntile1), dim3(CT_COLS), lap[0], 0); } break;
         }
         if (d.record) { LAUNCH((tk_edges<1, 2>), tile_grid, dim3(CT_COLS), lap[0], 0); }
     } else if (d.motion_gate) {

@@ -1,0 +1,77 @@
+"""Static properties of the gfx950 code objects inside libbotsort_hip.so, read on the CPU from the kernel metadata and the
+disassembly (llvm-readelf / llvm-objdump of /opt/rocm): no kernel of the step spills or uses scratch (measured cost of ANY
+scratch use: ~2 us per launch), the contraction is real MFMA code fed by LDS-DMA, nothing is built for
+another architecture.  Guards against the silent regressions this build has seen (a co-compiled template variant, a
+by-value struct select, a runtime-indexed register array)."""
+import glob
+import importlib
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+# kernels that are allowed a scratch frame, with the reason (bytes are upper bounds)
+SCRATCH_OK = {
+    "tk_edges_tall_gate_c": 64,      # the 256-row gated tile keeps the 128-register cap and spills 12 B (52 vs 65 us uncapped)
+    "k_lap": 128,                    # k_lap<8> (16384 x 4096 only): 8 edges per thread in registers, 108 B of spills
+}
+
+
+@pytest.fixture(scope="module")
+def code_objects(tmp_path_factory):
+    if not os.path.exists(os.path.join(LLVM, "llvm-readelf")):
+        pytest.skip("no ROCm LLVM tools")
+    lib_mod = importlib.import_module("bot-sort-onnx-tensorrt_amd._lib")
+    if not os.path.exists(lib_mod.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    d = tmp_path_factory.mktemp("cox")          # (llvm-objdump --offloading writes next to its input: work on a copy)
+    shutil.copy(lib_mod.LIB_PATH, d / "lib.so")
+    subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", "lib.so"], cwd=d, check=True, capture_output=True)
+    objs = sorted(glob.glob(str(d / "lib.so.*amdgcn*")))
+    assert objs, "no device code objects found"
+    return objs
+
+
+def _kernels(objs):
+    out = {}
+    for o in objs:
+        txt = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", o], capture_output=True, text=True, check=True).stdout
+        for block in txt.split(".agpr_count:")[1:]:                  # one block per kernel (first key of each entry)
+            f = dict(re.findall(r"\.(name|private_segment_fixed_size|vgpr_spill_count|sgpr_spill_count|vgpr_count|group_segment_fixed_size):\s+(\S+)", block))
+            if "name" in f:
+                out[f["name"]] = {k: int(v) for k, v in f.items() if k != "name"}
+    return out
+
+
+def test_only_gfx950_code(code_objects):
+    assert all(o.endswith("gfx950") for o in code_objects), code_objects
+
+
+def test_no_kernel_spills_or_uses_scratch(code_objects):
+    ks = _kernels(code_objects)
+    assert len(ks) >= 60, len(ks)
+    offenders = []
+    for name, f in ks.items():
+        scratch, spills = f.get("private_segment_fixed_size", 0), f.get("vgpr_spill_count", 0)      # (SGPR spills go to VGPR lanes, not memory)
+        if scratch == 0 and spills == 0:
+            continue
+        allowed = [cap for key, cap in SCRATCH_OK.items() if key in name]
+        if not allowed or scratch > max(allowed):
+            offenders.append((name, scratch, spills))
+    assert not offenders, offenders
+    assert max(f.get("group_segment_fixed_size", 0) for f in ks.values()) <= 160 * 1024
+
+
+def test_contraction_is_mfma_fed_by_lds_dma(code_objects):
+    asm = "".join(subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", o], capture_output=True, text=True, check=True).stdout for o in code_objects)
+    assert len(re.findall(r"v_mfma_i32_32x32x32_i8", asm)) >= 32          # int8 pre-filter (k_filter_i8, k_filter_splitk, face forms)
+    assert len(re.findall(r"v_mfma_f32_32x32x2_f32", asm)) >= 8           # exact float32 similarity GEMM (dense mode / standalone)
+    assert len(re.findall(r"global_load_lds_dwordx4", asm)) >= 32         # operand stages: memory -> LDS, 16 B per lane
+    assert len(re.findall(r"v_pk_(?:min|max)_i16", asm)) >= 64            # packed 16-bit box screening of the cost tiles
+    assert "v_mfma_scale_f32_32x32x64_f8f6f4" not in asm                  # the fp8 form is gone (round 2)
