@@ -267,7 +267,9 @@ __device__ __forceinline__ void build_grid(const Dev &d, int nhi, int32_t *tmp) 
     __syncthreads();
 }
 
-__device__ __forceinline__ void prep_dets(const Dev &d) {
+// GRID: also bin the high-score detections for tk_edges_grid (its 64 KiB of LDS counters would otherwise sit in EVERY
+// tk_front workgroup and leave one workgroup per CU instead of two)
+template <bool GRID> __device__ __forceinline__ void prep_dets(const Dev &d) {
     __shared__ int32_t tmp[1024];
     int32_t *h = d.hdr;
     const int tid = threadIdx.x, nth = blockDim.x;
@@ -288,7 +290,7 @@ __device__ __forceinline__ void prep_dets(const Dev &d) {
                                        [&](int j, int v) { const double s = (double)__int_as_float(v); return (s <= d.high) & (s >= d.low); },
                                        [&](int p, int j, int) { d.hi_idx[p] = j; }, [&](int p, int j, int) { d.lo_idx[p] = j; });
     const int nhi = nn.x, nlo = nn.y;
-    if (d.filter && d.use_grid) build_grid(d, nhi, tmp);
+    if constexpr (GRID) { if (d.filter && d.use_grid) build_grid(d, nhi, tmp); }
     if (tid < 3 * BTS_LAP_HDR_INTS) d.lap_hdr[tid] = 0;
     if (tid < 16 && d.filter) d.fstat[tid] = tid == 8 || tid == 12 ? 0x7fffffff : 0;
     if (tid == 0) {
@@ -352,12 +354,12 @@ __device__ __forceinline__ void copy_shadow(const int8_t *src_q, const float *sr
 // one launch: the first workgroups build the frame's lists (two jobs of nch chunks each, the detection lists, the free slots),
 // the others convert the detection rows
 __host__ __device__ constexpr int front_jobs(int nch) { return 2 * nch + 2; }
-template <bool CH> __global__ __launch_bounds__(1024) void tk_front(Dev d) {
+template <bool CH, bool GRID = false> __global__ __launch_bounds__(1024) void tk_front(Dev d) {
     TJ_BEGIN();
     const int b = blockIdx.x, nch = nchunks<CH>(d);
     if (b < nch) { prep_pool<CH>(d, b); if (b == 0) TJ_END(0, 0); }
     else if (b < 2 * nch) { prep_unconfirmed<CH>(d, b - nch); if (b == 2 * nch - 1) TJ_END(0, 1); }
-    else if (b == 2 * nch) { prep_dets(d); TJ_END(0, 2); }
+    else if (b == 2 * nch) { prep_dets<GRID>(d); TJ_END(0, 2); }
     else if (b == 2 * nch + 1) { prep_free(d); TJ_END(0, 3); }
     else { cvt_body(d, (long)b - front_jobs(nch)); if (b == front_jobs(nch)) TJ_END(0, 4); }
 }
@@ -2179,8 +2181,13 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
 
     seg_begin(BTS_SEG_STEP);
     seg_begin(BTS_SEG_PREP);
-    if (d.nch > 1) { LAUNCH(tk_front<true>, dim3(front_jobs(d.nch) + (d.filter ? bts_cdiv(mc, 4) : 0)), dim3(1024)); }
-    else { LAUNCH(tk_front<false>, dim3(front_jobs(1) + (d.filter ? bts_cdiv(mc, 4) : 0)), dim3(1024)); }
+    {
+        const dim3 fgrid(front_jobs(d.nch > 1 ? d.nch : 1) + (d.filter ? bts_cdiv(mc, 4) : 0));
+        if (d.use_grid && d.filter) {
+            if (d.nch > 1) { LAUNCH((tk_front<true, true>), fgrid, dim3(1024)); } else { LAUNCH((tk_front<false, true>), fgrid, dim3(1024)); }
+        } else if (d.nch > 1) { LAUNCH((tk_front<true, false>), fgrid, dim3(1024)); }
+        else { LAUNCH((tk_front<false, false>), fgrid, dim3(1024)); }
+    }
     seg_end(BTS_SEG_PREP);
     const bool dense = !d.filter || d.record;
     // split-K factor of the pre-filter: small problems have too few 128x128 tiles to fill 256 CUs
