@@ -267,7 +267,9 @@ __device__ __forceinline__ void build_grid(const Dev &d, int nhi, int32_t *tmp) 
     __syncthreads();
 }
 
-__device__ __forceinline__ void prep_dets(const Dev &d) {
+// GRID: also bin the high-score detections for tk_edges_grid (its 64 KiB of LDS counters would otherwise sit in EVERY
+// tk_front workgroup and leave one workgroup per CU instead of two)
+template <bool GRID> __device__ __forceinline__ void prep_dets(const Dev &d) {
     __shared__ int32_t tmp[1024];
     int32_t *h = d.hdr;
     const int tid = threadIdx.x, nth = blockDim.x;
@@ -288,7 +290,7 @@ __device__ __forceinline__ void prep_dets(const Dev &d) {
                                        [&](int j, int v) { const double s = (double)__int_as_float(v); return (s <= d.high) & (s >= d.low); },
                                        [&](int p, int j, int) { d.hi_idx[p] = j; }, [&](int p, int j, int) { d.lo_idx[p] = j; });
     const int nhi = nn.x, nlo = nn.y;
-    if (d.filter && d.use_grid) build_grid(d, nhi, tmp);
+    if constexpr (GRID) { if (d.filter && d.use_grid) build_grid(d, nhi, tmp); }
     if (tid < 3 * BTS_LAP_HDR_INTS) d.lap_hdr[tid] = 0;
     if (tid < 16 && d.filter) d.fstat[tid] = tid == 8 || tid == 12 ? 0x7fffffff : 0;
     if (tid == 0) {
@@ -352,12 +354,12 @@ __device__ __forceinline__ void copy_shadow(const int8_t *src_q, const float *sr
 // one launch: the first workgroups build the frame's lists (two jobs of nch chunks each, the detection lists, the free slots),
 // the others convert the detection rows
 __host__ __device__ constexpr int front_jobs(int nch) { return 2 * nch + 2; }
-template <bool CH> __global__ __launch_bounds__(1024) void tk_front(Dev d) {
+template <bool CH, bool GRID = false> __global__ __launch_bounds__(1024) void tk_front(Dev d) {
     TJ_BEGIN();
     const int b = blockIdx.x, nch = nchunks<CH>(d);
     if (b < nch) { prep_pool<CH>(d, b); if (b == 0) TJ_END(0, 0); }
     else if (b < 2 * nch) { prep_unconfirmed<CH>(d, b - nch); if (b == 2 * nch - 1) TJ_END(0, 1); }
-    else if (b == 2 * nch) { prep_dets(d); TJ_END(0, 2); }
+    else if (b == 2 * nch) { prep_dets<GRID>(d); TJ_END(0, 2); }
     else if (b == 2 * nch + 1) { prep_free(d); TJ_END(0, 3); }
     else { cvt_body(d, (long)b - front_jobs(nch)); if (b == front_jobs(nch)) TJ_END(0, 4); }
 }
@@ -437,8 +439,11 @@ __device__ __forceinline__ bool motion_gate_open(const Dev &d, long s, int det) 
 // MODE 2: record only (dense cost matrix for inspection, no edges).
 // ROWS = rows of a tile: 16, or 64 for big stage-1 problems (a tile's fixed cost -- its chains of dependent
 // loads -- dominates, the per-row screening is cheap).
-template <int STAGE, int MODE, int ROWS = CT_ROWS, bool GATE = false>
-__device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, int bx, int by, int accum) {
+// ACC = false compiles the split-K form of the pre-filter out (the tall tiles: the column records it keeps in registers
+// across the row loop pushed them over their 128-register cap -- 12-20 B of scratch, ~2 us per launch)
+template <int STAGE, int MODE, int ROWS = CT_ROWS, bool GATE = false, bool ACC = true>
+__device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, int bx, int by, int accum_rt) {
+    const int accum = ACC ? accum_rt : 0;
     __shared__ double sa[ROWS][4];
     __shared__ double sarea[ROWS];
     __shared__ int sflag[ROWS];
@@ -664,13 +669,13 @@ __device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, 
 
 // Persistent tiles: the live extents are only known on the device, so a fixed grid walks the
 // (column tile, row tile) space of the actual problem instead of launching capacity-sized grids.
-template <int STAGE, int MODE, int ROWS = CT_ROWS, bool GATE = false>
+template <int STAGE, int MODE, int ROWS = CT_ROWS, bool GATE = false, bool ACC = true>
 __device__ __forceinline__ void edges_all(const Dev &d, const bts_lap_work &w, int bid, int nblk, int accum = 0) {
     const int32_t *h = d.hdr;
     const int n = STAGE == 1 ? h[H_NPOOL] : STAGE == 2 ? h[H_NR2] : h[H_NUNC];
     const int m = STAGE == 1 ? h[H_NHI] : STAGE == 2 ? h[H_NLO] : h[H_NLEFT];
     const int nct = (m + CT_COLS - 1) / CT_COLS, ntile = nct * ((n + ROWS - 1) / ROWS);
-    for (int t = bid; t < ntile; t += nblk) edges_tile<STAGE, MODE, ROWS, GATE>(d, w, t % nct, t / nct, accum);
+    for (int t = bid; t < ntile; t += nblk) edges_tile<STAGE, MODE, ROWS, GATE, ACC>(d, w, t % nct, t / nct, accum);
 }
 
 template <int STAGE, int MODE, int ROWS = CT_ROWS, bool GATE = false>
@@ -682,7 +687,7 @@ __global__ __launch_bounds__(CT_COLS) void tk_edges(Dev d, bts_lap_work w, int a
 // would spill, and any scratch costs a launch ~2 us)
 template <int ROWS>
 __global__ __launch_bounds__(CT_COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) void tk_edges_tall(Dev d, bts_lap_work w, int accum) {
-    edges_all<1, 1, ROWS>(d, w, blockIdx.x, gridDim.x, accum);
+    edges_all<1, 1, ROWS, false, false>(d, w, blockIdx.x, gridDim.x, 0);      // (launched for the bitmap form only)
 }
 // the motion-gate form of the tall tiles: no register cap up to 128 rows (under it the gate's float64 factorisation
 // spills 8-12 bytes per lane, and any scratch costs a launch ~2 us); the 256-row tiles of the biggest problems keep the
@@ -690,11 +695,11 @@ __global__ __launch_bounds__(CT_COLS) __attribute__((amdgpu_waves_per_eu(4, 8)))
 // the gate: 52 us capped, 65 us uncapped, 43 us without the gate; 10000x2000, 128 rows: 34-35 us either way)
 template <int ROWS>
 __global__ __launch_bounds__(CT_COLS) void tk_edges_tall_gate(Dev d, bts_lap_work w, int accum) {
-    edges_all<1, 1, ROWS, true>(d, w, blockIdx.x, gridDim.x, accum);
+    edges_all<1, 1, ROWS, true, false>(d, w, blockIdx.x, gridDim.x, 0);
 }
 template <int ROWS>
 __global__ __launch_bounds__(CT_COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) void tk_edges_tall_gate_c(Dev d, bts_lap_work w, int accum) {
-    edges_all<1, 1, ROWS, true>(d, w, blockIdx.x, gridDim.x, accum);
+    edges_all<1, 1, ROWS, true, false>(d, w, blockIdx.x, gridDim.x, 0);
 }
 
 // ---- stage-1 cost edges by neighbour search (the default when the pre-filter left a candidate bitmap) -------------------
@@ -2176,8 +2181,13 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
 
     seg_begin(BTS_SEG_STEP);
     seg_begin(BTS_SEG_PREP);
-    if (d.nch > 1) { LAUNCH(tk_front<true>, dim3(front_jobs(d.nch) + (d.filter ? bts_cdiv(mc, 4) : 0)), dim3(1024)); }
-    else { LAUNCH(tk_front<false>, dim3(front_jobs(1) + (d.filter ? bts_cdiv(mc, 4) : 0)), dim3(1024)); }
+    {
+        const dim3 fgrid(front_jobs(d.nch > 1 ? d.nch : 1) + (d.filter ? bts_cdiv(mc, 4) : 0));
+        if (d.use_grid && d.filter) {
+            if (d.nch > 1) { LAUNCH((tk_front<true, true>), fgrid, dim3(1024)); } else { LAUNCH((tk_front<false, true>), fgrid, dim3(1024)); }
+        } else if (d.nch > 1) { LAUNCH((tk_front<true, false>), fgrid, dim3(1024)); }
+        else { LAUNCH((tk_front<false, false>), fgrid, dim3(1024)); }
+    }
     seg_end(BTS_SEG_PREP);
     const bool dense = !d.filter || d.record;
     // split-K factor of the pre-filter: small problems have too few 128x128 tiles to fill 256 CUs
@@ -2232,10 +2242,10 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
         case 4: LAUNCH((tk_edges<1, 1, 4, true>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
         case 8: LAUNCH((tk_edges<1, 1, 8, true>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
         case 16: LAUNCH((tk_edges<1, 1, 16, true>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
-        case 32: LAUNCH(tk_edges_tall_gate<32>, dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
-        case 64: LAUNCH(tk_edges_tall_gate<64>, dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
-        case 128: LAUNCH(tk_edges_tall_gate<128>, dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
-        default: LAUNCH(tk_edges_tall_gate_c<256>, dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
+        case 32: if (accum) { LAUNCH((tk_edges<1, 1, 32, true>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); } else { LAUNCH(tk_edges_tall_gate<32>, dim3(ntile1), dim3(CT_COLS), lap[0], 0); } break;
+        case 64: if (accum) { LAUNCH((tk_edges<1, 1, 64, true>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); } else { LAUNCH(tk_edges_tall_gate<64>, dim3(ntile1), dim3(CT_COLS), lap[0], 0); } break;
+        case 128: if (accum) { LAUNCH((tk_edges<1, 1, 128, true>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); } else { LAUNCH(tk_edges_tall_gate<128>, dim3(ntile1), dim3(CT_COLS), lap[0], 0); } break;
+        default: if (accum) { LAUNCH((tk_edges<1, 1, 256, true>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); } else { LAUNCH(tk_edges_tall_gate_c<256>, dim3(ntile1), dim3(CT_COLS), lap[0], 0); } break;
         }
         if (d.record) { LAUNCH((tk_edges<1, 2>), tile_grid, dim3(CT_COLS), lap[0], 0); }
     } else if (grid_form) {
@@ -2248,10 +2258,10 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
         case 4: LAUNCH((tk_edges<1, 1, 4>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
         case 8: LAUNCH((tk_edges<1, 1, 8>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
         case 16: LAUNCH((tk_edges<1, 1, 16>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
-        case 32: LAUNCH(tk_edges_tall<32>, dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
-        case 64: LAUNCH(tk_edges_tall<64>, dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
-        case 128: LAUNCH(tk_edges_tall<128>, dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
-        default: LAUNCH(tk_edges_tall<256>, dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
+        case 32: if (accum) { LAUNCH((tk_edges<1, 1, 32>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); } else { LAUNCH(tk_edges_tall<32>, dim3(ntile1), dim3(CT_COLS), lap[0], 0); } break;
+        case 64: if (accum) { LAUNCH((tk_edges<1, 1, 64>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); } else { LAUNCH(tk_edges_tall<64>, dim3(ntile1), dim3(CT_COLS), lap[0], 0); } break;
+        case 128: if (accum) { LAUNCH((tk_edges<1, 1, 128>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); } else { LAUNCH(tk_edges_tall<128>, dim3(ntile1), dim3(CT_COLS), lap[0], 0); } break;
+        default: if (accum) { LAUNCH((tk_edges<1, 1, 256>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); } else { LAUNCH(tk_edges_tall<256>, dim3(ntile1), dim3(CT_COLS), lap[0], 0); } break;
         }
         if (d.record) { LAUNCH((tk_edges<1, 2>), tile_grid, dim3(CT_COLS), lap[0], 0); }
     } else if (d.motion_gate) {

@@ -19,11 +19,6 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 SCRATCH_OK = {
     "tk_edges_tall_gate_c": 64,      # the 256-row gated tile keeps the 128-register cap and spills 12 B (52 vs 65 us uncapped)
     "k_lap": 128,                    # k_lap<8> (16384 x 4096 only): 8 edges per thread in registers, 108 B of spills
-    "tk_edges_tall": 24,             # REGRESSION of round 2 (0 B in round 1): the int8 column records of the split-K form stay
-                                     # live across the row loop and push the 128-register tiles into 12-20 B of scratch (2-4
-                                     # spilled registers, ~2-3 us per launch).  Fix = branch `tall-noaccum` (split-K form
-                                     # compiled out of the tall tiles: 0 B again); not merged because it could not be run
-                                     # on a GPU before access closed.
 }
 
 
