@@ -70,6 +70,8 @@ SIGNATURES = {
     "bts_tracker_step": (c_int, [_P, _P, _P, _P, _P, c_int, _P]),
     "bts_tracker_counts": (c_int, [_P, _P, _P]),
     "bts_tracker_export": (c_int, [_P, c_int, _P, _P, _P, _P, _P]),
+    "bts_tracker_export_lists": (c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    "bts_tracker_read_column": (c_int, [_P, c_int, _P, _P]),
     "bts_tracker_export_mot": (c_int, [_P, _P, _P]),
     "bts_tracker_export_mot_async": (c_int, [_P, _P, _P, _P]),
     "bts_tracker_export_state": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P]),

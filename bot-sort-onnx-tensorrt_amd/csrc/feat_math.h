@@ -29,8 +29,8 @@ __device__ __forceinline__ float block_sum(float v) {
 
 __device__ __forceinline__ bool vec4_ok(const void *p, int d) { return ((uintptr_t)p % 16 == 0) && (d % 4 == 0); }
 
-// row /= ||row||_2   (np.linalg.norm of a float32 vector = sqrt(dot(x,x)) in float32)
-__device__ __forceinline__ void renorm_row(float *row, int d, bool active = true) {
+// row /= ||row||_2   (np.linalg.norm of a float32 vector = sqrt(dot(x,x)) in float32); returns that norm to every thread of the group
+__device__ __forceinline__ float renorm_row(float *row, int d, bool active = true) {
     const int t = row_tid();
     float ss = 0.0f;
     const bool v4 = active && vec4_ok(row, d);
@@ -49,7 +49,7 @@ __device__ __forceinline__ void renorm_row(float *row, int d, bool active = true
             const int k = t + u * ROW_G;
             if (k < d / 4) r4[k] = make_float4(v[u].x / nrm, v[u].y / nrm, v[u].z / nrm, v[u].w / nrm);
         }
-        return;
+        return nrm;
     }
     if (v4) {
         float4 *r4 = reinterpret_cast<float4 *>(row);
@@ -63,10 +63,12 @@ __device__ __forceinline__ void renorm_row(float *row, int d, bool active = true
             v.x /= nrm; v.y /= nrm; v.z /= nrm; v.w /= nrm;
             r4[k] = v;
         }
+        return nrm;
     } else {
         if (active) for (int k = t; k < d; k += ROW_G) ss += row[k] * row[k];
         const float nrm = sqrtf(block_sum(ss));
         if (active) for (int k = t; k < d; k += ROW_G) row[k] /= nrm;
+        return nrm;
     }
 }
 
@@ -277,6 +279,24 @@ __device__ __forceinline__ void to_i8_row(const float *x, int8_t *q, float *meta
             meta[4 * c + 2] = alpha;
             meta[4 * c + 3] = finite ? uh - 1e-4f * (1.0f + ss) : -inf;
         }
+    }
+}
+
+// A detection row's record, as written by to_i8_row, describes the RAW row x (that is what the frame's similarities are
+// taken with, D:1453-1483).  The track that absorbs the detection keeps  u = x / |x|  (the row is renormalised in place
+// before it becomes the track's curr feature, D:492-502 / Q8), while its shadow stays the shadow of x.  For the pair
+// (u, b):  <u, b> >= gate  <=>  <x, b> >= gate * n,  n = |x|  -- the same test with the pair's gate G = gate * n, i.e.
+// with the ROW's share of 2 G raised from gate to gate (2 n - 1):
+//     prefix records:  uh += 1.03 gate (n - 1)          full row:  uh += gate (n - 1)
+// (n = 1: nothing changes; n < 1: the track's true similarities are LARGER than its shadow suggests and fewer pairs may
+// be dropped).  Applied by the thread that renormalises the row, to the detection's record, which copy_shadow then hands
+// to the track; nothing reads the record as a COLUMN record after that point of the frame.  A zero / non-finite norm
+// makes the row a candidate for everybody (the exact float32 path decides).
+__host__ __device__ inline void i8_track_side(float *meta, float nrm, float gate) {
+    const bool ok = nrm > 0.0f && nrm < 3.0e38f;
+    for (int c = 0; c <= I8_NCHK; ++c) {
+        const float k = c == I8_NCHK ? 1.0f : 1.03f;
+        meta[4 * c + 3] = ok ? meta[4 * c + 3] + k * gate * (nrm - 1.0f) : -__builtin_huge_valf();
     }
 }
 

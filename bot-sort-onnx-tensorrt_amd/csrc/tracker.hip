@@ -337,8 +337,9 @@ __device__ __forceinline__ void cvt_body(const Dev &d, long blk) {        // fou
     if (d.Df) feat::to_i8_row(IN(d, face_feats) + j * d.Df, d.dface_h + j * d.Df, d.dface_m + j * feat::I8_META, d.Df, d.gate_sim, on);
 }
 // A track's latest feature IS a detection row (curr = the matched / born detection's renormalised row, D:492-502): its
-// shadow and record are that detection's, copied (the record's slack covers the 1e-7 between a raw row and its in-place
-// renormalised self).  Called by the 256 threads that handle the row.
+// shadow is that detection's, copied, and so is its record -- which tk_mid1 has by then turned into the record of the
+// UNIT row x / |x| (feat::i8_track_side: a detection row need not arrive unit-norm; the record's slack covers the 1e-7
+// between x / |x| in exact arithmetic and the float32 row).  Called by the 256 threads that handle the row.
 __device__ __forceinline__ void copy_shadow(const int8_t *src_q, const float *src_m, int8_t *dst_q, float *dst_m, int dim) {
     const int t = feat::row_tid();
     if (dim % 16 == 0) {
@@ -708,8 +709,9 @@ __global__ __launch_bounds__(CT_COLS) __attribute__((amdgpu_waves_per_eu(4, 8)))
 // left to (2)).  (2) Appearance: the rows' words of the candidate bitmap are swept 64 at a time (coalesced); every
 // candidate pair gets the exact float32 dot product from the whole wavefront and ONE edge with min(IoU cost, 1 - sim)
 // (np.minimum of D:1554) when that is within the match threshold.  Edges are staged in LDS and appended
-// with one counter bump per wavefront.  Same edges as the tile form (tk_edges<1,1,R>), in another order -- the solver
-// does not depend on the order.
+// with one counter bump per wavefront.  Same edges as the tile form (tk_edges<1,1,R>) whenever match_thresh < 1 (the
+// launcher takes the tile form otherwise: with a threshold >= 1 even disjoint pairs are feasible at cost 1.0), in another
+// order -- the solver does not depend on the order.
 template <bool GATE>
 __global__ __launch_bounds__(64) void tk_edges_grid(Dev d, bts_lap_work w) {
     constexpr int EB = 512;
@@ -1399,8 +1401,14 @@ __device__ __forceinline__ void renorm_body(const Dev &d, int blk) {        // f
     const int q = blk * 4 + feat::row_group();
     const bool on = q < nhi + nlo;
     const long det = !on ? 0 : q < nhi ? d.hi_idx[q] : d.lo_idx[q - nhi];
-    feat::renorm_row(IN(d, feats) + det * d.D, d.D, on);
-    if (d.Df) feat::renorm_row(IN(d, face_feats) + det * d.Df, d.Df, on);
+    const float nb = feat::renorm_row(IN(d, feats) + det * d.D, d.D, on);
+    // the detection's record becomes the record of the unit row a track will hold (feat::i8_track_side): its column-side
+    // readers (k_filter, the stage-1 tiles) ran before this launch
+    if (d.filter && on && feat::row_tid() == 0) feat::i8_track_side(d.det_m + det * feat::I8_META, nb, d.gate_sim);
+    if (d.Df) {
+        const float nf = feat::renorm_row(IN(d, face_feats) + det * d.Df, d.Df, on);
+        if (d.filter && on && feat::row_tid() == 0) feat::i8_track_side(d.dface_m + det * feat::I8_META, nf, d.gate_sim);
+    }
 }
 
 // ---- match application (D:570-610).  FEAT=false: Kalman update + lifecycle, one thread per row with
@@ -1965,6 +1973,31 @@ int bts_tracker_default_config(bts_tracker_config *cfg) {
     return BTS_OK;
 }
 
+// What create and memory_bytes both derive from a config: the appearance mode actually used and the capacity of the
+// solver's edge lists.  The feasible pairs (cost <= match threshold) are O(detections) in any scene a tracker can
+// follow, hence 64 (T + M) by default; a configuration in which EVERY pair is feasible (a stage threshold >= 1: the
+// cost tiles then keep all rows, `!(limit < 1.0)`) and small tables keep the T * M that cannot overflow.  Overflow
+// raises the sticky capacity error (BTS_ECAPACITY from the next export).
+static int derive_sizes(const bts_tracker_config *cfg, Dev &d, int64_t *e_cap_out) {
+    d.T = cfg->max_tracks; d.Mx = cfg->max_dets; d.D = cfg->feat_dim; d.Df = cfg->face_dim;
+    d.record = cfg->record_costs ? 1 : 0;
+    // the pre-filter works on 128-element K steps; other feature widths take the dense float32 path
+    d.filter = (cfg->appearance_mode == BTS_APPEARANCE_FILTER && d.D % DBK == 0 && d.Df % DBK == 0) ? 1 : 0;
+    if (d.filter) {     // k_filter_i8 addresses the int8 shadows with 32-bit byte offsets (slot * dim)
+        const uint64_t lim = 1ull << 32;
+        BTS_REQUIRE((uint64_t)d.T * (uint64_t)d.D < lim && (uint64_t)d.Mx * (uint64_t)d.D < lim &&
+                    (uint64_t)d.T * (uint64_t)d.Df < lim && (uint64_t)d.Mx * (uint64_t)d.Df < lim,
+                    "max_tracks * feat_dim and max_dets * feat_dim must stay below 2^32 in the FILTER appearance mode");
+    }
+    const int64_t full = (int64_t)d.T * d.Mx, e_auto = 64ll * ((int64_t)d.T + d.Mx);
+    const bool all_feasible = !(cfg->match_thresh < 1.0) || !(cfg->second_match_thresh < 1.0) || !(cfg->unconfirmed_match_thresh < 1.0);
+    int64_t e_cap = full;
+    if (cfg->max_edges > 0) e_cap = full < cfg->max_edges ? full : cfg->max_edges;
+    else if (!all_feasible && full > e_auto) e_cap = e_auto;
+    *e_cap_out = e_cap;
+    return BTS_OK;
+}
+
 int bts_tracker_memory_bytes(const bts_tracker_config *cfg, uint64_t *out_bytes) {
     BTS_REQUIRE(cfg && out_bytes, "null argument");
     BTS_REQUIRE(cfg->max_tracks > 0 && cfg->max_dets > 0 && cfg->feat_dim > 0 && cfg->face_dim >= 0, "capacities");
@@ -1976,15 +2009,11 @@ int bts_tracker_memory_bytes(const bts_tracker_config *cfg, uint64_t *out_bytes)
     t->cfg = *cfg;
     Dev &d = t->dv;
     memset(&d, 0, sizeof(d));
-    d.T = cfg->max_tracks; d.Mx = cfg->max_dets; d.D = cfg->feat_dim; d.Df = cfg->face_dim;
-    d.record = cfg->record_costs ? 1 : 0;
-    d.filter = (cfg->appearance_mode == BTS_APPEARANCE_FILTER && d.D % DBK == 0 && d.Df % DBK == 0) ? 1 : 0;
+    int64_t e_cap = 0;
+    const int rc = derive_sizes(cfg, d, &e_cap);
+    if (rc) { delete t; return rc; }
     size_t off = 0;
     tracker_layout(t, nullptr, off);
-    int64_t e_cap = (int64_t)d.T * d.Mx;
-    const int64_t e_auto = 64ll * ((int64_t)d.T + d.Mx);
-    if (cfg->max_edges > 0) e_cap = e_cap < cfg->max_edges ? e_cap : cfg->max_edges;
-    else if (e_cap > e_auto) e_cap = e_auto;
     off += 2 * bts_lap_work_bytes(d.T, d.Mx, e_cap);
     *out_bytes = (uint64_t)off;
     delete t;
@@ -2003,13 +2032,16 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
     t->ctx = ctx; t->cfg = *cfg;
     Dev &d = t->dv;
     memset(&d, 0, sizeof(d));
-    d.T = cfg->max_tracks; d.Mx = cfg->max_dets; d.D = cfg->feat_dim; d.Df = cfg->face_dim;
+    int64_t e_cap = 0;
+    {
+        const int rc_sz = derive_sizes(cfg, d, &e_cap);
+        if (rc_sz) { delete t; return rc_sz; }
+    }
     d.high = cfg->track_high_thresh; d.low = cfg->track_low_thresh; d.new_thr = cfg->new_track_thresh;
     d.match1 = cfg->match_thresh; d.match2 = cfg->second_match_thresh; d.match3 = cfg->unconfirmed_match_thresh;
     d.prox = cfg->proximity_thresh; d.app = (float)cfg->appearance_thresh; d.dedupe_thr = cfg->dedupe_thresh;
     d.ema_a = (float)cfg->ema_alpha; d.ema_b = (float)(1.0 - cfg->ema_alpha);
     d.max_time_lost = (int)((double)cfg->frame_rate / 30.0 * cfg->track_buffer);    // D:1276-1277
-    d.record = cfg->record_costs ? 1 : 0;
     d.motion_gate = cfg->motion_gate ? 1 : 0;
     d.gate_thr = 9.4877;       // chi2inv95[4], D:139-149
     {   // list jobs over tables beyond ~6000 tracks are split into chunks of ~2048 entries, one workgroup each
@@ -2019,18 +2051,10 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
         d.nch = (!e && d.T <= 6144) ? 1 : bts_cdiv(d.T, rows);
         d.nch = d.nch < 1 ? 1 : d.nch > 8 ? 8 : d.nch;
     }
-    // the pre-filter works on 128-element K steps; other feature widths take the dense float32 path
-    d.filter = (cfg->appearance_mode == BTS_APPEARANCE_FILTER && d.D % DBK == 0 && d.Df % DBK == 0) ? 1 : 0;
     d.use_grid = getenv("BTS_EDGES_GRID") != nullptr ? 1 : 0;
     d.gate_sim = 1.0f - d.app;
     size_t off = 0;
     tracker_layout(t, nullptr, off);
-    // capacity of the solver's edge lists: the feasible pairs (cost <= match threshold) are O(detections) in any scene
-    // a tracker can follow; overflow raises the error flag (BTS_ECAPACITY from the next export)
-    int64_t e_cap = (int64_t)d.T * d.Mx;
-    const int64_t e_auto = 64ll * ((int64_t)d.T + d.Mx);
-    if (cfg->max_edges > 0) e_cap = e_cap < cfg->max_edges ? e_cap : cfg->max_edges;
-    else if (e_cap > e_auto) e_cap = e_auto;
     const size_t lap_off = off;
     off += bts_lap_work_bytes(d.T, d.Mx, e_cap);
     const size_t lap3_off = off;
@@ -2233,7 +2257,8 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
     seg_end(BTS_SEG_COS1);
     seg_begin(BTS_SEG_COST1);
     seg_begin(BTS_SEG_K_EDGES1);
-    const bool grid_form = d.use_grid && d.filter && !accum && !d.record;
+    // (the grid only finds OVERLAPPING pairs: a match threshold >= 1 makes every pair feasible, which only the tile form emits)
+    const bool grid_form = d.use_grid && d.filter && !accum && !d.record && d.match1 < 1.0;
     if (grid_form && d.motion_gate) {
         LAUNCH(tk_edges_grid<true>, dim3(bts_cdiv(T, 16)), dim3(64), lap[0]);
     } else if (d.filter && d.motion_gate) {
@@ -2434,6 +2459,38 @@ int bts_tracker_export(bts_tracker *t, int which, int32_t *ints_host, double *me
         BTS_HIP(hipStreamSynchronize(s));
     }
     return n;
+}
+
+int bts_tracker_export_lists(bts_tracker *t, int32_t *ints_pinned, double *mean_pinned, double *tlbr_pinned,
+                             float *score_pinned, int32_t *counts12_host, bts_stream stream) {
+    BTS_REQUIRE(t && counts12_host, "tracker, counts");
+    BTS_ON_DEVICE(t->ctx);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t T = (size_t)t->dv.T;
+    for (int which = 0; which < 2; ++which) {
+        // (a null output still needs a valid address for the kernel's stores: the staging arrays of bts_tracker_export)
+        hipLaunchKernelGGL(tk_export, dim3(bts_cdiv(t->dv.T, 256)), dim3(256), 0, s, t->dv, which,
+                           ints_pinned ? ints_pinned + which * T * 8 : t->x_ints, mean_pinned ? mean_pinned + which * T * 8 : t->x_mean,
+                           tlbr_pinned ? tlbr_pinned + which * T * 4 : t->x_tlbr, score_pinned ? score_pinned + which * T : t->x_score);
+        BTS_LAUNCH_CHECK();
+    }
+    BTS_HIP(hipMemcpyAsync(t->host_hdr, t->dv.hdr, H_SIZE * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    BTS_HIP(hipStreamSynchronize(s));
+    const int32_t *h = t->host_hdr;
+    const int map[12] = {H_FRAME, H_NTRACKED, H_NLOST, H_NREMOVED, H_LASTID, H_NPOOL, H_NHI, H_NLO, H_NUNC, H_NR2, H_NLEFT, H_ERR};
+    for (int k = 0; k < 12; ++k) counts12_host[k] = h[map[k]];
+    if (int rc = device_error_status(t)) return rc;
+    return h[H_NTRACKED] + h[H_NLOST];
+}
+
+int bts_tracker_read_column(bts_tracker *t, int field, int32_t *out_host, bts_stream stream) {
+    BTS_REQUIRE(t && out_host && field >= 0 && field <= 2, "tracker, field, out");
+    BTS_ON_DEVICE(t->ctx);
+    const Dev &d = t->dv;
+    const int32_t *src = field == 0 ? d.track_id : field == 1 ? d.state : d.frame_id;
+    BTS_HIP(hipMemcpyAsync(out_host, src, sizeof(int32_t) * (size_t)d.T, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    BTS_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return BTS_OK;
 }
 
 int bts_tracker_export_mot(bts_tracker *t, double *rows_host, bts_stream stream) {

@@ -5,14 +5,17 @@ The per-frame association cascade, Kalman filtering, feature bookkeeping and lis
 run on the MI355X with no host round trip; this module only
   * hands the frame's detections to the device (`BoTSORT.update_arrays`, or `update(image)` which
     first calls the -- unchanged, out-of-scope -- detector / ReID encoders like the reference),
-  * and, for drop-in compatibility, mirrors the resulting track lists into light `STrack` objects
-    exposing what the reference's caller reads (D:2135-2185): `tlbr`, `track_id`, `body`, ...
+  * and, for drop-in compatibility, mirrors the resulting track lists: ONE export call per frame lands both lists in
+    pinned host memory (`bts_tracker_export_lists`); `tracked_stracks` / `lost_stracks` are `TrackList`s over that
+    snapshot which build an `STrack` mirror only for the entries the caller touches (D:2135-2185 reads `tlbr`,
+    `track_id`, `body`); a mirror the caller keeps across frames re-reads its row on first access after each frame.
 `update_arrays(..., export=False)` skips that mirror for throughput-critical loops.
 """
 from __future__ import annotations
 
 import ctypes
 from collections import OrderedDict, deque
+from collections.abc import Sequence
 from typing import List, Optional
 
 import numpy as np
@@ -139,20 +142,43 @@ class BaseTrack:                       # D:389-437 (the ID counter lives in the 
 def _lazy(field, name):
     """A per-track array that lives in the device table of the owning BoTSORT (covariance, ReID feature rows): a mirror
     fetches it on first access after a frame (bts_tracker_read_slot) and caches it until the next frame; standalone
-    STracks (detection records, tracks driven by hand through activate / update) simply hold their own value."""
+    STracks (detection records, tracks driven by hand through activate / update) simply hold their own value.  A tracker
+    without face features never asks the device for them: the attribute stays None like the reference's (D:481-485)."""
     attr = "_" + name
 
     def get(self):
-        own = self._owner
-        if own is not None and self.slot >= 0 and self._fresh.get(name) != own.frame_id and self._live:
-            setattr(self, attr, own.device_tracker.read_slot(self.slot, field))
-            self._fresh[name] = own.frame_id
-        return getattr(self, attr)
+        d = self.__dict__
+        own = d.get("_owner")
+        if own is not None and d["_live"] and not (field >= 4 and own.face_dim == 0):
+            if d["_epoch"] != own._epoch:
+                own._refresh(self)
+            if d["_live"] and d["slot"] >= 0 and d["_fresh"].get(name) != own._epoch:
+                d[attr] = own.device_tracker.read_slot(d["slot"], field)
+                d["_fresh"][name] = own._epoch
+        return d.get(attr)
 
     def set(self, value):
-        setattr(self, attr, value)
-        if self._owner is not None:
-            self._fresh[name] = self._owner.frame_id
+        d = self.__dict__
+        d[attr] = value
+        if d.get("_owner") is not None:
+            d["_fresh"][name] = d["_owner"]._epoch
+
+    return property(get, set)
+
+
+def _mirrored(name, default):
+    """A field the device refreshes every frame (state, frame counters, mean, ...).  Standalone STracks hold a plain value;
+    a mirror owned by a BoTSORT re-reads its row of the current snapshot on the first access after a frame, so an object the
+    caller kept from an earlier frame shows the track's current state like the reference's mutated-in-place STrack does."""
+    def get(self):
+        d = self.__dict__
+        own = d.get("_owner")
+        if own is not None and d["_epoch"] != own._epoch and d["_live"]:
+            own._refresh(self)
+        return d.get(name, default)
+
+    def set(self, value):
+        self.__dict__[name] = value
 
     return property(get, set)
 
@@ -167,8 +193,19 @@ class STrack(BaseTrack):
     runs through the standalone C-ABI kernels (`KalmanFilter`, `bts_feature_ema`) on the arrays the object holds."""
     shared_kalman = None
 
+    mean = _mirrored("mean", None)
+    state = _mirrored("state", TrackState.New)
+    is_activated = _mirrored("is_activated", False)
+    frame_id = _mirrored("frame_id", 0)
+    start_frame = _mirrored("start_frame", 0)
+    tracklet_len = _mirrored("tracklet_len", 0)
+    score = _mirrored("score", 0)
+    det_index = _mirrored("det_index", -1)
+    slot = _mirrored("slot", -1)
+    _dev_tlbr = _mirrored("_dev_tlbr", None)
+
     def __init__(self, tlwh, score, feature_history=300, body=None, body_feature=None, face_feature=None):
-        self._owner, self._live, self._fresh = None, True, {}
+        self._owner, self._live, self._fresh, self._epoch = None, True, {}, -1
         self._tlwh = np.asarray(tlwh, dtype=np.float32)            # D:465
         self.kalman_filter = None
         self.mean, self._covariance = None, None
@@ -191,6 +228,37 @@ class STrack(BaseTrack):
             self.update_body_features(body_feature)                # D:477-478
         if face_feature is not None:
             self.update_face_features(face_feature)                # D:484-485
+
+    # ---- mirror of a device-resident track (built by BoTSORT, never by the caller) ---------------------------------
+    _ZERO_TLWH = np.zeros(4, dtype=np.float32)
+
+    @classmethod
+    def _new_mirror(cls, owner, track_id):
+        """A mirror without running __init__ (no deques, no arrays: thousands may be built per frame)."""
+        st = cls.__new__(cls)
+        st.__dict__.update(_owner=owner, _live=True, _fresh={}, _epoch=-1, _tlwh=cls._ZERO_TLWH, kalman_filter=owner.kalman_filter,
+                           _covariance=None, alpha=0.9, body=None, _body_curr_feature=None, _body_smooth_feature=None,
+                           _face_curr_feature=None, _face_smooth_feature=None, feature_history=owner.feature_history,
+                           track_id=track_id, slot=-1)
+        return st
+
+    def __getattr__(self, name):                   # (only reached when normal lookup fails: the mirrors' feature deques)
+        if name in ("body_features", "face_features") and "_owner" in self.__dict__:
+            dq = deque([], maxlen=self.__dict__.get("feature_history", 300))
+            self.__dict__[name] = dq
+            return dq
+        raise AttributeError(name)
+
+    def _bind(self, snap, which, k):
+        """Row k of list `which` of a snapshot becomes this mirror's state (the per-frame fields of D:439-610)."""
+        d = self.__dict__
+        i = snap.ints[which][k].tolist()
+        d["state"], d["is_activated"], d["frame_id"], d["start_frame"] = i[1], bool(i[2]), i[3], i[4]
+        d["tracklet_len"], d["det_index"], d["slot"] = i[5], i[6], i[7]
+        d["mean"] = snap.mean[which][k]
+        d["_dev_tlbr"] = snap.tlbr[which][k]
+        d["score"] = float(snap.score[which][k])
+        d["_epoch"] = snap.epoch
 
     covariance = _lazy(1, "covariance")
     body_curr_feature = _lazy(2, "body_curr_feature")
@@ -378,6 +446,85 @@ def tracker_memory_bytes(max_tracks: int, max_dets: int, feat_dim: int, face_dim
     return int(out.value)
 
 
+COUNT_KEYS = ("frame_id", "n_tracked", "n_lost", "n_removed", "last_id", "n_pool", "n_hi", "n_lo", "n_unconfirmed",
+              "n_stage2_rows", "n_stage3_cols", "errors")
+
+
+class Snapshot:
+    """One frame's tracked (0) and lost (1) lists as column arrays, list order: ints[which] [n,8] (track_id, state,
+    is_activated, frame_id, start_frame, tracklet_len, det_index, slot), mean [n,8], tlbr [n,4], score [n]."""
+    __slots__ = ("epoch", "counts", "ints", "mean", "tlbr", "score", "_ids", "_where")
+
+    def __init__(self, epoch, counts12, ints, mean, tlbr, score):
+        self.epoch, self.ints, self.mean, self.tlbr, self.score = epoch, ints, mean, tlbr, score
+        self.counts = dict(zip(COUNT_KEYS, (int(v) for v in counts12)))
+        self._ids, self._where = [None, None], None
+
+    def n(self, which):
+        return len(self.ints[which])
+
+    def ids(self, which):
+        """track ids of a list as Python ints (converted once per frame, on first use)."""
+        if self._ids[which] is None:
+            self._ids[which] = self.ints[which][:, 0].tolist()
+        return self._ids[which]
+
+    def locate(self, track_id):
+        """(which, row) of a track id, or None: the index is built on the first lookup of a frame (only mirrors the caller
+        kept from earlier frames need it -- list access binds by position)."""
+        if self._where is None:
+            w = {}
+            for which in (1, 0):
+                w.update(zip(self.ids(which), ((which, k) for k in range(self.n(which)))))
+            self._where = w
+        return self._where.get(track_id)
+
+
+class TrackList(Sequence):
+    """`tracked_stracks` / `lost_stracks` of one frame (D:1629-1639) over a Snapshot: len(), indexing, slicing and iteration
+    like the reference's lists, but the STrack mirror of an entry is only built when the entry is touched."""
+    __slots__ = ("_owner", "_snap", "_which", "_n", "_items")
+
+    def __init__(self, owner, snap, which):
+        self._owner, self._snap, self._which = owner, snap, which
+        self._n = snap.n(which)
+        self._items = [None] * self._n
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            return [self[i] for i in range(*k.indices(self._n))]
+        if k < 0:
+            k += self._n
+        if not 0 <= k < self._n:
+            raise IndexError("list index out of range")
+        st = self._items[k]
+        if st is None:
+            st = self._items[k] = self._owner._mirror_at(self._snap, self._which, k)
+        return st
+
+    def __iter__(self):
+        for k in range(self._n):
+            yield self[k]
+
+    def __add__(self, other):
+        return list(self) + list(other)
+
+    def __radd__(self, other):
+        return list(other) + list(self)
+
+    def __eq__(self, other):
+        return isinstance(other, (list, TrackList)) and len(other) == self._n and all(a is b for a, b in zip(self, other))
+
+    def copy(self):
+        return list(self)
+
+    def __repr__(self):
+        return "TrackList(%d %s)" % (self._n, "tracked" if self._which == 0 else "lost")
+
+
 class DeviceTracker:
     """Thin owner of a `bts_tracker` handle."""
 
@@ -404,6 +551,7 @@ class DeviceTracker:
         self._mean = np.empty((t, 8), dtype=np.float64)
         self._tlbr = np.empty((t, 4), dtype=np.float64)
         self._score = np.empty((t,), dtype=np.float32)
+        self._pin = None
 
     def reset(self):
         _lib.check(self._lib.bts_tracker_reset(self.handle, _lib.current_stream()))
@@ -414,6 +562,35 @@ class DeviceTracker:
         m = int(boxes.shape[0])
         _lib.check(self._lib.bts_tracker_step(self.handle, _lib.ptr(boxes), _lib.ptr(scores), _lib.ptr(feats),
                                               _lib.ptr(face_feats), m, _lib.current_stream()))
+
+    def export_lists(self, epoch: int = 0) -> "Snapshot":
+        """Both lists in one call (bts_tracker_export_lists): the export kernels write into pinned host buffers owned by
+        this object, one stream synchronisation; the rows are copied out, so a Snapshot stays valid when the next frame
+        is exported.  Raises BtsError when the device flagged a truncated frame."""
+        if self._pin is None:
+            t = self.cfg.max_tracks
+            spec = ((np.int32, 8), (np.float64, 8), (np.float64, 4), (np.float32, 1))
+            ptrs, views = [], []
+            for dt, w in spec:
+                pp = ctypes.c_void_p()
+                _lib.check(self._lib.bts_pinned_alloc(ctypes.byref(pp), 2 * t * w * np.dtype(dt).itemsize))
+                ptrs.append(pp)
+                ct = {np.int32: ctypes.c_int32, np.float64: ctypes.c_double, np.float32: ctypes.c_float}[dt]
+                a = np.ctypeslib.as_array(ctypes.cast(pp, ctypes.POINTER(ct)), shape=(2 * t, w))
+                views.append(a if w > 1 else a.reshape(2 * t))
+            self._pin = (ptrs, views)
+        ptrs, (vi, vm, vb, vs) = self._pin
+        c = np.zeros(12, dtype=np.int32)
+        _lib.check(self._lib.bts_tracker_export_lists(self.handle, ptrs[0], ptrs[1], ptrs[2], ptrs[3], c.ctypes.data, _lib.current_stream()))
+        t, n0, n1 = self.cfg.max_tracks, int(c[1]), int(c[2])
+        return Snapshot(epoch, c, [vi[:n0].copy(), vi[t:t + n1].copy()], [vm[:n0].copy(), vm[t:t + n1].copy()],
+                        [vb[:n0].copy(), vb[t:t + n1].copy()], [vs[:n0].copy(), vs[t:t + n1].copy()])
+
+    def read_column(self, field: int) -> np.ndarray:
+        """int32 [max_tracks], slot order: field 0 track_id, 1 state, 2 frame_id (bts_tracker_read_column)."""
+        out = np.empty(self.cfg.max_tracks, dtype=np.int32)
+        _lib.check(self._lib.bts_tracker_read_column(self.handle, int(field), out.ctypes.data, _lib.current_stream()))
+        return out
 
     def export_mot(self) -> np.ndarray:
         """MOTChallenge rows [n,10] of the tracked list: frame, id, left, top, width, height, conf, -1, -1, -1."""
@@ -476,9 +653,7 @@ class DeviceTracker:
     def counts(self) -> dict:
         c = np.zeros(12, dtype=np.int32)
         _lib.check(self._lib.bts_tracker_counts(self.handle, c.ctypes.data, _lib.current_stream()))
-        keys = ("frame_id", "n_tracked", "n_lost", "n_removed", "last_id", "n_pool", "n_hi", "n_lo", "n_unconfirmed",
-                "n_stage2_rows", "n_stage3_cols", "errors")
-        return dict(zip(keys, (int(v) for v in c)))
+        return dict(zip(COUNT_KEYS, (int(v) for v in c)))
 
     def export(self, which: int) -> dict:
         n = _lib.check(self._lib.bts_tracker_export(self.handle, which, self._ints.ctypes.data, self._mean.ctypes.data,
@@ -527,6 +702,10 @@ class DeviceTracker:
         return tot.value, cnt.value
 
     def close(self):
+        if getattr(self, "_pin", None):
+            for pp in self._pin[0]:
+                self._lib.bts_pinned_free(pp)
+            self._pin = None
         if getattr(self, "handle", None):
             self._lib.bts_tracker_destroy(self.handle)
             self.handle = None
@@ -587,8 +766,13 @@ class BoTSORT:
     def __init__(self, object_detection_model=None, body_feature_extractor_model=None,
                  face_feature_extractor_model=None, frame_rate: int = 30, *, max_tracks: int = 4096,
                  max_dets: int = 1024, feat_dim: Optional[int] = None, face_dim: Optional[int] = None,
-                 record_costs: bool = False, device: Optional[int] = None, **tracker_options):
-        """`tracker_options`: further `bts_tracker_config` fields by name (`motion_gate=1`, `appearance_mode=1`, ...)."""
+                 record_costs: bool = False, device: Optional[int] = None, lazy_lists: bool = True,
+                 keep_removed_state: bool = True, **tracker_options):
+        """`tracker_options`: further `bts_tracker_config` fields by name (`motion_gate=1`, `appearance_mode=1`, ...).
+        `lazy_lists=False` hands out plain Python lists with every mirror built (round-2 behaviour: O(tracks) Python per
+        frame); `keep_removed_state=False` skips reading a removed track's covariance / feature rows off the device."""
+        self.lazy_lists, self.keep_removed_state = bool(lazy_lists), bool(keep_removed_state)
+        self._epoch, self._snap = 0, None
         self.tracked_stracks: List[STrack] = []
         self.lost_stracks: List[STrack] = []
         self.removed_stracks: List[STrack] = []
@@ -654,51 +838,99 @@ class BoTSORT:
         """Camera-motion compensation of every tracked / lost track (STrack.multi_gmc, D:538-554)."""
         self.device_tracker.gmc(H)
 
-    def _export(self, bodies=None) -> List[STrack]:
-        """Mirror the device lists.  Raises BtsError when the device flagged a truncated frame (track table full, solver
-        edge list overflow): bts_tracker_export turns the sticky flag into a status.  With export=False nothing is read
-        back -- poll `device_tracker.counts()['errors']`."""
-        dt = self.device_tracker
-        out = []
-        for which in (0, 1):
-            tab = dt.export(which)
-            lst = []
-            for k in range(len(tab["track_id"])):
-                tid = int(tab["track_id"][k])
-                st = self._mirror.get(tid)
-                if st is None:
-                    st = STrack(np.zeros(4, dtype=np.float32), 0.0, self.feature_history)
-                    st.track_id = tid
-                    st._owner = self
-                    st.kalman_filter = self.kalman_filter
-                    self._mirror[tid] = st
-                st.mean = tab["mean"][k]
-                st._dev_tlbr = tab["tlbr"][k]
-                st.state = int(tab["state"][k])
-                st.is_activated = bool(tab["is_activated"][k])
-                st.frame_id = int(tab["frame_id"][k])
-                st.start_frame = int(tab["start_frame"][k])
-                st.tracklet_len = int(tab["tracklet_len"][k])
-                st.score = float(tab["score"][k])
-                st.det_index = int(tab["det_index"][k])
-                st.slot = int(tab["slot"][k])
-                if bodies is not None and st.frame_id == self.frame_id and 0 <= st.det_index < len(bodies):
-                    st.body = bodies[st.det_index]
-                    st.propagate_trackid_to_related_objects()
-                lst.append(st)
-            out.append(lst)
-        self.tracked_stracks, self.lost_stracks = out
-        live = {t.track_id for t in self.tracked_stracks} | {t.track_id for t in self.lost_stracks}
-        for tid in [t for t in self._mirror if t not in live]:
-            st = self._mirror.pop(tid)
-            # removed (D:1609-1612, D:1623-1627: goes to removed_stracks) or dropped by remove_duplicate_stracks (D:1637: just
-            # leaves the lists)?  The slot still holds the track this frame.
-            dev_id, dev_state = (int(v) for v in dt.read_slot(st.slot, 6)) if st.slot >= 0 else (tid, TrackState.Removed)
-            st._live = False            # its table slot may be recycled: the cached arrays are what is left of it
-            if dev_id == tid and dev_state == TrackState.Removed:
-                st.state = TrackState.Removed
-                self.removed_stracks.append(st)
+    def _export(self, bodies=None):
+        """Mirror the device lists: one export call per frame (both lists, pinned memory, one synchronisation); the lists
+        handed out are TrackLists that build STrack mirrors on access.  Raises BtsError when the device flagged a truncated
+        frame (track table full, solver edge list overflow): bts_tracker_export_lists turns the sticky flag into a status.
+        With export=False nothing is read back -- poll `device_tracker.counts()['errors']`."""
+        prev = self._snap
+        snap = self.device_tracker.export_lists(self._epoch + 1)
+        self._epoch += 1
+        self._snap = snap
+        # Who left both lists this frame?  total = previous total + births - vanished, births = ids handed out (D:565);
+        # the exact set difference (and the bulk read of the table's id / state columns) only runs on frames where the
+        # counters say somebody did
+        if prev is not None:
+            births = snap.counts["last_id"] - prev.counts["last_id"]
+            if births < 0 or prev.n(0) + prev.n(1) + births != snap.n(0) + snap.n(1):
+                self._finalise_vanished(prev, snap)
+        self.tracked_stracks = TrackList(self, snap, 0)
+        self.lost_stracks = TrackList(self, snap, 1)
+        if bodies is not None:
+            self._attach_bodies(snap, bodies)
+        if not self.lazy_lists:
+            self.tracked_stracks, self.lost_stracks = list(self.tracked_stracks), list(self.lost_stracks)
         return self.tracked_stracks
+
+    def _mirror_at(self, snap, which, k):
+        """The STrack mirror of entry k of a list (TrackList access): the same object for the same track across frames."""
+        tid = snap.ids(which)[k]
+        st = self._mirror.get(tid)
+        if st is None:
+            st = STrack._new_mirror(self, tid)
+            if snap.epoch == self._epoch:
+                self._mirror[tid] = st
+            else:                       # an entry of a list kept from an earlier frame whose track is gone: a frozen record
+                st._bind(snap, which, k)
+                st.__dict__["_live"] = False
+                return st
+        if snap.epoch == self._epoch and st.__dict__["_epoch"] != snap.epoch:
+            st._bind(snap, which, k)
+        return st
+
+    def _refresh(self, st):
+        """First access after a frame to a mirror the caller kept: re-read its row of the current snapshot."""
+        loc = self._snap.locate(st.track_id) if self._snap is not None else None
+        if loc is None:
+            st.__dict__["_epoch"] = self._epoch
+        else:
+            st._bind(self._snap, *loc)
+
+    def _finalise_vanished(self, prev, snap):
+        """Tracks of the previous frame's lists that are on neither list now: removed (D:1609-1612, D:1623-1627: they go to
+        removed_stracks) or dropped by remove_duplicate_stracks (D:1637: they just leave the lists).  The table slot still
+        holds the track this frame, so ONE bulk read of the id / state columns tells which; a mirror keeps its last values
+        (and, with keep_removed_state, its covariance / feature rows) because the slot may be recycled from the next frame on."""
+        prev_ints = np.concatenate([prev.ints[0], prev.ints[1]]) if prev.n(0) + prev.n(1) else np.zeros((0, 8), np.int32)
+        cur_ids = np.concatenate([snap.ints[0][:, 0], snap.ints[1][:, 0]])
+        gone = np.nonzero(~np.isin(prev_ints[:, 0], cur_ids))[0]
+        if len(gone) == 0:
+            return
+        dt = self.device_tracker
+        dev_id, dev_state = dt.read_column(0), dt.read_column(1)
+        n0 = prev.n(0)
+        for r in gone.tolist():
+            tid, slot = int(prev_ints[r, 0]), int(prev_ints[r, 7])
+            removed = dev_id[slot] == tid and dev_state[slot] == TrackState.Removed
+            st = self._mirror.pop(tid, None)
+            if st is None:
+                if not removed:
+                    continue                # never handed out and not removed: nobody can refer to it
+                st = STrack._new_mirror(self, tid)
+            st._bind(prev, 0 if r < n0 else 1, r if r < n0 else r - n0)
+            d = st.__dict__
+            d["_epoch"] = self._epoch
+            if self.keep_removed_state and dev_id[slot] == tid:
+                st.covariance, st.body_curr_feature, st.body_smooth_feature           # (fetched while the slot still holds the track)
+                if self.face_dim:
+                    st.face_curr_feature, st.face_smooth_feature
+            d["_live"] = False
+            if removed:
+                d["state"] = TrackState.Removed
+                self.removed_stracks.append(st)
+
+    def _attach_bodies(self, snap, bodies):
+        """update(image): the matched detection's Body goes onto its track and the track id onto the Body and its parts
+        (D:583, D:609, D:1638) -- for the tracks matched or born this frame, the only ones whose body changed."""
+        for which in (0, 1):
+            ints = snap.ints[which]
+            if len(ints) == 0:
+                continue
+            hit = np.nonzero((ints[:, 3] == self.frame_id) & (ints[:, 6] >= 0) & (ints[:, 6] < len(bodies)))[0]
+            for k in hit.tolist():
+                st = self._mirror_at(snap, which, k)
+                st.body = bodies[int(ints[k, 6])]
+                st.propagate_trackid_to_related_objects()
 
     # ---- reference signature (detector + encoders are the caller's objects, unchanged)
     def update(self, image: np.ndarray) -> List[STrack]:

@@ -259,6 +259,19 @@ int bts_tracker_counts(bts_tracker *trk, int32_t *counts12_host, bts_stream stre
 int bts_tracker_export(bts_tracker *trk, int which, int32_t *ints_host, double *mean_host,
                        double *tlbr_host, float *score_host, bts_stream stream);
 
+/* BOTH lists in one call, for a per-frame drop-in caller (the BoTSORT facade's mirror of tracked_stracks / lost_stracks,
+ * D:1629-1639): the export kernels write straight into PINNED host buffers of the caller (bts_pinned_alloc; each
+ * nullable), list 0 (tracked) in rows [0, max_tracks), list 1 (lost) in rows [max_tracks, 2 max_tracks); ONE stream
+ * synchronisation, no staging copies.  Layouts per row as in bts_tracker_export.  counts12_host as bts_tracker_counts.
+ * The sticky device error is turned into a status exactly as by bts_tracker_export.  Returns n_tracked + n_lost or <0. */
+int bts_tracker_export_lists(bts_tracker *trk, int32_t *ints_pinned, double *mean_pinned, double *tlbr_pinned,
+                             float *score_pinned, int32_t *counts12_host, bts_stream stream);
+
+/* One int32 column of the WHOLE table (max_tracks entries, slot order) to HOST: field 0 track_id, 1 state, 2 frame_id.
+ * What became of tracks that left both lists (removed vs dropped as a duplicate, D:1609-1637) for many slots at once --
+ * the bulk form of bts_tracker_read_slot(field 6).  Synchronises. */
+int bts_tracker_read_column(bts_tracker *trk, int field, int32_t *out_host, bts_stream stream);
+
 /* Batched consumer format (what the reference's main loop reads per track, D:2135-2185):
  * one MOTChallenge row per entry of the tracked list -- frame, id, left, top, width, height, conf, -1, -1, -1
  * (float64 [rows,10], HOST buffer sized for max_tracks rows).  Synchronises.  Returns the row count or <0. */

@@ -94,6 +94,15 @@ def test_tracker_memory_is_linear_in_the_capacities():
     assert f(16384, 4096, 2048, max_edges=100000) < big
     with pytest.raises(pkg.BtsError):
         f(0, 10, 128)
+    # a stage threshold >= 1 makes EVERY pair feasible: the edge lists then keep the T * M that cannot overflow
+    lean, full = f(8192, 2048, 128), f(8192, 2048, 128, match_thresh=1.0)
+    per_edge = 4 * 4 + 2 * 8 + 4      # e_row, e_col, csr_col, csr_lcol, hard + e_cost, csr_cost per list entry (lap.hip layout) ...
+    assert full - lean > 2 * (8192 * 2048 - 64 * (8192 + 2048)) * (per_edge - 8)      # ... for both work areas
+    assert f(8192, 2048, 128, second_match_thresh=1.5) == full and f(8192, 2048, 128, unconfirmed_match_thresh=1.0) == full
+    # the int8 shadows are addressed with 32-bit byte offsets: tables beyond 2^32 bytes are refused in FILTER mode, not mis-read
+    with pytest.raises(pkg.BtsError):
+        f(4 * 1024 * 1024, 256, 2048)
+    assert f(4 * 1024 * 1024, 256, 2048, appearance_mode=1) > 0
 
 
 def test_binding_argument_counts_match_the_header():

@@ -1,0 +1,173 @@
+"""Host logic of the BoTSORT facade (bot-sort-onnx-tensorrt_amd/tracker.py) on the CPU: the lazy TrackLists, mirrors kept
+across frames, the bulk detection of removed / dropped tracks.  The device tracker is replaced by a TEST DOUBLE that serves
+`export_lists / read_column / read_slot / counts` from the CPU oracle (tests may use the oracle; the product never does);
+the GPU tests (tests/test_gpu_round2.py) run the same facade over the real device tracker."""
+import importlib
+
+import numpy as np
+import pytest
+
+from oracle import bts_oracle as bo
+
+pkg = importlib.import_module("bot-sort-onnx-tensorrt_amd")
+trk = pkg.tracker
+
+
+class OracleBackedTracker:
+    """Stands in for DeviceTracker: every track gets a table slot for life (like the device's slot table)."""
+
+    def __init__(self, max_tracks, max_dets, feat_dim, face_dim=0, frame_rate=30, **kw):
+        self.cfg = type("Cfg", (), dict(max_tracks=max_tracks, max_dets=max_dets, feat_dim=feat_dim, face_dim=face_dim))()
+        self.ora = bo.TrackerOracle(frame_rate=frame_rate)
+        self.slot_of, self.rec_of_slot, self.reads = {}, {}, 0
+
+    def step(self, boxes, scores, feats, face_feats=None):
+        self.ora.update_arrays(np.asarray(boxes), np.asarray(scores, dtype=np.float64), np.asarray(feats).copy(),
+                               None if face_feats is None else np.asarray(face_feats).copy())
+        for t in self.ora.tracked + self.ora.lost:
+            if t.track_id not in self.slot_of:
+                s = len(self.slot_of)
+                self.slot_of[t.track_id] = s
+                self.rec_of_slot[s] = t
+
+    def _counts(self):
+        o = self.ora
+        return np.asarray([o.frame_id, len(o.tracked), len(o.lost), len(o.removed), o._count, 0, 0, 0, 0, 0, 0, 0], dtype=np.int32)
+
+    def counts(self):
+        return dict(zip(trk.COUNT_KEYS, (int(v) for v in self._counts())))
+
+    def export_lists(self, epoch=0):
+        cols = [[], [], [], []]
+        for lst in (self.ora.tracked, self.ora.lost):
+            n = len(lst)
+            ints = np.asarray([[t.track_id, t.state, int(t.is_activated), t.frame_id, t.start_frame, t.tracklet_len, t.det_index,
+                                self.slot_of[t.track_id]] for t in lst], dtype=np.int32).reshape(n, 8)
+            mean = np.asarray([np.asarray(t.mean, dtype=np.float64) for t in lst]).reshape(n, 8)
+            tlbr = np.asarray([np.asarray(t.tlbr, dtype=np.float64) for t in lst]).reshape(n, 4)
+            score = np.asarray([t.score for t in lst], dtype=np.float32)
+            for c, a in zip(cols, (ints, mean, tlbr, score)):
+                c.append(a)
+        return trk.Snapshot(epoch, self._counts(), *cols)
+
+    def read_column(self, field):
+        out = np.zeros(self.cfg.max_tracks, dtype=np.int32)
+        for s, t in self.rec_of_slot.items():
+            out[s] = (t.track_id, t.state, t.frame_id)[field]
+        return out
+
+    def read_slot(self, slot, field):
+        self.reads += 1
+        t = self.rec_of_slot[slot]
+        return {1: np.asarray(t.cov, dtype=np.float64), 2: t.body_curr, 3: t.body_smooth, 4: t.face_curr, 5: t.face_smooth}[field].copy()
+
+
+@pytest.fixture
+def bot(monkeypatch):
+    monkeypatch.setattr(trk, "DeviceTracker", OracleBackedTracker)
+
+    def make(**kw):
+        b = pkg.BoTSORT(None, None, None, **kw)
+
+        def update_arrays(boxes, scores, feats, face_feats=None, bodies=None, export=True):      # (the real one moves the arrays to the GPU)
+            b.device_tracker.step(boxes, scores, feats, face_feats)
+            b.frame_id += 1
+            return b._export(bodies) if export else None
+        b.update_arrays = update_arrays
+        return b
+    return make
+
+
+def _stream(K=48, M=24, D=32, seed=3, churn=0.15):
+    return pkg.synth.SyntheticStream(K, M, D, seed=seed, churn=churn)
+
+
+def test_lazy_lists_mirror_the_oracle_and_build_nothing_until_touched(bot):
+    b = bot(frame_rate=3, max_tracks=2048, max_dets=64, feat_dim=32)       # frame_rate 3: tracks expire after 30 frames
+    st = _stream()
+    ora = b.device_tracker.ora
+    kept, touched = {}, set()
+    for f in range(70):
+        fr = st.next()
+        out = b.update_arrays(fr.boxes, fr.scores, fr.feats)
+        assert out is b.tracked_stracks and isinstance(out, trk.TrackList) and len(out) == len(ora.tracked)
+        assert len(b.lost_stracks) == len(ora.lost)
+        if f % 7 == 3:
+            assert b._mirror.keys() <= touched, "mirrors were built although nobody touched the lists"
+            continue                                  # a frame whose lists the caller never looks at
+        for lst, want in ((b.tracked_stracks, ora.tracked), (b.lost_stracks, ora.lost)):
+            assert [t.track_id for t in lst] == [t.track_id for t in want]
+            touched |= {t.track_id for t in want}
+            assert [t.state for t in lst] == [t.state for t in want]
+            assert [t.is_activated for t in lst] == [bool(t.is_activated) for t in want]
+            assert [(t.frame_id, t.start_frame, t.tracklet_len) for t in lst] == [(t.frame_id, t.start_frame, t.tracklet_len) for t in want]
+            for mine, ref in zip(lst, want):
+                assert np.array_equal(mine.mean, np.asarray(ref.mean, dtype=np.float64))
+                assert np.array_equal(mine.tlbr, np.asarray(ref.tlbr, dtype=np.float64)) and mine.end_frame == ref.frame_id
+        if f == 5:
+            kept = {t.track_id: t for t in list(b.tracked_stracks)[:6]}
+        # an STrack the caller kept is THE object of that track on later frames, and shows the current state when read
+        for tid, obj in kept.items():
+            now = [t for t in ora.tracked + ora.lost if t.track_id == tid]
+            if now:
+                assert obj.frame_id == now[0].frame_id and obj.state == now[0].state
+                assert np.array_equal(obj.mean, np.asarray(now[0].mean, dtype=np.float64))
+                where = b.tracked_stracks if now[0] in ora.tracked else b.lost_stracks
+                assert any(t is obj for t in where)
+    assert len(ora.removed) > 0, "the stream must exercise removals"
+    # removed_stracks: every track that left both lists in state Removed, once, frozen with its last values and arrays
+    got = [t.track_id for t in b.removed_stracks]
+    assert len(got) == len(set(got)) and set(got) <= {t.track_id for t in ora.removed}
+    live = {t.track_id for t in ora.tracked + ora.lost}
+    assert set(got) == {t.track_id for t in ora.removed} - live
+    for t in b.removed_stracks:
+        assert t.state == pkg.TrackState.Removed and t.covariance is not None and t.covariance.shape == (8, 8)
+        assert t.body_curr_feature is not None and t.face_curr_feature is None
+
+
+def test_slices_negative_indices_and_list_helpers(bot):
+    b = bot(max_tracks=512, max_dets=64, feat_dim=32)
+    st = _stream(churn=0.0)
+    for _ in range(3):
+        fr = st.next()
+        out = b.update_arrays(fr.boxes, fr.scores, fr.feats)
+    n = len(out)
+    assert n > 8 and out[-1] is out[n - 1] and out[2:5] == [out[2], out[3], out[4]] and out[0] in out
+    with pytest.raises(IndexError):
+        out[n]
+    assert len(out + b.lost_stracks) == n + len(b.lost_stracks) and isinstance(out + [], list)
+    assert [t.track_id for t in pkg.tracker.joint_stracks(out, b.lost_stracks)] == [t.track_id for t in out] + [t.track_id for t in b.lost_stracks]
+    assert pkg.tracker.sub_stracks(out, out[:3]) == list(out[3:])
+    assert repr(out).startswith("TrackList(")
+
+
+def test_eager_lists_option_and_lazy_arrays(bot):
+    b = bot(max_tracks=512, max_dets=64, feat_dim=32, lazy_lists=False)
+    st = _stream(churn=0.0)
+    fr = st.next()
+    out = b.update_arrays(fr.boxes, fr.scores, fr.feats)
+    assert isinstance(out, list) and len(b._mirror) == len(out) + len(b.lost_stracks)
+    t0 = out[0]
+    before = b.device_tracker.reads
+    c1, c2 = t0.covariance, t0.covariance
+    assert b.device_tracker.reads == before + 1 and c1 is c2                   # fetched once per frame, on access
+    assert t0.face_curr_feature is None and t0.face_smooth_feature is None     # face_dim = 0: never asks the device (reference: None)
+    assert b.device_tracker.reads == before + 1
+    fr = st.next()
+    b.update_arrays(fr.boxes, fr.scores, fr.feats)
+    assert t0.covariance is not c1 and b.device_tracker.reads == before + 2    # a new frame: re-read on the next access
+
+
+def test_bodies_are_attached_and_ids_propagated(bot):
+    b = bot(max_tracks=512, max_dets=64, feat_dim=32)
+    st = _stream(churn=0.0)
+    for _ in range(2):
+        fr = st.next()
+        bodies = [pkg.Body(score=float(s), x1=int(x[0]), y1=int(x[1]), x2=int(x[2]), y2=int(x[3]), head=pkg.Head()) for x, s in zip(fr.boxes, fr.scores)]
+        out = b.update_arrays(fr.boxes, fr.scores, fr.feats, bodies=bodies)
+    hit = 0
+    for t in out:
+        if t.frame_id == b.frame_id and t.det_index >= 0:
+            assert t.body is bodies[t.det_index] and t.body.trackid == t.track_id and t.body.head.trackid == t.track_id
+            hit += 1
+    assert hit > 10

@@ -1,0 +1,134 @@
+"""Round-3 GPU parity tests: detection rows that do not arrive unit-norm through the int8 pre-filter, the
+one-call list export behind the BoTSORT facade, exact ties (see test_gpu_ties.py for the tie families)."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+INT_KEYS = ("track_id", "state", "is_activated", "frame_id", "start_frame", "tracklet_len")
+
+
+@pytest.fixture(scope="module")
+def bts():
+    pkg = importlib.import_module("bot-sort-onnx-tensorrt_amd")
+    pkg._lib.load(require_gpu=True)
+    return pkg
+
+
+@pytest.mark.parametrize("lo,hi", [(0.8, 0.95), (1.05, 1.25), (0.8, 1.25)])
+def test_filter_mode_with_non_unit_detection_norms(bts, lo, hi):
+    """A track's curr feature is the RENORMALISED detection row x / |x| (D:492-502, Q8) while this frame's similarities are
+    taken with the RAW rows.  Detections arrive with norms in [lo, hi]; boxes teleport every frame so that only the
+    appearance term can re-associate; the raw similarity |x| cos sits within +-0.02 of the 0.75 gate.  The int8 pre-filter
+    (FILTER) must hand the solver exactly the pairs the dense float32 path (DENSE) finds, and both must equal the oracle --
+    with the shadow record of a track taken from a non-unit row unadjusted, FILTER drops true matches for norms < 1."""
+    import torch
+    from oracle import bts_oracle as bo
+    rng = np.random.default_rng(int(lo * 1000 + hi * 10))
+    K, D = 1024, 256
+    proto = rng.standard_normal((K, D))
+    proto /= np.linalg.norm(proto, axis=1, keepdims=True)
+    a = bts.DeviceTracker(max_tracks=2304, max_dets=K, feat_dim=D)
+    b = bts.DeviceTracker(max_tracks=2304, max_dets=K, feat_dim=D, appearance_mode=1)
+    ora = bo.TrackerOracle()
+    matched = []
+    for f in range(5):
+        cx = rng.permutation(K) * 7 + 10
+        cy = rng.integers(100, 8000, K)
+        boxes = np.stack([cx, cy, cx + 5, cy + 9], 1).astype(np.int32)
+        scores = (rng.uniform(0.91, 0.99, K) if f == 0 else rng.uniform(0.5, 0.85, K)).astype(np.float32)
+        nrm = rng.uniform(lo, hi, K)
+        c = (0.75 + rng.uniform(3e-5, 0.02, K) * rng.choice([-1.0, 1.0], K)) / nrm           # raw similarity = |x| cos
+        c = np.minimum(c, 0.999)
+        if f == 0:
+            c[:] = 1.0
+        noise = rng.standard_normal((K, D))
+        noise -= (noise * proto).sum(1, keepdims=True) * proto
+        noise /= np.linalg.norm(noise, axis=1, keepdims=True)
+        unit = c[:, None] * proto + np.sqrt(1 - c[:, None] ** 2) * noise
+        feats = (nrm[:, None] * unit).astype(np.float32)
+        proto = feats.astype(np.float64) / np.linalg.norm(feats.astype(np.float64), axis=1, keepdims=True)
+        perm = rng.permutation(K)
+        boxes, scores, feats = boxes[perm], scores[perm], np.ascontiguousarray(feats[perm])
+        proto = proto[perm]
+        fr = (torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda())
+        a.step(*fr, torch.from_numpy(feats.copy()).cuda())
+        b.step(*fr, torch.from_numpy(feats.copy()).cuda())
+        ora.update_arrays(boxes, scores.astype(np.float64), feats.copy())
+        for k in (1, 2, 3):
+            ra, rb = a.stage_result(k), b.stage_result(k)
+            assert np.array_equal(ra["x"], rb["x"]) and np.array_equal(ra["y"], rb["y"]), (f, k)
+            assert np.array_equal(ra["m"], ora.trace["m%d" % k]), (f, k)
+        matched.append(len(a.stage_result(1)["m"]))
+        for which, lst in ((0, ora.tracked), (1, ora.lost)):
+            ta, tb, want = a.export(which), b.export(which), bo.TrackerOracle.table(lst)
+            for key in INT_KEYS:
+                assert np.array_equal(ta[key], tb[key]) and np.array_equal(ta[key], want[key]), (f, which, key)
+        assert a.counts() == b.counts() and a.counts()["errors"] == 0
+    assert min(matched[1:]) > K // 4          # about half of the raw similarities sit inside the gate, every frame
+    a.close(); b.close()
+
+
+def test_export_lists_equals_the_per_list_export(bts):
+    """bts_tracker_export_lists (both lists, pinned memory, one synchronisation) = two bts_tracker_export calls;
+    bts_tracker_read_column = bts_tracker_read_slot(field 6) for every slot."""
+    import torch
+    synth = bts.synth
+    st = synth.SyntheticStream(96, 48, 64, seed=11, churn=0.1)
+    trk = bts.DeviceTracker(max_tracks=512, max_dets=96, feat_dim=64, frame_rate=3)
+    for f in range(45):
+        fr = st.next()
+        trk.step(torch.from_numpy(fr.boxes).cuda(), torch.from_numpy(fr.scores).cuda(), torch.from_numpy(fr.feats.copy()).cuda())
+        if f % 4 and f < 40:
+            continue
+        snap = trk.export_lists(f)
+        c = trk.counts()
+        assert snap.counts == c and snap.n(0) == c["n_tracked"] and snap.n(1) == c["n_lost"]
+        for which in (0, 1):
+            t = trk.export(which)
+            i = snap.ints[which]
+            for col, key in enumerate(("track_id", "state", "is_activated", "frame_id", "start_frame", "tracklet_len", "det_index", "slot")):
+                assert np.array_equal(i[:, col], t[key]), (f, which, key)
+            assert np.array_equal(snap.mean[which], t["mean"]) and np.array_equal(snap.tlbr[which], t["tlbr"])
+            assert np.array_equal(snap.score[which], t["score"])
+        ids, states = trk.read_column(0), trk.read_column(1)
+        for s in list(snap.ints[0][:5, 7]) + list(snap.ints[1][:5, 7]):
+            one = trk.read_slot(int(s), 6)
+            assert (ids[s], states[s]) == (one[0], one[1])
+    assert c["n_lost"] > 0 and c["n_removed"] > 0
+    trk.close()
+
+
+def test_facade_lists_are_lazy_and_match_the_oracle(bts):
+    """BoTSORT.update_arrays over the real device tracker: TrackLists equal the oracle's lists; removed tracks reach
+    removed_stracks frozen; a mirror kept across frames follows its track (CPU twin: tests/test_facade_host.py)."""
+    from oracle import bts_oracle as bo
+    st = bts.synth.SyntheticStream(96, 48, 64, seed=12, churn=0.1)
+    bot = bts.BoTSORT(max_tracks=1024, max_dets=96, feat_dim=64, frame_rate=3)
+    ora = bo.TrackerOracle(frame_rate=3)
+    kept = None
+    for f in range(50):
+        fr = st.next()
+        out = bot.update_arrays(fr.boxes, fr.scores, fr.feats.copy())
+        ora.update_arrays(fr.boxes, fr.scores.astype(np.float64), fr.feats.copy())
+        assert isinstance(out, bts.tracker.TrackList) and len(out) == len(ora.tracked) and len(bot.lost_stracks) == len(ora.lost)
+        if f % 5 == 4:
+            continue                               # lists never touched on these frames
+        assert [t.track_id for t in out] == [t.track_id for t in ora.tracked]
+        assert [t.track_id for t in bot.lost_stracks] == [t.track_id for t in ora.lost]
+        assert [t.state for t in bot.lost_stracks] == [t.state for t in ora.lost]
+        for mine, ref in list(zip(out, ora.tracked))[::5]:
+            assert np.abs(mine.mean - np.asarray(ref.mean, dtype=np.float64)).max() <= 1e-6
+            assert np.abs(mine.tlbr - np.asarray(ref.tlbr, dtype=np.float64)).max() <= 1e-6
+        if f == 3:
+            kept = out[0]
+        if kept is not None:
+            now = [t for t in ora.tracked + ora.lost if t.track_id == kept.track_id]
+            if now:
+                assert kept.frame_id == now[0].frame_id and kept.state == now[0].state
+    live = {t.track_id for t in ora.tracked + ora.lost}
+    assert {t.track_id for t in bot.removed_stracks} == {t.track_id for t in ora.removed} - live and len(bot.removed_stracks) > 0
+    for t in bot.removed_stracks:
+        assert t.state == bts.TrackState.Removed and t.covariance.shape == (8, 8) and t.face_curr_feature is None

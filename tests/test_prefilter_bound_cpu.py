@@ -55,6 +55,17 @@ def shadows(x, gate):
     return q, rec, cst
 
 
+def track_side(rec, nrm, gate):
+    """feat::i8_track_side: the record of a raw row x becomes the record of the unit row x / |x| a track holds."""
+    f = np.float32
+    out = rec.copy()
+    k = np.asarray([1.03, 1.03, 1.03, 1.03, 1.0], dtype=np.float32)
+    out[:, :, 3] = rec[:, :, 3] + k[None, :] * f(gate) * (nrm.astype(np.float32)[:, None] - f(1.0))
+    bad = ~((nrm > 0) & (nrm < 3e38))
+    out[bad, :, 3] = -np.inf
+    return out
+
+
 def excluded(qa, ra, qb, rb, c, cst, d):
     """Pairwise (row i of a with row i of b) at checkpoint c (4 = full row), float32 like i8_excluded."""
     k = d if c == 4 else cst[c] * I8_STAGE
@@ -159,3 +170,48 @@ def test_non_finite_rows_are_never_dropped():
         ra[:2, :, 3] = -np.inf; ra[:2, :, 1] = np.inf
         for c in range(5):
             assert not excluded(qa, ra, qb, rb, c, cst, d)[:2].any()
+
+
+@pytest.mark.parametrize("d", [384, 512, 2048])
+def test_track_rows_copied_from_non_unit_detections_stay_sound(d):
+    """a track's row is the RENORMALISED detection row x / |x| while its shadow is the shadow of the raw x.
+    With the record turned into its track-side form (feat::i8_track_side, applied when the row is renormalised) the rule must
+    stay sound for detection norms of 0.8 .. 1.25 on BOTH sides -- and the unadjusted record must be shown to fail there,
+    so that this test cannot pass vacuously."""
+    rng = np.random.default_rng(7 * d)
+    gate, n = 0.75, 800
+    broke_without = 0
+    total = dropped = 0
+    for lo, hi in ((0.8, 1.25), (0.8, 0.95), (1.05, 1.25), (1.0, 1.0)):
+        base = unit(rng.standard_normal((n, d)))
+        noise = unit(rng.standard_normal((n, d)))
+        cosv = rng.uniform(0.6, 0.95, (n, 1))
+        near = unit(cosv * base + np.sqrt(1 - cosv ** 2) * unit(noise - (noise * base).sum(1, keepdims=True) * base))
+        na = rng.uniform(lo, hi, (n, 1)).astype(np.float32)
+        nb = rng.uniform(lo, hi, (n, 1)).astype(np.float32)
+        x_trk_raw = (base * na).astype(np.float32)            # the detection the track absorbed, as it arrived
+        y_det = (near * nb).astype(np.float32)                # this frame's raw detection
+        nrm = np.sqrt((x_trk_raw * x_trk_raw).sum(1, dtype=np.float32))
+        u = (x_trk_raw / nrm[:, None]).astype(np.float32)     # what the track's curr feature holds
+        truth = (u.astype(np.float64) * y_det.astype(np.float64)).sum(1)
+        qa, ra_raw, cst = shadows(x_trk_raw, gate)
+        qb, rb, _ = shadows(y_det, gate)
+        ra = track_side(ra_raw, nrm, gate)
+        for c in range(5):
+            if c < 4 and cst[c] * I8_STAGE >= d:
+                continue
+            ex = excluded(qa, ra, qb, rb, c, cst, d)
+            bad = ex & (truth >= gate)
+            assert not bad.any(), (d, c, lo, hi, float(truth[bad].max()), int(bad.sum()))
+            total += len(ex); dropped += int(ex.sum())
+            broke_without += int((excluded(qa, ra_raw, qb, rb, c, cst, d) & (truth >= gate)).sum())
+    assert dropped > 0.1 * total
+    assert broke_without > 0, "the unadjusted record should drop true matches when |x| < 1 (the finding this test pins)"
+    # degenerate norms: never dropped
+    z = np.zeros((4, d), dtype=np.float32)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        qz, rz, cst = shadows(z, gate)
+        rz = track_side(rz, np.zeros(4, dtype=np.float32), gate)
+        qb, rb, _ = shadows(unit(rng.standard_normal((4, d))), gate)
+        for c in range(5):
+            assert not excluded(qz, rz, qb, rb, c, cst, d).any()
