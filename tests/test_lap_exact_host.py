@@ -1,0 +1,186 @@
+"""The exact-tie code of the product (csrc/lap_exact.h: uniqueness certificate + phase-parallel replay of lap 0.4.0's dense
+JV) compiled for the CPU by tests/host_emul with an executor that runs a workgroup's threads one after the other, against
+the oracle's dense JV (oracle/lapjv_oracle.c) on tie families: INDEX vectors, not objectives.
+
+  * replay (forced): x, y identical to the dense JV's for every case, every emulated workgroup size, both thread orders, any
+    order of the edge list;
+  * certificate: whenever it says "unique", the assignment it was shown IS the dense JV's; it says "tied" on the tie families
+    that fool the fast solver (so the replay runs there) and "unique" on tie-free float costs (so it does not run there).
+The same source runs on the device as k_lap_exact (tests/test_gpu_ties.py compares THAT with the oracle on the GPU)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+from scipy.optimize import linear_sum_assignment
+
+from oracle import bts_oracle as bo
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def lapx():
+    d = os.path.join(HERE, "host_emul")
+    subprocess.check_call(["make", "-C", d, "-s"])
+    lib = ctypes.CDLL(os.path.join(d, "liblapx_host.so"))
+    P = ctypes.c_void_p
+    lib.lapx_host_exact.argtypes = [ctypes.c_int, ctypes.c_int, P, ctypes.c_int, ctypes.c_double, P, P, ctypes.c_int, ctypes.c_int,
+                                    ctypes.c_int, P, ctypes.c_uint, P]
+
+    def run(cost, L, x, y, nth=64, order=0, force=False, base=None, shuffle=0):
+        c = np.ascontiguousarray(cost, dtype=np.float64)
+        n, m = c.shape
+        x = np.ascontiguousarray(x, dtype=np.int32).copy()
+        y = np.ascontiguousarray(y, dtype=np.int32).copy()
+        info = np.zeros(4, dtype=np.int32)
+        b = None if base is None else np.ascontiguousarray(base, dtype=np.float64)
+        rc = lib.lapx_host_exact(n, m, c.ctypes.data, m, L, x.ctypes.data, y.ctypes.data, nth, order, int(force),
+                                 None if b is None else b.ctypes.data, shuffle, info.ctypes.data)
+        assert rc == 0 and info[1] == 0, (rc, info)
+        return x, y, {"tied": bool(info[0]), "replayed": bool(info[2]), "edges": int(info[3])}
+    return run
+
+
+def scipy_visible(c, L):
+    """SOME optimum of the extended problem (not the JV's on ties): what a fast exact solver would hand over."""
+    n, m = c.shape
+    ext = np.full((n + m, n + m), L / 2.0)
+    ext[n:, m:] = 0
+    ext[:n, :m] = c
+    r, q = linear_sum_assignment(ext)
+    x, y = np.full(n, -1, np.int32), np.full(m, -1, np.int32)
+    for i, j in zip(r, q):
+        if i < n and j < m:
+            x[i], y[j] = j, i
+    return x, y
+
+
+def jv(c, L):
+    _, x, y = bo.lapjv(np.ascontiguousarray(c, dtype=np.float64), extend_cost=True, cost_limit=L)
+    return np.asarray(x, dtype=np.int32), np.asarray(y, dtype=np.int32)
+
+
+def tie_families(rng, count, max_dim=10):
+    L = 0.8
+    for _ in range(count):
+        kind = int(rng.integers(0, 8))
+        n, m = (int(v) for v in rng.integers(1, max_dim, 2))
+        if kind == 0:
+            c = rng.integers(1, 6, (n, m)) / 5.0                       # integer grid: many ties, some at the limit
+        elif kind == 1:
+            c = rng.uniform(0.05, 0.95, (n, m)); c[rng.random((n, m)) < 0.5] = 1.0      # tie-free floats
+        elif kind == 2:
+            c = rng.uniform(0.05, 0.75, (n, m)); c[rng.random((n, m)) < 0.5] = 1.0
+            j = rng.integers(0, m); c = np.concatenate([c, c[:, j:j + 1]], 1)            # duplicated detection column
+        elif kind == 3:
+            c = rng.uniform(0.05, 0.75, (n, m)); c[rng.random((n, m)) < 0.5] = 1.0
+            i = rng.integers(0, n); c = np.concatenate([c, c[i:i + 1]], 0)               # duplicated track row
+        elif kind == 4:
+            c = np.full((n, m), rng.choice([0.25, 0.4, 0.8])); c[rng.random((n, m)) < 0.3] = 1.0     # all-equal blocks, also at L/2 and L
+        elif kind == 5:
+            c = rng.choice([0.1, 0.3, 0.4, 0.5, 0.7, 0.8, 1.0], (n, m))
+        elif kind == 6:
+            c = rng.choice([0.2, 0.6], (n, m)).astype(np.float64); c[rng.random((n, m)) < 0.6] = rng.choice([0.85, 0.9, 1.0])   # non-edges of several values
+        else:
+            c = np.round(rng.uniform(0.0, 1.0, (n, m)), 1)                               # one decimal: ties everywhere, zeros included
+        yield np.ascontiguousarray(c, dtype=np.float64), L
+
+
+def test_forced_replay_equals_the_dense_jv_on_tie_families(lapx):
+    rng = np.random.default_rng(0)
+    for k, (c, L) in enumerate(tie_families(rng, 2500)):
+        want = jv(c, L)
+        x0, y0 = scipy_visible(c, L)
+        for nth, order in ((64, 0), (7, 1), (1, 0), (256, 1)) if k % 5 == 0 else ((32, k & 1),):
+            x, y, info = lapx(c, L, x0, y0, nth=nth, order=order, force=True, shuffle=k % 7)
+            assert np.array_equal(x, want[0]) and np.array_equal(y, want[1]), (k, nth, order, c, x, want[0])
+
+
+def test_forced_replay_on_larger_sparse_problems(lapx):
+    """Tracker-shaped problems (few feasible edges, many rows without any, non-edges at several costs > L), with planted ties:
+    the regime in which lap's column list is rotated thousands of times per search (apply_runs)."""
+    rng = np.random.default_rng(1)
+    for k in range(40):
+        n, m = int(rng.integers(20, 140)), int(rng.integers(8, 60))
+        c = np.ones((n, m))
+        rows = rng.permutation(n)[:min(n, m)]
+        for j, i in enumerate(rows):
+            c[i, j % m] = np.round(rng.uniform(0.05, 0.6), 2 if k % 2 else 6)
+        extra = int(1.5 * m)
+        c[rng.integers(0, n, extra), rng.integers(0, m, extra)] = np.round(rng.uniform(0.1, 0.79, extra), 1 if k % 3 == 0 else 6)
+        far = (c == 1.0) & (rng.random((n, m)) < 0.05)
+        c[far] = rng.uniform(0.81, 0.99, int(far.sum()))
+        if k % 4 == 0:
+            c[:, -1] = c[:, 0]
+        want = jv(c, 0.8)
+        x0, y0 = scipy_visible(c, 0.8)
+        x, y, _ = lapx(c, 0.8, x0, y0, nth=64 if k % 2 else 256, order=k & 1, force=True, shuffle=k)
+        assert np.array_equal(x, want[0]) and np.array_equal(y, want[1]), k
+
+
+def test_certificate_is_sound_and_sharp(lapx):
+    rng = np.random.default_rng(2)
+    unique = tied = tied_and_scipy_differs = 0
+    for k, (c, L) in enumerate(tie_families(rng, 4000)):
+        want = jv(c, L)
+        x0, y0 = scipy_visible(c, L)
+        x, y, info = lapx(c, L, x0, y0, nth=64, order=k & 1, shuffle=k % 5)
+        # the end result is ALWAYS the dense JV's: either certified as is, or replayed
+        assert np.array_equal(x, want[0]) and np.array_equal(y, want[1]), (k, info, c)
+        assert info["replayed"] == info["tied"]
+        if info["tied"]:
+            tied += 1
+            tied_and_scipy_differs += not (np.array_equal(x0, want[0]) and np.array_equal(y0, want[1]))
+        else:
+            unique += 1
+            assert np.array_equal(x0, want[0]) and np.array_equal(y0, want[1]), (k, c)      # soundness
+        # the verdict does not depend on which optimum it is shown
+        _, _, info2 = lapx(c, L, want[0], want[1], nth=32, order=0)
+        assert info2["tied"] == info["tied"], (k, c)
+    assert unique > 800 and tied > 800 and tied_and_scipy_differs > 300
+
+
+def test_certificate_does_not_fire_on_tie_free_costs(lapx):
+    rng = np.random.default_rng(3)
+    for k in range(150):
+        n, m = (int(v) for v in rng.integers(5, 80, 2))
+        c = rng.uniform(0.05, 0.95, (n, m)); c[rng.random((n, m)) < 0.8] = 1.0
+        x0, y0 = scipy_visible(c, 0.8)
+        x, y, info = lapx(c, 0.8, x0, y0, nth=64, shuffle=k)
+        assert not info["tied"] and np.array_equal(x, x0) and np.array_equal(y, y0), k
+    # cost exactly at the limit: matched or not costs the same -> tied
+    _, _, info = lapx(np.full((1, 1), 0.8), 0.8, [0], [0])
+    assert info["tied"]
+    _, _, info = lapx(np.full((1, 1), 0.8), 0.8, [-1], [-1])
+    assert info["tied"]
+    _, _, info = lapx(np.full((1, 1), 0.3), 0.8, [0], [0])
+    assert not info["tied"]
+
+
+def test_patched_source_equals_the_dense_source(lapx):
+    """The tracker's cost source: non-edges come from a BASE matrix (the IoU cost), feasible edges from the edge list (where
+    the fused appearance term may have lowered them).  Replaying through it must give what the full matrix gives."""
+    rng = np.random.default_rng(4)
+    for k in range(300):
+        n, m = (int(v) for v in rng.integers(1, 12, 2))
+        base = np.round(rng.uniform(0.3, 1.0, (n, m)), 1)               # "IoU costs": ties, some <= L
+        fused = base.copy()
+        hit = rng.random((n, m)) < 0.25
+        fused[hit] = np.minimum(fused[hit], np.round(rng.uniform(0.0, 0.25, int(hit.sum())), 2))    # appearance lowers some entries
+        want = jv(fused, 0.8)
+        x0, y0 = scipy_visible(fused, 0.8)
+        x, y, _ = lapx(fused, 0.8, x0, y0, nth=16, order=k & 1, force=True, base=base, shuffle=k)
+        assert np.array_equal(x, want[0]) and np.array_equal(y, want[1]), k
+
+
+def test_empty_and_degenerate_shapes(lapx):
+    for n, m in ((1, 1), (1, 5), (5, 1), (3, 3)):
+        c = np.ones((n, m))                                              # no feasible edge at all
+        x, y, info = lapx(c, 0.8, np.full(n, -1), np.full(m, -1), force=True)
+        assert (x == -1).all() and (y == -1).all() and not info["tied"]
+    c = np.zeros((4, 4))                                                 # everything free and equal
+    want = jv(c, 0.8)
+    x, y, info = lapx(c, 0.8, *scipy_visible(c, 0.8))
+    assert info["tied"] and np.array_equal(x, want[0]) and np.array_equal(y, want[1])
