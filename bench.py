@@ -26,6 +26,10 @@ Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
   id_match          the metric's "assignment ID match vs ref": a second tracker handle stepped on the frames of
                     the oracle sample, compared frame by frame (assignment pairs of the three stages, ordered
                     track ids / states, Kalman means)
+  facade            what a drop-in caller of BoTSORT.update() gets (D:2130-2185): steps/s of BoTSORT.update_arrays(export=True)
+                    -- (a) the call alone (lazy track lists), (b) plus reading tlbr + track_id of EVERY returned track like the
+                    reference's drawing loop, (c) with eager lists (round-2 behaviour) -- at this workload, and at c2 when
+                    the workload is the headline size
 """
 from __future__ import annotations
 
@@ -328,6 +332,48 @@ def export_legs(pkg, trk, frames, torch):
                     "per frame, read one ring turn late); sync: bts_tracker_export_mot (stream sync + copy) after every step"}
 
 
+def facade_leg(pkg, torch, wl, n_frames, seed):
+    """The BoTSORT facade's own rate on one GPU: update_arrays(export=True) fed with frames already resident in HBM.
+    lists_only: the call returns lazy TrackLists (one bts_tracker_export_lists per frame, no per-track Python);
+    read_all:   the caller then reads tlbr and track_id of every returned track (the reference's loop D:2135-2143);
+    eager:      lazy_lists=False -- every STrack mirror built per frame (what round 2 did unconditionally)."""
+    K, M, D = pkg.synth.workload_dims(wl)
+    st = pkg.synth.make_workload(wl, seed=seed)
+    warm = 4
+
+    def frames(n):
+        out = []
+        for _ in range(n):
+            fr = st.next()
+            out.append((torch.from_numpy(fr.boxes).cuda(), torch.from_numpy(fr.scores).cuda(), torch.from_numpy(fr.feats).cuda()))
+        return out
+
+    res = {"workload": wl, "frames_per_leg": n_frames}
+    for name, lazy, read in (("lists_only", True, False), ("read_all", True, True), ("eager", False, False)):
+        bot = pkg.BoTSORT(max_tracks=table_rows(K), max_dets=max(K, M), feat_dim=D, device=torch.cuda.current_device(), lazy_lists=lazy)
+        st = pkg.synth.make_workload(wl, seed=seed)
+        for fr in frames(warm):
+            bot.update_arrays(*fr)
+        fl = frames(n_frames if name != "eager" else max(8, n_frames // 4))
+        torch.cuda.synchronize()
+        acc = 0
+        t0 = time.perf_counter()
+        for fr in fl:
+            out = bot.update_arrays(*fr)
+            if read:
+                for t in out:
+                    acc += t.track_id + int(t.tlbr[0])
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        res[name + "_steps_per_s"] = len(fl) / dt
+        res[name + "_us_per_step"] = 1e6 * dt / len(fl)
+        res["mean_tracked"] = len(bot.tracked_stracks)
+        bot.device_tracker.close()
+    res["what"] = ("BoTSORT.update_arrays(export=True) on device-resident frames; lists_only = the call (lazy TrackLists), read_all = + tlbr and "
+                   "track_id of every returned track, eager = lazy_lists=False (every mirror built per frame)")
+    return res
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "RANK" not in os.environ:
@@ -445,6 +491,13 @@ def main():
         export = export_legs(pkg, trk, timed, torch)
         assert trk.counts()["errors"] == 0
 
+    facade = None
+    if rank == 0 and S == 1 and not a.no_export and not a.graph and not a.dense and not a.motion_gate:
+        nf = max(16, min(a.steps, 64))
+        facade = facade_leg(pkg, torch, a.workload, nf, ms_seed(pkg, 0))
+        if a.workload == "target":
+            facade = {"target": facade, "c2": facade_leg(pkg, torch, "c2", 4 * nf, ms_seed(pkg, 0))}
+
     big = K > 1024
     id_multi = None
     if world > 1 and not a.no_cpu and S == 1 and not a.dense:
@@ -506,8 +559,12 @@ def main():
                                      "checkpoint, pairs handed to the exact float32 refinement")
         out["lap"] = {"stage%d" % s: dict(zip(("edges", "components", "overflow", "hard_edges", "form"),
                                                (lambda h: (int(h[0]), int(h[1]), int(h[2]), int(h[6]), int(h[8])))(trk.debug_lap(s)))) for s in (1, 2, 3)}
+        out["lap"]["stage1_us"] = round(breakdown.get("k_lap", 0.0), 2)      # the stage-1 launch alone (hipEvent pair around it)
+        out["lap"]["stage23_group_us"] = round(breakdown.get("stage2", 0.0), 2)   # k_lap(stages 2 + 3) + tk_apply23
         if export is not None:
             out["export_inclusive"] = export
+        if facade is not None:
+            out["facade"] = facade
         if id_multi is not None:
             keys = ("frames", "frames_identical", "assignment_pairs", "assignment_pairs_equal", "track_ids", "track_ids_equal", "device_errors")
             out["id_match"] = {k: sum(r[k] for r in id_multi) for k in keys}

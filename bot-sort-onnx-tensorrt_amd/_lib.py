@@ -28,7 +28,7 @@ class TrackerConfig(ctypes.Structure):
         ("match_thresh", c_double), ("second_match_thresh", c_double), ("unconfirmed_match_thresh", c_double),
         ("proximity_thresh", c_double), ("appearance_thresh", c_double), ("dedupe_thresh", c_double),
         ("ema_alpha", c_double), ("record_costs", c_int32), ("appearance_mode", c_int32), ("use_graph", c_int32),
-        ("motion_gate", c_int32), ("max_edges", c_int32),
+        ("motion_gate", c_int32), ("max_edges", c_int32), ("tie_mode", c_int32),
     ]
 
 
@@ -52,6 +52,7 @@ SIGNATURES = {
     "bts_fuse_cost_stage1": (c_int, [_P, _P, c_int, _P, _P, c_int, c_int, c_int, c_double, c_double, _P, c_int, _P]),
     "bts_fuse_cost_stage3": (c_int, [_P, _P, c_int, _P, c_int, c_int, c_int, c_double, c_double, _P, c_int, _P]),
     "bts_lapjv": (c_int, [_P, _P, c_int, c_int, c_int, c_double, _P, _P, _P]),
+    "bts_lapjv_exact": (c_int, [_P, _P, c_int, c_int, c_int, c_double, _P, _P, c_int, _P, _P]),
     "bts_feature_ema": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_double, _P]),
     "bts_feature_renorm": (c_int, [_P, _P, _P, c_int, c_int, _P]),
     "bts_debug_i8_rows": (c_int, [_P, _P, c_int, c_int, c_double, _P, _P, _P]),

@@ -155,6 +155,23 @@ int bts_lap_enqueue(const bts_lap_problem *probs, int count, hipStream_t stream,
 // reset hdr before edges are appended
 int bts_lap_enqueue_reset(const bts_lap_work *w, hipStream_t stream);
 
+// ---- exact-tie mode (lap_exact.h, kernel k_lap_exact in lap.hip) -----------------------------------
+// Runs behind bts_lap_enqueue on the same problems: certificate that the fast solver's (x, y) is the only optimum, else the
+// dense JV of lap 0.4.0 replayed on the implicit extended matrix.  One descriptor per problem: scratch + cost source.
+struct bts_lap_exact {
+    double *dbl = nullptr; size_t ndbl = 0;        // scratch (bts_lap_exact_sizes)
+    int32_t *ints = nullptr; size_t nints = 0;
+    // cost source of a real (row, column) pair that is NOT a feasible edge: a dense matrix (standalone entry point) ...
+    const double *cost = nullptr; int ld = 0;
+    // ... or the boxes of the stage (the tracker: non-edges are IoU costs; the edge list overrides the fused entries)
+    const double *abox = nullptr; const uint8_t *af32 = nullptr; const double *bbox = nullptr; const int32_t *bidx = nullptr;
+    int force_replay = 0;                          // tests: replay even when the certificate holds
+};
+void bts_lap_exact_sizes(int n_cap, int m_cap, int64_t e_cap, size_t *ndbl, size_t *nints);
+int bts_lap_exact_enqueue(const bts_lap_problem *probs, const bts_lap_exact *xs, int count, hipStream_t stream);
+// lap hdr words the exact step reports in (bts_tracker_debug_lap): certificate verdict, replay ran, watchdog / sweep flags
+constexpr int BTS_LAP_H_TIED = 40, BTS_LAP_H_REPLAYED = 41, BTS_LAP_H_XERR = 42;
+
 // ---- cosine similarity (cosine.hip) ------------------------------------------------------------
 // sim[i*ld+j] = max(0, <A[a_idx[i]], B[b_idx[j]]>) ; a_idx/b_idx nullable (= identity); the live
 // sizes come from dims (device, nullable -> use n_max/m_max).

@@ -19,6 +19,8 @@
 // Everything is deterministic regardless of the order edges were appended in.
 #include "bts_internal.h"
 #include "block_scan.h"
+#include "iou_math.h"
+#include "lap_exact.h"
 
 namespace {
 
@@ -1013,6 +1015,63 @@ template <int EC> __global__ __launch_bounds__(1024) void k_lap(LapPair P) {
 #endif
 }
 
+// ---- exact-tie mode: one workgroup per problem behind k_lap (lap_exact.h holds the algorithm; the same source runs on the
+//      CPU under tests/host_emul) ----------------------------------------------------------------------------------------
+struct DevEx {                          // the executor: a phase = every thread between two workgroup barriers
+    __device__ __forceinline__ int nth() const { return (int)blockDim.x; }
+    template <class F> __device__ __forceinline__ void phase(F f) { __syncthreads(); f((int)threadIdx.x); __syncthreads(); }
+    __device__ __forceinline__ int atomic_add(int32_t *p, int v) { return atomicAdd(p, v); }
+    __device__ __forceinline__ int atomic_max(int32_t *p, int v) { return atomicMax(p, v); }
+};
+struct DenseSrc {                       // bts_lapjv_exact: the caller's matrix is the whole truth
+    static constexpr bool patched = false;
+    const double *c; int ld;
+    __device__ __forceinline__ double real(int i, int j) const { return c[(long)i * ld + j]; }
+};
+struct BoxSrc {                         // the tracker: a pair that is not a feasible edge costs its IoU distance (D:1554, D:1570, D:1602)
+    static constexpr bool patched = true;
+    const double *abox; const uint8_t *af32; const double *bbox; const int32_t *bidx;
+    __device__ __forceinline__ double real(int i, int j) const {
+        const double *a = abox + (long)i * 4, *b = bbox + (long)bidx[j] * 4;
+        const double aa[4] = {a[0], a[1], a[2], a[3]}, bb[4] = {b[0], b[1], b[2], b[3]};
+        const bool fa = af32 ? af32[i] != 0 : false;
+        return iou::cost(aa, fa, iou::area(aa, fa), bb, true, iou::area(bb, true));
+    }
+};
+struct ExactPair { LapArgs p[2]; bts_lap_exact x[2]; };
+
+__global__ __launch_bounds__(1024) void k_lap_exact(ExactPair P) {
+    const LapArgs &A = P.p[blockIdx.x];
+    const bts_lap_exact &X = P.x[blockIdx.x];
+    const bts_lap_work &w = A.w;
+    const int n = A.dims ? A.dims[0] : A.n_max, m = A.dims ? A.dims[1] : A.m_max;
+    int E = RLX(&w.hdr[H_EDGES]);
+    if (RLX(&w.hdr[H_ERR]) || (long)E > w.e_cap) return;                  // (an overflowed edge list is already an error of the frame)
+    lapx::Work W;
+    W.N = n; W.M = m; W.L = A.limit; W.e_row = w.e_row; W.e_col = w.e_col; W.e_cost = w.e_cost; W.E = E;
+    W.x = A.x; W.y = A.y;
+    W.max_steps = 8000000L;                                               // ~40x what a 10 000 x 2 000 replay needs
+    if (!lapx::work_carve(W, n, m, E, (int)blockDim.x, X.dbl, X.ndbl, X.ints, X.nints)) {
+        if (threadIdx.x == 0) { RST(&w.hdr[BTS_LAP_H_XERR], 8); RST(&w.hdr[H_ERR], 4); }
+        return;
+    }
+    DevEx ex;
+    lapx::build_csr(ex, W);
+    lapx::tie_check(ex, W);
+    const int tied = W.sh[lapx::S_TIED];
+    const bool replay = tied || X.force_replay;
+    if (replay) {
+        if (X.cost) { const DenseSrc S{X.cost, X.ld}; lapx::jv_replay(ex, W, S); }
+        else { const BoxSrc S{X.abox, X.af32, X.bbox, X.bidx}; lapx::jv_replay(ex, W, S); }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int err = W.sh[lapx::S_ERR];
+        RST(&w.hdr[BTS_LAP_H_TIED], tied); RST(&w.hdr[BTS_LAP_H_REPLAYED], replay ? 1 : 0); RST(&w.hdr[BTS_LAP_H_XERR], err);
+        if (err & lapx::ERR_STEPS) RST(&w.hdr[H_ERR], 4);                 // the replay gave up: the frame's assignment is not the reference's
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------- host
@@ -1083,6 +1142,21 @@ int bts_lap_enqueue(const bts_lap_problem *probs, int count, hipStream_t stream,
     return BTS_OK;
 }
 
+void bts_lap_exact_sizes(int n_cap, int m_cap, int64_t e_cap, size_t *ndbl, size_t *nints) {
+    n_cap = n_cap < 1 ? 1 : n_cap; m_cap = m_cap < 1 ? 1 : m_cap; e_cap = e_cap < 1 ? 1 : e_cap;
+    *ndbl = lapx::work_doubles(n_cap, m_cap, (long)e_cap, 1024);
+    *nints = lapx::work_ints(n_cap, m_cap, (long)e_cap, 1024);
+}
+
+int bts_lap_exact_enqueue(const bts_lap_problem *probs, const bts_lap_exact *xs, int count, hipStream_t stream) {
+    ExactPair P;
+    P.p[0] = probs[0]; P.p[1] = probs[count > 1 ? 1 : 0];
+    P.x[0] = xs[0]; P.x[1] = xs[count > 1 ? 1 : 0];
+    hipLaunchKernelGGL(k_lap_exact, dim3(count), dim3(1024), 0, stream, P);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+
 int bts_lap_enqueue_dense(const bts_lap_work *w, const double *cost, int ld, const int32_t *dims,
                           int n_max, int m_max, double cost_limit, int32_t *x, int32_t *y,
                           hipStream_t stream) {
@@ -1117,4 +1191,44 @@ extern "C" int bts_lapjv(bts_context *ctx, const double *cost, int n, int m, int
     bts_lap_work w;
     bts_lap_work_carve(&w, ctx->scratch.base, n, m, e_cap);
     return bts_lap_enqueue_dense(&w, cost, ld, nullptr, n, m, cost_limit, x, y, (hipStream_t)stream);
+}
+
+// lap.lapjv(cost, extend_cost=True, cost_limit=L) with the reference's behaviour on exact cost ties as well: the fast
+// solver, then the exact-tie step (lap_exact.h).  info3_host (nullable; synchronises when given): {certificate said "tied",
+// the dense JV was replayed, error flags}.
+extern "C" int bts_lapjv_exact(bts_context *ctx, const double *cost, int n, int m, int ld, double cost_limit,
+                               int32_t *x, int32_t *y, int force_replay, int32_t *info3_host, bts_stream stream) {
+    BTS_REQUIRE(ctx && n >= 0 && m >= 0, "ctx, n, m");
+    BTS_ON_DEVICE(ctx);
+    BTS_REQUIRE(cost_limit == cost_limit && cost_limit < 1e300 && cost_limit >= 0.0, "cost_limit must be finite and >= 0");
+    if (info3_host) { info3_host[0] = info3_host[1] = info3_host[2] = 0; }
+    if (n == 0 && m == 0) return BTS_OK;
+    BTS_REQUIRE((n == 0 || x) && (m == 0 || y), "null x / y");
+    BTS_REQUIRE(n == 0 || m == 0 || (cost && ld >= m), "null cost / ld < m");
+    const int64_t e_cap = (int64_t)n * m;
+    BTS_REQUIRE(e_cap < (1ll << 31) && (int64_t)(n + m) * (n + m) < (1ll << 31), "n*m and (n+m)^2 must fit int32");
+    const size_t lap_bytes = bts_align(bts_lap_work_bytes(n, m, e_cap));
+    size_t ndbl = 0, nints = 0;
+    bts_lap_exact_sizes(n, m, e_cap, &ndbl, &nints);
+    const size_t dbl_bytes = bts_align(ndbl * sizeof(double));
+    int rc = ctx->scratch.ensure(lap_bytes + dbl_bytes + nints * sizeof(int32_t));
+    if (rc) return rc;
+    bts_lap_work w;
+    bts_lap_work_carve(&w, ctx->scratch.base, n, m, e_cap);
+    rc = bts_lap_enqueue_dense(&w, cost, ld, nullptr, n, m, cost_limit, x, y, (hipStream_t)stream);
+    if (rc) return rc;
+    bts_lap_problem P{w, nullptr, n, m, cost_limit, x, y, 0};
+    bts_lap_exact X;
+    X.dbl = (double *)((char *)ctx->scratch.base + lap_bytes); X.ndbl = ndbl;
+    X.ints = (int32_t *)((char *)ctx->scratch.base + lap_bytes + dbl_bytes); X.nints = nints;
+    X.cost = cost; X.ld = ld; X.force_replay = force_replay ? 1 : 0;
+    rc = bts_lap_exact_enqueue(&P, &X, 1, (hipStream_t)stream);
+    if (rc) return rc;
+    if (info3_host) {
+        int32_t h[BTS_LAP_HDR_INTS];
+        BTS_HIP(hipMemcpyAsync(h, w.hdr, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream));
+        BTS_HIP(hipStreamSynchronize((hipStream_t)stream));
+        info3_host[0] = h[BTS_LAP_H_TIED]; info3_host[1] = h[BTS_LAP_H_REPLAYED]; info3_host[2] = h[BTS_LAP_H_XERR] | (h[2] ? 0x100 : 0);
+    }
+    return BTS_OK;
 }

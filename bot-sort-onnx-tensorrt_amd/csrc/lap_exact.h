@@ -15,7 +15,8 @@
 //   2. jv_replay (only when the certificate fails): the dense JV itself -- column reduction, reduction transfer, two sweeps
 //      of augmenting row reduction, shortest augmenting paths with lap's ready / scan / todo column lists -- executed phase
 //      by phase on the IMPLICIT extended matrix (real block from the cost source, padding L/2 and 0), with every scan
-//      order, strictness and swap of lap 0.4.0's lapjv.cpp reproduced (the oracle restates that code: oracle/lapjv_oracle.c).
+//      order, strictness and swap of lap 0.4.0's lapjv.cpp reproduced (the tests compare it with the CPU checker's restatement of
+//      that code).
 //      Data-parallel inside a scan, sequential across scans like the original; its column-list bookkeeping (the order of
 //      `cols[]` decides ties) is done in closed form per RUN of consecutive list insertions (a run of r insertions rotates
 //      the examined todo segment by r -- see apply_runs).
@@ -23,7 +24,7 @@
 // The code is written against an EXECUTOR: `ex.phase(f)` runs f(tid) for every thread of the workgroup between two
 // barriers; code outside phases is uniform (it only reads what earlier phases left in memory).  The device executor is
 // __syncthreads; tests/host_emul compiles this very file for the CPU with an executor that runs the threads of a phase one
-// after the other (in either order), and compares (x, y) with the oracle's dense JV bit for bit on tie families
+// after the other (in either order), and compares (x, y) with the CPU checker's dense JV bit for bit on tie families
 // (tests/test_lap_exact_host.py).  No thread keeps private state across phases, so the emulation is faithful.
 #pragma once
 #include <stdint.h>

@@ -1889,6 +1889,7 @@ struct bts_tracker {
     Dev dv;
     bts_lap_work lap;      // stages 1 and 2 (sequential)
     bts_lap_work lap3;     // stage 3 runs next to stage 2: its own work area
+    bts_lap_exact xk[2];   // tie_mode 1: scratch of the exact-tie step, [0] stages 1 and 2 (sequential), [1] stage 3
     char *block = nullptr;
     size_t bytes = 0;
     // export staging
@@ -1970,6 +1971,7 @@ int bts_tracker_default_config(bts_tracker_config *cfg) {
     cfg->ema_alpha = 0.9; cfg->record_costs = 0; cfg->appearance_mode = BTS_APPEARANCE_FILTER; cfg->use_graph = 0;
     cfg->motion_gate = 0;      // the reference's loop never gates on motion (A6): off keeps parity
     cfg->max_edges = 0;        // automatic
+    cfg->tie_mode = 0;         // the fast solver's optimum (= the reference's whenever it is unique)
     return BTS_OK;
 }
 
@@ -1988,6 +1990,19 @@ static int derive_sizes(const bts_tracker_config *cfg, Dev &d, int64_t *e_cap_ou
         BTS_REQUIRE((uint64_t)d.T * (uint64_t)d.D < lim && (uint64_t)d.Mx * (uint64_t)d.D < lim &&
                     (uint64_t)d.T * (uint64_t)d.Df < lim && (uint64_t)d.Mx * (uint64_t)d.Df < lim,
                     "max_tracks * feat_dim and max_dets * feat_dim must stay below 2^32 in the FILTER appearance mode");
+    }
+    BTS_REQUIRE(cfg->tie_mode == 0 || cfg->tie_mode == 1, "tie_mode");
+    if (cfg->tie_mode) {
+        // the replay prices a pair that is not a feasible edge at its IoU cost: true as long as every pair the appearance term
+        // lowers (<= appearance_thresh) IS an edge of its stage, and nothing else edits the matrix (the motion gate does)
+        BTS_REQUIRE(!cfg->motion_gate, "tie_mode 1 needs motion_gate 0");
+        // (with face features a pair whose FACE passes the gate keeps its BODY distance even above the match threshold,
+        //  D:1543-1554: a non-edge that is not an IoU cost -- not carried by the edge list yet)
+        BTS_REQUIRE(cfg->face_dim == 0, "tie_mode 1 needs face_dim 0");
+        BTS_REQUIRE(cfg->appearance_thresh <= cfg->match_thresh && cfg->appearance_thresh <= cfg->unconfirmed_match_thresh &&
+                    cfg->match_thresh >= 0.0 && cfg->second_match_thresh >= 0.0 && cfg->unconfirmed_match_thresh >= 0.0,
+                    "tie_mode 1 needs 0 <= appearance_thresh <= match_thresh, unconfirmed_match_thresh and second_match_thresh >= 0");
+        BTS_REQUIRE(((int64_t)d.T + d.Mx) * ((int64_t)d.T + d.Mx) < (1ll << 31), "tie_mode 1 needs (max_tracks + max_dets)^2 < 2^31");
     }
     const int64_t full = (int64_t)d.T * d.Mx, e_auto = 64ll * ((int64_t)d.T + d.Mx);
     const bool all_feasible = !(cfg->match_thresh < 1.0) || !(cfg->second_match_thresh < 1.0) || !(cfg->unconfirmed_match_thresh < 1.0);
@@ -2015,6 +2030,11 @@ int bts_tracker_memory_bytes(const bts_tracker_config *cfg, uint64_t *out_bytes)
     size_t off = 0;
     tracker_layout(t, nullptr, off);
     off += 2 * bts_lap_work_bytes(d.T, d.Mx, e_cap);
+    if (cfg->tie_mode) {
+        size_t nd = 0, ni = 0;
+        bts_lap_exact_sizes(d.T, d.Mx, e_cap, &nd, &ni);
+        off += 2 * (bts_align(nd * sizeof(double)) + bts_align(ni * sizeof(int32_t)));
+    }
     *out_bytes = (uint64_t)off;
     delete t;
     return BTS_OK;
@@ -2059,6 +2079,14 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
     off += bts_lap_work_bytes(d.T, d.Mx, e_cap);
     const size_t lap3_off = off;
     off += bts_lap_work_bytes(d.T, d.Mx, e_cap);
+    size_t xk_off[2][2] = {{0, 0}, {0, 0}}, xk_nd = 0, xk_ni = 0;
+    if (cfg->tie_mode) {
+        bts_lap_exact_sizes(d.T, d.Mx, e_cap, &xk_nd, &xk_ni);
+        for (int k = 0; k < 2; ++k) {
+            xk_off[k][0] = off; off += bts_align(xk_nd * sizeof(double));
+            xk_off[k][1] = off; off += bts_align(xk_ni * sizeof(int32_t));
+        }
+    }
     t->bytes = off;
     if (hipMalloc((void **)&t->block, t->bytes) != hipSuccess) {
         (void)hipGetLastError();
@@ -2070,6 +2098,10 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
     tracker_layout(t, t->block, off);
     bts_lap_work_carve(&t->lap, t->block + lap_off, d.T, d.Mx, e_cap);
     bts_lap_work_carve(&t->lap3, t->block + lap3_off, d.T, d.Mx, e_cap);
+    for (int k = 0; k < 2 && cfg->tie_mode; ++k) {
+        t->xk[k].dbl = (double *)(t->block + xk_off[k][0]); t->xk[k].ndbl = xk_nd;
+        t->xk[k].ints = (int32_t *)(t->block + xk_off[k][1]); t->xk[k].nints = xk_ni;
+    }
     if (hipHostMalloc((void **)&t->host_hdr, H_SIZE * sizeof(int32_t)) != hipSuccess) {
         (void)hipGetLastError();
         (void)hipFree(t->block);
@@ -2308,6 +2340,16 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
         if (rc) return rc;
         if (want) t->prof_n++;
     }
+    // tie_mode 1: certificate (+ dense-JV replay where it fails) behind every assignment.  Cost source of a pair that is
+    // not a feasible edge: the stage's boxes (rows: pool / stage-2 rows / unconfirmed, columns through the stage's index list)
+    bts_lap_exact xs[3] = {t->xk[0], t->xk[0], t->xk[1]};
+    if (t->cfg.tie_mode) {
+        xs[0].abox = d.pool_tlbr; xs[0].af32 = nullptr; xs[0].bbox = d.det_tlbr; xs[0].bidx = d.hi_idx;
+        xs[1].abox = d.r2_tlbr; xs[1].af32 = nullptr; xs[1].bbox = d.det_tlbr; xs[1].bidx = d.lo_idx;
+        xs[2].abox = d.unc_tlbr; xs[2].af32 = d.unc_f32; xs[2].bbox = d.det_tlbr; xs[2].bidx = d.left_det;
+        rc = bts_lap_exact_enqueue(&prob[0], &xs[0], 1, s);
+        if (rc) return rc;
+    }
     seg_end(BTS_SEG_LAP1);
     seg_begin(BTS_SEG_APPLY1);
     if (d.nch > 1) { LAUNCH(tk_mid1<true>, dim3(mid1_jobs(d.nch) + bts_cdiv(mc, 4)), dim3(1024)); }
@@ -2332,6 +2374,10 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
     seg_begin(BTS_SEG_STAGE2);
     rc = bts_lap_enqueue(&prob[1], 2, s, nullptr);
     if (rc) return rc;
+    if (t->cfg.tie_mode) {
+        rc = bts_lap_exact_enqueue(&prob[1], &xs[1], 2, s);
+        if (rc) return rc;
+    }
     seg_begin(BTS_SEG_K_APPLY23);
     LAUNCH(tk_apply23, dim3(2 * kf_blocks + 2 * mc), dim3(256), kf_blocks, mc);
     seg_end(BTS_SEG_K_APPLY23);

@@ -107,9 +107,17 @@ def fuse_cost_stage3(iou_d, body_sim, proximity_thresh=0.5, appearance_thresh=0.
     return out.cpu().numpy()
 
 
-def lapjv(cost, extend_cost=True, cost_limit=np.inf):
+# The reference's behaviour on EXACT cost ties (lap.lapjv's dense JV scan orders) through bts_lapjv_exact: certificate +
+# replay (csrc/lap_exact.h).  Off by default until the device path has been run on a GPU (round 3: access closed); the fast
+# solver is index-identical whenever the optimum is unique.
+EXACT_TIES = False
+last_tie_info = None       # (certificate said tied, replay ran, error flags) of the last lapjv(exact_ties=True)
+
+
+def lapjv(cost, extend_cost=True, cost_limit=np.inf, exact_ties=None, force_replay=False):
     """`lap.lapjv(cost, extend_cost=True, cost_limit=L)` as the reference calls it (D:1686):
-    returns (opt, x, y)."""
+    returns (opt, x, y).  `exact_ties` (default: module switch EXACT_TIES): also reproduce the reference on exact ties."""
+    global last_tie_info
     import torch
     if not extend_cost or not np.isfinite(cost_limit):
         raise NotImplementedError("only lapjv(extend_cost=True, cost_limit=<finite>) is provided")
@@ -119,8 +127,16 @@ def lapjv(cost, extend_cost=True, cost_limit=np.inf):
     dc = _dev(c, np.float64)
     x = torch.empty((max(n, 1),), dtype=torch.int32, device="cuda")
     y = torch.empty((max(m, 1),), dtype=torch.int32, device="cuda")
-    _lib.check(lib.bts_lapjv(_lib.default_context().handle, _lib.ptr(dc), n, m, m, float(cost_limit), _lib.ptr(x),
-                             _lib.ptr(y), _lib.current_stream()))
+    if EXACT_TIES if exact_ties is None else exact_ties:
+        info = np.zeros(3, dtype=np.int32)
+        _lib.check(lib.bts_lapjv_exact(_lib.default_context().handle, _lib.ptr(dc), n, m, m, float(cost_limit), _lib.ptr(x),
+                                       _lib.ptr(y), 1 if force_replay else 0, info.ctypes.data, _lib.current_stream()))
+        last_tie_info = tuple(int(v) for v in info)
+        if info[2]:
+            raise _lib.BtsError("bts_lapjv_exact: the exact-tie step reported error flags 0x%x" % int(info[2]))
+    else:
+        _lib.check(lib.bts_lapjv(_lib.default_context().handle, _lib.ptr(dc), n, m, m, float(cost_limit), _lib.ptr(x),
+                                 _lib.ptr(y), _lib.current_stream()))
     xs, ys = x[:n].cpu().numpy(), y[:m].cpu().numpy()
     rows = np.nonzero(xs >= 0)[0]
     opt = float(c[rows, xs[rows]].sum())

@@ -19,7 +19,9 @@ term of the fused cost is actually exercised at every D):
 Adversarial variants (bench.py --workload crowd | hard-reid, tests): `side_scale` shrinks the canvas (40 instead of
 125 px per sqrt(identity): boxes overlap 5-10 deep, the IoU graph gets large connected components); `clusters` draws
 the prototypes around that many shared centres with per-identity spreads so that impostor cosines of 0.5-0.8 are
-commonplace (what post-ReLU ReID embeddings look like), instead of the near-orthogonal i.i.d. prototypes.  `clusters` draws
+commonplace (what post-ReLU ReID embeddings look like), instead of the near-orthogonal i.i.d. prototypes; `dup_frac`
+(workload `dup-box`) turns a fraction of the detections into exact copies of another box with unrelated embeddings -- exact
+cost ties, the only situation in which the fast assignment solver may differ from lap.lapjv.  `clusters` draws
 its extra randomness from a generator of its own and the reduced canvas margin applies only when `side_scale != 125`, so the
 streams of the plain configurations are bit-identical to round 1's (tests/test_fixtures_regenerate.py regenerates the fixtures
 and compares).
@@ -54,7 +56,7 @@ class Frame:
 class SyntheticStream:
     def __init__(self, n_ids: int, n_dets: int, feat_dim: int, seed: int = 1234,
                  churn: float = 0.0, low_frac: float = 0.125, face_dim: int = 0,
-                 feat_noise: float = 0.3, side_scale: float = 125.0, clusters: int = 0):
+                 feat_noise: float = 0.3, side_scale: float = 125.0, clusters: int = 0, dup_frac: float = 0.0):
         self.rng = np.random.default_rng(seed)
         self.K0 = n_ids
         self.M = n_dets
@@ -66,6 +68,8 @@ class SyntheticStream:
         self.side_scale = float(side_scale)
         self.side = int(math.ceil(side_scale * math.sqrt(n_ids)))
         self.clusters = int(clusters)
+        self.dup_frac = float(dup_frac)
+        self._dr = np.random.default_rng([int(seed), 0xd0b1]) if dup_frac else None     # (never touches self.rng)
         self._xr = np.random.default_rng([int(seed), 0x5eed]) if clusters else None      # (never touches self.rng)
         self._centres = None
         self.cx = np.empty(0)
@@ -146,8 +150,30 @@ class SyntheticStream:
             scores[low_pos] = r.uniform(0.12, 0.38, len(low_pos))
         perm = r.permutation(len(ids))
         fr = self._observe(ids[perm], scores[perm])
+        if self.dup_frac:
+            self._duplicate(fr)
         self.t += 1
         return fr
+
+    def _duplicate(self, fr: "Frame"):
+        """The `dup-box` scene: a fraction of the frame's detections become EXACT copies of another detection's box, and both
+        copies get unrelated random embeddings (appearance gated to 1 for every track): the two columns of the cost matrix
+        are identical IoU costs -- exact ties, the case in which lap.lapjv's answer depends on its scan orders (DESIGN.md
+        section 4).  What a detector emits when NMS is off or class-wise (same box, two classes)."""
+        x = self._dr
+        m = len(fr.boxes)
+        k = min(int(round(self.dup_frac * m)), m // 2)
+        if k == 0:
+            return
+        hi = np.nonzero(fr.scores > 0.5)[0]
+        if len(hi) < 2 * k:
+            return
+        pick = x.choice(hi, size=2 * k, replace=False)
+        src, dst = pick[:k], pick[k:]
+        fr.boxes[dst] = fr.boxes[src]
+        both = np.concatenate([src, dst])
+        f = x.standard_normal((2 * k, self.D)).astype(np.float32)
+        fr.feats[both] = f / np.linalg.norm(f, axis=1, keepdims=True)
 
 
 def make_stream(config: str, seed: int = 1234, **kw) -> SyntheticStream:
@@ -161,6 +187,7 @@ ADVERSARIAL = {
     "crowd": dict(side_scale=40.0),          # boxes overlap 5-10 deep
     "hard-reid": dict(clusters=32),          # impostor cosines 0.5-0.8
     "crowd-hard-reid": dict(side_scale=40.0, clusters=32),
+    "dup-box": dict(dup_frac=0.05),           # 5 % of the detections are exact copies of another box: cost ties
 }
 
 
@@ -182,6 +209,8 @@ def workload_text(name: str) -> str:
         txt += ", dense crowd (canvas 40 px per sqrt(identity): boxes overlap 5-10 deep)"
     if adv == "hard-reid" or adv == "crowd-hard-reid":
         txt += ", clustered embeddings (32 centres, impostor cosines 0.5-0.8)"
+    if adv == "dup-box":
+        txt += ", 5 % of the detections exact copies of another box with unrelated embeddings (exact cost ties)"
     return txt
 
 

@@ -133,6 +133,14 @@ int bts_fuse_cost_stage3(bts_context *ctx, const double *iou_d, int ld_iou, cons
 int bts_lapjv(bts_context *ctx, const double *cost, int n, int m, int ld, double cost_limit,
               int32_t *x, int32_t *y, bts_stream stream);
 
+/* The same call with the reference's behaviour on EXACT COST TIES as well (where the optimum is not unique lap.lapjv's
+ * answer is an artefact of its dense Jonker-Volgenant scan orders on the (n+m)^2 extended matrix): bts_lapjv's solver, then
+ * a uniqueness certificate and -- only where it fails, or with force_replay != 0 -- lap 0.4.0's dense JV replayed on the
+ * implicit extended matrix (csrc/lap_exact.h).  cost_limit >= 0; (n+m)^2 < 2^31.
+ * info3_host (nullable; synchronises when given): {certificate said "tied", replay ran, error flags (0 = none)}. */
+int bts_lapjv_exact(bts_context *ctx, const double *cost, int n, int m, int ld, double cost_limit,
+                    int32_t *x, int32_t *y, int force_replay, int32_t *info3_host, bts_stream stream);
+
 /* STrack.update_body_features / update_face_features, D:492-514, for k (track,det) pairs
  * (trk_idx / det_idx nullable = identity; rows of length d, float32):
  * curr[trk] = det row; smooth[trk] = normalise(alpha*smooth + (1-alpha)*det), or normalise(det)
@@ -220,8 +228,16 @@ typedef struct bts_tracker_config {
                                    applied to the sparse edge list, the N x M distance matrix is never formed
                                    (record_costs shows the cost matrix before the gate) */
     int32_t max_edges;          /* capacity of the assignment solver's edge lists (pairs with cost <= the stage's match
-                                   threshold); 0 = automatic: min(max_tracks * max_dets, 64 * (max_tracks + max_dets)).
+                                   threshold); 0 = automatic: min(max_tracks * max_dets, 64 * (max_tracks + max_dets)), or
+                                   max_tracks * max_dets when a stage threshold is >= 1 (every pair feasible).
                                    Overflow raises the sticky error flag (BTS_ECAPACITY) */
+    int32_t tie_mode;           /* 0 (default): the fast solver's optimum -- equal to lap.lapjv's whenever the optimum is
+                                   unique, one of the optima on exact cost ties.
+                                   1: the reference's result on ties as well -- every assignment is followed by a
+                                   uniqueness certificate and, where it fails, by the dense Jonker-Volgenant code of
+                                   lap 0.4.0 replayed on the implicit (N+M)^2 extended matrix (csrc/lap_exact.h): two more
+                                   launches per frame, and a frame WITH ties costs what the dense algorithm costs.
+                                   Needs motion_gate 0, face_dim 0 and appearance_thresh <= match_thresh, unconfirmed_match_thresh */
 } bts_tracker_config;
 
 /* Fill cfg with the reference's hard-coded values (D:1268-1277). */

@@ -21,10 +21,13 @@
  * in an (n+m) x (n+m) matrix filled with cost_limit/2, whose lower-right m x n
  * block is 0; assignments into the padding are reported as -1.
  *
- * PARITY STATUS: "parity unpinned" for tie-breaking -- there is no lap binary or
- * golden vector in the reference to pin against.  What IS pinned (tests/
- * test_oracle_vs_golden.py, tests/test_lap_ties.py): optimal objective and, on tie-free inputs, the visible
- * matching, against scipy.optimize.linear_sum_assignment on the same extended matrix.
+ * PARITY STATUS: "parity unpinned" for tie-breaking -- there is no lap binary or golden vector in the reference to pin
+ * against; the phase structure, scan orders and strictness of every comparison below follow lap 0.4.0's lapjv.cpp
+ * (_ccrrt_dense, _carr_dense, _find_dense, _scan_dense, find_path_dense, _ca_dense) as published.  What IS pinned
+ * (tests/test_oracle_vs_golden.py): optimal objective and, on tie-free inputs, the visible matching, against
+ * scipy.optimize.linear_sum_assignment on the same extended matrix.  On exact ties this file is the DEFINITION the product's
+ * exact-tie mode is tested against, index for index (tests/test_lap_exact_host.py on the CPU, tests/test_gpu_ties.py on
+ * the GPU).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
  *

@@ -1,0 +1,32 @@
+#!/bin/bash
+# Round 3, second call (after gpu_r3_a.sh is green): the measurements.  Bench lines of every workload incl. the new ones,
+# rocprofv3 kernel stats at the headline size, A/B of the merged tall-noaccum kernels against the round-2 library (ab/head.so),
+# cost of tie_mode 1 on a tie-free stream and on the dup-box scene.
+O=gpurun_out/r3b; mkdir -p $O
+for w in target c2 c3 c5 crowd hard-reid dup-box@c2; do
+  extra="--no-cpu"; [ $w = target ] && extra=""
+  timeout 900 python bench.py --workload $w $extra > $O/bench_$w.json 2> $O/bench_$w.err; echo "$w rc=$? $(python -c "import json,sys; d=json.load(open('$O/bench_$w.json')); print(round(d['value']), 'steps/s', d['roofline']['kernel'], round(d['roofline']['avg_us'],1), 'us', 'facade' in d)" 2>/dev/null)"
+done
+cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof_target -- python bench.py --steps 100 --no-cpu --no-export > $O/prof_target.log 2>&1
+python scripts/prof_top.py $O/prof_target > $O/target_kernel_stats.csv 2>/dev/null; head -20 $O/target_kernel_stats.csv
+[ -f ab/head.so ] && for w in target c3; do echo "== A/B $w"; VARIANTS="head" WL=$w KERN=tk_ bash scripts/gpu_ab2.sh 2>&1 | tail -12; done
+timeout 600 python - > $O/tie_mode_cost.txt 2>&1 <<'PY'
+import importlib, time, numpy as np, torch
+pkg = importlib.import_module("bot-sort-onnx-tensorrt_amd")
+for wl, kw in (("c2", {}), ("dup-box@c2", {})):
+    K, M, D = pkg.synth.workload_dims(wl)
+    for mode in (0, 1):
+        st = pkg.synth.make_workload(wl, seed=5)
+        trk = pkg.DeviceTracker(max_tracks=K + 256, max_dets=max(K, M), feat_dim=D, tie_mode=mode)
+        fr = [st.next() for _ in range(120)]
+        dev = [(torch.from_numpy(f.boxes).cuda(), torch.from_numpy(f.scores).cuda(), torch.from_numpy(f.feats).cuda()) for f in fr]
+        for f in dev[:20]: trk.step(*f)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for f in dev[20:]: trk.step(*f)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        tied = sum(int(trk.debug_lap(s)[40]) for s in (1, 2, 3))
+        print("%-12s tie_mode %d: %.1f us/step (last frame: %d tied stages, errors %d)" % (wl, mode, 1e6 * dt / 100, tied, trk.counts()["errors"]))
+        trk.close()
+PY
+cat $O/tie_mode_cost.txt

@@ -18,6 +18,7 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 # kernels that are allowed a scratch frame, with the reason (bytes are upper bounds)
 SCRATCH_OK = {
     "tk_edges_tall_gate_c": 64,      # the 256-row gated tile keeps the 128-register cap and spills 12 B (52 vs 65 us uncapped)
+    "k_lap_exact": 64,               # the exact-tie step (tie_mode 1 only, one workgroup, off the default path): 12 B, its cost is the replay's
     "k_lap": 128,                    # k_lap<8> (16384 x 4096 only): 8 edges per thread in registers, 108 B of spills
 }
 

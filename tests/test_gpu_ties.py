@@ -1,0 +1,149 @@
+"""Exact cost ties on the GPU: INDEX vectors against the dense JV of the oracle (= lap.lapjv's behaviour, D:1682-1693).
+
+  * bts_lapjv_exact (fast solver + certificate + replay, csrc/lap_exact.h run as k_lap_exact) on the tie families of
+    tests/test_lap_exact_host.py -- the same source the CPU emulation checks, now on the device;
+  * the fast solver alone (bts_lapjv) on the same families: same OBJECTIVE always, same indices whenever the certificate
+    says the optimum is unique (the stated, measured deviation of tie_mode 0: profiles/r03_tie_survey.txt);
+  * the tracker with tie_mode = 1 on the `dup-box` scene (exact copies of detection boxes) frame by frame against the
+    oracle; the mismatch RATE of tie_mode = 0 on the same stream is measured and bounded."""
+import importlib
+
+import numpy as np
+import pytest
+
+from tests.test_lap_exact_host import jv, tie_families
+
+pytestmark = pytest.mark.gpu
+
+INT_KEYS = ("track_id", "state", "is_activated", "frame_id", "start_frame", "tracklet_len")
+
+
+@pytest.fixture(scope="module")
+def bts():
+    pkg = importlib.import_module("bot-sort-onnx-tensorrt_amd")
+    pkg._lib.load(require_gpu=True)
+    return pkg
+
+
+def objective(c, x, y, limit):
+    rows = np.nonzero(x >= 0)[0]
+    return float(c[rows, x[rows]].sum()) + limit / 2 * ((x < 0).sum() + (y < 0).sum())
+
+
+def test_lapjv_exact_equals_the_dense_jv_on_tie_families(bts):
+    rng = np.random.default_rng(0)
+    m = bts.matching
+    tied = replayed = fast_differs = 0
+    for k, (c, L) in enumerate(tie_families(rng, 1200)):
+        want = jv(c, L)
+        _, x, y = m.lapjv(c, cost_limit=L, exact_ties=True)
+        info = m.last_tie_info
+        assert np.array_equal(x, want[0]) and np.array_equal(y, want[1]), (k, c, x, want[0], info)
+        assert info[0] == info[1] and info[2] == 0
+        tied += info[0]
+        _, xf, yf = m.lapjv(c, cost_limit=L, exact_ties=False)
+        assert abs(objective(c, xf, yf, L) - objective(c, want[0], want[1], L)) < 1e-9, k
+        same = np.array_equal(xf, want[0]) and np.array_equal(yf, want[1])
+        if not info[0]:
+            assert same, (k, c)                      # certified unique: the fast solver IS the reference
+        fast_differs += not same
+        if k % 10 == 0:                              # the replay alone (certificate bypassed) is the dense JV too
+            _, x2, y2 = m.lapjv(c, cost_limit=L, exact_ties=True, force_replay=True)
+            assert np.array_equal(x2, want[0]) and np.array_equal(y2, want[1]) and m.last_tie_info[1] == 1, k
+            replayed += 1
+    assert tied > 300 and fast_differs > 100 and replayed == 120
+
+
+def test_lapjv_exact_on_tracker_shaped_problems(bts):
+    """Hundreds of rows, few feasible edges, planted duplicate columns / rows: the replay's long runs of list insertions."""
+    rng = np.random.default_rng(1)
+    m = bts.matching
+    for k in range(12):
+        n, mm = int(rng.integers(200, 700)), int(rng.integers(60, 260))
+        c = np.ones((n, mm))
+        rows = rng.permutation(n)[:min(n, mm)]
+        for j, i in enumerate(rows):
+            c[i, j % mm] = np.round(rng.uniform(0.05, 0.6), 2 if k % 2 else 6)
+        extra = int(1.5 * mm)
+        c[rng.integers(0, n, extra), rng.integers(0, mm, extra)] = np.round(rng.uniform(0.1, 0.79, extra), 1 if k % 3 == 0 else 6)
+        far = (c == 1.0) & (rng.random((n, mm)) < 0.03)
+        c[far] = rng.uniform(0.81, 0.99, int(far.sum()))
+        c[:, -1] = c[:, 0]
+        c[-1] = c[int(rows[1])]
+        want = jv(c, 0.8)
+        _, x, y = m.lapjv(c, cost_limit=0.8, exact_ties=True)
+        assert np.array_equal(x, want[0]) and np.array_equal(y, want[1]) and m.last_tie_info[0] == 1, k
+
+
+def _dev_frame(fr):
+    import torch
+    return (torch.from_numpy(fr.boxes.astype(np.int32)).cuda(), torch.from_numpy(fr.scores.astype(np.float32)).cuda(),
+            torch.from_numpy(fr.feats.copy()).cuda())
+
+
+@pytest.mark.parametrize("K,M,D,mode", [(64, 32, 64, 0), (256, 128, 128, 0), (256, 128, 128, 1), (900, 300, 128, 0)])
+def test_tracker_tie_mode_1_on_duplicated_boxes_vs_oracle(bts, K, M, D, mode):
+    """`dup-box`: 10 % of the detections are exact copies of another box with unrelated embeddings -- identical cost
+    columns.  tie_mode 1 must reproduce the oracle (dense JV on every stage) index for index, id for id; tie_mode 0 on the
+    same stream keeps the same objective per stage but may pick the other copy: its rate is measured here."""
+    from oracle import bts_oracle as bo
+    synth = bts.synth
+    st = synth.SyntheticStream(K, M, D, seed=77, churn=0.05, dup_frac=0.1)
+    ora = bo.TrackerOracle()
+    a = bts.DeviceTracker(max_tracks=4 * K + 64, max_dets=max(K, M), feat_dim=D, tie_mode=1, appearance_mode=mode)
+    b = bts.DeviceTracker(max_tracks=4 * K + 64, max_dets=max(K, M), feat_dim=D, tie_mode=0, appearance_mode=mode)
+    tied_stages = fast_stage_diffs = stages = 0
+    diverged = False
+    for f in range(14):
+        fr = st.next()
+        a.step(*_dev_frame(fr)); b.step(*_dev_frame(fr))
+        ora.update_arrays(fr.boxes, fr.scores.astype(np.float64), fr.feats.copy())
+        for k in (1, 2, 3):
+            r = a.stage_result(k)
+            assert np.array_equal(r["m"], ora.trace["m%d" % k]), (f, k)
+            assert np.array_equal(r["u_trk"], ora.trace["u_trk%d" % k]) and np.array_equal(r["u_det"], ora.trace["u_det%d" % k]), (f, k)
+            h = a.debug_lap(k)
+            assert h[42] == 0, (f, k, h[40:43])
+            tied_stages += int(h[40]); stages += 1
+            if not diverged:
+                rb = b.stage_result(k)
+                fast_stage_diffs += not np.array_equal(rb["m"], r["m"])
+        for which, lst in ((0, ora.tracked), (1, ora.lost)):
+            t, want = a.export(which), bo.TrackerOracle.table(lst)
+            for key in INT_KEYS:
+                assert np.array_equal(t[key], want[key]), (f, which, key)
+            if len(t["mean"]):
+                assert np.abs(t["mean"] - want["mean"]).max() <= 1e-6
+            tb = b.export(which)
+            diverged |= not all(np.array_equal(tb[key], want[key]) for key in INT_KEYS)
+        assert a.counts()["errors"] == 0 and a.counts()["last_id"] == ora._count
+    assert tied_stages >= 8, "the scene must produce ties"
+    print("dup-box %dx%d: %d / %d stages tied; fast solver differed on %d stages before its lists diverged (%s)"
+          % (K, M, tied_stages, stages, fast_stage_diffs, "diverged" if diverged else "never diverged"))
+    a.close(); b.close()
+
+
+def test_tie_mode_1_is_silent_on_tie_free_streams(bts):
+    """A plain stream has no exact ties: the certificate holds on every stage (no replay), results = tie_mode 0 = oracle."""
+    from oracle import bts_oracle as bo
+    st = bts.synth.SyntheticStream(512, 256, 256, seed=4321)
+    ora = bo.TrackerOracle()
+    a = bts.DeviceTracker(max_tracks=1200, max_dets=512, feat_dim=256, tie_mode=1)
+    for f in range(8):
+        fr = st.next()
+        a.step(*_dev_frame(fr))
+        ora.update_arrays(fr.boxes, fr.scores.astype(np.float64), fr.feats.copy())
+        for k in (1, 2, 3):
+            assert np.array_equal(a.stage_result(k)["m"], ora.trace["m%d" % k]), (f, k)
+            h = a.debug_lap(k)
+            assert h[40] == 0 and h[41] == 0 and h[42] == 0, (f, k, h[40:43])
+    a.close()
+
+
+def test_tie_mode_configuration_rules(bts):
+    with pytest.raises(bts.BtsError, match="motion_gate"):
+        bts.DeviceTracker(max_tracks=64, max_dets=32, feat_dim=64, tie_mode=1, motion_gate=1)
+    with pytest.raises(bts.BtsError, match="face_dim"):
+        bts.DeviceTracker(max_tracks=64, max_dets=32, feat_dim=64, face_dim=32, tie_mode=1)
+    with pytest.raises(bts.BtsError, match="appearance_thresh"):
+        bts.DeviceTracker(max_tracks=64, max_dets=32, feat_dim=64, tie_mode=1, appearance_thresh=0.9)
