@@ -657,6 +657,7 @@ class TrackerOracle:
         dists = self._gate_stage1(dists, pool, dets_hi)
         m1, u_trk, u_det = linear_assignment(dists, self.match_thresh)
         tr["cost1"] = dists
+        tr["iou1"] = iou_d
         tr["m1"] = np.asarray(m1, dtype=np.int64).reshape(-1, 2)
         tr["u_trk1"] = np.asarray(u_trk, dtype=np.int64)
         tr["u_det1"] = np.asarray(u_det, dtype=np.int64)
@@ -703,6 +704,7 @@ class TrackerOracle:
                                   self.proximity_thresh, self.appearance_thresh)
         m3, u_unc, u_det3 = linear_assignment(dists3, 0.7)
         tr["cost3"] = dists3
+        tr["iou3"] = iou3
         tr["m3"] = np.asarray(m3, dtype=np.int64).reshape(-1, 2)
         tr["u_trk3"] = np.asarray(u_unc, dtype=np.int64)
         tr["u_det3"] = np.asarray(u_det3, dtype=np.int64)

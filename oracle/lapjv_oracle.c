@@ -26,7 +26,7 @@
  * (_ccrrt_dense, _carr_dense, _find_dense, _scan_dense, find_path_dense, _ca_dense) as published.  What IS pinned
  * (tests/test_oracle_vs_golden.py): optimal objective and, on tie-free inputs, the visible matching, against
  * scipy.optimize.linear_sum_assignment on the same extended matrix.  On exact ties this file is the DEFINITION the product's
- * exact-tie mode is tested against, index for index (tests/test_lap_exact_host.py on the CPU, tests/test_gpu_ties.py on
+ * exact-tie mode is tested against, index for index (tests/test_lap_exact_host.py on the CPU, tests/test_zz_gpu_ties.py on
  * the GPU).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.

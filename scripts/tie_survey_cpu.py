@@ -8,7 +8,7 @@ compiled for the host (tests/host_emul) next to the oracle's dense JV (= lap.lap
   2. per synthetic workload: in how many association stages of a stream the certificate fires at all (plain streams: never;
      the dup-box scene: wherever a duplicated box is in play).
 Output kept as profiles/r03_tie_survey_cpu.txt.  The device-side twin (fast solver vs dense JV, indices) is
-scripts/tie_survey.py / tests/test_gpu_ties.py."""
+scripts/tie_survey.py / tests/test_zz_gpu_ties.py."""
 import importlib
 import os
 import sys

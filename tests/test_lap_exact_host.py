@@ -6,7 +6,7 @@ the oracle's dense JV (oracle/lapjv_oracle.c) on tie families: INDEX vectors, no
     order of the edge list;
   * certificate: whenever it says "unique", the assignment it was shown IS the dense JV's; it says "tied" on the tie families
     that fool the fast solver (so the replay runs there) and "unique" on tie-free float costs (so it does not run there).
-The same source runs on the device as k_lap_exact (tests/test_gpu_ties.py compares THAT with the oracle on the GPU)."""
+The same source runs on the device as k_lap_exact (tests/test_zz_gpu_ties.py compares THAT with the oracle on the GPU)."""
 import ctypes
 import os
 import subprocess
@@ -184,3 +184,36 @@ def test_empty_and_degenerate_shapes(lapx):
     want = jv(c, 0.8)
     x, y, info = lapx(c, 0.8, *scipy_visible(c, 0.8))
     assert info["tied"] and np.array_equal(x, want[0]) and np.array_equal(y, want[1])
+
+
+def test_box_cost_source_premise_on_tracker_streams(lapx):
+    """What tie_mode 1 assumes inside the tracker (k_lap_exact's BoxSrc): an entry of a stage's cost matrix that is NOT a feasible
+    edge (cost > the stage's match threshold) is exactly the pair's IoU cost -- the appearance term only ever lowers entries to
+    <= appearance_thresh, which makes them edges (D:1539-1554, D:1590-1602).  Checked on the oracle's own stage matrices of
+    plain / churn / dense-crowd / dup-box streams, and the replay through (IoU base + feasible edges) must equal the dense JV on
+    the full fused matrix.  (With face features the premise can fail -- a pair whose FACE passes the gate keeps its BODY distance
+    even above the threshold -- which is why bts_tracker_create refuses tie_mode 1 with face_dim > 0.)"""
+    import importlib
+    pkg = importlib.import_module("bot-sort-onnx-tensorrt_amd")
+    checked = tied = 0
+    for kw in (dict(churn=0.1), dict(side_scale=40.0), dict(dup_frac=0.1, churn=0.05), dict(dup_frac=0.05, side_scale=60.0)):
+        st = pkg.synth.SyntheticStream(96, 48, 64, seed=31, **kw)
+        ora = bo.TrackerOracle()
+        for f in range(10):
+            fr = st.next()
+            ora.update_arrays(fr.boxes, fr.scores.astype(np.float64), fr.feats.copy())
+            for k, L, base_key in ((1, 0.8, "iou1"), (2, 0.5, "cost2"), (3, 0.7, "iou3")):
+                c, base = ora.trace["cost%d" % k], ora.trace[base_key]
+                if c.size == 0:
+                    continue
+                c = np.ascontiguousarray(c, dtype=np.float64); base = np.ascontiguousarray(base, dtype=np.float64)
+                far = c > L
+                assert np.array_equal(c[far], base[far]), (kw, f, k)                 # the premise
+                assert (c <= base).all()                                              # edges only ever lower an entry
+                want = jv(c, L)
+                x0, y0 = scipy_visible(c, L)
+                x, y, info = lapx(c, L, x0, y0, nth=64, order=f & 1, base=base, shuffle=f)
+                assert np.array_equal(x, want[0]) and np.array_equal(y, want[1]), (kw, f, k)
+                assert np.array_equal(x, ora.trace["x%d" % k]) if ("x%d" % k) in ora.trace else True
+                checked += 1; tied += info["tied"]
+    assert checked > 80 and tied > 10

@@ -1,5 +1,8 @@
-"""Round-3 GPU parity tests: detection rows that do not arrive unit-norm through the int8 pre-filter, the
-one-call list export behind the BoTSORT facade, exact ties (see test_gpu_ties.py for the tie families)."""
+"""(File name: sorts AFTER the GPU suites that were green on hardware in rounds 1-2, so that under `pytest -x` a failure of
+code that has never met a GPU -- round 3 had no GPU access -- cannot hide their result.)
+
+Round-3 GPU parity tests: detection rows that do not arrive unit-norm through the int8 pre-filter, the
+one-call list export behind the BoTSORT facade, exact ties (see test_zz_gpu_ties.py for the tie families)."""
 import importlib
 
 import numpy as np

@@ -1,4 +1,6 @@
-"""Exact cost ties on the GPU: INDEX vectors against the dense JV of the oracle (= lap.lapjv's behaviour, D:1682-1693).
+"""(File name: sorts after the suites that were green on hardware in rounds 1-2 -- see tests/test_zz_gpu_round3.py.)
+
+Exact cost ties on the GPU: INDEX vectors against the dense JV of the oracle (= lap.lapjv's behaviour, D:1682-1693).
 
   * bts_lapjv_exact (fast solver + certificate + replay, csrc/lap_exact.h run as k_lap_exact) on the tie families of
     tests/test_lap_exact_host.py -- the same source the CPU emulation checks, now on the device;
