@@ -773,6 +773,7 @@ class BoTSORT:
         frame); `keep_removed_state=False` skips reading a removed track's covariance / feature rows off the device."""
         self.lazy_lists, self.keep_removed_state = bool(lazy_lists), bool(keep_removed_state)
         self._epoch, self._snap = 0, None
+        self._removed_live = set()      # ids appended to removed_stracks that are still on a list (Q6: for one more frame)
         self.tracked_stracks: List[STrack] = []
         self.lost_stracks: List[STrack] = []
         self.removed_stracks: List[STrack] = []
@@ -856,6 +857,25 @@ class BoTSORT:
                 self._finalise_vanished(prev, snap)
         self.tracked_stracks = TrackList(self, snap, 0)
         self.lost_stracks = TrackList(self, snap, 1)
+        # removed_stracks.extend(removed_stracks) of D:1635 happens in the frame that marks a track removed; an expired lost
+        # track stays on lost_stracks for that one frame (it is filtered against the PREVIOUS removals, Q6): it shows up here
+        # as a lost row in state Removed.  (Unconfirmed tracks that stage 3 left unmatched leave the lists at once: they were
+        # appended by _finalise_vanished above -- the reference appends them first too.)
+        lost_ints = snap.ints[1]
+        if len(lost_ints):
+            for k in np.nonzero(lost_ints[:, 1] == TrackState.Removed)[0].tolist():
+                tid = int(lost_ints[k, 0])
+                if tid not in self._removed_live:
+                    self._removed_live.add(tid)
+                    self.removed_stracks.append(self._mirror_at(snap, 1, k))
+        if self._removed_live:
+            # a removed track that is matched again before it is filtered out is tracked again (the reference's "zombie":
+            # the same object stays on removed_stracks, and may be appended once more when it is removed again)
+            for which in (0, 1):
+                ints = snap.ints[which]
+                if len(ints):
+                    back = ints[(ints[:, 1] != TrackState.Removed) & np.isin(ints[:, 0], list(self._removed_live)), 0]
+                    self._removed_live.difference_update(back.tolist())
         if bodies is not None:
             self._attach_bodies(snap, bodies)
         if not self.lazy_lists:
@@ -904,8 +924,9 @@ class BoTSORT:
             removed = dev_id[slot] == tid and dev_state[slot] == TrackState.Removed
             st = self._mirror.pop(tid, None)
             if st is None:
-                if not removed:
-                    continue                # never handed out and not removed: nobody can refer to it
+                if not removed or tid in self._removed_live:
+                    self._removed_live.discard(tid)
+                    continue                # never handed out and not (newly) removed: nobody can refer to it
                 st = STrack._new_mirror(self, tid)
             st._bind(prev, 0 if r < n0 else 1, r if r < n0 else r - n0)
             d = st.__dict__
@@ -917,7 +938,10 @@ class BoTSORT:
             d["_live"] = False
             if removed:
                 d["state"] = TrackState.Removed
-                self.removed_stracks.append(st)
+                if tid in self._removed_live:
+                    self._removed_live.discard(tid)       # (already appended in the frame that removed it)
+                else:
+                    self.removed_stracks.append(st)
 
     def _attach_bodies(self, snap, bodies):
         """update(image): the matched detection's Body goes onto its track and the track id onto the Body and its parts

@@ -92,6 +92,7 @@ def test_lazy_lists_mirror_the_oracle_and_build_nothing_until_touched(bot):
         out = b.update_arrays(fr.boxes, fr.scores, fr.feats)
         assert out is b.tracked_stracks and isinstance(out, trk.TrackList) and len(out) == len(ora.tracked)
         assert len(b.lost_stracks) == len(ora.lost)
+        assert [t.track_id for t in b.removed_stracks] == [t.track_id for t in ora.removed], f
         if f % 7 == 3:
             assert b._mirror.keys() <= touched, "mirrors were built although nobody touched the lists"
             continue                                  # a frame whose lists the caller never looks at
@@ -115,14 +116,17 @@ def test_lazy_lists_mirror_the_oracle_and_build_nothing_until_touched(bot):
                 where = b.tracked_stracks if now[0] in ora.tracked else b.lost_stracks
                 assert any(t is obj for t in where)
     assert len(ora.removed) > 0, "the stream must exercise removals"
-    # removed_stracks: every track that left both lists in state Removed, once, frozen with its last values and arrays
-    got = [t.track_id for t in b.removed_stracks]
-    assert len(got) == len(set(got)) and set(got) <= {t.track_id for t in ora.removed}
+    # removed_stracks = the reference's list (D:1635), entry for entry, in its order: appended in the frame that marks the track
+    # removed -- an expired lost track while it is still on lost_stracks (Q6) -- and frozen with its last values and arrays
+    # once it has left the lists
+    assert [t.track_id for t in b.removed_stracks] == [t.track_id for t in ora.removed]
     live = {t.track_id for t in ora.tracked + ora.lost}
-    assert set(got) == {t.track_id for t in ora.removed} - live
-    for t in b.removed_stracks:
-        assert t.state == pkg.TrackState.Removed and t.covariance is not None and t.covariance.shape == (8, 8)
-        assert t.body_curr_feature is not None and t.face_curr_feature is None
+    for t, ref in zip(b.removed_stracks, ora.removed):
+        assert t.state == ref.state
+        if t.track_id not in live:
+            assert t.state == pkg.TrackState.Removed and t.covariance is not None and t.covariance.shape == (8, 8)
+            assert t.body_curr_feature is not None and t.face_curr_feature is None
+            assert np.array_equal(t.mean, np.asarray(ref.mean, dtype=np.float64))
 
 
 def test_slices_negative_indices_and_list_helpers(bot):
@@ -171,3 +175,30 @@ def test_bodies_are_attached_and_ids_propagated(bot):
             assert t.body is bodies[t.det_index] and t.body.trackid == t.track_id and t.body.head.trackid == t.track_id
             hit += 1
     assert hit > 10
+
+
+def test_zombie_refound_after_removal_like_the_reference(bot):
+    """Quirk Q6: a lost track that expires is appended to removed_stracks but stays on lost_stracks for one more frame (the list
+    is filtered against the PREVIOUS removals); matched in that frame it is tracked again while still sitting on
+    removed_stracks.  The facade's lists must show exactly that (same object on both lists, state Tracked)."""
+    b = bot(frame_rate=3, max_tracks=64, max_dets=8, feat_dim=16)             # max_time_lost = 30 frames
+    ora = b.device_tracker.ora
+    rng = np.random.default_rng(0)
+    proto = rng.standard_normal((3, 16)).astype(np.float32)
+    proto /= np.linalg.norm(proto, axis=1, keepdims=True)
+    boxes = np.asarray([[100, 100, 150, 220], [400, 100, 460, 230], [700, 300, 760, 420]], dtype=np.int32)
+    zombie = None
+    for f in range(40):
+        vis = [0, 1, 2] if (f <= 2 or f >= 34) else [1, 2]                    # identity 0 hides for 31 frames, then returns
+        out = b.update_arrays(boxes[vis], np.full(len(vis), 0.95, np.float32), proto[vis].copy())
+        assert [t.track_id for t in out] == [t.track_id for t in ora.tracked]
+        assert [t.track_id for t in b.lost_stracks] == [t.track_id for t in ora.lost]
+        assert [t.track_id for t in b.removed_stracks] == [t.track_id for t in ora.removed], f
+        assert [t.state for t in b.removed_stracks] == [t.state for t in ora.removed], f
+        if f == 33:
+            assert len(ora.removed) == 1 and ora.removed[0] in ora.lost, "the stream must expire identity 0 at frame 33"
+            zombie = b.removed_stracks[0]
+            assert zombie.state == pkg.TrackState.Removed and any(t is zombie for t in b.lost_stracks)
+        if f == 34:
+            assert ora.removed[0] in ora.tracked, "... and re-find it at frame 34"
+            assert zombie.state == pkg.TrackState.Tracked and any(t is zombie for t in out) and b.removed_stracks[0] is zombie
