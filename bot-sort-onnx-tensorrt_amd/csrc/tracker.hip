@@ -1075,7 +1075,12 @@ __global__ __launch_bounds__(256) void k_filter_splitk(Dev d, int m_max, int nti
 // candidate test (the operand buffer it lands in is idle then).
 constexpr int FILTER_PW = 512;       // 2 resident workgroups per CU (64 KiB of operand stages each)
 enum { FS_STAGES = 0, FS_TILES, FS_EARLY, FS_CAND, FS_CHECKS };     // ([5..7]: clock cycles / 64 in candidate tests, stage waits, in total, summed over the workgroups)
-template <bool FACE, int VAR = 0>
+// KF_FIRST (opt-in, BTS_PREDICT_FIRST=1 at create; NOT yet measured): the Kalman-predict workgroups take the FRONT of the grid.
+// Every wave of this kernel is allocated its 244 VGPRs, so a predict workgroup cannot share a SIMD with two resident GEMM
+// workgroups: behind them (the default) the predict work runs when the persistent GEMM workgroups retire, i.e. it is added to
+// the kernel's tail; in front it overlaps the GEMM's start, and the GEMM workgroups that start late are the ones that own the
+// fewest tiles.  The default instantiation is unchanged code.
+template <bool FACE, int VAR = 0, bool KF_FIRST = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_filter_i8(Dev d, int m_max, int ntiles, int gemm_blocks) {
     __shared__ __attribute__((aligned(1024))) int8_t As2[DNS][FBM * DBK];
     __shared__ __attribute__((aligned(1024))) int8_t Bs2[DNS][FBN * DBK];
@@ -1083,11 +1088,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                                                  // images: a test never waits for the readers of the previous one)
     __shared__ __attribute__((aligned(16))) int s_cnt[2][4];     // survivors per wavefront
     __shared__ __attribute__((aligned(16))) float sred[2][8];    // {min uh, max alpha, max r, -} of the rows' records, per row wavefront
-    if ((int)blockIdx.x >= gemm_blocks) {
+    const int kf_front = KF_FIRST ? (int)gridDim.x - gemm_blocks : 0;      // predict workgroups in front of the GEMM ones
+    if (KF_FIRST ? (int)blockIdx.x < kf_front : (int)blockIdx.x >= gemm_blocks) {
 #ifdef BTS_FILTER_TRACE
         const int p_beg = (int)(((long long)__builtin_amdgcn_s_memrealtime()) & 0x3fffffff);
 #endif
-        if (!FACE) predict_body(d, (int)blockIdx.x - gemm_blocks);
+        if (!FACE) predict_body(d, KF_FIRST ? (int)blockIdx.x : (int)blockIdx.x - gemm_blocks);
 #ifdef BTS_FILTER_TRACE
         if (threadIdx.x == 0) { atomicMin(&d.fstat[12], p_beg); atomicMax(&d.fstat[13], (int)(((long long)__builtin_amdgcn_s_memrealtime()) & 0x3fffffff)); }
 #endif
@@ -1166,7 +1172,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int stop_thr = 6 + (3 * FBM * FBN) / (2 * (n > 0 ? n : 1));
     const float i8_s2 = feat::i8_scale(Dd) * feat::i8_scale(Dd) * 0.99999f;        // integer dot products per unit of dequantised dot product
     int bm, bn;
-    int vt = next_live((int)blockIdx.x, bm, bn);
+    int vt = next_live((int)blockIdx.x - kf_front, bm, bn);
     if (vt >= ntiles) return;
     int ia[4], ib[4], irec;
     fetch_idx(bm, bn, ia, ib, irec);
@@ -1889,6 +1895,7 @@ struct bts_tracker {
     Dev dv;
     bts_lap_work lap;      // stages 1 and 2 (sequential)
     bts_lap_work lap3;     // stage 3 runs next to stage 2: its own work area
+    bool predict_first = false;   // BTS_PREDICT_FIRST=1 at create: k_filter_i8<.., KF_FIRST> (experiment, see the kernel)
     bts_lap_exact xk[2];   // tie_mode 1: scratch of the exact-tie step, [0] stages 1 and 2 (sequential), [1] stage 3
     char *block = nullptr;
     size_t bytes = 0;
@@ -2072,6 +2079,7 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
         d.nch = d.nch < 1 ? 1 : d.nch > 8 ? 8 : d.nch;
     }
     d.use_grid = getenv("BTS_EDGES_GRID") != nullptr ? 1 : 0;
+    t->predict_first = getenv("BTS_PREDICT_FIRST") != nullptr;
     d.gate_sim = 1.0f - d.app;
     size_t off = 0;
     tracker_layout(t, nullptr, off);
@@ -2263,7 +2271,8 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
         // one-pass form (candidate bitmap, prefix exits): up to FILTER_PW persistent workgroups walk the tiles;
         // small problems add split-K partial products instead (k_filter_splitk)
         const int gemm_blocks = ftiles < FILTER_PW ? ftiles : FILTER_PW;
-        if (!accum) { LAUNCH(k_filter_i8<false>, dim3(gemm_blocks + kf_blocks), dim3(256), mc, ftiles, gemm_blocks); }
+        if (!accum && t->predict_first) { LAUNCH((k_filter_i8<false, 0, true>), dim3(gemm_blocks + kf_blocks), dim3(256), mc, ftiles, gemm_blocks); }
+        else if (!accum) { LAUNCH(k_filter_i8<false>, dim3(gemm_blocks + kf_blocks), dim3(256), mc, ftiles, gemm_blocks); }
         else { LAUNCH(k_filter_splitk<false>, dim3(ftiles * split + kf_blocks), dim3(256), mc, ftiles, split); }
         seg_end(BTS_SEG_K_FILTER);
         if (d.Df) {

@@ -11,6 +11,11 @@ cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof_target -- python bench.py --steps 100 --no-cpu --no-export > $O/prof_target.log 2>&1
 python scripts/prof_top.py $O/prof_target > $O/target_kernel_stats.csv 2>/dev/null; head -20 $O/target_kernel_stats.csv
 [ -f ab/head.so ] && for w in target c3; do echo "== A/B $w"; VARIANTS="head" WL=$w KERN=tk_ bash scripts/gpu_ab2.sh 2>&1 | tail -12; done
+for rep in 1 2; do for pf in 0 1; do
+  if [ $pf = 1 ]; then export BTS_PREDICT_FIRST=1; else unset BTS_PREDICT_FIRST; fi
+  timeout 600 python bench.py --no-cpu --no-export --steps 300 > $O/pf_${pf}_$rep.json 2>/dev/null
+  echo "predict_first=$pf rep $rep: $(python -c "import json; d=json.load(open('$O/pf_${pf}_$rep.json')); print(round(d['value']), 'steps/s, k_filter', round(d['segments_us']['k_filter'],1), 'us')" 2>/dev/null)"
+done; done; unset BTS_PREDICT_FIRST
 timeout 600 python - > $O/tie_mode_cost.txt 2>&1 <<'PY'
 import importlib, time, numpy as np, torch
 pkg = importlib.import_module("bot-sort-onnx-tensorrt_amd")

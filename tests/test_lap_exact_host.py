@@ -217,3 +217,47 @@ def test_box_cost_source_premise_on_tracker_streams(lapx):
                 assert np.array_equal(x, ora.trace["x%d" % k]) if ("x%d" % k) in ora.trace else True
                 checked += 1; tied += info["tied"]
     assert checked > 80 and tied > 10
+
+
+def test_near_ties_around_the_tolerance(lapx):
+    """Ties broken by tiny perturbations, from far below the certificate's tolerance (1e-9) to far above it: whatever the
+    verdict, the end result is the dense JV's -- below the tolerance the replay runs (and, being the same arithmetic, follows
+    the JV through its own rounding), above it the optimum is unique for every exact solver."""
+    rng = np.random.default_rng(5)
+    verdicts = {}
+    for eps in (0.0, 1e-15, 1e-12, 1e-10, 5e-10, 3e-9, 1e-8, 1e-7, 1e-5):
+        tied = 0
+        for k in range(150):
+            n, m = (int(v) for v in rng.integers(2, 9, 2))
+            c = rng.integers(1, 5, (n, m)) / 5.0
+            c = c + eps * rng.integers(-3, 4, (n, m))              # exact multiples of eps: ties of the grid survive or split
+            c = np.clip(c, 0.0, 1.0)
+            want = jv(c, 0.8)
+            x, y, info = lapx(c, 0.8, *scipy_visible(c, 0.8), nth=32, order=k & 1, shuffle=k)
+            assert np.array_equal(x, want[0]) and np.array_equal(y, want[1]), (eps, k, c)
+            tied += info["tied"]
+        verdicts[eps] = tied
+    assert verdicts[0.0] > 80 and verdicts[1e-12] > 80            # below the tolerance: still "tied"
+    assert verdicts[1e-5] < verdicts[0.0]                          # far above: mostly split
+
+
+def test_replay_on_a_mid_size_problem_with_long_list_runs(lapx):
+    """600 x 200 with duplicated columns and rows: thousands of list insertions per search, runs longer than the queue they
+    rotate (apply_runs with r > q), several emulated workgroup sizes."""
+    rng = np.random.default_rng(6)
+    n, m = 600, 200
+    c = np.ones((n, m))
+    rows = rng.permutation(n)[:m]
+    for j, i in enumerate(rows):
+        c[i, j] = np.round(rng.uniform(0.05, 0.6), 2)
+    extra = 2 * m
+    c[rng.integers(0, n, extra), rng.integers(0, m, extra)] = np.round(rng.uniform(0.1, 0.79, extra), 1)
+    far = (c == 1.0) & (rng.random((n, m)) < 0.02)
+    c[far] = rng.uniform(0.81, 0.99, int(far.sum()))
+    c[:, -3:] = c[:, :3]
+    c[-2:] = c[[int(rows[4]), int(rows[9])]]
+    want = jv(c, 0.8)
+    x0, y0 = scipy_visible(c, 0.8)
+    for nth, order in ((1024, 0), (100, 1)):
+        x, y, info = lapx(c, 0.8, x0, y0, nth=nth, order=order, shuffle=3)
+        assert info["tied"] and np.array_equal(x, want[0]) and np.array_equal(y, want[1]), (nth, order)
