@@ -131,9 +131,13 @@ template <class Ex> LAPX_HD void build_csr(Ex &ex, Work &W) {
     const int nth = ex.nth(), N = W.N, E = W.E;
     ex.phase([&](int t) { for (int i = t; i <= N + 1; i += nth) W.rp[i] = 0; });
     ex.phase([&](int t) { for (int e = t; e < E; e += nth) { const int i = W.e_row[e]; if (i >= 0) ex.atomic_add(&W.rp[i + 2], 1); } });
-    // rp[i + 2] holds deg(i): an exclusive scan shifted by one leaves rp[i + 1] = start of row i, used as the fill cursor
-    ex.phase([&](int t) { if (t == 0) { int run = 0; for (int i = 0; i < N; ++i) { const int c = W.rp[i + 2]; W.rp[i + 2] = run + c; W.rp[i + 1] = run; run += c; } W.rp[0] = 0; } });
-    ex.phase([&](int t) { for (int i = t; i < N; i += nth) W.rcur[i] = W.rp[i + 1]; });
+    // rp[i + 2] holds deg(i): an exclusive scan leaves rp[i + 1] = start of row i (two-level: a chunk of rows per thread --
+    // the certificate runs every frame in tie_mode 1, so no phase walks all rows on one thread)
+    ex.phase([&](int t) { int lo, hi, c = 0; chunk(N, nth, t, lo, hi); for (int i = lo; i < hi; ++i) c += W.rp[i + 2]; W.ri[t] = c; });
+    ex.phase([&](int t) { if (t == 0) { int run = 0; for (int q = 0; q < nth; ++q) { const int c = W.ri[q]; W.ri[q] = run; run += c; } W.sh[S_CNT] = run; } });
+    // starts go to rcur first (they double as the fill cursors): rp still holds the degrees other threads are reading
+    ex.phase([&](int t) { int lo, hi; chunk(N, nth, t, lo, hi); int run = W.ri[t]; for (int i = lo; i < hi; ++i) { W.rcur[i] = run; run += W.rp[i + 2]; } });
+    ex.phase([&](int t) { for (int i = t; i < N; i += nth) W.rp[i + 1] = W.rcur[i]; if (t == 0) { W.rp[0] = 0; W.rp[N + 1] = W.sh[S_CNT]; } });
     ex.phase([&](int t) {
         for (int e = t; e < E; e += nth) {
             const int i = W.e_row[e];
