@@ -75,24 +75,30 @@ struct Work {
     long max_steps;           // watchdog: phases a call may run before it gives up (sets S_ERR)
 };
 
-// bytes of scratch for a problem of the given capacities (host side sizing; 8-byte granules)
-LAPX_HD size_t work_doubles(int N, int M, long E, int nth) { return (size_t)E + 2 * (size_t)M + (size_t)N + 3 * (size_t)(N + M) + D_SIZE + 2 * (size_t)nth; }
-LAPX_HD size_t work_ints(int N, int M, long E, int nth) { return (size_t)(N + 2) + (size_t)(N + 1) + (size_t)E + 2 * (size_t)(N + 1) + 10 * (size_t)(N + M) + S_SIZE + 3 * (size_t)nth; }
+// elements of scratch for a problem of the given capacities (host side sizing).  `gap`: unused elements left behind every
+// array -- 0 in the product; the CPU emulation harness carves with gaps, poisons them (AddressSanitizer) and checks a
+// sentinel pattern in them after every call, so that an index running off the end of one scratch array cannot hide in its
+// neighbour.
+constexpr int N_DBL_ARRAYS = 10, N_INT_ARRAYS = 19;
+LAPX_HD size_t work_doubles(int N, int M, long E, int nth, int gap = 0) {
+    return (size_t)E + 2 * (size_t)M + (size_t)N + 3 * (size_t)(N + M) + D_SIZE + 2 * (size_t)nth + (size_t)gap * N_DBL_ARRAYS;
+}
+LAPX_HD size_t work_ints(int N, int M, long E, int nth, int gap = 0) {
+    return (size_t)(N + 2) + (size_t)(N + 1) + (size_t)E + 2 * (size_t)(N + 1) + 10 * (size_t)(N + M) + S_SIZE + 3 * (size_t)nth + (size_t)gap * N_INT_ARRAYS;
+}
 
-// carve a Work out of two blocks (doubles first); returns false if either block is too small
-LAPX_HD bool work_carve(Work &W, int N, int M, long E, int nth, double *dbl, size_t ndbl, int32_t *ints, size_t nints) {
-    if (ndbl < work_doubles(N, M, E, nth) || nints < work_ints(N, M, E, nth)) return false;
+// carve a Work out of two blocks; returns false if either block is too small
+LAPX_HD bool work_carve(Work &W, int N, int M, long E, int nth, double *dbl, size_t ndbl, int32_t *ints, size_t nints, int gap = 0) {
+    if (ndbl < work_doubles(N, M, E, nth, gap) || nints < work_ints(N, M, E, nth, gap)) return false;
     const size_t n = (size_t)N + M;
-    W.ce_cost = dbl; dbl += E;
-    W.p0 = dbl; dbl += M; W.p1 = dbl; dbl += M; W.cm = dbl; dbl += N;
-    W.v = dbl; dbl += n; W.d = dbl; dbl += n; W.w = dbl; dbl += n;
-    W.shd = dbl; dbl += D_SIZE; W.rv1 = dbl; dbl += nth; W.rv2 = dbl; dbl += nth;
-    W.rp = ints; ints += N + 2; W.rcur = ints; ints += N + 1; W.ce_col = ints; ints += E;
-    W.alive = ints; ints += N + 1; W.has = ints; ints += N + 1;
-    W.xx = ints; ints += n; W.yy = ints; ints += n; W.cols = ints; ints += n; W.pred = ints; ints += n; W.freer = ints; ints += n;
-    W.tmpa = ints; ints += n; W.tmpb = ints; ints += n; W.flag = ints; ints += n; W.runs = ints; ints += n; W.uniq = ints; ints += n;
-    W.sh = ints; ints += S_SIZE; W.rj1 = ints; ints += nth; W.rj2 = ints; ints += nth; W.ri = ints; ints += nth;
-    return true;
+    int nd = 0, ni = 0;
+    auto D = [&](double *&field, size_t count) { field = dbl; dbl += count + gap; ++nd; };
+    auto I = [&](int32_t *&field, size_t count) { field = ints; ints += count + gap; ++ni; };
+    D(W.ce_cost, E); D(W.p0, M); D(W.p1, M); D(W.cm, N); D(W.v, n); D(W.d, n); D(W.w, n); D(W.shd, D_SIZE); D(W.rv1, nth); D(W.rv2, nth);
+    I(W.rp, N + 2); I(W.rcur, N + 1); I(W.ce_col, E); I(W.alive, N + 1); I(W.has, N + 1);
+    I(W.xx, n); I(W.yy, n); I(W.cols, n); I(W.pred, n); I(W.freer, n); I(W.tmpa, n); I(W.tmpb, n); I(W.flag, n); I(W.runs, n); I(W.uniq, n);
+    I(W.sh, S_SIZE); I(W.rj1, nth); I(W.rj2, nth); I(W.ri, nth);
+    return nd == N_DBL_ARRAYS && ni == N_INT_ARRAYS;
 }
 
 // ---- small helpers -------------------------------------------------------------------------------------------------------

@@ -7,6 +7,10 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include <utility>
+#if defined(__SANITIZE_ADDRESS__)
+#include <sanitizer/asan_interface.h>
+#endif
 
 namespace {
 
@@ -54,9 +58,24 @@ extern "C" int lapx_host_exact(int N, int M, const double *cost, int ld, double 
     const long E = (long)er.size();
     lapx::Work W;
     memset(&W, 0, sizeof(W));
-    std::vector<double> dbl(lapx::work_doubles(N, M, E, nth));
-    std::vector<int32_t> ints(lapx::work_ints(N, M, E, nth));
-    if (!lapx::work_carve(W, N, M, E, nth, dbl.data(), dbl.size(), ints.data(), ints.size())) return -1;
+    // scratch carved WITH GAPS behind every array: sentinel pattern (checked after the call) + ASan poison when built with it
+    const int GAP = 6;
+    std::vector<double> dbl(lapx::work_doubles(N, M, E, nth, GAP), -777.25);
+    std::vector<int32_t> ints(lapx::work_ints(N, M, E, nth, GAP), (int32_t)0x5e471e1);
+    if (!lapx::work_carve(W, N, M, E, nth, dbl.data(), dbl.size(), ints.data(), ints.size(), GAP)) return -1;
+    std::vector<std::pair<void *, size_t>> gaps;
+    {
+        const size_t n = (size_t)N + M;
+        double *dp[] = {W.ce_cost, W.p0, W.p1, W.cm, W.v, W.d, W.w, W.shd, W.rv1, W.rv2};
+        const size_t dn[] = {(size_t)E, (size_t)M, (size_t)M, (size_t)N, n, n, n, (size_t)lapx::D_SIZE, (size_t)nth, (size_t)nth};
+        for (int k = 0; k < 10; ++k) gaps.push_back({dp[k] + dn[k], GAP * sizeof(double)});
+        int32_t *ip[] = {W.rp, W.rcur, W.ce_col, W.alive, W.has, W.xx, W.yy, W.cols, W.pred, W.freer, W.tmpa, W.tmpb, W.flag, W.runs, W.uniq, W.sh, W.rj1, W.rj2, W.ri};
+        const size_t in[] = {(size_t)N + 2, (size_t)N + 1, (size_t)E, (size_t)N + 1, (size_t)N + 1, n, n, n, n, n, n, n, n, n, n, (size_t)lapx::S_SIZE, (size_t)nth, (size_t)nth, (size_t)nth};
+        for (int k = 0; k < 19; ++k) gaps.push_back({ip[k] + in[k], GAP * sizeof(int32_t)});
+    }
+#if defined(__SANITIZE_ADDRESS__)
+    for (auto &g : gaps) __asan_poison_memory_region(g.first, g.second);
+#endif
     W.N = N; W.M = M; W.L = L; W.e_row = er.data(); W.e_col = ec.data(); W.e_cost = ev.data(); W.E = (int)E;
     W.x = x; W.y = y; W.max_steps = 50000000L;
     HostEx ex{nth, order};
@@ -70,5 +89,14 @@ extern "C" int lapx_host_exact(int N, int M, const double *cost, int ld, double 
         else { DenseSrc S{cost, ld}; lapx::jv_replay(ex, W, S); }
     }
     info[1] = W.sh[lapx::S_ERR];
+#if defined(__SANITIZE_ADDRESS__)
+    for (auto &g : gaps) __asan_unpoison_memory_region(g.first, g.second);
+#endif
+    for (auto &g : gaps) {           // nothing may have written behind the end of a scratch array
+        const unsigned char *b = (const unsigned char *)g.first;
+        const bool is_dbl = g.second == GAP * sizeof(double);
+        for (int k = 0; k < GAP; ++k)
+            if (is_dbl ? ((const double *)b)[k] != -777.25 : ((const int32_t *)b)[k] != (int32_t)0x5e471e1) return -2;
+    }
     return 0;
 }

@@ -261,3 +261,46 @@ def test_replay_on_a_mid_size_problem_with_long_list_runs(lapx):
     for nth, order in ((1024, 0), (100, 1)):
         x, y, info = lapx(c, 0.8, x0, y0, nth=nth, order=order, shuffle=3)
         assert info["tied"] and np.array_equal(x, want[0]) and np.array_equal(y, want[1]), (nth, order)
+
+
+def test_exact_tie_source_under_sanitizers():
+    """The same source under AddressSanitizer + UBSan in a child interpreter (gcc's runtime preloaded): the harness leaves a
+    poisoned gap behind every scratch array (and a sentinel pattern checked after each call), so an index running off the end
+    of ONE of the 29 scratch arrays -- which on the device would silently land in its neighbour -- is an error here."""
+    import sys
+    d = os.path.join(HERE, "host_emul")
+    subprocess.check_call(["make", "-C", d, "-s", "asan"])
+    rt = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(rt) or not os.path.exists(rt):
+        pytest.skip("no gcc ASan runtime")
+    code = r"""
+import ctypes, numpy as np
+from tests import test_lap_exact_host as t
+lib = ctypes.CDLL(%r)
+P = ctypes.c_void_p
+lib.lapx_host_exact.argtypes = [ctypes.c_int, ctypes.c_int, P, ctypes.c_int, ctypes.c_double, P, P, ctypes.c_int, ctypes.c_int, ctypes.c_int, P, ctypes.c_uint, P]
+def run(c, L, x, y, nth, order, force, shuffle):
+    c = np.ascontiguousarray(c, dtype=np.float64); n, m = c.shape
+    x = np.ascontiguousarray(x, dtype=np.int32).copy(); y = np.ascontiguousarray(y, dtype=np.int32).copy()
+    info = np.zeros(4, dtype=np.int32)
+    rc = lib.lapx_host_exact(n, m, c.ctypes.data, m, L, x.ctypes.data, y.ctypes.data, nth, order, int(force), None, shuffle, info.ctypes.data)
+    assert rc == 0 and info[1] == 0, (rc, info)
+    return x, y
+rng = np.random.default_rng(11)
+for k, (c, L) in enumerate(t.tie_families(rng, 700, max_dim=16)):
+    want = t.jv(c, L)
+    x, y = run(c, L, *t.scipy_visible(c, L), int(rng.choice([1, 3, 64, 1024])), k & 1, k %% 2 == 0, k %% 11)
+    assert np.array_equal(x, want[0]) and np.array_equal(y, want[1]), k
+for n, m in ((1, 1), (1, 7), (7, 1)):
+    for v in (0.1, 0.8, 1.0):
+        c = np.full((n, m), v)
+        want = t.jv(c, 0.8)
+        x, y = run(c, 0.8, *t.scipy_visible(c, 0.8), 64, 0, True, 1)
+        assert np.array_equal(x, want[0]) and np.array_equal(y, want[1])
+print("ok")
+""" % os.path.join(d, "liblapx_host_asan.so")
+    env = dict(os.environ, LD_PRELOAD=rt, PYTHONPATH=os.path.dirname(HERE),
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=23", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1:exitcode=24")
+    p = subprocess.run([sys.executable, "-c", code], env=env, cwd=os.path.dirname(HERE), capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "ok" in p.stdout, "rc=%d\n%s\n%s" % (p.returncode, p.stdout[-2000:], p.stderr[-6000:])
+    assert "ERROR: AddressSanitizer" not in p.stderr and "runtime error:" not in p.stderr, p.stderr[-6000:]
