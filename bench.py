@@ -492,7 +492,7 @@ def main():
         assert trk.counts()["errors"] == 0
 
     facade = None
-    if rank == 0 and S == 1 and not a.no_export and not a.graph and not a.dense and not a.motion_gate:
+    if rank == 0 and world == 1 and S == 1 and not a.no_export and not a.graph and not a.dense and not a.motion_gate:
         nf = max(16, min(a.steps, 64))
         facade = facade_leg(pkg, torch, a.workload, nf, ms_seed(pkg, 0))
         if a.workload == "target":
