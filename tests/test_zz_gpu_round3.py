@@ -70,7 +70,11 @@ def test_filter_mode_with_non_unit_detection_norms(bts, lo, hi):
             for key in INT_KEYS:
                 assert np.array_equal(ta[key], tb[key]) and np.array_equal(ta[key], want[key]), (f, which, key)
         assert a.counts() == b.counts() and a.counts()["errors"] == 0
-    assert min(matched[1:]) > K // 4          # about half of the raw similarities sit inside the gate, every frame
+    # about half of the raw similarities sit inside the gate; a track that misses once keeps its old feature and is out of
+    # the game (its cosine with the drifted identity is the product of two): the matches halve per frame -- what matters is
+    # that the tracks matched at frame 2+ took their shadows from NON-UNIT rows at frame 1+ (the oracle, run on the CPU
+    # beforehand: 515 / 276 / 132 / 73 matches for norms 0.8 .. 0.95)
+    assert matched[1] > K // 4 and matched[2] > K // 8 and matched[3] > K // 16
     a.close(); b.close()
 
 
