@@ -16,6 +16,12 @@ for rep in 1 2; do for pf in 0 1; do
   timeout 600 python bench.py --no-cpu --no-export --steps 300 > $O/pf_${pf}_$rep.json 2>/dev/null
   echo "predict_first=$pf rep $rep: $(python -c "import json; d=json.load(open('$O/pf_${pf}_$rep.json')); print(round(d['value']), 'steps/s, k_filter', round(d['segments_us']['k_filter'],1), 'us')" 2>/dev/null)"
 done; done; unset BTS_PREDICT_FIRST
+# where k_filter_i8's time goes (its own cycle accounting; ab/ftrace.so = scripts/build_variant.sh ftrace FTRACE=1)
+if [ -f ab/ftrace.so ]; then
+  BTS_LIB_PATH=$PWD/ab/ftrace.so timeout 300 python scripts/dbg_filtertrace.py target > $O/filter_trace.txt 2>&1
+  BTS_PREDICT_FIRST=1 BTS_LIB_PATH=$PWD/ab/ftrace.so timeout 300 python scripts/dbg_filtertrace.py target >> $O/filter_trace.txt 2>&1
+  cat $O/filter_trace.txt
+fi
 timeout 600 python - > $O/tie_mode_cost.txt 2>&1 <<'PY'
 import importlib, time, numpy as np, torch
 pkg = importlib.import_module("bot-sort-onnx-tensorrt_amd")

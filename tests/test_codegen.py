@@ -76,3 +76,13 @@ def test_contraction_is_mfma_fed_by_lds_dma(code_objects):
     assert len(re.findall(r"global_load_lds_dwordx4", asm)) >= 32         # operand stages: memory -> LDS, 16 B per lane
     assert len(re.findall(r"v_pk_(?:min|max)_i16", asm)) >= 64            # packed 16-bit box screening of the cost tiles
     assert "v_mfma_scale_f32_32x32x64_f8f6f4" not in asm                  # the fp8 form is gone (round 2)
+
+
+def test_every_header_is_a_make_dependency():
+    """A header missing from the Makefile's HDRS leaves a stale object behind after an edit (round 3: lap_exact.h -- the
+    library shipped an older k_lap_exact than the tests had checked on the CPU until this was noticed)."""
+    csrc = os.path.join(REPO, "bot-sort-onnx-tensorrt_amd", "csrc")
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    hdrs = re.search(r"^HDRS\s*=\s*(.*)$", mk, flags=re.M).group(1).split()
+    have = sorted(os.path.basename(p) for p in glob.glob(os.path.join(csrc, "*.h")))
+    assert sorted(h for h in hdrs if "/" not in h) == have, (hdrs, have)
