@@ -41,3 +41,6 @@ for wl, kw in (("c2", {}), ("dup-box@c2", {})):
         trk.close()
 PY
 cat $O/tie_mode_cost.txt
+# HBM traffic per launch (FETCH_SIZE / WRITE_SIZE, separate counter-only passes) -> profiles/pmc_traffic.json for roofline.traffic
+rm -f gpurun_out/final/pmc_traffic.txt; bash scripts/gpu_pmc_traffic.sh target c2 > $O/pmc.log 2>&1; cp gpurun_out/final/pmc_traffic.txt $O/pmc_traffic.txt 2>/dev/null
+python scripts/pmc_to_json.py $O/pmc_traffic.txt > $O/pmc_traffic.json 2>/dev/null; head -c 600 $O/pmc_traffic.json
