@@ -43,4 +43,4 @@ PY
 cat $O/tie_mode_cost.txt
 # HBM traffic per launch (FETCH_SIZE / WRITE_SIZE, separate counter-only passes) -> profiles/pmc_traffic.json for roofline.traffic
 rm -f gpurun_out/final/pmc_traffic.txt; bash scripts/gpu_pmc_traffic.sh target c2 > $O/pmc.log 2>&1; cp gpurun_out/final/pmc_traffic.txt $O/pmc_traffic.txt 2>/dev/null
-python scripts/pmc_to_json.py $O/pmc_traffic.txt > $O/pmc_traffic.json 2>/dev/null; head -c 600 $O/pmc_traffic.json
+python scripts/pmc_to_json.py $O/pmc_traffic.txt; cp profiles/pmc_traffic.json $O/pmc_traffic.json; head -c 600 $O/pmc_traffic.json
