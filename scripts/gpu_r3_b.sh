@@ -10,7 +10,9 @@ done
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof_target -- python bench.py --steps 100 --no-cpu --no-export > $O/prof_target.log 2>&1
 python scripts/prof_top.py $O/prof_target > $O/target_kernel_stats.csv 2>/dev/null; head -20 $O/target_kernel_stats.csv
-[ -f ab/head.so ] && for w in target c3; do echo "== A/B $w"; VARIANTS="head" WL=$w KERN=tk_ bash scripts/gpu_ab2.sh 2>&1 | tail -12; done
+# A/B against the library of the last commit that ran on hardware in round 2 (ab/r2_8cbc337.so, built from a worktree of 8cbc337;
+# ab/head.so = scripts/build_variant.sh head): the three changed kernels of the default step
+[ -f ab/r2_8cbc337.so ] && [ -f ab/head.so ] && for w in target c3; do echo "== A/B $w"; VARIANTS="r2_8cbc337 head" WL=$w KERN="tk_front|tk_edges_tall|tk_mid1|k_filter" bash scripts/gpu_ab2.sh 2>&1 | tail -24; done
 for rep in 1 2; do for pf in 0 1; do
   if [ $pf = 1 ]; then export BTS_PREDICT_FIRST=1; else unset BTS_PREDICT_FIRST; fi
   timeout 600 python bench.py --no-cpu --no-export --steps 300 > $O/pf_${pf}_$rep.json 2>/dev/null
