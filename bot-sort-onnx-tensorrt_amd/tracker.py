@@ -810,7 +810,10 @@ class BoTSORT:
         """boxes[M,4] integer tlbr pixels, scores[M], body_feats[M,D] float32 (L2-normalised),
         face_feats[M,Df] float32 or None; NumPy arrays or CUDA tensors.  NOTE: like the reference
         (quirk Q8) rows of the feature arrays of used detections are renormalised in place -- on
-        the device copy."""
+        the device copy.  `export=False` enqueues the frame and returns None (nothing is read back; the lists of this
+        object are not refreshed); `removed_stracks` is the reference's list entry for entry as long as every frame is
+        exported -- tracks that were removed during a run of un-exported frames are not recovered afterwards (their table
+        slots may have been recycled)."""
         import torch
 
         def dev(a, dtype):
