@@ -355,15 +355,19 @@ __device__ __forceinline__ void copy_shadow(const int8_t *src_q, const float *sr
 // one launch: the first workgroups build the frame's lists (two jobs of nch chunks each, the detection lists, the free slots),
 // the others convert the detection rows
 __host__ __device__ constexpr int front_jobs(int nch) { return 2 * nch + 2; }
-template <bool CH, bool GRID = false> __global__ __launch_bounds__(1024) void tk_front(Dev d) {
+// CVT = false (opt-in, BTS_CVT_OVERLAP=1 at create; NOT yet measured): the detection-row conversion is not part of this launch --
+// it runs as tk_cvt on a side stream, where frame t+1's rows (which depend on nothing the tracker computes) are converted
+// under frame t's latency-bound kernels (lever (c)).  The default instantiations are unchanged code.
+template <bool CH, bool GRID = false, bool CVT = true> __global__ __launch_bounds__(1024) void tk_front(Dev d) {
     TJ_BEGIN();
     const int b = blockIdx.x, nch = nchunks<CH>(d);
     if (b < nch) { prep_pool<CH>(d, b); if (b == 0) TJ_END(0, 0); }
     else if (b < 2 * nch) { prep_unconfirmed<CH>(d, b - nch); if (b == 2 * nch - 1) TJ_END(0, 1); }
     else if (b == 2 * nch) { prep_dets<GRID>(d); TJ_END(0, 2); }
     else if (b == 2 * nch + 1) { prep_free(d); TJ_END(0, 3); }
-    else { cvt_body(d, (long)b - front_jobs(nch)); if (b == front_jobs(nch)) TJ_END(0, 4); }
+    else if constexpr (CVT) { cvt_body(d, (long)b - front_jobs(nch)); if (b == front_jobs(nch)) TJ_END(0, 4); }
 }
+__global__ __launch_bounds__(1024) void tk_cvt(Dev d) { cvt_body(d, (long)blockIdx.x); }
 
 __device__ __forceinline__ void predict_body(const Dev &d, int bid) {
     const int g = bid * 256 + threadIdx.x;
@@ -1896,6 +1900,14 @@ struct bts_tracker {
     bts_lap_work lap;      // stages 1 and 2 (sequential)
     bts_lap_work lap3;     // stage 3 runs next to stage 2: its own work area
     bool predict_first = false;   // BTS_PREDICT_FIRST=1 at create: k_filter_i8<.., KF_FIRST> (experiment, see the kernel)
+    // BTS_CVT_OVERLAP=1 at create (experiment, see tk_front): second set of detection shadows (frames alternate), a side
+    // stream, "shadows of frame k are ready" / "frame k is done with its shadows" events per buffer
+    bool cvt_overlap = false;
+    int8_t *det_h2 = nullptr, *dface_h2 = nullptr;
+    float *det_m2 = nullptr, *dface_m2 = nullptr;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_cvt[2] = {}, ev_done[2] = {};
+    bool ev_done_used[2] = {};
     bts_lap_exact xk[2];   // tie_mode 1: scratch of the exact-tie step, [0] stages 1 and 2 (sequential), [1] stage 3
     char *block = nullptr;
     size_t bytes = 0;
@@ -1953,6 +1965,10 @@ static void tracker_layout(bts_tracker *t, char *base, size_t &off) {
     if (d.filter) {
         SLOT(d.body_h, int8_t, T * D); SLOT(d.det_h, int8_t, M * D); SLOT(d.body_m, float, T * feat::I8_META); SLOT(d.det_m, float, M * feat::I8_META);
         SLOT(d.face_h, int8_t, T * Df); SLOT(d.dface_h, int8_t, M * Df); SLOT(d.face_m, float, T * feat::I8_META); SLOT(d.dface_m, float, M * feat::I8_META);
+        if (t->cvt_overlap) {
+            SLOT(t->det_h2, int8_t, M * D); SLOT(t->det_m2, float, M * feat::I8_META);
+            SLOT(t->dface_h2, int8_t, M * Df); SLOT(t->dface_m2, float, M * feat::I8_META);
+        }
         SLOT(d.fstat, int32_t, 16);
         SLOT(d.grid_hdr, int32_t, 8); SLOT(d.cell_start, int32_t, GRID_CELLS + 1); SLOT(d.cell_items, int32_t, M);
         // split-K accumulators: only tables small enough to ever need split K (< 256 tiles of 128 x 128) carry them
@@ -2034,6 +2050,7 @@ int bts_tracker_memory_bytes(const bts_tracker_config *cfg, uint64_t *out_bytes)
     int64_t e_cap = 0;
     const int rc = derive_sizes(cfg, d, &e_cap);
     if (rc) { delete t; return rc; }
+    t->cvt_overlap = getenv("BTS_CVT_OVERLAP") != nullptr && d.filter && !cfg->use_graph;
     size_t off = 0;
     tracker_layout(t, nullptr, off);
     off += 2 * bts_lap_work_bytes(d.T, d.Mx, e_cap);
@@ -2080,6 +2097,7 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
     }
     d.use_grid = getenv("BTS_EDGES_GRID") != nullptr ? 1 : 0;
     t->predict_first = getenv("BTS_PREDICT_FIRST") != nullptr;
+    t->cvt_overlap = getenv("BTS_CVT_OVERLAP") != nullptr && d.filter && !cfg->use_graph;
     d.gate_sim = 1.0f - d.app;
     size_t off = 0;
     tracker_layout(t, nullptr, off);
@@ -2138,6 +2156,12 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
               hipHostMalloc((void **)&t->h_in, sizeof(InDesc) * bts_tracker::RING) == hipSuccess;
     for (int k = 0; ok && k < bts_tracker::RING; ++k) ok = hipEventCreateWithFlags(&t->in_ev[k], hipEventDisableTiming) == hipSuccess;
     ok = ok && hipStreamCreateWithFlags(&t->cs[0], hipStreamNonBlocking) == hipSuccess;
+    if (t->cvt_overlap) {
+        ok = ok && hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking) == hipSuccess;
+        for (int k = 0; ok && k < 2; ++k)
+            ok = hipEventCreateWithFlags(&t->ev_cvt[k], hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&t->ev_done[k], hipEventDisableTiming) == hipSuccess;
+    }
     if (!ok) { (void)hipGetLastError(); bts_set_error("stream / event / descriptor allocation failed"); bts_tracker_destroy(t); return BTS_EHIP; }
     t->dv.in = nullptr;
     bts_lap_init();
@@ -2201,6 +2225,8 @@ int bts_tracker_destroy(bts_tracker *t) {
     if (t->gexec) (void)hipGraphExecDestroy(t->gexec);
     for (int k = 0; k < bts_tracker::RING; ++k) if (t->in_ev[k]) (void)hipEventDestroy(t->in_ev[k]);
     if (t->cs[0]) (void)hipStreamDestroy(t->cs[0]);
+    if (t->side) { (void)hipStreamSynchronize(t->side); (void)hipStreamDestroy(t->side); }
+    for (int k = 0; k < 2; ++k) { if (t->ev_cvt[k]) (void)hipEventDestroy(t->ev_cvt[k]); if (t->ev_done[k]) (void)hipEventDestroy(t->ev_done[k]); }
     if (t->d_in) (void)hipFree(t->d_in);
     if (t->h_in) (void)hipHostFree(t->h_in);
     if (t->block) (void)hipFree(t->block);
@@ -2223,7 +2249,12 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
     const bool prof_room = !capturing && t->prof_cap > 0 && t->prof_n < t->prof_cap && t->step_no % t->prof_stride == 0;
     auto seg_begin = [&](int id) { if (prof_room && t->prof_seg == id) (void)hipEventRecord(t->prof_ev[2 * t->prof_n], s); };
     auto seg_end = [&](int id) { if (prof_room && t->prof_seg == id) { (void)hipEventRecord(t->prof_ev[2 * t->prof_n + 1], s); t->prof_n++; } };
-    const Dev &d = t->dv;
+    // BTS_CVT_OVERLAP: this frame's detection shadows live in buffer (step & 1), converted on the side stream
+    const bool ov = t->cvt_overlap && !capturing;
+    const int ovp = (int)(t->step_no & 1);
+    Dev dstep = t->dv;
+    if (ov && ovp) { dstep.det_h = t->det_h2; dstep.det_m = t->det_m2; dstep.dface_h = t->dface_h2; dstep.dface_m = t->dface_m2; }
+    const Dev &d = dstep;
     const int T = d.T, M = d.Mx;
     const int cos_kernel = t->ctx->cos_kernel;
     int ntile = bts_cdiv(mc, CT_COLS) * bts_cdiv(T, CT_ROWS);
@@ -2245,7 +2276,19 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
 
     seg_begin(BTS_SEG_STEP);
     seg_begin(BTS_SEG_PREP);
-    {
+    if (ov) {
+        // (the buffer's previous user is the frame before last; the frame's input arrays must be complete when
+        //  bts_tracker_step is called -- the side stream does not wait for work pending on the caller's stream)
+        if (t->ev_done_used[ovp]) BTS_HIP(hipStreamWaitEvent(t->side, t->ev_done[ovp], 0));
+        LAUNCH_ON(t->side, tk_cvt, dim3(bts_cdiv(mc, 4)), dim3(1024));
+        BTS_HIP(hipEventRecord(t->ev_cvt[ovp], t->side));
+        const dim3 fgrid(front_jobs(d.nch > 1 ? d.nch : 1));
+        if (d.use_grid) {
+            if (d.nch > 1) { LAUNCH((tk_front<true, true, false>), fgrid, dim3(1024)); } else { LAUNCH((tk_front<false, true, false>), fgrid, dim3(1024)); }
+        } else if (d.nch > 1) { LAUNCH((tk_front<true, false, false>), fgrid, dim3(1024)); }
+        else { LAUNCH((tk_front<false, false, false>), fgrid, dim3(1024)); }
+        BTS_HIP(hipStreamWaitEvent(s, t->ev_cvt[ovp], 0));
+    } else {
         const dim3 fgrid(front_jobs(d.nch > 1 ? d.nch : 1) + (d.filter ? bts_cdiv(mc, 4) : 0));
         if (d.use_grid && d.filter) {
             if (d.nch > 1) { LAUNCH((tk_front<true, true>), fgrid, dim3(1024)); } else { LAUNCH((tk_front<false, true>), fgrid, dim3(1024)); }
@@ -2415,6 +2458,7 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
     else { LAUNCH(tk_finalize<false>, dim3(2), dim3(1024)); }
     seg_end(BTS_SEG_DEDUPE);
     seg_end(BTS_SEG_STEP);
+    if (ov) { BTS_HIP(hipEventRecord(t->ev_done[ovp], s)); t->ev_done_used[ovp] = true; }
 #undef LAUNCH
 #undef LAUNCH_ON
     return BTS_OK;

@@ -13,11 +13,14 @@ python scripts/prof_top.py $O/prof_target > $O/target_kernel_stats.csv 2>/dev/nu
 # A/B against the library of the last commit that ran on hardware in round 2 (ab/r2_8cbc337.so, built from a worktree of 8cbc337;
 # ab/head.so = scripts/build_variant.sh head): the three changed kernels of the default step
 [ -f ab/r2_8cbc337.so ] && [ -f ab/head.so ] && for w in target c3; do echo "== A/B $w"; VARIANTS="r2_8cbc337 head" WL=$w KERN="tk_front|tk_edges_tall|tk_mid1|k_filter" bash scripts/gpu_ab2.sh 2>&1 | tail -24; done
-for rep in 1 2; do for pf in 0 1; do
-  if [ $pf = 1 ]; then export BTS_PREDICT_FIRST=1; else unset BTS_PREDICT_FIRST; fi
-  timeout 600 python bench.py --no-cpu --no-export --steps 300 > $O/pf_${pf}_$rep.json 2>/dev/null
-  echo "predict_first=$pf rep $rep: $(python -c "import json; d=json.load(open('$O/pf_${pf}_$rep.json')); print(round(d['value']), 'steps/s, k_filter', round(d['segments_us']['k_filter'],1), 'us')" 2>/dev/null)"
-done; done; unset BTS_PREDICT_FIRST
+# scheduling experiments (same library, env switches read at bts_tracker_create), interleaved, at the headline size and c3
+for w in target c3; do for rep in 1 2; do for exp in none BTS_PREDICT_FIRST BTS_CVT_OVERLAP both; do
+  unset BTS_PREDICT_FIRST BTS_CVT_OVERLAP
+  [ $exp = BTS_PREDICT_FIRST -o $exp = both ] && export BTS_PREDICT_FIRST=1
+  [ $exp = BTS_CVT_OVERLAP -o $exp = both ] && export BTS_CVT_OVERLAP=1
+  timeout 600 python bench.py --workload $w --no-cpu --no-export --steps 300 > $O/exp_${w}_${exp}_$rep.json 2>/dev/null
+  echo "$w $exp rep $rep: $(python -c "import json; d=json.load(open('$O/exp_${w}_${exp}_$rep.json')); s=d['segments_us']; print(round(d['value']), 'steps/s; prep', round(s['prep'],1), 'k_filter', round(s['k_filter'],1), 'us')" 2>/dev/null)"
+done; done; done; unset BTS_PREDICT_FIRST BTS_CVT_OVERLAP
 # where k_filter_i8's time goes (its own cycle accounting; ab/ftrace.so = scripts/build_variant.sh ftrace FTRACE=1)
 if [ -f ab/ftrace.so ]; then
   BTS_LIB_PATH=$PWD/ab/ftrace.so timeout 300 python scripts/dbg_filtertrace.py target > $O/filter_trace.txt 2>&1

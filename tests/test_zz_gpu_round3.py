@@ -141,3 +141,51 @@ def test_facade_lists_are_lazy_and_match_the_oracle(bts):
     for t in bot.removed_stracks:
         if t.track_id not in live:
             assert t.state == bts.TrackState.Removed and t.covariance.shape == (8, 8) and t.face_curr_feature is None
+
+
+def _frames_on_device(bts, K, M, D, n, **kw):
+    import torch
+    st = bts.synth.SyntheticStream(K, M, D, seed=99, **kw)
+    out = []
+    for _ in range(n):
+        fr = st.next()
+        out.append((torch.from_numpy(fr.boxes).cuda(), torch.from_numpy(fr.scores).cuda(), torch.from_numpy(fr.feats.copy()).cuda()))
+    torch.cuda.synchronize()
+    return out
+
+
+def _same_run(bts, frames_a, frames_b, mk_a, mk_b):
+    import torch
+    a, b = mk_a(), mk_b()
+    for f, (fa, fb) in enumerate(zip(frames_a, frames_b)):
+        a.step(*fa); b.step(*fb)
+        for k in (1, 2, 3):
+            ra, rb = a.stage_result(k), b.stage_result(k)
+            assert np.array_equal(ra["x"], rb["x"]) and np.array_equal(ra["y"], rb["y"]), (f, k)
+        for which in (0, 1):
+            ta, tb = a.export(which), b.export(which)
+            for key in INT_KEYS:
+                assert np.array_equal(ta[key], tb[key]), (f, which, key)
+            assert np.array_equal(ta["mean"], tb["mean"]), (f, which)
+        assert a.counts() == b.counts() and a.counts()["errors"] == 0
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("K,M,D", [(512, 256, 256), (4096, 1024, 256)])
+def test_opt_in_experiments_change_no_result(bts, monkeypatch, K, M, D):
+    """BTS_PREDICT_FIRST (predict workgroups in front of the pre-filter's persistent GEMM workgroups) and BTS_CVT_OVERLAP
+    (detection-row conversion of frame t+1 on a side stream under frame t) are scheduling experiments: every assignment,
+    list and Kalman mean must be bit-identical to the default schedule.  Frames are resident before the steps are
+    enqueued (the overlap mode's contract); each tracker gets its own copy of them (rows are renormalised in place)."""
+    n = 14
+    mk = lambda: bts.DeviceTracker(max_tracks=K + 256, max_dets=max(K, M), feat_dim=D)
+    for env in ("BTS_PREDICT_FIRST", "BTS_CVT_OVERLAP"):
+        fa, fb = _frames_on_device(bts, K, M, D, n, churn=0.05), _frames_on_device(bts, K, M, D, n, churn=0.05)
+
+        def mk_exp():
+            monkeypatch.setenv(env, "1")
+            try:
+                return mk()
+            finally:
+                monkeypatch.delenv(env)
+        _same_run(bts, fa, fb, mk, mk_exp)
