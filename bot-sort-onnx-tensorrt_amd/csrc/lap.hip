@@ -1132,7 +1132,11 @@ int bts_lap_enqueue(const bts_lap_problem *probs, int count, hipStream_t stream,
     P.p[0] = A; P.p[1] = B;
     if (ev) (void)hipEventRecord(ev[0], stream);
     // a component is one wavefront's job: big problems (hundreds of components) get more helper workgroups
-    const int helpers = (A.n_max >= 2048 || B.n_max >= 2048) ? LAP_HELPERS_BIG : LAP_HELPERS;
+    int helpers = (A.n_max >= 2048 || B.n_max >= 2048) ? LAP_HELPERS_BIG : LAP_HELPERS;
+    {   // BTS_LAP_HELPERS: sweep knob (host side only: the grid's second dimension), read once
+        static const int forced = [] { const char *e = getenv("BTS_LAP_HELPERS"); return e ? atoi(e) : -1; }();
+        if (forced >= 0 && forced <= 255) helpers = forced;
+    }
     // edges a thread keeps in registers across the preparation passes: 4 (lists up to 4096 edges are read once), or 8 for
     // problems wide enough to produce longer lists (the instantiation costs the short ones a few percent)
     if (A.m_max > 3072 || B.m_max > 3072) hipLaunchKernelGGL(k_lap<8>, dim3(count, 1 + helpers), dim3(1024), LAP_LDS_BYTES, stream, P);

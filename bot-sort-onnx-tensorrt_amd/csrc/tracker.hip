@@ -2313,7 +2313,10 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
         seg_begin(BTS_SEG_K_FILTER);
         // one-pass form (candidate bitmap, prefix exits): up to FILTER_PW persistent workgroups walk the tiles;
         // small problems add split-K partial products instead (k_filter_splitk)
-        const int gemm_blocks = ftiles < FILTER_PW ? ftiles : FILTER_PW;
+        // (BTS_FILTER_PW: sweep knob for the number of persistent GEMM workgroups, host side only)
+        static const int pw_forced = [] { const char *e = getenv("BTS_FILTER_PW"); return e ? atoi(e) : 0; }();
+        const int pw = pw_forced > 0 ? pw_forced : FILTER_PW;
+        const int gemm_blocks = ftiles < pw ? ftiles : pw;
         if (!accum && t->predict_first) { LAUNCH((k_filter_i8<false, 0, true>), dim3(gemm_blocks + kf_blocks), dim3(256), mc, ftiles, gemm_blocks); }
         else if (!accum) { LAUNCH(k_filter_i8<false>, dim3(gemm_blocks + kf_blocks), dim3(256), mc, ftiles, gemm_blocks); }
         else { LAUNCH(k_filter_splitk<false>, dim3(ftiles * split + kf_blocks), dim3(256), mc, ftiles, split); }

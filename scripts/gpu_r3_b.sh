@@ -49,3 +49,12 @@ cat $O/tie_mode_cost.txt
 # HBM traffic per launch (FETCH_SIZE / WRITE_SIZE, separate counter-only passes) -> profiles/pmc_traffic.json for roofline.traffic
 rm -f gpurun_out/final/pmc_traffic.txt; bash scripts/gpu_pmc_traffic.sh target c2 > $O/pmc.log 2>&1; cp gpurun_out/final/pmc_traffic.txt $O/pmc_traffic.txt 2>/dev/null
 python scripts/pmc_to_json.py $O/pmc_traffic.txt; cp profiles/pmc_traffic.json $O/pmc_traffic.json; head -c 600 $O/pmc_traffic.json
+# host-side sweep knobs (no rebuild): helper workgroups of k_lap, persistent workgroups of k_filter_i8
+for w in target crowd; do for h in 15 31 63 127; do
+  BTS_LAP_HELPERS=$h timeout 600 python bench.py --workload $w --no-cpu --no-export --steps 200 > $O/helpers_${w}_$h.json 2>/dev/null
+  echo "$w BTS_LAP_HELPERS=$h: $(python -c "import json; d=json.load(open('$O/helpers_${w}_$h.json')); print(round(d['value']), 'steps/s; k_lap stage 1', d['lap']['stage1_us'], 'us')" 2>/dev/null)"
+done; done
+for pw in 369 448 512 553; do
+  BTS_FILTER_PW=$pw timeout 600 python bench.py --no-cpu --no-export --steps 200 > $O/pw_$pw.json 2>/dev/null
+  echo "target BTS_FILTER_PW=$pw: $(python -c "import json; d=json.load(open('$O/pw_$pw.json')); print(round(d['value']), 'steps/s; k_filter', round(d['segments_us']['k_filter'],1), 'us')" 2>/dev/null)"
+done
