@@ -24,7 +24,7 @@
 
 namespace {
 
-enum { H_EDGES = 0, H_COMPS = 1, H_ERR = 2, H_HARD = 3, H_NA = 4, H_MA = 5, H_NH = 6, H_MODE = 8,
+enum { H_EDGES = 0, H_COMPS = 1, H_ERR = 2, H_HARD = 3, H_NA = 4, H_MA = 5, H_NH = 6, H_OVR = 7, H_MODE = 8,
        H_READY = 32 };   // the flag the helper workgroups poll sits in its own 128-byte line   // hdr: edges, components, overflow flag,
                                                                               // components for k_solve, active rows / columns
 
@@ -1046,12 +1046,15 @@ __global__ __launch_bounds__(1024) void k_lap_exact(ExactPair P) {
     const bts_lap_work &w = A.w;
     const int n = A.dims ? A.dims[0] : A.n_max, m = A.dims ? A.dims[1] : A.m_max;
     int E = RLX(&w.hdr[H_EDGES]);
+    const int O = RLX(&w.hdr[H_OVR]);                                     // overrides above the limit, filled from the top end downwards
     if (RLX(&w.hdr[H_ERR]) || (long)E > w.e_cap) return;                  // (an overflowed edge list is already an error of the frame)
+    if ((long)E + O > w.e_cap) { if (threadIdx.x == 0) { RST(&w.hdr[BTS_LAP_H_XERR], 16); RST(&w.hdr[H_ERR], 4); } return; }
     lapx::Work W;
     W.N = n; W.M = m; W.L = A.limit; W.e_row = w.e_row; W.e_col = w.e_col; W.e_cost = w.e_cost; W.E = E;
+    W.O = O; W.o_base = w.e_cap - O;
     W.x = A.x; W.y = A.y;
     W.max_steps = 8000000L;                                               // ~40x what a 10 000 x 2 000 replay needs
-    if (!lapx::work_carve(W, n, m, E, (int)blockDim.x, X.dbl, X.ndbl, X.ints, X.nints)) {
+    if (!lapx::work_carve(W, n, m, (long)E + O, (int)blockDim.x, X.dbl, X.ndbl, X.ints, X.nints)) {
         if (threadIdx.x == 0) { RST(&w.hdr[BTS_LAP_H_XERR], 8); RST(&w.hdr[H_ERR], 4); }
         return;
     }

@@ -53,10 +53,14 @@ enum { ERR_STEPS = 1, ERR_BF = 2 };
 struct Work {
     int N, M;                 // real rows / columns
     double L;                 // cost_limit
-    // feasible edges (cost <= L), unsorted; entries with row < 0 are vacant
+    // feasible edges (cost <= L), unsorted, at [0, E); entries with row < 0 are vacant.  OVERRIDES at [o_base, o_base + O) of the
+    // same arrays: entries of the cost matrix ABOVE L that are not what the cost source says (face features: a pair whose face
+    // passes the appearance gate keeps its body distance even above the match threshold, D:1543-1554).  They never take
+    // part in the certificate (nothing above L is a feasible edge); the replay reads them like edges.
     const int32_t *e_row, *e_col;
     const double *e_cost;
-    int E;
+    int E, O;
+    long o_base;
     int32_t *x, *y;           // visible assignment, in: the fast solver's, out: the reference's
     // scratch, sizes in []; n = N + M
     int32_t *rp;              // [N + 2] row CSR of the edges
@@ -134,9 +138,10 @@ template <class Ex, class Pred> LAPX_HD int compact(Ex &ex, Work &W, int len, in
 
 // ---- the row CSR of the feasible edges (both steps use it) ---------------------------------------------------------------
 template <class Ex> LAPX_HD void build_csr(Ex &ex, Work &W) {
-    const int nth = ex.nth(), N = W.N, E = W.E;
+    const int nth = ex.nth(), N = W.N, E = W.E, EO = W.E + W.O;
+    auto at = [&](int k) -> long { return k < E ? (long)k : W.o_base + (k - E); };      // list position k -> array index
     ex.phase([&](int t) { for (int i = t; i <= N + 1; i += nth) W.rp[i] = 0; });
-    ex.phase([&](int t) { for (int e = t; e < E; e += nth) { const int i = W.e_row[e]; if (i >= 0) ex.atomic_add(&W.rp[i + 2], 1); } });
+    ex.phase([&](int t) { for (int k = t; k < EO; k += nth) { const int i = W.e_row[at(k)]; if (i >= 0) ex.atomic_add(&W.rp[i + 2], 1); } });
     // rp[i + 2] holds deg(i): an exclusive scan leaves rp[i + 1] = start of row i (two-level: a chunk of rows per thread --
     // the certificate runs every frame in tie_mode 1, so no phase walks all rows on one thread)
     ex.phase([&](int t) { int lo, hi, c = 0; chunk(N, nth, t, lo, hi); for (int i = lo; i < hi; ++i) c += W.rp[i + 2]; W.ri[t] = c; });
@@ -145,14 +150,15 @@ template <class Ex> LAPX_HD void build_csr(Ex &ex, Work &W) {
     ex.phase([&](int t) { int lo, hi; chunk(N, nth, t, lo, hi); int run = W.ri[t]; for (int i = lo; i < hi; ++i) { W.rcur[i] = run; run += W.rp[i + 2]; } });
     ex.phase([&](int t) { for (int i = t; i < N; i += nth) W.rp[i + 1] = W.rcur[i]; if (t == 0) { W.rp[0] = 0; W.rp[N + 1] = W.sh[S_CNT]; } });
     ex.phase([&](int t) {
-        for (int e = t; e < E; e += nth) {
+        for (int k = t; k < EO; k += nth) {
+            const long e = at(k);
             const int i = W.e_row[e];
             if (i < 0) continue;
             const int pos = ex.atomic_add(&W.rcur[i], 1);
             W.ce_col[pos] = W.e_col[e]; W.ce_cost[pos] = W.e_cost[e];
         }
     });
-    // row i's edges: [rp[i + 1], rp[i + 2])   (order inside a row is arbitrary: nothing below depends on it)
+    // row i's entries (edges and overrides): [rp[i + 1], rp[i + 2])   (order inside a row is arbitrary: nothing below depends on it)
 }
 LAPX_HD int row_lo(const Work &W, int i) { return W.rp[i + 1]; }
 LAPX_HD int row_hi(const Work &W, int i) { return W.rp[i + 2]; }
@@ -198,7 +204,7 @@ template <class Ex> LAPX_HD void tie_check(Ex &ex, Work &W) {
                 double best = pa[js];
                 for (int e = row_lo(W, i); e < row_hi(W, i); ++e) {
                     const int j = W.ce_col[e];
-                    if (j == js) continue;
+                    if (j == js || W.ce_cost[e] > L) continue;         // (above L: an override, not a feasible edge)
                     const double cand = (W.ce_cost[e] - W.cm[i]) + pa[j];
                     if (cand < best) best = cand;
                 }
@@ -228,7 +234,7 @@ template <class Ex> LAPX_HD void tie_check(Ex &ex, Work &W) {
                 bool out = false;
                 for (int e = row_lo(W, i); e < row_hi(W, i); ++e) {
                     const int j = W.ce_col[e];
-                    if (j == js) continue;
+                    if (j == js || W.ce_cost[e] > L) continue;
                     if ((W.ce_cost[e] + p[j]) - ui > TIE_TOL) continue;           // not tight
                     const int owner = W.y[j];
                     const int dst = owner >= 0 ? owner : N;

@@ -446,7 +446,10 @@ __device__ __forceinline__ bool motion_gate_open(const Dev &d, long s, int det) 
 // loads -- dominates, the per-row screening is cheap).
 // ACC = false compiles the split-K form of the pre-filter out (the tall tiles: the column records it keeps in registers
 // across the row loop pushed them over their 128-register cap -- 12-20 B of scratch, ~2 us per launch)
-template <int STAGE, int MODE, int ROWS = CT_ROWS, bool GATE = false, bool ACC = true>
+// XO = true (tie_mode 1 with face features): entries that the appearance term lowered but that stay ABOVE the match threshold
+// (a pair whose face passes the gate keeps its body distance, D:1543-1554) are handed to the exact-tie step as OVERRIDES, at
+// the top end of the solver's edge arrays (filled downwards, counter lap hdr[7]); the fast solver never sees them.
+template <int STAGE, int MODE, int ROWS = CT_ROWS, bool GATE = false, bool ACC = true, bool XO = false>
 __device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, int bx, int by, int accum_rt) {
     const int accum = ACC ? accum_rt : 0;
     __shared__ double sa[ROWS][4];
@@ -649,6 +652,10 @@ __device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, 
             }
             if (MODE == 2 || d.record) cost[o] = c;
         }
+        if (XO && STAGE == 1 && live && c > limit && c < iou_d) {
+            const long idx = w.e_cap - 1 - (long)atomicAdd(&w.hdr[7], 1);
+            if (idx >= 0) { w.e_row[idx] = i0 + r; w.e_col[idx] = q; w.e_cost[idx] = c; }
+        }
         bool edge = live && c <= limit;
         if (GATE && STAGE == 1 && edge) edge = motion_gate_open(d, d.pool_slot[i0 + r], det);
         if (MODE != 2) emit(edge, i0 + r, c);
@@ -674,18 +681,23 @@ __device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, 
 
 // Persistent tiles: the live extents are only known on the device, so a fixed grid walks the
 // (column tile, row tile) space of the actual problem instead of launching capacity-sized grids.
-template <int STAGE, int MODE, int ROWS = CT_ROWS, bool GATE = false, bool ACC = true>
+template <int STAGE, int MODE, int ROWS = CT_ROWS, bool GATE = false, bool ACC = true, bool XO = false>
 __device__ __forceinline__ void edges_all(const Dev &d, const bts_lap_work &w, int bid, int nblk, int accum = 0) {
     const int32_t *h = d.hdr;
     const int n = STAGE == 1 ? h[H_NPOOL] : STAGE == 2 ? h[H_NR2] : h[H_NUNC];
     const int m = STAGE == 1 ? h[H_NHI] : STAGE == 2 ? h[H_NLO] : h[H_NLEFT];
     const int nct = (m + CT_COLS - 1) / CT_COLS, ntile = nct * ((n + ROWS - 1) / ROWS);
-    for (int t = bid; t < ntile; t += nblk) edges_tile<STAGE, MODE, ROWS, GATE, ACC>(d, w, t % nct, t / nct, accum);
+    for (int t = bid; t < ntile; t += nblk) edges_tile<STAGE, MODE, ROWS, GATE, ACC, XO>(d, w, t % nct, t / nct, accum);
 }
 
 template <int STAGE, int MODE, int ROWS = CT_ROWS, bool GATE = false>
 __global__ __launch_bounds__(CT_COLS) void tk_edges(Dev d, bts_lap_work w, int accum) {
     edges_all<STAGE, MODE, ROWS, GATE>(d, w, blockIdx.x, gridDim.x, accum);
+}
+// stage-1 tiles that also emit the above-threshold overrides (tie_mode 1 with face features; every tile height, uncapped)
+template <int MODE, int ROWS>
+__global__ __launch_bounds__(CT_COLS) void tk_edges_xo(Dev d, bts_lap_work w, int accum) {
+    edges_all<1, MODE, ROWS, false, true, true>(d, w, blockIdx.x, gridDim.x, accum);
 }
 // the tall stage-1 tiles of big problems are throughput-bound on their screening loop (59 % of the wave cycles waiting
 // at 3 wavefronts per SIMD): capped at 128 registers they run 4 per SIMD (no spills at 32 / 64 rows; the short tiles
@@ -2020,8 +2032,7 @@ static int derive_sizes(const bts_tracker_config *cfg, Dev &d, int64_t *e_cap_ou
         // lowers (<= appearance_thresh) IS an edge of its stage, and nothing else edits the matrix (the motion gate does)
         BTS_REQUIRE(!cfg->motion_gate, "tie_mode 1 needs motion_gate 0");
         // (with face features a pair whose FACE passes the gate keeps its BODY distance even above the match threshold,
-        //  D:1543-1554: a non-edge that is not an IoU cost -- not carried by the edge list yet)
-        BTS_REQUIRE(cfg->face_dim == 0, "tie_mode 1 needs face_dim 0");
+        //  D:1543-1554: a non-edge that is not an IoU cost -- the stage-1 tiles hand those to the replay as overrides, tk_edges_xo)
         BTS_REQUIRE(cfg->appearance_thresh <= cfg->match_thresh && cfg->appearance_thresh <= cfg->unconfirmed_match_thresh &&
                     cfg->match_thresh >= 0.0 && cfg->second_match_thresh >= 0.0 && cfg->unconfirmed_match_thresh >= 0.0,
                     "tie_mode 1 needs 0 <= appearance_thresh <= match_thresh, unconfirmed_match_thresh and second_match_thresh >= 0");
@@ -2345,8 +2356,23 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
     seg_begin(BTS_SEG_COST1);
     seg_begin(BTS_SEG_K_EDGES1);
     // (the grid only finds OVERLAPPING pairs: a match threshold >= 1 makes every pair feasible, which only the tile form emits)
-    const bool grid_form = d.use_grid && d.filter && !accum && !d.record && d.match1 < 1.0;
-    if (grid_form && d.motion_gate) {
+    const bool xo = t->cfg.tie_mode && d.Df > 0;       // (the grid form does not emit overrides)
+    const bool grid_form = d.use_grid && d.filter && !accum && !d.record && d.match1 < 1.0 && !xo;
+    if (xo && d.filter) {
+        switch (trows) {
+        case 2: LAUNCH((tk_edges_xo<1, 2>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
+        case 4: LAUNCH((tk_edges_xo<1, 4>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
+        case 8: LAUNCH((tk_edges_xo<1, 8>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
+        case 16: LAUNCH((tk_edges_xo<1, 16>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
+        case 32: LAUNCH((tk_edges_xo<1, 32>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
+        case 64: LAUNCH((tk_edges_xo<1, 64>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
+        case 128: LAUNCH((tk_edges_xo<1, 128>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
+        default: LAUNCH((tk_edges_xo<1, 256>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
+        }
+        if (d.record) { LAUNCH((tk_edges<1, 2>), tile_grid, dim3(CT_COLS), lap[0], 0); }
+    } else if (xo) {
+        LAUNCH((tk_edges_xo<0, CT_ROWS>), tile_grid, dim3(CT_COLS), lap[0], 0);
+    } else if (grid_form && d.motion_gate) {
         LAUNCH(tk_edges_grid<true>, dim3(bts_cdiv(T, 16)), dim3(64), lap[0]);
     } else if (d.filter && d.motion_gate) {
         switch (trows) {

@@ -237,7 +237,7 @@ typedef struct bts_tracker_config {
                                    uniqueness certificate and, where it fails, by the dense Jonker-Volgenant code of
                                    lap 0.4.0 replayed on the implicit (N+M)^2 extended matrix (csrc/lap_exact.h): two more
                                    launches per frame, and a frame WITH ties costs what the dense algorithm costs.
-                                   Needs motion_gate 0, face_dim 0 and appearance_thresh <= match_thresh, unconfirmed_match_thresh */
+                                   Needs motion_gate 0 and appearance_thresh <= match_thresh, unconfirmed_match_thresh */
 } bts_tracker_config;
 
 /* Fill cfg with the reference's hard-coded values (D:1268-1277). */

@@ -105,7 +105,8 @@ def test_tracker_memory_is_linear_in_the_capacities():
     assert f(4 * 1024 * 1024, 256, 2048, appearance_mode=1) > 0
     # tie_mode 1 (exact-tie step): its scratch is linear in T + M + edges, and its configuration rules are checked on the host
     assert 0 < f(10000, 2000, 2048, tie_mode=1) - f(10000, 2000, 2048) < 40e6
-    for bad in (dict(motion_gate=1), dict(face_dim=128), dict(appearance_thresh=0.9), dict(match_thresh=-0.1)):
+    assert f(1024, 512, 256, face_dim=128, tie_mode=1) > f(1024, 512, 256, face_dim=128)      # faces are carried too (overrides)
+    for bad in (dict(motion_gate=1), dict(appearance_thresh=0.9), dict(match_thresh=-0.1)):
         with pytest.raises(pkg.BtsError):
             f(1024, 512, 256, tie_mode=1, **bad)
     with pytest.raises(pkg.BtsError):

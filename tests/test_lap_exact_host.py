@@ -195,28 +195,35 @@ def test_box_cost_source_premise_on_tracker_streams(lapx):
     even above the threshold -- which is why bts_tracker_create refuses tie_mode 1 with face_dim > 0.)"""
     import importlib
     pkg = importlib.import_module("bot-sort-onnx-tensorrt_amd")
-    checked = tied = 0
-    for kw in (dict(churn=0.1), dict(side_scale=40.0), dict(dup_frac=0.1, churn=0.05), dict(dup_frac=0.05, side_scale=60.0)):
+    checked = tied = overrides = 0
+    for kw in (dict(churn=0.1), dict(side_scale=40.0), dict(dup_frac=0.1, churn=0.05), dict(dup_frac=0.05, side_scale=60.0),
+               dict(dup_frac=0.1, churn=0.05, face_dim=32), dict(face_dim=32, side_scale=60.0)):
         st = pkg.synth.SyntheticStream(96, 48, 64, seed=31, **kw)
         ora = bo.TrackerOracle()
         for f in range(10):
             fr = st.next()
-            ora.update_arrays(fr.boxes, fr.scores.astype(np.float64), fr.feats.copy())
+            ora.update_arrays(fr.boxes, fr.scores.astype(np.float64), fr.feats.copy(),
+                              None if fr.face_feats is None else fr.face_feats.copy())
             for k, L, base_key in ((1, 0.8, "iou1"), (2, 0.5, "cost2"), (3, 0.7, "iou3")):
                 c, base = ora.trace["cost%d" % k], ora.trace[base_key]
                 if c.size == 0:
                     continue
                 c = np.ascontiguousarray(c, dtype=np.float64); base = np.ascontiguousarray(base, dtype=np.float64)
                 far = c > L
-                assert np.array_equal(c[far], base[far]), (kw, f, k)                 # the premise
-                assert (c <= base).all()                                              # edges only ever lower an entry
+                if not kw.get("face_dim"):
+                    assert np.array_equal(c[far], base[far]), (kw, f, k)             # the premise (body features only)
+                else:
+                    # with faces a far entry may be a body distance below the IoU cost: those travel as overrides (stage 1 only)
+                    overrides += int((c[far] != base[far]).sum())
+                    assert k == 1 or np.array_equal(c[far], base[far]), (kw, f, k)
+                assert (c <= base).all()                                              # the appearance term only ever lowers an entry
                 want = jv(c, L)
                 x0, y0 = scipy_visible(c, L)
                 x, y, info = lapx(c, L, x0, y0, nth=64, order=f & 1, base=base, shuffle=f)
                 assert np.array_equal(x, want[0]) and np.array_equal(y, want[1]), (kw, f, k)
                 assert np.array_equal(x, ora.trace["x%d" % k]) if ("x%d" % k) in ora.trace else True
                 checked += 1; tied += info["tied"]
-    assert checked > 80 and tied > 10
+    assert checked > 120 and tied > 15 and overrides > 5, (checked, tied, overrides)
 
 
 def test_near_ties_around_the_tolerance(lapx):
@@ -304,3 +311,31 @@ print("ok")
     p = subprocess.run([sys.executable, "-c", code], env=env, cwd=os.path.dirname(HERE), capture_output=True, text=True, timeout=900)
     assert p.returncode == 0 and "ok" in p.stdout, "rc=%d\n%s\n%s" % (p.returncode, p.stdout[-2000:], p.stderr[-6000:])
     assert "ERROR: AddressSanitizer" not in p.stderr and "runtime error:" not in p.stderr, p.stderr[-6000:]
+
+
+def test_overrides_above_the_limit(lapx):
+    """Face features: a pair whose FACE passes the appearance gate keeps its BODY distance in the cost matrix even when that
+    is above the match threshold (D:1543-1554) -- a non-edge that is not the IoU cost.  The device hands such entries to the
+    exact-tie step as OVERRIDES (top end of the edge arrays); the replay through (IoU base + edges + overrides) must equal the
+    dense JV on the full matrix, and the certificate must ignore them (nothing above the limit is a feasible edge)."""
+    rng = np.random.default_rng(8)
+    n_over = tied = 0
+    for k in range(400):
+        n, m = (int(v) for v in rng.integers(1, 12, 2))
+        base = np.round(rng.uniform(0.3, 1.0, (n, m)), 1)               # "IoU costs" with ties
+        fused = base.copy()
+        hit = rng.random((n, m)) < 0.2
+        fused[hit] = np.minimum(fused[hit], np.round(rng.uniform(0.0, 0.25, int(hit.sum())), 2))       # appearance edges
+        face = (rng.random((n, m)) < 0.15) & (base > 0.85)
+        fused[face] = np.round(rng.uniform(0.81, 0.84, int(face.sum())), 2)                              # body distance kept, above the limit
+        n_over += int(((fused > 0.8) & (fused != base)).sum())
+        want = jv(fused, 0.8)
+        x0, y0 = scipy_visible(fused, 0.8)
+        x, y, info = lapx(fused, 0.8, x0, y0, nth=16, order=k & 1, force=k % 2 == 0, base=base, shuffle=k)
+        assert np.array_equal(x, want[0]) and np.array_equal(y, want[1]), (k, info)
+        assert (info["edges"] >> 16) == int(((fused > 0.8) & (fused != base)).sum())
+        # the verdict is the one the full matrix gives without any notion of overrides
+        _, _, info2 = lapx(fused, 0.8, x0, y0, nth=16)
+        assert info2["tied"] == info["tied"], k
+        tied += info["tied"]
+    assert n_over > 300 and tied > 50

@@ -148,7 +148,44 @@ def test_tie_mode_1_is_silent_on_tie_free_streams(bts):
 def test_tie_mode_configuration_rules(bts):
     with pytest.raises(bts.BtsError, match="motion_gate"):
         bts.DeviceTracker(max_tracks=64, max_dets=32, feat_dim=64, tie_mode=1, motion_gate=1)
-    with pytest.raises(bts.BtsError, match="face_dim"):
-        bts.DeviceTracker(max_tracks=64, max_dets=32, feat_dim=64, face_dim=32, tie_mode=1)
     with pytest.raises(bts.BtsError, match="appearance_thresh"):
         bts.DeviceTracker(max_tracks=64, max_dets=32, feat_dim=64, tie_mode=1, appearance_thresh=0.9)
+
+
+@pytest.mark.parametrize("K,M,mode", [(96, 48, 0), (96, 48, 1), (400, 160, 0)])
+def test_tracker_tie_mode_1_with_face_features_vs_oracle(bts, K, M, mode):
+    """Face features on the dup-box scene: a duplicate keeps its identity's FACE while its body embedding is unrelated, so its
+    pair with that identity's track passes the gate through the face and keeps the BODY distance (~0.98, above the match
+    threshold, below the IoU cost 1.0 of the disjoint boxes) -- an entry of the cost matrix that is neither a feasible edge nor
+    an IoU cost.  The stage-1 tiles hand such entries to the exact-tie step as overrides (tk_edges_xo); with them the replay
+    must reproduce the oracle's dense JV, FILTER and DENSE appearance modes alike."""
+    import torch
+    from oracle import bts_oracle as bo
+    D, F = 64, 32
+    st = bts.synth.SyntheticStream(K, M, D, seed=31, churn=0.05, dup_frac=0.1, face_dim=F)
+    ora = bo.TrackerOracle()
+    a = bts.DeviceTracker(max_tracks=4 * K + 64, max_dets=max(K, M), feat_dim=D, face_dim=F, tie_mode=1, appearance_mode=mode)
+    tied = overrides = 0
+    for f in range(12):
+        fr = st.next()
+        a.step(torch.from_numpy(fr.boxes.astype(np.int32)).cuda(), torch.from_numpy(fr.scores.astype(np.float32)).cuda(),
+               torch.from_numpy(fr.feats.copy()).cuda(), torch.from_numpy(fr.face_feats.copy()).cuda())
+        ora.update_arrays(fr.boxes, fr.scores.astype(np.float64), fr.feats.copy(), fr.face_feats.copy())
+        for k in (1, 2, 3):
+            r = a.stage_result(k)
+            assert np.array_equal(r["m"], ora.trace["m%d" % k]), (f, k)
+            h = a.debug_lap(k)
+            assert h[42] == 0, (f, k, h[40:43])
+            tied += int(h[40])
+            if k == 1:
+                c, base = ora.trace["cost1"], ora.trace["iou1"]
+                want_over = int(((c > 0.8) & (c != base)).sum()) if c.size else 0
+                assert int(h[7]) == want_over, (f, int(h[7]), want_over)          # the tiles found exactly the oracle's overrides
+                overrides += want_over
+        for which, lst in ((0, ora.tracked), (1, ora.lost)):
+            t, want = a.export(which), bo.TrackerOracle.table(lst)
+            for key in INT_KEYS:
+                assert np.array_equal(t[key], want[key]), (f, which, key)
+        assert a.counts()["errors"] == 0
+    assert tied >= 4 and overrides > 0
+    a.close()
