@@ -215,3 +215,33 @@ def test_track_rows_copied_from_non_unit_detections_stay_sound(d):
         qb, rb, _ = shadows(unit(rng.standard_normal((4, d))), gate)
         for c in range(5):
             assert not excluded(qz, rz, qb, rb, c, cst, d).any()
+
+
+def test_restatement_matches_the_products_own_functions():
+    """checkpoints(), the scale and track_side() above are NumPy restatements; the product's versions are __host__ __device__
+    functions of csrc/feat_math.h -- called here on the CPU through tests/host_emul/libfeat_host.so (hipcc, host code only)."""
+    import ctypes, os, shutil, subprocess
+    if not shutil.which("hipcc") and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host_emul")
+    subprocess.check_call(["make", "-C", d, "-s", "feat"])
+    lib = ctypes.CDLL(os.path.join(d, "libfeat_host.so"))
+    lib.feat_host_i8_scale.restype = ctypes.c_float
+    lib.feat_host_track_side.argtypes = [ctypes.c_void_p, ctypes.c_float, ctypes.c_float]
+    assert lib.feat_host_meta_floats() == 20
+    for dim in (128, 384, 512, 1024, 2048, 4096):
+        out = (ctypes.c_int * 4)()
+        lib.feat_host_checkpoints(dim // I8_STAGE, out)
+        assert list(out) == checkpoints(dim // I8_STAGE), dim
+        assert lib.feat_host_i8_scale(dim) == np.float32(127.0) * np.sqrt(np.float32(dim)) / np.float32(I8_CLIP)
+    rng = np.random.default_rng(3)
+    rec = rng.uniform(-1, 1, (64, 5, 4)).astype(np.float32)
+    nrm = np.concatenate([rng.uniform(0.5, 1.5, 60), [0.0, np.inf, np.nan, 1.0]]).astype(np.float32)
+    with np.errstate(invalid="ignore"):
+        want = track_side(rec, nrm, 0.75)
+    got = rec.copy()
+    for i in range(64):
+        row = np.ascontiguousarray(got[i].reshape(-1))
+        lib.feat_host_track_side(row.ctypes.data, ctypes.c_float(nrm[i]), ctypes.c_float(0.75))
+        got[i] = row.reshape(5, 4)
+    assert np.array_equal(got, want, equal_nan=True)
