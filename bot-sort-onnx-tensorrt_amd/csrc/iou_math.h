@@ -4,7 +4,8 @@
 // tlbr, touching or disjoint boxes give IoU exactly 0 (cost exactly 1), no "+1" pixel convention.
 // The reference evaluates the expression with NumPy *scalars*, so every intermediate is float32
 // exactly when both of its operands are float32 (detections, never-predicted tracks) and float64
-// otherwise; max/min return one of their arguments.  Boxes are carried as float64 plus an
+// otherwise; max/min return one of their arguments.  (sub / mul / area / cost are __host__ __device__: the CPU emulation
+// tests of the exact-tie step run the very same arithmetic, tests/host_emul/lap_box_host.hip.)  Boxes are carried as float64 plus an
 // "is float32" flag (a float32 value is exactly representable), and the float32 branches below
 // reproduce those roundings bit for bit.  The final `1 - iou` is always float64.
 #pragma once
@@ -12,19 +13,19 @@
 
 namespace iou {
 
-__device__ __forceinline__ double sub(double hi, double lo, bool f32) {
+__host__ __device__ __forceinline__ double sub(double hi, double lo, bool f32) {
     return f32 ? (double)((float)hi - (float)lo) : hi - lo;
 }
-__device__ __forceinline__ double mul(double p, double q, bool f32) {
+__host__ __device__ __forceinline__ double mul(double p, double q, bool f32) {
     return f32 ? (double)((float)p * (float)q) : p * q;
 }
 
-__device__ __forceinline__ double area(const double b[4], bool f32) {
+__host__ __device__ __forceinline__ double area(const double b[4], bool f32) {
     return mul(sub(b[2], b[0], f32), sub(b[3], b[1], f32), f32);
 }
 
 // cost = 1 - IoU(a, b); area_a / area_b precomputed with area() above.
-__device__ __forceinline__ double cost(const double a[4], bool a32, double area_a, const double b[4],
+__host__ __device__ __forceinline__ double cost(const double a[4], bool a32, double area_a, const double b[4],
                                        bool b32, double area_b) {
     const bool tx0 = b[0] > a[0], ty0 = b[1] > a[1], tx1 = b[2] < a[2], ty1 = b[3] < a[3];
     const double x_lo = tx0 ? b[0] : a[0], y_lo = ty0 ? b[1] : a[1];

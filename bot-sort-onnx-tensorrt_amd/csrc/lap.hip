@@ -19,8 +19,8 @@
 // Everything is deterministic regardless of the order edges were appended in.
 #include "bts_internal.h"
 #include "block_scan.h"
-#include "iou_math.h"
 #include "lap_exact.h"
+#include "lap_src.h"
 
 namespace {
 
@@ -1022,21 +1022,6 @@ struct DevEx {                          // the executor: a phase = every thread 
     template <class F> __device__ __forceinline__ void phase(F f) { __syncthreads(); f((int)threadIdx.x); __syncthreads(); }
     __device__ __forceinline__ int atomic_add(int32_t *p, int v) { return atomicAdd(p, v); }
     __device__ __forceinline__ int atomic_max(int32_t *p, int v) { return atomicMax(p, v); }
-};
-struct DenseSrc {                       // bts_lapjv_exact: the caller's matrix is the whole truth
-    static constexpr bool patched = false;
-    const double *c; int ld;
-    __device__ __forceinline__ double real(int i, int j) const { return c[(long)i * ld + j]; }
-};
-struct BoxSrc {                         // the tracker: a pair that is not a feasible edge costs its IoU distance (D:1554, D:1570, D:1602)
-    static constexpr bool patched = true;
-    const double *abox; const uint8_t *af32; const double *bbox; const int32_t *bidx;
-    __device__ __forceinline__ double real(int i, int j) const {
-        const double *a = abox + (long)i * 4, *b = bbox + (long)bidx[j] * 4;
-        const double aa[4] = {a[0], a[1], a[2], a[3]}, bb[4] = {b[0], b[1], b[2], b[3]};
-        const bool fa = af32 ? af32[i] != 0 : false;
-        return iou::cost(aa, fa, iou::area(aa, fa), bb, true, iou::area(bb, true));
-    }
 };
 struct ExactPair { LapArgs p[2]; bts_lap_exact x[2]; };
 

@@ -32,6 +32,7 @@
 #include <stddef.h>
 
 #if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
 #define LAPX_HD __host__ __device__ __forceinline__
 #else
 #define LAPX_HD inline

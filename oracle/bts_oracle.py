@@ -646,6 +646,16 @@ class TrackerOracle:
         tr["hi_idx"] = np.asarray(hi_idx, dtype=np.int64)
         tr["lo_idx"] = np.asarray(lo_idx, dtype=np.int64)
 
+        # (test support: the boxes every stage's IoU matrix is built from, as float64 holders + "was float32" flags -- what the
+        #  device keeps in pool_tlbr / det_tlbr / r2_tlbr / unc_tlbr; tests/test_lap_exact_host.py feeds them to the product's
+        #  box cost source)
+        det_tlbr = np.zeros((M, 4), dtype=np.float64)
+        for lst, idx in ((dets_hi, hi_idx), (dets_lo, lo_idx)):
+            for t, i in zip(lst, idx):
+                det_tlbr[i] = t.tlbr
+        tr["det_tlbr"] = det_tlbr
+        tr["pool_tlbr"], tr["pool_f32"] = _as_box_array([t.tlbr for t in pool])
+
         # ---- stage 1: pool x high-score detections, D:1539-1566
         iou_d = self._iou(pool, dets_hi)
         if N > 0 and M > 0 and len(dets_hi) == 0:
@@ -672,6 +682,7 @@ class TrackerOracle:
 
         # ---- stage 2: still-tracked leftovers x low-score detections, D:1568-1586
         r_tracked = [pool[i] for i in u_trk if pool[i].state == TRACKED]
+        tr["r2_tlbr"], tr["r2_f32"] = _as_box_array([t.tlbr for t in r_tracked])
         dists2 = self._iou(r_tracked, dets_lo)
         m2, u_trk2, u_det2 = linear_assignment(dists2, 0.5)
         tr["cost2"] = dists2
@@ -694,6 +705,8 @@ class TrackerOracle:
 
         # ---- stage 3: unconfirmed x leftover high-score detections, D:1588-1612
         left = [dets_hi[i] for i in u_det]
+        tr["unc_tlbr"], tr["unc_f32"] = _as_box_array([t.tlbr for t in unconfirmed])
+        tr["left_det"] = np.asarray([d.det_index for d in left], dtype=np.int64)
         iou3 = self._iou(unconfirmed, left)
         D = body_feats.shape[1] if body_feats.ndim == 2 else 0
         uf = (np.asarray([t.body_curr for t in unconfirmed], dtype=np.float32)

@@ -4,6 +4,7 @@
 // hidden dependence between threads of one phase shows up as a difference.  tests/test_lap_exact_host.py drives it against
 // oracle/lapjv_oracle.c.  Nothing in the product loads this library.
 #include "../../bot-sort-onnx-tensorrt_amd/csrc/lap_exact.h"
+#include "host_ex.h"
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
@@ -13,17 +14,6 @@
 #endif
 
 namespace {
-
-struct HostEx {
-    int n, order;
-    int nth() const { return n; }
-    template <class F> void phase(F f) {
-        if (order == 0) for (int t = 0; t < n; ++t) f(t);
-        else for (int t = n - 1; t >= 0; --t) f(t);
-    }
-    int atomic_add(int32_t *p, int v) { const int o = *p; *p = o + v; return o; }
-    int atomic_max(int32_t *p, int v) { const int o = *p; if (v > o) *p = v; return o; }
-};
 
 struct DenseSrc {
     static constexpr bool patched = false;

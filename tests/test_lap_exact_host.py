@@ -339,3 +339,63 @@ def test_overrides_above_the_limit(lapx):
         assert info2["tied"] == info["tied"], k
         tied += info["tied"]
     assert n_over > 300 and tied > 50
+
+
+def test_tracker_box_source_on_the_cpu():
+    """The code k_lap_exact runs inside the tracker -- csrc/lap_src.h BoxSrc over csrc/iou_math.h's iou::cost -- compiled by hipcc
+    for the HOST and fed with the oracle's own stage data (pool / stage-2 / unconfirmed boxes with their float32 flags, detection
+    boxes, column index lists, feasible edges, overrides):
+      * the IoU cost matrix from the product's arithmetic equals the oracle's bit for bit (A13 once more, without a GPU);
+      * certificate + replay through the box source equal the dense JV on the stage's full cost matrix, for body-only and
+        face streams, dup-box scenes included."""
+    import importlib
+    import shutil
+    if not shutil.which("hipcc") and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    pkg = importlib.import_module("bot-sort-onnx-tensorrt_amd")
+    d = os.path.join(HERE, "host_emul")
+    subprocess.check_call(["make", "-C", d, "-s", "box"])
+    lib = ctypes.CDLL(os.path.join(d, "liblapx_box_host.so"))
+    P = ctypes.c_void_p
+    lib.lapx_host_box_matrix.argtypes = [ctypes.c_int, ctypes.c_int, P, P, P, P, P]
+    lib.lapx_host_exact_box.argtypes = [ctypes.c_int, ctypes.c_int, P, P, P, P, P, P, P, ctypes.c_int, ctypes.c_int, ctypes.c_long,
+                                        ctypes.c_double, P, P, ctypes.c_int, ctypes.c_int, ctypes.c_int, P]
+    stages = tied = overrides = 0
+    for kw in (dict(churn=0.1), dict(dup_frac=0.1, churn=0.05), dict(side_scale=40.0, dup_frac=0.05),
+               dict(dup_frac=0.1, churn=0.05, face_dim=32)):
+        st = pkg.synth.SyntheticStream(80, 40, 64, seed=17, **kw)
+        ora = bo.TrackerOracle()
+        for f in range(9):
+            fr = st.next()
+            ora.update_arrays(fr.boxes, fr.scores.astype(np.float64), fr.feats.copy(), None if fr.face_feats is None else fr.face_feats.copy())
+            tr = ora.trace
+            det = np.ascontiguousarray(tr["det_tlbr"], dtype=np.float64)
+            for k, L, ab, af, bidx, iou_key in ((1, 0.8, "pool_tlbr", "pool_f32", "hi_idx", "iou1"), (2, 0.5, "r2_tlbr", "r2_f32", "lo_idx", "cost2"),
+                                                (3, 0.7, "unc_tlbr", "unc_f32", "left_det", "iou3")):
+                c = np.ascontiguousarray(tr["cost%d" % k], dtype=np.float64)
+                n, m = c.shape
+                if n == 0 or m == 0:
+                    continue
+                abox = np.ascontiguousarray(tr[ab], dtype=np.float64)
+                af32 = np.ascontiguousarray(tr[af], dtype=np.uint8)
+                cols = np.ascontiguousarray(tr[bidx], dtype=np.int32)
+                assert abox.shape == (n, 4) and len(cols) == m
+                got = np.empty((n, m), dtype=np.float64)
+                lib.lapx_host_box_matrix(n, m, abox.ctypes.data, af32.ctypes.data, det.ctypes.data, cols.ctypes.data, got.ctypes.data)
+                assert np.array_equal(got, np.asarray(tr[iou_key], dtype=np.float64)), (kw, f, k)      # the product's IoU arithmetic = the oracle's
+                er, ec = np.nonzero(c <= L)
+                orow, ocol = np.nonzero((c > L) & (c != got))
+                E, O, hole = len(er), len(orow), 2
+                e_row = np.concatenate([er, np.full(hole, -9), orow[::-1]]).astype(np.int32)
+                e_col = np.concatenate([ec, np.full(hole, -9), ocol[::-1]]).astype(np.int32)
+                e_cost = np.concatenate([c[er, ec], np.full(hole, -9.0), c[orow, ocol][::-1]]).astype(np.float64)
+                want = jv(c, L)
+                x0, y0 = scipy_visible(c, L)
+                x, y, info = x0.copy(), y0.copy(), np.zeros(4, dtype=np.int32)
+                rc = lib.lapx_host_exact_box(n, m, abox.ctypes.data, af32.ctypes.data, det.ctypes.data, cols.ctypes.data, e_row.ctypes.data,
+                                             e_col.ctypes.data, e_cost.ctypes.data, E, O, E + hole, L, x.ctypes.data, y.ctypes.data, 64, f & 1,
+                                             int(f % 3 == 0), info.ctypes.data)
+                assert rc == 0 and info[1] == 0, (rc, info)
+                assert np.array_equal(x, want[0]) and np.array_equal(y, want[1]), (kw, f, k, info)
+                stages += 1; tied += int(info[0]); overrides += O
+    assert stages > 70 and tied > 15 and overrides > 5, (stages, tied, overrides)
