@@ -13,13 +13,15 @@
 #include <hip/hip_runtime.h>
 
 namespace kf {
+// (the scalar forms below are __host__ __device__: tests/host_emul/kf_host.hip runs them on the CPU against the golden vectors
+//  recorded from the reference -- the same arithmetic the standalone kernels and the tracker's initiate / project / gmc use)
 
 constexpr double W_POS = 1.0 / 20;   // D:163
 constexpr double W_VEL = 1.0 / 160;  // D:164
 
 // Noise std-devs squared for a box of width w, height h.  `f32` reproduces NumPy-2 scalar
 // promotion for float32 state (python_float * np.float32 -> float32), D:183-196 / D:283-292.
-__device__ __forceinline__ double sq_scaled(double weight, double x, bool f32) {
+__host__ __device__ __forceinline__ double sq_scaled(double weight, double x, bool f32) {
     if (f32) {
         float s = (float)weight * (float)x;
         return (double)(s * s);
@@ -29,7 +31,7 @@ __device__ __forceinline__ double sq_scaled(double weight, double x, bool f32) {
 }
 
 // mean' = F mean ; P' = F P F^T + Q(w,h)   (D:265-302)
-__device__ __forceinline__ void predict(double m[8], double P[64], bool f32) {
+__host__ __device__ __forceinline__ void predict(double m[8], double P[64], bool f32) {
     const double qp_w = sq_scaled(W_POS, m[2], f32), qp_h = sq_scaled(W_POS, m[3], f32);
     const double qv_w = sq_scaled(W_VEL, m[2], f32), qv_h = sq_scaled(W_VEL, m[3], f32);
 #pragma unroll
@@ -49,7 +51,7 @@ __device__ __forceinline__ void predict(double m[8], double P[64], bool f32) {
 }
 
 // Innovation covariance S = P[:4,:4] + R(w,h)   (D:236-263); zhat = m[:4].
-__device__ __forceinline__ void project(const double m[8], const double P[64], bool f32, double S[16]) {
+__host__ __device__ __forceinline__ void project(const double m[8], const double P[64], bool f32, double S[16]) {
     const double r_w = sq_scaled(W_POS, m[2], f32), r_h = sq_scaled(W_POS, m[3], f32);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -59,7 +61,7 @@ __device__ __forceinline__ void project(const double m[8], const double P[64], b
 }
 
 // Lower Cholesky factor of the 4x4 S (reads the lower triangle, like cho_factor(lower=True)).
-__device__ __forceinline__ void chol4(const double S[16], double L[16]) {
+__host__ __device__ __forceinline__ void chol4(const double S[16], double L[16]) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) L[i] = 0.0;
 #pragma unroll
@@ -80,7 +82,7 @@ __device__ __forceinline__ void chol4(const double S[16], double L[16]) {
 }
 
 // Solve (L L^T) x = b for one right-hand side of length 4, in place.
-__device__ __forceinline__ void chol4_solve(const double L[16], double b[4]) {
+__host__ __device__ __forceinline__ void chol4_solve(const double L[16], double b[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {   // forward: L y = b
         double t = b[i];
@@ -99,7 +101,7 @@ __device__ __forceinline__ void chol4_solve(const double L[16], double b[4]) {
 
 // Measurement update with z = (cx,cy,w,h) (float32 in the reference, D:304-336):
 //   K = P H^T S^-1 via the Cholesky factor; m += K (z - Hm); P -= K S K^T.
-__device__ __forceinline__ void update(double m[8], double P[64], const float z[4], bool f32) {
+__host__ __device__ __forceinline__ void update(double m[8], double P[64], const float z[4], bool f32) {
     double S[16], L[16];
     project(m, P, f32, S);
     chol4(S, L);
@@ -144,7 +146,7 @@ __device__ __forceinline__ void update(double m[8], double P[64], const float z[
 
 // KalmanFilter.initiate for a float32 measurement (cx,cy,w,h), D:166-197: the std-devs are
 // float32 products (2*w_pos = 0.1, 10*w_vel = 0.0625 as python floats, demoted to float32).
-__device__ __forceinline__ void initiate(const float z[4], double m[8], double P[64]) {
+__host__ __device__ __forceinline__ void initiate(const float z[4], double m[8], double P[64]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) { m[i] = (double)z[i]; m[i + 4] = 0.0; }
 #pragma unroll
@@ -158,7 +160,7 @@ __device__ __forceinline__ void initiate(const float z[4], double m[8], double P
 }
 
 // STrack.tlbr of a Kalman mean (D:624-642).  For float32 state every step is float32.
-__device__ __forceinline__ void mean_to_tlbr(const double m[8], bool f32, double out[4]) {
+__host__ __device__ __forceinline__ void mean_to_tlbr(const double m[8], bool f32, double out[4]) {
     if (f32) {
         float w = (float)m[2], h = (float)m[3];
         float x = (float)m[0] - w / 2, y = (float)m[1] - h / 2;
@@ -171,7 +173,7 @@ __device__ __forceinline__ void mean_to_tlbr(const double m[8], bool f32, double
 
 // STrack.multi_gmc (D:538-554): camera-motion warp  x <- kron(I4, R) x (+ t on the centre),
 // P <- R8 P R8^T  with R = H[:2,:2], t = H[:2,2].  R8 is block diagonal: pairs (0,1),(2,3),(4,5),(6,7).
-__device__ __forceinline__ void gmc(double m[8], double P[64], const double H[6]) {
+__host__ __device__ __forceinline__ void gmc(double m[8], double P[64], const double H[6]) {
     const double r00 = H[0], r01 = H[1], tx = H[2], r10 = H[3], r11 = H[4], ty = H[5];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {

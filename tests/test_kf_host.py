@@ -1,0 +1,139 @@
+"""The product's Kalman arithmetic on the CPU against the REFERENCE's golden vectors.
+
+csrc/kf_math.h's scalar forms (namespace kf: what k_initiate / k_project / k_gating / k_gmc, the tracker's births and the motion
+gate execute per thread, and what the 8-lane forms of predict / update are written to reproduce) are __host__ __device__;
+tests/host_emul/kf_host.hip compiles them with hipcc for the host.  Same bars as the GPU tests (tests/test_gpu_kernels.py):
+initiate / predict / project bit-identical to the vectors recorded from the reference (G1), update <= 1e-9 relative (LAPACK's
+summation order differs), gating <= 1e-10, multi_gmc <= 1e-12 (G7).  Round 3 had no GPU: this is the parity evidence for rows
+A2 - A8 / A22 that does not need one (the machine code of every kernel is unchanged since the last GPU-green run,
+profiles/r03_isa_vs_8cbc337.txt)."""
+import ctypes
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests.conftest import golden
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def kf():
+    if not shutil.which("hipcc") and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    d = os.path.join(HERE, "host_emul")
+    subprocess.check_call(["make", "-C", d, "-s", "kf"])
+    lib = ctypes.CDLL(os.path.join(d, "libkf_host.so"))
+    P = ctypes.c_void_p
+    for name, args in (("kf_host_initiate", [ctypes.c_int, P, P, P]), ("kf_host_predict", [ctypes.c_int, P, P, P, P]),
+                       ("kf_host_project", [ctypes.c_int, P, P, P, P, P]), ("kf_host_update", [ctypes.c_int, P, P, P, P]),
+                       ("kf_host_tlbr", [ctypes.c_int, P, P, P]), ("kf_host_gmc", [ctypes.c_int, P, P, P]),
+                       ("kf_host_maha", [P, P, ctypes.c_int, P, P])):
+        getattr(lib, name).argtypes = args
+    return lib
+
+
+def c64(a):
+    return np.ascontiguousarray(a, dtype=np.float64).copy()
+
+
+def close(a, b, rel=1e-9, abs_=1e-12):
+    err = np.abs(a - b)
+    tol = abs_ + rel * np.maximum(np.abs(a), np.abs(b))
+    assert (err <= tol).all(), float((err - tol).max())
+
+
+def test_initiate_bitwise(kf):
+    g = golden("g1_kalman.npz")
+    z = np.ascontiguousarray(g["meas32"], dtype=np.float32)
+    n = len(z)
+    m, c = np.empty((n, 8)), np.empty((n, 8, 8))
+    kf.kf_host_initiate(n, z.ctypes.data, m.ctypes.data, c.ctypes.data)
+    # the reference's state is float32 here (NumPy 2 scalar promotion); the product carries float64 holders of the same values
+    assert np.array_equal(m, g["init_mean"].astype(np.float64)) and np.array_equal(c, g["init_cov"].astype(np.float64))
+
+
+def test_predict_bitwise(kf):
+    g = golden("g1_kalman.npz")
+    n = len(g["state_mean"])
+    m, c = c64(g["state_mean"]), c64(g["state_cov"])
+    kf.kf_host_predict(n, m.ctypes.data, c.ctypes.data, None, None)
+    assert np.array_equal(m, g["multi_predict_mean"]) and np.array_equal(c, g["multi_predict_cov"])
+    assert np.array_equal(m[3], g["predict_mean"][3]) and np.array_equal(c[3], g["predict_cov"][3])
+    m, c = c64(g["state_mean"]), c64(g["state_cov"])
+    zv = np.ascontiguousarray(g["not_tracked"], dtype=np.uint8)
+    kf.kf_host_predict(n, m.ctypes.data, c.ctypes.data, None, zv.ctypes.data)             # the vw, vh = 0 rule (A8)
+    assert np.array_equal(m, g["multi_predict_z_mean"]) and np.array_equal(c, g["multi_predict_z_cov"])
+
+
+def test_predict_of_a_float32_batch(kf):
+    """frame 2: every pool row still holds the float32 state of initiate(): NumPy evaluates the process noise in float32 (Q10)."""
+    from oracle import bts_oracle as bo
+    g = golden("g1_kalman.npz")
+    want_m, want_c = bo.KalmanOracle().multi_predict(g["init_mean"].copy(), g["init_cov"].copy())
+    n = len(want_m)
+    m, c = c64(g["init_mean"]), c64(g["init_cov"])
+    ones = np.ones(n, dtype=np.uint8)
+    kf.kf_host_predict(n, m.ctypes.data, c.ctypes.data, ones.ctypes.data, None)
+    assert np.array_equal(m, want_m.astype(np.float64)) and np.array_equal(c, want_c.astype(np.float64))
+
+
+def test_project_bitwise_and_tlbr(kf):
+    g = golden("g1_kalman.npz")
+    n = len(g["state_mean"])
+    m, c = c64(g["state_mean"]), c64(g["state_cov"])
+    z, s = np.empty((n, 4)), np.empty((n, 4, 4))
+    kf.kf_host_project(n, m.ctypes.data, c.ctypes.data, None, z.ctypes.data, s.ctypes.data)
+    assert np.array_equal(z, g["project_mean"]) and np.array_equal(s, g["project_cov"])
+    out = np.empty((n, 4))
+    kf.kf_host_tlbr(n, m.ctypes.data, None, out.ctypes.data)
+    want = m[:, :4].copy(); want[:, :2] -= want[:, 2:] / 2; want[:, 2:] += want[:, :2]        # D:624-642
+    assert np.array_equal(out, want)
+
+
+def test_update_vs_golden(kf):
+    g = golden("g1_kalman.npz")
+    n = len(g["multi_predict_mean"])
+    m, c = c64(g["multi_predict_mean"]), c64(g["multi_predict_cov"])
+    z = np.ascontiguousarray(g["update_z"], dtype=np.float32)
+    kf.kf_host_update(n, m.ctypes.data, c.ctypes.data, z.ctypes.data, None)
+    close(m, g["update_mean"])
+    close(c, g["update_cov"], rel=1e-9, abs_=1e-9)
+
+
+def test_update_of_float32_state_vs_oracle(kf):
+    from oracle import bts_oracle as bo
+    g = golden("g1_kalman.npz")
+    ko = bo.KalmanOracle()
+    for i in range(6):
+        m0, c0 = g["init_mean"][i], g["init_cov"][i]
+        z = (m0[:4] + np.float32(1.5)).astype(np.float32)
+        wm, wc = ko.update(m0, c0, z)
+        m, c = c64(m0), c64(c0)
+        one = np.ones(1, dtype=np.uint8)
+        kf.kf_host_update(1, m.ctypes.data, c.ctypes.data, z.ctypes.data, one.ctypes.data)
+        close(m, np.asarray(wm, dtype=np.float64))
+        close(c, np.asarray(wc, dtype=np.float64), abs_=1e-9)
+
+
+def test_gating_distance(kf):
+    g = golden("g1_kalman.npz")
+    meas = c64(g["gate_meas"])
+    for i in range(4):
+        m, c = c64(g["state_mean"][i]), c64(g["state_cov"][i])
+        out = np.empty(len(meas))
+        kf.kf_host_maha(m.ctypes.data, c.ctypes.data, len(meas), meas.ctypes.data, out.ctypes.data)
+        close(out, g["gate_%d_0_maha" % i], rel=1e-10)
+
+
+def test_multi_gmc(kf):
+    g, g1 = golden("g7_gmc.npz"), golden("g1_kalman.npz")
+    n = len(g1["state_mean"])
+    m, c = c64(g1["state_mean"]), c64(g1["state_cov"])
+    h = c64(g["H"]).reshape(6)
+    kf.kf_host_gmc(n, m.ctypes.data, c.ctypes.data, h.ctypes.data)
+    close(m, g["mean"], rel=1e-13, abs_=1e-12)
+    close(c, g["cov"], rel=1e-12, abs_=1e-12)
