@@ -211,9 +211,17 @@ __host__ __device__ __forceinline__ void gmc(double m[8], double P[64], const do
 // results are bit-identical to them).
 namespace kf8 {
 
+// (On the CPU -- tests/host_emul/kf_host.hip -- grp() is served by a hook that runs the eight lanes of a group in lockstep by
+//  replay, so that these very functions can be held against the reference's golden vectors without a GPU.  The device pass
+//  sees exactly the code it always did.)
+#if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ double grp(double v, int src) { return __shfl(v, src, 8); }
+#else
+double kf8_host_grp(double v, int src);      // defined by the CPU test harness only
+inline double grp(double v, int src) { return kf8_host_grp(v, src); }
+#endif
 
-__device__ __forceinline__ void predict(double &mi, double Pr[8], int i, bool f32) {
+__host__ __device__ __forceinline__ void predict(double &mi, double Pr[8], int i, bool f32) {
     const double w = grp(mi, 2), h = grp(mi, 3);
     const double wh = (i & 1) ? h : w;                         // row i's noise uses w for even, h for odd i
     const double q = kf::sq_scaled(i < 4 ? kf::W_POS : kf::W_VEL, wh, f32);
@@ -230,7 +238,7 @@ __device__ __forceinline__ void predict(double &mi, double Pr[8], int i, bool f3
     for (int j = 0; j < 8; ++j) if (j == i) Pr[j] += q;
 }
 
-__device__ __forceinline__ void update(double &mi, double Pr[8], int i, const float z[4], bool f32) {
+__host__ __device__ __forceinline__ void update(double &mi, double Pr[8], int i, const float z[4], bool f32) {
     double S[16], L[16];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -267,7 +275,7 @@ __device__ __forceinline__ void update(double &mi, double Pr[8], int i, const fl
 }
 
 // STrack.tlbr from the group's mean; every lane gets the box
-__device__ __forceinline__ void tlbr(double mi, bool f32, double out[4]) {
+__host__ __device__ __forceinline__ void tlbr(double mi, bool f32, double out[4]) {
     double m[8];
 #pragma unroll
     for (int c = 0; c < 4; ++c) m[c] = grp(mi, c);

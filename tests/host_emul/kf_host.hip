@@ -44,3 +44,80 @@ extern "C" void kf_host_maha(const double *mean, const double *cov, int m, const
         out[q] = g;
     }
 }
+
+// ---- the 8-lane forms (kf8::predict / kf8::update / kf8::tlbr: what tk_predict, the predict workgroups of k_filter and the
+// Kalman ranges of tk_mid2 / tk_apply23 execute) on the CPU.  A group's eight lanes run in LOCKSTEP on the device and trade
+// values through grp() = __shfl(v, src, 8).  Here grp() is served by REPLAY: to learn what the lanes hold at their c-th grp()
+// call, every lane is re-run from the start with the answers of calls 0 .. c-1 and stopped at call c, where it leaves its
+// value; when a run passes the last call the lanes' results are final.  (All lanes make the same sequence of grp() calls:
+// none sits under a lane-dependent branch.)
+#include <array>
+#include <vector>
+namespace {
+struct Stop {};
+struct Replay {
+    std::vector<std::array<double, 8>> rec;     // rec[c][lane] = the value lane offered at its c-th grp() call
+    std::array<double, 8> pending;
+    int lane = 0, call = 0;
+} R;
+}  // namespace
+#if !defined(__HIP_DEVICE_COMPILE__)      // (the hook only exists in the host pass of kf_math.h)
+double kf8::kf8_host_grp(double v, int src) {
+    const int c = R.call++;
+    if (c < (int)R.rec.size()) return R.rec[c][src & 7];
+    R.pending[R.lane] = v;
+    throw Stop();
+}
+#endif
+template <class Body> static void lockstep(Body body) {      // body(lane) runs one lane start to end
+    R.rec.clear();
+    for (;;) {
+        int stopped = 0;
+        for (int l = 0; l < 8; ++l) {
+            R.lane = l; R.call = 0;
+            try { body(l); } catch (const Stop &) { ++stopped; }
+        }
+        if (stopped == 0) return;                             // every lane ran to its end: results are in place
+        R.rec.push_back(R.pending);
+    }
+}
+extern "C" void kf8_host_predict(int n, double *mean, double *cov, const uint8_t *f32, const uint8_t *zero_vel) {
+    for (int t = 0; t < n; ++t) {
+        double m0[8], P0[64], mo[8], Po[64];
+        for (int k = 0; k < 8; ++k) m0[k] = mean[8 * t + k];
+        for (int k = 0; k < 64; ++k) P0[k] = cov[64 * t + k];
+        if (zero_vel && zero_vel[t]) { m0[6] = 0.0; m0[7] = 0.0; }          // predict_body: `if (i >= 6 && state != Tracked) mi = 0`
+        lockstep([&](int i) {
+            double mi = m0[i], Pr[8];
+            for (int j = 0; j < 8; ++j) Pr[j] = P0[i * 8 + j];
+            kf8::predict(mi, Pr, i, f32 && f32[t]);
+            mo[i] = mi;
+            for (int j = 0; j < 8; ++j) Po[i * 8 + j] = Pr[j];
+        });
+        for (int k = 0; k < 8; ++k) mean[8 * t + k] = mo[k];
+        for (int k = 0; k < 64; ++k) cov[64 * t + k] = Po[k];
+    }
+}
+extern "C" void kf8_host_update(int n, double *mean, double *cov, const float *z, const uint8_t *f32) {
+    for (int t = 0; t < n; ++t) {
+        double m0[8], P0[64], mo[8], Po[64];
+        for (int k = 0; k < 8; ++k) m0[k] = mean[8 * t + k];
+        for (int k = 0; k < 64; ++k) P0[k] = cov[64 * t + k];
+        lockstep([&](int i) {
+            double mi = m0[i], Pr[8];
+            for (int j = 0; j < 8; ++j) Pr[j] = P0[i * 8 + j];
+            kf8::update(mi, Pr, i, z + 4 * t, f32 && f32[t]);
+            mo[i] = mi;
+            for (int j = 0; j < 8; ++j) Po[i * 8 + j] = Pr[j];
+        });
+        for (int k = 0; k < 8; ++k) mean[8 * t + k] = mo[k];
+        for (int k = 0; k < 64; ++k) cov[64 * t + k] = Po[k];
+    }
+}
+extern "C" void kf8_host_tlbr(int n, const double *mean, const uint8_t *f32, double *out) {
+    for (int t = 0; t < n; ++t) {
+        double b[8][4];
+        lockstep([&](int i) { kf8::tlbr(mean[8 * t + i], f32 && f32[t], b[i]); });
+        for (int c = 0; c < 4; ++c) out[4 * t + c] = b[5][c];               // (every lane gets the box: take any)
+    }
+}

@@ -137,3 +137,60 @@ def test_multi_gmc(kf):
     kf.kf_host_gmc(n, m.ctypes.data, c.ctypes.data, h.ctypes.data)
     close(m, g["mean"], rel=1e-13, abs_=1e-12)
     close(c, g["cov"], rel=1e-12, abs_=1e-12)
+
+
+# ---- the 8-lane forms (kf8::): the code of the tracker's predict and update paths ------------------------------------------
+def _kf8(kf):
+    P = ctypes.c_void_p
+    kf.kf8_host_predict.argtypes = [ctypes.c_int, P, P, P, P]
+    kf.kf8_host_update.argtypes = [ctypes.c_int, P, P, P, P]
+    kf.kf8_host_tlbr.argtypes = [ctypes.c_int, P, P, P]
+    return kf
+
+
+def test_eight_lane_predict_bitwise(kf):
+    """kf8::predict -- eight lanes per track trading values through __shfl on the device, run in lockstep by replay here -- is
+    bit-identical to the reference's multi_predict (G1), incl. the vw, vh = 0 rule and the all-float32 batch (Q10), and to the
+    scalar form."""
+    from oracle import bts_oracle as bo
+    _kf8(kf)
+    g = golden("g1_kalman.npz")
+    n = len(g["state_mean"])
+    m, c = c64(g["state_mean"]), c64(g["state_cov"])
+    kf.kf8_host_predict(n, m.ctypes.data, c.ctypes.data, None, None)
+    assert np.array_equal(m, g["multi_predict_mean"]) and np.array_equal(c, g["multi_predict_cov"])
+    m, c = c64(g["state_mean"]), c64(g["state_cov"])
+    zv = np.ascontiguousarray(g["not_tracked"], dtype=np.uint8)
+    kf.kf8_host_predict(n, m.ctypes.data, c.ctypes.data, None, zv.ctypes.data)
+    assert np.array_equal(m, g["multi_predict_z_mean"]) and np.array_equal(c, g["multi_predict_z_cov"])
+    want_m, want_c = bo.KalmanOracle().multi_predict(g["init_mean"].copy(), g["init_cov"].copy())
+    m, c = c64(g["init_mean"]), c64(g["init_cov"])
+    ones = np.ones(n, dtype=np.uint8)
+    kf.kf8_host_predict(n, m.ctypes.data, c.ctypes.data, ones.ctypes.data, None)
+    assert np.array_equal(m, want_m.astype(np.float64)) and np.array_equal(c, want_c.astype(np.float64))
+    out = np.empty((n, 4))
+    kf.kf8_host_tlbr(n, m.ctypes.data, None, out.ctypes.data)
+    want = m[:, :4].copy(); want[:, :2] -= want[:, 2:] / 2; want[:, 2:] += want[:, :2]
+    assert np.array_equal(out, want)
+
+
+def test_eight_lane_update_vs_golden_and_scalar_form(kf):
+    _kf8(kf)
+    g = golden("g1_kalman.npz")
+    n = len(g["multi_predict_mean"])
+    z = np.ascontiguousarray(g["update_z"], dtype=np.float32)
+    m, c = c64(g["multi_predict_mean"]), c64(g["multi_predict_cov"])
+    kf.kf8_host_update(n, m.ctypes.data, c.ctypes.data, z.ctypes.data, None)
+    close(m, g["update_mean"])
+    close(c, g["update_cov"], rel=1e-9, abs_=1e-9)
+    ms, cs = c64(g["multi_predict_mean"]), c64(g["multi_predict_cov"])
+    kf.kf_host_update(n, ms.ctypes.data, cs.ctypes.data, z.ctypes.data, None)
+    assert np.array_equal(m, ms) and np.array_equal(c, cs)            # "the same sequence of operations as kf::update"
+    # float32 state (unconfirmed tracks updated straight from initiate(), Q5 / Q10)
+    m, c = c64(g["init_mean"]), c64(g["init_cov"])
+    ms, cs = m.copy(), c.copy()
+    z2 = np.ascontiguousarray(g["init_mean"][:, :4] + np.float32(1.5), dtype=np.float32)
+    ones = np.ones(n, dtype=np.uint8)
+    kf.kf8_host_update(n, m.ctypes.data, c.ctypes.data, z2.ctypes.data, ones.ctypes.data)
+    kf.kf_host_update(n, ms.ctypes.data, cs.ctypes.data, z2.ctypes.data, ones.ctypes.data)
+    assert np.array_equal(m, ms) and np.array_equal(c, cs)
