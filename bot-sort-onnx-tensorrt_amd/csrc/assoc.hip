@@ -8,6 +8,7 @@
 // These kernels are HBM-write bound: 8 B of output per pair against 64 B per *box* of input.
 #include "bts_internal.h"
 #include "iou_math.h"
+#include "cost_math.h"
 
 namespace {
 
@@ -42,31 +43,6 @@ __global__ __launch_bounds__(TILE_COLS) void k_iou_distance(const double *__rest
         const double aa[4] = {sa[r][0], sa[r][1], sa[r][2], sa[r][3]};
         cost[(long)(i0 + r) * ld + j] = iou::cost(aa, sflag[r] != 0, sarea[r], bb, bf, area_b);
     }
-}
-
-// np.isclose(x, 0.9999999, atol=1e-8, rtol=1e-8) evaluated in float64 (D:1481-1483)
-__device__ __forceinline__ float face_fixup(float s) {
-    const double d = fabs((double)s - 0.9999999);
-    return d <= 1e-08 + 1e-08 * 0.9999999 ? 0.0f : s;
-}
-
-// D:1539-1554.  emb/face distances are float32 (1.0 - float32), the thresholds compare in the
-// dtype NumPy uses (float32 vs 0.25, float64 vs 0.5) and the minimum is float64.
-__device__ __forceinline__ double fuse1(double iou_d, float body_sim, float face_sim, double prox, float app) {
-    float emb = 1.0f - body_sim;
-    const float face = 1.0f - face_sim;
-    const bool far = fminf(emb, face) > app;
-    if (far) emb = 1.0f;
-    (void)prox;   // the proximity gate only re-sets entries that are already 1 (quirk Q2)
-    return fmin(iou_d, (double)emb);
-}
-
-// D:1590-1602
-__device__ __forceinline__ double fuse3(double iou_d, float body_sim, double prox, float app) {
-    float emb = 1.0f - body_sim;
-    if (emb > app) emb = 1.0f;
-    if (iou_d > prox) emb = 1.0f;
-    return fmin(iou_d, (double)emb);
 }
 
 __global__ __launch_bounds__(256) void k_fuse1(const double *__restrict__ iou_d, int ld_iou,

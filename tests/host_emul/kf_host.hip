@@ -1,6 +1,6 @@
 // tests/host_emul/kf_host.hip -- TEST INFRASTRUCTURE.  The scalar Kalman arithmetic of csrc/kf_math.h (namespace kf: initiate,
 // predict, project, update with its 4x4 Cholesky, mean_to_tlbr, gmc -- __host__ __device__) called on the CPU, batch by batch,
-// so that tests/test_kf_host.py can hold it against the golden vectors recorded from the reference (tests/golden/g1_kalman.npz,
+// so that tests/test_product_math_host.py can hold it against the golden vectors recorded from the reference (tests/golden/g1_kalman.npz,
 // g7_gmc.npz) without a GPU.  Built by hipcc with the product's flags (-ffp-contract=off: NumPy never fuses a*b+c).
 #include "../../bot-sort-onnx-tensorrt_amd/csrc/kf_math.h"
 #include <stdint.h>

@@ -1,4 +1,4 @@
-"""The product's Kalman arithmetic on the CPU against the REFERENCE's golden vectors.
+"""The product's Kalman and cost arithmetic on the CPU against the REFERENCE's golden vectors.
 
 csrc/kf_math.h's scalar forms (namespace kf: what k_initiate / k_project / k_gating / k_gmc, the tracker's births and the motion
 gate execute per thread, and what the 8-lane forms of predict / update are written to reproduce) are __host__ __device__;
@@ -194,3 +194,49 @@ def test_eight_lane_update_vs_golden_and_scalar_form(kf):
     kf.kf8_host_update(n, m.ctypes.data, c.ctypes.data, z2.ctypes.data, ones.ctypes.data)
     kf.kf_host_update(n, ms.ctypes.data, cs.ctypes.data, z2.ctypes.data, ones.ctypes.data)
     assert np.array_equal(m, ms) and np.array_equal(c, cs)
+
+
+# ---- the fused association costs (csrc/cost_math.h) -------------------------------------------------------------------------
+def test_fused_costs_on_the_cpu_vs_golden():
+    """fuse1 / fuse3 / face_fixup -- what k_fuse1 / k_fuse3 evaluate per element -- compiled for the host: stage-1 costs
+    bit-identical to the matrices recorded from the reference (G3), and to the oracle on values exactly at the thresholds and at
+    the face "0.9999999" rule."""
+    from oracle import bts_oracle as bo
+    if not shutil.which("hipcc") and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    d = os.path.join(HERE, "host_emul")
+    subprocess.check_call(["make", "-C", d, "-s", "cost"])
+    lib = ctypes.CDLL(os.path.join(d, "libcost_host.so"))
+    P = ctypes.c_void_p
+    lib.cost_host_fuse1.argtypes = [ctypes.c_long, P, P, P, ctypes.c_double, ctypes.c_float, P]
+    lib.cost_host_fuse3.argtypes = [ctypes.c_long, P, P, ctypes.c_double, ctypes.c_float, P]
+
+    def f1(iou_d, body, face):
+        i, b = c64(iou_d), np.ascontiguousarray(body, dtype=np.float32)
+        f = None if face is None else np.ascontiguousarray(face, dtype=np.float32)
+        out = np.empty_like(i)
+        lib.cost_host_fuse1(i.size, i.ctypes.data, b.ctypes.data, None if f is None else f.ctypes.data, 0.5, 0.25, out.ctypes.data)
+        return out
+
+    def f3(iou_d, body):
+        i, b = c64(iou_d), np.ascontiguousarray(body, dtype=np.float32)
+        out = np.empty_like(i)
+        lib.cost_host_fuse3(i.size, i.ctypes.data, b.ctypes.data, 0.5, 0.25, out.ctypes.data)
+        return out
+
+    g = golden("g3_fused.npz")
+    for k in range(int(g["n_rec"])):
+        assert np.array_equal(f1(g["s1_%d_iou" % k], g["s1_%d_body_sim" % k], g["s1_%d_face_sim" % k]), g["s1_%d_cost" % k]), k
+        if "s3_%d_cost" % k in g.files:
+            sim = bo.cosine_similarity(g["s3_%d_trk_feats" % k], g["s3_%d_det_feats" % k])       # (the GEMM itself needs the GPU)
+            assert np.abs(f3(g["s3_%d_iou" % k], sim) - g["s3_%d_cost" % k]).max() <= 2e-6, k
+    rng = np.random.default_rng(9)
+    iou_d = rng.uniform(0, 1, (40, 33))
+    body = rng.uniform(0, 1, (40, 33)).astype(np.float32)
+    face = rng.uniform(0, 1, (40, 33)).astype(np.float32)
+    body[0, :4] = [0.75, np.float32(0.75) + np.float32(1e-7), 0.7499999, 1.0]
+    face[1, :3] = [0.9999999, np.float32(1.0), 0.99999994]
+    iou_d[2, :3] = [0.5, 0.5000000001, 0.4999999]
+    assert np.array_equal(f1(iou_d, body, face), bo.fuse_cost_stage1(iou_d, body.copy(), bo.face_similarity_fixup(face)))
+    assert np.array_equal(f3(iou_d, body), bo.fuse_cost_stage3(iou_d, body.copy()))
+    assert np.array_equal(f1(iou_d, body, None), bo.fuse_cost_stage1(iou_d, body.copy(), np.zeros_like(face)))
