@@ -51,9 +51,25 @@ __host__ __device__ __forceinline__ double cost(const double a[4], bool a32, dou
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 struct ScreenBox { s16x2 lo, hi; };
 
-__device__ __forceinline__ ScreenBox screen_box(const double b[4]) {
-    auto lo = [](double v) { const int i = __double2int_rd(v); return (short)(i < -16000 ? -16000 : i > 15999 ? 15999 : i); };
-    auto hi = [](double v) { const int i = __double2int_ru(v); return (short)((i < -15999 ? -15999 : i > 16000 ? 16000 : i) - 1); };
+// (round towards -inf / +inf with saturation; NaN -> 0 like the device conversion.  The host forms exist for the CPU property
+//  test of the screening, tests/test_product_math_host.py: the device pass uses the hardware conversions as before.)
+__host__ __device__ __forceinline__ int screen_floor(double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __double2int_rd(v);
+#else
+    return v != v ? 0 : v <= -2147483648.0 ? (int)0x80000000 : v >= 2147483647.0 ? 0x7fffffff : (int)__builtin_floor(v);
+#endif
+}
+__host__ __device__ __forceinline__ int screen_ceil(double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __double2int_ru(v);
+#else
+    return v != v ? 0 : v <= -2147483648.0 ? (int)0x80000000 : v >= 2147483647.0 ? 0x7fffffff : (int)__builtin_ceil(v);
+#endif
+}
+__host__ __device__ __forceinline__ ScreenBox screen_box(const double b[4]) {
+    auto lo = [](double v) { const int i = screen_floor(v); return (short)(i < -16000 ? -16000 : i > 15999 ? 15999 : i); };
+    auto hi = [](double v) { const int i = screen_ceil(v); return (short)((i < -15999 ? -15999 : i > 16000 ? 16000 : i) - 1); };
     ScreenBox s;
     s.lo = s16x2{lo(b[0]), lo(b[1])};
     s.hi = s16x2{hi(b[2]), hi(b[3])};
@@ -61,9 +77,9 @@ __device__ __forceinline__ ScreenBox screen_box(const double b[4]) {
 }
 
 // a box that overlaps nothing (lo beyond every hi)
-__device__ __forceinline__ ScreenBox screen_none() { ScreenBox s; s.lo = s16x2{16001, 16001}; s.hi = s16x2{-16001, -16001}; return s; }
+__host__ __device__ __forceinline__ ScreenBox screen_none() { ScreenBox s; s.lo = s16x2{16001, 16001}; s.hi = s16x2{-16001, -16001}; return s; }
 
-__device__ __forceinline__ bool screen_overlap(const ScreenBox &a, const ScreenBox &b) {
+__host__ __device__ __forceinline__ bool screen_overlap(const ScreenBox &a, const ScreenBox &b) {
     const s16x2 lo = __builtin_elementwise_max(a.lo, b.lo), hi = __builtin_elementwise_min(a.hi, b.hi);
     const s16x2 dd = hi - lo;                      // both halves >= 0 <=> lo < hi + 1 in x and in y
     return (__builtin_bit_cast(unsigned, dd) & 0x80008000u) == 0u;

@@ -34,3 +34,17 @@ extern "C" int lapx_host_exact_box(int N, int M, const double *abox, const uint8
     info[1] = W.sh[lapx::S_ERR];
     return 0;
 }
+
+// ---- the conservative overlap screening of the cost / duplicate tiles (iou::screen_box / screen_overlap) on the CPU -------
+// out[i * m + j] = 1 iff the screening says "these two boxes may overlap" (a 0 makes the tile skip the pair's exact IoU)
+extern "C" void iou_host_screen(int n, int m, const double *a, const double *b, uint8_t *out) {
+    for (int i = 0; i < n; ++i) {
+        const iou::ScreenBox sa = iou::screen_box(a + 4 * i);
+        for (int j = 0; j < m; ++j) out[(size_t)i * m + j] = iou::screen_overlap(sa, iou::screen_box(b + 4 * j)) ? 1 : 0;
+    }
+}
+extern "C" int iou_host_screen_none(int m, const double *b) {      // screen_none() overlaps nothing: returns how many it "overlaps"
+    int hits = 0;
+    for (int j = 0; j < m; ++j) hits += iou::screen_overlap(iou::screen_none(), iou::screen_box(b + 4 * j)) ? 1 : 0;
+    return hits;
+}

@@ -240,3 +240,46 @@ def test_fused_costs_on_the_cpu_vs_golden():
     assert np.array_equal(f1(iou_d, body, face), bo.fuse_cost_stage1(iou_d, body.copy(), bo.face_similarity_fixup(face)))
     assert np.array_equal(f3(iou_d, body), bo.fuse_cost_stage3(iou_d, body.copy()))
     assert np.array_equal(f1(iou_d, body, None), bo.fuse_cost_stage1(iou_d, body.copy(), np.zeros_like(face)))
+
+
+def test_overlap_screening_never_misses_a_pair():
+    """The cost and duplicate tiles skip a pair's exact float64 IoU when iou::screen_overlap says the boxes are disjoint (boxes
+    rounded OUTWARD to 16-bit pixels, packed compare).  A missed overlap would be a missing edge -- a silent parity bug -- so the
+    screening must say "maybe" for EVERY pair whose exact boxes overlap: fractional coordinates, boxes touching at a pixel
+    boundary, sub-pixel boxes, coordinates far outside the 16-bit range, negative coordinates.  (And it must not be vacuous.)"""
+    if not shutil.which("hipcc") and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    d = os.path.join(HERE, "host_emul")
+    subprocess.check_call(["make", "-C", d, "-s", "box"])
+    lib = ctypes.CDLL(os.path.join(d, "liblapx_box_host.so"))
+    P = ctypes.c_void_p
+    lib.iou_host_screen.argtypes = [ctypes.c_int, ctypes.c_int, P, P, P]
+    lib.iou_host_screen_none.argtypes = [ctypes.c_int, P]
+    rng = np.random.default_rng(21)
+
+    def boxes(n, lo, hi, wmax, frac=True):
+        x = rng.uniform(lo, hi, n); y = rng.uniform(lo, hi, n)
+        w = rng.uniform(0.01, wmax, n); h = rng.uniform(0.01, wmax, n)
+        b = np.stack([x, y, x + w, y + h], 1)
+        return b if frac else np.rint(b)
+
+    skipped = total = 0
+    for lo, hi, wmax, frac in ((0, 2000, 150, True), (0, 300, 40, False), (-500, 500, 90, True), (15900, 16100, 50, True),
+                               (-16100, -15900, 50, True), (-1e6, 1e6, 3e5, True), (0, 50, 0.9, True), (1e9, 3e9, 1e9, True)):
+        a, b = boxes(300, lo, hi, wmax, frac), boxes(260, lo, hi, wmax, frac)
+        a[:20, 2:] = a[:20, :2] + np.rint(rng.uniform(1, 30, (20, 2)))                   # integer-sized boxes ...
+        b[:20, :2] = a[:20, 2:]                                                          # ... whose neighbour starts exactly where they end (touching: no overlap)
+        b[:20, 2:] = b[:20, :2] + 10
+        b[20:40] = a[20:40]                                                              # identical boxes
+        out = np.zeros((len(a), len(b)), dtype=np.uint8)
+        lib.iou_host_screen(len(a), len(b), np.ascontiguousarray(a).ctypes.data, np.ascontiguousarray(b).ctypes.data, out.ctypes.data)
+        x_lo = np.maximum(a[:, None, 0], b[None, :, 0]); x_hi = np.minimum(a[:, None, 2], b[None, :, 2])
+        y_lo = np.maximum(a[:, None, 1], b[None, :, 1]); y_hi = np.minimum(a[:, None, 3], b[None, :, 3])
+        overlap = (x_hi > x_lo) & (y_hi > y_lo)                                          # D:1705: anything else is IoU 0 exactly
+        assert not (overlap & (out == 0)).any(), (lo, hi, int((overlap & (out == 0)).sum()))
+        skipped += int((out == 0).sum()); total += out.size
+        assert lib.iou_host_screen_none(len(b), np.ascontiguousarray(b).ctypes.data) == 0
+    assert skipped > 0.5 * total          # most disjoint pairs are indeed screened out
+    nan = np.full((1, 4), np.nan)
+    out = np.zeros((1, 1), dtype=np.uint8)
+    lib.iou_host_screen(1, 1, nan.ctypes.data, np.asarray([[0.0, 0.0, 5.0, 5.0]]).ctypes.data, out.ctypes.data)      # (must not crash)
