@@ -10,7 +10,11 @@ namespace bscan {
 // Workgroup barrier for hand-offs through LDS only: __syncthreads() also waits for every outstanding global
 // store of the wavefront to be acknowledged (a memory round trip, ~1-2 us) -- needed only when global data
 // written before the barrier is read by other threads after it.
+#if defined(BTS_HOST_EMU)      // (tests/hip_emu: the CPU stand-in has one kind of workgroup barrier)
+__device__ __forceinline__ void lds_barrier() { __syncthreads(); }
+#else
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
 
 // exclusive scan of one int per thread; *total = sum over the workgroup.  smem: >= 17 ints.
 __device__ __forceinline__ int exscan(int v, int *smem, int *total) {

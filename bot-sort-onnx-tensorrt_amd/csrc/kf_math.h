@@ -214,7 +214,7 @@ namespace kf8 {
 // (On the CPU -- tests/host_emul/kf_host.hip -- grp() is served by a hook that runs the eight lanes of a group in lockstep by
 //  replay, so that these very functions can be held against the reference's golden vectors without a GPU.  The device pass
 //  sees exactly the code it always did.)
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) || defined(BTS_HOST_EMU)
 __device__ __forceinline__ double grp(double v, int src) { return __shfl(v, src, 8); }
 #else
 double kf8_host_grp(double v, int src);      // defined by the CPU test harness only

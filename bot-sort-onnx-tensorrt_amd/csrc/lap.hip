@@ -51,7 +51,9 @@ typedef bts_lap_problem LapArgs;
 // decision, every lane reads it back): drain this wave's outstanding stores/loads before going on.
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#if !defined(BTS_HOST_EMU)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -952,7 +954,11 @@ constexpr unsigned LAP_LDS_BYTES = sizeof(SmallPipe) > 16 * sizeof(SmallLds) ? s
 struct LapPair { LapArgs p[2]; };     // (indexed by blockIdx.x straight out of the kernel-argument segment)
 
 template <int EC> __global__ __launch_bounds__(1024) void k_lap(LapPair P) {
+#if defined(BTS_HOST_EMU)
+    char *const lds_raw = emu::dynamic_lds();
+#else
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+#endif
     __shared__ int32_t tmp[1024];
     __shared__ int s_c;
     const LapArgs &A = P.p[blockIdx.x];
@@ -987,7 +993,9 @@ template <int EC> __global__ __launch_bounds__(1024) void k_lap(LapPair P) {
         __syncthreads();
         if (!solo && tid == 0) {       // publish (stores -> barrier -> one lane: agent release, drain, relaxed flag)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#if !defined(BTS_HOST_EMU)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
             RST(&w.hdr[H_READY], 1 + C);
         }
         TR(w, 8);

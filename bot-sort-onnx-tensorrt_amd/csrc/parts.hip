@@ -91,7 +91,11 @@ __global__ __launch_bounds__(64) void k_parts_resolve(const int4 *__restrict__ b
                                                       const int32_t *__restrict__ cnt, const int32_t *__restrict__ ct,
                                                       const double *__restrict__ ciou, const long long *__restrict__ cd2,
                                                       uint8_t *__restrict__ used_io, int picks, int32_t *__restrict__ out) {
+#if defined(BTS_HOST_EMU)
+    uint8_t *const used = reinterpret_cast<uint8_t *>(emu::dynamic_lds());
+#else
     extern __shared__ uint8_t used[];
+#endif
     const int lane = threadIdx.x;
     for (int t = lane; t < nt; t += 64) used[t] = used_io[t];
     __syncthreads();

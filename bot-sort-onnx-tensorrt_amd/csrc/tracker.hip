@@ -863,6 +863,11 @@ __global__ __launch_bounds__(64) void tk_edges_grid(Dev d, bts_lap_work w) {
     flush();
 }
 
+// (tile shape of the pre-filter GEMM: also what the host side sizes its grids with)
+constexpr int FBM = 128, FBN = 128;      // tile of the pre-filter GEMM
+constexpr int DBK = feat::I8_STAGE;      // its K step: 128 int8 elements = one full 128-byte line per row and stage
+constexpr int FILTER_PW = 512;       // 2 resident workgroups per CU (64 KiB of operand stages each)
+#if !defined(BTS_HOST_EMU)      // (tests/hip_emu: MFMA, LDS-DMA and inline assembly have no CPU stand-in -- the emulated library serves the DENSE appearance mode only)
 // ---- appearance pre-filter: int8 MFMA GEMM with prefix exits + exact float32 refine -----------------------------
 // Stage-1 appearance can change a cost only where  min(1 - body_sim, 1 - face_sim) <= appearance_thresh
 // (D:1543-1547), i.e. for similarities >= 0.75 -- about one pair per detection out of N*M.  So the
@@ -875,8 +880,6 @@ __global__ __launch_bounds__(64) void tk_edges_grid(Dev d, bts_lap_work w) {
 // non-matching pairs are far from the gate that is after ~5/16 of K; the survivors of an early stop are candidates
 // like the others (a superset -- the exact refinement decides).
 typedef int i32x16 __attribute__((ext_vector_type(16)));
-constexpr int FBM = 128, FBN = 128;      // tile of the pre-filter GEMM
-constexpr int DBK = feat::I8_STAGE;      // its K step: 128 int8 elements = one full 128-byte line per row and stage
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, slot = bid / 8;
@@ -1089,7 +1092,6 @@ __global__ __launch_bounds__(256) void k_filter_splitk(Dev d, int m_max, int nti
 // that opens a tile (index lists -> row pointers -> first stage) is taken off the tile's critical path: the NEXT tile's
 // indices are fetched while the current K loop runs, and its first stage is issued before the current tile's last
 // candidate test (the operand buffer it lands in is idle then).
-constexpr int FILTER_PW = 512;       // 2 resident workgroups per CU (64 KiB of operand stages each)
 enum { FS_STAGES = 0, FS_TILES, FS_EARLY, FS_CAND, FS_CHECKS };     // ([5..7]: clock cycles / 64 in candidate tests, stage waits, in total, summed over the workgroups)
 // KF_FIRST (opt-in, BTS_PREDICT_FIRST=1 at create; NOT yet measured): the Kalman-predict workgroups take the FRONT of the grid.
 // Every wave of this kernel is allocated its 244 VGPRs, so a predict workgroup cannot share a SIMD with two resident GEMM
@@ -1415,6 +1417,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int off = 32; off; off >>= 1) st_cand += __shfl_xor(st_cand, off);
     if (lane == 0 && st_cand) atomicAdd(&d.fstat[FS_CAND], st_cand);
 }
+
+#endif  // !BTS_HOST_EMU
 
 // ---- detection feature rows: in-place renormalisation (quirk Q8) ------------------------------------------
 __device__ __forceinline__ void renorm_body(const Dev &d, int blk) {        // four rows per 1024-thread workgroup
@@ -2020,6 +2024,9 @@ static int derive_sizes(const bts_tracker_config *cfg, Dev &d, int64_t *e_cap_ou
     d.record = cfg->record_costs ? 1 : 0;
     // the pre-filter works on 128-element K steps; other feature widths take the dense float32 path
     d.filter = (cfg->appearance_mode == BTS_APPEARANCE_FILTER && d.D % DBK == 0 && d.Df % DBK == 0) ? 1 : 0;
+#if defined(BTS_HOST_EMU)
+    d.filter = 0;       // (tests/hip_emu: no pre-filter GEMM on the CPU -- every tracker runs the dense float32 appearance path)
+#endif
     if (d.filter) {     // k_filter_i8 addresses the int8 shadows with 32-bit byte offsets (slot * dim)
         const uint64_t lim = 1ull << 32;
         BTS_REQUIRE((uint64_t)d.T * (uint64_t)d.D < lim && (uint64_t)d.Mx * (uint64_t)d.D < lim &&
@@ -2328,14 +2335,22 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
         static const int pw_forced = [] { const char *e = getenv("BTS_FILTER_PW"); return e ? atoi(e) : 0; }();
         const int pw = pw_forced > 0 ? pw_forced : FILTER_PW;
         const int gemm_blocks = ftiles < pw ? ftiles : pw;
+#if !defined(BTS_HOST_EMU)
         if (!accum && t->predict_first) { LAUNCH((k_filter_i8<false, 0, true>), dim3(gemm_blocks + kf_blocks), dim3(256), mc, ftiles, gemm_blocks); }
         else if (!accum) { LAUNCH(k_filter_i8<false>, dim3(gemm_blocks + kf_blocks), dim3(256), mc, ftiles, gemm_blocks); }
         else { LAUNCH(k_filter_splitk<false>, dim3(ftiles * split + kf_blocks), dim3(256), mc, ftiles, split); }
+#else
+        (void)gemm_blocks; bts_set_error("the CPU emulation has no pre-filter GEMM (appearance_mode must be DENSE)"); return BTS_EINVAL;
+#endif
         seg_end(BTS_SEG_K_FILTER);
         if (d.Df) {
             const int fsplit = split < bts_cdiv(d.Df, DBK) ? split : bts_cdiv(d.Df, DBK);
+#if !defined(BTS_HOST_EMU)
             if (!accum) { LAUNCH(k_filter_i8<true>, dim3(gemm_blocks), dim3(256), mc, ftiles, gemm_blocks); }
             else { LAUNCH(k_filter_splitk<true>, dim3(ftiles * fsplit), dim3(256), mc, ftiles, fsplit); }
+#else
+            (void)fsplit;
+#endif
         }
     } else {
         seg_begin(BTS_SEG_PREDICT);

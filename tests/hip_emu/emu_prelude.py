@@ -1,0 +1,67 @@
+"""TEST INFRASTRUCTURE: makes a CPU-only interpreter look like it has one GPU, for running the package against the CPU
+emulation of its kernels (tests/hip_emu/libbotsort_emu.so, selected through BTS_LIB_PATH).  "Device" memory of the emulated
+library is host memory, so torch CPU tensors stand in for CUDA tensors: `.cuda()`, `device="cuda"` and the stream / device
+queries are patched to no-ops.  Imported (as a pytest plugin: -p tests.hip_emu.emu_prelude) only by the child processes of
+tests/test_emu_*.py -- never by the product."""
+import os
+
+import torch
+
+assert os.environ.get("BTS_LIB_PATH", "").endswith("libbotsort_emu.so"), "the emulation prelude is for the emulated library only"
+
+
+class _Stream:
+    cuda_stream = 0
+
+    def synchronize(self):
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+class _Event:
+    def __init__(self, *a, **k):
+        pass
+
+    def record(self, *a, **k):
+        pass
+
+    def synchronize(self):
+        pass
+
+
+torch.cuda.is_available = lambda: True
+torch.cuda.device_count = lambda: 1
+torch.cuda.current_device = lambda: 0
+torch.cuda.set_device = lambda d: None
+torch.cuda.synchronize = lambda *a, **k: None
+torch.cuda.current_stream = lambda *a, **k: _Stream()
+torch.cuda.default_stream = lambda *a, **k: _Stream()
+torch.cuda.Stream = lambda *a, **k: _Stream()
+torch.cuda.set_stream = lambda s: None
+torch.cuda.stream = lambda s: _Stream()
+torch.cuda.Event = _Event
+torch.Tensor.cuda = lambda self, *a, **k: self.clone()       # (a host -> device copy is a COPY: kernels must not write into the caller's array)
+_to = torch.Tensor.to
+
+
+def _to_cpu(self, *a, **k):
+    k.pop("device", None)
+    a = tuple(x for x in a if not (isinstance(x, (str, torch.device)) and "cuda" in str(x)))
+    had_device = True
+    return _to(self, *a, **k).clone() if (a or k) else self.clone()
+
+
+torch.Tensor.to = _to_cpu
+for _name in ("empty", "zeros", "ones", "full", "tensor", "as_tensor"):
+    _orig = getattr(torch, _name)
+
+    def _wrap(*a, _o=_orig, **k):
+        if "cuda" in str(k.get("device", "")):
+            k.pop("device")
+        return _o(*a, **k)
+    setattr(torch, _name, _wrap)

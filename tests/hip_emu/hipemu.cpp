@@ -1,0 +1,200 @@
+// tests/hip_emu/hipemu.cpp -- TEST INFRASTRUCTURE: the scheduler of the CPU stand-in for HIP (hip/hip_runtime.h next to it).
+// One workgroup at a time; its threads are ucontext fibres run round-robin until each blocks at a rendezvous:
+//   * __syncthreads: released when every thread of the workgroup that has not returned waits at it;
+//   * a wavefront collective: lanes of one wavefront waiting at the SAME call site form a group; when every live lane of the
+//     wavefront is blocked (at a collective or at the workgroup barrier), the group with the lowest call-site id is served --
+//     its members are the "active lanes" of that instruction, exactly like an exec mask; diverged lanes wait their turn.
+#include "hip/hip_runtime.h"
+#include <ucontext.h>
+#include <sys/mman.h>
+#include <vector>
+
+namespace emu {
+
+enum State { READY, AT_BARRIER, AT_WAVE, DONE };
+struct Thread {
+    ucontext_t ctx;
+    int tid = 0;
+    State st = READY;
+    Op op = OP_SHFL;
+    int site = 0, arg = 0, arg2 = 0;
+    uint64_t value = 0, old = 0, result = 0;
+    int bar_val = 0;
+};
+
+static constexpr size_t STACK = 256 * 1024;
+static char *g_stacks = nullptr;
+static size_t g_nstacks = 0;
+static std::vector<Thread> g_th;
+static ucontext_t g_sched;
+static Thread *g_cur = nullptr;
+static dim3 g_bid, g_bdim, g_gdim;
+static const std::function<void()> *g_body = nullptr;
+alignas(64) static char g_dyn_lds[160 * 1024];
+static int g_bar_or = 0;
+
+Thread *cur() { return g_cur; }
+unsigned tid_x() { return (unsigned)g_cur->tid; }
+unsigned bid(int a) { return a == 0 ? g_bid.x : a == 1 ? g_bid.y : g_bid.z; }
+unsigned bdim(int a) { return a == 0 ? g_bdim.x : a == 1 ? g_bdim.y : g_bdim.z; }
+unsigned gdim(int a) { return a == 0 ? g_gdim.x : a == 1 ? g_gdim.y : g_gdim.z; }
+char *dynamic_lds() { return g_dyn_lds; }
+
+static void yield_to_scheduler() { swapcontext(&g_cur->ctx, &g_sched); }
+
+void barrier() {
+    g_cur->st = AT_BARRIER; g_cur->bar_val = 0;
+    yield_to_scheduler();
+}
+int barrier_or(int v) {
+    g_cur->st = AT_BARRIER; g_cur->bar_val = v;
+    yield_to_scheduler();
+    return g_bar_or;
+}
+uint64_t collective(Op op, int site, uint64_t value, int arg, int arg2, uint64_t old_value) {
+    Thread *t = g_cur;
+    t->op = op; t->site = site; t->value = value; t->arg = arg; t->arg2 = arg2; t->old = old_value; t->st = AT_WAVE;
+    yield_to_scheduler();
+    return t->result;
+}
+
+static void trampoline() {
+    (*g_body)();
+    g_cur->st = DONE;
+    swapcontext(&g_cur->ctx, &g_sched);
+}
+
+static int dpp_source(int lane, int ctrl, bool &valid) {       // source lane of a DPP control word, for `lane`
+    valid = true;
+    const int row = lane & ~15, r = lane & 15;
+    if (ctrl >= 0x00 && ctrl <= 0xFF) return (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);            // quad_perm
+    if (ctrl >= 0x101 && ctrl <= 0x10F) { const int n = ctrl & 15; valid = r + n <= 15; return lane + n; }   // row_shl
+    if (ctrl >= 0x111 && ctrl <= 0x11F) { const int n = ctrl & 15; valid = r >= n; return lane - n; }        // row_shr
+    if (ctrl >= 0x121 && ctrl <= 0x12F) { const int n = ctrl & 15; return row | ((r - n) & 15); }            // row_ror
+    if (ctrl == 0x140) return row | (15 - r);                                                                  // row_mirror
+    if (ctrl == 0x141) return (lane & ~7) | (7 - (lane & 7));                                                  // row_half_mirror
+    if (ctrl == 0x142) { valid = lane >= 16; return (row - 16) | 15; }                                         // row_bcast:15
+    if (ctrl == 0x143) { valid = lane >= 32; return 31; }                                                      // row_bcast:31
+    fprintf(stderr, "hipemu: DPP control 0x%x not emulated\n", ctrl);
+    abort();
+}
+
+static void serve_group(int wave_base, int nlanes, const std::vector<int> &members) {
+    Thread *th = &g_th[wave_base];
+    bool in[64] = {false};
+    for (int l : members) in[l] = true;
+    const Thread &first = th[members[0]];
+    const Op op = first.op;
+    uint64_t ballot = 0;
+    if (op == OP_BALLOT) for (int l : members) if (th[l].value) ballot |= 1ull << l;
+    for (int l : members) {
+        Thread &t = th[l];
+        switch (op) {
+        case OP_SHFL: { const int w = t.arg2, s = (l & ~(w - 1)) | (t.arg & (w - 1)); t.result = (s < nlanes && in[s]) ? th[s].value : t.value; break; }
+        case OP_SHFL_XOR: { const int s = l ^ t.arg; t.result = (s < nlanes && in[s] && (s & ~(t.arg2 - 1)) == (l & ~(t.arg2 - 1))) ? th[s].value : t.value; break; }
+        case OP_SHFL_UP: { const int w = t.arg2, s = l - t.arg; t.result = (s >= (l & ~(w - 1)) && in[s]) ? th[s].value : t.value; break; }
+        case OP_BALLOT: t.result = ballot; break;
+        case OP_READLANE: { const int s = t.arg & 63; t.result = (s < nlanes && in[s]) ? th[s].value : 0; break; }
+        case OP_READFIRST: t.result = first.value; break;
+        case OP_DPP: {
+            bool valid;
+            const int s = dpp_source(l, t.arg, valid);
+            const int row_mask = t.arg2 & 0xf;
+            const bool bound = (t.arg2 & 0x100) != 0;
+            if (!((row_mask >> (l >> 4)) & 1)) t.result = t.old;
+            else if (!valid || s < 0 || s >= 64 || !(s < nlanes && in[s])) t.result = bound ? 0 : t.old;
+            else t.result = th[s].value;
+            break;
+        }
+        case OP_WAVE_BARRIER: t.result = 0; break;
+        }
+    }
+    for (int l : members) th[l].st = READY;
+}
+
+static void run_block(int nthreads) {
+    if ((size_t)nthreads > g_nstacks) {
+        if (g_stacks) munmap(g_stacks, g_nstacks * STACK);
+        g_nstacks = (size_t)nthreads;
+        g_stacks = (char *)mmap(nullptr, g_nstacks * STACK, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (g_stacks == (char *)MAP_FAILED) { perror("hipemu: mmap"); abort(); }
+    }
+    g_th.assign((size_t)nthreads, Thread());
+    for (int t = 0; t < nthreads; ++t) {
+        Thread &T = g_th[t];
+        T.tid = t; T.st = READY;
+        getcontext(&T.ctx);
+        T.ctx.uc_stack.ss_sp = g_stacks + (size_t)t * STACK;
+        T.ctx.uc_stack.ss_size = STACK;
+        T.ctx.uc_link = &g_sched;
+        makecontext(&T.ctx, trampoline, 0);
+    }
+    const int nwaves = (nthreads + 63) / 64;
+    for (;;) {
+        bool progress = false, all_done = true;
+        for (int t = 0; t < nthreads; ++t) {
+            if (g_th[t].st == READY) {
+                g_cur = &g_th[t];
+                swapcontext(&g_sched, &g_th[t].ctx);
+                progress = true;
+            }
+            if (g_th[t].st != DONE) all_done = false;
+        }
+        if (all_done) return;
+        // wavefront collectives
+        bool served = false;
+        for (int w = 0; w < nwaves; ++w) {
+            const int base = w * 64, nl = std::min(64, nthreads - base);
+            int best = 0x7fffffff;
+            bool blocked = true, any = false;
+            for (int l = 0; l < nl; ++l) {
+                const Thread &T = g_th[base + l];
+                if (T.st == READY) blocked = false;
+                if (T.st == AT_WAVE) { any = true; best = std::min(best, T.site); }
+            }
+            if (!blocked || !any) continue;
+            std::vector<int> members;
+            for (int l = 0; l < nl; ++l) if (g_th[base + l].st == AT_WAVE && g_th[base + l].site == best) members.push_back(l);
+            serve_group(base, nl, members);
+            served = true;
+        }
+        if (served) continue;
+        // workgroup barrier
+        bool all_bar = true;
+        int orv = 0;
+        for (int t = 0; t < nthreads; ++t) {
+            if (g_th[t].st == DONE) continue;
+            if (g_th[t].st != AT_BARRIER) all_bar = false;
+            orv |= g_th[t].bar_val;
+        }
+        if (all_bar) {
+            g_bar_or = orv != 0;
+            for (int t = 0; t < nthreads; ++t) if (g_th[t].st == AT_BARRIER) g_th[t].st = READY;
+            continue;
+        }
+        if (!progress) {
+            fprintf(stderr, "hipemu: deadlock in block (%u,%u,%u): ", g_bid.x, g_bid.y, g_bid.z);
+            for (int t = 0; t < nthreads && t < 128; ++t) fprintf(stderr, "%d", (int)g_th[t].st);
+            fprintf(stderr, "\n");
+            abort();
+        }
+    }
+}
+
+void launch(dim3 grid, dim3 block, size_t dyn_lds, const std::function<void()> &body) {
+    if (g_cur) { fprintf(stderr, "hipemu: nested launch\n"); abort(); }
+    if (dyn_lds > sizeof(g_dyn_lds)) { fprintf(stderr, "hipemu: %zu bytes of dynamic LDS\n", dyn_lds); abort(); }
+    g_body = &body;
+    g_gdim = grid; g_bdim = block;
+    const int nthreads = (int)(block.x * block.y * block.z);
+    for (unsigned z = 0; z < grid.z; ++z)
+        for (unsigned y = 0; y < grid.y; ++y)
+            for (unsigned x = 0; x < grid.x; ++x) {
+                g_bid = dim3(x, y, z);
+                run_block(nthreads);
+            }
+    g_cur = nullptr;
+    g_body = nullptr;
+}
+
+}  // namespace emu
