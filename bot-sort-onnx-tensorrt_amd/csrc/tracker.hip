@@ -867,7 +867,8 @@ __global__ __launch_bounds__(64) void tk_edges_grid(Dev d, bts_lap_work w) {
 constexpr int FBM = 128, FBN = 128;      // tile of the pre-filter GEMM
 constexpr int DBK = feat::I8_STAGE;      // its K step: 128 int8 elements = one full 128-byte line per row and stage
 constexpr int FILTER_PW = 512;       // 2 resident workgroups per CU (64 KiB of operand stages each)
-#if !defined(BTS_HOST_EMU)      // (tests/hip_emu: MFMA, LDS-DMA and inline assembly have no CPU stand-in -- the emulated library serves the DENSE appearance mode only)
+enum { FS_STAGES = 0, FS_TILES, FS_EARLY, FS_CAND, FS_CHECKS };     // ([5..7]: clock cycles / 64 in candidate tests, stage waits, in total, summed over the workgroups)
+#if !defined(BTS_HOST_EMU)      // (tests/hip_emu: MFMA, LDS-DMA and inline assembly have no CPU stand-in -- contract-level stand-ins of the two kernels follow in the #else)
 // ---- appearance pre-filter: int8 MFMA GEMM with prefix exits + exact float32 refine -----------------------------
 // Stage-1 appearance can change a cost only where  min(1 - body_sim, 1 - face_sim) <= appearance_thresh
 // (D:1543-1547), i.e. for similarities >= 0.75 -- about one pair per detection out of N*M.  So the
@@ -1092,7 +1093,6 @@ __global__ __launch_bounds__(256) void k_filter_splitk(Dev d, int m_max, int nti
 // that opens a tile (index lists -> row pointers -> first stage) is taken off the tile's critical path: the NEXT tile's
 // indices are fetched while the current K loop runs, and its first stage is issued before the current tile's last
 // candidate test (the operand buffer it lands in is idle then).
-enum { FS_STAGES = 0, FS_TILES, FS_EARLY, FS_CAND, FS_CHECKS };     // ([5..7]: clock cycles / 64 in candidate tests, stage waits, in total, summed over the workgroups)
 // KF_FIRST (opt-in, BTS_PREDICT_FIRST=1 at create; NOT yet measured): the Kalman-predict workgroups take the FRONT of the grid.
 // Every wave of this kernel is allocated its 244 VGPRs, so a predict workgroup cannot share a SIMD with two resident GEMM
 // workgroups: behind them (the default) the predict work runs when the persistent GEMM workgroups retire, i.e. it is added to
@@ -1418,6 +1418,65 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (lane == 0 && st_cand) atomicAdd(&d.fstat[FS_CAND], st_cand);
 }
 
+#else   // BTS_HOST_EMU ------------------------------------------------------------------------------------------------
+// Contract-level stand-ins of the two pre-filter kernels for the CPU emulation (tests/hip_emu): same grids, same inputs
+// (the int8 shadows and records tk_front / tk_mid1 / copy_shadow maintain), same outputs (candidate bitmap resp. integer
+// accumulators, predict workgroups riding along) -- but a plain loop instead of the MFMA GEMM, and the exclusion rule applied
+// per pair on the FULL row (feat::i8_excluded with the full-row records).  The real kernel stops tiles at prefix checkpoints
+// and tests against per-tile summaries, so its candidate set is a superset of this one; both sets are supersets of the pairs
+// that reach the gate as long as the rule is sound, which is what the tests on top (FILTER vs DENSE vs the oracle) check.
+template <bool FACE, int VAR = 0, bool KF_FIRST = false>
+__global__ __launch_bounds__(256) void k_filter_i8(Dev d, int m_max, int ntiles, int gemm_blocks) {
+    const int kf_front = KF_FIRST ? (int)gridDim.x - gemm_blocks : 0;
+    if (KF_FIRST ? (int)blockIdx.x < kf_front : (int)blockIdx.x >= gemm_blocks) {
+        if (!FACE) predict_body(d, KF_FIRST ? (int)blockIdx.x : (int)blockIdx.x - gemm_blocks);
+        return;
+    }
+    const int n = d.hdr[H_NPOOL], m = d.hdr[H_NHI];
+    const int Dd = FACE ? d.Df : d.D;
+    const int8_t *A = FACE ? d.face_h : d.body_h, *B = FACE ? d.dface_h : d.det_h;
+    const float *ma = FACE ? d.face_m : d.body_m, *mb = FACE ? d.dface_m : d.det_m;
+    const int nbn = (m_max + FBN - 1) / FBN;
+    int cand = 0;
+    for (int vt = (int)blockIdx.x - kf_front; vt < ntiles; vt += gemm_blocks) {
+        const int bm = vt / nbn, bn = vt % nbn;
+        for (int p = threadIdx.x; p < FBM * FBN; p += blockDim.x) {
+            const int i = bm * FBM + p / FBN, q = bn * FBN + p % FBN;
+            if (i >= n || q >= m) continue;
+            const long slot = d.pool_slot[i], det = d.hi_idx[q];
+            int dot = 0;
+            for (int k = 0; k < Dd; ++k) dot += (int)A[slot * Dd + k] * (int)B[det * Dd + k];
+            if (!feat::i8_excluded(dot, feat::i8_rec(ma + slot * feat::I8_META, feat::I8_NCHK), feat::i8_rec(mb + det * feat::I8_META, feat::I8_NCHK))) {
+                atomicOr(&d.cbits[(long)i * d.cb_ld + (q >> 5)], 1u << (q & 31));
+                ++cand;
+            }
+        }
+    }
+    if (cand) atomicAdd(&d.fstat[FS_CAND], cand);
+    if (threadIdx.x == 0 && (int)blockIdx.x == kf_front) { atomicAdd(&d.fstat[FS_TILES], ntiles); atomicAdd(&d.fstat[FS_STAGES], ntiles * (Dd / DBK)); }
+}
+template <bool FACE>
+__global__ __launch_bounds__(256) void k_filter_splitk(Dev d, int m_max, int ntiles, int nsplit) {
+    if ((int)blockIdx.x >= ntiles * nsplit) {
+        if (!FACE) predict_body(d, (int)blockIdx.x - ntiles * nsplit);
+        return;
+    }
+    if ((int)blockIdx.x / ntiles != 0) return;                       // (the first K split of a tile adds the whole product)
+    const int n = d.hdr[H_NPOOL], m = d.hdr[H_NHI];
+    const int Dd = FACE ? d.Df : d.D;
+    const int8_t *A = FACE ? d.face_h : d.body_h, *B = FACE ? d.dface_h : d.det_h;
+    int32_t *approx = FACE ? d.approx_f : d.approx;
+    const int nbn = (m_max + FBN - 1) / FBN;
+    const int vt = (int)blockIdx.x % ntiles, bm = vt / nbn, bn = vt % nbn;
+    for (int p = threadIdx.x; p < FBM * FBN; p += blockDim.x) {
+        const int i = bm * FBM + p / FBN, q = bn * FBN + p % FBN;
+        if (i >= n || q >= m) continue;
+        const long slot = d.pool_slot[i], det = d.hi_idx[q];
+        int dot = 0;
+        for (int k = 0; k < Dd; ++k) dot += (int)A[slot * Dd + k] * (int)B[det * Dd + k];
+        atomicAdd(&approx[(long)i * d.Mx + q], dot);
+    }
+}
 #endif  // !BTS_HOST_EMU
 
 // ---- detection feature rows: in-place renormalisation (quirk Q8) ------------------------------------------
@@ -2024,9 +2083,6 @@ static int derive_sizes(const bts_tracker_config *cfg, Dev &d, int64_t *e_cap_ou
     d.record = cfg->record_costs ? 1 : 0;
     // the pre-filter works on 128-element K steps; other feature widths take the dense float32 path
     d.filter = (cfg->appearance_mode == BTS_APPEARANCE_FILTER && d.D % DBK == 0 && d.Df % DBK == 0) ? 1 : 0;
-#if defined(BTS_HOST_EMU)
-    d.filter = 0;       // (tests/hip_emu: no pre-filter GEMM on the CPU -- every tracker runs the dense float32 appearance path)
-#endif
     if (d.filter) {     // k_filter_i8 addresses the int8 shadows with 32-bit byte offsets (slot * dim)
         const uint64_t lim = 1ull << 32;
         BTS_REQUIRE((uint64_t)d.T * (uint64_t)d.D < lim && (uint64_t)d.Mx * (uint64_t)d.D < lim &&
@@ -2335,22 +2391,14 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
         static const int pw_forced = [] { const char *e = getenv("BTS_FILTER_PW"); return e ? atoi(e) : 0; }();
         const int pw = pw_forced > 0 ? pw_forced : FILTER_PW;
         const int gemm_blocks = ftiles < pw ? ftiles : pw;
-#if !defined(BTS_HOST_EMU)
         if (!accum && t->predict_first) { LAUNCH((k_filter_i8<false, 0, true>), dim3(gemm_blocks + kf_blocks), dim3(256), mc, ftiles, gemm_blocks); }
         else if (!accum) { LAUNCH(k_filter_i8<false>, dim3(gemm_blocks + kf_blocks), dim3(256), mc, ftiles, gemm_blocks); }
         else { LAUNCH(k_filter_splitk<false>, dim3(ftiles * split + kf_blocks), dim3(256), mc, ftiles, split); }
-#else
-        (void)gemm_blocks; bts_set_error("the CPU emulation has no pre-filter GEMM (appearance_mode must be DENSE)"); return BTS_EINVAL;
-#endif
         seg_end(BTS_SEG_K_FILTER);
         if (d.Df) {
             const int fsplit = split < bts_cdiv(d.Df, DBK) ? split : bts_cdiv(d.Df, DBK);
-#if !defined(BTS_HOST_EMU)
             if (!accum) { LAUNCH(k_filter_i8<true>, dim3(gemm_blocks), dim3(256), mc, ftiles, gemm_blocks); }
             else { LAUNCH(k_filter_splitk<true>, dim3(ftiles * fsplit), dim3(256), mc, ftiles, fsplit); }
-#else
-            (void)fsplit;
-#endif
         }
     } else {
         seg_begin(BTS_SEG_PREDICT);

@@ -62,6 +62,10 @@ void launch(dim3 grid, dim3 block, size_t dyn_lds, const std::function<void()> &
 void barrier();                                  // __syncthreads
 int barrier_or(int v);
 char *dynamic_lds();
+// A thread that keeps spinning on something another WORKGROUP has to write (workgroups run one at a time here): after a few
+// spins the whole workgroup is abandoned and re-run from its start once the rest of the launch has run -- valid because
+// everything this code base does in front of such a wait is idempotent (counting, and a publish of the same value).
+void spin();
 // wavefront collectives: every participating lane calls with the same `site`
 enum Op { OP_SHFL, OP_SHFL_XOR, OP_SHFL_UP, OP_BALLOT, OP_READLANE, OP_READFIRST, OP_DPP, OP_WAVE_BARRIER };
 uint64_t collective(Op op, int site, uint64_t value, int arg, int arg2, uint64_t old_value);
@@ -83,7 +87,7 @@ static inline void __syncthreads() { emu::barrier(); }
 static inline int __syncthreads_or(int v) { return emu::barrier_or(v); }
 static inline void __threadfence() {}
 #define __builtin_amdgcn_fence(...) ((void)0)
-#define __builtin_amdgcn_s_sleep(n) ((void)0)
+#define __builtin_amdgcn_s_sleep(n) emu::spin()      /* only used inside spin-waits on another workgroup */
 #define __builtin_amdgcn_wave_barrier() ((void)emu::collective(emu::OP_WAVE_BARRIER, __COUNTER__, 0, 0, 0, 0))
 static inline unsigned long long __builtin_amdgcn_s_memrealtime() { static unsigned long long t = 0; return t += 1; }
 #define __ATOMIC_RELAXED_EMU 0

@@ -32,6 +32,8 @@ static dim3 g_bid, g_bdim, g_gdim;
 static const std::function<void()> *g_body = nullptr;
 alignas(64) static char g_dyn_lds[160 * 1024];
 static int g_bar_or = 0;
+static int g_spins = 0;
+static bool g_defer = false;
 
 Thread *cur() { return g_cur; }
 unsigned tid_x() { return (unsigned)g_cur->tid; }
@@ -56,6 +58,12 @@ uint64_t collective(Op op, int site, uint64_t value, int arg, int arg2, uint64_t
     t->op = op; t->site = site; t->value = value; t->arg = arg; t->arg2 = arg2; t->old = old_value; t->st = AT_WAVE;
     yield_to_scheduler();
     return t->result;
+}
+
+void spin() {
+    if (++g_spins < 64) return;
+    g_defer = true;
+    swapcontext(&g_cur->ctx, &g_sched);          // never resumed: the scheduler drops the workgroup and re-runs it later
 }
 
 static void trampoline() {
@@ -112,7 +120,8 @@ static void serve_group(int wave_base, int nlanes, const std::vector<int> &membe
     for (int l : members) th[l].st = READY;
 }
 
-static void run_block(int nthreads) {
+static bool run_block(int nthreads) {        // false: the workgroup was deferred (it waits for workgroups that have not run yet)
+    g_spins = 0; g_defer = false;
     if ((size_t)nthreads > g_nstacks) {
         if (g_stacks) munmap(g_stacks, g_nstacks * STACK);
         g_nstacks = (size_t)nthreads;
@@ -136,11 +145,12 @@ static void run_block(int nthreads) {
             if (g_th[t].st == READY) {
                 g_cur = &g_th[t];
                 swapcontext(&g_sched, &g_th[t].ctx);
+                if (g_defer) return false;
                 progress = true;
             }
             if (g_th[t].st != DONE) all_done = false;
         }
-        if (all_done) return;
+        if (all_done) return true;
         // wavefront collectives
         bool served = false;
         for (int w = 0; w < nwaves; ++w) {
@@ -187,12 +197,19 @@ void launch(dim3 grid, dim3 block, size_t dyn_lds, const std::function<void()> &
     g_body = &body;
     g_gdim = grid; g_bdim = block;
     const int nthreads = (int)(block.x * block.y * block.z);
+    std::vector<dim3> todo, later;
     for (unsigned z = 0; z < grid.z; ++z)
         for (unsigned y = 0; y < grid.y; ++y)
-            for (unsigned x = 0; x < grid.x; ++x) {
-                g_bid = dim3(x, y, z);
-                run_block(nthreads);
-            }
+            for (unsigned x = 0; x < grid.x; ++x) todo.push_back(dim3(x, y, z));
+    while (!todo.empty()) {
+        later.clear();
+        for (const dim3 &b : todo) {
+            g_bid = b;
+            if (!run_block(nthreads)) later.push_back(b);
+        }
+        if (later.size() == todo.size()) { fprintf(stderr, "hipemu: %zu workgroups wait for each other forever\n", later.size()); abort(); }
+        todo = later;
+    }
     g_cur = nullptr;
     g_body = nullptr;
 }
