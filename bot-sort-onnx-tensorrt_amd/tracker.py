@@ -774,6 +774,7 @@ class BoTSORT:
         self.lazy_lists, self.keep_removed_state = bool(lazy_lists), bool(keep_removed_state)
         self._epoch, self._snap = 0, None
         self._removed_live = set()      # ids appended to removed_stracks that are still on a list (Q6: for one more frame)
+        self._repeats = []              # (id, mirror) of expired lost tracks the reference appends a second time this frame
         self.tracked_stracks: List[STrack] = []
         self.lost_stracks: List[STrack] = []
         self.removed_stracks: List[STrack] = []
@@ -862,15 +863,26 @@ class BoTSORT:
         self.lost_stracks = TrackList(self, snap, 1)
         # removed_stracks.extend(removed_stracks) of D:1635 happens in the frame that marks a track removed; an expired lost
         # track stays on lost_stracks for that one frame (it is filtered against the PREVIOUS removals, Q6): it shows up here
-        # as a lost row in state Removed.  (Unconfirmed tracks that stage 3 left unmatched leave the lists at once: they were
-        # appended by _finalise_vanished above -- the reference appends them first too.)
+        # as a lost row in state Removed.  The frame after, the expiry loop (D:1623-1627) runs over it once more -- it is
+        # appended a SECOND time -- and only then does it leave the list: _finalise_vanished above parked those repeats in
+        # self._repeats; both kinds are appended in the order of the loop, i.e. of the previous frame's lost list.
+        # (Unconfirmed tracks that stage 3 left unmatched leave the lists at once: they were appended by _finalise_vanished
+        # -- the reference appends them first too.)
         lost_ints = snap.ints[1]
+        fresh = []
         if len(lost_ints):
             for k in np.nonzero(lost_ints[:, 1] == TrackState.Removed)[0].tolist():
                 tid = int(lost_ints[k, 0])
                 if tid not in self._removed_live:
                     self._removed_live.add(tid)
-                    self.removed_stracks.append(self._mirror_at(snap, 1, k))
+                    fresh.append((tid, self._mirror_at(snap, 1, k)))
+        repeats, self._repeats = self._repeats, []
+        if repeats and fresh:
+            order = {int(t): i for i, t in enumerate(prev.ints[1][:, 0].tolist())}
+            both = sorted(repeats + fresh, key=lambda e: order.get(e[0], len(order)))
+        else:
+            both = repeats or fresh
+        self.removed_stracks.extend(st for _, st in both)
         if self._removed_live:
             # a removed track that is matched again before it is filtered out is tracked again (the reference's "zombie":
             # the same object stays on removed_stracks, and may be appended once more when it is removed again)
@@ -927,9 +939,9 @@ class BoTSORT:
             removed = dev_id[slot] == tid and dev_state[slot] == TrackState.Removed
             st = self._mirror.pop(tid, None)
             if st is None:
-                if not removed or tid in self._removed_live:
+                if not removed:
                     self._removed_live.discard(tid)
-                    continue                # never handed out and not (newly) removed: nobody can refer to it
+                    continue                # never handed out and not removed: nobody can refer to it
                 st = STrack._new_mirror(self, tid)
             st._bind(prev, 0 if r < n0 else 1, r if r < n0 else r - n0)
             d = st.__dict__
@@ -941,8 +953,9 @@ class BoTSORT:
             d["_live"] = False
             if removed:
                 d["state"] = TrackState.Removed
-                if tid in self._removed_live:
-                    self._removed_live.discard(tid)       # (already appended in the frame that removed it)
+                self._removed_live.discard(tid)
+                if r >= n0:       # off the lost list: expired last frame (appended then, and once more now) or expired and
+                    self._repeats.append((tid, st))      # dropped as a duplicate in one frame -- _export puts it in loop order
                 else:
                     self.removed_stracks.append(st)
 

@@ -3,6 +3,7 @@ across frames, the bulk detection of removed / dropped tracks.  The device track
 `export_lists / read_column / read_slot / counts` from the CPU oracle (tests may use the oracle; the product never does);
 the GPU tests (tests/test_gpu_round2.py) run the same facade over the real device tracker."""
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -202,3 +203,25 @@ def test_zombie_refound_after_removal_like_the_reference(bot):
         if f == 34:
             assert ora.removed[0] in ora.tracked, "... and re-find it at frame 34"
             assert zombie.state == pkg.TrackState.Tracked and any(t is zombie for t in out) and b.removed_stracks[0] is zombie
+
+
+def test_expired_lost_tracks_are_appended_twice_like_the_reference(bot):
+    """D:1623-1627 runs over lost_stracks as the frame found it: a track that expired the frame before is still there (Q6), is
+    marked removed and appended AGAIN, and only then filtered.  The recorded lifecycle stream has such repeats (and frames where
+    a repeat and a first expiry interleave in lost-list order): removed_stracks must equal the reference's list on every frame."""
+    import collections
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g6_lifecycle.npz"))
+    K, M, D, frames = int(g["K"]), int(g["M"]), int(g["D"]), int(g["frames"])
+    b = bot(frame_rate=int(g["frame_rate"]), max_tracks=4096, max_dets=max(K, M) + 8, feat_dim=D)   # (the double never recycles slots)
+    st = pkg.synth.SyntheticStream(K, M, D, seed=int(g["seed"]), churn=float(g["churn"]))
+    ora = b.device_tracker.ora
+    for f in range(frames):
+        fr = st.next()
+        b.update_arrays(fr.boxes, fr.scores, fr.feats)
+        assert len(ora.removed) == int(g["f%d_n_removed" % f]), "the oracle itself must follow the recorded reference"
+        assert [t.track_id for t in b.removed_stracks] == [t.track_id for t in ora.removed], f
+    twice = [k for k, v in collections.Counter(t.track_id for t in ora.removed).items() if v > 1]
+    assert len(twice) >= 3, "the stream must exercise the repeats"
+    for tid in twice:
+        objs = [t for t in b.removed_stracks if t.track_id == tid]
+        assert all(o is objs[0] for o in objs), "the reference appends the same object"
