@@ -578,6 +578,26 @@ __device__ __forceinline__ double wave_min_d(double d, int cn) {
     return bcast_d(d, 0);
 }
 
+// Step counters of the component solvers: emulator build only (tests/hip_emu; scripts/lap_steps_cpu.py reads them) -- the
+// device build compiles LSTAT to nothing.
+#if defined(BTS_HOST_EMU)
+static long long g_lapstat[16];
+extern "C" void bts_emu_lap_stats(long long *out, int reset) {
+    for (int k = 0; k < 16; ++k) { if (out) out[k] = g_lapstat[k]; if (reset) g_lapstat[k] = 0; }
+}
+#define LSTAT(k, n) do { if (lane == 0) g_lapstat[k] += (n); } while (0)
+#define LSTAT_MAX(k, n) do { if (lane == 0 && g_lapstat[k] < (n)) g_lapstat[k] = (n); } while (0)
+#define LSTAT_DECL(v) long long v = 0
+#define LSTAT_INC(v) (++v)
+#else
+#define LSTAT_DECL(v)
+#define LSTAT_INC(v)
+#define LSTAT(k, n) do { } while (0)
+#define LSTAT_MAX(k, n) do { } while (0)
+#endif
+enum { LS_PACKED = 0, LS_TALL = 1, LS_GLOBAL = 2, LS_AUG = 3, LS_STEPS = 4, LS_RELAX = 5, LS_TALL_AUG = 6, LS_TALL_STEPS = 7, LS_TALL_RELAX = 8,
+       LS_MAX_COMP_STEPS = 9, LS_PATH = 10, LS_TALL_PRELUDE = 11 };
+
 // ---- 3. one wavefront per packed component: shortest augmenting paths ---------------------------------
 constexpr int DN_R = 8, DN_C = 32;   // components up to DN_R x DN_C also get a dense cost block
 struct SmallLds {                    // per-wavefront adjacency copy
@@ -604,6 +624,7 @@ __device__ __forceinline__ bool solve_packed(const LapArgs &A, int c, int lane, 
     const int rs = d.x, cs = d.y, r = d.z & 0xff, cn = (d.z >> 8) & 0xff, ne = d.z >> 16, eb = d.w;
     if (r > 64 || cn > 64 || ne > SM_EDGES) return false;
     const bool dense = r <= DN_R && cn <= DN_C && ne <= DN_R * DN_C;
+    LSTAT(LS_PACKED, 1);
     double *ecs = dense ? L.ecost + DN_R * DN_C : L.ecost;
     const int4 ri = lane < r ? w.rowinfo[rs + lane] : make_int4(0x7fffffff, 0, 0, 0);
     const int my_col = lane < cn ? w.colid[cs + lane] : 0x7fffffff;
@@ -642,7 +663,9 @@ __device__ __forceinline__ bool solve_packed(const LapArgs &A, int c, int lane, 
             double exit_d = limit - bcast_d(u, i0);
             int exit_row = i0, cur = i0, end_col = -1;
             double dcur = 0.0, mu = 0.0;
+            LSTAT(LS_AUG, 1);
             for (;;) {
+                LSTAT(LS_STEPS, 1);
                 relax(cur, bcast_d(u, cur), dcur, dist, pred, scanned);
                 const bool cand = lane < cn && !scanned;
                 const double bd = wave_min_d(cand ? dist : INF, cn);
@@ -696,6 +719,7 @@ __device__ __forceinline__ bool solve_packed(const LapArgs &A, int c, int lane, 
     } else {
         run([&](int cur, double ucur, double dcur, double &dist, int &pred, bool scanned) {
             const int e0 = bcast_i(e_lo, cur), e1 = bcast_i(e_hi, cur);
+            LSTAT(LS_RELAX, e1 - e0);
             for (int e = e0; e < e1; ++e) {
                 if (L.ecol[e] == lane && !scanned) {
                     const double nd = dcur + ((ecs[e] - ucur) - v);
@@ -726,6 +750,9 @@ __device__ __forceinline__ bool solve_packed_tall(const LapArgs &A, int c, int l
     const int4 d = w.cdesc[c];
     const int rs = d.x, cs = d.y, r = d.z & 0xff, cn = (d.z >> 8) & 0xff, ne = d.z >> 16, eb = d.w;
     if (r >= TALL_R + 1 || cn > 64 || ne > SM_EDGES) return false;
+    LSTAT(LS_TALL, 1);
+    LSTAT(LS_TALL_PRELUDE, 2 * r);
+    LSTAT_DECL(steps_here);
     int4 ri[TALL_S];
 #pragma unroll
     for (int s = 0; s < TALL_S; ++s) ri[s] = lane + 64 * s < r ? w.rowinfo[rs + lane + 64 * s] : make_int4(0x7fffffff, 0, 0, 0);
@@ -767,10 +794,14 @@ __device__ __forceinline__ bool solve_packed_tall(const LapArgs &A, int c, int l
         double exit_d = limit - bcast_d(sel4(u, i0 >> 6), i0 & 63);
         int exit_row = i0, cur = i0, end_col = -1;
         double dcur = 0.0, mu = 0.0;
+        LSTAT(LS_TALL_AUG, 1);
         for (;;) {
             const int cs_ = cur >> 6, cl = cur & 63;
             const double ucur = bcast_d(sel4(u, cs_), cl);
             const int e0 = bcast_i(sel4(e_lo, cs_), cl), e1 = bcast_i(sel4(e_hi, cs_), cl);
+            LSTAT(LS_TALL_STEPS, 1);
+            LSTAT(LS_TALL_RELAX, e1 - e0);
+            LSTAT_INC(steps_here);
             for (int e = e0; e < e1; ++e) {
                 if (L.ecol[e] == lane && !scanned) {
                     const double nd = dcur + ((L.ecost[e] - ucur) - v);
@@ -835,6 +866,171 @@ __device__ __forceinline__ bool solve_packed_tall(const LapArgs &A, int c, int l
         for (int s = 0; s < TALL_S; ++s) { const int t = __shfl(my_row[s], yl); if (ys == s) yrow = t; }
         if (lane < cn) A.y[my_col] = yc >= 0 ? yrow : -1;
     }
+    LSTAT_MAX(LS_MAX_COMP_STEPS, steps_here);
+    lds_sync();                 // the next component of this wavefront reuses L
+    return true;
+}
+
+// Tall components, COLUMN form (round 3; the row form above is kept for A/B: -DBTS_LAP_TALL_ROWFORM).  A tall component has
+// more rows than columns (r > 64 >= cn; dense crowds: 100-250 track rows around 20-60 detections), and most of its rows
+// end unmatched.  The row form pays one shortest-path search per ROW; this one starts with every row on its private exit
+// (u = limit, tight) and runs one search per COLUMN over the rows -- cn searches instead of r, and short ones, because a
+// search ends at the first row that is still on its exit.  Same objective, same optimum (unique unless costs tie).
+// State: rows in LDS, indexed by the row's rank in ascending id order (u, dist, pred, partner, scanned); columns one per
+// lane in registers (v, partner).  The adjacency is re-sorted by column (CSC) so that relaxing from a column is one
+// parallel pass of the lanes over that column's edges.  Tie-breaking: columns in ascending id order, the smallest row on
+// equal distance, a match preferred over leaving the column free on equality.
+struct TallLds {
+    double ecost[SM_EDGES];                      // by column
+    double u[256], dist[256];                    // (dist doubles as the id table of the ranking pass, u as the column counters)
+    uint8_t erow[SM_EDGES];
+    uint8_t pred[256], xr[256], scanned[256];    // pred: column lane; xr: column lane or TALL_NONE
+    uint16_t cptr[66];
+};
+constexpr int TALL_NONE = 255;
+constexpr int COLFORM_MIN_ROWS = 16;      // components with more rows than this AND more rows than columns take the column form
+union WaveLds { SmallLds s; TallLds t; };        // one stride for both layouts: wavefronts of a workgroup use either
+
+__device__ __forceinline__ bool solve_tall_cols(const LapArgs &A, int c, int lane, TallLds &L) {
+    const bts_lap_work &w = A.w;
+    const double limit = A.limit, INF = __builtin_huge_val();
+    const int4 d = w.cdesc[c];
+    const int rs = d.x, cs = d.y, r = d.z & 0xff, cn = (d.z >> 8) & 0xff, ne = d.z >> 16;
+    if (r >= TALL_R + 1 || cn > 64 || ne > SM_EDGES) return false;
+    LSTAT(LS_TALL, 1);
+    LSTAT_DECL(steps_here);
+    int4 ri[TALL_S];
+    int rk[TALL_S];
+    int32_t *ids = reinterpret_cast<int32_t *>(L.dist), *cnt = reinterpret_cast<int32_t *>(L.u);
+#pragma unroll
+    for (int s = 0; s < TALL_S; ++s) {
+        const int k = lane + 64 * s;
+        ri[s] = k < r ? w.rowinfo[rs + k] : make_int4(0x7fffffff, 0, 0, 0);
+        rk[s] = 0;
+        if (k < r) ids[k] = ri[s].x;
+    }
+    cnt[lane] = 0;
+    const int my_col = lane < cn ? w.colid[cs + lane] : 0x7fffffff;
+    int crank = 0;
+    for (int q = 0; q < cn; ++q) crank += bcast_i(my_col, q) < my_col ? 1 : 0;
+    lds_sync();
+    for (int q = 0; q < r; ++q) {                 // rank = rows with a smaller id (LDS broadcast reads)
+        const int idq = ids[q];
+#pragma unroll
+        for (int s = 0; s < TALL_S; ++s) rk[s] += idq < ri[s].x ? 1 : 0;
+    }
+    // adjacency by column: count, scan, fill (the order of a column's edges does not matter: one edge per row)
+#pragma unroll
+    for (int s = 0; s < TALL_S; ++s)
+        for (int e = ri[s].y; e < ri[s].z; ++e) atomicAdd(&cnt[w.csr_lcol[e]], 1);
+    lds_sync();
+    {
+        const int deg = cnt[lane], incl = wave_incl_scan(deg);
+        lds_sync();
+        cnt[lane] = incl - deg;
+        L.cptr[lane] = (uint16_t)(incl - deg);
+        if (lane == 63) L.cptr[64] = (uint16_t)incl;
+    }
+    lds_sync();
+    double vmin = INF;                            // (kept per edge below, reduced per column afterwards)
+#pragma unroll
+    for (int s = 0; s < TALL_S; ++s)
+        for (int e = ri[s].y; e < ri[s].z; ++e) {
+            const int pos = atomicAdd(&cnt[w.csr_lcol[e]], 1);
+            L.ecost[pos] = w.csr_cost[e];
+            L.erow[pos] = (uint8_t)rk[s];
+        }
+    (void)vmin;
+    lds_sync();
+    // duals: every row on its exit (u = limit), v = column minimum - limit (<= 0: every edge costs <= limit)
+#pragma unroll
+    for (int s = 0; s < TALL_S; ++s) { const int k = lane + 64 * s; L.u[k] = limit; L.xr[k] = TALL_NONE; }
+    double v = 0.0;
+    {
+        double mn = limit;
+        for (int k = L.cptr[lane]; k < L.cptr[lane + 1]; ++k) mn = fmin(mn, L.ecost[k]);
+        v = mn - limit;
+    }
+    int yc = -1;                                  // column -> row rank
+    lds_sync();
+    for (int t = 0; t < cn; ++t) {
+        const int j0 = __ffsll((long long)__ballot(lane < cn && crank == t)) - 1;
+#pragma unroll
+        for (int s = 0; s < TALL_S; ++s) { const int k = lane + 64 * s; L.dist[k] = INF; L.scanned[k] = 0; }
+        lds_sync();
+        double exit_d = -bcast_d(v, j0), dcur = 0.0, mu = 0.0;
+        int exit_col = j0, cur = j0, end_row = -1;
+        LSTAT(LS_TALL_AUG, 1);
+        for (;;) {
+            const double vcur = bcast_d(v, cur);
+            const int k1 = L.cptr[cur + 1];
+            LSTAT(LS_TALL_STEPS, 1);
+            LSTAT(LS_TALL_RELAX, (k1 - L.cptr[cur] + 63) / 64);
+            LSTAT_INC(steps_here);
+            for (int k = L.cptr[cur] + lane; k < k1; k += 64) {
+                const int i = L.erow[k];
+                if (!L.scanned[i]) {
+                    const double nd = dcur + ((L.ecost[k] - L.u[i]) - vcur);
+                    if (nd < L.dist[i]) { L.dist[i] = nd; L.pred[i] = (uint8_t)cur; }
+                }
+            }
+            lds_sync();
+            double bl = INF;
+            int bi_l = 0x7fffffff;
+#pragma unroll
+            for (int s = 0; s < TALL_S; ++s) {
+                const int k = lane + 64 * s;
+                const double dd = (k < r && !L.scanned[k]) ? L.dist[k] : INF;
+                if (dd < bl) { bl = dd; bi_l = k; }
+            }
+            const double bd = wave_min_d(bl, 64);
+            if (!(bd < INF) || exit_d < bd) { mu = exit_d; break; }
+            const unsigned long long tie = __ballot(bl == bd);
+            int bi = bcast_i(bi_l, __ffsll((long long)tie) - 1);
+            if (tie & (tie - 1))
+                for (unsigned long long q = tie & (tie - 1); q; q &= q - 1) { const int o = bcast_i(bi_l, __ffsll((long long)q) - 1); bi = o < bi ? o : bi; }
+            const int own = L.xr[bi];
+            if (own == TALL_NONE) { mu = bd; end_row = bi; break; }
+            if (lane == 0) L.scanned[bi] = 1;
+            cur = own; dcur = bd;
+            const double e2 = bd - bcast_d(v, own);
+            if (e2 < exit_d) { exit_d = e2; exit_col = own; }
+            lds_sync();
+        }
+        // duals: every scanned row hands its delta to the column that owns it
+        if (lane < cn && yc >= 0 && L.scanned[yc]) v += mu - L.dist[yc];
+        if (lane == j0) v += mu;
+#pragma unroll
+        for (int s = 0; s < TALL_S; ++s) { const int k = lane + 64 * s; if (L.scanned[k]) L.u[k] -= mu - L.dist[k]; }
+        // augment
+        int i = end_row;
+        if (i < 0) {
+            if (exit_col == j0) { lds_sync(); continue; }
+            i = bcast_i(yc, exit_col);
+            if (lane == exit_col) yc = -1;
+        }
+        for (;;) {
+            const int j = L.pred[i];
+            const int prev = bcast_i(yc, j);
+            LSTAT(LS_PATH, 1);
+            if (lane == 0) L.xr[i] = (uint8_t)j;
+            if (lane == j) yc = i;
+            if (j == j0) break;
+            i = prev;
+        }
+        lds_sync();
+    }
+#pragma unroll
+    for (int s = 0; s < TALL_S; ++s) {
+        const int mine = lane + 64 * s < r ? L.xr[rk[s]] : TALL_NONE;
+        const int xcol = __shfl(my_col, mine != TALL_NONE ? mine : 0);
+        if (lane + 64 * s < r) {
+            A.x[ri[s].x] = mine != TALL_NONE ? xcol : -1;
+            if (mine != TALL_NONE) A.y[xcol] = ri[s].x;
+        }
+    }
+    if (lane < cn && yc < 0) A.y[my_col] = -1;
+    LSTAT_MAX(LS_MAX_COMP_STEPS, steps_here);
     lds_sync();                 // the next component of this wavefront reuses L
     return true;
 }
@@ -845,6 +1041,7 @@ __device__ __forceinline__ void solve_component(const LapArgs &A, int c, int lan
     const double limit = A.limit;
     const double INF = __builtin_huge_val();
     int32_t *x = A.x, *y = A.y;
+    LSTAT(LS_GLOBAL, 1);
     const int rs = LDG(&w.crow_ptr[c]), r = LDG(&w.crow_ptr[c + 1]) - rs;
     const int cs = LDG(&w.ccol_ptr[c]), cn = LDG(&w.ccol_ptr[c + 1]) - cs;
 
@@ -949,7 +1146,8 @@ __device__ __forceinline__ void solve_component(const LapArgs &A, int c, int lan
 // workgroups wait for hdr[H_READY] (1 + number of packed components) and share the components.
 constexpr int LAP_SOLO_EDGES = 64;   // edge lists up to this length are solved by the preparing workgroup alone
 constexpr int LAP_HELPERS = 15, LAP_HELPERS_BIG = 63;    // helper workgroups per problem (16 wavefronts each): small / big problems
-constexpr unsigned LAP_LDS_BYTES = sizeof(SmallPipe) > 16 * sizeof(SmallLds) ? sizeof(SmallPipe) : 16 * sizeof(SmallLds);
+constexpr unsigned LAP_LDS_BYTES = sizeof(SmallPipe) > 16 * sizeof(WaveLds) ? sizeof(SmallPipe) : 16 * sizeof(WaveLds);
+static_assert(LAP_LDS_BYTES + 4096 + 64 <= 160 * 1024, "k_lap: dynamic + static LDS exceed a CU's 160 KiB");
 
 struct LapPair { LapArgs p[2]; };     // (indexed by blockIdx.x straight out of the kernel-argument segment)
 
@@ -1013,10 +1211,20 @@ template <int EC> __global__ __launch_bounds__(1024) void k_lap(LapPair P) {
         TRH(w, 10);
     }
     if (C == 0) return;
-    SmallLds *lds = reinterpret_cast<SmallLds *>(lds_raw);
+    WaveLds *lds = reinterpret_cast<WaveLds *>(lds_raw);
     const int gw = blockIdx.y * (nth >> 6) + wid, nw = (solo ? 1 : gridDim.y) * (nth >> 6);
-    for (int c = gw; c < C; c += nw)
-        if (!solve_packed(A, c, lane, lds[wid]) && !solve_packed_tall(A, c, lane, lds[wid])) solve_component(A, c, lane);
+    for (int c = gw; c < C; c += nw) {
+#ifdef BTS_LAP_TALL_ROWFORM
+        if (solve_packed(A, c, lane, lds[wid].s) || solve_packed_tall(A, c, lane, lds[wid].s)) continue;
+#else
+        // one search per row (solve_packed) or per column (solve_tall_cols), whichever side is shorter; small components
+        // stay with the row form and its dense cost block
+        const int dz = w.cdesc[c].z, r_ = dz & 0xff, cn_ = (dz >> 8) & 0xff;
+        if (r_ > COLFORM_MIN_ROWS && r_ > cn_ ? solve_tall_cols(A, c, lane, lds[wid].t) : solve_packed(A, c, lane, lds[wid].s)) continue;
+        if (solve_tall_cols(A, c, lane, lds[wid].t)) continue;       // (more than 64 rows but not more rows than columns)
+#endif
+        solve_component(A, c, lane);
+    }
 #ifdef BTS_LAP_TRACE
     __syncthreads();
     if (blockIdx.y <= 1) TR(w, 11 + blockIdx.y);

@@ -7,6 +7,7 @@
 #include "hip/hip_runtime.h"
 #include <ucontext.h>
 #include <sys/mman.h>
+#include <mutex>
 #include <vector>
 
 namespace emu {
@@ -191,7 +192,10 @@ static bool run_block(int nthreads) {        // false: the workgroup was deferre
     }
 }
 
+static std::mutex g_launch_mu;      // host threads that drive several streams take turns: one launch at a time
+
 void launch(dim3 grid, dim3 block, size_t dyn_lds, const std::function<void()> &body) {
+    std::lock_guard<std::mutex> lock(g_launch_mu);
     if (g_cur) { fprintf(stderr, "hipemu: nested launch\n"); abort(); }
     if (dyn_lds > sizeof(g_dyn_lds)) { fprintf(stderr, "hipemu: %zu bytes of dynamic LDS\n", dyn_lds); abort(); }
     g_body = &body;

@@ -189,3 +189,43 @@ def test_opt_in_experiments_change_no_result(bts, monkeypatch, K, M, D):
             finally:
                 monkeypatch.delenv(env)
         _same_run(bts, fa, fb, mk, mk_exp)
+
+
+def _crowd_blocks(rng, shapes, limit):
+    """Block-diagonal cost matrix: every block a crowd-shaped component (rows = tracks around a few detections, each row
+    with 1-4 feasible columns of its block), continuous costs (no ties)."""
+    n, m = sum(s[0] for s in shapes), sum(s[1] for s in shapes)
+    c = np.ones((n, m))
+    r0 = c0 = 0
+    for r, cn, scarce in shapes:
+        for i in range(r):
+            # `scarce`: most rows crowd onto the first few columns, so that some columns lose every row they touch
+            pool = cn if not scarce or rng.uniform() < 0.3 else max(1, cn // 4)
+            deg = int(rng.integers(1, 5)) if r * 2.5 <= 480 else int(rng.integers(1, 3))      # (<= 512 edges per component)
+            for j in rng.choice(pool, size=min(pool, deg), replace=False):
+                c[r0 + i, c0 + j] = rng.uniform(0.02, limit - 0.01)
+        for j in range(cn):                       # every column touched (a column without edges is not part of a component)
+            if (c[r0:r0 + r, c0 + j] < 1.0).sum() == 0:
+                c[r0 + int(rng.integers(r)), c0 + j] = rng.uniform(0.02, limit - 0.01)
+        r0, c0 = r0 + r, c0 + cn
+    p, q = rng.permutation(n), rng.permutation(m)      # rows / columns of a component are not contiguous ids
+    return c[p][:, q]
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_lapjv_column_form_components_vs_oracle(bts, seed):
+    """Components with more rows than columns (dense crowds) are solved with one shortest-path search per COLUMN
+    (solve_tall_cols, lap.hip; round 3, never run on a GPU): 17 ... 254 rows around 3 ... 64 columns, up to 512 edges, with
+    columns that must stay free and searches that re-route earlier matches.  Tie-free costs: the optimum is unique, so the
+    indices must equal the oracle's dense JV.  Shapes with no more rows than columns (row form) ride along."""
+    from oracle import bts_oracle as bo
+    rng = np.random.default_rng(900 + seed)
+    shapes = [(17, 4, False), (40, 12, True), (64, 20, False), (65, 64, False), (120, 30, True), (200, 50, False),
+              (254, 64, False), (250, 8, True), (30, 40, False), (90, 3, True), (16, 5, False), (33, 33, False)]
+    order = rng.permutation(len(shapes))
+    limit = float(rng.choice([0.5, 0.8]))
+    c = _crowd_blocks(rng, [shapes[k] for k in order], limit)
+    _, xo, yo = bo.lapjv(c, True, limit)
+    _, x, y = bts.lapjv(c, True, limit)
+    assert np.array_equal(x, xo) and np.array_equal(y, yo), seed
+    assert (yo < 0).sum() > 0 and (xo < 0).sum() > 0, "the case must leave columns and rows unmatched"
