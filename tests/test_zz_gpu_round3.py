@@ -178,7 +178,7 @@ def test_opt_in_experiments_change_no_result(bts, monkeypatch, K, M, D):
     list and Kalman mean must be bit-identical to the default schedule.  Frames are resident before the steps are
     enqueued (the overlap mode's contract); each tracker gets its own copy of them (rows are renormalised in place)."""
     n = 14
-    mk = lambda: bts.DeviceTracker(max_tracks=K + 256, max_dets=max(K, M), feat_dim=D)
+    mk = lambda: bts.DeviceTracker(max_tracks=2 * K, max_dets=max(K, M), feat_dim=D)      # (churn: the table also holds the lost and the newly born)
     for env in ("BTS_PREDICT_FIRST", "BTS_CVT_OVERLAP"):
         fa, fb = _frames_on_device(bts, K, M, D, n, churn=0.05), _frames_on_device(bts, K, M, D, n, churn=0.05)
 
