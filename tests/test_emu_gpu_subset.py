@@ -1,0 +1,46 @@
+"""A slice of the `-m gpu` parity tests run on the CPU, through the REAL kernel sources: tests/hip_emu compiles csrc/*.hip as
+plain C++ against a lockstep stand-in for the HIP subset they use (fibres per thread, rendezvous at barriers and wavefront
+collectives) and builds a library with the product's C ABI; the child pytest below loads it through BTS_LIB_PATH and runs the
+unmodified GPU tests (tests.hip_emu.emu_prelude re-points torch's device calls).  TEST INFRASTRUCTURE: the emulated library is
+never what ships or what is measured, and it says nothing about speed, memory ordering between workgroups, or the three
+kernels whose bodies are MFMA / LDS-DMA assembly (k_filter_i8, k_filter_splitk: contract-level stand-ins; k_cos_mfma: the
+tests of the float32 GEMM run its non-MFMA sibling) -- it checks that the code as written computes what the oracle computes.
+Round 3 had no GPU: this is how its GPU tests were run before they ever met one (the whole of the five GPU files passes on
+the emulator except graph capture and four sizes that time out)."""
+import os
+import re
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU = os.path.join(REPO, "tests", "hip_emu")
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+SUBSET = [
+    "tests/test_gpu_kernels.py",                                                    # every standalone kernel vs oracle / golden
+    "tests/test_gpu_tracker.py::test_edge_frames",
+    "tests/test_gpu_tracker.py::test_tracker_gmc",
+    "tests/test_gpu_tracker.py::test_botsort_update_image_with_parts",
+    "tests/test_gpu_tracker.py::test_ragged_shapes_vs_oracle",                      # (the three small shapes, -k below)
+    "tests/test_gpu_round2.py::test_lapjv_tall_components",
+    "tests/test_gpu_round2.py::test_device_errors_reach_the_caller",
+    "tests/test_gpu_round2.py::test_strack_lifecycle_methods_vs_oracle",
+    "tests/test_zz_gpu_round3.py::test_lapjv_column_form_components_vs_oracle",
+]
+DESELECT = "not (ragged and not (5-2-64 or 4-1-64 or 17-9-128)) and not (column_form and not 0)"
+
+
+@pytest.mark.skipif(not os.path.exists(CLANG) or shutil.which("make") is None, reason="needs ROCm's clang++ and make")
+def test_gpu_parity_tests_pass_on_the_emulated_kernels():
+    subprocess.check_call(["make", "-C", EMU, "-s", "-j4"])
+    env = dict(os.environ, BTS_LIB_PATH=os.path.join(EMU, "libbotsort_emu.so"))
+    cmd = [sys.executable, "-m", "pytest", "-m", "gpu", "-p", "tests.hip_emu.emu_prelude", "-p", "no:cacheprovider", "-q",
+           "--no-header", "-n", "4", "--timeout", "600", "-k", DESELECT] + SUBSET
+    out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=1500)
+    tail = "\n".join(out.stdout.splitlines()[-25:]) + out.stderr[-2000:]
+    assert out.returncode == 0, tail
+    m = re.search(r"(\d+) passed", out.stdout)
+    assert m and int(m.group(1)) >= 60, tail
