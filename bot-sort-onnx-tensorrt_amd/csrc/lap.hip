@@ -206,7 +206,13 @@ constexpr int SM_C = SM_EH / 2;      // components: a hard edge shares its row o
                                      // component has >= 2 edges (and, being connected, at most edges + 1 rows and columns:
                                      // row slots + column slots <= SM_EH + SM_C)
 constexpr int SM_EDGES = 512;        // edge budget of the register/LDS solver, per wavefront
-constexpr int TALL_S = 4, TALL_R = 254;       // rows of a component the register solvers take (solve_packed: 64, solve_packed_tall: TALL_S row
+constexpr int BIG_R = 2048, BIG_C = 512, BIG_E = 6144;      // what ONE wavefront solves with the workgroup's whole LDS (solve_big_cols)
+constexpr int TALL_S = 4, TALL_R = 254;
+#ifdef BTS_LAP_TALL_ROWFORM                       // (the round-2 solvers, kept for A/B: nothing beyond a wavefront's share of LDS)
+constexpr int ADMIT_R = 254, ADMIT_C = 64, ADMIT_E = 512;
+#else
+constexpr int ADMIT_R = BIG_R, ADMIT_C = BIG_C, ADMIT_E = BIG_E;
+#endif       // rows of a component the register solvers take (solve_packed: 64, solve_packed_tall: TALL_S row
                                               // slots per lane; the packed descriptor keeps the row count in 8 bits, 255 = "255 or more")
 
 struct SmallPipe {                   // LDS image of the hard sub-problem (slot space); 34 B per hard edge
@@ -369,9 +375,9 @@ template <int EC> __device__ int small_pipeline(const LapArgs &A, SmallPipe &L, 
     uint16_t *lane_of_col = L.lane_of_col();
     if (tid < 192) {
         const int wv = tid >> 6, ln = tid & 63;
-        const bool over = wv == 0 ? wave_exscan_lds(L.crp, C, L.crp, cur_r, TALL_R, ln)      // (TALL_R rows: solve_packed_tall)
-                        : wv == 1 ? wave_exscan_lds(L.ccp, C, L.ccp, cur_c, 64, ln)
-                                  : wave_exscan_lds(L.ecnt, C, ebase, ecur, SM_EDGES, ln);
+        const bool over = wv == 0 ? wave_exscan_lds(L.crp, C, L.crp, cur_r, ADMIT_R, ln)     // (what the LDS solvers take)
+                        : wv == 1 ? wave_exscan_lds(L.ccp, C, L.ccp, cur_c, ADMIT_C, ln)
+                                  : wave_exscan_lds(L.ecnt, C, ebase, ecur, ADMIT_E, ln);
         if (over) L.maxr = 65;
     }
     bscan::lds_barrier();
@@ -391,8 +397,10 @@ template <int EC> __device__ int small_pipeline(const LapArgs &A, SmallPipe &L, 
         lane_of_col[s] = (uint16_t)(pos - L.ccp[c]);
         w.colid[pos] = L.acol[s];
     }
-    for (int c = tid; c < C; c += nth)
-        w.cdesc[c] = make_int4(L.crp[c], L.ccp[c], (L.crp[c + 1] - L.crp[c]) | ((L.ccp[c + 1] - L.ccp[c]) << 8) | (L.ecnt[c] << 16), ebase[c]);
+    for (int c = tid; c <= C; c += nth) {                 // (entry C: the end of the last component's blocks)
+        const int r = c < C ? L.crp[c + 1] - L.crp[c] : 0, cn = c < C ? L.ccp[c + 1] - L.ccp[c] : 0, ne = c < C ? L.ecnt[c] : 0;
+        w.cdesc[c] = make_int4(L.crp[c], L.ccp[c], (r > 255 ? 255 : r) | ((cn > 255 ? 255 : cn) << 8) | ((ne > 0x7fff ? 0x7fff : ne) << 16), ebase[c]);
+    }
     TR(w, 6);
     if (!cached) __syncthreads();                         // (w.hard[] is read back below: its stores must have landed)
     else bscan::lds_barrier();
@@ -506,6 +514,7 @@ __device__ __forceinline__ void large_pipeline(const LapArgs &A, int EH, int32_t
         const int ne = w.gstart[r0 + r] - w.gstart[r0];
         w.cdesc[c] = make_int4(r0, c0, (r > 255 ? 255 : r) | ((cn > 255 ? 255 : cn) << 8) | ((ne > 0x7fff ? 0x7fff : ne) << 16), w.gstart[r0]);
     }
+    if (tid == 0) w.cdesc[C] = make_int4(NA, MA, 0, EH);  // (the end of the last component's blocks)
     __syncthreads();
     for (int h = tid; h < EH; h += nth) {
         const int e = w.hard[h];
@@ -596,7 +605,7 @@ extern "C" void bts_emu_lap_stats(long long *out, int reset) {
 #define LSTAT_MAX(k, n) do { } while (0)
 #endif
 enum { LS_PACKED = 0, LS_TALL = 1, LS_GLOBAL = 2, LS_AUG = 3, LS_STEPS = 4, LS_RELAX = 5, LS_TALL_AUG = 6, LS_TALL_STEPS = 7, LS_TALL_RELAX = 8,
-       LS_MAX_COMP_STEPS = 9, LS_PATH = 10, LS_TALL_PRELUDE = 11 };
+       LS_MAX_COMP_STEPS = 9, LS_PATH = 10, LS_TALL_PRELUDE = 11, LS_GLOBAL_ROWS = 12, LS_GLOBAL_COLS = 13, LS_GLOBAL_STEPS = 14, LS_BIG = 15 };
 
 // ---- 3. one wavefront per packed component: shortest augmenting paths ---------------------------------
 constexpr int DN_R = 8, DN_C = 32;   // components up to DN_R x DN_C also get a dense cost block
@@ -1035,6 +1044,159 @@ __device__ __forceinline__ bool solve_tall_cols(const LapArgs &A, int c, int lan
     return true;
 }
 
+// Components beyond a wavefront's share of LDS (more than TALL_R rows, 64 columns or SM_EDGES edges: the core of a dense
+// crowd now and then -- 261 rows x 76 columns in the crowd scene) used to go to the global-memory solver below, where every
+// step of a search is a chain of L2 round trips (~2 ms for that component).  They are queued instead, and once every
+// wavefront of the workgroup is done with its own components, wavefront 0 solves them with the WHOLE dynamic LDS of the
+// workgroup: the column form of solve_tall_cols with the column state in LDS as well (up to BIG_R x BIG_C, BIG_E edges).
+constexpr int BIG_NONE = 0xffff, BIG_QUEUE = 64;
+struct BigLds {
+    double ecost[BIG_E];                         // by column
+    double u[BIG_R], dist[BIG_R];                // (dist doubles as the id table of the ranking pass)
+    double v[BIG_C];                             // (doubles as the column counters while the adjacency is re-sorted)
+    int32_t colid[BIG_C];
+    uint16_t erow[BIG_E];
+    uint16_t pred[BIG_R], xr[BIG_R], rank[BIG_R];
+    uint16_t yc[BIG_C], cptr[BIG_C + 2], corder[BIG_C];
+    uint8_t scanned[BIG_R];
+};
+
+__device__ __forceinline__ bool fits_big(const bts_lap_work &w, int c) {
+    const int4 d = w.cdesc[c], e = w.cdesc[c + 1];
+    return e.x - d.x <= BIG_R && e.y - d.y <= BIG_C && e.w - d.w <= BIG_E;
+}
+
+__device__ __forceinline__ void solve_big_cols(const LapArgs &A, int c, int lane, BigLds &L) {
+    const bts_lap_work &w = A.w;
+    const double limit = A.limit, INF = __builtin_huge_val();
+    const int4 d = w.cdesc[c], dn = w.cdesc[c + 1];
+    const int rs = d.x, cs = d.y, r = dn.x - rs, cn = dn.y - cs;
+    LSTAT(LS_BIG, 1);
+    LSTAT_MAX(LS_GLOBAL_ROWS, r);
+    LSTAT_MAX(LS_GLOBAL_COLS, cn);
+    int32_t *ids = reinterpret_cast<int32_t *>(L.dist), *cnt = reinterpret_cast<int32_t *>(L.v);
+    for (int k = lane; k < r; k += 64) ids[k] = w.rowinfo[rs + k].x;
+    for (int j = lane; j < cn; j += 64) { L.colid[j] = w.colid[cs + j]; cnt[j] = 0; }
+    lds_sync();
+    for (int k = lane; k < r; k += 64) {          // rows / columns in ascending id order
+        const int id = ids[k];
+        int rk = 0;
+        for (int q = 0; q < r; ++q) rk += ids[q] < id ? 1 : 0;
+        L.rank[k] = (uint16_t)rk;
+    }
+    for (int j = lane; j < cn; j += 64) {
+        const int id = L.colid[j];
+        int rk = 0;
+        for (int q = 0; q < cn; ++q) rk += L.colid[q] < id ? 1 : 0;
+        L.corder[rk] = (uint16_t)j;
+    }
+    for (int k = lane; k < r; k += 64) {
+        const int4 ri = w.rowinfo[rs + k];
+        for (int e = ri.y; e < ri.z; ++e) atomicAdd(&cnt[w.csr_lcol[e]], 1);
+    }
+    lds_sync();
+    {
+        const int per = (cn + 63) >> 6, lo = min(cn, lane * per), hi = min(cn, lo + per);
+        int sum = 0;
+        for (int k = lo; k < hi; ++k) sum += cnt[k];
+        int run = wave_incl_scan(sum) - sum;
+        lds_sync();
+        for (int k = lo; k < hi; ++k) { const int t = cnt[k]; cnt[k] = run; L.cptr[k] = (uint16_t)run; run += t; }
+        if (hi == cn) L.cptr[cn] = (uint16_t)run;
+    }
+    lds_sync();
+    for (int k = lane; k < r; k += 64) {
+        const int4 ri = w.rowinfo[rs + k];
+        const uint16_t rk = L.rank[k];
+        for (int e = ri.y; e < ri.z; ++e) {
+            const int pos = atomicAdd(&cnt[w.csr_lcol[e]], 1);
+            L.ecost[pos] = w.csr_cost[e];
+            L.erow[pos] = rk;
+        }
+    }
+    lds_sync();
+    for (int i = lane; i < r; i += 64) { L.u[i] = limit; L.xr[i] = (uint16_t)BIG_NONE; }
+    for (int j = lane; j < cn; j += 64) {
+        double mn = limit;
+        for (int k = L.cptr[j]; k < L.cptr[j + 1]; ++k) mn = fmin(mn, L.ecost[k]);
+        L.v[j] = mn - limit;                      // (cnt[] is dead: lds_sync above)
+        L.yc[j] = (uint16_t)BIG_NONE;
+    }
+    lds_sync();
+    for (int t = 0; t < cn; ++t) {
+        const int j0 = L.corder[t];
+        for (int i = lane; i < r; i += 64) { L.dist[i] = INF; L.scanned[i] = 0; }
+        lds_sync();
+        double exit_d = -L.v[j0], dcur = 0.0, mu = 0.0;
+        int exit_col = j0, cur = j0, end_row = -1;
+        LSTAT(LS_TALL_AUG, 1);
+        for (;;) {
+            const double vcur = L.v[cur];
+            const int k1 = L.cptr[cur + 1];
+            LSTAT(LS_GLOBAL_STEPS, 1);
+            for (int k = L.cptr[cur] + lane; k < k1; k += 64) {
+                const int i = L.erow[k];
+                if (!L.scanned[i]) {
+                    const double nd = dcur + ((L.ecost[k] - L.u[i]) - vcur);
+                    if (nd < L.dist[i]) { L.dist[i] = nd; L.pred[i] = (uint16_t)cur; }
+                }
+            }
+            lds_sync();
+            double bl = INF;
+            int bi_l = 0x7fffffff;
+            for (int i = lane; i < r; i += 64) {
+                const double dd = L.scanned[i] ? INF : L.dist[i];
+                if (dd < bl) { bl = dd; bi_l = i; }
+            }
+            const double bd = wave_min_d(bl, 64);
+            if (!(bd < INF) || exit_d < bd) { mu = exit_d; break; }
+            const unsigned long long tie = __ballot(bl == bd);
+            int bi = bcast_i(bi_l, __ffsll((long long)tie) - 1);
+            if (tie & (tie - 1))
+                for (unsigned long long q = tie & (tie - 1); q; q &= q - 1) { const int o = bcast_i(bi_l, __ffsll((long long)q) - 1); bi = o < bi ? o : bi; }
+            const int own = L.xr[bi];
+            if (own == BIG_NONE) { mu = bd; end_row = bi; break; }
+            cur = own; dcur = bd;
+            const double e2 = bd - L.v[own];
+            if (e2 < exit_d) { exit_d = e2; exit_col = own; }
+            lds_sync();
+            if (lane == 0) L.scanned[bi] = 1;
+            lds_sync();
+        }
+        // duals (every lane has left the search: nothing below is read by another lane before the next lds_sync)
+        for (int j = lane; j < cn; j += 64) {
+            const int y = L.yc[j];
+            if (y != BIG_NONE && L.scanned[y]) L.v[j] += mu - L.dist[y];
+        }
+        for (int i = lane; i < r; i += 64) if (L.scanned[i]) L.u[i] -= mu - L.dist[i];
+        lds_sync();
+        if (lane == 0) {
+            L.v[j0] += mu;
+            int i = end_row;
+            bool go = true;
+            if (i < 0) {
+                if (exit_col == j0) go = false;
+                else { i = L.yc[exit_col]; L.yc[exit_col] = (uint16_t)BIG_NONE; }
+            }
+            while (go) {
+                const int j = L.pred[i], prev = L.yc[j];
+                L.xr[i] = (uint16_t)j;
+                L.yc[j] = (uint16_t)i;
+                if (j == j0) break;
+                i = prev;
+            }
+        }
+        lds_sync();
+    }
+    for (int k = lane; k < r; k += 64) {
+        const int gid = w.rowinfo[rs + k].x, mcol = L.xr[L.rank[k]];
+        A.x[gid] = mcol != BIG_NONE ? L.colid[mcol] : -1;
+        if (mcol != BIG_NONE) A.y[L.colid[mcol]] = gid;
+    }
+    for (int j = lane; j < cn; j += 64) if (L.yc[j] == BIG_NONE) A.y[L.colid[j]] = -1;
+    lds_sync();
+}
+
 // General path (any component size): state in global memory.
 __device__ __forceinline__ void solve_component(const LapArgs &A, int c, int lane) {
     const bts_lap_work &w = A.w;
@@ -1044,6 +1206,8 @@ __device__ __forceinline__ void solve_component(const LapArgs &A, int c, int lan
     LSTAT(LS_GLOBAL, 1);
     const int rs = LDG(&w.crow_ptr[c]), r = LDG(&w.crow_ptr[c + 1]) - rs;
     const int cs = LDG(&w.ccol_ptr[c]), cn = LDG(&w.ccol_ptr[c + 1]) - cs;
+    LSTAT_MAX(LS_GLOBAL_ROWS, r);
+    LSTAT_MAX(LS_GLOBAL_COLS, cn);
 
     // rows in ascending order (the grouping pass appended them in arbitrary order)
     for (int k = lane; k < r; k += 64) {
@@ -1073,6 +1237,7 @@ __device__ __forceinline__ void solve_component(const LapArgs &A, int c, int lan
         double dcur = 0.0, mu = 0.0;
         int end_col = -1;                  // >= 0: path ends at this free column
         for (;;) {
+            LSTAT(LS_GLOBAL_STEPS, 1);
             const double ucur = LDG(&w.u[cur]);
             const int scur = LDG(&w.slot_of_row[cur]);
             const int e1 = LDG(&w.rhi[scur]);
@@ -1147,7 +1312,8 @@ __device__ __forceinline__ void solve_component(const LapArgs &A, int c, int lan
 constexpr int LAP_SOLO_EDGES = 64;   // edge lists up to this length are solved by the preparing workgroup alone
 constexpr int LAP_HELPERS = 15, LAP_HELPERS_BIG = 63;    // helper workgroups per problem (16 wavefronts each): small / big problems
 constexpr unsigned LAP_LDS_BYTES = sizeof(SmallPipe) > 16 * sizeof(WaveLds) ? sizeof(SmallPipe) : 16 * sizeof(WaveLds);
-static_assert(LAP_LDS_BYTES + 4096 + 64 <= 160 * 1024, "k_lap: dynamic + static LDS exceed a CU's 160 KiB");
+static_assert(sizeof(BigLds) <= LAP_LDS_BYTES, "solve_big_cols: its image must fit the kernel's dynamic LDS");
+static_assert(LAP_LDS_BYTES + 4096 + 512 <= 160 * 1024, "k_lap: dynamic + static LDS exceed a CU's 160 KiB");
 
 struct LapPair { LapArgs p[2]; };     // (indexed by blockIdx.x straight out of the kernel-argument segment)
 
@@ -1158,7 +1324,9 @@ template <int EC> __global__ __launch_bounds__(1024) void k_lap(LapPair P) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
 #endif
     __shared__ int32_t tmp[1024];
-    __shared__ int s_c;
+    __shared__ int s_c, s_nbig;
+    __shared__ int32_t s_big[BIG_QUEUE];
+    if (threadIdx.x == 0) s_nbig = 0;             // (a workgroup barrier sits on every path to the component loop)
     const LapArgs &A = P.p[blockIdx.x];
     const bts_lap_work &w = A.w;
     const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63, wid = tid >> 6;
@@ -1222,9 +1390,25 @@ template <int EC> __global__ __launch_bounds__(1024) void k_lap(LapPair P) {
         const int dz = w.cdesc[c].z, r_ = dz & 0xff, cn_ = (dz >> 8) & 0xff;
         if (r_ > COLFORM_MIN_ROWS && r_ > cn_ ? solve_tall_cols(A, c, lane, lds[wid].t) : solve_packed(A, c, lane, lds[wid].s)) continue;
         if (solve_tall_cols(A, c, lane, lds[wid].t)) continue;       // (more than 64 rows but not more rows than columns)
+        // beyond a wavefront's share of LDS: queued for the end of the loop (the SMALL preparation admits nothing that
+        // solve_big_cols cannot take and at most 63 such components; the LARGE one also feeds the global-memory solver)
+        if (fits_big(w, c)) {
+            int slot = 0;
+            if (lane == 0) slot = atomicAdd(&s_nbig, 1);
+            slot = __shfl(slot, 0);
+            if (slot < BIG_QUEUE) { if (lane == 0) s_big[slot] = c; continue; }
+        }
+        if (RLX(&w.hdr[H_MODE]) != 2) { if (lane == 0) RST(&w.hdr[H_ERR], 8); continue; }      // (cannot happen: loud, not wrong)
 #endif
         solve_component(A, c, lane);
     }
+#ifndef BTS_LAP_TALL_ROWFORM
+    __syncthreads();                              // every wavefront is done with its share of the dynamic LDS
+    if (wid == 0) {
+        const int nb = s_nbig < BIG_QUEUE ? s_nbig : BIG_QUEUE;
+        for (int k = 0; k < nb; ++k) solve_big_cols(A, s_big[k], lane, *reinterpret_cast<BigLds *>(lds_raw));
+    }
+#endif
 #ifdef BTS_LAP_TRACE
     __syncthreads();
     if (blockIdx.y <= 1) TR(w, 11 + blockIdx.y);
@@ -1292,7 +1476,7 @@ static void layout(bts_lap_work *w, char *base, size_t &off, int n, int m, int64
     SLOT(ccur_r, int32_t, n + 1); SLOT(ccur_c, int32_t, n + 1);
     SLOT(crows, int32_t, n); SLOT(crows_s, int32_t, n); SLOT(ccols, int32_t, m); SLOT(comp_list, int32_t, n);
     SLOT(slot_of_row, int32_t, n); SLOT(slot_of_col, int32_t, m); SLOT(col_local, int32_t, m); SLOT(colid, int32_t, m);
-    SLOT(cdesc, int4, n); SLOT(rowinfo, int4, n); SLOT(rpos, int32_t, n); SLOT(gstart, int32_t, n + 1); SLOT(rlo, int32_t, n); SLOT(rhi, int32_t, n); SLOT(csr_lcol, int32_t, e); SLOT(arow, int32_t, n); SLOT(acol, int32_t, m); SLOT(hard, int32_t, e);
+    SLOT(cdesc, int4, n + 1); SLOT(rowinfo, int4, n); SLOT(rpos, int32_t, n); SLOT(gstart, int32_t, n + 1); SLOT(rlo, int32_t, n); SLOT(rhi, int32_t, n); SLOT(csr_lcol, int32_t, e); SLOT(arow, int32_t, n); SLOT(acol, int32_t, m); SLOT(hard, int32_t, e);
     SLOT(u, double, n); SLOT(v, double, m); SLOT(dist, double, m);
     SLOT(pred, int32_t, m); SLOT(scanned, int32_t, m);
 #undef SLOT

@@ -22,7 +22,7 @@ import tests.hip_emu.emu_prelude                                      # noqa: E4
 from oracle import bts_oracle as bo                                   # noqa: E402
 
 pkg = importlib.import_module("bot-sort-onnx-tensorrt_amd")
-NAMES = ["packed", "tall", "global", "aug", "steps", "relax", "tall_aug", "tall_steps", "tall_relax", "max_comp_steps", "path", "tall_prelude"]
+NAMES = ["packed", "tall", "global", "aug", "steps", "relax", "tall_aug", "tall_steps", "tall_relax", "max_comp_steps", "path", "tall_prelude", "big_or_global_rows", "big_or_global_cols", "big_or_global_steps", "big"]
 
 
 def main():

@@ -207,6 +207,14 @@ def _crowd_blocks(rng, shapes, limit):
         for j in range(cn):                       # every column touched (a column without edges is not part of a component)
             if (c[r0:r0 + r, c0 + j] < 1.0).sum() == 0:
                 c[r0 + int(rng.integers(r)), c0 + j] = rng.uniform(0.02, limit - 0.01)
+        if r > 254 or cn > 64:                    # the big blocks are ONE component each: a path through all their columns
+            for j in range(cn):
+                for i in (j % r, (j + 1) % r):
+                    if c[r0 + i, c0 + j] >= 1.0:
+                        c[r0 + i, c0 + j] = rng.uniform(0.02, limit - 0.01)
+            for i in range(r):                    # ... and every row on it
+                if (c[r0 + i, c0:c0 + cn] < 1.0).sum() == 0 or i >= cn:
+                    c[r0 + i, c0 + i % cn] = min(c[r0 + i, c0 + i % cn], rng.uniform(0.02, limit - 0.01))
         r0, c0 = r0 + r, c0 + cn
     p, q = rng.permutation(n), rng.permutation(m)      # rows / columns of a component are not contiguous ids
     return c[p][:, q]
@@ -229,3 +237,26 @@ def test_lapjv_column_form_components_vs_oracle(bts, seed):
     _, x, y = bts.lapjv(c, True, limit)
     assert np.array_equal(x, xo) and np.array_equal(y, yo), seed
     assert (yo < 0).sum() > 0 and (xo < 0).sum() > 0, "the case must leave columns and rows unmatched"
+
+
+@pytest.mark.parametrize("case", ["lds-prep", "global-prep", "wide", "beyond"])
+def test_lapjv_components_beyond_a_wavefronts_lds_vs_oracle(bts, case):
+    """Components with more than 254 rows, 64 columns or 512 edges (the core of a dense crowd) are queued and solved by one
+    wavefront with the workgroup's whole LDS (solve_big_cols, lap.hip; round 3) instead of the global-memory solver:
+    `lds-prep` -- few enough non-trivial edges for the LDS preparation, which now admits such components; `global-prep` --
+    more than 4096 non-trivial edges; `wide` -- more columns than rows; `beyond` -- a component past even that solver's
+    limits (600 columns) still takes the global-memory path.  Tie-free costs: indices equal the oracle's dense JV."""
+    from oracle import bts_oracle as bo
+    rng = np.random.default_rng({"lds-prep": 1, "global-prep": 2, "wide": 3, "beyond": 4}[case])
+    limit = 0.8
+    big = {"lds-prep": [(300, 100, False), (260, 70, True)], "global-prep": [(400, 120, True), (270, 66, False)],
+           "wide": [(100, 300, False), (200, 200, False)], "beyond": [(700, 600, False), (300, 90, True)]}[case]
+    small = [(int(rng.integers(2, 40)), int(rng.integers(1, 12)), False) for _ in range(30 if case != "global-prep" else 420)]
+    shapes = big + small
+    order = rng.permutation(len(shapes))
+    c = _crowd_blocks(rng, [shapes[k] for k in order], limit)
+    hard = int((c <= limit).sum())
+    assert hard > 4300 if case == "global-prep" else hard < 4000 or case == "beyond", hard      # (which preparation runs)
+    _, xo, yo = bo.lapjv(c, True, limit)
+    _, x, y = bts.lapjv(c, True, limit)
+    assert np.array_equal(x, xo) and np.array_equal(y, yo), case
