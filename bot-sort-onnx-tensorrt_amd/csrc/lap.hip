@@ -47,6 +47,29 @@ typedef bts_lap_problem LapArgs;
 
 
 
+// Step counters of the component solvers: emulator build only (tests/hip_emu; scripts/lap_steps_cpu.py reads them) -- the
+// device build compiles LSTAT to nothing.
+#if defined(BTS_HOST_EMU)
+static long long g_lapstat[24];
+extern "C" void bts_emu_lap_stats(long long *out, int reset) {
+    for (int k = 0; k < 24; ++k) { if (out) out[k] = g_lapstat[k]; if (reset) g_lapstat[k] = 0; }
+}
+#define LSTAT(k, n) do { if (lane == 0) g_lapstat[k] += (n); } while (0)
+#define LSTAT_MAX(k, n) do { if (lane == 0 && g_lapstat[k] < (n)) g_lapstat[k] = (n); } while (0)
+#define LSTAT_DECL(v) long long v = 0
+#define PSTAT(k) do { if (threadIdx.x == 0) g_lapstat[k] += 1; } while (0)
+#define LSTAT_INC(v) (++v)
+#else
+#define LSTAT_DECL(v)
+#define PSTAT(k) do { } while (0)
+#define LSTAT_INC(v)
+#define LSTAT(k, n) do { } while (0)
+#define LSTAT_MAX(k, n) do { } while (0)
+#endif
+enum { LS_PACKED = 0, LS_TALL = 1, LS_GLOBAL = 2, LS_AUG = 3, LS_STEPS = 4, LS_RELAX = 5, LS_TALL_AUG = 6, LS_TALL_STEPS = 7, LS_TALL_RELAX = 8,
+       LS_MAX_COMP_STEPS = 9, LS_PATH = 10, LS_TALL_PRELUDE = 11, LS_GLOBAL_ROWS = 12, LS_GLOBAL_COLS = 13, LS_GLOBAL_STEPS = 14, LS_BIG = 15,
+       LS_PREP_A = 16, LS_PREP_B = 17, LS_PREP_LARGE = 18, LS_PREP_AGAIN = 19 };
+
 // Lanes of one wavefront hand values to each other through global memory (lane 0 publishes a
 // decision, every lane reads it back): drain this wave's outstanding stores/loads before going on.
 __device__ __forceinline__ void wave_sync() {
@@ -193,7 +216,7 @@ __device__ int block_exscan(int32_t *arr, int len, int32_t *tmp) {
 // Workgroup 0 of the launch prepares; it publishes the packed problem on hdr[H_READY] and the helper
 // workgroups of the same launch (spinning on that one word) share the components with it.
 // Two forms of the preparation:
-//   SMALL (<= SM_EH hard edges, components <= 64 x 64 with <= SM_EDGES edges): slot space, in LDS;
+//   SMALL (<= SM_EH_MAX hard edges, two layouts; components up to what solve_big_cols takes): slot space, in LDS;
 //   LARGE: node space, in the global work area (any size; oversize components go to the general
 //          global-memory solver).
 // Invariant kept across calls: deg[] / cdeg[] are zero outside this kernel.
@@ -215,26 +238,39 @@ constexpr int ADMIT_R = BIG_R, ADMIT_C = BIG_C, ADMIT_E = BIG_E;
 #endif       // rows of a component the register solvers take (solve_packed: 64, solve_packed_tall: TALL_S row
                                               // slots per lane; the packed descriptor keeps the row count in 8 bits, 255 = "255 or more")
 
-struct SmallPipe {                   // LDS image of the hard sub-problem (slot space); 34 B per hard edge
-    uint16_t hr[SM_EH], hc[SM_EH];                // hard edge -> row, column (global ids first, then slots)
-    uint16_t arow[SM_EH], acol[SM_EH];            // slot -> global row / column
+// LDS image of the hard sub-problem (slot space).  The HEAD (edge -> row / column, slot -> id) is the same for every layout;
+// the TAIL comes in two sizes (round 3): A = up to SM_EH edges and SM_EH / 2 components (24 B + 8 B per edge: plain scenes,
+// many tiny components), B = up to SM_EH_MAX edges and SM_EH_MAX / 4 components (dense crowds: 5 000+ edges in ~230
+// components) -- which one is known once the non-trivial edges are counted.  Row slots are numbered from the bottom of a
+// node array and column slots from its top (rows + columns <= edges + components).
+constexpr int SM_EH_MAX = 6144;      // hard-edge budget of the LDS form, layout B
+struct SmallHead {
+    uint16_t hr[SM_EH_MAX], hc[SM_EH_MAX];        // hard edge -> row, column (global ids first, then slots)
     int32_t NA, MA, C, maxr, EH, pad_[3];
+};
+template <int EHC, int CC> struct SmallTail {
+    static constexpr int kEdges = EHC, kComps = CC, kNodes = EHC + CC;
     // ---- everything below is dead while the node table is alive: the table borrows it ----
-    int32_t parent[SM_EH + SM_C];                 // union-find: row slots [0,NA), column slots [NA, NA+MA)
-    int32_t rptr[SM_EH + 1];                      // row slot -> edges
-    int32_t cid[SM_EH + 1];                       // root row slot -> component; later ebase / ecur
-    int32_t crp[SM_C + 1], ccp[SM_C + 1];         // component -> first row / column of its group
-    int32_t ecnt[SM_C];                           // component -> edges
-    int32_t cur_c_[SM_C];
-    uint16_t comp[SM_EH], ccomp[SM_EH];           // row slot / column slot -> component; ccomp later lane_of_col
+    int32_t parent[kNodes];                       // union-find: row slots [0,NA), column slots [NA, NA+MA); a final root: -1 - component
+    int32_t rptr[EHC + 1];                        // row slot -> edges
+    int32_t crp[CC + 1], ccp[CC + 1];             // component -> first row / column of its group
+    int32_t ecnt[CC], cur_c_[CC];                 // component -> edges; column cursor
+    int32_t ebase_[CC + 1], ecur_[CC];            // component -> first edge / edge cursor
+    uint16_t anode[kNodes];                       // slot -> global row (from the bottom) / column (from the top)
+    uint16_t cnode[kNodes];                       // row slot / column slot -> component; column part later lane_of_col
     // arrays with disjoint lifetimes share storage
     __device__ int32_t *cursor() { return parent; }            // [NA] (after the roots are known)
-    __device__ int32_t *cur_r() { return parent + SM_EH; }     // [C]
-    __device__ int32_t *cur_c() { return cur_c_; }
-    __device__ int32_t *ebase() { return cid; }                // [C+1] component -> first edge (after comp holds component ids)
-    __device__ int32_t *ecur() { return cid + SM_C + 1; }      // [C]
-    __device__ uint16_t *lane_of_col() { return ccomp; }       // column slot -> lane inside its component (same)
+    __device__ int32_t *cur_r() { return parent + EHC; }       // [C]
+    __device__ uint16_t &arow(int s) { return anode[s]; }
+    __device__ uint16_t &acol(int s) { return anode[kNodes - 1 - s]; }
+    __device__ uint16_t &comp(int s) { return cnode[s]; }
+    __device__ uint16_t &ccomp(int s) { return cnode[kNodes - 1 - s]; }
 };
+typedef SmallTail<SM_EH, SM_C> SmallTailA;
+typedef SmallTail<SM_EH_MAX, SM_EH_MAX / 4> SmallTailB;
+constexpr size_t SMALL_TAIL_BYTES = sizeof(SmallTailA) > sizeof(SmallTailB) ? sizeof(SmallTailA) : sizeof(SmallTailB);
+constexpr size_t SMALL_PIPE_BYTES = sizeof(SmallHead) + SMALL_TAIL_BYTES;
+static_assert(sizeof(SmallHead) % 16 == 0, "the tail starts aligned");
 
 __device__ int find_root_lds(int32_t *parent, int x) {
     int p = parent[x];
@@ -243,13 +279,11 @@ __device__ int find_root_lds(int32_t *parent, int x) {
 }
 
 // SMALL preparation, entirely in LDS (the global work area's deg/cdeg are not touched).  The node
-// table (degree, then slot, of every row and column) borrows the storage of the arrays that only
-// come alive after it is dead.  Returns 0 when the problem is fully prepared/solved as far as this
+// table (degree, then slot, of every row and column) borrows the storage of the tail, which only
+// comes alive after it is dead.  Returns 0 when the problem is fully prepared/solved as far as this
 // workgroup goes, -1 when the LARGE form has to take over (nothing global was changed except x/y of
-// isolated pairs, which the LARGE form rewrites identically).
-constexpr int TABLE_CAP = 6 * SM_EH + SM_C;  // node-table entries that fit in the borrowed storage
-static_assert(sizeof(SmallPipe) - offsetof(SmallPipe, parent) >= TABLE_CAP * sizeof(int32_t), "node table does not fit");
-static_assert(TABLE_CAP < 65536, "global ids are kept in 16 bits");
+// isolated pairs, which the LARGE form rewrites identically), -2 when it has to start over.
+constexpr int TABLE_CAP = (int)(SMALL_TAIL_BYTES / sizeof(int32_t)) < 65535 ? (int)(SMALL_TAIL_BYTES / sizeof(int32_t)) : 65535;  // node-table entries (global ids are kept in 16 bits)
 
 // inclusive prefix sum across the 64 lanes: DPP row shifts, then the row broadcasts (lane 15 -> next row, lane 31 -> rows 2, 3)
 __device__ __forceinline__ int wave_incl_scan(int v) {
@@ -277,11 +311,119 @@ __device__ __forceinline__ bool wave_exscan_lds(const int32_t *src, int len, int
     return over;
 }
 
-template <int EC> __device__ int small_pipeline(const LapArgs &A, SmallPipe &L, int E, int n, int m, int32_t *tmp) {
+// second half of the SMALL preparation, for one tail layout: slots -> components -> packed export
+template <int EC, class Tail>
+__device__ __forceinline__ int small_tail(const LapArgs &A, SmallHead &H, Tail &L, int32_t *tab, int EH, int n, bool cached,
+                                          const int (&hs)[EC], const double (&hcost)[EC]) {
     const bts_lap_work &w = A.w;
     const int tid = threadIdx.x, nth = blockDim.x;
-    int32_t *tab = L.parent;                              // [n + m]: rows, then columns
-    if (tid == 0) { L.NA = 0; L.MA = 0; L.C = 0; L.maxr = 0; L.EH = 0; }
+    for (int h = tid; h < EH; h += nth) {                 // dense slots; the table entry becomes FIRST | slot
+        const int i = H.hr[h], j = H.hc[h];
+        if (!(atomicOr(&tab[i], FIRST) & FIRST)) atomicExch(&tab[i], FIRST | atomicAdd(&H.NA, 1));
+        if (!(atomicOr(&tab[n + j], FIRST) & FIRST)) atomicExch(&tab[n + j], FIRST | atomicAdd(&H.MA, 1));
+    }
+    bscan::lds_barrier();
+    const int NA = H.NA, MA = H.MA;
+    // (row, col) -> slots in place; the slot -> id arrays live in the tail, i.e. inside the table: their values wait in registers
+    // of the edge's thread until the table is dead
+    int gi[(SM_EH_MAX + 1023) / 1024], gj[(SM_EH_MAX + 1023) / 1024];
+#pragma unroll
+    for (int k = 0; k < (SM_EH_MAX + 1023) / 1024; ++k) {
+        const int h = tid + k * 1024;
+        gi[k] = gj[k] = -1;
+        if (h < EH) {
+            gi[k] = H.hr[h]; gj[k] = H.hc[h];
+            H.hr[h] = (uint16_t)(tab[gi[k]] & ~FIRST); H.hc[h] = (uint16_t)(tab[n + gj[k]] & ~FIRST);
+        }
+    }
+    bscan::lds_barrier();                                      // the table is dead from here on
+    TR(w, 3);
+    if (NA + MA > Tail::kNodes) return -2;                     // (more components than this layout holds: checked before anything is indexed by slot)
+#pragma unroll
+    for (int k = 0; k < (SM_EH_MAX + 1023) / 1024; ++k)        // (every edge of a row writes the same id: benign)
+        if (gi[k] >= 0) { L.arow(H.hr[tid + k * 1024]) = (uint16_t)gi[k]; L.acol(H.hc[tid + k * 1024]) = (uint16_t)gj[k]; }
+    for (int s = tid; s < NA; s += nth) { L.parent[s] = s; L.rptr[s] = 0; }
+    for (int s = tid; s < MA; s += nth) L.parent[NA + s] = NA + s;
+    bscan::lds_barrier();
+    for (int h = tid; h < EH; h += nth) { unite(L.parent, H.hr[h], NA + H.hc[h]); atomicAdd(&L.rptr[H.hr[h]], 1); }
+    bscan::lds_barrier();
+    for (int s = tid; s < NA; s += nth) L.comp(s) = (uint16_t)find_root_lds(L.parent, s);       // (read-only walks; a root is always a row slot)
+    for (int s = tid; s < MA; s += nth) L.ccomp(s) = (uint16_t)find_root_lds(L.parent, NA + s);
+    bscan::lds_barrier();
+    for (int s = tid; s < NA; s += nth)                   // the roots hand out component ids: kept in their (now dead) parent cell
+        if (L.comp(s) == s) {
+            const int c = atomicAdd(&H.C, 1);
+            L.parent[s] = -1 - c;
+            if (c < Tail::kComps) { L.crp[c] = 0; L.ccp[c] = 0; L.ecnt[c] = 0; }
+        }
+    bscan::lds_barrier();
+    const int C = H.C;
+    TR(w, 4);
+    if (C > Tail::kComps) return -2;
+    for (int s = tid; s < NA; s += nth) { const int c = -1 - L.parent[L.comp(s)]; L.comp(s) = (uint16_t)c; atomicAdd(&L.crp[c], 1); atomicAdd(&L.ecnt[c], L.rptr[s]); }
+    for (int s = tid; s < MA; s += nth) { const int c = -1 - L.parent[L.ccomp(s)]; L.ccomp(s) = (uint16_t)c; atomicAdd(&L.ccp[c], 1); }
+    bscan::lds_barrier();
+    // Three wavefronts scan the component tables side by side -- rows, columns, edges: group offsets plus the cursors
+    // the grouping pass bumps -- and check them against the solver's limits (a plain flag: no contended atomics).
+    // (cursor / cur_r alias parent[]: every read of the component ids kept there happened before the barrier above)
+    int32_t *cursor = L.cursor(), *cur_r = L.cur_r(), *cur_c = L.cur_c_, *ebase = L.ebase_, *ecur = L.ecur_;
+    if (tid < 192) {
+        const int wv = tid >> 6, ln = tid & 63;
+        const bool over = wv == 0 ? wave_exscan_lds(L.crp, C, L.crp, cur_r, ADMIT_R, ln)     // (what the LDS solvers take)
+                        : wv == 1 ? wave_exscan_lds(L.ccp, C, L.ccp, cur_c, ADMIT_C, ln)
+                                  : wave_exscan_lds(L.ecnt, C, ebase, ecur, ADMIT_E, ln);
+        if (over) H.maxr = 65;
+    }
+    bscan::lds_barrier();
+    const bool fits = H.maxr <= 64;
+    TR(w, 5);
+    if (!fits) return -2;                                 // (the table is gone by now: the other form starts over)
+    // rows / columns grouped by component; a row takes its edge range from its component's block, so that the
+    // edges of one component are contiguous (rows and ranges in arbitrary order inside: the solver sorts rows by id)
+    for (int s = tid; s < NA; s += nth) {
+        const int c = L.comp(s), deg = L.rptr[s];
+        const int pos = atomicAdd(&cur_r[c], 1), e0 = atomicAdd(&ecur[c], deg);
+        cursor[s] = e0;
+        w.rowinfo[pos] = make_int4(L.arow(s), e0, e0 + deg, 0);
+    }
+    for (int s = tid; s < MA; s += nth) {
+        const int c = L.ccomp(s), pos = atomicAdd(&cur_c[c], 1);
+        L.ccomp(s) = (uint16_t)(pos - L.ccp[c]);          // from here on: the column's lane inside its component
+        w.colid[pos] = L.acol(s);
+    }
+    for (int c = tid; c <= C; c += nth) {                 // (entry C: the end of the last component's blocks)
+        const int r = c < C ? L.crp[c + 1] - L.crp[c] : 0, cn = c < C ? L.ccp[c + 1] - L.ccp[c] : 0, ne = c < C ? L.ecnt[c] : 0;
+        w.cdesc[c] = make_int4(L.crp[c], L.ccp[c], (r > 255 ? 255 : r) | ((cn > 255 ? 255 : cn) << 8) | ((ne > 0x7fff ? 0x7fff : ne) << 16), ebase[c]);
+    }
+    TR(w, 6);
+    if (!cached) __syncthreads();                         // (w.hard[] is read back below: its stores must have landed)
+    else bscan::lds_barrier();
+    if (cached) {
+#pragma unroll
+        for (int k = 0; k < EC; ++k)
+            if (hs[k] >= 0) {
+                const int pos = atomicAdd(&cursor[H.hr[hs[k]]], 1);
+                w.csr_lcol[pos] = L.ccomp(H.hc[hs[k]]);
+                w.csr_cost[pos] = hcost[k];
+            }
+    } else {
+        for (int h = tid; h < EH; h += nth) {
+            const int pos = atomicAdd(&cursor[H.hr[h]], 1);
+            w.csr_lcol[pos] = L.ccomp(H.hc[h]);
+            w.csr_cost[pos] = w.e_cost[RLX(&w.hard[h])];
+        }
+    }
+    if (tid == 0) { RST(&w.hdr[H_COMPS], C); RST(&w.hdr[H_HARD], C); RST(&w.hdr[H_MODE], 1); RST(&w.hdr[H_NH], EH); }
+    TR(w, 7);
+    return 0;
+}
+
+template <int EC> __device__ __forceinline__ int small_pipeline(const LapArgs &A, char *lds, int E, int n, int m, int32_t *tmp) {
+    const bts_lap_work &w = A.w;
+    const int tid = threadIdx.x, nth = blockDim.x;
+    SmallHead &H = *reinterpret_cast<SmallHead *>(lds);
+    int32_t *tab = reinterpret_cast<int32_t *>(lds + sizeof(SmallHead));      // [n + m]: rows, then columns
+    if (tid == 0) { H.NA = 0; H.MA = 0; H.C = 0; H.maxr = 0; H.EH = 0; }
     // The edge list is read from global memory ONCE: every pass that walks it uses the same edge -> thread mapping
     // and keeps (row, col) in registers (up to EC per thread; longer lists are re-read).  A thread also remembers
     // the queue position of each of its hard edges and fetches their costs while the component phases run: the
@@ -308,8 +450,8 @@ template <int EC> __device__ int small_pipeline(const LapArgs &A, SmallPipe &L, 
     auto classify = [&](int e, int i, int j) -> int {     // isolated pairs are final; the rest is queued
         if (i < 0) return -1;
         if (tab[i] == 1 && tab[n + j] == 1) { A.x[i] = j; A.y[j] = i; return -1; }
-        const int h = atomicAdd(&L.EH, 1);
-        if (h < SM_EH) { L.hr[h] = (uint16_t)i; L.hc[h] = (uint16_t)j; }
+        const int h = atomicAdd(&H.EH, 1);
+        if (h < SM_EH_MAX) { H.hr[h] = (uint16_t)i; H.hc[h] = (uint16_t)j; }
         w.hard[h] = e;                                    // (the queue of the global-memory form, should it take over)
         return h;
     };
@@ -320,10 +462,10 @@ template <int EC> __device__ int small_pipeline(const LapArgs &A, SmallPipe &L, 
         for (int e = tid; e < E; e += nth) classify(e, w.e_row[e], w.e_col[e]);
     }
     bscan::lds_barrier();
-    const int EH = L.EH;
+    const int EH = H.EH;
     TR(w, 2);
     if (EH == 0) return 0;
-    if (EH > SM_EH) {
+    if (EH > SM_EH_MAX) {
         // Too many non-trivial edges for the LDS form: hand over to the global-memory form WITHOUT redoing the degree
         // count and the isolated pairs there (three passes of global atomics): its queue w.hard[] is filled, and the
         // degrees of the rows / columns it will touch are copied out of the LDS table.
@@ -342,86 +484,9 @@ template <int EC> __device__ int small_pipeline(const LapArgs &A, SmallPipe &L, 
     }
 #pragma unroll
     for (int k = 0; k < EC; ++k) hcost[k] = hs[k] >= 0 ? w.e_cost[tid + k * nth] : 0.0;      // consumed by the export at the very end
-    for (int h = tid; h < EH; h += nth) {                 // dense slots; the table entry becomes FIRST | slot
-        const int i = L.hr[h], j = L.hc[h];
-        if (!(atomicOr(&tab[i], FIRST) & FIRST)) { const int s = atomicAdd(&L.NA, 1); L.arow[s] = (uint16_t)i; atomicExch(&tab[i], FIRST | s); }
-        if (!(atomicOr(&tab[n + j], FIRST) & FIRST)) { const int s = atomicAdd(&L.MA, 1); L.acol[s] = (uint16_t)j; atomicExch(&tab[n + j], FIRST | s); }
-    }
-    bscan::lds_barrier();
-    const int NA = L.NA, MA = L.MA;
-    for (int h = tid; h < EH; h += nth) { L.hr[h] = (uint16_t)(tab[L.hr[h]] & ~FIRST); L.hc[h] = (uint16_t)(tab[n + L.hc[h]] & ~FIRST); }      // (row, col) -> slots, in place
-    bscan::lds_barrier();                                      // the table is dead from here on
-    TR(w, 3);
-    for (int s = tid; s < NA; s += nth) { L.parent[s] = s; L.rptr[s] = 0; }
-    for (int s = tid; s < MA; s += nth) L.parent[NA + s] = NA + s;
-    bscan::lds_barrier();
-    for (int h = tid; h < EH; h += nth) { unite(L.parent, L.hr[h], NA + L.hc[h]); atomicAdd(&L.rptr[L.hr[h]], 1); }
-    bscan::lds_barrier();
-    for (int s = tid; s < NA; s += nth) {                 // roots (read-only walks; always a row slot) hand out component ids
-        const int r = find_root_lds(L.parent, s);
-        L.comp[s] = (uint16_t)r;
-        if (r == s) { const int c = atomicAdd(&L.C, 1); L.cid[s] = c; L.crp[c] = 0; L.ccp[c] = 0; L.ecnt[c] = 0; }
-    }
-    for (int s = tid; s < MA; s += nth) L.ccomp[s] = (uint16_t)find_root_lds(L.parent, NA + s);
-    bscan::lds_barrier();
-    const int C = L.C;
-    TR(w, 4);
-    for (int s = tid; s < NA; s += nth) { const int c = L.cid[L.comp[s]]; L.comp[s] = (uint16_t)c; atomicAdd(&L.crp[c], 1); atomicAdd(&L.ecnt[c], L.rptr[s]); }
-    for (int s = tid; s < MA; s += nth) { const int c = L.cid[L.ccomp[s]]; L.ccomp[s] = (uint16_t)c; atomicAdd(&L.ccp[c], 1); }
-    bscan::lds_barrier();
-    // Three wavefronts scan the component tables side by side -- rows, columns, edges: group offsets plus the cursors
-    // the grouping pass bumps -- and check them against the solver's limits (a plain flag: no contended atomics).
-    int32_t *cursor = L.cursor(), *cur_r = L.cur_r(), *cur_c = L.cur_c(), *ebase = L.ebase(), *ecur = L.ecur();
-    uint16_t *lane_of_col = L.lane_of_col();
-    if (tid < 192) {
-        const int wv = tid >> 6, ln = tid & 63;
-        const bool over = wv == 0 ? wave_exscan_lds(L.crp, C, L.crp, cur_r, ADMIT_R, ln)     // (what the LDS solvers take)
-                        : wv == 1 ? wave_exscan_lds(L.ccp, C, L.ccp, cur_c, ADMIT_C, ln)
-                                  : wave_exscan_lds(L.ecnt, C, ebase, ecur, ADMIT_E, ln);
-        if (over) L.maxr = 65;
-    }
-    bscan::lds_barrier();
-    const bool fits = L.maxr <= 64;
-    TR(w, 5);
-    if (!fits) return -2;                                 // (the table is gone by now: the other form starts over)
-    // rows / columns grouped by component; a row takes its edge range from its component's block, so that the
-    // edges of one component are contiguous (rows and ranges in arbitrary order inside: the solver sorts rows by id)
-    for (int s = tid; s < NA; s += nth) {
-        const int c = L.comp[s], deg = L.rptr[s];
-        const int pos = atomicAdd(&cur_r[c], 1), e0 = atomicAdd(&ecur[c], deg);
-        cursor[s] = e0;
-        w.rowinfo[pos] = make_int4(L.arow[s], e0, e0 + deg, 0);
-    }
-    for (int s = tid; s < MA; s += nth) {
-        const int c = L.ccomp[s], pos = atomicAdd(&cur_c[c], 1);
-        lane_of_col[s] = (uint16_t)(pos - L.ccp[c]);
-        w.colid[pos] = L.acol[s];
-    }
-    for (int c = tid; c <= C; c += nth) {                 // (entry C: the end of the last component's blocks)
-        const int r = c < C ? L.crp[c + 1] - L.crp[c] : 0, cn = c < C ? L.ccp[c + 1] - L.ccp[c] : 0, ne = c < C ? L.ecnt[c] : 0;
-        w.cdesc[c] = make_int4(L.crp[c], L.ccp[c], (r > 255 ? 255 : r) | ((cn > 255 ? 255 : cn) << 8) | ((ne > 0x7fff ? 0x7fff : ne) << 16), ebase[c]);
-    }
-    TR(w, 6);
-    if (!cached) __syncthreads();                         // (w.hard[] is read back below: its stores must have landed)
-    else bscan::lds_barrier();
-    if (cached) {
-#pragma unroll
-        for (int k = 0; k < EC; ++k)
-            if (hs[k] >= 0) {
-                const int pos = atomicAdd(&cursor[L.hr[hs[k]]], 1);
-                w.csr_lcol[pos] = lane_of_col[L.hc[hs[k]]];
-                w.csr_cost[pos] = hcost[k];
-            }
-    } else {
-        for (int h = tid; h < EH; h += nth) {
-            const int pos = atomicAdd(&cursor[L.hr[h]], 1);
-            w.csr_lcol[pos] = lane_of_col[L.hc[h]];
-            w.csr_cost[pos] = w.e_cost[RLX(&w.hard[h])];
-        }
-    }
-    if (tid == 0) { RST(&w.hdr[H_COMPS], C); RST(&w.hdr[H_HARD], C); RST(&w.hdr[H_MODE], 1); RST(&w.hdr[H_NH], EH); }
-    TR(w, 7);
-    return 0;
+    PSTAT(EH <= SM_EH ? LS_PREP_A : LS_PREP_B);
+    if (EH <= SM_EH) return small_tail<EC>(A, H, *reinterpret_cast<SmallTailA *>(lds + sizeof(SmallHead)), tab, EH, n, cached, hs, hcost);
+    return small_tail<EC>(A, H, *reinterpret_cast<SmallTailB *>(lds + sizeof(SmallHead)), tab, EH, n, cached, hs, hcost);
 }
 
 // one counter bump per wavefront instead of one contended global atomic per lane: returns this lane's slot (pred lanes)
@@ -586,26 +651,6 @@ __device__ __forceinline__ double wave_min_d(double d, int cn) {
     if (cn > 32) d = fmin(d, __shfl_xor(d, 32));
     return bcast_d(d, 0);
 }
-
-// Step counters of the component solvers: emulator build only (tests/hip_emu; scripts/lap_steps_cpu.py reads them) -- the
-// device build compiles LSTAT to nothing.
-#if defined(BTS_HOST_EMU)
-static long long g_lapstat[16];
-extern "C" void bts_emu_lap_stats(long long *out, int reset) {
-    for (int k = 0; k < 16; ++k) { if (out) out[k] = g_lapstat[k]; if (reset) g_lapstat[k] = 0; }
-}
-#define LSTAT(k, n) do { if (lane == 0) g_lapstat[k] += (n); } while (0)
-#define LSTAT_MAX(k, n) do { if (lane == 0 && g_lapstat[k] < (n)) g_lapstat[k] = (n); } while (0)
-#define LSTAT_DECL(v) long long v = 0
-#define LSTAT_INC(v) (++v)
-#else
-#define LSTAT_DECL(v)
-#define LSTAT_INC(v)
-#define LSTAT(k, n) do { } while (0)
-#define LSTAT_MAX(k, n) do { } while (0)
-#endif
-enum { LS_PACKED = 0, LS_TALL = 1, LS_GLOBAL = 2, LS_AUG = 3, LS_STEPS = 4, LS_RELAX = 5, LS_TALL_AUG = 6, LS_TALL_STEPS = 7, LS_TALL_RELAX = 8,
-       LS_MAX_COMP_STEPS = 9, LS_PATH = 10, LS_TALL_PRELUDE = 11, LS_GLOBAL_ROWS = 12, LS_GLOBAL_COLS = 13, LS_GLOBAL_STEPS = 14, LS_BIG = 15 };
 
 // ---- 3. one wavefront per packed component: shortest augmenting paths ---------------------------------
 constexpr int DN_R = 8, DN_C = 32;   // components up to DN_R x DN_C also get a dense cost block
@@ -1311,7 +1356,7 @@ __device__ __forceinline__ void solve_component(const LapArgs &A, int c, int lan
 // workgroups wait for hdr[H_READY] (1 + number of packed components) and share the components.
 constexpr int LAP_SOLO_EDGES = 64;   // edge lists up to this length are solved by the preparing workgroup alone
 constexpr int LAP_HELPERS = 15, LAP_HELPERS_BIG = 63;    // helper workgroups per problem (16 wavefronts each): small / big problems
-constexpr unsigned LAP_LDS_BYTES = sizeof(SmallPipe) > 16 * sizeof(WaveLds) ? sizeof(SmallPipe) : 16 * sizeof(WaveLds);
+constexpr unsigned LAP_LDS_BYTES = SMALL_PIPE_BYTES > 16 * sizeof(WaveLds) ? (unsigned)SMALL_PIPE_BYTES : 16 * (unsigned)sizeof(WaveLds);
 static_assert(sizeof(BigLds) <= LAP_LDS_BYTES, "solve_big_cols: its image must fit the kernel's dynamic LDS");
 static_assert(LAP_LDS_BYTES + 4096 + 512 <= 160 * 1024, "k_lap: dynamic + static LDS exceed a CU's 160 KiB");
 
@@ -1348,10 +1393,12 @@ template <int EC> __global__ __launch_bounds__(1024) void k_lap(LapPair P) {
             __syncthreads();
         }
         int state = E > 0 ? -2 : 0;
-        if (E > 0 && n + m <= TABLE_CAP) state = small_pipeline<EC>(A, *reinterpret_cast<SmallPipe *>(lds_raw), E, n, m, tmp);
+        if (E > 0 && n + m <= TABLE_CAP) state = small_pipeline<EC>(A, lds_raw, E, n, m, tmp);
         if (state < 0) {                                  // LARGE form: global degree arrays
             __syncthreads();
             const int EH = state == -1 && n + m <= TABLE_CAP ? RLX(&w.hdr[H_NH]) : isolated_pairs(A, E);
+            PSTAT(LS_PREP_LARGE);
+            if (state == -2) PSTAT(LS_PREP_AGAIN);
             if (EH > 0) large_pipeline(A, EH, tmp, reinterpret_cast<int32_t *>(lds_raw), (int)(LAP_LDS_BYTES / sizeof(int32_t)));
         }
         __syncthreads();

@@ -22,7 +22,7 @@ import tests.hip_emu.emu_prelude                                      # noqa: E4
 from oracle import bts_oracle as bo                                   # noqa: E402
 
 pkg = importlib.import_module("bot-sort-onnx-tensorrt_amd")
-NAMES = ["packed", "tall", "global", "aug", "steps", "relax", "tall_aug", "tall_steps", "tall_relax", "max_comp_steps", "path", "tall_prelude", "big_or_global_rows", "big_or_global_cols", "big_or_global_steps", "big"]
+NAMES = ["packed", "tall", "global", "aug", "steps", "relax", "tall_aug", "tall_steps", "tall_relax", "max_comp_steps", "path", "tall_prelude", "big_or_global_rows", "big_or_global_cols", "big_or_global_steps", "big", "prep_lds_a", "prep_lds_b", "prep_global", "prep_started_over"]
 
 
 def main():
@@ -37,7 +37,7 @@ def main():
     lib.bts_emu_lap_stats.argtypes = [ctypes.c_void_p, ctypes.c_int]
     st = pkg.synth.SyntheticStream(a.K, a.M, a.D, seed=11, **pkg.synth.ADVERSARIAL.get(a.workload, {}))
     ora = bo.TrackerOracle()
-    tot = np.zeros(16, dtype=np.int64)
+    tot = np.zeros(24, dtype=np.int64)
     for f in range(a.frames + 1):
         fr = st.next()
         ora.update_arrays(fr.boxes, fr.scores.astype(np.float64), fr.feats.copy())
@@ -47,7 +47,7 @@ def main():
         lib.bts_emu_lap_stats(None, 1)
         t0 = time.time()
         _, x, y = pkg.matching.lapjv(c, extend_cost=True, cost_limit=0.8)
-        out = np.zeros(16, dtype=np.int64)
+        out = np.zeros(24, dtype=np.int64)
         lib.bts_emu_lap_stats(out.ctypes.data, 1)
         want = ora.trace["m1"]
         got = np.asarray([[i, j] for i, j in enumerate(x) if j >= 0]).reshape(-1, 2)

@@ -30,6 +30,7 @@ SUBSET = [
     "tests/test_gpu_round2.py::test_strack_lifecycle_methods_vs_oracle",
     "tests/test_zz_gpu_round3.py::test_lapjv_column_form_components_vs_oracle",
     "tests/test_zz_gpu_round3.py::test_lapjv_components_beyond_a_wavefronts_lds_vs_oracle",
+    "tests/test_zz_gpu_round3.py::test_lapjv_lds_preparation_layouts_vs_oracle",
 ]
 DESELECT = "not (ragged and not (5-2-64 or 4-1-64 or 17-9-128)) and not (column_form and not 0)"
 
@@ -44,4 +45,4 @@ def test_gpu_parity_tests_pass_on_the_emulated_kernels():
     tail = "\n".join(out.stdout.splitlines()[-25:]) + out.stderr[-2000:]
     assert out.returncode == 0, tail
     m = re.search(r"(\d+) passed", out.stdout)
-    assert m and int(m.group(1)) >= 64, tail
+    assert m and int(m.group(1)) >= 67, tail

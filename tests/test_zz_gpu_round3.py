@@ -260,3 +260,24 @@ def test_lapjv_components_beyond_a_wavefronts_lds_vs_oracle(bts, case):
     _, xo, yo = bo.lapjv(c, True, limit)
     _, x, y = bts.lapjv(c, True, limit)
     assert np.array_equal(x, xo) and np.array_equal(y, yo), case
+
+
+@pytest.mark.parametrize("case", ["b-crowd", "b-too-many-components", "past-b"])
+def test_lapjv_lds_preparation_layouts_vs_oracle(bts, case):
+    """The solver's LDS preparation has two layouts since round 3: up to 4096 non-trivial edges with up to 2048 components, or
+    up to 6144 edges with up to 1536 components (dense crowds: 5 000+ edges in a few hundred components).  `b-crowd`: ~5 000
+    edges in crowd-shaped components (layout B); `b-too-many-components`: ~4 600 edges in 2 300 two-edge components -- layout B
+    finds more components than it holds and the global-memory preparation starts over; `past-b`: more than 6144 edges."""
+    from oracle import bts_oracle as bo
+    rng = np.random.default_rng({"b-crowd": 11, "b-too-many-components": 12, "past-b": 13}[case])
+    limit = 0.8
+    if case == "b-too-many-components":
+        shapes = [(2, 1, False)] * 2300
+    else:
+        shapes = [(int(rng.integers(20, 64)), int(rng.integers(6, 20)), bool(rng.integers(2))) for _ in range(56 if case == "b-crowd" else 80)]
+    c = _crowd_blocks(rng, shapes, limit)
+    hard = int((c <= limit).sum())
+    assert {"b-crowd": 4300 < hard < 6000, "b-too-many-components": 4300 < hard < 6000, "past-b": hard > 6300}[case], hard
+    _, xo, yo = bo.lapjv(c, True, limit)
+    _, x, y = bts.lapjv(c, True, limit)
+    assert np.array_equal(x, xo) and np.array_equal(y, yo), case
