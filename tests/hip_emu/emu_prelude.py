@@ -33,6 +33,9 @@ class _Event:
     def synchronize(self):
         pass
 
+    def elapsed_time(self, other):        # (the emulator does not tell time; callers only need a positive number)
+        return 1.0
+
 
 torch.cuda.is_available = lambda: True
 torch.cuda.device_count = lambda: 1
