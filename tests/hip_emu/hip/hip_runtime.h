@@ -16,6 +16,7 @@
 #include <stdio.h>
 #include <math.h>
 #include <functional>
+#include <vector>
 #include <algorithm>
 
 // ---- qualifiers -------------------------------------------------------------------------------------------------------------
@@ -170,9 +171,9 @@ static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
 static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
 static inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
 static inline hipError_t hipMemset(void *p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
-static inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t = nullptr) { memset(p, v, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t = nullptr);
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
-static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t = nullptr);
 static inline hipError_t hipMemcpy2DAsync(void *d, size_t dp, const void *s, size_t sp, size_t w, size_t h, hipMemcpyKind, hipStream_t = nullptr) {
     for (size_t r = 0; r < h; ++r) memmove((char *)d + r * dp, (const char *)s + r * sp, w);
     return hipSuccess;
@@ -189,13 +190,25 @@ static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t = nullptr) { ret
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.001f; return hipSuccess; }
 template <class F> static inline hipError_t hipFuncSetAttribute(F, hipFuncAttribute, int) { return hipSuccess; }
-// hipGraph: not emulated (use_graph is refused by the emulated build)
-static inline hipError_t hipStreamBeginCapture(hipStream_t, int) { return hipErrorInvalidValue; }
-static inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t *g) { *g = nullptr; return hipErrorInvalidValue; }
-static inline hipError_t hipGraphInstantiate(hipGraphExec_t *, hipGraph_t, void *, void *, size_t) { return hipErrorInvalidValue; }
-static inline hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
-static inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipErrorInvalidValue; }
-static inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
+// hipGraph: while a capture is open, launches / async copies / memsets are RECORDED as closures (arguments frozen by value,
+// like kernel nodes) instead of executed; a graph launch runs the recorded list in order.  One capture at a time; forked
+// capture streams and the events between them are no-ops here, as every stream is in-order.
+struct EmuGraph { std::vector<std::function<void()>> nodes; };
+struct EmuGraphExec { std::vector<std::function<void()>> nodes; };
+namespace emu {
+EmuGraph *&capturing();
+void launch_or_record(dim3 grid, dim3 block, size_t dyn_lds, std::function<void()> body);
+static inline bool record(std::function<void()> f) { if (!capturing()) return false; capturing()->nodes.push_back(std::move(f)); return true; }
+}
+static inline hipError_t hipStreamBeginCapture(hipStream_t, int) { if (emu::capturing()) return hipErrorInvalidValue; emu::capturing() = new EmuGraph(); return hipSuccess; }
+static inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t *g) { *g = emu::capturing(); emu::capturing() = nullptr; return *g ? hipSuccess : hipErrorInvalidValue; }
+static inline hipError_t hipGraphInstantiate(hipGraphExec_t *e, hipGraph_t g, void *, void *, size_t) { *e = new EmuGraphExec{g->nodes}; return hipSuccess; }
+static inline hipError_t hipGraphDestroy(hipGraph_t g) { delete g; return hipSuccess; }
+static inline hipError_t hipGraphLaunch(hipGraphExec_t e, hipStream_t) { for (auto &f : e->nodes) f(); return hipSuccess; }
+static inline hipError_t hipGraphExecDestroy(hipGraphExec_t e) { delete e; return hipSuccess; }
+
+static inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { if (!emu::record([=]() { memset(p, v, n); })) memset(p, v, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { if (!emu::record([=]() { memmove(d, s, n); })) memmove(d, s, n); return hipSuccess; }
 
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
-    emu::launch(dim3(grid), dim3(block), (size_t)(shmem), [=]() { kern(__VA_ARGS__); })
+    emu::launch_or_record(dim3(grid), dim3(block), (size_t)(shmem), [=]() { kern(__VA_ARGS__); })

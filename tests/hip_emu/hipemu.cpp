@@ -218,4 +218,10 @@ void launch(dim3 grid, dim3 block, size_t dyn_lds, const std::function<void()> &
     g_body = nullptr;
 }
 
+EmuGraph *&capturing() { static EmuGraph *g = nullptr; return g; }
+void launch_or_record(dim3 grid, dim3 block, size_t dyn_lds, std::function<void()> body) {
+    if (capturing()) { capturing()->nodes.push_back([=]() { launch(grid, block, dyn_lds, body); }); return; }
+    launch(grid, block, dyn_lds, body);
+}
+
 }  // namespace emu

@@ -6,7 +6,7 @@ never what ships or what is measured, and it says nothing about speed, memory or
 kernels whose bodies are MFMA / LDS-DMA assembly (k_filter_i8, k_filter_splitk: contract-level stand-ins; k_cos_mfma: the
 tests of the float32 GEMM run its non-MFMA sibling) -- it checks that the code as written computes what the oracle computes.
 Round 3 had no GPU: this is how its GPU tests were run before they ever met one (the whole of the five GPU files passes on
-the emulator except graph capture and four sizes that time out)."""
+the emulator)."""
 import os
 import re
 import shutil
