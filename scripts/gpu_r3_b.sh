@@ -15,7 +15,8 @@ python scripts/prof_top.py $O/prof_target > $O/target_kernel_stats.csv 2>/dev/nu
 [ -f ab/r2_8cbc337.so ] && [ -f ab/head.so ] && for w in target c3; do echo "== A/B $w"; VARIANTS="r2_8cbc337 head" WL=$w KERN="tk_front|tk_edges_tall|tk_mid1|k_filter" bash scripts/gpu_ab2.sh 2>&1 | tail -24; done
 # k_lap: column-form / whole-LDS component solvers (round 3, default) against the round-2 row forms
 # (ab/lap_rowform.so = scripts/build_variant.sh lap_rowform EXTRA=-DBTS_LAP_TALL_ROWFORM), on the crowd scenes and the headline size
-[ -f ab/lap_rowform.so ] && [ -f ab/head.so ] && for w in crowd crowd-hard-reid target; do echo "== A/B k_lap $w"; VARIANTS="lap_rowform head" WL=$w KERN="k_lap" bash scripts/gpu_ab2.sh 2>&1 | tail -12; done
+# (lap_rowform shares round 3's preparation layouts: it isolates the solvers; r2_8cbc337 is the whole round-2 library)
+[ -f ab/lap_rowform.so ] && [ -f ab/head.so ] && for w in crowd crowd-hard-reid target; do echo "== A/B k_lap $w"; VARIANTS="$([ -f ab/r2_8cbc337.so ] && echo r2_8cbc337) lap_rowform head" WL=$w KERN="k_lap" bash scripts/gpu_ab2.sh 2>&1 | tail -18; done
 # scheduling experiments (same library, env switches read at bts_tracker_create), interleaved, at the headline size and c3
 for w in target c3; do for rep in 1 2; do for exp in none BTS_PREDICT_FIRST BTS_CVT_OVERLAP both; do
   unset BTS_PREDICT_FIRST BTS_CVT_OVERLAP
