@@ -17,6 +17,8 @@ python scripts/prof_top.py $O/prof_target > $O/target_kernel_stats.csv 2>/dev/nu
 # (ab/lap_rowform.so = scripts/build_variant.sh lap_rowform EXTRA=-DBTS_LAP_TALL_ROWFORM), on the crowd scenes and the headline size
 # (lap_rowform shares round 3's preparation layouts: it isolates the solvers; r2_8cbc337 is the whole round-2 library)
 [ -f ab/lap_rowform.so ] && [ -f ab/head.so ] && for w in crowd crowd-hard-reid target; do echo "== A/B k_lap $w"; VARIANTS="$([ -f ab/r2_8cbc337.so ] && echo r2_8cbc337) lap_rowform head" WL=$w KERN="k_lap" bash scripts/gpu_ab2.sh 2>&1 | tail -18; done
+# k_lap's own phase timeline (ab/trace.so = scripts/build_variant.sh trace TRACE=1): where the preparation and the solve spend the launch
+if [ -f ab/trace.so ]; then BTS_LIB_PATH=$PWD/ab/trace.so timeout 600 python scripts/dbg_laptrace.py crowd c3 target > $O/lap_trace.txt 2>&1; cat $O/lap_trace.txt; fi
 # scheduling experiments (same library, env switches read at bts_tracker_create), interleaved, at the headline size and c3
 for w in target c3; do for rep in 1 2; do for exp in none BTS_PREDICT_FIRST BTS_CVT_OVERLAP both; do
   unset BTS_PREDICT_FIRST BTS_CVT_OVERLAP
