@@ -4,7 +4,7 @@ pkg = importlib.import_module("bot-sort-onnx-tensorrt_amd")
 for wl in sys.argv[1:]:
     K, M, D = pkg.synth.workload_dims(wl)
     st = pkg.synth.make_workload(wl, seed=1234)
-    trk = pkg.DeviceTracker(max_tracks=K + 64, max_dets=max(K, M), feat_dim=D)
+    trk = pkg.DeviceTracker(max_tracks=2 * K, max_dets=max(K, M), feat_dim=D)
     acc = []
     for f in range(40):
         fr = st.next()
