@@ -7,6 +7,7 @@
 #include "hip/hip_runtime.h"
 #include <ucontext.h>
 #include <sys/mman.h>
+#include <algorithm>
 #include <mutex>
 #include <vector>
 
@@ -205,6 +206,17 @@ void launch(dim3 grid, dim3 block, size_t dyn_lds, const std::function<void()> &
     for (unsigned z = 0; z < grid.z; ++z)
         for (unsigned y = 0; y < grid.y; ++y)
             for (unsigned x = 0; x < grid.x; ++x) todo.push_back(dim3(x, y, z));
+    // HIPEMU_ORDER=reverse | shuffle[:seed]: the hardware promises no execution order between workgroups -- results that
+    // depend on it (the order entries are appended through atomic counters, who finishes last) must not change
+    static const char *order = getenv("HIPEMU_ORDER");
+    if (order && !strncmp(order, "reverse", 7)) std::reverse(todo.begin(), todo.end());
+    else if (order && !strncmp(order, "shuffle", 7)) {
+        static uint64_t rng = order[7] == ':' ? strtoull(order + 8, nullptr, 10) * 2654435761u + 1 : 12345;
+        for (size_t i = todo.size(); i > 1; --i) {
+            rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+            std::swap(todo[i - 1], todo[(size_t)((rng >> 33) % i)]);
+        }
+    }
     while (!todo.empty()) {
         later.clear();
         for (const dim3 &b : todo) {
