@@ -141,9 +141,13 @@ static bool run_block(int nthreads) {        // false: the workgroup was deferre
         makecontext(&T.ctx, trampoline, 0);
     }
     const int nwaves = (nthreads + 63) / 64;
+    // HIPEMU_THREADS=reverse: the threads of a workgroup take their turns in descending order -- a hand-off between
+    // wavefronts that lacks its barrier works in one order and breaks in the other
+    static const bool rev = getenv("HIPEMU_THREADS") && !strcmp(getenv("HIPEMU_THREADS"), "reverse");
     for (;;) {
         bool progress = false, all_done = true;
-        for (int t = 0; t < nthreads; ++t) {
+        for (int tt = 0; tt < nthreads; ++tt) {
+            const int t = rev ? nthreads - 1 - tt : tt;
             if (g_th[t].st == READY) {
                 g_cur = &g_th[t];
                 swapcontext(&g_sched, &g_th[t].ctx);
