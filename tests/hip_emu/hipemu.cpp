@@ -35,7 +35,6 @@ static const std::function<void()> *g_body = nullptr;
 alignas(64) static char g_dyn_lds[160 * 1024];
 static int g_bar_or = 0;
 static int g_spins = 0;
-static bool g_defer = false;
 
 Thread *cur() { return g_cur; }
 unsigned tid_x() { return (unsigned)g_cur->tid; }
@@ -62,10 +61,13 @@ uint64_t collective(Op op, int site, uint64_t value, int arg, int arg2, uint64_t
     return t->result;
 }
 
+// A spin on something another thread has to write.  The spinner first lets the other threads of its workgroup run (the value
+// may come from one of them: lane 0 publishes, its neighbours wait); only when a whole pass over the workgroup was nothing
+// but spinners -- the value has to come from another WORKGROUP -- is the workgroup dropped, to be re-run later.
+static bool g_spun = false;          // the thread that just came back to the scheduler did so from spin()
 void spin() {
-    if (++g_spins < 64) return;
-    g_defer = true;
-    swapcontext(&g_cur->ctx, &g_sched);          // never resumed: the scheduler drops the workgroup and re-runs it later
+    g_spun = true;
+    swapcontext(&g_cur->ctx, &g_sched);          // (stays READY; if the workgroup is dropped it is never resumed)
 }
 
 static void trampoline() {
@@ -123,7 +125,7 @@ static void serve_group(int wave_base, int nlanes, const std::vector<int> &membe
 }
 
 static bool run_block(int nthreads) {        // false: the workgroup was deferred (it waits for workgroups that have not run yet)
-    g_spins = 0; g_defer = false;
+    g_spins = 0;
     if ((size_t)nthreads > g_nstacks) {
         if (g_stacks) munmap(g_stacks, g_nstacks * STACK);
         g_nstacks = (size_t)nthreads;
@@ -145,18 +147,21 @@ static bool run_block(int nthreads) {        // false: the workgroup was deferre
     // wavefronts that lacks its barrier works in one order and breaks in the other
     static const bool rev = getenv("HIPEMU_THREADS") && !strcmp(getenv("HIPEMU_THREADS"), "reverse");
     for (;;) {
-        bool progress = false, all_done = true;
+        bool progress = false, all_done = true, moved = false, spinners = false;
         for (int tt = 0; tt < nthreads; ++tt) {
             const int t = rev ? nthreads - 1 - tt : tt;
             if (g_th[t].st == READY) {
                 g_cur = &g_th[t];
+                g_spun = false;
                 swapcontext(&g_sched, &g_th[t].ctx);
-                if (g_defer) return false;
                 progress = true;
+                if (g_spun) spinners = true; else moved = true;
             }
             if (g_th[t].st != DONE) all_done = false;
         }
         if (all_done) return true;
+        if (spinners && !moved && ++g_spins >= 4) return false;      // only spinners are left runnable: the wait is for another workgroup
+        if (moved) g_spins = 0;
         // wavefront collectives
         bool served = false;
         for (int w = 0; w < nwaves; ++w) {
