@@ -72,6 +72,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline, the ID match and the standalone kernels")
     ap.add_argument("--no-export", action="store_true", help="skip the export-inclusive legs")
+    ap.add_argument("--no-standalone", action="store_true", help="skip the standalone kernel rooflines of the small workloads")
     ap.add_argument("--dense", action="store_true", help="dense float32 appearance path instead of the int8 pre-filter")
     ap.add_argument("--graph", action="store_true", help="replay each step as one hipGraph (bts_tracker_config.use_graph)")
     ap.add_argument("--breakdown", action="store_true", help="also print the per-segment timing table to stderr")
@@ -249,19 +250,42 @@ def cpu_baseline(pkg, wl, seed, budget_s, checker=None, faithful=True, max_frame
                       % (n, n + 1, t_used, os.cpu_count() or 0)}
 
 
-def pmc_traffic(workload, kernel_name):
-    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE,
-    separate runs: scripts/gpu_pmc_traffic.sh -> scripts/pmc_to_json.py).  None when no pass covers this workload."""
+def pmc_traffic(workload, kernel_name, lib_path=None):
+    """(HBM bytes per launch of the roofline kernel, provenance) from the committed rocprofv3 --pmc passes (FETCH_SIZE /
+    WRITE_SIZE, separate runs: scripts/gpu_pmc_traffic.sh -> scripts/pmc_to_json.py).  The counters belong to the machine
+    code they were taken on: every entry of profiles/pmc_traffic.json carries the hash of its kernel's instruction stream
+    (scripts/kernel_hashes.py --stamp), and the figure is quoted only when the LOADED library holds a kernel of that name
+    with the same hash -- otherwise traffic is None and the provenance says so."""
+    src = {"file": "profiles/pmc_traffic.json", "taken_at_commit": None, "kernel_hash": None, "loaded_library_matches": None}
     try:
-        tab = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))["workloads"][workload]
+        doc = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
+        src["taken_at_commit"] = doc.get("taken_at_commit")
+        tab = doc["workloads"][workload]
     except Exception:
-        return None
+        src["note"] = "no counter pass covers this workload"
+        return None, src
+    sys.path.insert(0, os.path.join(REPO, "scripts"))
+    try:
+        import kernel_hashes as kh
+        live = kh.library_hashes(lib_path) if lib_path else {}
+    except Exception as e:
+        src["note"] = "kernel hashes of the loaded library unavailable (%s): counters not quoted" % str(e)[:120]
+        return None, src
     bases = [alt.strip().split("<")[0] for alt in kernel_name.split("|")]      # (a kernel may have several forms)
-    best = None
+    live_hashes = {h for n, h in live.items() if kh.base(n) in bases}
+    best, stale = None, False
     for k, v in tab.items():
-        if k.split("<")[0] in bases and v.get("traffic_bytes") is not None:
-            best = max(best or 0.0, v["traffic_bytes"])       # the form that ran (the others are absent or tiny)
-    return best
+        if k.split("<")[0] not in bases or v.get("traffic_bytes") is None:
+            continue
+        if v.get("kernel_hash") and v["kernel_hash"] in live_hashes:
+            if best is None or v["traffic_bytes"] > best:      # the form that ran (the others are absent or tiny)
+                best, src["kernel_hash"] = v["traffic_bytes"], v["kernel_hash"]
+        else:
+            stale = True
+    src["loaded_library_matches"] = best is not None
+    if best is None and stale:
+        src["note"] = "the kernel's machine code has changed since the counter pass: re-run scripts/gpu_pmc_traffic.sh"
+    return best, src
 
 
 def several_streams(a, counts):
@@ -279,6 +303,20 @@ def several_streams(a, counts):
         except Exception as e:          # a reported extra, never fatal for the headline line
             out.append({"streams": n, "value": None, "error": str(e)[:200]})
     return out
+
+
+def guarded(name, fn, *args, **kw):
+    """Every leg BEHIND the timed region is an extra: whatever it raises becomes {"error": ...} in its object and the
+    headline line (value, roofline, cpu_baseline) is still printed -- a first-contact failure in the export, facade or
+    checker code must not cost the measurement."""
+    try:
+        return fn(*args, **kw)
+    except BaseException as e:          # (incl. SystemExit / assertion failures of a leg)
+        if isinstance(e, KeyboardInterrupt):
+            raise
+        import traceback
+        sys.stderr.write("bench.py: leg %r failed:\n%s\n" % (name, traceback.format_exc()))
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
 
 
 def ms_seed(pkg, rank):
@@ -467,65 +505,79 @@ def main():
     # ---- behind the timed region: which kernel dominates a step, and its duration (separate event passes)
     breakdown = {}
     more = [next_frame() for _ in range(PROBE)]
-    for seg in SEGMENTS + tuple(k for k in KERNELS if k not in SEGMENTS) + ("step",):
-        trk.profile_enable(seg, PROBE)
-        for fr in more:
+
+    def probe_kernels():
+        for seg in SEGMENTS + tuple(k for k in KERNELS if k not in SEGMENTS) + ("step",):
+            trk.profile_enable(seg, PROBE)
+            for fr in more:
+                trk.step(*fr)
+            ms_, n_ = trk.profile_read()
+            breakdown[seg] = 1e3 * ms_ / max(n_, 1)
+        segment = a.segment if a.segment != "auto" else max(KERNELS, key=lambda k: breakdown[k])
+        roof_frames = (timed + more)[: a.roofline_steps] if len(timed) + len(more) >= a.roofline_steps else timed + more
+        trk.profile_enable(segment, len(roof_frames))
+        for fr in roof_frames:
             trk.step(*fr)
-        ms_, n_ = trk.profile_read()
-        breakdown[seg] = 1e3 * ms_ / max(n_, 1)
-    segment = a.segment if a.segment != "auto" else max(KERNELS, key=lambda k: breakdown[k])
-    roof_frames = (timed + more)[: a.roofline_steps] if len(timed) + len(more) >= a.roofline_steps else timed + more
-    trk.profile_enable(segment, len(roof_frames))
-    for fr in roof_frames:
-        trk.step(*fr)
-    torch.cuda.synchronize()
-    seg_ms, seg_n = trk.profile_read()
-    trk.profile_enable("step", 0)
-    if trk.counts()["errors"] != 0 and not IGNORE:
-        trk.export(0)            # (raises with the device's own account of what overflowed, and when)
+        torch.cuda.synchronize()
+        seg_ms, seg_n = trk.profile_read()
+        trk.profile_enable("step", 0)
+        return segment, seg_ms, seg_n
+
+    probe = guarded("kernel_probe", probe_kernels)
+    probe_error = probe.get("error") if isinstance(probe, dict) else None
+    segment, seg_ms, seg_n = ("k_filter", 0.0, 0) if probe_error else probe
+    late_errors = guarded("device_errors", lambda: trk.counts()["errors"])
+    if late_errors != 0 and not IGNORE and not isinstance(late_errors, dict):
+        guarded("device_error_message", trk.export, 0)            # (logs the device's own account of what overflowed, and when)
     if a.breakdown and rank == 0:
         sys.stderr.write("segment us/step: " + json.dumps({k: round(v, 1) for k, v in breakdown.items()}) + "\n")
 
     export = None
     if rank == 0 and S == 1 and not a.no_export and not a.graph:
-        export = export_legs(pkg, trk, timed, torch)
-        assert trk.counts()["errors"] == 0
+        export = guarded("export_inclusive", export_legs, pkg, trk, timed, torch)
 
     facade = None
     if rank == 0 and world == 1 and S == 1 and not a.no_export and not a.graph and not a.dense and not a.motion_gate:
         nf = max(16, min(a.steps, 64))
-        facade = facade_leg(pkg, torch, a.workload, nf, ms_seed(pkg, 0))
+        facade = guarded("facade", facade_leg, pkg, torch, a.workload, nf, ms_seed(pkg, 0))
         if a.workload == "target":
-            facade = {"target": facade, "c2": facade_leg(pkg, torch, "c2", 4 * nf, ms_seed(pkg, 0))}
+            facade = {"target": facade, "c2": guarded("facade_c2", facade_leg, pkg, torch, "c2", 4 * nf, ms_seed(pkg, 0))}
 
     big = K > 1024
     id_multi = None
     if world > 1 and not a.no_cpu and S == 1 and not a.dense:
         # ID match of EVERY rank's stream (N > 1: no CPU baseline, that is the N = 1 line's): steady-state frames of this
         # rank's stream through a second handle and the oracle (vectorised IoU form: the checker, not a timing), gathered
-        chk = IdMatch(pkg, K, M, D, a.motion_gate)
-        cpu_baseline(pkg, a.workload, ms_seed(pkg, rank), 120.0, chk, faithful=False, max_frames=4 if big else 24, motion_gate=a.motion_gate)
+        def rank_ids():
+            chk = IdMatch(pkg, K, M, D, a.motion_gate)
+            cpu_baseline(pkg, a.workload, ms_seed(pkg, rank), 120.0, chk, faithful=False, max_frames=4 if big else 24, motion_gate=a.motion_gate)
+            return dict(chk.result(), stream_seed=int(ms_seed(pkg, rank)))
         id_multi = [None] * world
-        dist.all_gather_object(id_multi, chk.result())
+        dist.all_gather_object(id_multi, guarded("id_match(rank %d)" % rank, rank_ids))      # (every rank takes part, whatever its checker did)
 
     if rank == 0:
-        filt = trk.debug_filter()
-        bound, amount, unit, peak = kernel_model(segment, K, M, D, a.dense, filt)
-        seg_s = (seg_ms / 1e3) / max(seg_n, 1)
+        filt = guarded("prefilter", trk.debug_filter)
+        filt_ok = isinstance(filt, dict) and "error" not in filt
+        bound, amount, unit, peak = kernel_model(segment, K, M, D, a.dense, filt if filt_ok else None)
+        seg_s = (seg_ms / 1e3) / max(seg_n, 1) if seg_n else None
         if bound == "mfma":
-            achieved, runit = amount / seg_s / 1e12, "TOP/s"
+            achieved, runit = (amount / seg_s / 1e12 if seg_s else None), "TOP/s"
         else:
-            achieved, runit = amount / seg_s / 1e9, "GB/s"
+            achieved, runit = (amount / seg_s / 1e9 if seg_s else None), "GB/s"
         step_s = elapsed / a.steps
         b_survey, b_built = step_bytes(K, M, D)
+        traffic = guarded("roofline.traffic", pmc_traffic, a.workload, KERNELS[segment], getattr(pkg._lib, "LIB_PATH", None))
+        traffic, traffic_src = traffic if isinstance(traffic, tuple) else (None, traffic)
         kern_roof = {"kernel": KERNELS[segment], "bound": bound,
                      "bound_peak": "dense int8 MFMA 5 POP/s" if bound == "mfma" else "HBM3E 8 TB/s",
-                     "achieved": achieved, "peak": peak, "unit": runit, "frac": achieved / peak,
-                     "traffic": pmc_traffic(a.workload, KERNELS[segment]),
+                     "achieved": achieved, "peak": peak, "unit": runit, "frac": achieved / peak if achieved is not None else None,
+                     "traffic": traffic, "traffic_source": traffic_src,
                      "traffic_unit": "bytes per launch (HBM, rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes, profiles/pmc_traffic.json)",
-                     "avg_us": 1e6 * seg_s, "launches_timed": seg_n,
+                     "avg_us": 1e6 * seg_s if seg_s else None, "launches_timed": seg_n,
                      "timed_in": "separate pass of %d steps behind the timed region, one hipEvent pair per launch on the step's stream" % seg_n,
                      "algorithmic_per_launch": amount, "algorithmic_unit": unit}
+        if probe_error:
+            kern_roof["error"] = probe_error
         out = {
             "metric": "tracker update-steps/sec (N_tracks x M_dets)",
             "value": ms.aggregate_throughput(a.steps * S, elapsed, world),
@@ -539,58 +591,87 @@ def main():
                        "tracks": K, "dets": M, "feat_dim": D, "streams": world * S, "parallelism": "%d stream%s/GPU, no collective" % (S, "" if S == 1 else "s (own HIP stream + host thread each)"),
                        "launch": "hipGraph replay" if a.graph else "eager", "motion_gate": bool(a.motion_gate),
                        "spawn": "self-spawned ranks" if os.environ.get("BTS_BENCH_SPAWNED") else ("torch.distributed.run" if world > 1 else "single process"),
-                       "oversubscribed": bool(world > ndev)},
-            # flat fields = the dominant kernel (contract); .kernel repeats it with its bound type, .step is the whole step
-            "roofline": dict(kern_roof, kernel_detail=None),
+                       "oversubscribed": bool(world > ndev),
+                       "opt_in": {k: v for k, v in os.environ.items() if k.startswith("BTS_") and k not in ("BTS_BENCH_SPAWNED", "BTS_LIB_PATH")}},
+            # flat fields = the dominant kernel (contract); .step is the whole step
+            "roofline": kern_roof,
         }
-        out["roofline"].pop("kernel_detail")
         out["roofline"]["step"] = {
             "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "us_per_step": 1e6 * step_s,
             "algorithmic_bytes_survey_formula": b_survey, "achieved_survey": b_survey / step_s / 1e9, "frac_survey": b_survey / step_s / 1e9 / HBM_PEAK_GBS,
             "algorithmic_bytes_as_built": b_built, "achieved_as_built": b_built / step_s / 1e9, "frac_as_built": b_built / step_s / 1e9 / HBM_PEAK_GBS,
-            "formula": "SURVEY.md 8(d) with fp32 element sizes (survey) / float64 Kalman rows, no N x M matrix, fp8 shadows (as built): bench.py step_bytes()"}
+            "formula": "SURVEY.md 8(d) with fp32 element sizes (survey) / float64 Kalman rows, no N x M matrix, int8 shadows (as built): bench.py step_bytes()"}
         out["segments_us"] = {k: round(v, 2) for k, v in breakdown.items()}
+        if not isinstance(late_errors, dict) and late_errors != 0:
+            out["device_errors_after_timed_region"] = late_errors
         Mh = max(1, counts.get("n_hi", M) or M)
-        if hasattr(trk, "_filter_raw") and os.environ.get("BTS_BENCH_IGNORE_ERRORS"):
-            filt = dict(filt, raw=[int(v) for v in trk._filter_raw])
-        out["prefilter"] = dict(filt, full_k_stages_equivalent=int(-(-K // 128) * -(-Mh // 128) * (D // 128)),
-                                candidates_per_high_detection=filt["candidates"] / Mh,
-                                what="last step: K stages of 128 elements run over all 128 x 128 tiles, tiles that stopped at a prefix "
-                                     "checkpoint, pairs handed to the exact float32 refinement")
-        out["lap"] = {"stage%d" % s: dict(zip(("edges", "components", "overflow", "hard_edges", "form"),
-                                               (lambda h: (int(h[0]), int(h[1]), int(h[2]), int(h[6]), int(h[8])))(trk.debug_lap(s)))) for s in (1, 2, 3)}
-        out["lap"]["stage1_us"] = round(breakdown.get("k_lap", 0.0), 2)      # the stage-1 launch alone (hipEvent pair around it)
-        out["lap"]["stage23_group_us"] = round(breakdown.get("stage2", 0.0), 2)   # k_lap(stages 2 + 3) + tk_apply23
+        if filt_ok:
+            if hasattr(trk, "_filter_raw") and os.environ.get("BTS_BENCH_IGNORE_ERRORS"):
+                filt = dict(filt, raw=[int(v) for v in trk._filter_raw])
+            out["prefilter"] = dict(filt, full_k_stages_equivalent=int(-(-K // 128) * -(-Mh // 128) * (D // 128)),
+                                    candidates_per_high_detection=filt["candidates"] / Mh,
+                                    what="last step: K stages of 128 elements run over all 128 x 128 tiles, tiles that stopped at a prefix "
+                                         "checkpoint, pairs handed to the exact float32 refinement")
+        else:
+            out["prefilter"] = filt
+
+        def lap_info():
+            d = {"stage%d" % s: dict(zip(("edges", "components", "overflow", "hard_edges", "form"),
+                                         (lambda h: (int(h[0]), int(h[1]), int(h[2]), int(h[6]), int(h[8])))(trk.debug_lap(s)))) for s in (1, 2, 3)}
+            d["stage1_us"] = round(breakdown.get("k_lap", 0.0), 2)      # the stage-1 launch alone (hipEvent pair around it)
+            d["stage23_group_us"] = round(breakdown.get("stage2", 0.0), 2)   # k_lap(stages 2 + 3) + tk_apply23
+            return d
+        out["lap"] = guarded("lap", lap_info)
         if export is not None:
             out["export_inclusive"] = export
         if facade is not None:
             out["facade"] = facade
         if id_multi is not None:
-            keys = ("frames", "frames_identical", "assignment_pairs", "assignment_pairs_equal", "track_ids", "track_ids_equal", "device_errors")
-            out["id_match"] = {k: sum(r[k] for r in id_multi) for k in keys}
-            out["id_match"].update({"kalman_mean_max_abs_err": max(r["kalman_mean_max_abs_err"] for r in id_multi), "kalman_tolerance": 1e-4,
-                                    "streams": world, "frames_identical_per_stream": [r["frames_identical"] for r in id_multi],
-                                    "against": "CPU oracle, the first frames of every rank's own stream"})
+            def gather_ids():
+                bad = [r for r in id_multi if not isinstance(r, dict) or "error" in r]
+                if bad:
+                    return {"error": "rank checker failed: %s" % str(bad[0])[:200], "streams": world}
+                keys = ("frames", "frames_identical", "assignment_pairs", "assignment_pairs_equal", "track_ids", "track_ids_equal", "device_errors")
+                d = {k: sum(r[k] for r in id_multi) for k in keys}
+                d.update({"kalman_mean_max_abs_err": max(r["kalman_mean_max_abs_err"] for r in id_multi), "kalman_tolerance": 1e-4,
+                          "streams": world, "frames_identical_per_stream": [r["frames_identical"] for r in id_multi],
+                          "stream_seeds": [r.get("stream_seed") for r in id_multi],
+                          "against": "CPU oracle, the first frames of every rank's own stream"})
+                return d
+            out["id_match"] = guarded("id_match", gather_ids)
         if not a.no_cpu and world == 1:
-            if not big:
+            if not big and not a.no_standalone:
                 # the dense kernels of the path, standalone, against their rooflines (a few seconds; at small sizes the
                 # step above is launch-bound, these show what the kernels do when they have work)
-                out["standalone_rooflines"] = importlib.import_module("bot-sort-onnx-tensorrt_amd.microbench").run(full=False)
+                out["standalone_rooflines"] = guarded("standalone_rooflines", lambda: importlib.import_module("bot-sort-onnx-tensorrt_amd.microbench").run(full=False))
             if a.several_streams and S == 1 and not a.graph:
                 # what ONE GPU serves when it is given several independent streams of this workload (own handle, HIP stream
                 # and host thread each: multistream.run_concurrent); not the headline configuration (1 stream per GPU)
                 out["several_streams_one_gpu"] = several_streams(a, (4, 8))
-            checker = IdMatch(pkg, K, M, D, a.motion_gate) if (S == 1 and not a.dense) else None
+            checker = guarded("id_match", IdMatch, pkg, K, M, D, a.motion_gate) if (S == 1 and not a.dense) else None
+            checker_err = checker if isinstance(checker, dict) else None
+            if checker_err:
+                checker = None
             if not big:
-                out["cpu_baseline"] = cpu_baseline(pkg, a.workload, ms_seed(pkg, 0), a.cpu_seconds, checker, motion_gate=a.motion_gate)
+                out["cpu_baseline"] = guarded("cpu_baseline", cpu_baseline, pkg, a.workload, ms_seed(pkg, 0), a.cpu_seconds, checker, motion_gate=a.motion_gate)
+                if isinstance(out["cpu_baseline"], dict) and "error" in out["cpu_baseline"] and checker is not None:
+                    # the checker raised inside the timed oracle loop: the baseline itself is re-taken without it
+                    out["id_match"] = {"error": out["cpu_baseline"]["error"]}
+                    checker = None
+                    out["cpu_baseline"] = guarded("cpu_baseline", cpu_baseline, pkg, a.workload, ms_seed(pkg, 0), a.cpu_seconds, None, motion_gate=a.motion_gate)
             else:
                 # big tables: the structure-faithful oracle takes seconds to minutes per frame -- it is timed alone on what
                 # fits the budget, and the ID match runs on 4 steady-state frames of the vectorised form of the same oracle
-                out["cpu_baseline"] = cpu_baseline(pkg, a.workload, ms_seed(pkg, 0), a.cpu_seconds, None, motion_gate=a.motion_gate)
+                out["cpu_baseline"] = guarded("cpu_baseline", cpu_baseline, pkg, a.workload, ms_seed(pkg, 0), a.cpu_seconds, None, motion_gate=a.motion_gate)
                 if checker is not None:
-                    cpu_baseline(pkg, a.workload, ms_seed(pkg, 0), 120.0, checker, faithful=False, max_frames=4, motion_gate=a.motion_gate)
+                    r = guarded("id_match", cpu_baseline, pkg, a.workload, ms_seed(pkg, 0), 120.0, checker, faithful=False, max_frames=4, motion_gate=a.motion_gate)
+                    if isinstance(r, dict) and "error" in r:
+                        out["id_match"] = {"error": r["error"]}
+                        checker = None
             if checker is not None:
-                out["id_match"] = checker.result()
+                out["id_match"] = guarded("id_match", checker.result)
+            elif checker_err:
+                out["id_match"] = checker_err
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

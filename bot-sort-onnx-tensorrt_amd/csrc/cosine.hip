@@ -27,7 +27,6 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
 }
 
-#if !defined(BTS_HOST_EMU)      // (tests/hip_emu: no MFMA on the CPU -- the emulated library always takes the vector-ALU kernel)
 __global__ __launch_bounds__(256) void k_cos_mfma(const float *__restrict__ a, const int32_t *__restrict__ a_idx, int lda,
                                                   const float *__restrict__ b, const int32_t *__restrict__ b_idx, int ldb,
                                                   int d, const int32_t *__restrict__ dims, int n_max, int m_max,
@@ -118,8 +117,6 @@ __global__ __launch_bounds__(256) void k_cos_mfma(const float *__restrict__ a, c
         }
 }
 
-#endif  // !BTS_HOST_EMU
-
 // float32 vector-ALU variant: 64x64 tile, 256 threads, 4x4 outputs per thread, BK = 16.
 __global__ __launch_bounds__(256) void k_cos_valu(const float *__restrict__ a, const int32_t *__restrict__ a_idx, int lda,
                                                   const float *__restrict__ b, const int32_t *__restrict__ b_idx, int ldb,
@@ -174,16 +171,11 @@ int bts_cos_enqueue(int which, const float *a, const int32_t *a_idx, int lda, co
                     float *sim, int ld, hipStream_t stream) {
     if (n_max <= 0 || m_max <= 0) return BTS_OK;
     const bool aligned = ((uintptr_t)a % 16 == 0) && ((uintptr_t)b % 16 == 0) && lda % 4 == 0 && ldb % 4 == 0 && d % 4 == 0;
-#if !defined(BTS_HOST_EMU)
     if (which == BTS_COS_MFMA_F32 && aligned) {
         const int nblk = bts_cdiv(n_max, BM) * bts_cdiv(m_max, BN);
         hipLaunchKernelGGL(k_cos_mfma, dim3(nblk), dim3(256), 0, stream, a, a_idx, lda, b, b_idx, ldb, d, dims,
                            n_max, m_max, sim, ld);
-    } else
-#else
-    (void)aligned;
-#endif
-    {
+    } else {
         const int nblk = bts_cdiv(n_max, 64) * bts_cdiv(m_max, 64);
         hipLaunchKernelGGL(k_cos_valu, dim3(nblk), dim3(256), 0, stream, a, a_idx, lda, b, b_idx, ldb, d, dims,
                            n_max, m_max, sim, ld);

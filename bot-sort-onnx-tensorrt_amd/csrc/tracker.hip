@@ -868,7 +868,6 @@ constexpr int FBM = 128, FBN = 128;      // tile of the pre-filter GEMM
 constexpr int DBK = feat::I8_STAGE;      // its K step: 128 int8 elements = one full 128-byte line per row and stage
 constexpr int FILTER_PW = 512;       // 2 resident workgroups per CU (64 KiB of operand stages each)
 enum { FS_STAGES = 0, FS_TILES, FS_EARLY, FS_CAND, FS_CHECKS };     // ([5..7]: clock cycles / 64 in candidate tests, stage waits, in total, summed over the workgroups)
-#if !defined(BTS_HOST_EMU)      // (tests/hip_emu: MFMA, LDS-DMA and inline assembly have no CPU stand-in -- contract-level stand-ins of the two kernels follow in the #else)
 // ---- appearance pre-filter: int8 MFMA GEMM with prefix exits + exact float32 refine -----------------------------
 // Stage-1 appearance can change a cost only where  min(1 - body_sim, 1 - face_sim) <= appearance_thresh
 // (D:1543-1547), i.e. for similarities >= 0.75 -- about one pair per detection out of N*M.  So the
@@ -901,9 +900,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 //   * one workgroup barrier per stage behind an s_waitcnt vmcnt issued in inline assembly together with it;
 //   * a lane's 16-byte fragment read is the 16 K values it feeds to ONE K = 32 MFMA (which K indices a lane
 //     holds is free as long as both operands agree).
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int DNS = 2;                 // (DBK = 128 elements = 128 bytes per row and stage, defined above)
+#if !defined(BTS_HOST_EMU)
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
-constexpr int DNS = 2;                 // (DBK = 128 elements = 128 bytes per row and stage, defined above)
+typedef unsigned lds_t;                // an LDS byte address, as the ds_* instructions take it
+#define LDS_ADDR(p) ((lds_t)(__UINTPTR_TYPE__)(lds_void *)(p))
 
 template <int N> __device__ __forceinline__ void wait_stage_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
@@ -912,8 +916,7 @@ template <int N> __device__ __forceinline__ void wait_stage_barrier() {
 // drains EVERY outstanding LDS-DMA load first (it cannot tell the ring's stages apart), which would
 // serialise the pipeline.  The explicit lgkmcnt wait below takes the fragments as operands so that no
 // MFMA can be scheduled above it.
-typedef int v4i __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ v4i lds_read16(unsigned addr) {
+__device__ __forceinline__ v4i lds_read16(lds_t addr) {
     v4i v;
     asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
     return v;
@@ -921,8 +924,7 @@ __device__ __forceinline__ v4i lds_read16(unsigned addr) {
 template <int N> __device__ __forceinline__ void lds_wait(v4i &a, v4i &b, v4i &c, v4i &e) {
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(e) : "n"(N));
 }
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f32x4 lds_read16f(unsigned addr) {
+__device__ __forceinline__ f32x4 lds_read16f(lds_t addr) {
     f32x4 v;
     asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
     return v;
@@ -931,13 +933,32 @@ __device__ __forceinline__ f32x4 lds_read16f(unsigned addr) {
 __device__ __forceinline__ void lds_wait_f(f32x4 &a, f32x4 &b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)); }
 __device__ __forceinline__ void lds_wait_i(v4i &a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a)); }
 __device__ __forceinline__ void lds_wait_f1(f32x4 &a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a)); }
-__device__ __forceinline__ void lds_write8(unsigned addr, float x, float y) {
+__device__ __forceinline__ void lds_write8(lds_t addr, float x, float y) {
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     const f32x2 v = {x, y};
     asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
-__device__ __forceinline__ void lds_write16(unsigned addr, f32x4 v) { asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
-__device__ __forceinline__ void lds_write4(unsigned addr, int v) { asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_write16(lds_t addr, f32x4 v) { asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_write4(lds_t addr, int v) { asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+#else
+// tests/hip_emu: the same kernels on the CPU.  An "LDS address" is the host address of the __shared__ object; the LDS accesses
+// above become plain loads / stores, the waits vanish (the emulator's LDS-DMA is immediate) and the stage barrier is the
+// workgroup barrier.  The MFMA and global_load_lds builtins are served by tests/hip_emu/hip/hip_runtime.h at instruction level.
+typedef void lds_void;
+typedef const void gbl_void;
+typedef uintptr_t lds_t;
+#define LDS_ADDR(p) ((lds_t)(p))
+template <int N> __device__ __forceinline__ void wait_stage_barrier() { __syncthreads(); }
+__device__ __forceinline__ v4i lds_read16(lds_t addr) { v4i v; memcpy(&v, (const void *)addr, 16); return v; }
+template <int N> __device__ __forceinline__ void lds_wait(v4i &, v4i &, v4i &, v4i &) {}
+__device__ __forceinline__ f32x4 lds_read16f(lds_t addr) { f32x4 v; memcpy(&v, (const void *)addr, 16); return v; }
+__device__ __forceinline__ void lds_wait_f(f32x4 &, f32x4 &) {}
+__device__ __forceinline__ void lds_wait_i(v4i &) {}
+__device__ __forceinline__ void lds_wait_f1(f32x4 &) {}
+__device__ __forceinline__ void lds_write8(lds_t addr, float x, float y) { float v[2] = {x, y}; memcpy((void *)addr, v, 8); }
+__device__ __forceinline__ void lds_write16(lds_t addr, f32x4 v) { memcpy((void *)addr, &v, 16); }
+__device__ __forceinline__ void lds_write4(lds_t addr, int v) { memcpy((void *)addr, &v, 4); }
+#endif
 
 // minimum / maximum over a wavefront, returned to every lane: DPP steps inside the 16-lane rows, then the four rows through the scalar side
 template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
@@ -970,7 +991,7 @@ struct FragMap {
 typedef int v8i_ __attribute__((ext_vector_type(8)));
 typedef float f32x16_ __attribute__((ext_vector_type(16)));
 template <int VAR = 0>
-__device__ __forceinline__ void stage_mfma(unsigned abase, unsigned bbase, const FragMap &fm, int fh, i32x16 (&acc)[2][2]) {
+__device__ __forceinline__ void stage_mfma(lds_t abase, lds_t bbase, const FragMap &fm, int fh, i32x16 (&acc)[2][2]) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         v4i fa[2][2], fb[2][2];
@@ -1063,7 +1084,7 @@ __global__ __launch_bounds__(256) void k_filter_splitk(Dev d, int m_max, int nti
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0;
     const int frow = lane & 31, fh = lane >> 5;
-    const unsigned lds_a = (unsigned)(__UINTPTR_TYPE__)(lds_void *)&As2[0][0], lds_b = (unsigned)(__UINTPTR_TYPE__)(lds_void *)&Bs2[0][0];
+    const lds_t lds_a = LDS_ADDR(&As2[0][0]), lds_b = LDS_ADDR(&Bs2[0][0]);
     FragMap fm;
     fm.init(wr, wc, frow);
     stage(0, kt0);
@@ -1131,11 +1152,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     auto skip_unused = [&](int j) { return (j < feat::I8_NCHK && chk_at(j) >= kt_all) ? (int)feat::I8_NCHK : j; };
     const int prow = lane >> 3, pchunk = lane & 7;
     const int frow = lane & 31, fh = lane >> 5;
-    const unsigned lds_a = (unsigned)(__UINTPTR_TYPE__)(lds_void *)&As2[0][0], lds_b = (unsigned)(__UINTPTR_TYPE__)(lds_void *)&Bs2[0][0];
+    const lds_t lds_a = LDS_ADDR(&As2[0][0]), lds_b = LDS_ADDR(&Bs2[0][0]);
     FragMap fm;
     fm.init(wr, wc, frow);
-    const unsigned lds_rec = (unsigned)(__UINTPTR_TYPE__)(lds_void *)&srec2[0][0], lds_cnt = (unsigned)(__UINTPTR_TYPE__)(lds_void *)&s_cnt[0][0],
-                   lds_red = (unsigned)(__UINTPTR_TYPE__)(lds_void *)&sred[0][0];
+    const lds_t lds_rec = LDS_ADDR(&srec2[0][0]), lds_cnt = LDS_ADDR(&s_cnt[0][0]), lds_red = LDS_ADDR(&sred[0][0]);
     // live tiles of this workgroup, in order: vt = blockIdx.x, + gemm_blocks, ... (tiles past the live extents are skipped)
     auto next_live = [&](int vt, int &bm, int &bn) {
         for (; vt < ntiles; vt += gemm_blocks) {
@@ -1257,8 +1277,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 // Every LDS access of the test is inline assembly: for an LDS access it can see, the compiler first drains ALL
                 // outstanding LDS-DMA loads (s_waitcnt vmcnt(0)) -- the operand stage that is landing under this test.
                 // The records are in image `rimg` since the last stage barrier at the latest.
-                const unsigned srec_a = lds_rec + (unsigned)rimg * (unsigned)((FBM + FBN) * 16);
-                const unsigned scnt_a = lds_cnt + (unsigned)flip * 16u, sred_a = lds_red + (unsigned)flip * 32u;
+                const lds_t srec_a = lds_rec + (unsigned)rimg * (unsigned)((FBM + FBN) * 16);
+                const lds_t scnt_a = lds_cnt + (unsigned)flip * 16u, sred_a = lds_red + (unsigned)flip * 32u;
                 // survivors of this lane: sv[mi] bit ni * 16 + r.  All shadows share one scale, so "excluded" (feat::i8_excluded:
                 //     dot / s^2 + alpha_i r_j + alpha_j r_i  <  uh_i + uh_j)
                 // becomes ONE integer compare per accumulator against a per-column threshold once the tile's rows are
@@ -1418,66 +1438,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (lane == 0 && st_cand) atomicAdd(&d.fstat[FS_CAND], st_cand);
 }
 
-#else   // BTS_HOST_EMU ------------------------------------------------------------------------------------------------
-// Contract-level stand-ins of the two pre-filter kernels for the CPU emulation (tests/hip_emu): same grids, same inputs
-// (the int8 shadows and records tk_front / tk_mid1 / copy_shadow maintain), same outputs (candidate bitmap resp. integer
-// accumulators, predict workgroups riding along) -- but a plain loop instead of the MFMA GEMM, and the exclusion rule applied
-// per pair on the FULL row (feat::i8_excluded with the full-row records).  The real kernel stops tiles at prefix checkpoints
-// and tests against per-tile summaries, so its candidate set is a superset of this one; both sets are supersets of the pairs
-// that reach the gate as long as the rule is sound, which is what the tests on top (FILTER vs DENSE vs the oracle) check.
-template <bool FACE, int VAR = 0, bool KF_FIRST = false>
-__global__ __launch_bounds__(256) void k_filter_i8(Dev d, int m_max, int ntiles, int gemm_blocks) {
-    const int kf_front = KF_FIRST ? (int)gridDim.x - gemm_blocks : 0;
-    if (KF_FIRST ? (int)blockIdx.x < kf_front : (int)blockIdx.x >= gemm_blocks) {
-        if (!FACE) predict_body(d, KF_FIRST ? (int)blockIdx.x : (int)blockIdx.x - gemm_blocks);
-        return;
-    }
-    const int n = d.hdr[H_NPOOL], m = d.hdr[H_NHI];
-    const int Dd = FACE ? d.Df : d.D;
-    const int8_t *A = FACE ? d.face_h : d.body_h, *B = FACE ? d.dface_h : d.det_h;
-    const float *ma = FACE ? d.face_m : d.body_m, *mb = FACE ? d.dface_m : d.det_m;
-    const int nbn = (m_max + FBN - 1) / FBN;
-    int cand = 0;
-    for (int vt = (int)blockIdx.x - kf_front; vt < ntiles; vt += gemm_blocks) {
-        const int bm = vt / nbn, bn = vt % nbn;
-        for (int p = threadIdx.x; p < FBM * FBN; p += blockDim.x) {
-            const int i = bm * FBM + p / FBN, q = bn * FBN + p % FBN;
-            if (i >= n || q >= m) continue;
-            const long slot = d.pool_slot[i], det = d.hi_idx[q];
-            int dot = 0;
-            for (int k = 0; k < Dd; ++k) dot += (int)A[slot * Dd + k] * (int)B[det * Dd + k];
-            if (!feat::i8_excluded(dot, feat::i8_rec(ma + slot * feat::I8_META, feat::I8_NCHK), feat::i8_rec(mb + det * feat::I8_META, feat::I8_NCHK))) {
-                atomicOr(&d.cbits[(long)i * d.cb_ld + (q >> 5)], 1u << (q & 31));
-                ++cand;
-            }
-        }
-    }
-    if (cand) atomicAdd(&d.fstat[FS_CAND], cand);
-    if (threadIdx.x == 0 && (int)blockIdx.x == kf_front) { atomicAdd(&d.fstat[FS_TILES], ntiles); atomicAdd(&d.fstat[FS_STAGES], ntiles * (Dd / DBK)); }
-}
-template <bool FACE>
-__global__ __launch_bounds__(256) void k_filter_splitk(Dev d, int m_max, int ntiles, int nsplit) {
-    if ((int)blockIdx.x >= ntiles * nsplit) {
-        if (!FACE) predict_body(d, (int)blockIdx.x - ntiles * nsplit);
-        return;
-    }
-    if ((int)blockIdx.x / ntiles != 0) return;                       // (the first K split of a tile adds the whole product)
-    const int n = d.hdr[H_NPOOL], m = d.hdr[H_NHI];
-    const int Dd = FACE ? d.Df : d.D;
-    const int8_t *A = FACE ? d.face_h : d.body_h, *B = FACE ? d.dface_h : d.det_h;
-    int32_t *approx = FACE ? d.approx_f : d.approx;
-    const int nbn = (m_max + FBN - 1) / FBN;
-    const int vt = (int)blockIdx.x % ntiles, bm = vt / nbn, bn = vt % nbn;
-    for (int p = threadIdx.x; p < FBM * FBN; p += blockDim.x) {
-        const int i = bm * FBM + p / FBN, q = bn * FBN + p % FBN;
-        if (i >= n || q >= m) continue;
-        const long slot = d.pool_slot[i], det = d.hi_idx[q];
-        int dot = 0;
-        for (int k = 0; k < Dd; ++k) dot += (int)A[slot * Dd + k] * (int)B[det * Dd + k];
-        atomicAdd(&approx[(long)i * d.Mx + q], dot);
-    }
-}
-#endif  // !BTS_HOST_EMU
 
 // ---- detection feature rows: in-place renormalisation (quirk Q8) ------------------------------------------
 __device__ __forceinline__ void renorm_body(const Dev &d, int blk) {        // four rows per 1024-thread workgroup

@@ -68,8 +68,12 @@ char *dynamic_lds();
 // everything this code base does in front of such a wait is idempotent (counting, and a publish of the same value).
 void spin();
 // wavefront collectives: every participating lane calls with the same `site`
-enum Op { OP_SHFL, OP_SHFL_XOR, OP_SHFL_UP, OP_BALLOT, OP_READLANE, OP_READFIRST, OP_DPP, OP_WAVE_BARRIER };
+enum Op { OP_SHFL, OP_SHFL_XOR, OP_SHFL_UP, OP_BALLOT, OP_READLANE, OP_READFIRST, OP_DPP, OP_WAVE_BARRIER, OP_GATHER };
 uint64_t collective(Op op, int site, uint64_t value, int arg, int arg2, uint64_t old_value);
+// operand exchange of a matrix instruction: every participating lane deposits `n` <= GATHER_MAX bytes; returns the wavefront's
+// staging area [64][GATHER_MAX] (lanes that do not take part read as zero), valid until the wavefront's next gather
+constexpr int GATHER_MAX = 64;
+const char *gather(int site, const void *mine, int n);
 }  // namespace emu
 
 struct EmuIdx { struct F { int axis; int which; operator unsigned() const; } x{0, 0}, y{1, 0}, z{2, 0}; };
@@ -147,6 +151,56 @@ template <class T> static inline T atomicMin(T *p, T v) { T o = *p; if (v < o) *
 template <class T> static inline T atomicExch(T *p, T v) { T o = *p; *p = v; return o; }
 template <class T> static inline T atomicCAS(T *p, T cmp, T v) { T o = *p; if (o == cmp) *p = v; return o; }
 static inline unsigned atomicOr(unsigned *p, int v) { unsigned o = *p; *p = o | (unsigned)v; return o; }
+
+// ---- matrix instructions, LDS-DMA (instruction-level stand-ins: the lanes of a wavefront meet at the call site) ---------------
+// v_mfma_i32_32x32x32_i8: lane l supplies 16 K-values of A row (l & 31) and of B column (l & 31), K half (l >> 5); it receives
+// D[(r & 3) + 8 (r >> 2) + 4 (l >> 5)][l & 31] in c[r] -- the C/D map of the 32 x 32 MFMAs (MI355X_MICROARCH.md; what the
+// kernels' epilogues index by, validated on hardware by the round-1/2 GPU runs).  Which K indices a lane holds cancels out
+// as long as both operands use the same assignment.
+typedef int emu_v4i __attribute__((ext_vector_type(4)));
+typedef int emu_i32x16 __attribute__((ext_vector_type(16)));
+typedef float emu_f32x16 __attribute__((ext_vector_type(16)));
+static inline emu_i32x16 emu_mfma_i32_32x32x32_i8(int site, emu_v4i a, emu_v4i b, emu_i32x16 c) {
+    struct { emu_v4i a, b; } mine = {a, b};
+    const char *all = emu::gather(site, &mine, 32);
+    const int lane = (int)(emu::tid_x() & 63), j = lane & 31, half = lane >> 5;
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+        int sum = 0;
+        for (int h = 0; h < 2; ++h) {
+            const int8_t *A = (const int8_t *)(all + (i + 32 * h) * emu::GATHER_MAX), *B = (const int8_t *)(all + (j + 32 * h) * emu::GATHER_MAX + 16);
+            for (int k = 0; k < 16; ++k) sum += (int)A[k] * (int)B[k];
+        }
+        c[r] += sum;
+    }
+    return c;
+}
+#define __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, x, y, z) emu_mfma_i32_32x32x32_i8(__COUNTER__, (a), (b), (c))
+// v_mfma_f32_32x32x2_f32: lane l supplies A[l & 31][l >> 5] and B[l >> 5][l & 31]; a k-ordered float32 fma chain
+static inline emu_f32x16 emu_mfma_f32_32x32x2f32(int site, float a, float b, emu_f32x16 c) {
+    struct { float a, b; } mine = {a, b};
+    const char *all = emu::gather(site, &mine, 8);
+    const int lane = (int)(emu::tid_x() & 63), j = lane & 31, half = lane >> 5;
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+        for (int k = 0; k < 2; ++k) {
+            float av, bv;
+            memcpy(&av, all + (i + 32 * k) * emu::GATHER_MAX, 4);
+            memcpy(&bv, all + (j + 32 * k) * emu::GATHER_MAX + 4, 4);
+            c[r] = fmaf(av, bv, c[r]);
+        }
+    }
+    return c;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu_mfma_f32_32x32x2f32(__COUNTER__, (a), (b), (c))
+// (only named inside a discarded `if constexpr` branch of a timing experiment)
+#define __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, ...) (c)
+// global_load_lds (16 B per lane): the LDS image is lane-linear from the wave-uniform base -- lane l's bytes land at base + 16 l.
+// Immediate here (the hardware's is asynchronous: s_waitcnt vmcnt + barrier protocols are not modelled, only their data flow).
+static inline void emu_global_load_lds(const void *g, void *lds_base, int size) {
+    memcpy((char *)lds_base + (size_t)(emu::tid_x() & 63) * (size_t)size, g, (size_t)size);
+}
+#define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) emu_global_load_lds((const void *)(g), (void *)(l), (size))
 
 // ---- runtime API subset -----------------------------------------------------------------------------------------------------
 typedef int hipError_t;

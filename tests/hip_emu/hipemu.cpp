@@ -22,6 +22,7 @@ struct Thread {
     int site = 0, arg = 0, arg2 = 0;
     uint64_t value = 0, old = 0, result = 0;
     int bar_val = 0;
+    const void *blob = nullptr;      // OP_GATHER: this lane's deposit
 };
 
 static constexpr size_t STACK = 256 * 1024;
@@ -59,6 +60,15 @@ uint64_t collective(Op op, int site, uint64_t value, int arg, int arg2, uint64_t
     t->op = op; t->site = site; t->value = value; t->arg = arg; t->arg2 = arg2; t->old = old_value; t->st = AT_WAVE;
     yield_to_scheduler();
     return t->result;
+}
+
+alignas(64) static char g_gather[16][64][GATHER_MAX];      // [wavefront][lane][bytes]
+const char *gather(int site, const void *mine, int n) {
+    Thread *t = g_cur;
+    if (n > GATHER_MAX || t->tid >= 16 * 64) { fprintf(stderr, "hipemu: gather of %d bytes / thread %d\n", n, t->tid); abort(); }
+    t->op = OP_GATHER; t->site = site; t->blob = mine; t->arg = n; t->st = AT_WAVE;
+    yield_to_scheduler();
+    return &g_gather[t->tid >> 6][0][0];
 }
 
 // A spin on something another thread has to write.  The spinner first lets the other threads of its workgroup run (the value
@@ -119,7 +129,13 @@ static void serve_group(int wave_base, int nlanes, const std::vector<int> &membe
             break;
         }
         case OP_WAVE_BARRIER: t.result = 0; break;
+        case OP_GATHER: break;
         }
+    }
+    if (op == OP_GATHER) {               // deposits are copied while every member is still parked at the call site
+        char (*stage)[GATHER_MAX] = g_gather[wave_base >> 6];
+        memset(stage, 0, sizeof(g_gather[0]));
+        for (int l : members) memcpy(stage[l], th[l].blob, (size_t)th[l].arg);
     }
     for (int l : members) th[l].st = READY;
 }

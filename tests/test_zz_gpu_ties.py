@@ -5,7 +5,7 @@ Exact cost ties on the GPU: INDEX vectors against the dense JV of the oracle (= 
   * bts_lapjv_exact (fast solver + certificate + replay, csrc/lap_exact.h run as k_lap_exact) on the tie families of
     tests/test_lap_exact_host.py -- the same source the CPU emulation checks, now on the device;
   * the fast solver alone (bts_lapjv) on the same families: same OBJECTIVE always, same indices whenever the certificate
-    says the optimum is unique (the stated, measured deviation of tie_mode 0: profiles/r03_tie_survey.txt);
+    says the optimum is unique (the stated, measured deviation of tie_mode 0: profiles/r03_tie_survey_cpu.txt);
   * the tracker with tie_mode = 1 on the `dup-box` scene (exact copies of detection boxes) frame by frame against the
     oracle; the mismatch RATE of tie_mode = 0 on the same stream is measured and bounded."""
 import importlib
