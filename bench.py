@@ -72,6 +72,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline, the ID match and the standalone kernels")
     ap.add_argument("--no-export", action="store_true", help="skip the export-inclusive legs")
+    ap.add_argument("--id-frames", type=int, default=0, help="frames of every rank's ID match under --gpus N (default: 24, or 4 for big tables)")
     ap.add_argument("--no-standalone", action="store_true", help="skip the standalone kernel rooflines of the small workloads")
     ap.add_argument("--dense", action="store_true", help="dense float32 appearance path instead of the int8 pre-filter")
     ap.add_argument("--graph", action="store_true", help="replay each step as one hipGraph (bts_tracker_config.use_graph)")
@@ -458,6 +459,9 @@ def main():
     opts = dict(appearance_mode=1 if a.dense else 0, use_graph=1 if a.graph else 0, motion_gate=1 if a.motion_gate else 0)
     trk = pkg.DeviceTracker(max_tracks=table_rows(K, a.motion_gate), max_dets=max(K, M), feat_dim=D, device=torch.cuda.current_device(), **opts)
 
+    if hasattr(pkg._lib.load(), "bts_tracker_inputs_resident"):
+        trk.inputs_resident(True)        # (every frame is uploaded and synchronised before the loop that steps on it; only the
+                                         #  opt-in BTS_CVT_OVERLAP pipelining looks at this promise)
     ms = importlib.import_module("bot-sort-onnx-tensorrt_amd.multistream")
     ddist = dist if world > 1 else None
 
@@ -550,7 +554,7 @@ def main():
         # rank's stream through a second handle and the oracle (vectorised IoU form: the checker, not a timing), gathered
         def rank_ids():
             chk = IdMatch(pkg, K, M, D, a.motion_gate)
-            cpu_baseline(pkg, a.workload, ms_seed(pkg, rank), 120.0, chk, faithful=False, max_frames=4 if big else 24, motion_gate=a.motion_gate)
+            cpu_baseline(pkg, a.workload, ms_seed(pkg, rank), 120.0, chk, faithful=False, max_frames=a.id_frames or (4 if big else 24), motion_gate=a.motion_gate)
             return dict(chk.result(), stream_seed=int(ms_seed(pkg, rank)))
         id_multi = [None] * world
         dist.all_gather_object(id_multi, guarded("id_match(rank %d)" % rank, rank_ids))      # (every rank takes part, whatever its checker did)

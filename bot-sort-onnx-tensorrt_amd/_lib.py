@@ -29,6 +29,7 @@ class TrackerConfig(ctypes.Structure):
         ("proximity_thresh", c_double), ("appearance_thresh", c_double), ("dedupe_thresh", c_double),
         ("ema_alpha", c_double), ("record_costs", c_int32), ("appearance_mode", c_int32), ("use_graph", c_int32),
         ("motion_gate", c_int32), ("max_edges", c_int32), ("tie_mode", c_int32),
+        ("kalman_dtype", c_int32), ("cost_dtype", c_int32),
     ]
 
 
@@ -69,6 +70,7 @@ SIGNATURES = {
     "bts_tracker_destroy": (c_int, [_P]),
     "bts_tracker_reset": (c_int, [_P, _P]),
     "bts_tracker_step": (c_int, [_P, _P, _P, _P, _P, c_int, _P]),
+    "bts_tracker_inputs_resident": (c_int, [_P, c_int]),
     "bts_tracker_counts": (c_int, [_P, _P, _P]),
     "bts_tracker_export": (c_int, [_P, c_int, _P, _P, _P, _P, _P]),
     "bts_tracker_export_lists": (c_int, [_P, _P, _P, _P, _P, _P, _P]),

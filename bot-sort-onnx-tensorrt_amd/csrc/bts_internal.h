@@ -151,7 +151,9 @@ struct bts_lap_problem {
 int bts_lap_init();
 // Enqueue 1 or 2 independent problems (they share one launch).
 // `ev` (nullable): four pre-created events recorded around k_prepare and k_solve (measurement hook).
-int bts_lap_enqueue(const bts_lap_problem *probs, int count, hipStream_t stream, hipEvent_t *ev = nullptr);
+// `form`: 0 = column forms (default), 1 = the round-2 row forms (k_lap<EC, false>), -1 = the process default (BTS_LAP_FORM=row | col).
+int bts_lap_enqueue(const bts_lap_problem *probs, int count, hipStream_t stream, hipEvent_t *ev = nullptr, int form = -1);
+int bts_lap_form_from_env();
 // reset hdr before edges are appended
 int bts_lap_enqueue_reset(const bts_lap_work *w, hipStream_t stream);
 

@@ -29,3 +29,19 @@ __host__ __device__ __forceinline__ double fuse3(double iou_d, float body_sim, d
     return fmin(iou_d, (double)emb);
 }
 
+
+// float64 -> IEEE binary16, round to nearest even, returned widened (bts_tracker_config.cost_dtype = BTS_F16: what
+// numpy's astype(float16) does to a float64 cost).  Association costs live in [0, 1] (+inf for gated pairs); the general
+// cases are kept so that the function is the conversion, not an approximation of it: overflow -> inf, subnormals, NaN.
+__host__ __device__ inline double round_to_f16(double v) {
+    if (!(v == v)) return v;
+    const double a = fabs(v);
+    if (a >= 65520.0) return v < 0 ? -__builtin_huge_val() : __builtin_huge_val();      // (65504 + half an ulp rounds to inf)
+    if (a == 0.0) return v;
+    int e;
+    (void)frexp(a, &e);                      // a = f * 2^e, f in [0.5, 1)
+    int q = e - 11;                          // ulp exponent of a binary16 normal: 11 significant bits
+    if (q < -24) q = -24;                    // subnormals: fixed ulp 2^-24
+    const double r = ldexp(nearbyint(ldexp(a, -q)), q);      // (nearbyint: ties to even in the default rounding mode)
+    return v < 0 ? -r : r;
+}

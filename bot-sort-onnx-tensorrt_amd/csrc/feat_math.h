@@ -148,10 +148,20 @@ constexpr int I8_STAGE = 128;                 // elements per K stage of the pre
 constexpr int I8_META = 4 * (I8_NCHK + 1);    // floats per row record
 // record layout: five float4 {1/s, r, alpha_c, uh_c}, c = 0 .. I8_NCHK (the last: full row) -- the float4 of a checkpoint is what
 // a candidate test reads, and one 16-byte global -> LDS transfer per row brings it there
-__host__ __device__ inline void i8_checkpoints(int kt_all, int (&c)[I8_NCHK]) {
-    // stages after which a tile may stop: ~5/16, 7/16, 10/16, 13/16 of the row (strictly increasing, at least 3 stages --
-    // shorter prefixes are statistically useless --, unused ones = kt_all)
-    const int num[I8_NCHK] = {5, 7, 10, 13};
+// The FIRST checkpoint is where a prefix test starts to exclude anything: a prefix holding the fraction f of a unit row's
+// energy excludes a pair of unrelated rows once  f > 1.03 (1 - gate) + slack  (uh > 0 in to_i8_row), i.e. f > 0.2575 + slack
+// at the reference's gate 0.75.  `first16` = that fraction in sixteenths: 5 is the round-2 set {5, 7, 10, 13} (what the
+// standalone diagnostics use); the tracker derives it from its gate (i8_first_checkpoint: 6 at 0.75 -- at 5/16 the test of
+// a 128-row tile, which works with the SMALLEST prefix energy of its rows, excludes next to nothing, so every tile ran on
+// to 7/16; with {6, 8, 11, 14} it stops one stage earlier).  BTS_I8_FIRST16 overrides (A/B).
+__host__ __device__ inline int i8_first_checkpoint(float appearance_thresh) {
+    const int f = (int)ceilf(16.0f * (1.03f * appearance_thresh + 0.10f));
+    return f < 3 ? 3 : f > 12 ? 12 : f;
+}
+__host__ __device__ inline void i8_checkpoints(int kt_all, int (&c)[I8_NCHK], int first16 = 5) {
+    // stages after which a tile may stop: ~first16/16 of the row, then +2/16, +5/16, +8/16 (strictly increasing, at least 3
+    // stages -- shorter prefixes are statistically useless --, unused ones = kt_all)
+    const int num[I8_NCHK] = {first16, first16 + 2, first16 + 5, first16 + 8};
     int prev = 2;
     for (int j = 0; j < I8_NCHK; ++j) {
         int v = (kt_all * num[j] + 15) / 16;
@@ -197,10 +207,10 @@ __device__ __forceinline__ int i8_round(float v) { return (int)__builtin_rintf(f
 
 // x[d] -> q[d] (int8), meta[I8_META].  `gate` = the similarity the appearance term must reach (1 - appearance_thresh).
 // Called by all threads of the row group; inactive groups only take part in the barriers.
-__device__ __forceinline__ void to_i8_row(const float *x, int8_t *q, float *meta, int d, float gate, bool active = true) {
+__device__ __forceinline__ void to_i8_row(const float *x, int8_t *q, float *meta, int d, float gate, bool active = true, int first16 = 5) {
     const int t = row_tid();
     int cst[I8_NCHK];
-    i8_checkpoints(d / I8_STAGE, cst);
+    i8_checkpoints(d / I8_STAGE, cst, first16);
     float ss = 0.0f, mx = 0.0f;
     const bool v4 = active && vec4_ok(x, d) && (uintptr_t)q % 4 == 0 && d / 4 <= 2 * ROW_G;
     float4 v[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};

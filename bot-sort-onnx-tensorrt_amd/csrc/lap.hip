@@ -231,12 +231,19 @@ constexpr int SM_C = SM_EH / 2;      // components: a hard edge shares its row o
 constexpr int SM_EDGES = 512;        // edge budget of the register/LDS solver, per wavefront
 constexpr int BIG_R = 2048, BIG_C = 512, BIG_E = 6144;      // what ONE wavefront solves with the workgroup's whole LDS (solve_big_cols)
 constexpr int TALL_S = 4, TALL_R = 254;
-#ifdef BTS_LAP_TALL_ROWFORM                       // (the round-2 solvers, kept for A/B: nothing beyond a wavefront's share of LDS)
-constexpr int ADMIT_R = 254, ADMIT_C = 64, ADMIT_E = 512;
-#else
-constexpr int ADMIT_R = BIG_R, ADMIT_C = BIG_C, ADMIT_E = BIG_E;
-#endif       // rows of a component the register solvers take (solve_packed: 64, solve_packed_tall: TALL_S row
-                                              // slots per lane; the packed descriptor keeps the row count in 8 bits, 255 = "255 or more")
+// Two FORMS of the solver kernel, chosen by the host per launch (k_lap<EC, CROWD>; bts_lap_enqueue):
+//   CROWD = true  (default): components with more rows than columns in column form, components beyond a wavefront's share of
+//                 LDS by one wavefront with the workgroup's whole LDS (solve_tall_cols / solve_big_cols), both LDS layouts of
+//                 the preparation;
+//   CROWD = false (BTS_LAP_FORM=row): the round-2 solvers -- row forms only (solve_packed / solve_packed_tall), the LDS
+//                 preparation admits nothing beyond a wavefront's share of LDS and has one layout; everything else takes the
+//                 global-memory path.  Kept as a selectable form (the column forms had never run on hardware), and
+//                 about a third smaller in code.
+// What the LDS preparation admits: rows / columns / edges of a component (the packed descriptor keeps the row count in 8 bits,
+// 255 = "255 or more"; solve_packed takes 64 rows, solve_packed_tall TALL_S row slots per lane).
+template <bool CROWD> struct Admit {
+    static constexpr int R = CROWD ? BIG_R : 254, C = CROWD ? BIG_C : 64, E = CROWD ? BIG_E : 512;
+};
 
 // LDS image of the hard sub-problem (slot space).  The HEAD (edge -> row / column, slot -> id) is the same for every layout;
 // the TAIL comes in two sizes (round 3): A = up to SM_EH edges and SM_EH / 2 components (24 B + 8 B per edge: plain scenes,
@@ -312,7 +319,7 @@ __device__ __forceinline__ bool wave_exscan_lds(const int32_t *src, int len, int
 }
 
 // second half of the SMALL preparation, for one tail layout: slots -> components -> packed export
-template <int EC, class Tail>
+template <int EC, bool CROWD, class Tail>
 __device__ __forceinline__ int small_tail(const LapArgs &A, SmallHead &H, Tail &L, int32_t *tab, int EH, int n, bool cached,
                                           const int (&hs)[EC], const double (&hcost)[EC]) {
     const bts_lap_work &w = A.w;
@@ -369,9 +376,9 @@ __device__ __forceinline__ int small_tail(const LapArgs &A, SmallHead &H, Tail &
     int32_t *cursor = L.cursor(), *cur_r = L.cur_r(), *cur_c = L.cur_c_, *ebase = L.ebase_, *ecur = L.ecur_;
     if (tid < 192) {
         const int wv = tid >> 6, ln = tid & 63;
-        const bool over = wv == 0 ? wave_exscan_lds(L.crp, C, L.crp, cur_r, ADMIT_R, ln)     // (what the LDS solvers take)
-                        : wv == 1 ? wave_exscan_lds(L.ccp, C, L.ccp, cur_c, ADMIT_C, ln)
-                                  : wave_exscan_lds(L.ecnt, C, ebase, ecur, ADMIT_E, ln);
+        const bool over = wv == 0 ? wave_exscan_lds(L.crp, C, L.crp, cur_r, Admit<CROWD>::R, ln)     // (what the LDS solvers take)
+                        : wv == 1 ? wave_exscan_lds(L.ccp, C, L.ccp, cur_c, Admit<CROWD>::C, ln)
+                                  : wave_exscan_lds(L.ecnt, C, ebase, ecur, Admit<CROWD>::E, ln);
         if (over) H.maxr = 65;
     }
     bscan::lds_barrier();
@@ -418,7 +425,8 @@ __device__ __forceinline__ int small_tail(const LapArgs &A, SmallHead &H, Tail &
     return 0;
 }
 
-template <int EC> __device__ __forceinline__ int small_pipeline(const LapArgs &A, char *lds, int E, int n, int m, int32_t *tmp) {
+template <int EC, bool CROWD> __device__ __forceinline__ int small_pipeline(const LapArgs &A, char *lds, int E, int n, int m, int32_t *tmp) {
+    constexpr int EH_MAX = CROWD ? SM_EH_MAX : SM_EH;      // (the row form keeps the one layout of round 2)
     const bts_lap_work &w = A.w;
     const int tid = threadIdx.x, nth = blockDim.x;
     SmallHead &H = *reinterpret_cast<SmallHead *>(lds);
@@ -451,7 +459,7 @@ template <int EC> __device__ __forceinline__ int small_pipeline(const LapArgs &A
         if (i < 0) return -1;
         if (tab[i] == 1 && tab[n + j] == 1) { A.x[i] = j; A.y[j] = i; return -1; }
         const int h = atomicAdd(&H.EH, 1);
-        if (h < SM_EH_MAX) { H.hr[h] = (uint16_t)i; H.hc[h] = (uint16_t)j; }
+        if (h < EH_MAX) { H.hr[h] = (uint16_t)i; H.hc[h] = (uint16_t)j; }
         w.hard[h] = e;                                    // (the queue of the global-memory form, should it take over)
         return h;
     };
@@ -465,7 +473,7 @@ template <int EC> __device__ __forceinline__ int small_pipeline(const LapArgs &A
     const int EH = H.EH;
     TR(w, 2);
     if (EH == 0) return 0;
-    if (EH > SM_EH_MAX) {
+    if (EH > EH_MAX) {
         // Too many non-trivial edges for the LDS form: hand over to the global-memory form WITHOUT redoing the degree
         // count and the isolated pairs there (three passes of global atomics): its queue w.hard[] is filled, and the
         // degrees of the rows / columns it will touch are copied out of the LDS table.
@@ -485,8 +493,9 @@ template <int EC> __device__ __forceinline__ int small_pipeline(const LapArgs &A
 #pragma unroll
     for (int k = 0; k < EC; ++k) hcost[k] = hs[k] >= 0 ? w.e_cost[tid + k * nth] : 0.0;      // consumed by the export at the very end
     PSTAT(EH <= SM_EH ? LS_PREP_A : LS_PREP_B);
-    if (EH <= SM_EH) return small_tail<EC>(A, H, *reinterpret_cast<SmallTailA *>(lds + sizeof(SmallHead)), tab, EH, n, cached, hs, hcost);
-    return small_tail<EC>(A, H, *reinterpret_cast<SmallTailB *>(lds + sizeof(SmallHead)), tab, EH, n, cached, hs, hcost);
+    if (!CROWD || EH <= SM_EH) return small_tail<EC, CROWD>(A, H, *reinterpret_cast<SmallTailA *>(lds + sizeof(SmallHead)), tab, EH, n, cached, hs, hcost);
+    if constexpr (CROWD) return small_tail<EC, CROWD>(A, H, *reinterpret_cast<SmallTailB *>(lds + sizeof(SmallHead)), tab, EH, n, cached, hs, hcost);
+    return -2;
 }
 
 // one counter bump per wavefront instead of one contended global atomic per lane: returns this lane's slot (pred lanes)
@@ -925,7 +934,7 @@ __device__ __forceinline__ bool solve_packed_tall(const LapArgs &A, int c, int l
     return true;
 }
 
-// Tall components, COLUMN form (round 3; the row form above is kept for A/B: -DBTS_LAP_TALL_ROWFORM).  A tall component has
+// Tall components, COLUMN form (round 3; the row form above is the BTS_LAP_FORM=row instantiation, k_lap<EC, false>).  A tall component has
 // more rows than columns (r > 64 >= cn; dense crowds: 100-250 track rows around 20-60 detections), and most of its rows
 // end unmatched.  The row form pays one shortest-path search per ROW; this one starts with every row on its private exit
 // (u = limit, tight) and runs one search per COLUMN over the rows -- cn searches instead of r, and short ones, because a
@@ -1094,7 +1103,9 @@ __device__ __forceinline__ bool solve_tall_cols(const LapArgs &A, int c, int lan
 // step of a search is a chain of L2 round trips (~2 ms for that component).  They are queued instead, and once every
 // wavefront of the workgroup is done with its own components, wavefront 0 solves them with the WHOLE dynamic LDS of the
 // workgroup: the column form of solve_tall_cols with the column state in LDS as well (up to BIG_R x BIG_C, BIG_E edges).
-constexpr int BIG_NONE = 0xffff, BIG_QUEUE = 64;
+constexpr int BIG_NONE = 0xffff, BIG_QUEUE = 96;      // (a SMALL preparation holds <= SM_EH_MAX edges, a queued component >= 65 of them -- more than
+                                                       //  64 columns, > 254 rows or > 512 edges --: at most 94 can exist, the queue cannot overflow)
+static_assert(BIG_QUEUE > SM_EH_MAX / 65, "the big-component queue holds every component a SMALL preparation can admit");
 struct BigLds {
     double ecost[BIG_E];                         // by column
     double u[BIG_R], dist[BIG_R];                // (dist doubles as the id table of the ranking pass)
@@ -1362,7 +1373,7 @@ static_assert(LAP_LDS_BYTES + 4096 + 512 <= 160 * 1024, "k_lap: dynamic + static
 
 struct LapPair { LapArgs p[2]; };     // (indexed by blockIdx.x straight out of the kernel-argument segment)
 
-template <int EC> __global__ __launch_bounds__(1024) void k_lap(LapPair P) {
+template <int EC, bool CROWD = true> __global__ __launch_bounds__(1024) void k_lap(LapPair P) {
 #if defined(BTS_HOST_EMU)
     char *const lds_raw = emu::dynamic_lds();
 #else
@@ -1393,7 +1404,7 @@ template <int EC> __global__ __launch_bounds__(1024) void k_lap(LapPair P) {
             __syncthreads();
         }
         int state = E > 0 ? -2 : 0;
-        if (E > 0 && n + m <= TABLE_CAP) state = small_pipeline<EC>(A, lds_raw, E, n, m, tmp);
+        if (E > 0 && n + m <= TABLE_CAP) state = small_pipeline<EC, CROWD>(A, lds_raw, E, n, m, tmp);
         if (state < 0) {                                  // LARGE form: global degree arrays
             __syncthreads();
             const int EH = state == -1 && n + m <= TABLE_CAP ? RLX(&w.hdr[H_NH]) : isolated_pairs(A, E);
@@ -1429,33 +1440,34 @@ template <int EC> __global__ __launch_bounds__(1024) void k_lap(LapPair P) {
     WaveLds *lds = reinterpret_cast<WaveLds *>(lds_raw);
     const int gw = blockIdx.y * (nth >> 6) + wid, nw = (solo ? 1 : gridDim.y) * (nth >> 6);
     for (int c = gw; c < C; c += nw) {
-#ifdef BTS_LAP_TALL_ROWFORM
-        if (solve_packed(A, c, lane, lds[wid].s) || solve_packed_tall(A, c, lane, lds[wid].s)) continue;
-#else
-        // one search per row (solve_packed) or per column (solve_tall_cols), whichever side is shorter; small components
-        // stay with the row form and its dense cost block
-        const int dz = w.cdesc[c].z, r_ = dz & 0xff, cn_ = (dz >> 8) & 0xff;
-        if (r_ > COLFORM_MIN_ROWS && r_ > cn_ ? solve_tall_cols(A, c, lane, lds[wid].t) : solve_packed(A, c, lane, lds[wid].s)) continue;
-        if (solve_tall_cols(A, c, lane, lds[wid].t)) continue;       // (more than 64 rows but not more rows than columns)
-        // beyond a wavefront's share of LDS: queued for the end of the loop (the SMALL preparation admits nothing that
-        // solve_big_cols cannot take and at most 63 such components; the LARGE one also feeds the global-memory solver)
-        if (fits_big(w, c)) {
-            int slot = 0;
-            if (lane == 0) slot = atomicAdd(&s_nbig, 1);
-            slot = __shfl(slot, 0);
-            if (slot < BIG_QUEUE) { if (lane == 0) s_big[slot] = c; continue; }
+        if constexpr (!CROWD) {
+            if (solve_packed(A, c, lane, lds[wid].s) || solve_packed_tall(A, c, lane, lds[wid].s)) continue;
+        } else {
+            // one search per row (solve_packed) or per column (solve_tall_cols), whichever side is shorter; small components
+            // stay with the row form and its dense cost block
+            const int dz = w.cdesc[c].z, r_ = dz & 0xff, cn_ = (dz >> 8) & 0xff;
+            if (r_ > COLFORM_MIN_ROWS && r_ > cn_ ? solve_tall_cols(A, c, lane, lds[wid].t) : solve_packed(A, c, lane, lds[wid].s)) continue;
+            if (solve_tall_cols(A, c, lane, lds[wid].t)) continue;       // (more than 64 rows but not more rows than columns)
+            // beyond a wavefront's share of LDS: queued for the end of the loop (the SMALL preparation admits nothing that
+            // solve_big_cols cannot take, and never more such components than the queue holds; the LARGE one also feeds the
+            // global-memory solver)
+            if (fits_big(w, c)) {
+                int slot = 0;
+                if (lane == 0) slot = atomicAdd(&s_nbig, 1);
+                slot = __shfl(slot, 0);
+                if (slot < BIG_QUEUE) { if (lane == 0) s_big[slot] = c; continue; }
+            }
+            if (RLX(&w.hdr[H_MODE]) != 2) { if (lane == 0) RST(&w.hdr[H_ERR], 8); continue; }      // (cannot happen: loud, not wrong)
         }
-        if (RLX(&w.hdr[H_MODE]) != 2) { if (lane == 0) RST(&w.hdr[H_ERR], 8); continue; }      // (cannot happen: loud, not wrong)
-#endif
         solve_component(A, c, lane);
     }
-#ifndef BTS_LAP_TALL_ROWFORM
-    __syncthreads();                              // every wavefront is done with its share of the dynamic LDS
-    if (wid == 0) {
-        const int nb = s_nbig < BIG_QUEUE ? s_nbig : BIG_QUEUE;
-        for (int k = 0; k < nb; ++k) solve_big_cols(A, s_big[k], lane, *reinterpret_cast<BigLds *>(lds_raw));
+    if constexpr (CROWD) {
+        __syncthreads();                              // every wavefront is done with its share of the dynamic LDS
+        if (wid == 0) {
+            const int nb = s_nbig < BIG_QUEUE ? s_nbig : BIG_QUEUE;
+            for (int k = 0; k < nb; ++k) solve_big_cols(A, s_big[k], lane, *reinterpret_cast<BigLds *>(lds_raw));
+        }
     }
-#endif
 #ifdef BTS_LAP_TRACE
     __syncthreads();
     if (blockIdx.y <= 1) TR(w, 11 + blockIdx.y);
@@ -1550,16 +1562,18 @@ int bts_lap_enqueue_reset(const bts_lap_work *w, hipStream_t stream) {
 int bts_lap_init() {      // the solver kernel needs more than the default 64 KiB of dynamic LDS
     static bool attr_set = false;
     if (!attr_set) {
-        BTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lap<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)LAP_LDS_BYTES));
-        BTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lap<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)LAP_LDS_BYTES));
+        BTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lap<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LAP_LDS_BYTES));
+        BTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lap<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LAP_LDS_BYTES));
+        BTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lap<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LAP_LDS_BYTES));
+        BTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lap<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LAP_LDS_BYTES));
         attr_set = true;
     }
     return BTS_OK;
 }
 
-int bts_lap_enqueue(const bts_lap_problem *probs, int count, hipStream_t stream, hipEvent_t *ev) {
+int bts_lap_form_from_env() { const char *e = getenv("BTS_LAP_FORM"); return e && !strcmp(e, "row") ? 1 : 0; }
+
+int bts_lap_enqueue(const bts_lap_problem *probs, int count, hipStream_t stream, hipEvent_t *ev, int form) {
     int rc0 = bts_lap_init();
     if (rc0) return rc0;
     const bts_lap_problem &A = probs[0], &B = probs[count > 1 ? 1 : 0];
@@ -1574,8 +1588,18 @@ int bts_lap_enqueue(const bts_lap_problem *probs, int count, hipStream_t stream,
     }
     // edges a thread keeps in registers across the preparation passes: 4 (lists up to 4096 edges are read once), or 8 for
     // problems wide enough to produce longer lists (the instantiation costs the short ones a few percent)
-    if (A.m_max > 3072 || B.m_max > 3072) hipLaunchKernelGGL(k_lap<8>, dim3(count, 1 + helpers), dim3(1024), LAP_LDS_BYTES, stream, P);
-    else hipLaunchKernelGGL(k_lap<4>, dim3(count, 1 + helpers), dim3(1024), LAP_LDS_BYTES, stream, P);
+    // the solver's FORM (see Admit<>): column forms unless the caller (a tracker: BTS_LAP_FORM when it was created) or, for the
+    // standalone entry points, the process environment asks for the round-2 row forms.  Both are exact -- on tie-free costs they
+    // return the same indices
+    static const int env_form = bts_lap_form_from_env();
+    const bool row_form = (form < 0 ? env_form : form) == 1;
+    const bool wide = A.m_max > 3072 || B.m_max > 3072;
+    const dim3 grid(count, 1 + helpers);
+    if (row_form) {
+        if (wide) hipLaunchKernelGGL((k_lap<8, false>), grid, dim3(1024), LAP_LDS_BYTES, stream, P);
+        else hipLaunchKernelGGL((k_lap<4, false>), grid, dim3(1024), LAP_LDS_BYTES, stream, P);
+    } else if (wide) hipLaunchKernelGGL((k_lap<8, true>), grid, dim3(1024), LAP_LDS_BYTES, stream, P);
+    else hipLaunchKernelGGL((k_lap<4, true>), grid, dim3(1024), LAP_LDS_BYTES, stream, P);
     BTS_LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[1], stream);
     return BTS_OK;

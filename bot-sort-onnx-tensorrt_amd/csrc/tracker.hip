@@ -11,6 +11,7 @@
 // That is what makes a step capturable in a hipGraph and lets frames be enqueued back to back.
 #include "bts_internal.h"
 #include "block_scan.h"
+#include "cost_math.h"
 #include "feat_math.h"
 #include "iou_math.h"
 #include "kf_math.h"
@@ -85,6 +86,9 @@ struct Dev {
     uint32_t *cbits;                                   // [T][cb_ld] candidate bitmap of the one-pass pre-filter (self-cleaning)
     int cb_ld;                                         // 32-bit words per bitmap row
     float gate_sim;                                    // the similarity the appearance term must reach: 1 - appearance_thresh
+    int sf32;                                          // kalman_dtype BTS_F32: mean / cov hold float32 elements (same rows, half the bytes)
+    int c16;                                           // cost_dtype BTS_F16: association costs rounded to binary16 before thresholds and the solver
+    int chk_first;                                     // first prefix checkpoint of the pre-filter, in sixteenths of the row (feat::i8_checkpoints)
     int32_t use_grid;                                   // BTS_EDGES_GRID=1 at create: stage-1 edges by neighbour search (experimental; wins only for very large frames)
     int32_t *grid_hdr, *cell_start, *cell_items;       // uniform grid over the frame's high-score detections (prep_dets -> tk_edges_grid)
     int32_t *fstat;                                    // [8] pre-filter counters of the frame: K stages run, tiles, prefix exits, candidates
@@ -121,26 +125,55 @@ template <class Load, class Pred, class Emit>
 __device__ __forceinline__ int block_compact(int L, int32_t *tmp, Load load, Pred pred, Emit emit) { return bscan::compact_ws(L, tmp, load, pred, emit); }
 __device__ __forceinline__ int block_exscan_i(int v, int32_t *tmp, int *total) { return bscan::exscan(v, tmp, total); }
 
+// The Kalman state of a slot: float64 rows (default, the reference's dtype), or -- kalman_dtype BTS_F32 -- float32 elements in
+// the same arrays; either way the arithmetic works on float64 registers (the float32 form widens at the load and rounds at
+// the store).  d.sf32 is uniform over the launch: one scalar branch per access group.
+__device__ __forceinline__ double ld_mean(const Dev &d, long slot, int c) {
+    return d.sf32 ? (double)reinterpret_cast<const float *>(d.mean)[slot * 8 + c] : d.mean[slot * 8 + c];
+}
+__device__ __forceinline__ void st_mean(const Dev &d, long slot, int c, double v) {
+    if (d.sf32) reinterpret_cast<float *>(d.mean)[slot * 8 + c] = (float)v; else d.mean[slot * 8 + c] = v;
+}
+__device__ __forceinline__ double ld_cov(const Dev &d, long slot, int c) {
+    return d.sf32 ? (double)reinterpret_cast<const float *>(d.cov)[slot * 64 + c] : d.cov[slot * 64 + c];
+}
+__device__ __forceinline__ void st_cov(const Dev &d, long slot, int c, double v) {
+    if (d.sf32) reinterpret_cast<float *>(d.cov)[slot * 64 + c] = (float)v; else d.cov[slot * 64 + c] = v;
+}
 __device__ __forceinline__ void load_state(const Dev &d, int slot, double m[8], double P[64]) {
 #pragma unroll
-    for (int c = 0; c < 8; ++c) m[c] = d.mean[(long)slot * 8 + c];
+    for (int c = 0; c < 8; ++c) m[c] = ld_mean(d, slot, c);
 #pragma unroll
-    for (int c = 0; c < 64; ++c) P[c] = d.cov[(long)slot * 64 + c];
+    for (int c = 0; c < 64; ++c) P[c] = ld_cov(d, slot, c);
 }
 __device__ __forceinline__ void store_state(const Dev &d, int slot, const double m[8], const double P[64]) {
 #pragma unroll
-    for (int c = 0; c < 8; ++c) d.mean[(long)slot * 8 + c] = m[c];
+    for (int c = 0; c < 8; ++c) st_mean(d, slot, c, m[c]);
 #pragma unroll
-    for (int c = 0; c < 64; ++c) d.cov[(long)slot * 64 + c] = P[c];
+    for (int c = 0; c < 64; ++c) st_cov(d, slot, c, P[c]);
 }
 // 8-lane form: lane i of the group holds element i of the mean and row i of the covariance
 __device__ __forceinline__ void load_row(const Dev &d, int slot, int i, double &mi, double Pr[8]) {
+    if (d.sf32) {
+        mi = (double)reinterpret_cast<const float *>(d.mean)[(long)slot * 8 + i];
+        const float4 *p = reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(d.cov) + (long)slot * 64 + i * 8);
+        const float4 a = p[0], b = p[1];
+        Pr[0] = a.x; Pr[1] = a.y; Pr[2] = a.z; Pr[3] = a.w; Pr[4] = b.x; Pr[5] = b.y; Pr[6] = b.z; Pr[7] = b.w;
+        return;
+    }
     mi = d.mean[(long)slot * 8 + i];
     const double2 *p = reinterpret_cast<const double2 *>(d.cov + (long)slot * 64 + i * 8);
 #pragma unroll
     for (int j = 0; j < 4; ++j) { const double2 v = p[j]; Pr[2 * j] = v.x; Pr[2 * j + 1] = v.y; }
 }
 __device__ __forceinline__ void store_row(const Dev &d, int slot, int i, double mi, const double Pr[8]) {
+    if (d.sf32) {
+        reinterpret_cast<float *>(d.mean)[(long)slot * 8 + i] = (float)mi;
+        float4 *p = reinterpret_cast<float4 *>(reinterpret_cast<float *>(d.cov) + (long)slot * 64 + i * 8);
+        p[0] = make_float4((float)Pr[0], (float)Pr[1], (float)Pr[2], (float)Pr[3]);
+        p[1] = make_float4((float)Pr[4], (float)Pr[5], (float)Pr[6], (float)Pr[7]);
+        return;
+    }
     d.mean[(long)slot * 8 + i] = mi;
     double2 *p = reinterpret_cast<double2 *>(d.cov + (long)slot * 64 + i * 8);
 #pragma unroll
@@ -149,7 +182,7 @@ __device__ __forceinline__ void store_row(const Dev &d, int slot, int i, double 
 __device__ __forceinline__ void slot_tlbr(const Dev &d, int slot, double out[4]) {
     double m[8];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) m[c] = d.mean[(long)slot * 8 + c];
+    for (int c = 0; c < 4; ++c) m[c] = ld_mean(d, slot, c);
     kf::mean_to_tlbr(m, d.f32[slot] != 0, out);
 }
 
@@ -333,8 +366,8 @@ __device__ __forceinline__ void prep_free(const Dev &d) {
 __device__ __forceinline__ void cvt_body(const Dev &d, long blk) {        // four rows per 1024-thread workgroup
     const long j = blk * 4 + feat::row_group();
     const bool on = j < IN(d, m);
-    feat::to_i8_row(IN(d, feats) + j * d.D, d.det_h + j * d.D, d.det_m + j * feat::I8_META, d.D, d.gate_sim, on);
-    if (d.Df) feat::to_i8_row(IN(d, face_feats) + j * d.Df, d.dface_h + j * d.Df, d.dface_m + j * feat::I8_META, d.Df, d.gate_sim, on);
+    feat::to_i8_row(IN(d, feats) + j * d.D, d.det_h + j * d.D, d.det_m + j * feat::I8_META, d.D, d.gate_sim, on, d.chk_first);
+    if (d.Df) feat::to_i8_row(IN(d, face_feats) + j * d.Df, d.dface_h + j * d.Df, d.dface_m + j * feat::I8_META, d.Df, d.gate_sim, on, d.chk_first);
 }
 // A track's latest feature IS a detection row (curr = the matched / born detection's renormalised row, D:492-502): its
 // shadow is that detection's, copied, and so is its record -- which tk_mid1 has by then turned into the record of the
@@ -392,11 +425,6 @@ __global__ __launch_bounds__(256) void tk_predict(Dev d) { predict_body(d, block
 // ---- cost tiles ----------------------------------------------------------------------------------------
 constexpr int CT_ROWS = 16, CT_COLS = 256;
 
-__device__ __forceinline__ float face_fixup(float s) {
-    const double dd = fabs((double)s - 0.9999999);
-    return dd <= 1e-08 + 1e-08 * 0.9999999 ? 0.0f : s;
-}
-
 // ---- optional motion gate on the stage-1 pairs --------------------------------------------------------------------
 // KalmanFilter.gating_distance (D:338-380, metric 'maha', all four coordinates) is defined by the reference but never
 // called from its update loop; with bts_tracker_config.motion_gate the cascade applies it the way
@@ -412,11 +440,11 @@ __device__ __forceinline__ bool motion_gate_open(const Dev &d, long s, int det) 
     const bool f = d.f32[s] != 0;
     double mu[4], S[16], L[16], y[4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) mu[a] = d.mean[s * 8 + a];
+    for (int a = 0; a < 4; ++a) mu[a] = ld_mean(d, s, a);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j <= i; ++j) S[i * 4 + j] = d.cov[s * 64 + i * 8 + j];      // (cho_factor reads the lower triangle)
+        for (int j = 0; j <= i; ++j) S[i * 4 + j] = ld_cov(d, s, i * 8 + j);      // (cho_factor reads the lower triangle)
     const double r_w = kf::sq_scaled(kf::W_POS, mu[2], f), r_h = kf::sq_scaled(kf::W_POS, mu[3], f);      // D:236-263
     S[0] += r_w; S[5] += r_h; S[10] += r_w; S[15] += r_h;
     kf::chol4(S, L);
@@ -650,8 +678,10 @@ __device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, 
                 if (iou_d > d.prox) emb = 1.0f;
                 c = fmin(iou_d, (double)emb);
             }
+            if (d.c16) c = round_to_f16(c);
             if (MODE == 2 || d.record) cost[o] = c;
         }
+        if (MODE == 1 && d.c16) c = round_to_f16(c);      // cost_dtype BTS_F16: the value the threshold test and the solver see
         if (XO && STAGE == 1 && live && c > limit && c < iou_d) {
             const long idx = w.e_cap - 1 - (long)atomicAdd(&w.hdr[7], 1);
             if (idx >= 0) { w.e_row[idx] = i0 + r; w.e_col[idx] = q; w.e_cost[idx] = c; }
@@ -813,6 +843,7 @@ __global__ __launch_bounds__(64) void tk_edges_grid(Dev d, bts_lap_work w) {
                 const int det = d.hi_idx[q];
                 const double bb[4] = {d.det_tlbr[det * 4 + 0], d.det_tlbr[det * 4 + 1], d.det_tlbr[det * 4 + 2], d.det_tlbr[det * 4 + 3]};
                 c = iou::cost(aa, false, area_a, bb, true, iou::area(bb, true));
+                if (d.c16) c = round_to_f16(c);
                 edge = c <= limit;
                 if (GATE && edge) edge = motion_gate_open(d, d.pool_slot[i], det);
             }
@@ -851,6 +882,7 @@ __global__ __launch_bounds__(64) void tk_edges_grid(Dev d, bts_lap_work w) {
                             const double bb[4] = {d.det_tlbr[det * 4 + 0], d.det_tlbr[det * 4 + 1], d.det_tlbr[det * 4 + 2], d.det_tlbr[det * 4 + 3]};
                             double c = iou::cost(ra, false, rarea, bb, true, iou::area(bb, true));
                             if (!(fminf(emb, face) > d.app)) c = fmin(c, (double)emb);
+                            if (d.c16) c = round_to_f16(c);
                             bool edge = lane == 0 && c <= limit;
                             if (GATE && edge) edge = motion_gate_open(d, strk, (int)det);
                             emit(edge, row, q, c);
@@ -1146,7 +1178,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid >> 1, wc = wid & 1;
     const int kt_all = Dd / DBK;
     int chk[feat::I8_NCHK];
-    feat::i8_checkpoints(kt_all, chk);
+    feat::i8_checkpoints(kt_all, chk, d.chk_first);
     static_assert(feat::I8_NCHK == 4, "chk_at selects by hand (a runtime-indexed register array would go to scratch)");
     auto chk_at = [&](int j) { return j == 0 ? chk[0] : j == 1 ? chk[1] : j == 2 ? chk[2] : chk[3]; };
     auto skip_unused = [&](int j) { return (j < feat::I8_NCHK && chk_at(j) >= kt_all) ? (int)feat::I8_NCHK : j; };
@@ -1642,7 +1674,7 @@ template <bool CH> __global__ __launch_bounds__(1024) void tk_merge(Dev d) {
                 d.has_body[s] = 1; d.has_face[s] = d.Df ? 1 : 0;
                 // position half of KalmanFilter.initiate (D:166-197): the duplicate test of this frame reads
                 // it while the rest of the state is still being initialised (tk_tail)
-                for (int c = 0; c < 4; ++c) d.mean[(long)s * 8 + c] = (double)d.det_xywh[det * 4 + c];
+                for (int c = 0; c < 4; ++c) st_mean(d, s, c, (double)d.det_xywh[det * 4 + c]);
             });
         if (tid == 0) {
             const int nborn = min(nborn_want, nfree);
@@ -1723,8 +1755,8 @@ __device__ __forceinline__ void birth_body(const Dev &d, int k) {
         const float z[4] = {d.det_xywh[det * 4 + 0], d.det_xywh[det * 4 + 1], d.det_xywh[det * 4 + 2], d.det_xywh[det * 4 + 3]};
         double m[8], P[64];
         kf::initiate(z, m, P);
-        for (int c = 4; c < 8; ++c) d.mean[s * 8 + c] = m[c];          // m[0..3] were written by tk_merge
-        for (int c = 0; c < 64; ++c) d.cov[s * 64 + c] = P[c];
+        for (int c = 4; c < 8; ++c) st_mean(d, s, c, m[c]);          // m[0..3] were written by tk_merge
+        for (int c = 0; c < 64; ++c) st_cov(d, s, c, P[c]);
     }
     // the detection row was renormalised in place; curr and smooth alias it in the reference
     for (int c = threadIdx.x; c < d.D; c += blockDim.x) {
@@ -1870,7 +1902,7 @@ __global__ __launch_bounds__(256) void tk_export(Dev d, int which, int32_t *ints
     ints[k * 8 + 0] = d.track_id[s]; ints[k * 8 + 1] = d.state[s]; ints[k * 8 + 2] = d.is_activated[s];
     ints[k * 8 + 3] = d.frame_id[s]; ints[k * 8 + 4] = d.start_frame[s]; ints[k * 8 + 5] = d.tracklet_len[s];
     ints[k * 8 + 6] = d.det_index[s]; ints[k * 8 + 7] = s;
-    for (int c = 0; c < 8; ++c) mean[k * 8 + c] = d.mean[(long)s * 8 + c];
+    for (int c = 0; c < 8; ++c) mean[k * 8 + c] = ld_mean(d, s, c);
     double b[4];
     slot_tlbr(d, s, b);
     for (int c = 0; c < 4; ++c) tlbr[k * 4 + c] = b[c];
@@ -1916,7 +1948,7 @@ __global__ __launch_bounds__(256) void tk_gather_state(Dev d, int which, int fie
     const long s = which == 0 ? d.tracked[k] : d.lost[k];
     if (field == 0) {
         double *o = (double *)out + (long)blockIdx.x * 64;
-        for (int c = threadIdx.x; c < 64; c += blockDim.x) o[c] = d.cov[s * 64 + c];
+        for (int c = threadIdx.x; c < 64; c += blockDim.x) o[c] = ld_cov(d, s, c);
         return;
     }
     const int w = field <= 2 ? d.D : d.Df;
@@ -1934,6 +1966,8 @@ struct bts_tracker {
     Dev dv;
     bts_lap_work lap;      // stages 1 and 2 (sequential)
     bts_lap_work lap3;     // stage 3 runs next to stage 2: its own work area
+    int lap_form = 0;             // BTS_LAP_FORM=row at create: the assignment kernel's round-2 row forms (bts_lap_enqueue)
+    bool onepass = false;         // BTS_FILTER_ONEPASS=1 at create: the persistent one-pass pre-filter also for split-K-sized problems
     bool predict_first = false;   // BTS_PREDICT_FIRST=1 at create: k_filter_i8<.., KF_FIRST> (experiment, see the kernel)
     // BTS_CVT_OVERLAP=1 at create (experiment, see tk_front): second set of detection shadows (frames alternate), a side
     // stream, "shadows of frame k are ready" / "frame k is done with its shadows" events per buffer
@@ -1942,6 +1976,8 @@ struct bts_tracker {
     float *det_m2 = nullptr, *dface_m2 = nullptr;
     hipStream_t side = nullptr;
     hipEvent_t ev_cvt[2] = {}, ev_done[2] = {};
+    bool inputs_resident = false; // bts_tracker_inputs_resident
+    hipEvent_t ev_in = nullptr;   // "the caller's stream has reached this step": the side stream waits for it before it reads the frame's arrays
     bool ev_done_used[2] = {};
     bts_lap_exact xk[2];   // tie_mode 1: scratch of the exact-tie step, [0] stages 1 and 2 (sequential), [1] stage 3
     char *block = nullptr;
@@ -1971,7 +2007,11 @@ static void tracker_layout(bts_tracker *t, char *base, size_t &off) {
     Dev &d = t->dv;
     const size_t T = d.T, M = d.Mx, D = d.D, Df = d.Df ? d.Df : 1;
 #define SLOT(ptr, type, count) { size_t o = take(off, sizeof(type) * (size_t)(count)); ptr = base ? (type *)(base + o) : nullptr; }
-    SLOT(d.mean, double, 8 * T); SLOT(d.cov, double, 64 * T);
+    {   // Kalman rows: float64, or float32 elements in the same arrays (kalman_dtype BTS_F32)
+        const size_t el = d.sf32 ? sizeof(float) : sizeof(double);
+        size_t o = take(off, el * 8 * T); d.mean = base ? (double *)(base + o) : nullptr;
+        o = take(off, el * 64 * T); d.cov = base ? (double *)(base + o) : nullptr;
+    }
     SLOT(d.f32, uint8_t, T); SLOT(d.in_removed, uint8_t, T); SLOT(d.in_use, uint8_t, T);
     SLOT(d.agg, unsigned long long, J_COUNT * bscan::CHUNK_MAX);
     SLOT(d.has_body, uint8_t, T); SLOT(d.has_face, uint8_t, T);
@@ -2030,6 +2070,7 @@ int bts_tracker_default_config(bts_tracker_config *cfg) {
     cfg->motion_gate = 0;      // the reference's loop never gates on motion (A6): off keeps parity
     cfg->max_edges = 0;        // automatic
     cfg->tie_mode = 0;         // the fast solver's optimum (= the reference's whenever it is unique)
+    cfg->kalman_dtype = BTS_F64; cfg->cost_dtype = BTS_F64;      // the reference's arithmetic (BASELINE config 5's mode: BTS_F32 / BTS_F16)
     return BTS_OK;
 }
 
@@ -2050,6 +2091,11 @@ static int derive_sizes(const bts_tracker_config *cfg, Dev &d, int64_t *e_cap_ou
                     "max_tracks * feat_dim and max_dets * feat_dim must stay below 2^32 in the FILTER appearance mode");
     }
     BTS_REQUIRE(cfg->tie_mode == 0 || cfg->tie_mode == 1, "tie_mode");
+    BTS_REQUIRE(cfg->kalman_dtype == BTS_F64 || cfg->kalman_dtype == BTS_F32, "kalman_dtype: BTS_F64 or BTS_F32");
+    BTS_REQUIRE(cfg->cost_dtype == BTS_F64 || cfg->cost_dtype == BTS_F16, "cost_dtype: BTS_F64 or BTS_F16");
+    BTS_REQUIRE(!(cfg->cost_dtype == BTS_F16 && cfg->tie_mode), "cost_dtype BTS_F16 needs tie_mode 0 (the exact-tie replay prices pairs from the boxes)");
+    d.sf32 = cfg->kalman_dtype == BTS_F32 ? 1 : 0;
+    d.c16 = cfg->cost_dtype == BTS_F16 ? 1 : 0;
     if (cfg->tie_mode) {
         // the replay prices a pair that is not a feasible edge at its IoU cost: true as long as every pair the appearance term
         // lowers (<= appearance_thresh) IS an edge of its stage, and nothing else edits the matrix (the motion gate does)
@@ -2132,7 +2178,14 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
     d.use_grid = getenv("BTS_EDGES_GRID") != nullptr ? 1 : 0;
     t->predict_first = getenv("BTS_PREDICT_FIRST") != nullptr;
     t->cvt_overlap = getenv("BTS_CVT_OVERLAP") != nullptr && d.filter && !cfg->use_graph;
+    t->lap_form = bts_lap_form_from_env();
+    t->onepass = getenv("BTS_FILTER_ONEPASS") != nullptr;
     d.gate_sim = 1.0f - d.app;
+    {   // first prefix checkpoint of the pre-filter: from the gate, or BTS_I8_FIRST16 (3 .. 12; 5 = the round-2 set)
+        const char *e = getenv("BTS_I8_FIRST16");
+        const int f = e ? atoi(e) : 0;
+        d.chk_first = (f >= 3 && f <= 12) ? f : feat::i8_first_checkpoint(d.app);
+    }
     size_t off = 0;
     tracker_layout(t, nullptr, off);
     const size_t lap_off = off;
@@ -2195,6 +2248,7 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
         for (int k = 0; ok && k < 2; ++k)
             ok = hipEventCreateWithFlags(&t->ev_cvt[k], hipEventDisableTiming) == hipSuccess &&
                  hipEventCreateWithFlags(&t->ev_done[k], hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&t->ev_in, hipEventDisableTiming) == hipSuccess;
     }
     if (!ok) { (void)hipGetLastError(); bts_set_error("stream / event / descriptor allocation failed"); bts_tracker_destroy(t); return BTS_EHIP; }
     t->dv.in = nullptr;
@@ -2261,6 +2315,7 @@ int bts_tracker_destroy(bts_tracker *t) {
     if (t->cs[0]) (void)hipStreamDestroy(t->cs[0]);
     if (t->side) { (void)hipStreamSynchronize(t->side); (void)hipStreamDestroy(t->side); }
     for (int k = 0; k < 2; ++k) { if (t->ev_cvt[k]) (void)hipEventDestroy(t->ev_cvt[k]); if (t->ev_done[k]) (void)hipEventDestroy(t->ev_done[k]); }
+    if (t->ev_in) (void)hipEventDestroy(t->ev_in);
     if (t->d_in) (void)hipFree(t->d_in);
     if (t->h_in) (void)hipHostFree(t->h_in);
     if (t->block) (void)hipFree(t->block);
@@ -2311,8 +2366,15 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
     seg_begin(BTS_SEG_STEP);
     seg_begin(BTS_SEG_PREP);
     if (ov) {
-        // (the buffer's previous user is the frame before last; the frame's input arrays must be complete when
-        //  bts_tracker_step is called -- the side stream does not wait for work pending on the caller's stream)
+        // The side stream reads this frame's feature rows.  Unless the caller has promised that they are complete when the
+        // step is called (bts_tracker_inputs_resident), it is ordered behind whatever the caller's stream holds at this point
+        // -- an upload, a ReID encoder writing the rows -- through an event recorded here; that event also sits
+        // behind the previous step's kernels, so only the promise buys the overlap with them.
+        // (the shadow buffer's previous user is the frame before last)
+        if (!t->inputs_resident) {
+            BTS_HIP(hipEventRecord(t->ev_in, s));
+            BTS_HIP(hipStreamWaitEvent(t->side, t->ev_in, 0));
+        }
         if (t->ev_done_used[ovp]) BTS_HIP(hipStreamWaitEvent(t->side, t->ev_done[ovp], 0));
         LAUNCH_ON(t->side, tk_cvt, dim3(bts_cdiv(mc, 4)), dim3(1024));
         BTS_HIP(hipEventRecord(t->ev_cvt[ovp], t->side));
@@ -2339,6 +2401,9 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
         // at least ~64 workgroups; beyond that only while it shortens a long K loop (every split adds N*M float atomics)
         while (d.approx && split * 2 <= kt_all && split < 16 && (ftiles * split < 64 || (ftiles * split < 256 && kt_all / split > 8))) split *= 2;
     }
+    // BTS_FILTER_ONEPASS=1 (read at create): the persistent one-pass form (k_filter_i8) also for problems small enough for split K
+    // (host side only: lets the tests drive that kernel's tile walk and prefix exits at sizes a CPU emulation handles)
+    if (t->onepass) split = 1;
     const int accum = split > 1;
     // ---- first association: pool x high-score detections
     seg_begin(BTS_SEG_COS1);
@@ -2440,7 +2505,7 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
         hipEvent_t ev2[2];
         const bool want = prof_room && t->prof_seg == BTS_SEG_K_LAP;
         if (want) { ev2[0] = t->prof_ev[2 * t->prof_n]; ev2[1] = t->prof_ev[2 * t->prof_n + 1]; }
-        rc = bts_lap_enqueue(&prob[0], 1, s, want ? ev2 : nullptr);
+        rc = bts_lap_enqueue(&prob[0], 1, s, want ? ev2 : nullptr, t->lap_form);
         if (rc) return rc;
         if (want) t->prof_n++;
     }
@@ -2476,7 +2541,7 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
     // ---- second association (remaining tracked rows x low-score detections) and the unconfirmed
     //      tracks (x leftover high-score detections): independent problems, shared launches
     seg_begin(BTS_SEG_STAGE2);
-    rc = bts_lap_enqueue(&prob[1], 2, s, nullptr);
+    rc = bts_lap_enqueue(&prob[1], 2, s, nullptr, t->lap_form);
     if (rc) return rc;
     if (t->cfg.tie_mode) {
         rc = bts_lap_exact_enqueue(&prob[1], &xs[1], 2, s);
@@ -2557,6 +2622,12 @@ int bts_tracker_step(bts_tracker *t, const int32_t *boxes, const float *scores, 
         if (rc) return rc;
     }
     t->step_no++;
+    return BTS_OK;
+}
+
+int bts_tracker_inputs_resident(bts_tracker *t, int flag) {
+    BTS_REQUIRE(t, "tracker");
+    t->inputs_resident = flag != 0;
     return BTS_OK;
 }
 
@@ -2711,6 +2782,15 @@ int bts_tracker_read_slot(bts_tracker *t, int slot, int field, void *out_host, b
         return BTS_OK;
     }
     BTS_REQUIRE(field < 4 || d.Df > 0, "the tracker carries no face features");
+    if (d.sf32 && field <= 1) {       // float32 state rows: widened on the host (the call's contract is float64)
+        const int cnt = field == 0 ? 8 : 64;
+        float tmp[64];
+        const float *srcf = reinterpret_cast<const float *>(field == 0 ? d.mean : d.cov) + (size_t)slot * cnt;
+        BTS_HIP(hipMemcpyAsync(tmp, srcf, sizeof(float) * cnt, hipMemcpyDeviceToHost, (hipStream_t)stream));
+        BTS_HIP(hipStreamSynchronize((hipStream_t)stream));
+        for (int k = 0; k < cnt; ++k) ((double *)out_host)[k] = (double)tmp[k];
+        return BTS_OK;
+    }
     const void *src = field == 0 ? (const void *)(d.mean + (size_t)slot * 8) : field == 1 ? (const void *)(d.cov + (size_t)slot * 64)
                     : field == 2 ? (const void *)(d.body_curr + (size_t)slot * d.D) : field == 3 ? (const void *)(d.body_smooth + (size_t)slot * d.D)
                     : field == 4 ? (const void *)(d.face_curr + (size_t)slot * d.Df) : (const void *)(d.face_smooth + (size_t)slot * d.Df);

@@ -563,6 +563,12 @@ class DeviceTracker:
         _lib.check(self._lib.bts_tracker_step(self.handle, _lib.ptr(boxes), _lib.ptr(scores), _lib.ptr(feats),
                                               _lib.ptr(face_feats), m, _lib.current_stream()))
 
+    def inputs_resident(self, flag: bool = True):
+        """Promise (bts_tracker_inputs_resident) that the tensors given to the following step() calls are complete in device
+        memory when step() is called -- nothing pending on any stream still writes them.  bench.py makes it for its frames
+        (uploaded and synchronised before the timed region); the BoTSORT facade, which uploads per call, does not."""
+        _lib.check(self._lib.bts_tracker_inputs_resident(self.handle, 1 if flag else 0))
+
     def export_lists(self, epoch: int = 0) -> "Snapshot":
         """Both lists in one call (bts_tracker_export_lists): the export kernels write into pinned host buffers owned by
         this object, one stream synchronisation; the rows are copied out, so a Snapshot stays valid when the next frame

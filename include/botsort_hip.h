@@ -238,7 +238,18 @@ typedef struct bts_tracker_config {
                                    lap 0.4.0 replayed on the implicit (N+M)^2 extended matrix (csrc/lap_exact.h): two more
                                    launches per frame, and a frame WITH ties costs what the dense algorithm costs.
                                    Needs motion_gate 0 and appearance_thresh <= match_thresh, unconfirmed_match_thresh */
+    int32_t kalman_dtype;       /* enum bts_dtype: BTS_F64 (default) = the reference's float64 state, bit-parity tests apply.
+                                   BTS_F32 = the arithmetic mode BASELINE config 5 names ("fp32 Kalman"): mean / covariance are
+                                   STORED as float32 (half the Kalman bytes of a step); the filter arithmetic of a predict /
+                                   update still runs in float64 registers on the widened values and rounds once at the store.
+                                   Not bit-identical to the reference: parity is an ID-match RATE plus the 1e-4 bound on the
+                                   state (tests/test_zz_gpu_round4.py) */
+    int32_t cost_dtype;         /* BTS_F64 (default) | BTS_F16: every association cost is rounded to IEEE binary16 (round to
+                                   nearest even, straight from float64) before it is compared with the stage's threshold and
+                                   handed to the solver -- config 5's "fp16 cost matrix" (this design has no matrix to store:
+                                   the rounding is what the mode means for the results).  Needs tie_mode 0 */
 } bts_tracker_config;
+enum bts_dtype { BTS_F64 = 0, BTS_F32 = 1, BTS_F16 = 2 };
 
 /* Fill cfg with the reference's hard-coded values (D:1268-1277). */
 int bts_tracker_default_config(bts_tracker_config *cfg);
@@ -261,6 +272,13 @@ int bts_tracker_reset(bts_tracker *trk, bts_stream stream);
  * Enqueues the whole association cascade on `stream`; no host synchronisation. */
 int bts_tracker_step(bts_tracker *trk, const int32_t *boxes, const float *scores, float *feats,
                      float *face_feats, int m, bts_stream stream);
+
+/* A promise about the arrays handed to the FOLLOWING bts_tracker_step calls: flag != 0 = they are complete in device memory
+ * when the call is made (no upload or encoder kernel still pending on any stream writes them), flag == 0 (default) = they
+ * are ordered on `stream` like any other work.  Only matters to the opt-in pipelining of the detection-row conversion
+ * (BTS_CVT_OVERLAP=1 when the tracker is created): with the promise the side stream converts frame t + 1's rows under frame
+ * t's kernels; without it the side stream first waits for an event recorded on `stream` at the step's entry. */
+int bts_tracker_inputs_resident(bts_tracker *trk, int flag);
 
 /* Sizes after the last enqueued step (synchronises `stream`):
  * counts[0]=frame_id [1]=n_tracked [2]=n_lost [3]=n_removed_total [4]=last_track_id

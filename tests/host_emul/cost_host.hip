@@ -7,3 +7,6 @@ extern "C" void cost_host_fuse1(long count, const double *iou_d, const float *bo
 extern "C" void cost_host_fuse3(long count, const double *iou_d, const float *body, double prox, float app, double *out) {
     for (long k = 0; k < count; ++k) out[k] = fuse3(iou_d[k], body[k], prox, app);
 }
+extern "C" void cost_host_round_f16(long count, const double *in, double *out) {
+    for (long k = 0; k < count; ++k) out[k] = round_to_f16(in[k]);
+}

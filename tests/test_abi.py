@@ -56,7 +56,7 @@ def test_config_struct_layout_matches_the_header():
     decl = re.findall(r"(int32_t|double)\s+(\w+)\s*;", body)
     want = [(n, {"int32_t": ctypes.c_int32, "double": ctypes.c_double}[t]) for t, n in decl]
     assert want == list(lib_mod.TrackerConfig._fields_)
-    assert ctypes.sizeof(lib_mod.TrackerConfig) == 6 * 4 + 10 * 8 + 5 * 4 + 4      # (+ tail padding to 8)
+    assert ctypes.sizeof(lib_mod.TrackerConfig) == 6 * 4 + 10 * 8 + 8 * 4          # (6 + 8 int32 fields, 10 doubles; no padding)
 
 
 def test_product_path_never_imports_the_oracle():

@@ -5,8 +5,11 @@ the GPU box the same sharding drives the HIP tracker) and the test checks that
   * a rank's result is identical to running that stream alone in a single process,
   * the control plane (barrier, max/sum over ranks, aggregate steps/s) works."""
 import importlib
+import json
 import os
+import shutil
 import socket
+import subprocess
 import sys
 
 import numpy as np
@@ -67,3 +70,44 @@ def test_two_streams_two_ranks(tmp_path):
     assert outs[0] != outs[1]
     assert ms.aggregate_throughput(100, 2.0, 2) == 100.0
     assert ms.streams_of_rank(8, 3, 4) == [3, 7]
+
+
+EMU = os.path.join(REPO, "tests", "hip_emu")
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/clang++") or shutil.which("make") is None, reason="needs ROCm's clang++ and make")
+def test_bench_two_ranks_run_the_product(tmp_path):
+    """The real N > 1 path of bench.py ("next" item 5): `bench.py --gpus 2 --oversubscribe` self-spawns two ranks
+    (bench.self_spawn: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*, gloo control plane, rank 0's stdout passed through), every
+    rank creates its OWN tracker handle of the PRODUCT library -- here the CPU emulation of its kernel sources, which is what
+    a box without a GPU can run; on the GPU box the same command drives libbotsort_hip.so -- steps its own seeded stream, and
+    checks it against the oracle; rank 0 prints ONE JSON line.  Asserted: exactly one line, n_gpus = 2, the ID match carries
+    one entry per stream, both streams are frame-identical to the oracle, and the two ranks used different stream seeds."""
+    subprocess.check_call(["make", "-C", EMU, "-s", "-j4"])
+    site = tmp_path / "site"
+    site.mkdir()
+    # every python process of the spawn tree imports the emulation prelude first (sitecustomize is imported at start-up)
+    (site / "sitecustomize.py").write_text("import tests.hip_emu.emu_prelude\n")
+    env = dict(os.environ, BTS_LIB_PATH=os.path.join(EMU, "libbotsort_emu.so"),
+               PYTHONPATH=os.pathsep.join([str(site), REPO] + ([os.environ["PYTHONPATH"]] if os.environ.get("PYTHONPATH") else [])))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--oversubscribe", "--workload", "c1", "--steps", "3",
+           "--warmup", "3", "--no-export", "--roofline-steps", "1", "--id-frames", "6"]
+    r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]                  # rank 0 only, nothing else on stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3
+    assert d["config"]["streams"] == 2 and d["config"]["spawn"] == "self-spawned ranks" and d["config"]["oversubscribed"] is True
+    assert d["value"] > 0 and d["roofline"]["step"]["us_per_step"] > 0
+    im = d["id_match"]
+    assert "error" not in im, im
+    assert im["streams"] == 2 and len(im["frames_identical_per_stream"]) == 2
+    assert im["frames_identical_per_stream"] == [6, 6] and im["frames"] == 12 and im["frames_identical"] == 12
+    assert im["assignment_pairs_equal"] == im["assignment_pairs"] > 0 and im["track_ids_equal"] == im["track_ids"] > 0
+    assert im["device_errors"] == 0 and im["kalman_mean_max_abs_err"] < 1e-4
+    ms = importlib.import_module("bot-sort-onnx-tensorrt_amd.multistream")
+    assert im["stream_seeds"] == [ms.stream_seed(1234, 0), ms.stream_seed(1234, 1)] and im["stream_seeds"][0] != im["stream_seeds"][1]
+    assert "cpu_baseline" not in d                            # (the N = 1 line's: "on rank 0 at N=1 only")

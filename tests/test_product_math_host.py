@@ -283,3 +283,27 @@ def test_overlap_screening_never_misses_a_pair():
     nan = np.full((1, 4), np.nan)
     out = np.zeros((1, 1), dtype=np.uint8)
     lib.iou_host_screen(1, 1, nan.ctypes.data, np.asarray([[0.0, 0.0, 5.0, 5.0]]).ctypes.data, out.ctypes.data)      # (must not crash)
+
+
+def test_cost_rounding_is_numpys_float16():
+    """bts_tracker_config.cost_dtype = BTS_F16 (BASELINE config 5's "fp16 cost matrix") rounds every association cost with
+    csrc/cost_math.h round_to_f16: that IS float64 -> binary16 -> float64 as NumPy does it (round to nearest even, straight
+    from float64) -- normals, ties exactly between two half values, subnormals, overflow, signs, inf / NaN."""
+    if not shutil.which("hipcc") and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    d = os.path.join(HERE, "host_emul")
+    subprocess.check_call(["make", "-C", d, "-s", "cost"])
+    lib = ctypes.CDLL(os.path.join(d, "libcost_host.so"))
+    lib.cost_host_round_f16.argtypes = [ctypes.c_long, ctypes.c_void_p, ctypes.c_void_p]
+    rng = np.random.default_rng(16)
+    halves = np.arange(0, 0x7c00, dtype=np.uint16).view(np.float16).astype(np.float64)       # every finite non-negative half
+    mids = (halves[:-1] + halves[1:]) / 2                                                     # exact ties
+    v = np.concatenate([rng.uniform(0, 1, 200000), rng.uniform(0, 1, 20000) ** 8, halves, mids, np.nextafter(mids, 0), np.nextafter(mids, 1e9),
+                        10.0 ** rng.uniform(-9, 5.2, 50000), [0.0, 65504.0, 65519.999, 65520.0, 1e300, np.inf, 5.96e-8, 2.98e-8, 2.9802322387695312e-08, 1e-12]])
+    v = np.ascontiguousarray(np.concatenate([v, -v, [np.nan]]))
+    out = np.empty_like(v)
+    lib.cost_host_round_f16(v.size, v.ctypes.data, out.ctypes.data)
+    with np.errstate(over="ignore"):
+        want = v.astype(np.float16).astype(np.float64)
+    assert np.array_equal(out, want, equal_nan=True), np.flatnonzero(~((out == want) | (np.isnan(out) & np.isnan(want))))[:10]
+    assert np.array_equal(np.signbit(out), np.signbit(want))
