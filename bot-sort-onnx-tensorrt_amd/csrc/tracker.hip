@@ -91,6 +91,14 @@ struct Dev {
     int chk_first;                                     // first prefix checkpoint of the pre-filter, in sixteenths of the row (feat::i8_checkpoints)
     int32_t use_grid;                                   // BTS_EDGES_GRID=1 at create: stage-1 edges by neighbour search (experimental; wins only for very large frames)
     int32_t *grid_hdr, *cell_start, *cell_items;       // uniform grid over the frame's high-score detections (prep_dets -> tk_edges_grid)
+    // BTS_EDGES_SORTED=1 at create (opt-in stage-1 form, tk_edges_sorted): the pre-filter's candidates also leave it as a LIST --
+    // one slot of CAND_W {pool row, high-score column} pairs per (tile, wavefront) quadrant, count in cand_cnt (-1: more than a
+    // slot holds, the quadrant's bitmap words are swept instead); consumed by the candidate wavefronts of tk_edges_sorted,
+    // cleared (with the bitmap bits) by tk_mid1
+    int32_t sorted;                                    // the form is on for this tracker
+    int32_t *cand_cnt;                                 // [f_slots]
+    int2 *cand;                                        // [f_slots][CAND_W]
+    int32_t f_ntiles, f_mc;                            // this step's pre-filter tiling (tiles, detection bound): what a slot index decodes with
     int32_t *fstat;                                    // [8] pre-filter counters of the frame: K stages run, tiles, prefix exits, candidates
     const InDesc *in;          // inputs of the current step: descriptor in memory (hipGraph replay) ...
     InDesc iv;                 // ... or by value in the kernel arguments (eager launches, in == nullptr)
@@ -323,7 +331,7 @@ template <bool GRID> __device__ __forceinline__ void prep_dets(const Dev &d) {
                                        [&](int j, int v) { const double s = (double)__int_as_float(v); return (s <= d.high) & (s >= d.low); },
                                        [&](int p, int j, int) { d.hi_idx[p] = j; }, [&](int p, int j, int) { d.lo_idx[p] = j; });
     const int nhi = nn.x, nlo = nn.y;
-    if constexpr (GRID) { if (d.filter && d.use_grid) build_grid(d, nhi, tmp); }
+    if constexpr (GRID) { if (d.filter && (d.use_grid || d.sorted)) build_grid(d, nhi, tmp); }
     if (tid < 3 * BTS_LAP_HDR_INTS) d.lap_hdr[tid] = 0;
     if (tid < 16 && d.filter) d.fstat[tid] = tid == 8 || tid == 12 ? 0x7fffffff : 0;
     if (tid == 0) {
@@ -899,6 +907,7 @@ __global__ __launch_bounds__(64) void tk_edges_grid(Dev d, bts_lap_work w) {
 constexpr int FBM = 128, FBN = 128;      // tile of the pre-filter GEMM
 constexpr int DBK = feat::I8_STAGE;      // its K step: 128 int8 elements = one full 128-byte line per row and stage
 constexpr int FILTER_PW = 512;       // 2 resident workgroups per CU (64 KiB of operand stages each)
+constexpr int CAND_W = 32;           // candidate pairs a (tile, wavefront) slot of the candidate list holds (Dev::cand)
 enum { FS_STAGES = 0, FS_TILES, FS_EARLY, FS_CAND, FS_CHECKS };     // ([5..7]: clock cycles / 64 in candidate tests, stage waits, in total, summed over the workgroups)
 // ---- appearance pre-filter: int8 MFMA GEMM with prefix exits + exact float32 refine -----------------------------
 // Stage-1 appearance can change a cost only where  min(1 - body_sim, 1 - face_sim) <= appearance_thresh
@@ -1151,7 +1160,9 @@ __global__ __launch_bounds__(256) void k_filter_splitk(Dev d, int m_max, int nti
 // workgroups: behind them (the default) the predict work runs when the persistent GEMM workgroups retire, i.e. it is added to
 // the kernel's tail; in front it overlaps the GEMM's start, and the GEMM workgroups that start late are the ones that own the
 // fewest tiles.  The default instantiation is unchanged code.
-template <bool FACE, int VAR = 0, bool KF_FIRST = false>
+// LIST (BTS_EDGES_SORTED=1 at create): a tile's survivors are also written to the candidate list, one slot per wavefront of the
+// tile, for the candidate wavefronts of tk_edges_sorted.  The default instantiation is unchanged code.
+template <bool FACE, int VAR = 0, bool KF_FIRST = false, bool LIST = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_filter_i8(Dev d, int m_max, int ntiles, int gemm_blocks) {
     __shared__ __attribute__((aligned(1024))) int8_t As2[DNS][FBM * DBK];
     __shared__ __attribute__((aligned(1024))) int8_t Bs2[DNS][FBN * DBK];
@@ -1395,6 +1406,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                             atomicOr(&d.cbits[(long)i * d.cb_ld + (q >> 5)], 1u << (q & 31));
                         }
                     }
+                    if constexpr (LIST) {
+                        int wtot = cnt;
+#pragma unroll
+                        for (int off = 32; off; off >>= 1) wtot += __shfl_xor(wtot, off);
+                        wtot = __builtin_amdgcn_readfirstlane(wtot);
+                        if (wtot > 0) {                          // (about every other wavefront of a tile: one true match per detection)
+                            const int slot = vt * 4 + wid;
+                            if (wtot <= CAND_W) {
+                                int pre = cnt;                   // inclusive scan of the lanes' counts
+#pragma unroll
+                                for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(pre, off); if (lane >= off) pre += t; }
+                                int pos = slot * CAND_W + pre - cnt;
+#pragma unroll
+                                for (int mi = 0; mi < 2; ++mi) {
+                                    unsigned bits = sv[mi];
+                                    while (bits) {
+                                        const int b = __ffs((int)bits) - 1, r = b & 15;
+                                        bits &= bits - 1;
+                                        const int q = bn * FBN + wc * 64 + (b >> 4) * 32 + frow;
+                                        const int i = bm * FBM + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                                        d.cand[pos++] = make_int2(i, q);
+                                    }
+                                }
+                            }
+                            if (lane == 0) d.cand_cnt[slot] = wtot <= CAND_W ? wtot : -1;      // (-1: the consumer sweeps the quadrant's bitmap words)
+                        }
+                    }
                     st_cand += cnt;
                     if (!at_end) ++st_early;
                     const int here = at_end ? kt_all : kt;
@@ -1470,6 +1508,261 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (lane == 0 && st_cand) atomicAdd(&d.fstat[FS_CAND], st_cand);
 }
 
+
+// ---- stage-1 edges, SORTED / LIST form (opt-in: BTS_EDGES_SORTED=1 when the tracker is created; NOT yet measured) --------------
+// What the tile form above spends its time on is (a) screening every row of a tile against every wavefront's 64 columns --
+// N M / 64 wave-rows of ~20 instructions, nearly all of them for nothing: a wavefront's columns are 64 detections from all over
+// the image, so no row can be ruled out as a whole -- and (b) the exact dot products of the appearance candidates, which sit in
+// the row loop of whichever wavefront happens to own the pair.  This form takes both out of the tiles:
+//   * COLUMNS are visited in the order of the uniform grid over the detection centres that tk_front builds (build_grid:
+//     Dev::cell_items = the high-score detections sorted by cell, row-major).  A wavefront's 64 columns are then neighbours;
+//     their union box U (packed 16-bit pixels, rounded outward like every screening box) covers a few percent of the image
+//     and ONE test per row against U -- lane = row, 64 rows per instruction -- leaves the handful of rows that can overlap
+//     any of them.  Only those are screened per pair and evaluated exactly (bit-identical iou::cost, same dtype flags).
+//   * CANDIDATES arrive as a list (k_filter_i8<.., LIST>): the workgroups behind the tiles take one pair per wavefront --
+//     exact float32 dot product, the pair's IoU cost, ONE edge with min(IoU cost, 1 - sim) (np.minimum of D:1554) -- all in
+//     parallel instead of serialised inside tiles.  A tile drops an IoU edge whose pair is a candidate (bit test on the few
+//     edges it staged, at its flush): the candidate wavefront owns that pair, so every pair still yields at most one edge.
+// Same edge SET as tk_edges<1,1,R> (another order; the solver does not depend on it).  The bitmap is not consumed here: tk_mid1
+// clears the listed bits and the counts.  Restrictions (the launcher falls back to the tile form): no face features, no
+// motion gate, no cost recording, match threshold < 1, the one-pass pre-filter (not split K).
+__device__ __forceinline__ unsigned wave_min_pk16(unsigned v) {      // per-half signed minimum over the wavefront, to every lane
+    typedef short s2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int off = 32; off; off >>= 1) {
+        const unsigned o = (unsigned)__shfl_xor((int)v, off);
+        v = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(s2, v), __builtin_bit_cast(s2, o)));
+    }
+    return v;
+}
+__device__ __forceinline__ unsigned wave_max_pk16(unsigned v) {
+    typedef short s2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int off = 32; off; off >>= 1) {
+        const unsigned o = (unsigned)__shfl_xor((int)v, off);
+        v = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s2, v), __builtin_bit_cast(s2, o)));
+    }
+    return v;
+}
+
+// per-wavefront edge staging shared by the tiles and the candidate wavefronts of tk_edges_sorted
+constexpr int SE_EB = 128;
+struct SortedStage {
+    double c[CT_COLS / 64][SE_EB];
+    int32_t r[CT_COLS / 64][SE_EB], q[CT_COLS / 64][SE_EB];
+};
+
+template <int ROWS>
+__device__ __forceinline__ void edges_tile_sorted(const Dev &d, const bts_lap_work &w, int bx, int by, SortedStage &S) {
+    __shared__ double sa[ROWS][4];
+    __shared__ double sarea[ROWS];
+    __shared__ iou::ScreenBox sboxf[ROWS];
+    __shared__ int s_wcnt[CT_COLS / 64], s_base;
+    const int32_t *h = d.hdr;
+    const int n = h[H_NPOOL], m = h[H_NHI];
+    const int i0 = by * ROWS, qs = bx * CT_COLS + threadIdx.x;      // qs: position in the grid order
+    const bool live = qs < m;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    // chains of dependent loads start side by side before the barrier: this thread's column (grid order -> high-score index ->
+    // detection -> box), the tile's row boxes
+    const int q = live ? d.cell_items[qs] : 0;
+    const int det = live ? d.hi_idx[q] : 0;
+    const double bb[4] = {d.det_tlbr[det * 4 + 0], d.det_tlbr[det * 4 + 1], d.det_tlbr[det * 4 + 2], d.det_tlbr[det * 4 + 3]};
+    for (int u = threadIdx.x; u < ROWS; u += CT_COLS) {
+        if (i0 + u < n) {
+            const int i = i0 + u;
+            const double box[4] = {d.pool_tlbr[i * 4 + 0], d.pool_tlbr[i * 4 + 1], d.pool_tlbr[i * 4 + 2], d.pool_tlbr[i * 4 + 3]};
+            for (int c = 0; c < 4; ++c) sa[u][c] = box[c];
+            sarea[u] = iou::area(box, false);
+            sboxf[u] = iou::screen_box(box);
+        } else sboxf[u] = iou::screen_none();
+    }
+    __syncthreads();
+    const double area_b = iou::area(bb, true);
+    const iou::ScreenBox bf = live ? iou::screen_box(bb) : iou::screen_none();      // (a dead column overlaps nothing)
+    iou::ScreenBox U;                                                               // union of this wavefront's column boxes
+    U.lo = __builtin_bit_cast(iou::s16x2, wave_min_pk16(__builtin_bit_cast(unsigned, bf.lo)));
+    U.hi = __builtin_bit_cast(iou::s16x2, wave_max_pk16(__builtin_bit_cast(unsigned, bf.hi)));
+    const double limit = d.match1;
+    const int rows = min(ROWS, n - i0);
+    int wcount = 0;
+    // An IoU edge whose pair is an appearance candidate belongs to the candidate wavefronts (one edge per pair): the staged
+    // edges are tested against the bitmap when they are flushed -- all bit loads of a flush travel together.
+    unsigned long long keep[SE_EB / 64];
+    auto test_staged = [&]() {                               // -> number of staged edges that stay
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        int kept = 0;
+#pragma unroll
+        for (int k0 = 0; k0 < SE_EB / 64; ++k0) {
+            const int k = k0 * 64 + lane;
+            bool kp = false;
+            if (k < wcount) kp = !((d.cbits[(long)S.r[wid][k] * d.cb_ld + (S.q[wid][k] >> 5)] >> (S.q[wid][k] & 31)) & 1u);
+            keep[k0] = __ballot(kp);
+            kept += __popcll(keep[k0]);
+        }
+        return kept;
+    };
+    auto write_kept = [&](int pos0) {
+#pragma unroll
+        for (int k0 = 0; k0 < SE_EB / 64; ++k0) {
+            const int k = k0 * 64 + lane;
+            if ((keep[k0] >> lane) & 1ull) {
+                const int pos = pos0 + __popcll(keep[k0] & ((1ull << lane) - 1ull));
+                if (pos < w.e_cap) { w.e_row[pos] = S.r[wid][k]; w.e_col[pos] = S.q[wid][k]; w.e_cost[pos] = S.c[wid][k]; }
+                else w.hdr[2] = 1;
+            }
+            pos0 += __popcll(keep[k0]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        wcount = 0;
+    };
+    auto emit = [&](bool pred, int row, double c) {          // convergent: every lane of the wavefront calls it
+        const unsigned long long mk = __ballot(pred);
+        if (!mk) return;
+        if (wcount + __popcll(mk) > SE_EB) {                  // mid-tile overflow of the staging buffer (dense crowds): this wavefront's own bump
+            const int kept = test_staged();
+            int base = 0;
+            if (lane == 0 && kept) base = atomicAdd(&w.hdr[0], kept);
+            write_kept(__shfl(base, 0));
+        }
+        if (pred) {
+            const int p = wcount + __popcll(mk & ((1ull << lane) - 1ull));
+            S.c[wid][p] = c; S.r[wid][p] = row; S.q[wid][p] = q;
+        }
+        wcount += __popcll(mk);
+    };
+#pragma unroll 1
+    for (int base = 0; base < rows; base += 64) {
+        // rows of this block that can overlap ANY of the wavefront's columns: lane = row
+        const int rr = base + lane;
+        unsigned long long touch = __ballot(rr < rows && iou::screen_overlap(sboxf[rr & (ROWS - 1)], U));
+        while (touch) {
+            const int r = base + __ffsll((long long)touch) - 1;
+            touch &= touch - 1;
+            if (!__ballot(iou::screen_overlap(sboxf[r], bf))) continue;
+            const double aa[4] = {sa[r][0], sa[r][1], sa[r][2], sa[r][3]};
+            double c = iou::cost(aa, false, sarea[r], bb, true, area_b);
+            if (d.c16) c = round_to_f16(c);
+            emit(live && c <= limit, i0 + r, c);
+        }
+    }
+    // end of tile: ONE counter bump for the whole workgroup
+    const int kept = test_staged();
+    if (lane == 0) s_wcnt[wid] = kept;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int k = 0; k < CT_COLS / 64; ++k) tot += s_wcnt[k];
+        s_base = tot ? atomicAdd(&w.hdr[0], tot) : 0;
+    }
+    __syncthreads();
+    int pos0 = s_base;
+    for (int k = 0; k < wid; ++k) pos0 += s_wcnt[k];
+    write_kept(pos0);
+    __syncthreads();          // the tile's LDS is reused by the workgroup's next tile
+}
+
+// one candidate pair (pool row i, high-score column q), handled by a whole wavefront: returns its edge cost to lane 0
+__device__ __forceinline__ bool cand_pair(const Dev &d, int i, int q, int lane, double &c_out) {
+    const long strk = d.pool_slot[i], det = d.hi_idx[q];
+    const float emb = 1.0f - fmaxf(0.0f, feat::wave_dot<4>(d.body_curr + strk * d.D, IN(d, feats) + det * d.D, d.D, lane));
+    const double aa[4] = {d.pool_tlbr[i * 4 + 0], d.pool_tlbr[i * 4 + 1], d.pool_tlbr[i * 4 + 2], d.pool_tlbr[i * 4 + 3]};
+    const double bb[4] = {d.det_tlbr[det * 4 + 0], d.det_tlbr[det * 4 + 1], d.det_tlbr[det * 4 + 2], d.det_tlbr[det * 4 + 3]};
+    double c = iou::cost(aa, false, iou::area(aa, false), bb, true, iou::area(bb, true));
+    if (!(fminf(emb, 1.0f) > d.app)) c = fmin(c, (double)emb);      // (no face features in this form: the face distance is 1)
+    if (d.c16) c = round_to_f16(c);
+    c_out = c;
+    return c <= d.match1;
+}
+
+__device__ __forceinline__ void cand_all(const Dev &d, const bts_lap_work &w, int bid, int nblk, SortedStage &S) {
+    const int32_t *h = d.hdr;
+    const int n = h[H_NPOOL], m = h[H_NHI];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int nslots = d.f_ntiles * 4, nbn = (d.f_mc + FBN - 1) / FBN;
+    int wcount = 0;
+    auto flush = [&]() {
+        if (wcount == 0) return;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&w.hdr[0], wcount);
+        base = __shfl(base, 0);
+        for (int k = lane; k < wcount; k += 64) {
+            const int pos = base + k;
+            if (pos < w.e_cap) { w.e_row[pos] = S.r[wid][k]; w.e_col[pos] = S.q[wid][k]; w.e_cost[pos] = S.c[wid][k]; }
+            else w.hdr[2] = 1;
+        }
+        wcount = 0;
+    };
+    auto pair = [&](int i, int q) {                           // convergent
+        double c;
+        const bool edge = cand_pair(d, i, q, lane, c);
+        if (edge) {
+            if (wcount == SE_EB) flush();
+            if (lane == 0) { S.c[wid][wcount] = c; S.r[wid][wcount] = i; S.q[wid][wcount] = q; }
+            ++wcount;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
+    for (int s = bid * (CT_COLS / 64) + wid; s < nslots; s += nblk * (CT_COLS / 64)) {
+        const int cnt = __builtin_amdgcn_readfirstlane(d.cand_cnt[s]);
+        if (cnt == 0) continue;
+        if (cnt > 0) {
+            const int2 mine = lane < cnt ? d.cand[(long)s * CAND_W + lane] : make_int2(0, 0);
+            for (int e = 0; e < cnt; ++e) pair(__shfl(mine.x, e), __shfl(mine.y, e));
+        } else {
+            // the slot overflowed: sweep the quadrant's 64 bitmap words (64 rows x the one aligned 8-byte word of its 64 columns)
+            const int vb = xcd_remap(s >> 2, d.f_ntiles), bm = vb / nbn, bn = vb % nbn, wr = (s & 3) >> 1, wc = s & 1;
+            const int row = bm * FBM + wr * 64 + lane, col0 = bn * FBN + wc * 64;
+            unsigned long long word = 0ull;
+            if (row < n && col0 < d.Mx) word = *reinterpret_cast<const unsigned long long *>(&d.cbits[(long)row * d.cb_ld + (col0 >> 5)]);
+            unsigned long long any = __ballot(word != 0ull);
+            while (any) {
+                const int src = __ffsll((long long)any) - 1;
+                any &= any - 1;
+                unsigned long long bits = ((unsigned long long)(unsigned)__shfl((int)(word >> 32), src) << 32) | (unsigned)__shfl((int)word, src);
+                while (bits) {
+                    const int b = __ffsll((long long)bits) - 1;
+                    bits &= bits - 1;
+                    if (col0 + b < m) pair(bm * FBM + wr * 64 + src, col0 + b);
+                }
+            }
+        }
+    }
+    flush();
+}
+
+template <int ROWS>
+__global__ __launch_bounds__(CT_COLS) __attribute__((amdgpu_waves_per_eu(4, 8))) void tk_edges_sorted(Dev d, bts_lap_work w, int tile_blocks) {
+    __shared__ SortedStage S;
+    if ((int)blockIdx.x >= tile_blocks) { cand_all(d, w, (int)blockIdx.x - tile_blocks, (int)gridDim.x - tile_blocks, S); return; }
+    const int32_t *h = d.hdr;
+    const int n = h[H_NPOOL], m = h[H_NHI];
+    const int nct = (m + CT_COLS - 1) / CT_COLS, ntile = nct * ((n + ROWS - 1) / ROWS);
+    for (int t = blockIdx.x; t < ntile; t += tile_blocks) edges_tile_sorted<ROWS>(d, w, t % nct, t / nct, S);
+}
+
+// the candidate list and the bitmap bits it names are cleared for the next frame (workgroups of tk_mid1, behind the assignment)
+__device__ __forceinline__ void cand_clear(const Dev &d, int bid, int nblk) {
+    const int32_t *h = d.hdr;
+    const int n = h[H_NPOOL];
+    const int lane = threadIdx.x & 63, wv = bid * ((int)blockDim.x >> 6) + ((int)threadIdx.x >> 6), nw = nblk * ((int)blockDim.x >> 6);
+    const int nslots = d.f_ntiles * 4, nbn = (d.f_mc + FBN - 1) / FBN;
+    for (int s = wv; s < nslots; s += nw) {
+        const int cnt = __builtin_amdgcn_readfirstlane(d.cand_cnt[s]);
+        if (cnt == 0) continue;
+        if (cnt > 0) {
+            if (lane < cnt) { const int2 e = d.cand[(long)s * CAND_W + lane]; d.cbits[(long)e.x * d.cb_ld + (e.y >> 5)] = 0u; }
+        } else {
+            const int vb = xcd_remap(s >> 2, d.f_ntiles), bm = vb / nbn, bn = vb % nbn, wr = (s & 3) >> 1, wc = s & 1;
+            const int row = bm * FBM + wr * 64 + lane, col0 = bn * FBN + wc * 64;
+            if (row < n && col0 < d.Mx) *reinterpret_cast<unsigned long long *>(&d.cbits[(long)row * d.cb_ld + (col0 >> 5)]) = 0ull;
+        }
+        if (lane == 0) d.cand_cnt[s] = 0;
+    }
+}
 
 // ---- detection feature rows: in-place renormalisation (quirk Q8) ------------------------------------------
 __device__ __forceinline__ void renorm_body(const Dev &d, int blk) {        // four rows per 1024-thread workgroup
@@ -1621,11 +1914,13 @@ template <bool CH> __device__ __forceinline__ void after1_body(const Dev &d, int
 }
 
 // one launch after the first assignment: workgroups 0-2 prepare stages 2/3, the others renormalise rows
-template <bool CH> __global__ __launch_bounds__(1024) void tk_mid1(Dev d) {
+// (clear_blocks > 0 only with the sorted / list form of stage 1: the last workgroups clear the candidate list, cand_clear)
+template <bool CH> __global__ __launch_bounds__(1024) void tk_mid1(Dev d, int clear_blocks) {
     TJ_BEGIN();
-    const int b = blockIdx.x, nch = nchunks<CH>(d);
+    const int b = blockIdx.x, nch = nchunks<CH>(d), first_clear = (int)gridDim.x - clear_blocks;
     if (b < nch) { after1_body<CH>(d, 0, b); if (b == nch - 1) TJ_END(1, 0); }
     else if (b < nch + 2) { after1_body<CH>(d, 1 + (b - nch), 0); TJ_END(1, 1 + (b - nch)); }
+    else if (b >= first_clear) cand_clear(d, b - first_clear, clear_blocks);
     else { renorm_body(d, b - mid1_jobs(nch)); if (b == mid1_jobs(nch)) TJ_END(1, 3); }
 }
 
@@ -2044,6 +2339,10 @@ static void tracker_layout(bts_tracker *t, char *base, size_t &off) {
             SLOT(t->det_h2, int8_t, M * D); SLOT(t->det_m2, float, M * feat::I8_META);
             SLOT(t->dface_h2, int8_t, M * Df); SLOT(t->dface_m2, float, M * feat::I8_META);
         }
+        if (d.sorted) {
+            const size_t slots = (size_t)bts_cdiv((int)T, FBM) * (size_t)bts_cdiv((int)M, FBN) * 4;
+            SLOT(d.cand_cnt, int32_t, slots); SLOT(d.cand, int2, slots * CAND_W);
+        }
         SLOT(d.fstat, int32_t, 16);
         SLOT(d.grid_hdr, int32_t, 8); SLOT(d.cell_start, int32_t, GRID_CELLS + 1); SLOT(d.cell_items, int32_t, M);
         // split-K accumulators: only tables small enough to ever need split K (< 256 tiles of 128 x 128) carry them
@@ -2094,6 +2393,9 @@ static int derive_sizes(const bts_tracker_config *cfg, Dev &d, int64_t *e_cap_ou
     BTS_REQUIRE(cfg->kalman_dtype == BTS_F64 || cfg->kalman_dtype == BTS_F32, "kalman_dtype: BTS_F64 or BTS_F32");
     BTS_REQUIRE(cfg->cost_dtype == BTS_F64 || cfg->cost_dtype == BTS_F16, "cost_dtype: BTS_F64 or BTS_F16");
     BTS_REQUIRE(!(cfg->cost_dtype == BTS_F16 && cfg->tie_mode), "cost_dtype BTS_F16 needs tie_mode 0 (the exact-tie replay prices pairs from the boxes)");
+    // BTS_EDGES_SORTED=1 (read when the tracker is created / sized): stage-1 edges in the sorted / list form (tk_edges_sorted)
+    d.sorted = (getenv("BTS_EDGES_SORTED") != nullptr && d.filter && d.Df == 0 && !cfg->motion_gate && !cfg->record_costs &&
+                cfg->match_thresh < 1.0 && !cfg->use_graph) ? 1 : 0;
     d.sf32 = cfg->kalman_dtype == BTS_F32 ? 1 : 0;
     d.c16 = cfg->cost_dtype == BTS_F16 ? 1 : 0;
     if (cfg->tie_mode) {
@@ -2232,6 +2534,12 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
         bts_tracker_destroy(t);
         return BTS_EHIP;
     }
+    if (t->dv.sorted && hipMemset(t->dv.cand_cnt, 0, sizeof(int32_t) * (size_t)bts_cdiv(t->dv.T, FBM) * (size_t)bts_cdiv(t->dv.Mx, FBN) * 4) != hipSuccess) {
+        (void)hipGetLastError();
+        bts_set_error("hipMemset failed");
+        bts_tracker_destroy(t);
+        return BTS_EHIP;
+    }
     // the assignment work area keeps "degree arrays are zero between calls" (lap.hip)
     if (hipMemset(t->block + lap_off, 0, t->bytes - lap_off) != hipSuccess) {
         (void)hipGetLastError();
@@ -2342,6 +2650,7 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
     const bool ov = t->cvt_overlap && !capturing;
     const int ovp = (int)(t->step_no & 1);
     Dev dstep = t->dv;
+    dstep.f_ntiles = bts_cdiv(dstep.T, FBM) * bts_cdiv(mc, FBN); dstep.f_mc = mc;      // (the pre-filter's tiling of this step: candidate-list slots decode with it)
     if (ov && ovp) { dstep.det_h = t->det_h2; dstep.det_m = t->det_m2; dstep.dface_h = t->dface_h2; dstep.dface_m = t->dface_m2; }
     const Dev &d = dstep;
     const int T = d.T, M = d.Mx;
@@ -2379,14 +2688,14 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
         LAUNCH_ON(t->side, tk_cvt, dim3(bts_cdiv(mc, 4)), dim3(1024));
         BTS_HIP(hipEventRecord(t->ev_cvt[ovp], t->side));
         const dim3 fgrid(front_jobs(d.nch > 1 ? d.nch : 1));
-        if (d.use_grid) {
+        if (d.use_grid || d.sorted) {
             if (d.nch > 1) { LAUNCH((tk_front<true, true, false>), fgrid, dim3(1024)); } else { LAUNCH((tk_front<false, true, false>), fgrid, dim3(1024)); }
         } else if (d.nch > 1) { LAUNCH((tk_front<true, false, false>), fgrid, dim3(1024)); }
         else { LAUNCH((tk_front<false, false, false>), fgrid, dim3(1024)); }
         BTS_HIP(hipStreamWaitEvent(s, t->ev_cvt[ovp], 0));
     } else {
         const dim3 fgrid(front_jobs(d.nch > 1 ? d.nch : 1) + (d.filter ? bts_cdiv(mc, 4) : 0));
-        if (d.use_grid && d.filter) {
+        if ((d.use_grid || d.sorted) && d.filter) {
             if (d.nch > 1) { LAUNCH((tk_front<true, true>), fgrid, dim3(1024)); } else { LAUNCH((tk_front<false, true>), fgrid, dim3(1024)); }
         } else if (d.nch > 1) { LAUNCH((tk_front<true, false>), fgrid, dim3(1024)); }
         else { LAUNCH((tk_front<false, false>), fgrid, dim3(1024)); }
@@ -2416,7 +2725,9 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
         static const int pw_forced = [] { const char *e = getenv("BTS_FILTER_PW"); return e ? atoi(e) : 0; }();
         const int pw = pw_forced > 0 ? pw_forced : FILTER_PW;
         const int gemm_blocks = ftiles < pw ? ftiles : pw;
-        if (!accum && t->predict_first) { LAUNCH((k_filter_i8<false, 0, true>), dim3(gemm_blocks + kf_blocks), dim3(256), mc, ftiles, gemm_blocks); }
+        if (!accum && d.sorted && t->predict_first) { LAUNCH((k_filter_i8<false, 0, true, true>), dim3(gemm_blocks + kf_blocks), dim3(256), mc, ftiles, gemm_blocks); }
+        else if (!accum && d.sorted) { LAUNCH((k_filter_i8<false, 0, false, true>), dim3(gemm_blocks + kf_blocks), dim3(256), mc, ftiles, gemm_blocks); }
+        else if (!accum && t->predict_first) { LAUNCH((k_filter_i8<false, 0, true>), dim3(gemm_blocks + kf_blocks), dim3(256), mc, ftiles, gemm_blocks); }
         else if (!accum) { LAUNCH(k_filter_i8<false>, dim3(gemm_blocks + kf_blocks), dim3(256), mc, ftiles, gemm_blocks); }
         else { LAUNCH(k_filter_splitk<false>, dim3(ftiles * split + kf_blocks), dim3(256), mc, ftiles, split); }
         seg_end(BTS_SEG_K_FILTER);
@@ -2446,7 +2757,21 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
     // (the grid only finds OVERLAPPING pairs: a match threshold >= 1 makes every pair feasible, which only the tile form emits)
     const bool xo = t->cfg.tie_mode && d.Df > 0;       // (the grid form does not emit overrides)
     const bool grid_form = d.use_grid && d.filter && !accum && !d.record && d.match1 < 1.0 && !xo;
-    if (xo && d.filter) {
+    if (d.sorted && !accum) {
+        // sorted / list form: tiles in grid order (at least 32 rows tall: a tile's rows cost next to nothing here) + the
+        // candidate wavefronts, one launch
+        int srows = trows < 32 ? 32 : trows;
+        while (srows < 256 && bts_cdiv(mc, CT_COLS) * bts_cdiv(T, srows) > TILE_GOAL) srows *= 2;
+        const int stiles = bts_cdiv(mc, CT_COLS) * bts_cdiv(T, srows);
+        int cblocks = bts_cdiv(d.f_ntiles * 4, CT_COLS / 64);
+        if (cblocks > 512) cblocks = 512;
+        switch (srows) {
+        case 32: LAUNCH(tk_edges_sorted<32>, dim3(stiles + cblocks), dim3(CT_COLS), lap[0], stiles); break;
+        case 64: LAUNCH(tk_edges_sorted<64>, dim3(stiles + cblocks), dim3(CT_COLS), lap[0], stiles); break;
+        case 128: LAUNCH(tk_edges_sorted<128>, dim3(stiles + cblocks), dim3(CT_COLS), lap[0], stiles); break;
+        default: LAUNCH(tk_edges_sorted<256>, dim3(stiles + cblocks), dim3(CT_COLS), lap[0], stiles); break;
+        }
+    } else if (xo && d.filter) {
         switch (trows) {
         case 2: LAUNCH((tk_edges_xo<1, 2>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
         case 4: LAUNCH((tk_edges_xo<1, 4>), dim3(ntile1), dim3(CT_COLS), lap[0], accum); break;
@@ -2521,8 +2846,9 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
     }
     seg_end(BTS_SEG_LAP1);
     seg_begin(BTS_SEG_APPLY1);
-    if (d.nch > 1) { LAUNCH(tk_mid1<true>, dim3(mid1_jobs(d.nch) + bts_cdiv(mc, 4)), dim3(1024)); }
-    else { LAUNCH(tk_mid1<false>, dim3(mid1_jobs(1) + bts_cdiv(mc, 4)), dim3(1024)); }       // stage-2/3 lists read pre-update states: before the stage-1 updates
+    const int clear_blocks = d.sorted ? 16 : 0;      // (the sorted / list form: the candidate list and its bitmap bits are cleared here)
+    if (d.nch > 1) { LAUNCH(tk_mid1<true>, dim3(mid1_jobs(d.nch) + bts_cdiv(mc, 4) + clear_blocks), dim3(1024), clear_blocks); }
+    else { LAUNCH(tk_mid1<false>, dim3(mid1_jobs(1) + bts_cdiv(mc, 4) + clear_blocks), dim3(1024), clear_blocks); }       // stage-2/3 lists read pre-update states: before the stage-1 updates
     if (dense) {
         rc = bts_cos_enqueue(cos_kernel, d.body_curr, d.unc_slot, d.D, feats, d.left_det, d.D, d.D, d.hdr + H_DIMS3, T, mc,
                              d.sim, M, s);

@@ -227,3 +227,118 @@ def test_cvt_overlap_with_and_without_the_residency_promise(bts, monkeypatch, re
             assert np.array_equal(ta["mean"], tb["mean"])
     assert ref.counts() == exp.counts() and ref.counts()["errors"] == 0
     ref.close(); exp.close()
+
+
+def _sorted_vs_default(bts, monkeypatch, frames_fn, K_tab, M_cap, D, nframes, oracle=True, onepass=True):
+    """the same frames through a default tracker and one created with BTS_EDGES_SORTED=1 (+ BTS_FILTER_ONEPASS so that small
+    problems take the one-pass pre-filter the sorted form builds on): stage results, track tables and Kalman means must be
+    IDENTICAL frame by frame (the edge SET is the same, only its order differs), and equal to the oracle's."""
+    from oracle import bts_oracle as bo
+    if onepass:
+        monkeypatch.setenv("BTS_FILTER_ONEPASS", "1")
+    ref = bts.DeviceTracker(max_tracks=K_tab, max_dets=M_cap, feat_dim=D)
+    monkeypatch.setenv("BTS_EDGES_SORTED", "1")
+    exp = bts.DeviceTracker(max_tracks=K_tab, max_dets=M_cap, feat_dim=D)
+    monkeypatch.delenv("BTS_EDGES_SORTED")
+    ora = bo.TrackerOracle(faithful_iou=False) if oracle else None
+    matched = 0
+    for f in range(nframes):
+        fr = frames_fn(f)
+        ref.step(*_dev(fr)); exp.step(*_dev(fr))
+        if ora is not None:
+            ora.update_arrays(fr.boxes, fr.scores.astype(np.float64), fr.feats.copy(), None)
+        for k in (1, 2, 3):
+            a, b = ref.stage_result(k), exp.stage_result(k)
+            assert np.array_equal(a["x"], b["x"]) and np.array_equal(a["y"], b["y"]), (f, k)
+            if ora is not None:
+                assert np.array_equal(b["m"], np.asarray(ora.trace["m%d" % k]).reshape(-1, 2)), (f, k)
+        matched += len(exp.stage_result(1)["m"])
+        for which in (0, 1):
+            ta, tb = ref.export(which), exp.export(which)
+            for key in INT_KEYS:
+                assert np.array_equal(ta[key], tb[key]), (f, which, key)
+            assert np.array_equal(ta["mean"], tb["mean"]), (f, which)
+        # the sorted form leaves no candidate bit behind (tk_mid1 clears what the list names): the next frame starts clean
+        assert ref.counts() == exp.counts() and exp.counts()["errors"] == 0, (f, exp.counts())
+        la, lb = ref.debug_lap(1), exp.debug_lap(1)
+        assert int(la[0]) == int(lb[0]), (f, int(la[0]), int(lb[0]))          # the same number of stage-1 edges
+    ref.close(); exp.close()
+    return matched
+
+
+@pytest.mark.parametrize("name", ["plain", "crowd@c2", "hard-reid@c2"])
+def test_sorted_list_form_of_stage1_equals_the_tile_form(bts, monkeypatch, name):
+    """BTS_EDGES_SORTED=1: stage-1 edges from tiles over spatially sorted columns (wave-union row skipping) plus candidate
+    wavefronts fed by the pre-filter's candidate LIST.  Plain scene with churn, a dense crowd (staging-buffer overflow inside a
+    tile, big components), clustered embeddings (more candidates per quadrant)."""
+    synth = bts.synth
+    if name == "plain":
+        K, M, D = 600, 300, 256
+        st = synth.SyntheticStream(K, M, D, seed=21, churn=0.05)
+    else:
+        K, M, D = synth.workload_dims(name)
+        st = synth.make_workload(name, seed=77)
+    matched = _sorted_vs_default(bts, monkeypatch, lambda f: st.next(), K + 256, max(K, M), D, 6)
+    assert matched > 3 * M
+
+
+def test_sorted_list_form_when_a_candidate_slot_overflows(bts, monkeypatch):
+    """Every detection carries (nearly) the same feature row as every track: each 64 x 64 quadrant of the pre-filter holds far
+    more candidates than a list slot (32) -- the consumer sweeps the quadrant's bitmap words instead, and tk_mid1 clears them."""
+    rng = np.random.default_rng(8)
+    K, D = 160, 128
+    base = rng.standard_normal(D)
+    base /= np.linalg.norm(base)
+
+    class Fr:
+        pass
+
+    def frame(f):
+        fr = Fr()
+        cx = rng.permutation(K) * 40 + 10
+        cy = rng.integers(100, 4000, K)
+        fr.boxes = np.stack([cx, cy, cx + 30, cy + 60], 1).astype(np.int32)
+        fr.scores = (rng.uniform(0.91, 0.99, K) if f == 0 else rng.uniform(0.5, 0.85, K)).astype(np.float32)
+        noise = rng.standard_normal((K, D)) * 0.02
+        fr.feats = (base[None, :] + noise).astype(np.float32)
+        fr.feats /= np.linalg.norm(fr.feats, axis=1, keepdims=True)
+        return fr
+
+    matched = _sorted_vs_default(bts, monkeypatch, frame, 256, K, D, 4)
+    assert matched > K
+
+
+def test_sorted_list_form_at_a_size_that_is_one_pass_by_itself(bts, monkeypatch):
+    """4224 x 2048 x 256 (528 pre-filter tiles > the 512 persistent workgroups): no test knob on the pre-filter, tiles of 32
+    rows and more, cosines within +-0.01 of the gate with teleporting boxes (only candidates can re-associate)."""
+    rng = np.random.default_rng(77)
+    K, D = 2048, 256
+    state = {"proto": None}
+    proto = rng.standard_normal((K, D))
+    state["proto"] = proto / np.linalg.norm(proto, axis=1, keepdims=True)
+
+    class Fr:
+        pass
+
+    def frame(f):
+        proto = state["proto"]
+        fr = Fr()
+        cx = rng.permutation(K) * 7 + 10
+        cy = rng.integers(100, 8000, K)
+        boxes = np.stack([cx, cy, cx + 5, cy + 9], 1).astype(np.int32)
+        scores = (rng.uniform(0.91, 0.99, K) if f == 0 else rng.uniform(0.5, 0.85, K)).astype(np.float32)
+        c = 0.75 + rng.uniform(3e-5, 0.01, K) * rng.choice([-1.0, 1.0], K)
+        if f == 0:
+            c[:] = 1.0
+        noise = rng.standard_normal((K, D))
+        noise -= (noise * proto).sum(1, keepdims=True) * proto
+        noise /= np.linalg.norm(noise, axis=1, keepdims=True)
+        feats = (c[:, None] * proto + np.sqrt(1 - c[:, None] ** 2) * noise).astype(np.float32)
+        proto = feats.astype(np.float64) / np.linalg.norm(feats.astype(np.float64), axis=1, keepdims=True)
+        perm = rng.permutation(K)
+        fr.boxes, fr.scores, fr.feats = boxes[perm], scores[perm], np.ascontiguousarray(feats[perm])
+        state["proto"] = proto[perm]
+        return fr
+
+    matched = _sorted_vs_default(bts, monkeypatch, frame, 4224, K, D, 3, oracle=False, onepass=False)
+    assert matched > K
