@@ -21,11 +21,13 @@ namespace {
 enum {   // hdr[] fields
     H_FRAME = 0, H_NTRACKED, H_NLOST, H_NREMOVED, H_LASTID, H_NPOOL, H_NHI, H_NLO, H_NUNC, H_NR2, H_NLEFT,
     H_ERR, H_NCONF, H_ALLF32, H_NFREE, H_NDETS, H_NKEEP, H_NB, H_NRF, H_NL0, H_NL1, H_NBORN,
-    H_DIMS1 = 24, H_DIMS2 = 26, H_DIMS3 = 28, H_SIZE = 32
+    H_DIMS1 = 24, H_DIMS2 = 26, H_DIMS3 = 28,      // ([30], [31]: frame and count of the first capacity error)
+    // BTS_LISTS_AHEAD: the NEXT frame's pool / unconfirmed sizes, produced by tk_finalize, moved into place by the next tk_front_dets
+    H_NPOOL_N = 32, H_NCONF_N, H_NUNC_N, H_ALLF32_N, H_SIZE = 40
 };
 enum { ERR_TRACK_CAPACITY = 1, ERR_LAP_EDGES = 2, ERR_CHUNK_WAIT = 4 };
 // list jobs that are split over `Dev::nch` consecutive workgroups (bscan::Chunk): their slices of Dev::agg
-enum { J_POOL = 0, J_UNC, J_R2, J_KEEP, J_RF, J_L0, J_L1, J_FT, J_FL, J_COUNT };
+enum { J_POOL = 0, J_UNC, J_R2, J_KEEP, J_RF, J_L0, J_L1, J_FT, J_FL, J_PB, J_COUNT };
 
 // Per-workgroup durations of the list jobs (make TRACE=1, bts_debug_jobtrace): 100 MHz ticks at g_jobtrace[kernel * 8 + job].
 __device__ int g_jobtrace[64];
@@ -96,6 +98,7 @@ struct Dev {
     // slot holds, the quadrant's bitmap words are swept instead); consumed by the candidate wavefronts of tk_edges_sorted,
     // cleared (with the bitmap bits) by tk_mid1
     int32_t sorted;                                    // the form is on for this tracker
+    int32_t ahead;                                     // BTS_LISTS_AHEAD=1 at create: tk_finalize also builds the next frame's pool / unconfirmed / free lists
     int32_t *cand_cnt;                                 // [f_slots]
     int2 *cand;                                        // [f_slots][CAND_W]
     int32_t f_ntiles, f_mc;                            // this step's pre-filter tiling (tiles, detection bound): what a slot index decodes with
@@ -409,6 +412,22 @@ template <bool CH, bool GRID = false, bool CVT = true> __global__ __launch_bound
     else if constexpr (CVT) { cvt_body(d, (long)b - front_jobs(nch)); if (b == front_jobs(nch)) TJ_END(0, 4); }
 }
 __global__ __launch_bounds__(1024) void tk_cvt(Dev d) { cvt_body(d, (long)blockIdx.x); }
+// BTS_LISTS_AHEAD: the frame opens with the detection side alone -- workgroup 0 builds the detection lists, moves the sizes the
+// previous tk_finalize left in the *_N header words into place (what prep_pool / prep_unconfirmed wrote at this point) and
+// clears the duplicate-removal flags; the others convert the detection rows (unless tk_cvt does, CVT = false)
+template <bool GRID, bool CVT> __global__ __launch_bounds__(1024) void tk_front_dets(Dev d) {
+    if (blockIdx.x != 0) { if constexpr (CVT) cvt_body(d, (long)blockIdx.x - 1); return; }
+    prep_dets<GRID>(d);
+    int32_t *h = d.hdr;
+    for (int s = threadIdx.x; s < d.T; s += blockDim.x) { d.drop_t[s] = 0; d.drop_l[s] = 0; }
+    if (threadIdx.x == 0) {
+        const int N = h[H_NPOOL_N], nunc = h[H_NUNC_N];
+        h[H_FRAME] += 1;
+        h[H_NPOOL] = N; h[H_NCONF] = h[H_NCONF_N]; h[H_ALLF32] = h[H_ALLF32_N];
+        h[H_DIMS1] = N; h[H_NR2] = 0; h[H_DIMS2] = 0;
+        h[H_NUNC] = nunc; h[H_DIMS3] = nunc;
+    }
+}
 
 __device__ __forceinline__ void predict_body(const Dev &d, int bid) {
     const int g = bid * 256 + threadIdx.x;
@@ -2133,12 +2152,76 @@ __global__ __launch_bounds__(CT_COLS) void tk_tail(Dev d, int dedupe_blocks) {
 }
 
 // ---- frame epilogue: final lists (one workgroup each), drop flags cleared for the next frame ------------------
+// BTS_LISTS_AHEAD (Dev::ahead; opt-in, NOT yet measured): the list jobs that open the NEXT frame -- pool = confirmed ++ lost,
+// unconfirmed, free slots (prep_pool / prep_unconfirmed / prep_free of tk_front) -- depend on nothing but this frame's final
+// lists, so they run here, in the same launch as the compactions that produce those lists and straight from the same inputs
+// (tracked2 / lost2 + drop flags): the next frame then opens with the detection-side work alone (tk_front_dets), which in
+// turn can be overlapped with this frame's tail (BTS_CVT_OVERLAP).  Their sizes go to the *_N header words; the drop flags
+// are cleared by tk_front_dets (they have several readers here).
+template <bool CH> __device__ __forceinline__ void ahead_body(const Dev &d, int job, int ch, int32_t *tmp) {
+    int32_t *h = d.hdr;
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const int nt2 = h[H_NKEEP] + h[H_NB] + h[H_NRF], nl2 = h[H_NL0] + h[H_NL1];
+    const bool last = ch == nchunks<CH>(d) - 1;
+    if (job == 0) {
+        // pool = [kept tracked that are activated] ++ [kept lost]   (D:1414-1423 of the next frame)
+        const bscan::Chunk ca = chunk_of(d, J_POOL, ch), cb = chunk_of(d, J_PB, ch);
+        // "every pool row still holds float32 state" (H_ALLF32, see prep_pool): only on the frame after the first one
+        const bool chk = h[H_FRAME] == 1;
+        int f64 = 0;
+        if (chk) {
+            int a, b;
+            job_range<CH>(ca, nt2, a, b);
+            for (int k = a + tid; k < b; k += nth) { const int s = tracked2_at(d, k); if (!d.drop_t[k] && (d.is_activated[s] != 0) & !d.f32[s]) f64 = 1; }
+            job_range<CH>(cb, nl2, a, b);
+            for (int k = a + tid; k < b; k += nth) if (!d.drop_l[k] && !d.f32[lost2_at(d, k)]) f64 = 1;
+            f64 = __syncthreads_or(f64);
+        }
+        int nconf = 0;
+        bool any64 = false;
+        job_compact<CH>(ca, nt2, tmp, [&](int k) { return tracked2_at(d, k); }, [&](int k, int s) { return !d.drop_t[k] && d.is_activated[s] != 0; },
+                        [&](int p, int k, int s) { d.pool_slot[p] = s; }, f64 != 0, true, &nconf, &any64);
+        const int nl = job_compact<CH>(cb, nl2, tmp, [&](int k) { return lost2_at(d, k); }, [&](int k, int s) { return !d.drop_l[k]; },
+                                       [&](int p, int k, int s) { d.pool_slot[nconf + p] = s; });
+        if (last && tid == 0) {
+            const int N = nconf + nl;
+            h[H_NPOOL_N] = N; h[H_NCONF_N] = nconf;
+            h[H_ALLF32_N] = (N > 0 && chk && !any64) ? 1 : 0;
+        }
+    } else if (job == 1) {
+        const int nunc = job_compact<CH>(chunk_of(d, J_UNC, ch), nt2, tmp, [&](int k) { return tracked2_at(d, k); },
+                                         [&](int k, int s) { return !d.drop_t[k] && d.is_activated[s] == 0; }, [&](int p, int k, int s) { d.unc_slot[p] = s; });
+        if (last && tid == 0) h[H_NUNC_N] = nunc;
+    } else {
+        // free slots = the table minus the kept entries of both lists (prep_free, from the same inputs)
+        __shared__ uint32_t used[FREE_BITS_WORDS];
+        const bool lds = d.T <= 32 * FREE_BITS_WORDS;
+        if (lds) {
+            for (int k = tid; k < (d.T + 31) / 32; k += nth) used[k] = 0u;
+            __syncthreads();
+            bscan::for_batched<4>(nt2, [&](int k) { return tracked2_at(d, k); }, [&](int k, int s) { if (!d.drop_t[k]) atomicOr(&used[s >> 5], 1u << (s & 31)); });
+            bscan::for_batched<4>(nl2, [&](int k) { return lost2_at(d, k); }, [&](int k, int s) { if (!d.drop_l[k]) atomicOr(&used[s >> 5], 1u << (s & 31)); });
+            __syncthreads();
+        } else {
+            for (int s = tid; s < d.T; s += nth) d.in_use[s] = 0;
+            __syncthreads();
+            bscan::for_batched<4>(nt2, [&](int k) { return tracked2_at(d, k); }, [&](int k, int s) { if (!d.drop_t[k]) d.in_use[s] = 1; });
+            bscan::for_batched<4>(nl2, [&](int k) { return lost2_at(d, k); }, [&](int k, int s) { if (!d.drop_l[k]) d.in_use[s] = 1; });
+            __syncthreads();
+        }
+        const int nfree = block_compact(d.T, tmp, [&](int s) { return lds ? (int)((used[s >> 5] >> (s & 31)) & 1u) : (int)d.in_use[s]; },
+                                        [&](int s, int v) { return v == 0; }, [&](int p, int s, int) { d.free_list[p] = s; });
+        if (tid == 0) h[H_NFREE] = nfree;
+    }
+}
+
 template <bool CH> __global__ __launch_bounds__(1024) void tk_finalize(Dev d) {
     __shared__ int32_t tmp[1024];
     int32_t *h = d.hdr;
     const int tid = threadIdx.x, nth = blockDim.x;
     TJ_BEGIN();
     const int nch = nchunks<CH>(d), job = (int)blockIdx.x / nch, ch = (int)blockIdx.x % nch;
+    if (job >= 2) { ahead_body<CH>(d, job - 2, ch, tmp); return; }      // (launched only with Dev::ahead: pool, unconfirmed, free)
     int lo, hi;
     if (job == 0) {
         const int nt2 = h[H_NKEEP] + h[H_NB] + h[H_NRF];
@@ -2146,7 +2229,7 @@ template <bool CH> __global__ __launch_bounds__(1024) void tk_finalize(Dev d) {
         const int nt = job_compact<CH>(cx, nt2, tmp, [&](int k) { return tracked2_at(d, k); }, [&](int k, int s) { return !d.drop_t[k]; },
                                             [&](int p, int k, int s) { d.tracked[p] = s; });
         job_range<CH>(cx, nt2, lo, hi);
-        for (int k = lo + tid; k < hi; k += nth) d.drop_t[k] = 0;
+        if (!d.ahead) for (int k = lo + tid; k < hi; k += nth) d.drop_t[k] = 0;
         if (ch == nch - 1 && tid == 0) h[H_NTRACKED] = nt;
     } else {
         const int nl2 = h[H_NL0] + h[H_NL1];
@@ -2154,7 +2237,7 @@ template <bool CH> __global__ __launch_bounds__(1024) void tk_finalize(Dev d) {
         const int nl = job_compact<CH>(cx, nl2, tmp, [&](int k) { return lost2_at(d, k); }, [&](int k, int s) { return !d.drop_l[k]; },
                                             [&](int p, int k, int s) { d.lost[p] = s; });
         job_range<CH>(cx, nl2, lo, hi);
-        for (int k = lo + tid; k < hi; k += nth) d.drop_l[k] = 0;
+        if (!d.ahead) for (int k = lo + tid; k < hi; k += nth) d.drop_l[k] = 0;
         if (ch == nch - 1 && tid == 0) h[H_NLOST] = nl;
     }
     if (ch == nch - 1) TJ_END(3, job);
@@ -2186,6 +2269,7 @@ __global__ __launch_bounds__(64) void tk_gmc(Dev d, Warp6 w) {
     kf::gmc(m, P, w.h);
     store_state(d, s, m, P);
     d.f32[s] = 0;                                   // R8.dot(mean) is float64 whatever the state was
+    if (k == 0) d.hdr[H_ALLF32_N] = 0;              // (BTS_LISTS_AHEAD: ... and so is the verdict tk_finalize took ahead for the next frame)
 }
 
 // ---- export -----------------------------------------------------------------------------------------------------
@@ -2396,6 +2480,8 @@ static int derive_sizes(const bts_tracker_config *cfg, Dev &d, int64_t *e_cap_ou
     // BTS_EDGES_SORTED=1 (read when the tracker is created / sized): stage-1 edges in the sorted / list form (tk_edges_sorted)
     d.sorted = (getenv("BTS_EDGES_SORTED") != nullptr && d.filter && d.Df == 0 && !cfg->motion_gate && !cfg->record_costs &&
                 cfg->match_thresh < 1.0 && !cfg->use_graph) ? 1 : 0;
+    // BTS_LISTS_AHEAD=1 (read at create): the next frame's pool / unconfirmed / free lists are built by tk_finalize
+    d.ahead = (getenv("BTS_LISTS_AHEAD") != nullptr && !cfg->use_graph) ? 1 : 0;
     d.sf32 = cfg->kalman_dtype == BTS_F32 ? 1 : 0;
     d.c16 = cfg->cost_dtype == BTS_F16 ? 1 : 0;
     if (cfg->tie_mode) {
@@ -2674,6 +2760,7 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
 
     seg_begin(BTS_SEG_STEP);
     seg_begin(BTS_SEG_PREP);
+    const bool want_grid = (d.use_grid || d.sorted) && d.filter;
     if (ov) {
         // The side stream reads this frame's feature rows.  Unless the caller has promised that they are complete when the
         // step is called (bts_tracker_inputs_resident), it is ordered behind whatever the caller's stream holds at this point
@@ -2687,15 +2774,22 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
         if (t->ev_done_used[ovp]) BTS_HIP(hipStreamWaitEvent(t->side, t->ev_done[ovp], 0));
         LAUNCH_ON(t->side, tk_cvt, dim3(bts_cdiv(mc, 4)), dim3(1024));
         BTS_HIP(hipEventRecord(t->ev_cvt[ovp], t->side));
-        const dim3 fgrid(front_jobs(d.nch > 1 ? d.nch : 1));
-        if (d.use_grid || d.sorted) {
-            if (d.nch > 1) { LAUNCH((tk_front<true, true, false>), fgrid, dim3(1024)); } else { LAUNCH((tk_front<false, true, false>), fgrid, dim3(1024)); }
-        } else if (d.nch > 1) { LAUNCH((tk_front<true, false, false>), fgrid, dim3(1024)); }
-        else { LAUNCH((tk_front<false, false, false>), fgrid, dim3(1024)); }
+        if (d.ahead) {
+            if (want_grid) { LAUNCH((tk_front_dets<true, false>), dim3(1), dim3(1024)); } else { LAUNCH((tk_front_dets<false, false>), dim3(1), dim3(1024)); }
+        } else {
+            const dim3 fgrid(front_jobs(d.nch > 1 ? d.nch : 1));
+            if (want_grid) {
+                if (d.nch > 1) { LAUNCH((tk_front<true, true, false>), fgrid, dim3(1024)); } else { LAUNCH((tk_front<false, true, false>), fgrid, dim3(1024)); }
+            } else if (d.nch > 1) { LAUNCH((tk_front<true, false, false>), fgrid, dim3(1024)); }
+            else { LAUNCH((tk_front<false, false, false>), fgrid, dim3(1024)); }
+        }
         BTS_HIP(hipStreamWaitEvent(s, t->ev_cvt[ovp], 0));
+    } else if (d.ahead) {
+        const dim3 fgrid(1 + (d.filter ? bts_cdiv(mc, 4) : 0));
+        if (want_grid) { LAUNCH((tk_front_dets<true, true>), fgrid, dim3(1024)); } else { LAUNCH((tk_front_dets<false, true>), fgrid, dim3(1024)); }
     } else {
         const dim3 fgrid(front_jobs(d.nch > 1 ? d.nch : 1) + (d.filter ? bts_cdiv(mc, 4) : 0));
-        if ((d.use_grid || d.sorted) && d.filter) {
+        if (want_grid) {
             if (d.nch > 1) { LAUNCH((tk_front<true, true>), fgrid, dim3(1024)); } else { LAUNCH((tk_front<false, true>), fgrid, dim3(1024)); }
         } else if (d.nch > 1) { LAUNCH((tk_front<true, false>), fgrid, dim3(1024)); }
         else { LAUNCH((tk_front<false, false>), fgrid, dim3(1024)); }
@@ -2897,8 +2991,9 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
         default: LAUNCH(tk_tail<64>, dim3(nd + mc), dim3(CT_COLS), nd); break;
         }
     }
-    if (d.nch > 1) { LAUNCH(tk_finalize<true>, dim3(2 * d.nch), dim3(1024)); }
-    else { LAUNCH(tk_finalize<false>, dim3(2), dim3(1024)); }
+    // (BTS_LISTS_AHEAD: + the pool and unconfirmed jobs of the next frame, nch chunks each, and its free-slot job)
+    if (d.nch > 1) { LAUNCH(tk_finalize<true>, dim3(d.ahead ? 4 * d.nch + 1 : 2 * d.nch), dim3(1024)); }
+    else { LAUNCH(tk_finalize<false>, dim3(d.ahead ? 5 : 2), dim3(1024)); }
     seg_end(BTS_SEG_DEDUPE);
     seg_end(BTS_SEG_STEP);
     if (ov) { BTS_HIP(hipEventRecord(t->ev_done[ovp], s)); t->ev_done_used[ovp] = true; }

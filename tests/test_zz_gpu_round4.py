@@ -341,4 +341,59 @@ def test_sorted_list_form_at_a_size_that_is_one_pass_by_itself(bts, monkeypatch)
         return fr
 
     matched = _sorted_vs_default(bts, monkeypatch, frame, 4224, K, D, 3, oracle=False, onepass=False)
-    assert matched > K
+    assert matched > K // 2            # (frame 1: about half of the cosines inside the gate, frame 2: half of those)
+
+
+@pytest.mark.parametrize("combo", ["ahead", "ahead+cvt", "ahead+sorted+cvt+predict_first"])
+@pytest.mark.parametrize("K,M,D", [(300, 150, 128), (2600, 700, 128)])
+def test_lists_ahead_changes_no_result(bts, monkeypatch, combo, K, M, D):
+    """BTS_LISTS_AHEAD=1: tk_finalize also builds the next frame's pool / unconfirmed / free lists (from tracked2 / lost2 and the
+    drop flags, i.e. before the final lists exist) and the frame opens with tk_front_dets alone.  Alone and together with the
+    other opt-in forms; with births, expiries and duplicate removal going on (churn), a camera-motion update between frames 1
+    and 2 (it turns every float32 state into float64: the H_ALLF32 verdict taken ahead must follow) and a reset in the middle.
+    The second size runs the split list jobs (chunks) where the table is large enough for them (BTS_CHUNK_ROWS)."""
+    synth = bts.synth
+    from oracle import bts_oracle as bo
+    if K > 1000:
+        monkeypatch.setenv("BTS_CHUNK_ROWS", "512")
+    ref = bts.DeviceTracker(max_tracks=K + K // 2, max_dets=max(K, M), feat_dim=D)
+    monkeypatch.setenv("BTS_LISTS_AHEAD", "1")
+    monkeypatch.setenv("BTS_FILTER_ONEPASS", "1")
+    if "cvt" in combo:
+        monkeypatch.setenv("BTS_CVT_OVERLAP", "1")
+    if "sorted" in combo:
+        monkeypatch.setenv("BTS_EDGES_SORTED", "1")
+    if "predict_first" in combo:
+        monkeypatch.setenv("BTS_PREDICT_FIRST", "1")
+    exp = bts.DeviceTracker(max_tracks=K + K // 2, max_dets=max(K, M), feat_dim=D)
+    for v in ("BTS_LISTS_AHEAD", "BTS_CVT_OVERLAP", "BTS_EDGES_SORTED", "BTS_PREDICT_FIRST", "BTS_FILTER_ONEPASS"):
+        monkeypatch.delenv(v, raising=False)
+    exp.inputs_resident(True)
+    ora = bo.TrackerOracle(faithful_iou=False)
+    st = synth.SyntheticStream(K, M, D, seed=31, churn=0.08)
+    H = np.array([[1.0, 0.002, 3.0], [-0.002, 1.0, -2.0]])
+    nframes = 9 if K < 1000 else 5
+    for f in range(nframes):
+        if f == 1 and K < 1000:                  # camera motion between the first two frames (oracle: STrack.multi_gmc on both lists)
+            ref.gmc(H); exp.gmc(H)
+            bo.multi_gmc_lists(ora, H) if hasattr(bo, "multi_gmc_lists") else None
+        if f == 6:
+            ref.reset(); exp.reset()
+            ora = bo.TrackerOracle(faithful_iou=False)
+        fr = st.next()
+        ref.step(*_dev(fr)); exp.step(*_dev(fr))
+        gmc_in_oracle = hasattr(bo, "multi_gmc_lists") or not (K < 1000 and 1 <= f < 6)
+        if gmc_in_oracle:
+            ora.update_arrays(fr.boxes, fr.scores.astype(np.float64), fr.feats.copy(), None)
+        for k in (1, 2, 3):
+            a, b = ref.stage_result(k), exp.stage_result(k)
+            assert np.array_equal(a["x"], b["x"]) and np.array_equal(a["y"], b["y"]), (f, k)
+            if gmc_in_oracle:
+                assert np.array_equal(b["m"], np.asarray(ora.trace["m%d" % k]).reshape(-1, 2)), (f, k)
+        for which in (0, 1):
+            ta, tb = ref.export(which), exp.export(which)
+            for key in INT_KEYS + ("slot",):
+                assert np.array_equal(ta[key], tb[key]), (f, which, key)
+            assert np.array_equal(ta["mean"], tb["mean"]), (f, which)
+        assert ref.counts() == exp.counts() and exp.counts()["errors"] == 0, (f, ref.counts(), exp.counts())
+    ref.close(); exp.close()
