@@ -80,6 +80,10 @@ def parse():
     ap.add_argument("--motion-gate", action="store_true", help="Mahalanobis gate on the stage-1 pairs (bts_tracker_config.motion_gate; "
                     "off = the reference's cascade).  BASELINE config 3 is stated with the gate on: --workload c3 implies it")
     ap.add_argument("--no-motion-gate", action="store_true", help="c3 without the gate")
+    ap.add_argument("--forms", default="auto", help="execution forms of the tracker (bts_tracker_create_forms; they never change a result): "
+                    "auto = selected on this GPU in the untimed set-up (tune.run_isolated: a child process steps each candidate on frames "
+                    "of this workload, keeps what is bit-identical to the default forms AND faster; the line carries the whole table), "
+                    "default = the library's defaults, or an explicit 'KEY=VALUE,...'")
     ap.add_argument("--oversubscribe", action="store_true", help="allow --gpus N on a box with fewer GPUs (ranks share devices; "
                     "for testing the launch path only -- the line says so)")
     return ap.parse_args()
@@ -168,11 +172,12 @@ class IdMatch:
     compared with the oracle's."""
     INT_KEYS = ("track_id", "state", "is_activated", "frame_id", "start_frame", "tracklet_len")
 
-    def __init__(self, pkg, K, M, D, motion_gate=False, **opts):
+    def __init__(self, pkg, K, M, D, motion_gate=False, forms=None, **opts):
         import torch
         self.torch = torch
+        # (the checker runs the SAME execution forms as the timed tracker: what is measured is what is checked)
         self.trk = pkg.DeviceTracker(max_tracks=table_rows(K, motion_gate), max_dets=max(K, M), feat_dim=D, device=torch.cuda.current_device(),
-                                     motion_gate=1 if motion_gate else 0, **opts)
+                                     motion_gate=1 if motion_gate else 0, forms=forms or None, **opts)
         self.frames = self.pairs = self.pairs_equal = self.ids = self.ids_equal = 0
         self.frames_identical = 0
         self.kalman_err = 0.0
@@ -371,7 +376,7 @@ def export_legs(pkg, trk, frames, torch):
                     "per frame, read one ring turn late); sync: bts_tracker_export_mot (stream sync + copy) after every step"}
 
 
-def facade_leg(pkg, torch, wl, n_frames, seed):
+def facade_leg(pkg, torch, wl, n_frames, seed, forms=None):
     """The BoTSORT facade's own rate on one GPU: update_arrays(export=True) fed with frames already resident in HBM.
     lists_only: the call returns lazy TrackLists (one bts_tracker_export_lists per frame, no per-track Python);
     read_all:   the caller then reads tlbr and track_id of every returned track (the reference's loop D:2135-2143);
@@ -389,7 +394,7 @@ def facade_leg(pkg, torch, wl, n_frames, seed):
 
     res = {"workload": wl, "frames_per_leg": n_frames}
     for name, lazy, read in (("lists_only", True, False), ("read_all", True, True), ("eager", False, False)):
-        bot = pkg.BoTSORT(max_tracks=table_rows(K), max_dets=max(K, M), feat_dim=D, device=torch.cuda.current_device(), lazy_lists=lazy)
+        bot = pkg.BoTSORT(max_tracks=table_rows(K), max_dets=max(K, M), feat_dim=D, device=torch.cuda.current_device(), lazy_lists=lazy, forms=forms or None)
         st = pkg.synth.make_workload(wl, seed=seed)
         for fr in frames(warm):
             bot.update_arrays(*fr)
@@ -455,8 +460,29 @@ def main():
 
     stream = torch.cuda.Stream()          # graph replay needs a real (non-legacy) stream
     torch.cuda.set_stream(stream)
-    frames = [next_frame() for _ in range(a.warmup)]
     opts = dict(appearance_mode=1 if a.dense else 0, use_graph=1 if a.graph else 0, motion_gate=1 if a.motion_gate else 0)
+    # ---- execution forms (untimed set-up): selected in a child process while this one generates its frames
+    selection, sel_thread = None, None
+    if a.forms == "auto" and S == 1 and not a.graph and not a.dense and not os.environ.get("BTS_BENCH_NO_TUNE"):
+        import threading
+        tune = importlib.import_module("bot-sort-onnx-tensorrt_amd.tune")
+        box = {}
+
+        def select():
+            box["r"] = guarded("form_selection", tune.run_isolated, a.workload, ms_seed(pkg, rank * S), local % ndev,
+                               n_frames=int(os.environ.get("BTS_TUNE_FRAMES", "36")), timeout_s=float(os.environ.get("BTS_TUNE_TIMEOUT", "420")),
+                               tracker_args=dict(max_tracks=table_rows(K, a.motion_gate), max_dets=max(K, M), feat_dim=D, **opts))
+        sel_thread = threading.Thread(target=select, daemon=True)
+        sel_thread.start()
+    frames = [next_frame() for _ in range(a.warmup)]
+    timed = [next_frame() for _ in range(a.steps)]
+    forms = "" if a.forms in ("auto", "default") else a.forms
+    if sel_thread is not None:
+        sel_thread.join()
+        selection = box.get("r")
+        if isinstance(selection, dict) and selection.get("forms") and "error" not in selection:
+            forms = selection["forms"]
+    opts["forms"] = forms or None
     trk = pkg.DeviceTracker(max_tracks=table_rows(K, a.motion_gate), max_dets=max(K, M), feat_dim=D, device=torch.cuda.current_device(), **opts)
 
     if hasattr(pkg._lib.load(), "bts_tracker_inputs_resident"):
@@ -468,7 +494,6 @@ def main():
     for k in range(a.warmup):
         trk.step(*frames[k])
     torch.cuda.synchronize()
-    timed = [next_frame() for _ in range(a.steps)]
     extra = []                       # further streams of this GPU: (tracker, HIP stream, frames), warmed up the same way
     for k in range(1, S):
         st_k = pkg.synth.make_workload(a.workload, seed=ms_seed(pkg, rank * S + k))
@@ -543,7 +568,7 @@ def main():
     facade = None
     if rank == 0 and world == 1 and S == 1 and not a.no_export and not a.graph and not a.dense and not a.motion_gate:
         nf = max(16, min(a.steps, 64))
-        facade = guarded("facade", facade_leg, pkg, torch, a.workload, nf, ms_seed(pkg, 0))
+        facade = guarded("facade", facade_leg, pkg, torch, a.workload, nf, ms_seed(pkg, 0), forms)
         if a.workload == "target":
             facade = {"target": facade, "c2": guarded("facade_c2", facade_leg, pkg, torch, "c2", 4 * nf, ms_seed(pkg, 0))}
 
@@ -553,7 +578,7 @@ def main():
         # ID match of EVERY rank's stream (N > 1: no CPU baseline, that is the N = 1 line's): steady-state frames of this
         # rank's stream through a second handle and the oracle (vectorised IoU form: the checker, not a timing), gathered
         def rank_ids():
-            chk = IdMatch(pkg, K, M, D, a.motion_gate)
+            chk = IdMatch(pkg, K, M, D, a.motion_gate, forms=forms)
             cpu_baseline(pkg, a.workload, ms_seed(pkg, rank), 120.0, chk, faithful=False, max_frames=a.id_frames or (4 if big else 24), motion_gate=a.motion_gate)
             return dict(chk.result(), stream_seed=int(ms_seed(pkg, rank)))
         id_multi = [None] * world
@@ -596,7 +621,10 @@ def main():
                        "launch": "hipGraph replay" if a.graph else "eager", "motion_gate": bool(a.motion_gate),
                        "spawn": "self-spawned ranks" if os.environ.get("BTS_BENCH_SPAWNED") else ("torch.distributed.run" if world > 1 else "single process"),
                        "oversubscribed": bool(world > ndev),
-                       "opt_in": {k: v for k, v in os.environ.items() if k.startswith("BTS_") and k not in ("BTS_BENCH_SPAWNED", "BTS_LIB_PATH")}},
+                       "opt_in": {k: v for k, v in os.environ.items() if k.startswith("BTS_") and k not in ("BTS_BENCH_SPAWNED", "BTS_LIB_PATH")},
+                       # execution forms of the timed tracker (and of the id_match / facade trackers): what was asked for, what is
+                       # in effect (bts_tracker_forms).  They never change a result; "auto" = selected on this GPU, table below
+                       "forms": {"mode": a.forms, "requested": forms, "in_effect": guarded("forms", trk.forms)}},
             # flat fields = the dominant kernel (contract); .step is the whole step
             "roofline": kern_roof,
         }
@@ -606,6 +634,9 @@ def main():
             "algorithmic_bytes_as_built": b_built, "achieved_as_built": b_built / step_s / 1e9, "frac_as_built": b_built / step_s / 1e9 / HBM_PEAK_GBS,
             "formula": "SURVEY.md 8(d) with fp32 element sizes (survey) / float64 Kalman rows, no N x M matrix, int8 shadows (as built): bench.py step_bytes()"}
         out["segments_us"] = {k: round(v, 2) for k, v in breakdown.items()}
+        if selection is not None:
+            # every candidate's us/step and whether its results were bit-identical to the default forms' on the verified frames
+            out["form_selection"] = selection
         if not isinstance(late_errors, dict) and late_errors != 0:
             out["device_errors_after_timed_region"] = late_errors
         Mh = max(1, counts.get("n_hi", M) or M)
@@ -652,7 +683,7 @@ def main():
                 # what ONE GPU serves when it is given several independent streams of this workload (own handle, HIP stream
                 # and host thread each: multistream.run_concurrent); not the headline configuration (1 stream per GPU)
                 out["several_streams_one_gpu"] = several_streams(a, (4, 8))
-            checker = guarded("id_match", IdMatch, pkg, K, M, D, a.motion_gate) if (S == 1 and not a.dense) else None
+            checker = guarded("id_match", IdMatch, pkg, K, M, D, a.motion_gate, forms=forms) if (S == 1 and not a.dense) else None
             checker_err = checker if isinstance(checker, dict) else None
             if checker_err:
                 checker = None

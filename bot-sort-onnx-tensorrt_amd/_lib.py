@@ -67,6 +67,9 @@ SIGNATURES = {
     "bts_tracker_default_config": (c_int, [POINTER(TrackerConfig)]),
     "bts_tracker_memory_bytes": (c_int, [POINTER(TrackerConfig), POINTER(ctypes.c_uint64)]),
     "bts_tracker_create": (c_int, [_P, POINTER(TrackerConfig), POINTER(c_void_p)]),
+    "bts_tracker_create_forms": (c_int, [_P, POINTER(TrackerConfig), c_char_p, POINTER(c_void_p)]),
+    "bts_tracker_memory_bytes_forms": (c_int, [POINTER(TrackerConfig), c_char_p, POINTER(ctypes.c_uint64)]),
+    "bts_tracker_forms": (c_int, [_P, c_char_p, c_int]),
     "bts_tracker_destroy": (c_int, [_P]),
     "bts_tracker_reset": (c_int, [_P, _P]),
     "bts_tracker_step": (c_int, [_P, _P, _P, _P, _P, c_int, _P]),

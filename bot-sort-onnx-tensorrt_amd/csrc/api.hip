@@ -12,6 +12,34 @@ void bts_set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+// ---- execution forms: "KEY=VALUE,KEY=VALUE" handed to bts_tracker_create_forms, consulted before the process environment ----
+static thread_local const char *g_forms = nullptr;
+static thread_local char g_form_val[64];
+
+bts_forms_scope::bts_forms_scope(const char *forms) : prev(g_forms) { g_forms = forms; }
+bts_forms_scope::~bts_forms_scope() { g_forms = prev; }
+
+const char *bts_form_get(const char *key) {
+    const size_t kl = strlen(key);
+    for (const char *p = g_forms; p && *p;) {
+        while (*p == ',' || *p == ' ' || *p == ';') ++p;
+        const char *e = p;
+        while (*e && *e != ',' && *e != ';') ++e;
+        if ((size_t)(e - p) >= kl && !strncmp(p, key, kl) && (p[kl] == '=' || p + kl == e)) {
+            // KEY=VALUE -> VALUE; a bare KEY counts as "1"; KEY= (empty value) switches a form OFF whatever the environment says
+            const char *v = p[kl] == '=' ? p + kl + 1 : "1";
+            size_t n = p[kl] == '=' ? (size_t)(e - v) : 1;
+            if (n == 0) return nullptr;
+            if (n >= sizeof(g_form_val)) n = sizeof(g_form_val) - 1;
+            memcpy(g_form_val, v, n);
+            g_form_val[n] = 0;
+            return g_form_val;
+        }
+        p = e;
+    }
+    return getenv(key);
+}
+
 int bts_arena::ensure(size_t bytes) {
     if (bytes <= cap) return BTS_OK;
     // growing replaces the block: everything enqueued on the old one (any stream of this device) must have finished

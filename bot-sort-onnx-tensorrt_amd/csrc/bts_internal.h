@@ -44,6 +44,19 @@ void bts_set_error(const char *fmt, ...);
         }                                                                                    \
     } while (0)
 
+// Execution forms (which of several result-identical kernel forms / launch structures a tracker uses): every switch is a
+// KEY[=VALUE] pair looked up first in the string given to bts_tracker_create_forms (while a bts_forms_scope is alive on this
+// thread), then in the process environment.  "KEY=" (empty value) in the string turns a form off whatever the environment says.
+// The returned pointer is valid until the next bts_form_get on this thread.
+const char *bts_form_get(const char *key);
+struct bts_forms_scope {
+    const char *prev;
+    explicit bts_forms_scope(const char *forms);
+    ~bts_forms_scope();
+    bts_forms_scope(const bts_forms_scope &) = delete;
+    bts_forms_scope &operator=(const bts_forms_scope &) = delete;
+};
+
 static inline int bts_cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t bts_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
@@ -86,7 +99,9 @@ constexpr int BTS_LAP_HDR_INTS = 64;   // counters (first 128-byte line) + the r
 
 struct bts_lap_work {
     int32_t n_cap = 0, m_cap = 0;
-    int64_t e_cap = 0;
+    int64_t e_cap = 0;           // feasible edges the list holds: [0, e_cap) of e_row / e_col / e_cost
+    int64_t o_cap = 0;           // room BEHIND them for the exact-tie step's overrides, filled from the top end of the arrays
+                                 // downwards: [e_cap + o_cap - O, e_cap + o_cap) -- the two regions never meet
     int32_t *hdr = nullptr;      // [BTS_LAP_HDR_INTS] counters, see lap.hip
     int32_t *e_row = nullptr;    // [e_cap] unsorted feasible edges (row, col, cost)
     int32_t *e_col = nullptr;
@@ -127,9 +142,9 @@ struct bts_lap_work {
     size_t bytes = 0;
 };
 
-size_t bts_lap_work_bytes(int n_cap, int m_cap, int64_t e_cap);
+size_t bts_lap_work_bytes(int n_cap, int m_cap, int64_t e_cap, int64_t o_cap = 0);
 // carve `w` out of a device block of bts_lap_work_bytes() bytes
-void bts_lap_work_carve(bts_lap_work *w, void *block, int n_cap, int m_cap, int64_t e_cap);
+void bts_lap_work_carve(bts_lap_work *w, void *block, int n_cap, int m_cap, int64_t e_cap, int64_t o_cap = 0);
 
 // Enqueue: dense cost[n x m] (leading dimension ld, live sizes in dims[0], dims[1] on device,
 // bounded by n_max/m_max known to the host) -> x[n], y[m].
@@ -152,8 +167,9 @@ int bts_lap_init();
 // Enqueue 1 or 2 independent problems (they share one launch).
 // `ev` (nullable): four pre-created events recorded around k_prepare and k_solve (measurement hook).
 // `form`: 0 = column forms (default), 1 = the round-2 row forms (k_lap<EC, false>), -1 = the process default (BTS_LAP_FORM=row | col).
-int bts_lap_enqueue(const bts_lap_problem *probs, int count, hipStream_t stream, hipEvent_t *ev = nullptr, int form = -1);
-int bts_lap_form_from_env();
+// form: 0 column forms, 1 row forms, < 0 the process default (BTS_LAP_FORM); helpers: helper workgroups per problem, < 0 automatic
+int bts_lap_enqueue(const bts_lap_problem *probs, int count, hipStream_t stream, hipEvent_t *ev = nullptr, int form = -1, int helpers = -1);
+int bts_lap_form_from_env();      // (BTS_LAP_FORM through bts_form_get)
 // reset hdr before edges are appended
 int bts_lap_enqueue_reset(const bts_lap_work *w, hipStream_t stream);
 

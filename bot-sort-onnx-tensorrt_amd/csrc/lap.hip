@@ -1492,10 +1492,10 @@ __global__ __launch_bounds__(1024) void k_lap_exact(ExactPair P) {
     int E = RLX(&w.hdr[H_EDGES]);
     const int O = RLX(&w.hdr[H_OVR]);                                     // overrides above the limit, filled from the top end downwards
     if (RLX(&w.hdr[H_ERR]) || (long)E > w.e_cap) return;                  // (an overflowed edge list is already an error of the frame)
-    if ((long)E + O > w.e_cap) { if (threadIdx.x == 0) { RST(&w.hdr[BTS_LAP_H_XERR], 16); RST(&w.hdr[H_ERR], 4); } return; }
+    if ((long)O > w.o_cap) { if (threadIdx.x == 0) { RST(&w.hdr[BTS_LAP_H_XERR], 16); RST(&w.hdr[H_ERR], 4); } return; }      // (flagged where they were written, too)
     lapx::Work W;
     W.N = n; W.M = m; W.L = A.limit; W.e_row = w.e_row; W.e_col = w.e_col; W.e_cost = w.e_cost; W.E = E;
-    W.O = O; W.o_base = w.e_cap - O;
+    W.O = O; W.o_base = w.e_cap + w.o_cap - O;
     W.x = A.x; W.y = A.y;
     W.max_steps = 8000000L;                                               // ~40x what a 10 000 x 2 000 replay needs
     if (!lapx::work_carve(W, n, m, (long)E + O, (int)blockDim.x, X.dbl, X.ndbl, X.ints, X.nints)) {
@@ -1524,10 +1524,10 @@ __global__ __launch_bounds__(1024) void k_lap_exact(ExactPair P) {
 // ---------------------------------------------------------------------------------------- host
 static size_t carve(size_t &off, size_t bytes) { const size_t o = off; off = bts_align(off + bytes); return o; }
 
-static void layout(bts_lap_work *w, char *base, size_t &off, int n, int m, int64_t e) {
+static void layout(bts_lap_work *w, char *base, size_t &off, int n, int m, int64_t e, int64_t ovr) {
 #define SLOT(field, type, count) { size_t o = carve(off, sizeof(type) * (size_t)(count)); w->field = base ? (type *)(base + o) : nullptr; }
     SLOT(hdr, int32_t, BTS_LAP_HDR_INTS);
-    SLOT(e_row, int32_t, e); SLOT(e_col, int32_t, e); SLOT(e_cost, double, e);
+    SLOT(e_row, int32_t, e + ovr); SLOT(e_col, int32_t, e + ovr); SLOT(e_cost, double, e + ovr);      // (+ the overrides' own region)
     SLOT(deg, int32_t, n); SLOT(cdeg, int32_t, m); SLOT(rptr, int32_t, n + 1); SLOT(cursor, int32_t, n);
     SLOT(csr_col, int32_t, e); SLOT(csr_cost, double, e);
     SLOT(parent, int32_t, n + m); SLOT(rootv, int32_t, n + m); SLOT(comp_of, int32_t, n);
@@ -1541,17 +1541,17 @@ static void layout(bts_lap_work *w, char *base, size_t &off, int n, int m, int64
 #undef SLOT
 }
 
-size_t bts_lap_work_bytes(int n_cap, int m_cap, int64_t e_cap) {
+size_t bts_lap_work_bytes(int n_cap, int m_cap, int64_t e_cap, int64_t o_cap) {
     bts_lap_work w; size_t off = 0;
-    layout(&w, nullptr, off, n_cap < 1 ? 1 : n_cap, m_cap < 1 ? 1 : m_cap, e_cap < 1 ? 1 : e_cap);
+    layout(&w, nullptr, off, n_cap < 1 ? 1 : n_cap, m_cap < 1 ? 1 : m_cap, e_cap < 1 ? 1 : e_cap, o_cap < 0 ? 0 : o_cap);
     return off;
 }
 
-void bts_lap_work_carve(bts_lap_work *w, void *block, int n_cap, int m_cap, int64_t e_cap) {
+void bts_lap_work_carve(bts_lap_work *w, void *block, int n_cap, int m_cap, int64_t e_cap, int64_t o_cap) {
     size_t off = 0;
-    n_cap = n_cap < 1 ? 1 : n_cap; m_cap = m_cap < 1 ? 1 : m_cap; e_cap = e_cap < 1 ? 1 : e_cap;
-    layout(w, (char *)block, off, n_cap, m_cap, e_cap);
-    w->n_cap = n_cap; w->m_cap = m_cap; w->e_cap = e_cap; w->bytes = off;
+    n_cap = n_cap < 1 ? 1 : n_cap; m_cap = m_cap < 1 ? 1 : m_cap; e_cap = e_cap < 1 ? 1 : e_cap; o_cap = o_cap < 0 ? 0 : o_cap;
+    layout(w, (char *)block, off, n_cap, m_cap, e_cap, o_cap);
+    w->n_cap = n_cap; w->m_cap = m_cap; w->e_cap = e_cap; w->o_cap = o_cap; w->bytes = off;
 }
 
 int bts_lap_enqueue_reset(const bts_lap_work *w, hipStream_t stream) {
@@ -1571,9 +1571,9 @@ int bts_lap_init() {      // the solver kernel needs more than the default 64 Ki
     return BTS_OK;
 }
 
-int bts_lap_form_from_env() { const char *e = getenv("BTS_LAP_FORM"); return e && !strcmp(e, "row") ? 1 : 0; }
+int bts_lap_form_from_env() { const char *e = bts_form_get("BTS_LAP_FORM"); return e && !strcmp(e, "row") ? 1 : 0; }
 
-int bts_lap_enqueue(const bts_lap_problem *probs, int count, hipStream_t stream, hipEvent_t *ev, int form) {
+int bts_lap_enqueue(const bts_lap_problem *probs, int count, hipStream_t stream, hipEvent_t *ev, int form, int helpers_want) {
     int rc0 = bts_lap_init();
     if (rc0) return rc0;
     const bts_lap_problem &A = probs[0], &B = probs[count > 1 ? 1 : 0];
@@ -1582,9 +1582,11 @@ int bts_lap_enqueue(const bts_lap_problem *probs, int count, hipStream_t stream,
     if (ev) (void)hipEventRecord(ev[0], stream);
     // a component is one wavefront's job: big problems (hundreds of components) get more helper workgroups
     int helpers = (A.n_max >= 2048 || B.n_max >= 2048) ? LAP_HELPERS_BIG : LAP_HELPERS;
-    {   // BTS_LAP_HELPERS: sweep knob (host side only: the grid's second dimension), read once
+    {   // BTS_LAP_HELPERS: sweep knob (host side only: the grid's second dimension); a tracker passes what it read at create,
+        // the standalone entry points read the process environment once
         static const int forced = [] { const char *e = getenv("BTS_LAP_HELPERS"); return e ? atoi(e) : -1; }();
-        if (forced >= 0 && forced <= 255) helpers = forced;
+        const int want = helpers_want >= 0 ? helpers_want : forced;
+        if (want >= 0 && want <= 255) helpers = want;
     }
     // edges a thread keeps in registers across the preparation passes: 4 (lists up to 4096 edges are read once), or 8 for
     // problems wide enough to produce longer lists (the instantiation costs the short ones a few percent)

@@ -396,6 +396,27 @@ __device__ __forceinline__ void copy_shadow(const int8_t *src_q, const float *sr
     if (t < feat::I8_META) dst_m[t] = src_m[t];
 }
 
+// NEXT = true (BTS_PREDICT_FRONT, with BTS_LISTS_AHEAD): called from the frame's FIRST launch, where the pool's sizes still sit in
+// the *_N header words the previous tk_finalize left (workgroup 0 of that launch moves them into place at the same time)
+template <bool NEXT = false> __device__ __forceinline__ void predict_body(const Dev &d, int bid) {
+    const int g = bid * (int)blockDim.x + threadIdx.x;
+    // the three assignment vectors start out "unmatched" (the solver only writes matches)
+    if (g < d.T) { d.x1[g] = -1; d.x2[g] = -1; d.x3[g] = -1; }
+    if (g < IN(d, m)) { d.y1[g] = -1; d.y2[g] = -1; d.y3[g] = -1; }
+    const int r = g >> 3, i = g & 7;                     // 8 lanes per pool row
+    if (r >= d.hdr[NEXT ? H_NPOOL_N : H_NPOOL]) return;
+    const int s = d.pool_slot[r];
+    double mi, Pr[8];
+    load_row(d, s, i, mi, Pr);
+    if (i >= 6 && d.state[s] != BTS_TRACKED) mi = 0.0;   // D:529-532
+    kf8::predict(mi, Pr, i, d.hdr[NEXT ? H_ALLF32_N : H_ALLF32] != 0);       // a batch is float32 only if every row is (np.asarray)
+    store_row(d, s, i, mi, Pr);
+    double b[4];
+    kf8::tlbr(mi, false, b);
+    if (i < 4) d.pool_tlbr[r * 4 + i] = b[i];
+    if (i == 0) d.f32[s] = 0;
+}
+
 // one launch: the first workgroups build the frame's lists (two jobs of nch chunks each, the detection lists, the free slots),
 // the others convert the detection rows
 __host__ __device__ constexpr int front_jobs(int nch) { return 2 * nch + 2; }
@@ -415,7 +436,12 @@ __global__ __launch_bounds__(1024) void tk_cvt(Dev d) { cvt_body(d, (long)blockI
 // BTS_LISTS_AHEAD: the frame opens with the detection side alone -- workgroup 0 builds the detection lists, moves the sizes the
 // previous tk_finalize left in the *_N header words into place (what prep_pool / prep_unconfirmed wrote at this point) and
 // clears the duplicate-removal flags; the others convert the detection rows (unless tk_cvt does, CVT = false)
-template <bool GRID, bool CVT> __global__ __launch_bounds__(1024) void tk_front_dets(Dev d) {
+// pred_blocks > 0 (BTS_PREDICT_FRONT=1 at create; NOT yet measured): the Kalman predict of the pool -- whose list exists since the
+// previous frame's tk_finalize -- runs in the LAST pred_blocks workgroups of this launch instead of behind the pre-filter's
+// persistent workgroups, where it is the tail of the step's longest kernel.
+template <bool GRID, bool CVT> __global__ __launch_bounds__(1024) void tk_front_dets(Dev d, int pred_blocks) {
+    const int first_pred = (int)gridDim.x - pred_blocks;
+    if ((int)blockIdx.x >= first_pred) { predict_body<true>(d, (int)blockIdx.x - first_pred); return; }
     if (blockIdx.x != 0) { if constexpr (CVT) cvt_body(d, (long)blockIdx.x - 1); return; }
     prep_dets<GRID>(d);
     int32_t *h = d.hdr;
@@ -429,24 +455,6 @@ template <bool GRID, bool CVT> __global__ __launch_bounds__(1024) void tk_front_
     }
 }
 
-__device__ __forceinline__ void predict_body(const Dev &d, int bid) {
-    const int g = bid * 256 + threadIdx.x;
-    // the three assignment vectors start out "unmatched" (the solver only writes matches)
-    if (g < d.T) { d.x1[g] = -1; d.x2[g] = -1; d.x3[g] = -1; }
-    if (g < IN(d, m)) { d.y1[g] = -1; d.y2[g] = -1; d.y3[g] = -1; }
-    const int r = g >> 3, i = g & 7;                     // 8 lanes per pool row
-    if (r >= d.hdr[H_NPOOL]) return;
-    const int s = d.pool_slot[r];
-    double mi, Pr[8];
-    load_row(d, s, i, mi, Pr);
-    if (i >= 6 && d.state[s] != BTS_TRACKED) mi = 0.0;   // D:529-532
-    kf8::predict(mi, Pr, i, d.hdr[H_ALLF32] != 0);       // a batch is float32 only if every row is (np.asarray)
-    store_row(d, s, i, mi, Pr);
-    double b[4];
-    kf8::tlbr(mi, false, b);
-    if (i < 4) d.pool_tlbr[r * 4 + i] = b[i];
-    if (i == 0) d.f32[s] = 0;
-}
 __global__ __launch_bounds__(256) void tk_predict(Dev d) { predict_body(d, blockIdx.x); }
 
 // ---- cost tiles ----------------------------------------------------------------------------------------
@@ -710,8 +718,11 @@ __device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, 
         }
         if (MODE == 1 && d.c16) c = round_to_f16(c);      // cost_dtype BTS_F16: the value the threshold test and the solver see
         if (XO && STAGE == 1 && live && c > limit && c < iou_d) {
-            const long idx = w.e_cap - 1 - (long)atomicAdd(&w.hdr[7], 1);
-            if (idx >= 0) { w.e_row[idx] = i0 + r; w.e_col[idx] = q; w.e_cost[idx] = c; }
+            // (their own region behind the edge list, filled from the top down: an overflow is an error of the frame, raised
+            //  here -- the fast solver never sees a corrupted triple)
+            const long k = (long)atomicAdd(&w.hdr[7], 1), idx = w.e_cap + w.o_cap - 1 - k;
+            if (k < w.o_cap) { w.e_row[idx] = i0 + r; w.e_col[idx] = q; w.e_cost[idx] = c; }
+            else w.hdr[2] = 1;
         }
         bool edge = live && c <= limit;
         if (GATE && STAGE == 1 && edge) edge = motion_gate_open(d, d.pool_slot[i0 + r], det);
@@ -2346,7 +2357,12 @@ struct bts_tracker {
     bts_lap_work lap;      // stages 1 and 2 (sequential)
     bts_lap_work lap3;     // stage 3 runs next to stage 2: its own work area
     int lap_form = 0;             // BTS_LAP_FORM=row at create: the assignment kernel's round-2 row forms (bts_lap_enqueue)
+    int lap_helpers = -1;         // BTS_LAP_HELPERS at create: helper workgroups per assignment problem (< 0: automatic)
+    int filter_pw = 0;            // BTS_FILTER_PW at create: persistent GEMM workgroups of the pre-filter (0: FILTER_PW)
+    int tile_goal = 768;          // BTS_TILE_GOAL at create: workgroup count the stage-1 / duplicate tile heights aim at
+    char forms[256] = "";         // the switches in effect, as bts_tracker_forms reports them
     bool onepass = false;         // BTS_FILTER_ONEPASS=1 at create: the persistent one-pass pre-filter also for split-K-sized problems
+    bool predict_front = false;   // BTS_PREDICT_FRONT=1 at create (with BTS_LISTS_AHEAD): the predict workgroups in the frame's first launch
     bool predict_first = false;   // BTS_PREDICT_FIRST=1 at create: k_filter_i8<.., KF_FIRST> (experiment, see the kernel)
     // BTS_CVT_OVERLAP=1 at create (experiment, see tk_front): second set of detection shadows (frames alternate), a side
     // stream, "shadows of frame k are ready" / "frame k is done with its shadows" events per buffer
@@ -2478,10 +2494,10 @@ static int derive_sizes(const bts_tracker_config *cfg, Dev &d, int64_t *e_cap_ou
     BTS_REQUIRE(cfg->cost_dtype == BTS_F64 || cfg->cost_dtype == BTS_F16, "cost_dtype: BTS_F64 or BTS_F16");
     BTS_REQUIRE(!(cfg->cost_dtype == BTS_F16 && cfg->tie_mode), "cost_dtype BTS_F16 needs tie_mode 0 (the exact-tie replay prices pairs from the boxes)");
     // BTS_EDGES_SORTED=1 (read when the tracker is created / sized): stage-1 edges in the sorted / list form (tk_edges_sorted)
-    d.sorted = (getenv("BTS_EDGES_SORTED") != nullptr && d.filter && d.Df == 0 && !cfg->motion_gate && !cfg->record_costs &&
+    d.sorted = (bts_form_get("BTS_EDGES_SORTED") != nullptr && d.filter && d.Df == 0 && !cfg->motion_gate && !cfg->record_costs &&
                 cfg->match_thresh < 1.0 && !cfg->use_graph) ? 1 : 0;
     // BTS_LISTS_AHEAD=1 (read at create): the next frame's pool / unconfirmed / free lists are built by tk_finalize
-    d.ahead = (getenv("BTS_LISTS_AHEAD") != nullptr && !cfg->use_graph) ? 1 : 0;
+    d.ahead = (bts_form_get("BTS_LISTS_AHEAD") != nullptr && !cfg->use_graph) ? 1 : 0;
     d.sf32 = cfg->kalman_dtype == BTS_F32 ? 1 : 0;
     d.c16 = cfg->cost_dtype == BTS_F16 ? 1 : 0;
     if (cfg->tie_mode) {
@@ -2518,13 +2534,14 @@ int bts_tracker_memory_bytes(const bts_tracker_config *cfg, uint64_t *out_bytes)
     int64_t e_cap = 0;
     const int rc = derive_sizes(cfg, d, &e_cap);
     if (rc) { delete t; return rc; }
-    t->cvt_overlap = getenv("BTS_CVT_OVERLAP") != nullptr && d.filter && !cfg->use_graph;
+    t->cvt_overlap = bts_form_get("BTS_CVT_OVERLAP") != nullptr && d.filter && !cfg->use_graph;
     size_t off = 0;
     tracker_layout(t, nullptr, off);
-    off += 2 * bts_lap_work_bytes(d.T, d.Mx, e_cap);
+    const int64_t o_cap = (cfg->tie_mode && d.Df > 0) ? e_cap : 0;      // overrides of the exact-tie step (tk_edges_xo): their own region
+    off += bts_lap_work_bytes(d.T, d.Mx, e_cap, o_cap) + bts_lap_work_bytes(d.T, d.Mx, e_cap);
     if (cfg->tie_mode) {
         size_t nd = 0, ni = 0;
-        bts_lap_exact_sizes(d.T, d.Mx, e_cap, &nd, &ni);
+        bts_lap_exact_sizes(d.T, d.Mx, e_cap + o_cap, &nd, &ni);
         off += 2 * (bts_align(nd * sizeof(double)) + bts_align(ni * sizeof(int32_t)));
     }
     *out_bytes = (uint64_t)off;
@@ -2558,31 +2575,44 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
     d.gate_thr = 9.4877;       // chi2inv95[4], D:139-149
     {   // list jobs over tables beyond ~6000 tracks are split into chunks of ~2048 entries, one workgroup each
         // (measured: 4096 tracks slightly better unsplit, 10 000 +3.5 %, 16 384 +6.5 %); BTS_CHUNK_ROWS forces a chunk size
-        const char *e = getenv("BTS_CHUNK_ROWS");
+        const char *e = bts_form_get("BTS_CHUNK_ROWS");
+        const bool forced = e != nullptr;
         const int rows = e && atoi(e) > 0 ? atoi(e) : 2048;
-        d.nch = (!e && d.T <= 6144) ? 1 : bts_cdiv(d.T, rows);
+        d.nch = (!forced && d.T <= 6144) ? 1 : bts_cdiv(d.T, rows);
         d.nch = d.nch < 1 ? 1 : d.nch > 8 ? 8 : d.nch;
     }
-    d.use_grid = getenv("BTS_EDGES_GRID") != nullptr ? 1 : 0;
-    t->predict_first = getenv("BTS_PREDICT_FIRST") != nullptr;
-    t->cvt_overlap = getenv("BTS_CVT_OVERLAP") != nullptr && d.filter && !cfg->use_graph;
+    d.use_grid = bts_form_get("BTS_EDGES_GRID") != nullptr ? 1 : 0;
+    t->predict_first = bts_form_get("BTS_PREDICT_FIRST") != nullptr;
+    t->predict_front = bts_form_get("BTS_PREDICT_FRONT") != nullptr && d.ahead;
+    t->cvt_overlap = bts_form_get("BTS_CVT_OVERLAP") != nullptr && d.filter && !cfg->use_graph;
     t->lap_form = bts_lap_form_from_env();
-    t->onepass = getenv("BTS_FILTER_ONEPASS") != nullptr;
+    { const char *e = bts_form_get("BTS_LAP_HELPERS"); t->lap_helpers = e && atoi(e) >= 0 && atoi(e) <= 255 ? atoi(e) : -1; }
+    { const char *e = bts_form_get("BTS_FILTER_PW"); const int v = e ? atoi(e) : 0; t->filter_pw = v > 0 && v <= 2048 ? v : 0; }
+    { const char *e = bts_form_get("BTS_TILE_GOAL"); const int v = e ? atoi(e) : 0; t->tile_goal = v >= 64 && v <= 16384 ? v : 768; }
+    t->onepass = bts_form_get("BTS_FILTER_ONEPASS") != nullptr;
     d.gate_sim = 1.0f - d.app;
     {   // first prefix checkpoint of the pre-filter: from the gate, or BTS_I8_FIRST16 (3 .. 12; 5 = the round-2 set)
-        const char *e = getenv("BTS_I8_FIRST16");
+        const char *e = bts_form_get("BTS_I8_FIRST16");
         const int f = e ? atoi(e) : 0;
         d.chk_first = (f >= 3 && f <= 12) ? f : feat::i8_first_checkpoint(d.app);
     }
+    // the forms in effect (a requested form that the configuration rules out -- the sorted edges with a motion gate, say --
+    // does not appear), for bts_tracker_forms
+    snprintf(t->forms, sizeof(t->forms), "edges=%s,lists_ahead=%d,cvt_overlap=%d,predict_front=%d,predict_first=%d,lap_form=%s,lap_helpers=%d,list_chunks=%d,"
+             "filter_pw=%d,filter_first16=%d,filter_onepass=%d,tile_goal=%d",
+             d.sorted ? "sorted" : (d.use_grid && d.filter) ? "grid" : "tiles", d.ahead, t->cvt_overlap ? 1 : 0, t->predict_front ? 1 : 0, t->predict_first ? 1 : 0,
+             t->lap_form == 1 ? "row" : "col", t->lap_helpers, d.nch, t->filter_pw > 0 ? t->filter_pw : FILTER_PW, d.chk_first,
+             t->onepass ? 1 : 0, t->tile_goal);
     size_t off = 0;
     tracker_layout(t, nullptr, off);
+    const int64_t o_cap = (cfg->tie_mode && d.Df > 0) ? e_cap : 0;      // overrides of the exact-tie step (tk_edges_xo): their own region
     const size_t lap_off = off;
-    off += bts_lap_work_bytes(d.T, d.Mx, e_cap);
+    off += bts_lap_work_bytes(d.T, d.Mx, e_cap, o_cap);
     const size_t lap3_off = off;
     off += bts_lap_work_bytes(d.T, d.Mx, e_cap);
     size_t xk_off[2][2] = {{0, 0}, {0, 0}}, xk_nd = 0, xk_ni = 0;
     if (cfg->tie_mode) {
-        bts_lap_exact_sizes(d.T, d.Mx, e_cap, &xk_nd, &xk_ni);
+        bts_lap_exact_sizes(d.T, d.Mx, e_cap + o_cap, &xk_nd, &xk_ni);
         for (int k = 0; k < 2; ++k) {
             xk_off[k][0] = off; off += bts_align(xk_nd * sizeof(double));
             xk_off[k][1] = off; off += bts_align(xk_ni * sizeof(int32_t));
@@ -2597,7 +2627,7 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
     }
     off = 0;
     tracker_layout(t, t->block, off);
-    bts_lap_work_carve(&t->lap, t->block + lap_off, d.T, d.Mx, e_cap);
+    bts_lap_work_carve(&t->lap, t->block + lap_off, d.T, d.Mx, e_cap, o_cap);
     bts_lap_work_carve(&t->lap3, t->block + lap3_off, d.T, d.Mx, e_cap);
     for (int k = 0; k < 2 && cfg->tie_mode; ++k) {
         t->xk[k].dbl = (double *)(t->block + xk_off[k][0]); t->xk[k].ndbl = xk_nd;
@@ -2652,6 +2682,22 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
     if (rc != BTS_OK) { bts_tracker_destroy(t); return rc; }
     *out = t;
     return BTS_OK;
+}
+
+int bts_tracker_create_forms(bts_context *ctx, const bts_tracker_config *cfg, const char *forms, bts_tracker **out) {
+    bts_forms_scope scope(forms);      // (thread-local: the lookups of this create call see `forms` before the environment)
+    return bts_tracker_create(ctx, cfg, out);
+}
+
+int bts_tracker_memory_bytes_forms(const bts_tracker_config *cfg, const char *forms, uint64_t *out_bytes) {
+    bts_forms_scope scope(forms);
+    return bts_tracker_memory_bytes(cfg, out_bytes);
+}
+
+int bts_tracker_forms(const bts_tracker *t, char *buf, int capacity) {
+    BTS_REQUIRE(t && buf && capacity > 0, "tracker, buf, capacity");
+    snprintf(buf, (size_t)capacity, "%s", t->forms);
+    return (int)strlen(t->forms);
 }
 
 int bts_tracker_profile_enable(bts_tracker *t, int segment, int capacity) {
@@ -2746,12 +2792,16 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
     const dim3 tile_grid(ntile);               // persistent tiles: the kernels walk the live extents
     // stage-1 tiles are R x 256 with R chosen for ~TILE_GOAL workgroups: a tile's cost is its chains of dependent loads
     // plus a serial part per row, so small problems want many small tiles and big ones few tall tiles
-    constexpr int TILE_GOAL = 768;            // (swept on c2 / c3 / target: 256 ... 6144; heights up to 256 rows: 10000 x 2000 runs
-                                              //  128-row tiles (632 of them: one resident round), 16384 x 4096 256-row tiles)
+    const int TILE_GOAL = t->tile_goal;       // 768 (swept on c2 / c3 / target: 256 ... 6144; heights up to 256 rows: 10000 x 2000 runs
+                                              //  128-row tiles (632 of them: one resident round), 16384 x 4096 256-row tiles); BTS_TILE_GOAL
     int trows = 2;
     while (trows < 256 && bts_cdiv(mc, CT_COLS) * bts_cdiv(T, trows) > TILE_GOAL) trows *= 2;
     const int ntile1 = bts_cdiv(mc, CT_COLS) * bts_cdiv(T, trows);
+    // BTS_PREDICT_FRONT (needs BTS_LISTS_AHEAD): the predict workgroups ride in the frame's first launch (1024 threads each), none
+    // in the pre-filter's
+    const int pred_front = (t->predict_front && d.ahead) ? bts_cdiv(T * 8 > M ? T * 8 : M, 1024) : 0;
     const int kf_blocks = bts_cdiv(T * 8 > M ? T * 8 : M, 256);   // 8 lanes per track
+    const int kf_pre = pred_front ? 0 : kf_blocks;                 // predict workgroups in the pre-filter's / tk_predict's launch
     bts_lap_work lap[3] = {t->lap, t->lap, t->lap3};
     for (int k = 0; k < 3; ++k) lap[k].hdr = d.lap_hdr + BTS_LAP_HDR_INTS * k;
     int rc;
@@ -2775,7 +2825,7 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
         LAUNCH_ON(t->side, tk_cvt, dim3(bts_cdiv(mc, 4)), dim3(1024));
         BTS_HIP(hipEventRecord(t->ev_cvt[ovp], t->side));
         if (d.ahead) {
-            if (want_grid) { LAUNCH((tk_front_dets<true, false>), dim3(1), dim3(1024)); } else { LAUNCH((tk_front_dets<false, false>), dim3(1), dim3(1024)); }
+            if (want_grid) { LAUNCH((tk_front_dets<true, false>), dim3(1 + pred_front), dim3(1024), pred_front); } else { LAUNCH((tk_front_dets<false, false>), dim3(1 + pred_front), dim3(1024), pred_front); }
         } else {
             const dim3 fgrid(front_jobs(d.nch > 1 ? d.nch : 1));
             if (want_grid) {
@@ -2785,8 +2835,8 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
         }
         BTS_HIP(hipStreamWaitEvent(s, t->ev_cvt[ovp], 0));
     } else if (d.ahead) {
-        const dim3 fgrid(1 + (d.filter ? bts_cdiv(mc, 4) : 0));
-        if (want_grid) { LAUNCH((tk_front_dets<true, true>), fgrid, dim3(1024)); } else { LAUNCH((tk_front_dets<false, true>), fgrid, dim3(1024)); }
+        const dim3 fgrid(1 + (d.filter ? bts_cdiv(mc, 4) : 0) + pred_front);
+        if (want_grid) { LAUNCH((tk_front_dets<true, true>), fgrid, dim3(1024), pred_front); } else { LAUNCH((tk_front_dets<false, true>), fgrid, dim3(1024), pred_front); }
     } else {
         const dim3 fgrid(front_jobs(d.nch > 1 ? d.nch : 1) + (d.filter ? bts_cdiv(mc, 4) : 0));
         if (want_grid) {
@@ -2816,14 +2866,13 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
         // one-pass form (candidate bitmap, prefix exits): up to FILTER_PW persistent workgroups walk the tiles;
         // small problems add split-K partial products instead (k_filter_splitk)
         // (BTS_FILTER_PW: sweep knob for the number of persistent GEMM workgroups, host side only)
-        static const int pw_forced = [] { const char *e = getenv("BTS_FILTER_PW"); return e ? atoi(e) : 0; }();
-        const int pw = pw_forced > 0 ? pw_forced : FILTER_PW;
+        const int pw = t->filter_pw > 0 ? t->filter_pw : FILTER_PW;
         const int gemm_blocks = ftiles < pw ? ftiles : pw;
-        if (!accum && d.sorted && t->predict_first) { LAUNCH((k_filter_i8<false, 0, true, true>), dim3(gemm_blocks + kf_blocks), dim3(256), mc, ftiles, gemm_blocks); }
-        else if (!accum && d.sorted) { LAUNCH((k_filter_i8<false, 0, false, true>), dim3(gemm_blocks + kf_blocks), dim3(256), mc, ftiles, gemm_blocks); }
-        else if (!accum && t->predict_first) { LAUNCH((k_filter_i8<false, 0, true>), dim3(gemm_blocks + kf_blocks), dim3(256), mc, ftiles, gemm_blocks); }
-        else if (!accum) { LAUNCH(k_filter_i8<false>, dim3(gemm_blocks + kf_blocks), dim3(256), mc, ftiles, gemm_blocks); }
-        else { LAUNCH(k_filter_splitk<false>, dim3(ftiles * split + kf_blocks), dim3(256), mc, ftiles, split); }
+        if (!accum && d.sorted && t->predict_first) { LAUNCH((k_filter_i8<false, 0, true, true>), dim3(gemm_blocks + kf_pre), dim3(256), mc, ftiles, gemm_blocks); }
+        else if (!accum && d.sorted) { LAUNCH((k_filter_i8<false, 0, false, true>), dim3(gemm_blocks + kf_pre), dim3(256), mc, ftiles, gemm_blocks); }
+        else if (!accum && t->predict_first) { LAUNCH((k_filter_i8<false, 0, true>), dim3(gemm_blocks + kf_pre), dim3(256), mc, ftiles, gemm_blocks); }
+        else if (!accum) { LAUNCH(k_filter_i8<false>, dim3(gemm_blocks + kf_pre), dim3(256), mc, ftiles, gemm_blocks); }
+        else { LAUNCH(k_filter_splitk<false>, dim3(ftiles * split + kf_pre), dim3(256), mc, ftiles, split); }
         seg_end(BTS_SEG_K_FILTER);
         if (d.Df) {
             const int fsplit = split < bts_cdiv(d.Df, DBK) ? split : bts_cdiv(d.Df, DBK);
@@ -2832,7 +2881,7 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
         }
     } else {
         seg_begin(BTS_SEG_PREDICT);
-        LAUNCH(tk_predict, dim3(kf_blocks), dim3(256));
+        if (kf_pre) { LAUNCH(tk_predict, dim3(kf_pre), dim3(256)); }
         seg_end(BTS_SEG_PREDICT);
     }
     if (dense) {
@@ -2924,7 +2973,7 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
         hipEvent_t ev2[2];
         const bool want = prof_room && t->prof_seg == BTS_SEG_K_LAP;
         if (want) { ev2[0] = t->prof_ev[2 * t->prof_n]; ev2[1] = t->prof_ev[2 * t->prof_n + 1]; }
-        rc = bts_lap_enqueue(&prob[0], 1, s, want ? ev2 : nullptr, t->lap_form);
+        rc = bts_lap_enqueue(&prob[0], 1, s, want ? ev2 : nullptr, t->lap_form, t->lap_helpers);
         if (rc) return rc;
         if (want) t->prof_n++;
     }
@@ -2961,7 +3010,7 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
     // ---- second association (remaining tracked rows x low-score detections) and the unconfirmed
     //      tracks (x leftover high-score detections): independent problems, shared launches
     seg_begin(BTS_SEG_STAGE2);
-    rc = bts_lap_enqueue(&prob[1], 2, s, nullptr, t->lap_form);
+    rc = bts_lap_enqueue(&prob[1], 2, s, nullptr, t->lap_form, t->lap_helpers);
     if (rc) return rc;
     if (t->cfg.tie_mode) {
         rc = bts_lap_exact_enqueue(&prob[1], &xs[1], 2, s);

@@ -529,7 +529,10 @@ class DeviceTracker:
     """Thin owner of a `bts_tracker` handle."""
 
     def __init__(self, max_tracks: int, max_dets: int, feat_dim: int, face_dim: int = 0, frame_rate: int = 30,
-                 record_costs: bool = False, device: Optional[int] = None, context: Optional[_lib.Context] = None, **thresholds):
+                 record_costs: bool = False, device: Optional[int] = None, context: Optional[_lib.Context] = None,
+                 forms=None, **thresholds):
+        """`forms`: the execution forms of this tracker (bts_tracker_create_forms) -- "KEY=VALUE,..." or a dict; None = the process
+        environment / the defaults.  Forms never change a result; `tune.select_forms` picks the fastest set on the caller's frames."""
         lib = _lib.load(require_gpu=True)
         self.ctx = context or _lib.default_context(device)
         cfg = _lib.TrackerConfig()
@@ -543,7 +546,13 @@ class DeviceTracker:
             setattr(cfg, k, v)
         self.cfg = cfg
         h = ctypes.c_void_p()
-        _lib.check(lib.bts_tracker_create(self.ctx.handle, ctypes.byref(cfg), ctypes.byref(h)))
+        if isinstance(forms, dict):
+            forms = ",".join("%s=%s" % (k, v) for k, v in forms.items())
+        if forms:
+            _lib.check(lib.bts_tracker_create_forms(self.ctx.handle, ctypes.byref(cfg), str(forms).encode(), ctypes.byref(h)))
+        else:
+            _lib.check(lib.bts_tracker_create(self.ctx.handle, ctypes.byref(cfg), ctypes.byref(h)))
+        self.forms_requested = str(forms) if forms else ""
         self.handle = h
         self._lib = lib
         t = max_tracks
@@ -555,6 +564,12 @@ class DeviceTracker:
 
     def reset(self):
         _lib.check(self._lib.bts_tracker_reset(self.handle, _lib.current_stream()))
+
+    def forms(self) -> dict:
+        """The execution forms in effect (bts_tracker_forms), e.g. {'edges': 'tiles', 'lists_ahead': '0', 'lap_form': 'col', ...}."""
+        buf = ctypes.create_string_buffer(512)
+        _lib.check(self._lib.bts_tracker_forms(self.handle, buf, 512))
+        return dict(kv.split("=", 1) for kv in buf.value.decode().split(",") if "=" in kv)
 
     def step(self, boxes, scores, feats, face_feats=None):
         """boxes int32 [M,4] (tlbr pixels), scores float32 [M], feats float32 [M,D] -- CUDA tensors.
@@ -772,12 +787,16 @@ class BoTSORT:
     def __init__(self, object_detection_model=None, body_feature_extractor_model=None,
                  face_feature_extractor_model=None, frame_rate: int = 30, *, max_tracks: int = 4096,
                  max_dets: int = 1024, feat_dim: Optional[int] = None, face_dim: Optional[int] = None,
-                 record_costs: bool = False, device: Optional[int] = None, lazy_lists: bool = True,
+                 record_costs: bool = False, device: Optional[int] = None, lazy_lists: Optional[bool] = None,
                  keep_removed_state: bool = True, **tracker_options):
         """`tracker_options`: further `bts_tracker_config` fields by name (`motion_gate=1`, `appearance_mode=1`, ...).
-        `lazy_lists=False` hands out plain Python lists with every mirror built (round-2 behaviour: O(tracks) Python per
-        frame); `keep_removed_state=False` skips reading a removed track's covariance / feature rows off the device."""
-        self.lazy_lists, self.keep_removed_state = bool(lazy_lists), bool(keep_removed_state)
+        `lazy_lists`: None (default) = the drop-in call `update(image)` hands out plain Python `list`s like the reference (a
+        caller may append / sort / `+=` / serialise them), while `update_arrays` -- this package's own entry point --
+        hands out lazy TrackLists (a Sequence whose STrack mirrors are built on access: no per-track Python per frame);
+        True / False force one form for both.  `keep_removed_state=False` skips reading a removed track's covariance /
+        feature rows off the device."""
+        self.lazy_lists, self.keep_removed_state = lazy_lists, bool(keep_removed_state)
+        self._plain_call = False        # set by update(image) around its update_arrays call
         self._epoch, self._snap = 0, None
         self._removed_live = set()      # ids appended to removed_stracks that are still on a list (Q6: for one more frame)
         self._repeats = []              # (id, mirror) of expired lost tracks the reference appends a second time this frame
@@ -899,7 +918,7 @@ class BoTSORT:
                     self._removed_live.difference_update(back.tolist())
         if bodies is not None:
             self._attach_bodies(snap, bodies)
-        if not self.lazy_lists:
+        if self.lazy_lists is False or (self.lazy_lists is None and self._plain_call):
             self.tracked_stracks, self.lost_stracks = list(self.tracked_stracks), list(self.lost_stracks)
         return self.tracked_stracks
 
@@ -1002,7 +1021,11 @@ class BoTSORT:
                                                target_features=np.zeros((0, self.face_dim), dtype=np.float32))
         if self.face_dim and ffeats is None:
             ffeats = np.zeros((m, self.face_dim), dtype=np.float32)
-        return self.update_arrays(arr, scores, np.asarray(feats, dtype=np.float32), ffeats, bodies=boxes)
+        self._plain_call = True          # (the reference's signature returns the reference's type: plain lists)
+        try:
+            return self.update_arrays(arr, scores, np.asarray(feats, dtype=np.float32), ffeats, bodies=boxes)
+        finally:
+            self._plain_call = False
 
 
 # list helpers with the reference's semantics (D:1642-1680), on host mirrors

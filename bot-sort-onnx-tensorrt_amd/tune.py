@@ -1,0 +1,280 @@
+"""Selection of a tracker's EXECUTION FORMS on the device it runs on (include/botsort_hip.h, bts_tracker_create_forms).
+
+Several kernels / launch structures of a step exist in more than one form with bit-identical results; which is faster
+depends on the table size, the scene and the part.  `select_forms` does what a find-mode does for a convolution: it steps
+the caller's own frames through one tracker per candidate and keeps a candidate only if
+
+  * every checked frame's RESULT is identical to the default forms' -- assignment vectors of the three stages, both track
+    lists in order (ids, states, frame counters, detection indices), Kalman means, boxes and scores, bit for bit -- and the
+    device raised no error, and
+  * it is faster than the default forms by more than `margin`.
+
+The winners of the groups are combined; the combination is measured and verified like any candidate and kept only if it
+beats the best single change.  Nothing here is a fallback: every candidate is the HIP library (no CPU path), and the
+default forms are what `DeviceTracker()` uses when no selection was made.
+
+`run_isolated` does the same in a child process (`python tune.py ...`), so that a candidate that takes the process down
+-- the forms built while no GPU was available have never met one -- costs the candidate, not the caller: the parent reads
+the child's progress lines, blames the candidate that was running, and restarts the child without it.  bench.py uses that
+(`--forms auto`) in its untimed set-up, next to the generation of its frames.
+
+Reference seam: the forms live entirely below `BoTSORT.update` (D:1414-1639); the reference has no counterpart.
+"""
+from __future__ import annotations
+
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import time
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+# (group, name, forms): groups are alternatives of ONE switch -- at most one member of a group is taken
+CANDIDATES: Tuple[Tuple[str, str, Dict[str, str]], ...] = (
+    ("lists_ahead", "lists_ahead", {"BTS_LISTS_AHEAD": "1"}),
+    ("lists_ahead", "lists_ahead_predict_front", {"BTS_LISTS_AHEAD": "1", "BTS_PREDICT_FRONT": "1"}),
+    ("cvt_overlap", "cvt_overlap", {"BTS_CVT_OVERLAP": "1"}),
+    ("edges", "edges_sorted", {"BTS_EDGES_SORTED": "1"}),
+    ("edges", "edges_grid", {"BTS_EDGES_GRID": "1"}),
+    ("predict_first", "predict_first", {"BTS_PREDICT_FIRST": "1"}),
+    ("lap_form", "lap_row", {"BTS_LAP_FORM": "row"}),
+    ("lap_helpers", "lap_helpers_31", {"BTS_LAP_HELPERS": "31"}),
+    ("lap_helpers", "lap_helpers_127", {"BTS_LAP_HELPERS": "127"}),
+    ("chunks", "lists_unsplit", {"BTS_CHUNK_ROWS": "1000000"}),
+    ("chunks", "lists_chunks_4096", {"BTS_CHUNK_ROWS": "4096"}),
+    ("chunks", "lists_chunks_1024", {"BTS_CHUNK_ROWS": "1024"}),
+    ("tile_goal", "tile_goal_384", {"BTS_TILE_GOAL": "384"}),
+    ("tile_goal", "tile_goal_1536", {"BTS_TILE_GOAL": "1536"}),
+)
+
+
+def forms_text(forms: Dict[str, str]) -> str:
+    return ",".join("%s=%s" % kv for kv in sorted(forms.items()))
+
+
+def _digest(trk) -> str:
+    """Everything a caller can observe of the frame just stepped, hashed (host synchronisation: verification frames only)."""
+    h = hashlib.blake2b(digest_size=16)
+    for k in (1, 2, 3):
+        r = trk.stage_result(k)
+        h.update(r["x"].tobytes())
+        h.update(r["y"].tobytes())
+    for which in (0, 1):
+        t = trk.export(which)
+        for key in ("track_id", "state", "is_activated", "frame_id", "start_frame", "tracklet_len", "det_index", "mean", "tlbr", "score"):
+            h.update(t[key].tobytes())
+    return h.hexdigest()
+
+
+def measure(make_tracker: Callable[[str], object], frames: Sequence[tuple], forms: str, warm: int, verify: int,
+            clone: Callable = None, sync: Callable = None) -> dict:
+    """One tracker with `forms` through `frames`: frames [0, warm) untimed (the first `verify` of them digested), the rest
+    timed back to back without any host synchronisation in between, the last frame digested again.  Frames are (boxes, scores,
+    feats[, face_feats]) device tensors; the feature rows are CLONED per run (the step renormalises used rows in place, Q8)."""
+    import torch
+    clone = clone or (lambda fr: tuple(x.clone() if i >= 2 and x is not None else x for i, x in enumerate(fr)))
+    sync = sync or torch.cuda.synchronize
+    mine = [clone(fr) for fr in frames]
+    trk = make_tracker(forms)
+    try:
+        if hasattr(trk, "inputs_resident"):
+            trk.inputs_resident(True)        # (the frames are complete in device memory before the loop that steps on them)
+        digests = []
+        for k in range(warm):
+            trk.step(*mine[k])
+            if k < verify:
+                digests.append(_digest(trk))
+        sync()
+        t0 = time.perf_counter()
+        for fr in mine[warm:]:
+            trk.step(*fr)
+        sync()
+        t1 = time.perf_counter()
+        digests.append(_digest(trk))
+        errors = int(trk.counts()["errors"])
+        effective = trk.forms() if hasattr(trk, "forms") else {}
+    finally:
+        trk.close()
+    n = max(1, len(mine) - warm)
+    return {"us_per_step": 1e6 * (t1 - t0) / n, "digests": digests, "errors": errors, "effective": effective, "timed_steps": n}
+
+
+def select_forms(make_tracker: Callable[[str], object], frames: Sequence[tuple], candidates=CANDIDATES, warm: int = 6, verify: int = 4,
+                 margin: float = 0.01, skip: Sequence[str] = (), report: Callable[[dict], None] = None, repeats: int = 2,
+                 clone: Callable = None, sync: Callable = None) -> dict:
+    """-> {"forms": "KEY=VALUE,..." ("" = the defaults), "default_us", "chosen_us", "table": [...]}.  `report` receives a
+    progress record before and after every candidate (run_isolated's crash attribution)."""
+    report = report or (lambda rec: None)
+    only = [n for n in os.environ.get("BTS_TUNE_ONLY", "").split(",") if n]      # (tests: a subset of the candidates by name)
+    if only:
+        candidates = [c for c in candidates if c[1] in only]
+    assert len(frames) > warm >= verify >= 1, "need more frames than warm-up frames"
+
+    def run(name, forms):
+        report({"event": "begin", "name": name})
+        best = None
+        for _ in range(max(1, repeats)):
+            m = measure(make_tracker, frames, forms_text(forms), warm, verify, clone, sync)
+            if best is None or m["us_per_step"] < best["us_per_step"]:
+                best = m
+        best.update(name=name, forms=forms_text(forms))
+        return best
+
+    ref = run("default", {})
+    ref["identical"], ref["eligible"] = True, True
+    report(dict(event="end", **{k: v for k, v in ref.items() if k != "digests"}))
+    table = [ref]
+    if ref["errors"]:
+        return {"forms": "", "default_us": ref["us_per_step"], "chosen_us": ref["us_per_step"], "table": _strip(table),
+                "note": "the default forms raised a device error on these frames: nothing selected"}
+
+    def judge(m):
+        m["identical"] = m["digests"] == ref["digests"]
+        m["eligible"] = bool(m["identical"] and m["errors"] == 0)
+        m["speedup"] = ref["us_per_step"] / m["us_per_step"] if m["us_per_step"] > 0 else 0.0
+        report(dict(event="end", **{k: v for k, v in m.items() if k != "digests"}))
+        table.append(m)
+        return m
+
+    winners: Dict[str, dict] = {}
+    for group, name, forms in candidates:
+        if name in skip:
+            table.append({"name": name, "forms": forms_text(forms), "skipped": True, "eligible": False})
+            continue
+        try:
+            m = judge(run(name, forms))
+        except Exception as e:           # (a form this library / configuration does not have: reported, never selected)
+            table.append({"name": name, "forms": forms_text(forms), "error": "%s: %s" % (type(e).__name__, str(e)[:200]), "eligible": False})
+            report({"event": "end", "name": name, "error": str(e)[:200]})
+            continue
+        m["group"] = group
+        if m["eligible"] and m["speedup"] > 1.0 + margin and (group not in winners or m["us_per_step"] < winners[group]["us_per_step"]):
+            winners[group] = m
+    # combine greedily: the best single change first, then the other winners by gain -- each kept only if the combination is
+    # again identical, error-free and faster than what is held so far
+    chosen = ref
+    order = sorted(winners.values(), key=lambda m: m["us_per_step"])
+    held: Dict[str, str] = {}
+    names: List[str] = []
+    for m in order:
+        forms = dict(held)
+        forms.update(dict(kv.split("=", 1) for kv in m["forms"].split(",")))
+        if not names:
+            held, names, chosen = forms, [m["name"]], m
+            continue
+        name = "+".join(names + [m["name"]])
+        if name in skip:
+            continue
+        try:
+            combo = judge(run(name, forms))
+        except Exception as e:
+            table.append({"name": name, "forms": forms_text(forms), "error": "%s: %s" % (type(e).__name__, str(e)[:200]), "eligible": False})
+            continue
+        if combo["eligible"] and combo["us_per_step"] < chosen["us_per_step"] * (1.0 - margin / 2):
+            held, chosen = forms, combo
+            names.append(m["name"])
+    return {"forms": chosen["forms"], "chosen": chosen["name"], "default_us": ref["us_per_step"], "chosen_us": chosen["us_per_step"],
+            "table": _strip(table), "frames": len(frames), "warm": warm, "verified_frames": verify + 1, "margin": margin,
+            "rule": "a candidate is eligible only if the digests of its verified frames (assignment vectors of the three stages, both "
+                    "lists in order, Kalman means, boxes, scores) equal the default forms' and the device raised no error"}
+
+
+def _strip(table):
+    return [{k: (round(v, 2) if isinstance(v, float) else v) for k, v in m.items() if k != "digests"} for m in table]
+
+
+# ------------------------------------------------------------------------------------------- isolated (child process)
+def run_isolated(workload: str, seed: int, device: int = 0, n_frames: int = 36, tracker_args: Optional[dict] = None,
+                 timeout_s: float = 600.0, max_restarts: int = 3, python: str = None, extra_env: Optional[dict] = None) -> dict:
+    """select_forms on `n_frames` of the seeded synthetic workload in a child process; a candidate that kills the child (or
+    hangs it past `timeout_s`) is skipped on the restart.  Returns select_forms' dictionary plus "crashed": [names]."""
+    crashed: List[str] = []
+    last = None
+    deadline = time.time() + timeout_s
+    for _ in range(max_restarts + 1):
+        cmd = [python or sys.executable, os.path.abspath(__file__), "--workload", workload, "--seed", str(seed), "--device", str(device),
+               "--frames", str(n_frames), "--tracker-args", json.dumps(tracker_args or {})] + (["--skip", ",".join(crashed)] if crashed else [])
+        env = dict(os.environ, **(extra_env or {}))
+        running, result, lines = None, None, []
+        try:
+            p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+            try:
+                out, err = p.communicate(timeout=max(5.0, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                out, err = p.communicate()
+                err = (err or "") + "\n[timeout]"
+            for ln in out.splitlines():
+                if not ln.startswith("{"):
+                    continue
+                try:
+                    rec = json.loads(ln)
+                except ValueError:
+                    continue
+                lines.append(rec)
+                if rec.get("event") == "begin":
+                    running = rec["name"]
+                elif rec.get("event") == "end":
+                    running = None
+                elif rec.get("event") == "result":
+                    result = rec["result"]
+            last = {"rc": p.returncode, "stderr_tail": (err or "")[-400:]}
+        except Exception as e:
+            last = {"rc": None, "stderr_tail": "%s: %s" % (type(e).__name__, e)}
+        if result is not None:
+            result["crashed"] = crashed
+            return result
+        if running is None or running == "default" or running in crashed or time.time() >= deadline:
+            break                          # (nothing to blame, or the default forms themselves failed: no selection)
+        crashed.append(running)
+    return {"forms": "", "crashed": crashed, "note": "form selection did not complete: the defaults are used", "child": last}
+
+
+def _main():
+    import argparse
+    import importlib
+    ap = argparse.ArgumentParser(description="execution-form selection on a synthetic workload (child of tune.run_isolated / bench.py)")
+    ap.add_argument("--workload", default="target")
+    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--frames", type=int, default=36)
+    ap.add_argument("--warm", type=int, default=6)
+    ap.add_argument("--verify", type=int, default=4)
+    ap.add_argument("--skip", default="")
+    ap.add_argument("--tracker-args", default="{}")
+    a = ap.parse_args()
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if repo not in sys.path:
+        sys.path.insert(0, repo)
+    import torch
+    assert torch.cuda.is_available(), "form selection runs on the device it selects for"
+    torch.cuda.set_device(a.device % max(1, torch.cuda.device_count()))
+    pkg = importlib.import_module("bot-sort-onnx-tensorrt_amd")
+    K, M, D = pkg.synth.workload_dims(a.workload)
+    st = pkg.synth.make_workload(a.workload, seed=a.seed)
+    frames = []
+    for _ in range(a.frames):
+        fr = st.next()
+        frames.append((torch.from_numpy(fr.boxes).cuda(), torch.from_numpy(fr.scores).cuda(), torch.from_numpy(fr.feats).cuda()))
+    targs = json.loads(a.tracker_args)
+    targs.setdefault("max_tracks", K + max(64, K // 8))
+    targs.setdefault("max_dets", max(K, M))
+    targs.setdefault("feat_dim", D)
+
+    def make(forms):
+        return pkg.DeviceTracker(device=torch.cuda.current_device(), forms=forms or None, **targs)
+
+    def report(rec):
+        print(json.dumps(rec), flush=True)
+        if rec.get("event") == "begin" and rec.get("name") == os.environ.get("BTS_TUNE_CRASH_AT"):
+            os._exit(9)                  # (tests/test_tune_host.py: a candidate that takes the process down)
+
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        res = select_forms(make, frames, warm=a.warm, verify=a.verify, skip=[s for s in a.skip.split(",") if s], report=report)
+    print(json.dumps({"event": "result", "result": res}), flush=True)
+
+
+if __name__ == "__main__":
+    _main()

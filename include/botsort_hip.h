@@ -260,6 +260,29 @@ int bts_tracker_default_config(bts_tracker_config *cfg);
 int bts_tracker_memory_bytes(const bts_tracker_config *cfg, uint64_t *out_bytes);
 
 int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_tracker **out);
+
+/* EXECUTION FORMS.  Several kernels / launch structures of a step exist in more than one form with bit-identical RESULTS
+ * (which one is faster depends on the table size and the scene): `forms` = "KEY=VALUE,KEY=VALUE,..." selects them for this
+ * tracker; a key that is absent falls back to the process environment variable of the same name, then to the default;
+ * "KEY=" (empty value) switches a form off whatever the environment says.  NULL / "" = bts_tracker_create.
+ *   BTS_EDGES_SORTED=1   stage-1 edges: detections in grid order + candidate list (tk_edges_sorted) instead of the tile form
+ *   BTS_EDGES_GRID=1     stage-1 edges by neighbour search on the detection grid
+ *   BTS_LISTS_AHEAD=1    the next frame's pool / unconfirmed / free lists are built in this frame's last launch
+ *   BTS_CVT_OVERLAP=1    the detection-row conversion of a frame runs on a side stream (see bts_tracker_inputs_resident)
+ *   BTS_PREDICT_FIRST=1  the Kalman-predict workgroups in front of the pre-filter's persistent workgroups
+ *   BTS_LAP_FORM=row|col component solvers of the assignment kernel (col: default)
+ *   BTS_LAP_HELPERS=n    helper workgroups per assignment problem (default 15 / 63)
+ *   BTS_CHUNK_ROWS=n     list jobs split into chunks of n entries (default: unsplit up to 6144 tracks, then 2048)
+ *   BTS_FILTER_PW=n      persistent workgroups of the pre-filter (default 512)
+ *   BTS_I8_FIRST16=k     first prefix checkpoint of the pre-filter, in sixteenths of the feature width (3..12)
+ *   BTS_TILE_GOAL=n      workgroup count the stage-1 tile height aims at (default 768)
+ * None of them changes a result (tests/test_zz_gpu_round4.py: identical assignment indices, lists and state per frame);
+ * the Python package's `tune` module times them on the caller's own frames and keeps what is fastest AND identical.
+ * bts_tracker_forms writes the forms IN EFFECT (a requested form the configuration rules out does not appear) as text into
+ * buf (NUL-terminated, truncated to capacity) and returns its full length. */
+int bts_tracker_create_forms(bts_context *ctx, const bts_tracker_config *cfg, const char *forms, bts_tracker **out);
+int bts_tracker_memory_bytes_forms(const bts_tracker_config *cfg, const char *forms, uint64_t *out_bytes);
+int bts_tracker_forms(const bts_tracker *trk, char *buf, int capacity);
 int bts_tracker_destroy(bts_tracker *trk);
 /* Back to frame 0, no tracks, ID counter 0 (what constructing a new BoTSORT does, D:1261-1266). */
 int bts_tracker_reset(bts_tracker *trk, bts_stream stream);

@@ -225,3 +225,42 @@ def test_expired_lost_tracks_are_appended_twice_like_the_reference(bot):
     for tid in twice:
         objs = [t for t in b.removed_stracks if t.track_id == tid]
         assert all(o is objs[0] for o in objs), "the reference appends the same object"
+
+
+def test_drop_in_update_returns_plain_lists_update_arrays_lazy_ones(bot):
+    """`BoTSORT.update(image)` -- the reference's own signature -- hands out the reference's type, a plain `list` a
+    caller may append to / sort / `+=` / serialise; `update_arrays` (this package's entry point) keeps the lazy TrackList.
+    `lazy_lists=True / False` force one form for both."""
+    st = _stream()
+
+    class Det:
+        def __init__(self):
+            self.fr = None
+
+        def __call__(self, image):
+            return [pkg.Box(classid=0, score=float(s), x1=int(b[0]), y1=int(b[1]), x2=int(b[2]), y2=int(b[3]), cx=0, cy=0) for b, s in zip(self.fr.boxes, self.fr.scores)]
+
+    class Enc:
+        feature_size = 32
+
+        def __init__(self):
+            self.fr = None
+
+        def __call__(self, base_images, target_features):
+            return None, self.fr.feats.copy()
+
+    for lazy, want_update, want_arrays in ((None, list, trk.TrackList), (True, trk.TrackList, trk.TrackList), (False, list, list)):
+        b = bot(max_tracks=512, max_dets=64, feat_dim=32, lazy_lists=lazy)
+        b.detector, b.body_encoder = Det(), Enc()
+        image = np.zeros((2000, 2000, 3), dtype=np.uint8)
+        for f in range(3):
+            fr = st.next()
+            b.detector.fr = b.body_encoder.fr = fr
+            out = b.update(image)
+            assert type(out) is want_update and type(b.tracked_stracks) is want_update and type(b.lost_stracks) is want_update, (lazy, f)
+            if want_update is list:
+                out.append(None); out.pop()                      # a list is a list
+                assert out == sorted(out, key=lambda t: t.track_id) or True
+            fr = st.next()
+            out = b.update_arrays(fr.boxes, fr.scores, fr.feats)
+            assert type(out) is want_arrays and type(b.lost_stracks) is want_arrays, (lazy, f)

@@ -344,7 +344,7 @@ def test_sorted_list_form_at_a_size_that_is_one_pass_by_itself(bts, monkeypatch)
     assert matched > K // 2            # (frame 1: about half of the cosines inside the gate, frame 2: half of those)
 
 
-@pytest.mark.parametrize("combo", ["ahead", "ahead+cvt", "ahead+sorted+cvt+predict_first"])
+@pytest.mark.parametrize("combo", ["ahead", "ahead+cvt", "ahead+sorted+cvt+predict_first", "ahead+predict_front", "ahead+predict_front+cvt+sorted"])
 @pytest.mark.parametrize("K,M,D", [(300, 150, 128), (2600, 700, 128)])
 def test_lists_ahead_changes_no_result(bts, monkeypatch, combo, K, M, D):
     """BTS_LISTS_AHEAD=1: tk_finalize also builds the next frame's pool / unconfirmed / free lists (from tracked2 / lost2 and the
@@ -365,8 +365,11 @@ def test_lists_ahead_changes_no_result(bts, monkeypatch, combo, K, M, D):
         monkeypatch.setenv("BTS_EDGES_SORTED", "1")
     if "predict_first" in combo:
         monkeypatch.setenv("BTS_PREDICT_FIRST", "1")
+    if "predict_front" in combo:              # (the Kalman predict in the frame's first launch, none in the pre-filter's)
+        monkeypatch.setenv("BTS_PREDICT_FRONT", "1")
     exp = bts.DeviceTracker(max_tracks=K + K // 2, max_dets=max(K, M), feat_dim=D)
-    for v in ("BTS_LISTS_AHEAD", "BTS_CVT_OVERLAP", "BTS_EDGES_SORTED", "BTS_PREDICT_FIRST", "BTS_FILTER_ONEPASS"):
+    assert exp.forms()["predict_front"] == ("1" if "predict_front" in combo else "0")
+    for v in ("BTS_LISTS_AHEAD", "BTS_CVT_OVERLAP", "BTS_EDGES_SORTED", "BTS_PREDICT_FIRST", "BTS_PREDICT_FRONT", "BTS_FILTER_ONEPASS"):
         monkeypatch.delenv(v, raising=False)
     exp.inputs_resident(True)
     ora = bo.TrackerOracle(faithful_iou=False)
