@@ -69,6 +69,8 @@ struct Dev {
     int32_t *hdr;
     // per-frame work
     int32_t *pool_slot, *unc_slot, *hi_idx, *lo_idx, *r2_row, *r2_slot, *left_hi, *left_det, *born_slot;
+    int32_t *r2_of_slot, *unc_of_slot;                 // BTS_MERGE_EARLY: slot -> index in the stage-2 row list / the unconfirmed list (validated by a read-back)
+    int merge_early;                                   // BTS_MERGE_EARLY=1: the list jobs of tk_merge ride in the launch of tk_apply23
     double *pool_tlbr, *unc_tlbr, *det_tlbr, *r2_tlbr;
     uint8_t *unc_f32, *ones;
     float *det_xywh;
@@ -90,6 +92,7 @@ struct Dev {
     float gate_sim;                                    // the similarity the appearance term must reach: 1 - appearance_thresh
     int sf32;                                          // kalman_dtype BTS_F32: mean / cov hold float32 elements (same rows, half the bytes)
     int c16;                                           // cost_dtype BTS_F16: association costs rounded to binary16 before thresholds and the solver
+    int f_guess;                                       // BTS_FILTER_GUESS=1: a workgroup's first tile is already predicted to stop at the first checkpoint
     int chk_first;                                     // first prefix checkpoint of the pre-filter, in sixteenths of the row (feat::i8_checkpoints)
     int32_t use_grid;                                   // BTS_EDGES_GRID=1 at create: stage-1 edges by neighbour search (experimental; wins only for very large frames)
     int32_t *grid_hdr, *cell_start, *cell_items;       // uniform grid over the frame's high-score detections (prep_dets -> tk_edges_grid)
@@ -242,7 +245,7 @@ template <bool CH> __device__ __forceinline__ void prep_unconfirmed(const Dev &d
     int32_t *h = d.hdr;
     const int nt = h[H_NTRACKED];
     const int nunc = job_compact<CH>(chunk_of(d, J_UNC, ch), nt, tmp, [&](int k) { return d.tracked[k]; },
-                                          [&](int k, int s) { return d.is_activated[s] == 0; }, [&](int p, int k, int s) { d.unc_slot[p] = s; });
+                                          [&](int k, int s) { return d.is_activated[s] == 0; }, [&](int p, int k, int s) { d.unc_slot[p] = s; if (d.merge_early) d.unc_of_slot[s] = p; });
     if (ch == nchunks<CH>(d) - 1 && threadIdx.x == 0) { h[H_NUNC] = nunc; h[H_DIMS3] = nunc; }
 }
 
@@ -1304,7 +1307,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // The prediction moves up at once and down only after three earlier stops in a row (a stop before the predicted one
     // costs a cold first stage of the next tile, a stop after it a cold K stage: late is the cheaper mistake); tests at
     // checkpoints before the predicted one are skipped except on every fourth tile (the probe that lets it move down).
-    int last_exit = -1, early_run = 0, tile_no = 0;
+    // (Dev::f_guess, BTS_FILTER_GUESS=1 at create; NOT yet measured: the FIRST tile is predicted to stop at the first checkpoint
+    //  as well -- on separable embeddings every tile does -- so the next tile's first stage is on its way before the first test
+    //  instead of after it: one cold tile opening less per workgroup, which has two or three tiles at the headline size.  Only
+    //  what is prefetched changes: the tests, their order and the candidate bits are the same.)
+    int last_exit = d.f_guess ? chk[0] : -1, early_run = 0, tile_no = 0;
     int st_stages = 0, st_early = 0, st_cand = 0;
 #ifdef BTS_FILTER_TRACE
     long long tm_check = 0, tm_wait = 0, tm_all = 0, tm_first = 0, tm_pro = 0;      // clock cycles of this workgroup: candidate tests, stage waits, total, first test, prologue
@@ -1841,7 +1848,7 @@ __device__ __forceinline__ void apply_body(const Dev &d, int bid) {
         if (threadIdx.x == 0) { d.has_body[s] = 1; if (d.Df) d.has_face[s] = 1; }
         return;
     }
-    const int g = bid * 256 + threadIdx.x;                    // ---- Kalman + lifecycle: 8 lanes per row
+    const int g = bid * (int)blockDim.x + threadIdx.x;        // ---- Kalman + lifecycle: 8 lanes per row
     const int r = g >> 3, i = g & 7;
     if (r >= n) return;
     const int s = rslot[r];
@@ -1872,6 +1879,28 @@ __device__ __forceinline__ void apply_body(const Dev &d, int bid) {
     d.frame_id[s] = frame;
     d.score[s] = IN(d, scores)[det];
     d.det_index[s] = det;
+}
+
+// the feature rows of apply_body<STAGE, true> in a 1024-thread workgroup: four matched columns per workgroup, one per row group
+// (a group without a match only takes part in the barriers of the row arithmetic)
+template <int STAGE>
+__device__ __forceinline__ void apply_feat4(const Dev &d, int bid) {
+    const int32_t *h = d.hdr;
+    const int n = STAGE == 2 ? h[H_NR2] : h[H_NUNC], m = STAGE == 2 ? h[H_NLO] : h[H_NLEFT];
+    const int32_t *rslot = STAGE == 2 ? d.r2_slot : d.unc_slot, *cdet = STAGE == 2 ? d.lo_idx : d.left_det, *ys = STAGE == 2 ? d.y2 : d.y3;
+    const int xq = bid * 4 + feat::row_group();
+    const int r = xq < m ? ys[xq] : -1;
+    const bool on = r >= 0 && r < n;
+    const long s = on ? rslot[r] : 0, det = on ? cdet[xq] : 0;
+    feat::ema_row(d.body_curr + s * d.D, d.body_smooth + s * d.D, IN(d, feats) + det * d.D, d.D, on && d.has_body[s] != 0, d.ema_a, d.ema_b, on);
+    if (d.Df)
+        feat::ema_row(d.face_curr + s * d.Df, d.face_smooth + s * d.Df, IN(d, face_feats) + det * d.Df, d.Df, on && d.has_face[s] != 0, d.ema_a, d.ema_b, on);
+    if (!on) return;
+    if (d.filter) {
+        copy_shadow(d.det_h + det * d.D, d.det_m + det * feat::I8_META, d.body_h + s * d.D, d.body_m + s * feat::I8_META, d.D);
+        if (d.Df) copy_shadow(d.dface_h + det * d.Df, d.dface_m + det * feat::I8_META, d.face_h + s * d.Df, d.face_m + s * feat::I8_META, d.Df);
+    }
+    if (feat::row_tid() == 0) { d.has_body[s] = 1; if (d.Df) d.has_face[s] = 1; }
 }
 
 // One launch after the stage-1 lists are rebuilt (tk_mid1): the stage-1 Kalman updates, the stage-1
@@ -1923,6 +1952,7 @@ template <bool CH> __device__ __forceinline__ void after1_body(const Dev &d, int
                                              [&](int r, int s) { return (d.x1[r] < 0) & (d.state[s] == BTS_TRACKED); },
                                              [&](int p, int r, int s) {
                                                  d.r2_row[p] = r; d.r2_slot[p] = s;
+                                                 if (d.merge_early) d.r2_of_slot[s] = p;
                                                  for (int c = 0; c < 4; ++c) d.r2_tlbr[p * 4 + c] = d.pool_tlbr[r * 4 + c];
                                              });
         if (ch == nchunks<CH>(d) - 1 && threadIdx.x == 0) { h[H_NR2] = nr2; h[H_DIMS2] = nr2; }
@@ -1969,13 +1999,21 @@ __device__ __forceinline__ int lost2_at(const Dev &d, int k) {
     return k < c0 ? d.lost2[k] : d.lost2[d.T + (k - c0)];
 }
 
-template <bool CH> __global__ __launch_bounds__(1024) void tk_merge(Dev d) {
+// EARLY (BTS_MERGE_EARLY=1 at create; NOT yet measured): the five jobs run in the launch that APPLIES stages 2 and 3
+// (tk_apply23_merge) instead of behind it -- one launch boundary less.  Four of them never read what that application
+// writes (they work from the assignment vectors, the lists, frame counters of LOST tracks and free slots); "kept tracked"
+// did, through the state the application sets (Lost for a stage-2 row left unmatched, Removed for an unconfirmed track left
+// unmatched): here it takes the same verdict from the assignment vectors -- a member of the old tracked list is a stage-2 row
+// (kept iff x2 >= 0), an unconfirmed track (kept iff x3 >= 0) or was matched in stage 1 (kept) -- through slot -> list-index
+// maps written where those lists are built (r2_of_slot: tk_mid1, unc_of_slot: tk_front / tk_finalize) and validated by reading
+// the list entry back, so a stale map entry of an earlier frame can never be taken for a membership.
+template <bool CH, bool EARLY> __device__ __forceinline__ void merge_body(const Dev &d, int blk) {
     __shared__ int32_t tmp[1024];
     int32_t *h = d.hdr;
     const int tid = threadIdx.x, nth = blockDim.x;
     const int frame = h[H_FRAME];
     TJ_BEGIN();
-    const int nch = nchunks<CH>(d), job = blockIdx.x == 0 ? 0 : 1 + ((int)blockIdx.x - 1) / nch, ch = blockIdx.x == 0 ? 0 : ((int)blockIdx.x - 1) % nch;
+    const int nch = nchunks<CH>(d), job = blk == 0 ? 0 : 1 + (blk - 1) / nch, ch = blk == 0 ? 0 : (blk - 1) % nch;
     const bool last = ch == nch - 1;
     if (job == 0) {
         // births in ascending leftover-detection order (new ids ascending, quirk Q7)
@@ -2013,8 +2051,20 @@ template <bool CH> __global__ __launch_bounds__(1024) void tk_merge(Dev d) {
         }
     } else if (job == 1) {
         const int nt = h[H_NTRACKED];
-        const int n_keep = job_compact<CH>(chunk_of(d, J_KEEP, ch), nt, tmp, [&](int k) { return d.tracked[k]; },
-                                                [&](int k, int s) { return d.state[s] == BTS_TRACKED; }, [&](int p, int k, int s) { d.tracked2[p] = s; });
+        int n_keep;
+        if constexpr (EARLY) {
+            const unsigned nr2 = (unsigned)h[H_NR2], nunc = (unsigned)h[H_NUNC];
+            n_keep = job_compact<CH>(chunk_of(d, J_KEEP, ch), nt, tmp, [&](int k) { return d.tracked[k]; },
+                                     [&](int k, int s) {
+                                         const unsigned q = (unsigned)d.r2_of_slot[s], u = (unsigned)d.unc_of_slot[s];
+                                         const bool in2 = q < nr2 && d.r2_slot[q < nr2 ? q : 0] == s;
+                                         const bool in3 = u < nunc && d.unc_slot[u < nunc ? u : 0] == s;
+                                         return in2 ? d.x2[q] >= 0 : in3 ? d.x3[u] >= 0 : true;
+                                     }, [&](int p, int k, int s) { d.tracked2[p] = s; });
+        } else {
+            n_keep = job_compact<CH>(chunk_of(d, J_KEEP, ch), nt, tmp, [&](int k) { return d.tracked[k]; },
+                                     [&](int k, int s) { return d.state[s] == BTS_TRACKED; }, [&](int p, int k, int s) { d.tracked2[p] = s; });
+        }
         if (last && tid == 0) h[H_NKEEP] = n_keep;
     } else if (job == 2) {
         // re-found = lost rows of the pool (rows >= nconf) that stage 1 matched; no per-slot flag needed
@@ -2067,6 +2117,22 @@ template <bool CH> __global__ __launch_bounds__(1024) void tk_merge(Dev d) {
         if (last && tid == 0) h[H_NL1] = n_l1;
     }
     if (last) TJ_END(2, job);
+}
+template <bool CH> __global__ __launch_bounds__(1024) void tk_merge(Dev d) { merge_body<CH, false>(d, (int)blockIdx.x); }
+// BTS_MERGE_EARLY: stages 2 and 3 applied AND the list merge, one launch of 1024-thread workgroups -- the list jobs first (they
+// are the longer chains), then the Kalman ranges (8 lanes per row) and the feature rows (four matched columns per workgroup)
+template <bool CH> __global__ __launch_bounds__(1024) void tk_apply23_merge(Dev d, int kf_blocks, int feat_blocks) {
+    int b = (int)blockIdx.x;
+    const int mj = merge_jobs(nchunks<CH>(d));
+    if (b >= mj + 2 * kf_blocks) {
+        b -= mj + 2 * kf_blocks;
+        if (b < feat_blocks) apply_feat4<2>(d, b); else apply_feat4<3>(d, b - feat_blocks);
+    } else if (b >= mj) {
+        b -= mj;
+        if (b < kf_blocks) apply_body<2, false>(d, b); else apply_body<3, false>(d, b - kf_blocks);
+    } else {
+        merge_body<CH, true>(d, b);
+    }
 }
 
 // Kalman initiate + feature rows of the newborn tracks (D:556-568, D:492-514): one workgroup per
@@ -2201,7 +2267,7 @@ template <bool CH> __device__ __forceinline__ void ahead_body(const Dev &d, int 
         }
     } else if (job == 1) {
         const int nunc = job_compact<CH>(chunk_of(d, J_UNC, ch), nt2, tmp, [&](int k) { return tracked2_at(d, k); },
-                                         [&](int k, int s) { return !d.drop_t[k] && d.is_activated[s] == 0; }, [&](int p, int k, int s) { d.unc_slot[p] = s; });
+                                         [&](int k, int s) { return !d.drop_t[k] && d.is_activated[s] == 0; }, [&](int p, int k, int s) { d.unc_slot[p] = s; if (d.merge_early) d.unc_of_slot[s] = p; });
         if (last && tid == 0) h[H_NUNC_N] = nunc;
     } else {
         // free slots = the table minus the kept entries of both lists (prep_free, from the same inputs)
@@ -2418,7 +2484,7 @@ static void tracker_layout(bts_tracker *t, char *base, size_t &off) {
     SLOT(d.tracked, int32_t, T); SLOT(d.lost, int32_t, T); SLOT(d.tracked2, int32_t, 3 * T); SLOT(d.lost2, int32_t, 2 * T);
     SLOT(d.free_list, int32_t, T); SLOT(d.hdr, int32_t, H_SIZE);
     SLOT(d.pool_slot, int32_t, T); SLOT(d.unc_slot, int32_t, T); SLOT(d.hi_idx, int32_t, M); SLOT(d.lo_idx, int32_t, M);
-    SLOT(d.r2_row, int32_t, T); SLOT(d.r2_slot, int32_t, T); SLOT(d.left_hi, int32_t, M); SLOT(d.left_det, int32_t, M);
+    SLOT(d.r2_row, int32_t, T); SLOT(d.r2_slot, int32_t, T); SLOT(d.r2_of_slot, int32_t, d.merge_early ? T : 1); SLOT(d.unc_of_slot, int32_t, d.merge_early ? T : 1); SLOT(d.left_hi, int32_t, M); SLOT(d.left_det, int32_t, M);
     SLOT(d.born_slot, int32_t, M);
     SLOT(d.pool_tlbr, double, 4 * T); SLOT(d.unc_tlbr, double, 4 * T); SLOT(d.det_tlbr, double, 4 * M);
     SLOT(d.r2_tlbr, double, 4 * T); SLOT(d.unc_f32, uint8_t, T); SLOT(d.ones, uint8_t, M); SLOT(d.det_xywh, float, 4 * M);
@@ -2498,6 +2564,8 @@ static int derive_sizes(const bts_tracker_config *cfg, Dev &d, int64_t *e_cap_ou
                 cfg->match_thresh < 1.0 && !cfg->use_graph) ? 1 : 0;
     // BTS_LISTS_AHEAD=1 (read at create): the next frame's pool / unconfirmed / free lists are built by tk_finalize
     d.ahead = (bts_form_get("BTS_LISTS_AHEAD") != nullptr && !cfg->use_graph) ? 1 : 0;
+    // BTS_MERGE_EARLY=1 (read at create): tk_merge's jobs in the launch of tk_apply23 (tk_apply23_merge)
+    d.merge_early = bts_form_get("BTS_MERGE_EARLY") != nullptr ? 1 : 0;
     d.sf32 = cfg->kalman_dtype == BTS_F32 ? 1 : 0;
     d.c16 = cfg->cost_dtype == BTS_F16 ? 1 : 0;
     if (cfg->tie_mode) {
@@ -2591,6 +2659,7 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
     { const char *e = bts_form_get("BTS_TILE_GOAL"); const int v = e ? atoi(e) : 0; t->tile_goal = v >= 64 && v <= 16384 ? v : 768; }
     t->onepass = bts_form_get("BTS_FILTER_ONEPASS") != nullptr;
     d.gate_sim = 1.0f - d.app;
+    d.f_guess = bts_form_get("BTS_FILTER_GUESS") != nullptr ? 1 : 0;
     {   // first prefix checkpoint of the pre-filter: from the gate, or BTS_I8_FIRST16 (3 .. 12; 5 = the round-2 set)
         const char *e = bts_form_get("BTS_I8_FIRST16");
         const int f = e ? atoi(e) : 0;
@@ -2598,11 +2667,11 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
     }
     // the forms in effect (a requested form that the configuration rules out -- the sorted edges with a motion gate, say --
     // does not appear), for bts_tracker_forms
-    snprintf(t->forms, sizeof(t->forms), "edges=%s,lists_ahead=%d,cvt_overlap=%d,predict_front=%d,predict_first=%d,lap_form=%s,lap_helpers=%d,list_chunks=%d,"
-             "filter_pw=%d,filter_first16=%d,filter_onepass=%d,tile_goal=%d",
-             d.sorted ? "sorted" : (d.use_grid && d.filter) ? "grid" : "tiles", d.ahead, t->cvt_overlap ? 1 : 0, t->predict_front ? 1 : 0, t->predict_first ? 1 : 0,
+    snprintf(t->forms, sizeof(t->forms), "edges=%s,lists_ahead=%d,merge_early=%d,cvt_overlap=%d,predict_front=%d,predict_first=%d,lap_form=%s,lap_helpers=%d,list_chunks=%d,"
+             "filter_pw=%d,filter_first16=%d,filter_onepass=%d,filter_guess=%d,tile_goal=%d",
+             d.sorted ? "sorted" : (d.use_grid && d.filter) ? "grid" : "tiles", d.ahead, d.merge_early, t->cvt_overlap ? 1 : 0, t->predict_front ? 1 : 0, t->predict_first ? 1 : 0,
              t->lap_form == 1 ? "row" : "col", t->lap_helpers, d.nch, t->filter_pw > 0 ? t->filter_pw : FILTER_PW, d.chk_first,
-             t->onepass ? 1 : 0, t->tile_goal);
+             t->onepass ? 1 : 0, d.f_guess, t->tile_goal);
     size_t off = 0;
     tracker_layout(t, nullptr, off);
     const int64_t o_cap = (cfg->tie_mode && d.Df > 0) ? e_cap : 0;      // overrides of the exact-tie step (tk_edges_xo): their own region
@@ -3017,12 +3086,20 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
         if (rc) return rc;
     }
     seg_begin(BTS_SEG_K_APPLY23);
-    LAUNCH(tk_apply23, dim3(2 * kf_blocks + 2 * mc), dim3(256), kf_blocks, mc);
+    if (d.merge_early) {
+        // (BTS_MERGE_EARLY: + births and the list merge, see tk_apply23_merge; the merge segment below is then empty)
+        const int kf4 = bts_cdiv(kf_blocks, 4), ft4 = bts_cdiv(mc, 4);
+        if (d.nch > 1) { LAUNCH(tk_apply23_merge<true>, dim3(merge_jobs(d.nch) + 2 * kf4 + 2 * ft4), dim3(1024), kf4, ft4); }
+        else { LAUNCH(tk_apply23_merge<false>, dim3(merge_jobs(1) + 2 * kf4 + 2 * ft4), dim3(1024), kf4, ft4); }
+    } else {
+        LAUNCH(tk_apply23, dim3(2 * kf_blocks + 2 * mc), dim3(256), kf_blocks, mc);
+    }
     seg_end(BTS_SEG_K_APPLY23);
     seg_end(BTS_SEG_STAGE2);
     // ---- births, list merge, duplicate removal
     seg_begin(BTS_SEG_MERGE);
-    if (d.nch > 1) { LAUNCH(tk_merge<true>, dim3(merge_jobs(d.nch)), dim3(1024)); }
+    if (d.merge_early) { }
+    else if (d.nch > 1) { LAUNCH(tk_merge<true>, dim3(merge_jobs(d.nch)), dim3(1024)); }
     else { LAUNCH(tk_merge<false>, dim3(merge_jobs(1)), dim3(1024)); }
     seg_end(BTS_SEG_MERGE);
     seg_begin(BTS_SEG_DEDUPE);

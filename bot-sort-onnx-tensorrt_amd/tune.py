@@ -34,10 +34,12 @@ from typing import Callable, Dict, List, Optional, Sequence, Tuple
 CANDIDATES: Tuple[Tuple[str, str, Dict[str, str]], ...] = (
     ("lists_ahead", "lists_ahead", {"BTS_LISTS_AHEAD": "1"}),
     ("lists_ahead", "lists_ahead_predict_front", {"BTS_LISTS_AHEAD": "1", "BTS_PREDICT_FRONT": "1"}),
+    ("merge_early", "merge_early", {"BTS_MERGE_EARLY": "1"}),
     ("cvt_overlap", "cvt_overlap", {"BTS_CVT_OVERLAP": "1"}),
     ("edges", "edges_sorted", {"BTS_EDGES_SORTED": "1"}),
     ("edges", "edges_grid", {"BTS_EDGES_GRID": "1"}),
     ("predict_first", "predict_first", {"BTS_PREDICT_FIRST": "1"}),
+    ("filter_guess", "filter_guess", {"BTS_FILTER_GUESS": "1"}),
     ("lap_form", "lap_row", {"BTS_LAP_FORM": "row"}),
     ("lap_helpers", "lap_helpers_31", {"BTS_LAP_HELPERS": "31"}),
     ("lap_helpers", "lap_helpers_127", {"BTS_LAP_HELPERS": "127"}),

@@ -268,8 +268,11 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
  *   BTS_EDGES_SORTED=1   stage-1 edges: detections in grid order + candidate list (tk_edges_sorted) instead of the tile form
  *   BTS_EDGES_GRID=1     stage-1 edges by neighbour search on the detection grid
  *   BTS_LISTS_AHEAD=1    the next frame's pool / unconfirmed / free lists are built in this frame's last launch
+ *   BTS_MERGE_EARLY=1    births and the list merge in the launch that applies stages 2 and 3 (one launch less)
  *   BTS_CVT_OVERLAP=1    the detection-row conversion of a frame runs on a side stream (see bts_tracker_inputs_resident)
  *   BTS_PREDICT_FIRST=1  the Kalman-predict workgroups in front of the pre-filter's persistent workgroups
+ *   BTS_PREDICT_FRONT=1  (with BTS_LISTS_AHEAD) the Kalman predict in the frame's first launch, none in the pre-filter's
+ *   BTS_FILTER_GUESS=1   a pre-filter workgroup predicts its FIRST tile, too, to stop at the first checkpoint (prefetch only)
  *   BTS_LAP_FORM=row|col component solvers of the assignment kernel (col: default)
  *   BTS_LAP_HELPERS=n    helper workgroups per assignment problem (default 15 / 63)
  *   BTS_CHUNK_ROWS=n     list jobs split into chunks of n entries (default: unsplit up to 6144 tracks, then 2048)

@@ -147,7 +147,7 @@ def test_solver_forms_agree(bts, monkeypatch, name, form):
     trk.close()
 
 
-@pytest.mark.parametrize("first16", [None, "5", "8"])
+@pytest.mark.parametrize("first16", [None, "5", "8", "guess", "guess8"])
 def test_one_pass_prefilter_prefix_exits_vs_dense(bts, monkeypatch, first16):
     """The persistent one-pass form of the pre-filter (k_filter_i8: tile walk, LDS-DMA double buffering, prefix checkpoints,
     exit prediction, the next tile's first stage issued under the test) at a size small enough for a CPU emulation:
@@ -156,6 +156,11 @@ def test_one_pass_prefilter_prefix_exits_vs_dense(bts, monkeypatch, first16):
     DENSE frame by frame, for the round-2 checkpoint set (5), the gate-derived default and a late first checkpoint (8)."""
     import torch
     monkeypatch.setenv("BTS_FILTER_ONEPASS", "1")
+    guess = first16 is not None and first16.startswith("guess")      # BTS_FILTER_GUESS: a workgroup's first tile is predicted to stop
+    if guess:                                                        # at the first checkpoint as well (changes prefetches only); with
+        monkeypatch.setenv("BTS_FILTER_GUESS", "1")                  # a late first checkpoint the prediction is sometimes wrong
+        monkeypatch.setenv("BTS_FILTER_PW", "2")                     # (two persistent workgroups: three tiles each, so the
+        first16 = first16[5:] or None                                #  next-tile prefetch of a first tile is exercised)
     if first16 is not None:
         monkeypatch.setenv("BTS_I8_FIRST16", first16)
     rng = np.random.default_rng(41)
@@ -163,6 +168,7 @@ def test_one_pass_prefilter_prefix_exits_vs_dense(bts, monkeypatch, first16):
     proto = rng.standard_normal((K, D))
     proto /= np.linalg.norm(proto, axis=1, keepdims=True)
     a = bts.DeviceTracker(max_tracks=384, max_dets=K, feat_dim=D)
+    assert a.forms()["filter_guess"] == ("1" if guess else "0")
     b = bts.DeviceTracker(max_tracks=384, max_dets=K, feat_dim=D, appearance_mode=1)
     early, matched1 = 0, 0
     for f in range(4):
@@ -344,7 +350,8 @@ def test_sorted_list_form_at_a_size_that_is_one_pass_by_itself(bts, monkeypatch)
     assert matched > K // 2            # (frame 1: about half of the cosines inside the gate, frame 2: half of those)
 
 
-@pytest.mark.parametrize("combo", ["ahead", "ahead+cvt", "ahead+sorted+cvt+predict_first", "ahead+predict_front", "ahead+predict_front+cvt+sorted"])
+@pytest.mark.parametrize("combo", ["ahead", "ahead+cvt", "ahead+sorted+cvt+predict_first", "ahead+predict_front", "ahead+predict_front+cvt+sorted",
+                                   "merge_early", "ahead+merge_early+predict_front+cvt+sorted"])
 @pytest.mark.parametrize("K,M,D", [(300, 150, 128), (2600, 700, 128)])
 def test_lists_ahead_changes_no_result(bts, monkeypatch, combo, K, M, D):
     """BTS_LISTS_AHEAD=1: tk_finalize also builds the next frame's pool / unconfirmed / free lists (from tracked2 / lost2 and the
@@ -357,7 +364,10 @@ def test_lists_ahead_changes_no_result(bts, monkeypatch, combo, K, M, D):
     if K > 1000:
         monkeypatch.setenv("BTS_CHUNK_ROWS", "512")
     ref = bts.DeviceTracker(max_tracks=K + K // 2, max_dets=max(K, M), feat_dim=D)
-    monkeypatch.setenv("BTS_LISTS_AHEAD", "1")
+    if "ahead" in combo:
+        monkeypatch.setenv("BTS_LISTS_AHEAD", "1")
+    if "merge_early" in combo:                # (births + list merge in the launch that applies stages 2 and 3: tk_apply23_merge)
+        monkeypatch.setenv("BTS_MERGE_EARLY", "1")
     monkeypatch.setenv("BTS_FILTER_ONEPASS", "1")
     if "cvt" in combo:
         monkeypatch.setenv("BTS_CVT_OVERLAP", "1")
@@ -369,7 +379,8 @@ def test_lists_ahead_changes_no_result(bts, monkeypatch, combo, K, M, D):
         monkeypatch.setenv("BTS_PREDICT_FRONT", "1")
     exp = bts.DeviceTracker(max_tracks=K + K // 2, max_dets=max(K, M), feat_dim=D)
     assert exp.forms()["predict_front"] == ("1" if "predict_front" in combo else "0")
-    for v in ("BTS_LISTS_AHEAD", "BTS_CVT_OVERLAP", "BTS_EDGES_SORTED", "BTS_PREDICT_FIRST", "BTS_PREDICT_FRONT", "BTS_FILTER_ONEPASS"):
+    assert exp.forms()["merge_early"] == ("1" if "merge_early" in combo else "0") and exp.forms()["lists_ahead"] == ("1" if "ahead" in combo else "0")
+    for v in ("BTS_MERGE_EARLY", "BTS_LISTS_AHEAD", "BTS_CVT_OVERLAP", "BTS_EDGES_SORTED", "BTS_PREDICT_FIRST", "BTS_PREDICT_FRONT", "BTS_FILTER_ONEPASS"):
         monkeypatch.delenv(v, raising=False)
     exp.inputs_resident(True)
     ora = bo.TrackerOracle(faithful_iou=False)
