@@ -70,6 +70,7 @@ struct Dev {
     // per-frame work
     int32_t *pool_slot, *unc_slot, *hi_idx, *lo_idx, *r2_row, *r2_slot, *left_hi, *left_det, *born_slot;
     int32_t *r2_of_slot, *unc_of_slot;                 // BTS_MERGE_EARLY: slot -> index in the stage-2 row list / the unconfirmed list (validated by a read-back)
+    int renorm_fused;                                  // BTS_RENORM_FUSED=1: a stage-1 matched detection row is renormalised by the workgroup that absorbs it (tk_mid2)
     int merge_early;                                   // BTS_MERGE_EARLY=1: the list jobs of tk_merge ride in the launch of tk_apply23
     double *pool_tlbr, *unc_tlbr, *det_tlbr, *r2_tlbr;
     uint8_t *unc_f32, *ones;
@@ -1806,7 +1807,10 @@ __device__ __forceinline__ void renorm_body(const Dev &d, int blk) {        // f
     const int32_t *h = d.hdr;
     const int nhi = h[H_NHI], nlo = h[H_NLO];
     const int q = blk * 4 + feat::row_group();
-    const bool on = q < nhi + nlo;
+    // (Dev::renorm_fused, BTS_RENORM_FUSED=1 at create; NOT yet measured: the rows stage 1 matched -- most of them -- are left to
+    //  the feature workgroups of tk_mid2, which read them anyway: one 4 D-byte read per match less, and this launch is down to
+    //  its list jobs plus the few unmatched / low-score rows.  Same functions on the same values: bit-identical rows.)
+    const bool on = q < nhi + nlo && !(d.renorm_fused && q < nhi && d.y1[q < nhi ? q : 0] >= 0);
     const long det = !on ? 0 : q < nhi ? d.hi_idx[q] : d.lo_idx[q - nhi];
     const float nb = feat::renorm_row(IN(d, feats) + det * d.D, d.D, on);
     // the detection's record becomes the record of the unit row a track will hold (feat::i8_track_side): its column-side
@@ -1838,6 +1842,17 @@ __device__ __forceinline__ void apply_body(const Dev &d, int bid) {
         const int r = ys[xq];
         if (r < 0 || r >= n) return;
         const long s = rslot[r], det = cdet[xq];
+        if (STAGE == 1 && d.renorm_fused) {
+            // this row was skipped by renorm_body (tk_mid1): renormalised here, in place (Q8), by the threads that read it next
+            // (thread t rewrites exactly the elements it reads back below); the record turns into the unit row's like there
+            const float nb = feat::renorm_row(IN(d, feats) + det * d.D, d.D, true);
+            if (d.filter && feat::row_tid() == 0) feat::i8_track_side(d.det_m + det * feat::I8_META, nb, d.gate_sim);
+            if (d.Df) {
+                const float nf = feat::renorm_row(IN(d, face_feats) + det * d.Df, d.Df, true);
+                if (d.filter && feat::row_tid() == 0) feat::i8_track_side(d.dface_m + det * feat::I8_META, nf, d.gate_sim);
+            }
+            __syncthreads();                 // (the record: copy_shadow below reads it with other threads)
+        }
         feat::ema_row(d.body_curr + s * d.D, d.body_smooth + s * d.D, IN(d, feats) + det * d.D, d.D, d.has_body[s] != 0, d.ema_a, d.ema_b);
         if (d.Df)
             feat::ema_row(d.face_curr + s * d.Df, d.face_smooth + s * d.Df, IN(d, face_feats) + det * d.Df, d.Df, d.has_face[s] != 0, d.ema_a, d.ema_b);
@@ -2566,6 +2581,7 @@ static int derive_sizes(const bts_tracker_config *cfg, Dev &d, int64_t *e_cap_ou
     d.ahead = (bts_form_get("BTS_LISTS_AHEAD") != nullptr && !cfg->use_graph) ? 1 : 0;
     // BTS_MERGE_EARLY=1 (read at create): tk_merge's jobs in the launch of tk_apply23 (tk_apply23_merge)
     d.merge_early = bts_form_get("BTS_MERGE_EARLY") != nullptr ? 1 : 0;
+    d.renorm_fused = bts_form_get("BTS_RENORM_FUSED") != nullptr ? 1 : 0;
     d.sf32 = cfg->kalman_dtype == BTS_F32 ? 1 : 0;
     d.c16 = cfg->cost_dtype == BTS_F16 ? 1 : 0;
     if (cfg->tie_mode) {
@@ -2667,9 +2683,9 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
     }
     // the forms in effect (a requested form that the configuration rules out -- the sorted edges with a motion gate, say --
     // does not appear), for bts_tracker_forms
-    snprintf(t->forms, sizeof(t->forms), "edges=%s,lists_ahead=%d,merge_early=%d,cvt_overlap=%d,predict_front=%d,predict_first=%d,lap_form=%s,lap_helpers=%d,list_chunks=%d,"
+    snprintf(t->forms, sizeof(t->forms), "edges=%s,lists_ahead=%d,merge_early=%d,renorm_fused=%d,cvt_overlap=%d,predict_front=%d,predict_first=%d,lap_form=%s,lap_helpers=%d,list_chunks=%d,"
              "filter_pw=%d,filter_first16=%d,filter_onepass=%d,filter_guess=%d,tile_goal=%d",
-             d.sorted ? "sorted" : (d.use_grid && d.filter) ? "grid" : "tiles", d.ahead, d.merge_early, t->cvt_overlap ? 1 : 0, t->predict_front ? 1 : 0, t->predict_first ? 1 : 0,
+             d.sorted ? "sorted" : (d.use_grid && d.filter) ? "grid" : "tiles", d.ahead, d.merge_early, d.renorm_fused, t->cvt_overlap ? 1 : 0, t->predict_front ? 1 : 0, t->predict_first ? 1 : 0,
              t->lap_form == 1 ? "row" : "col", t->lap_helpers, d.nch, t->filter_pw > 0 ? t->filter_pw : FILTER_PW, d.chk_first,
              t->onepass ? 1 : 0, d.f_guess, t->tile_goal);
     size_t off = 0;

@@ -35,6 +35,7 @@ CANDIDATES: Tuple[Tuple[str, str, Dict[str, str]], ...] = (
     ("lists_ahead", "lists_ahead", {"BTS_LISTS_AHEAD": "1"}),
     ("lists_ahead", "lists_ahead_predict_front", {"BTS_LISTS_AHEAD": "1", "BTS_PREDICT_FRONT": "1"}),
     ("merge_early", "merge_early", {"BTS_MERGE_EARLY": "1"}),
+    ("renorm_fused", "renorm_fused", {"BTS_RENORM_FUSED": "1"}),
     ("cvt_overlap", "cvt_overlap", {"BTS_CVT_OVERLAP": "1"}),
     ("edges", "edges_sorted", {"BTS_EDGES_SORTED": "1"}),
     ("edges", "edges_grid", {"BTS_EDGES_GRID": "1"}),

@@ -269,6 +269,7 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
  *   BTS_EDGES_GRID=1     stage-1 edges by neighbour search on the detection grid
  *   BTS_LISTS_AHEAD=1    the next frame's pool / unconfirmed / free lists are built in this frame's last launch
  *   BTS_MERGE_EARLY=1    births and the list merge in the launch that applies stages 2 and 3 (one launch less)
+ *   BTS_RENORM_FUSED=1   a detection row matched in stage 1 is renormalised by the workgroup that absorbs it into its track
  *   BTS_CVT_OVERLAP=1    the detection-row conversion of a frame runs on a side stream (see bts_tracker_inputs_resident)
  *   BTS_PREDICT_FIRST=1  the Kalman-predict workgroups in front of the pre-filter's persistent workgroups
  *   BTS_PREDICT_FRONT=1  (with BTS_LISTS_AHEAD) the Kalman predict in the frame's first launch, none in the pre-filter's

@@ -411,3 +411,57 @@ def test_lists_ahead_changes_no_result(bts, monkeypatch, combo, K, M, D):
             assert np.array_equal(ta["mean"], tb["mean"]), (f, which)
         assert ref.counts() == exp.counts() and exp.counts()["errors"] == 0, (f, ref.counts(), exp.counts())
     ref.close(); exp.close()
+
+
+@pytest.mark.parametrize("K,M,D,F,combo", [(300, 150, 128, 0, "fused"), (200, 120, 128, 128, "fused"), (300, 150, 128, 0, "fused+merge_early+ahead")])
+def test_renorm_fused_changes_no_row(bts, monkeypatch, K, M, D, F, combo):
+    """BTS_RENORM_FUSED=1: the in-place renormalisation (Q8, D:492-514) of a detection row that stage 1 matched moves from tk_mid1
+    into the tk_mid2 workgroup that absorbs the row into its track.  Detection rows arrive with norms between 0.5 and 2, so the
+    renormalisation is not a no-op: per frame the caller's feature array after the step (every row, matched or not), both
+    feature tables of both lists, the assignments, the lists and the Kalman means must be bit-identical to the default form's."""
+    import torch
+    st = bts.synth.SyntheticStream(K, M, D, seed=77, churn=0.08, face_dim=F)
+    rng = np.random.default_rng(5)
+    ref = bts.DeviceTracker(max_tracks=K + K // 2, max_dets=max(K, M), feat_dim=D, face_dim=F)
+    monkeypatch.setenv("BTS_RENORM_FUSED", "1")
+    if "merge_early" in combo:
+        monkeypatch.setenv("BTS_MERGE_EARLY", "1")
+    if "ahead" in combo:
+        monkeypatch.setenv("BTS_LISTS_AHEAD", "1")
+    exp = bts.DeviceTracker(max_tracks=K + K // 2, max_dets=max(K, M), feat_dim=D, face_dim=F)
+    assert exp.forms()["renorm_fused"] == "1" and ref.forms()["renorm_fused"] == "0"
+    for v in ("BTS_RENORM_FUSED", "BTS_MERGE_EARLY", "BTS_LISTS_AHEAD"):
+        monkeypatch.delenv(v, raising=False)
+    matched = 0
+    for f in range(8):
+        fr = st.next()
+        scale = rng.uniform(0.5, 2.0, (len(fr.feats), 1)).astype(np.float32)
+        feats = np.ascontiguousarray(fr.feats * scale)
+        faces = np.ascontiguousarray(fr.face_feats * scale) if F else None
+        outs = []
+        for trk in (ref, exp):
+            fa = torch.from_numpy(feats.copy()).cuda()
+            fb = torch.from_numpy(faces.copy()).cuda() if F else None
+            trk.step(torch.from_numpy(fr.boxes.astype(np.int32)).cuda(), torch.from_numpy(fr.scores.astype(np.float32)).cuda(), fa, fb)
+            torch.cuda.synchronize()
+            outs.append((fa.cpu().numpy(), fb.cpu().numpy() if F else None))
+        assert np.array_equal(outs[0][0], outs[1][0]), f                     # the caller's rows (Q8), bit for bit
+        if F:
+            assert np.array_equal(outs[0][1], outs[1][1]), f
+        if f > 0:
+            assert not np.array_equal(outs[0][0], feats)                      # (and the renormalisation did something)
+        for k in (1, 2, 3):
+            a, b = ref.stage_result(k), exp.stage_result(k)
+            assert np.array_equal(a["x"], b["x"]) and np.array_equal(a["y"], b["y"]), (f, k)
+        matched += len(ref.stage_result(1)["m"])
+        for which in (0, 1):
+            ta, tb = ref.export(which), exp.export(which)
+            for key in INT_KEYS + ("slot",):
+                assert np.array_equal(ta[key], tb[key]), (f, which, key)
+            assert np.array_equal(ta["mean"], tb["mean"]), (f, which)
+            sa, sb = ref.export_state(which, cov=False, body=True, face=bool(F)), exp.export_state(which, cov=False, body=True, face=bool(F))
+            for key in sa:
+                assert np.array_equal(sa[key], sb[key]), (f, which, key)
+        assert ref.counts() == exp.counts() and exp.counts()["errors"] == 0
+    assert matched > 3 * M
+    ref.close(); exp.close()
