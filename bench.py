@@ -463,6 +463,11 @@ def main():
     opts = dict(appearance_mode=1 if a.dense else 0, use_graph=1 if a.graph else 0, motion_gate=1 if a.motion_gate else 0)
     # ---- execution forms (untimed set-up): selected in a child process while this one generates its frames
     selection, sel_thread = None, None
+    FORM_KEYS = ("BTS_EDGES_SORTED", "BTS_EDGES_GRID", "BTS_LISTS_AHEAD", "BTS_MERGE_EARLY", "BTS_RENORM_FUSED", "BTS_CVT_OVERLAP", "BTS_PREDICT_FIRST",
+                 "BTS_PREDICT_FRONT", "BTS_FILTER_GUESS", "BTS_LAP_FORM", "BTS_LAP_HELPERS", "BTS_CHUNK_ROWS", "BTS_FILTER_PW", "BTS_I8_FIRST16",
+                 "BTS_TILE_GOAL", "BTS_FILTER_ONEPASS")
+    if a.forms == "auto" and any(k in os.environ for k in FORM_KEYS):
+        a.forms = "env"                 # (forms given through the environment -- an A/B run -- are taken as they are: no selection)
     if a.forms == "auto" and S == 1 and not a.graph and not a.dense and not os.environ.get("BTS_BENCH_NO_TUNE"):
         import threading
         tune = importlib.import_module("bot-sort-onnx-tensorrt_amd.tune")
@@ -476,7 +481,7 @@ def main():
         sel_thread.start()
     frames = [next_frame() for _ in range(a.warmup)]
     timed = [next_frame() for _ in range(a.steps)]
-    forms = "" if a.forms in ("auto", "default") else a.forms
+    forms = "" if a.forms in ("auto", "default", "env") else a.forms
     if sel_thread is not None:
         sel_thread.join()
         selection = box.get("r")

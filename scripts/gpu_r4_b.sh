@@ -8,7 +8,7 @@ for w in target c2 c3 c5 crowd hard-reid dup-box@c2; do
   timeout 900 python bench.py --workload $w $extra > $O/bench_$w.json 2> $O/bench_$w.err; echo "$w rc=$? $(python -c "import json,sys; d=json.load(open('$O/bench_$w.json')); print(round(d['value']), 'steps/s', d['roofline']['kernel'], round(d['roofline']['avg_us'],1), 'us', d.get('id_match',{}).get('frames_identical'))" 2>/dev/null)"
 done
 for w in crowd crowd-hard-reid c3 target; do for rep in 1 2; do for form in col row; do
-  BTS_LAP_FORM=$form timeout 600 python bench.py --workload $w --no-cpu --no-export --steps 200 > $O/lap_${w}_${form}_$rep.json 2>/dev/null
+  BTS_LAP_FORM=$form timeout 600 python bench.py --forms default --workload $w --no-cpu --no-export --steps 200 > $O/lap_${w}_${form}_$rep.json 2>/dev/null
   echo "$w BTS_LAP_FORM=$form rep $rep: $(python -c "import json; d=json.load(open('$O/lap_${w}_${form}_$rep.json')); print(round(d['value']), 'steps/s; k_lap stage 1', d['lap']['stage1_us'], 'us')" 2>/dev/null)"
 done; done; done
 if [ -f ab/trace.so ]; then BTS_LIB_PATH=$PWD/ab/trace.so timeout 600 python scripts/dbg_laptrace.py crowd c3 target > $O/lap_trace.txt 2>&1; cat $O/lap_trace.txt; fi
@@ -41,7 +41,7 @@ cat $O/tie_mode_cost.txt
 rm -f gpurun_out/final/pmc_traffic.txt; bash scripts/gpu_pmc_traffic.sh target c2 > $O/pmc.log 2>&1; cp gpurun_out/final/pmc_traffic.txt $O/pmc_traffic.txt 2>/dev/null
 python scripts/pmc_to_json.py $O/pmc_traffic.txt && python scripts/kernel_hashes.py --stamp profiles/pmc_traffic.json bot-sort-onnx-tensorrt_amd/libbotsort_hip.so "$(cat $O/../commit.txt 2>/dev/null || echo HEAD)"; cp profiles/pmc_traffic.json $O/pmc_traffic.json; head -c 600 $O/pmc_traffic.json
 for w in target crowd; do for h in 15 31 63 127; do
-  BTS_LAP_HELPERS=$h timeout 600 python bench.py --workload $w --no-cpu --no-export --steps 200 > $O/helpers_${w}_$h.json 2>/dev/null
+  BTS_LAP_HELPERS=$h timeout 600 python bench.py --forms default --workload $w --no-cpu --no-export --steps 200 > $O/helpers_${w}_$h.json 2>/dev/null
   echo "$w BTS_LAP_HELPERS=$h: $(python -c "import json; d=json.load(open('$O/helpers_${w}_$h.json')); print(round(d['value']), 'steps/s; k_lap stage 1', d['lap']['stage1_us'], 'us')" 2>/dev/null)"
 done; done
 # config 5's arithmetic mode: what the float32 state / binary16 costs change in time and in HBM traffic at 16384 x 4096 x 384

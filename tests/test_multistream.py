@@ -88,7 +88,9 @@ def test_bench_two_ranks_run_the_product(tmp_path):
     site.mkdir()
     # every python process of the spawn tree imports the emulation prelude first (sitecustomize is imported at start-up)
     (site / "sitecustomize.py").write_text("import tests.hip_emu.emu_prelude\n")
-    env = dict(os.environ, BTS_LIB_PATH=os.path.join(EMU, "libbotsort_emu.so"),
+    # (--forms auto, the default, runs the execution-form selection in a child process per rank: here with ONE candidate and few
+    #  frames -- the emulator takes a second per step)
+    env = dict(os.environ, BTS_LIB_PATH=os.path.join(EMU, "libbotsort_emu.so"), BTS_TUNE_ONLY="merge_early", BTS_TUNE_FRAMES="8",
                PYTHONPATH=os.pathsep.join([str(site), REPO] + ([os.environ["PYTHONPATH"]] if os.environ.get("PYTHONPATH") else [])))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
@@ -102,6 +104,11 @@ def test_bench_two_ranks_run_the_product(tmp_path):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3
     assert d["config"]["streams"] == 2 and d["config"]["spawn"] == "self-spawned ranks" and d["config"]["oversubscribed"] is True
     assert d["value"] > 0 and d["roofline"]["step"]["us_per_step"] > 0
+    # the form selection ran (rank 0's table is in the line): the candidate's results were bit-identical to the default forms'
+    assert d["config"]["forms"]["mode"] == "auto" and "in_effect" in d["config"]["forms"]
+    sel = {m["name"]: m for m in d["form_selection"]["table"]}
+    assert sel["default"]["eligible"] and sel["merge_early"]["identical"] is True and sel["merge_early"]["errors"] == 0, d["form_selection"]
+    assert d["form_selection"]["crashed"] == []
     im = d["id_match"]
     assert "error" not in im, im
     assert im["streams"] == 2 and len(im["frames_identical_per_stream"]) == 2
