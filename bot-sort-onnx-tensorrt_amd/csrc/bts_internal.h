@@ -139,12 +139,21 @@ struct bts_lap_work {
     double *dist = nullptr;      // [m_cap] tentative distances of a search
     int32_t *pred = nullptr;     // [m_cap] predecessor row of a column in the search tree
     int32_t *scanned = nullptr;  // [m_cap]
+    // SELF form of the launch (lap.hip, struct Packed): x_slices > 0 = every helper workgroup has its own copy of the packed-
+    // component arrays (slice k >= 1 at x_* + (k - 1) * x?_cap; slice 0 = the arrays above) and x_order holds every slice's
+    // rank -> component table (slice k at x_order + k * xd_cap)
+    int32_t x_slices = 0, xr_cap = 0, xc_cap = 0, xd_cap = 0, xe_cap = 0;
+    int4 *x_rowinfo = nullptr, *x_cdesc = nullptr;
+    int32_t *x_colid = nullptr, *x_lcol = nullptr, *x_order = nullptr;
+    double *x_cost = nullptr;
     size_t bytes = 0;
 };
 
-size_t bts_lap_work_bytes(int n_cap, int m_cap, int64_t e_cap, int64_t o_cap = 0);
+size_t bts_lap_work_bytes(int n_cap, int m_cap, int64_t e_cap, int64_t o_cap = 0, int self_slices = 0);
 // carve `w` out of a device block of bts_lap_work_bytes() bytes
-void bts_lap_work_carve(bts_lap_work *w, void *block, int n_cap, int m_cap, int64_t e_cap, int64_t o_cap = 0);
+void bts_lap_work_carve(bts_lap_work *w, void *block, int n_cap, int m_cap, int64_t e_cap, int64_t o_cap = 0, int self_slices = 0);
+// helper workgroups bts_lap_enqueue launches per problem (`helpers` < 0: automatic, from the problem's row capacity)
+int bts_lap_helpers_for(int n_max, int helpers);
 
 // Enqueue: dense cost[n x m] (leading dimension ld, live sizes in dims[0], dims[1] on device,
 // bounded by n_max/m_max known to the host) -> x[n], y[m].

@@ -318,11 +318,37 @@ __device__ __forceinline__ bool wave_exscan_lds(const int32_t *src, int len, int
     return over;
 }
 
+// ---- SELF preparation (bts_lap_work::x_slices > 0, BTS_LAP_SELF=1 when a tracker is created; NOT yet measured) -----------------
+// The classic launch has workgroup 0 prepare the packed components and hand them to the helper workgroups through memory:
+// an agent-scope release, a flag the helpers poll, an acquire, and a cold re-read of the packed arrays on other compute units
+// -- a fixed cost of the launch, and the one hand-written protocol BETWEEN workgroups on the step's critical path.  In the SELF
+// form every workgroup of the launch runs the (LDS) preparation itself, at the same time, exports the packed components into
+// its OWN slice of the work area and solves its share of them: nothing is exchanged between workgroups.  Which components a
+// workgroup's wavefronts take must not depend on the order its atomics happened to run in, so a component is named by what
+// every workgroup agrees on -- the smallest global row id it contains: the components are ranked by that id (bitmap + prefix
+// popcount in LDS), rank r goes to wavefront r mod (wavefronts of the launch), exactly the classic round-robin.  Only for
+// problems the tracker issues (`fresh`: x / y preset) and only while the LDS preparation takes the problem; whenever that one
+// gives up (every workgroup reaches the same verdict from the same edge list) the launch continues in the classic form.
+struct Packed {                      // the packed-component arrays of one slice
+    int4 *rowinfo, *cdesc;
+    int32_t *colid, *csr_lcol, *order;
+    double *csr_cost;
+};
+__device__ __forceinline__ Packed packed_of(const bts_lap_work &w, int xw) {
+    Packed p;
+    if (xw <= 0) { p.rowinfo = w.rowinfo; p.cdesc = w.cdesc; p.colid = w.colid; p.csr_lcol = w.csr_lcol; p.csr_cost = w.csr_cost; p.order = w.x_order; return p; }
+    const size_t k = (size_t)(xw - 1);
+    p.rowinfo = w.x_rowinfo + k * (size_t)w.xr_cap; p.cdesc = w.x_cdesc + k * (size_t)w.xd_cap; p.colid = w.x_colid + k * (size_t)w.xc_cap;
+    p.csr_lcol = w.x_lcol + k * (size_t)w.xe_cap; p.csr_cost = w.x_cost + k * (size_t)w.xe_cap; p.order = w.x_order + (k + 1) * (size_t)w.xd_cap;
+    return p;
+}
+
 // second half of the SMALL preparation, for one tail layout: slots -> components -> packed export
 template <int EC, bool CROWD, class Tail>
 __device__ __forceinline__ int small_tail(const LapArgs &A, SmallHead &H, Tail &L, int32_t *tab, int EH, int n, bool cached,
-                                          const int (&hs)[EC], const double (&hcost)[EC]) {
+                                          const int (&hs)[EC], const double (&hcost)[EC], int xw) {
     const bts_lap_work &w = A.w;
+    const Packed pk = packed_of(w, xw);
     const int tid = threadIdx.x, nth = blockDim.x;
     for (int h = tid; h < EH; h += nth) {                 // dense slots; the table entry becomes FIRST | slot
         const int i = H.hr[h], j = H.hc[h];
@@ -391,16 +417,16 @@ __device__ __forceinline__ int small_tail(const LapArgs &A, SmallHead &H, Tail &
         const int c = L.comp(s), deg = L.rptr[s];
         const int pos = atomicAdd(&cur_r[c], 1), e0 = atomicAdd(&ecur[c], deg);
         cursor[s] = e0;
-        w.rowinfo[pos] = make_int4(L.arow(s), e0, e0 + deg, 0);
+        pk.rowinfo[pos] = make_int4(L.arow(s), e0, e0 + deg, 0);
     }
     for (int s = tid; s < MA; s += nth) {
         const int c = L.ccomp(s), pos = atomicAdd(&cur_c[c], 1);
         L.ccomp(s) = (uint16_t)(pos - L.ccp[c]);          // from here on: the column's lane inside its component
-        w.colid[pos] = L.acol(s);
+        pk.colid[pos] = L.acol(s);
     }
     for (int c = tid; c <= C; c += nth) {                 // (entry C: the end of the last component's blocks)
         const int r = c < C ? L.crp[c + 1] - L.crp[c] : 0, cn = c < C ? L.ccp[c + 1] - L.ccp[c] : 0, ne = c < C ? L.ecnt[c] : 0;
-        w.cdesc[c] = make_int4(L.crp[c], L.ccp[c], (r > 255 ? 255 : r) | ((cn > 255 ? 255 : cn) << 8) | ((ne > 0x7fff ? 0x7fff : ne) << 16), ebase[c]);
+        pk.cdesc[c] = make_int4(L.crp[c], L.ccp[c], (r > 255 ? 255 : r) | ((cn > 255 ? 255 : cn) << 8) | ((ne > 0x7fff ? 0x7fff : ne) << 16), ebase[c]);
     }
     TR(w, 6);
     if (!cached) __syncthreads();                         // (w.hard[] is read back below: its stores must have landed)
@@ -410,22 +436,46 @@ __device__ __forceinline__ int small_tail(const LapArgs &A, SmallHead &H, Tail &
         for (int k = 0; k < EC; ++k)
             if (hs[k] >= 0) {
                 const int pos = atomicAdd(&cursor[H.hr[hs[k]]], 1);
-                w.csr_lcol[pos] = L.ccomp(H.hc[hs[k]]);
-                w.csr_cost[pos] = hcost[k];
+                pk.csr_lcol[pos] = L.ccomp(H.hc[hs[k]]);
+                pk.csr_cost[pos] = hcost[k];
             }
     } else {
         for (int h = tid; h < EH; h += nth) {
             const int pos = atomicAdd(&cursor[H.hr[h]], 1);
-            w.csr_lcol[pos] = L.ccomp(H.hc[h]);
-            w.csr_cost[pos] = w.e_cost[RLX(&w.hard[h])];
+            pk.csr_lcol[pos] = L.ccomp(H.hc[h]);
+            pk.csr_cost[pos] = w.e_cost[RLX(&w.hard[h])];
         }
     }
-    if (tid == 0) { RST(&w.hdr[H_COMPS], C); RST(&w.hdr[H_HARD], C); RST(&w.hdr[H_MODE], 1); RST(&w.hdr[H_NH], EH); }
+    if (tid == 0) { RST(&w.hdr[H_COMPS], C); RST(&w.hdr[H_HARD], C); RST(&w.hdr[H_MODE], xw >= 0 ? 3 : 1); RST(&w.hdr[H_NH], EH); }      // (mode 3: SELF form)
+    if (xw >= 0) {
+        // SELF form: rank -> component, by the smallest global row id of each component (see Packed).  Everything of the tail is
+        // dead except comp() / arow(): cmin and the bitmap live in parent[], the word prefix in rptr[] (+ a throw-away copy in crp[])
+        static_assert(Tail::kNodes >= 2 * 2048 && Tail::kEdges >= 2048, "the ranking borrows parent[] (2 x 2048 words) and rptr[] (2049)");
+        int32_t *cmin = L.parent, *bm = L.parent + 2048, *pre = L.rptr;
+        const int nwords = (n + 31) >> 5;                 // (n + m <= TABLE_CAP <= 65535: at most 2048 words)
+        bscan::lds_barrier();                             // the export above is done with cursor[] (= parent[])
+        for (int c = tid; c < C; c += nth) cmin[c] = 0x7fffffff;
+        for (int k = tid; k < nwords; k += nth) bm[k] = 0;
+        bscan::lds_barrier();
+        for (int s = tid; s < NA; s += nth) atomicMin(&cmin[L.comp(s)], (int)L.arow(s));
+        bscan::lds_barrier();
+        for (int c = tid; c < C; c += nth) atomicOr(&bm[cmin[c] >> 5], (int)(1u << (cmin[c] & 31)));
+        bscan::lds_barrier();
+        for (int k = tid; k < nwords; k += nth) pre[k] = __popc((unsigned)bm[k]);
+        bscan::lds_barrier();
+        if (tid < 64) wave_exscan_lds(pre, nwords, pre, pre, 0x7fffffff, tid);
+        bscan::lds_barrier();
+        for (int c = tid; c < C; c += nth) {
+            const int id = cmin[c], r = pre[id >> 5] + __popc((unsigned)bm[id >> 5] & ((1u << (id & 31)) - 1u));
+            pk.order[r] = c;
+        }
+    }
     TR(w, 7);
     return 0;
 }
 
-template <int EC, bool CROWD> __device__ __forceinline__ int small_pipeline(const LapArgs &A, char *lds, int E, int n, int m, int32_t *tmp) {
+// xw: -1 = classic (this is workgroup 0, the only one that prepares); >= 0 = SELF form, this workgroup's slice (0 = workgroup 0)
+template <int EC, bool CROWD> __device__ __forceinline__ int small_pipeline(const LapArgs &A, char *lds, int E, int n, int m, int32_t *tmp, int xw) {
     constexpr int EH_MAX = CROWD ? SM_EH_MAX : SM_EH;      // (the row form keeps the one layout of round 2)
     const bts_lap_work &w = A.w;
     const int tid = threadIdx.x, nth = blockDim.x;
@@ -460,7 +510,7 @@ template <int EC, bool CROWD> __device__ __forceinline__ int small_pipeline(cons
         if (tab[i] == 1 && tab[n + j] == 1) { A.x[i] = j; A.y[j] = i; return -1; }
         const int h = atomicAdd(&H.EH, 1);
         if (h < EH_MAX) { H.hr[h] = (uint16_t)i; H.hc[h] = (uint16_t)j; }
-        w.hard[h] = e;                                    // (the queue of the global-memory form, should it take over)
+        if (xw <= 0) w.hard[h] = e;                       // (the queue of the global-memory form, should it take over: workgroup 0's)
         return h;
     };
     if (cached) {
@@ -477,6 +527,7 @@ template <int EC, bool CROWD> __device__ __forceinline__ int small_pipeline(cons
         // Too many non-trivial edges for the LDS form: hand over to the global-memory form WITHOUT redoing the degree
         // count and the isolated pairs there (three passes of global atomics): its queue w.hard[] is filled, and the
         // degrees of the rows / columns it will touch are copied out of the LDS table.
+        if (xw > 0) return -1;                            // (SELF form, a helper: workgroup 0 carries on alone, classic hand-over)
         auto publish = [&](int i, int j) {
             if (i < 0 || (tab[i] == 1 && tab[n + j] == 1)) return;
             RST(&w.deg[i], tab[i]); RST(&w.cdeg[j], tab[n + j]);
@@ -493,8 +544,8 @@ template <int EC, bool CROWD> __device__ __forceinline__ int small_pipeline(cons
 #pragma unroll
     for (int k = 0; k < EC; ++k) hcost[k] = hs[k] >= 0 ? w.e_cost[tid + k * nth] : 0.0;      // consumed by the export at the very end
     PSTAT(EH <= SM_EH ? LS_PREP_A : LS_PREP_B);
-    if (!CROWD || EH <= SM_EH) return small_tail<EC, CROWD>(A, H, *reinterpret_cast<SmallTailA *>(lds + sizeof(SmallHead)), tab, EH, n, cached, hs, hcost);
-    if constexpr (CROWD) return small_tail<EC, CROWD>(A, H, *reinterpret_cast<SmallTailB *>(lds + sizeof(SmallHead)), tab, EH, n, cached, hs, hcost);
+    if (!CROWD || EH <= SM_EH) return small_tail<EC, CROWD>(A, H, *reinterpret_cast<SmallTailA *>(lds + sizeof(SmallHead)), tab, EH, n, cached, hs, hcost, xw);
+    if constexpr (CROWD) return small_tail<EC, CROWD>(A, H, *reinterpret_cast<SmallTailB *>(lds + sizeof(SmallHead)), tab, EH, n, cached, hs, hcost, xw);
     return -2;
 }
 
@@ -675,11 +726,12 @@ static_assert(2 * DN_R * DN_C <= SM_EDGES, "dense block + its edge list share ec
 // inside the search.  Small components (most of them: a few rows) keep a dense rows x columns cost
 // block, so that relaxing from a row is ONE LDS read per lane instead of a walk over the row's edge list.
 // Returns false if the component does not fit.
-__device__ __forceinline__ bool solve_packed(const LapArgs &A, int c, int lane, SmallLds &L) {
+__device__ __forceinline__ bool solve_packed(const LapArgs &A, int c, int lane, SmallLds &L, int xw = 0) {
     const bts_lap_work &w = A.w;
+    const Packed pk = packed_of(w, xw);
     const double limit = A.limit, INF = __builtin_huge_val();
     TRH(w, 13);
-    const int4 d = w.cdesc[c];
+    const int4 d = pk.cdesc[c];
 #ifdef BTS_LAP_TRACE
     if (d.x < 0) return false;
 #endif
@@ -689,9 +741,9 @@ __device__ __forceinline__ bool solve_packed(const LapArgs &A, int c, int lane, 
     const bool dense = r <= DN_R && cn <= DN_C && ne <= DN_R * DN_C;
     LSTAT(LS_PACKED, 1);
     double *ecs = dense ? L.ecost + DN_R * DN_C : L.ecost;
-    const int4 ri = lane < r ? w.rowinfo[rs + lane] : make_int4(0x7fffffff, 0, 0, 0);
-    const int my_col = lane < cn ? w.colid[cs + lane] : 0x7fffffff;
-    for (int e = lane; e < ne; e += 64) { ecs[e] = w.csr_cost[eb + e]; L.ecol[e] = w.csr_lcol[eb + e]; }   // one contiguous block
+    const int4 ri = lane < r ? pk.rowinfo[rs + lane] : make_int4(0x7fffffff, 0, 0, 0);
+    const int my_col = lane < cn ? pk.colid[cs + lane] : 0x7fffffff;
+    for (int e = lane; e < ne; e += 64) { ecs[e] = pk.csr_cost[eb + e]; L.ecol[e] = pk.csr_lcol[eb + e]; }   // one contiguous block
     if (dense)
         for (int k = lane; k < DN_R * DN_C; k += 64) L.ecost[k] = INF;
     // rows in ascending id order (the grouping appended them in arbitrary order)
@@ -807,10 +859,11 @@ __device__ __forceinline__ bool solve_packed(const LapArgs &A, int c, int lane, 
 // i lives in lane i & 63, slot i >> 6); the column state stays one per lane.  Slots are selected with wave-uniform
 // indices through unrolled selects (a runtime-indexed register array would go to scratch).
 template <class T> __device__ __forceinline__ T sel4(const T (&a)[TALL_S], int s) { return s == 0 ? a[0] : s == 1 ? a[1] : s == 2 ? a[2] : a[3]; }
-__device__ __forceinline__ bool solve_packed_tall(const LapArgs &A, int c, int lane, SmallLds &L) {
+__device__ __forceinline__ bool solve_packed_tall(const LapArgs &A, int c, int lane, SmallLds &L, int xw = 0) {
     const bts_lap_work &w = A.w;
+    const Packed pk = packed_of(w, xw);
     const double limit = A.limit, INF = __builtin_huge_val();
-    const int4 d = w.cdesc[c];
+    const int4 d = pk.cdesc[c];
     const int rs = d.x, cs = d.y, r = d.z & 0xff, cn = (d.z >> 8) & 0xff, ne = d.z >> 16, eb = d.w;
     if (r >= TALL_R + 1 || cn > 64 || ne > SM_EDGES) return false;
     LSTAT(LS_TALL, 1);
@@ -818,9 +871,9 @@ __device__ __forceinline__ bool solve_packed_tall(const LapArgs &A, int c, int l
     LSTAT_DECL(steps_here);
     int4 ri[TALL_S];
 #pragma unroll
-    for (int s = 0; s < TALL_S; ++s) ri[s] = lane + 64 * s < r ? w.rowinfo[rs + lane + 64 * s] : make_int4(0x7fffffff, 0, 0, 0);
-    const int my_col = lane < cn ? w.colid[cs + lane] : 0x7fffffff;
-    for (int e = lane; e < ne; e += 64) { L.ecost[e] = w.csr_cost[eb + e]; L.ecol[e] = w.csr_lcol[eb + e]; }
+    for (int s = 0; s < TALL_S; ++s) ri[s] = lane + 64 * s < r ? pk.rowinfo[rs + lane + 64 * s] : make_int4(0x7fffffff, 0, 0, 0);
+    const int my_col = lane < cn ? pk.colid[cs + lane] : 0x7fffffff;
+    for (int e = lane; e < ne; e += 64) { L.ecost[e] = pk.csr_cost[eb + e]; L.ecol[e] = pk.csr_lcol[eb + e]; }
     // rows in ascending id order: rank = number of rows with a smaller id, then every row moves to (rank & 63, rank >> 6)
     int my_row[TALL_S], e_lo[TALL_S], e_hi[TALL_S], rank[TALL_S];
 #pragma unroll
@@ -954,10 +1007,11 @@ constexpr int TALL_NONE = 255;
 constexpr int COLFORM_MIN_ROWS = 16;      // components with more rows than this AND more rows than columns take the column form
 union WaveLds { SmallLds s; TallLds t; };        // one stride for both layouts: wavefronts of a workgroup use either
 
-__device__ __forceinline__ bool solve_tall_cols(const LapArgs &A, int c, int lane, TallLds &L) {
+__device__ __forceinline__ bool solve_tall_cols(const LapArgs &A, int c, int lane, TallLds &L, int xw = 0) {
     const bts_lap_work &w = A.w;
+    const Packed pk = packed_of(w, xw);
     const double limit = A.limit, INF = __builtin_huge_val();
-    const int4 d = w.cdesc[c];
+    const int4 d = pk.cdesc[c];
     const int rs = d.x, cs = d.y, r = d.z & 0xff, cn = (d.z >> 8) & 0xff, ne = d.z >> 16;
     if (r >= TALL_R + 1 || cn > 64 || ne > SM_EDGES) return false;
     LSTAT(LS_TALL, 1);
@@ -968,12 +1022,12 @@ __device__ __forceinline__ bool solve_tall_cols(const LapArgs &A, int c, int lan
 #pragma unroll
     for (int s = 0; s < TALL_S; ++s) {
         const int k = lane + 64 * s;
-        ri[s] = k < r ? w.rowinfo[rs + k] : make_int4(0x7fffffff, 0, 0, 0);
+        ri[s] = k < r ? pk.rowinfo[rs + k] : make_int4(0x7fffffff, 0, 0, 0);
         rk[s] = 0;
         if (k < r) ids[k] = ri[s].x;
     }
     cnt[lane] = 0;
-    const int my_col = lane < cn ? w.colid[cs + lane] : 0x7fffffff;
+    const int my_col = lane < cn ? pk.colid[cs + lane] : 0x7fffffff;
     int crank = 0;
     for (int q = 0; q < cn; ++q) crank += bcast_i(my_col, q) < my_col ? 1 : 0;
     lds_sync();
@@ -985,7 +1039,7 @@ __device__ __forceinline__ bool solve_tall_cols(const LapArgs &A, int c, int lan
     // adjacency by column: count, scan, fill (the order of a column's edges does not matter: one edge per row)
 #pragma unroll
     for (int s = 0; s < TALL_S; ++s)
-        for (int e = ri[s].y; e < ri[s].z; ++e) atomicAdd(&cnt[w.csr_lcol[e]], 1);
+        for (int e = ri[s].y; e < ri[s].z; ++e) atomicAdd(&cnt[pk.csr_lcol[e]], 1);
     lds_sync();
     {
         const int deg = cnt[lane], incl = wave_incl_scan(deg);
@@ -999,8 +1053,8 @@ __device__ __forceinline__ bool solve_tall_cols(const LapArgs &A, int c, int lan
 #pragma unroll
     for (int s = 0; s < TALL_S; ++s)
         for (int e = ri[s].y; e < ri[s].z; ++e) {
-            const int pos = atomicAdd(&cnt[w.csr_lcol[e]], 1);
-            L.ecost[pos] = w.csr_cost[e];
+            const int pos = atomicAdd(&cnt[pk.csr_lcol[e]], 1);
+            L.ecost[pos] = pk.csr_cost[e];
             L.erow[pos] = (uint8_t)rk[s];
         }
     (void)vmin;
@@ -1117,22 +1171,24 @@ struct BigLds {
     uint8_t scanned[BIG_R];
 };
 
-__device__ __forceinline__ bool fits_big(const bts_lap_work &w, int c) {
-    const int4 d = w.cdesc[c], e = w.cdesc[c + 1];
+__device__ __forceinline__ bool fits_big(const bts_lap_work &w, int c, int xw = 0) {
+    const Packed pk = packed_of(w, xw);
+    const int4 d = pk.cdesc[c], e = pk.cdesc[c + 1];
     return e.x - d.x <= BIG_R && e.y - d.y <= BIG_C && e.w - d.w <= BIG_E;
 }
 
-__device__ __forceinline__ void solve_big_cols(const LapArgs &A, int c, int lane, BigLds &L) {
+__device__ __forceinline__ void solve_big_cols(const LapArgs &A, int c, int lane, BigLds &L, int xw = 0) {
     const bts_lap_work &w = A.w;
+    const Packed pk = packed_of(w, xw);
     const double limit = A.limit, INF = __builtin_huge_val();
-    const int4 d = w.cdesc[c], dn = w.cdesc[c + 1];
+    const int4 d = pk.cdesc[c], dn = pk.cdesc[c + 1];
     const int rs = d.x, cs = d.y, r = dn.x - rs, cn = dn.y - cs;
     LSTAT(LS_BIG, 1);
     LSTAT_MAX(LS_GLOBAL_ROWS, r);
     LSTAT_MAX(LS_GLOBAL_COLS, cn);
     int32_t *ids = reinterpret_cast<int32_t *>(L.dist), *cnt = reinterpret_cast<int32_t *>(L.v);
-    for (int k = lane; k < r; k += 64) ids[k] = w.rowinfo[rs + k].x;
-    for (int j = lane; j < cn; j += 64) { L.colid[j] = w.colid[cs + j]; cnt[j] = 0; }
+    for (int k = lane; k < r; k += 64) ids[k] = pk.rowinfo[rs + k].x;
+    for (int j = lane; j < cn; j += 64) { L.colid[j] = pk.colid[cs + j]; cnt[j] = 0; }
     lds_sync();
     for (int k = lane; k < r; k += 64) {          // rows / columns in ascending id order
         const int id = ids[k];
@@ -1147,8 +1203,8 @@ __device__ __forceinline__ void solve_big_cols(const LapArgs &A, int c, int lane
         L.corder[rk] = (uint16_t)j;
     }
     for (int k = lane; k < r; k += 64) {
-        const int4 ri = w.rowinfo[rs + k];
-        for (int e = ri.y; e < ri.z; ++e) atomicAdd(&cnt[w.csr_lcol[e]], 1);
+        const int4 ri = pk.rowinfo[rs + k];
+        for (int e = ri.y; e < ri.z; ++e) atomicAdd(&cnt[pk.csr_lcol[e]], 1);
     }
     lds_sync();
     {
@@ -1162,11 +1218,11 @@ __device__ __forceinline__ void solve_big_cols(const LapArgs &A, int c, int lane
     }
     lds_sync();
     for (int k = lane; k < r; k += 64) {
-        const int4 ri = w.rowinfo[rs + k];
+        const int4 ri = pk.rowinfo[rs + k];
         const uint16_t rk = L.rank[k];
         for (int e = ri.y; e < ri.z; ++e) {
-            const int pos = atomicAdd(&cnt[w.csr_lcol[e]], 1);
-            L.ecost[pos] = w.csr_cost[e];
+            const int pos = atomicAdd(&cnt[pk.csr_lcol[e]], 1);
+            L.ecost[pos] = pk.csr_cost[e];
             L.erow[pos] = rk;
         }
     }
@@ -1245,7 +1301,7 @@ __device__ __forceinline__ void solve_big_cols(const LapArgs &A, int c, int lane
         lds_sync();
     }
     for (int k = lane; k < r; k += 64) {
-        const int gid = w.rowinfo[rs + k].x, mcol = L.xr[L.rank[k]];
+        const int gid = pk.rowinfo[rs + k].x, mcol = L.xr[L.rank[k]];
         A.x[gid] = mcol != BIG_NONE ? L.colid[mcol] : -1;
         if (mcol != BIG_NONE) A.y[L.colid[mcol]] = gid;
     }
@@ -1388,6 +1444,28 @@ template <int EC, bool CROWD = true> __global__ __launch_bounds__(1024) void k_l
     const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63, wid = tid >> 6;
     int C = 0;
     bool solo = false;
+    // SELF form (see Packed): every workgroup of the launch prepares for itself -- a tracker's problem (x / y preset), slices for
+    // every helper, an edge list short enough to stay in registers across the passes (the export then needs no queue in memory)
+    int E0 = 0;
+    bool self = A.fresh && gridDim.y > 1 && w.x_slices >= (int)gridDim.y - 1;
+    if (self) {
+        E0 = RLX(&w.hdr[H_EDGES]);
+        if ((long)E0 > w.e_cap) E0 = (int)w.e_cap;
+        const int n0 = A.dims ? A.dims[0] : A.n_max, m0 = A.dims ? A.dims[1] : A.m_max;
+        self = E0 > LAP_SOLO_EDGES && E0 <= EC * nth && n0 + m0 <= TABLE_CAP;
+        if (!self && blockIdx.y > 0 && E0 <= LAP_SOLO_EDGES) return;      // (workgroup 0 solves a short list alone)
+    }
+    int xw = self ? (int)blockIdx.y : -1;
+    bool wait_for_0 = blockIdx.y > 0 && !self;
+    if (blockIdx.y > 0 && self) {
+        // a helper of the SELF form: the same preparation as workgroup 0, into this workgroup's slice
+        const int n = A.dims ? A.dims[0] : A.n_max, m = A.dims ? A.dims[1] : A.m_max;
+        const int state = small_pipeline<EC, CROWD>(A, lds_raw, E0, n, m, tmp, xw);
+        __syncthreads();
+        if (state == 0) C = RLX(&w.hdr[H_HARD]);          // (this workgroup's own store -- every workgroup stores the same count)
+        else { wait_for_0 = true; xw = -1; }              // the LDS preparation gave up (so did workgroup 0's): classic hand-over
+        __syncthreads();
+    }
     if (blockIdx.y == 0) {
         const int n = A.dims ? A.dims[0] : A.n_max, m = A.dims ? A.dims[1] : A.m_max;
         TR(w, 0);
@@ -1404,7 +1482,8 @@ template <int EC, bool CROWD = true> __global__ __launch_bounds__(1024) void k_l
             __syncthreads();
         }
         int state = E > 0 ? -2 : 0;
-        if (E > 0 && n + m <= TABLE_CAP) state = small_pipeline<EC, CROWD>(A, lds_raw, E, n, m, tmp);
+        if (E > 0 && n + m <= TABLE_CAP) state = small_pipeline<EC, CROWD>(A, lds_raw, E, n, m, tmp, xw);
+        if (self && state < 0) { self = false; xw = -1; }      // (the helpers reached the same verdict and wait for the flag)
         if (state < 0) {                                  // LARGE form: global degree arrays
             __syncthreads();
             const int EH = state == -1 && n + m <= TABLE_CAP ? RLX(&w.hdr[H_NH]) : isolated_pairs(A, E);
@@ -1415,7 +1494,7 @@ template <int EC, bool CROWD = true> __global__ __launch_bounds__(1024) void k_l
         __syncthreads();
         C = RLX(&w.hdr[H_HARD]);
         __syncthreads();
-        if (!solo && tid == 0) {       // publish (stores -> barrier -> one lane: agent release, drain, relaxed flag)
+        if (!solo && !self && tid == 0) {       // publish (stores -> barrier -> one lane: agent release, drain, relaxed flag)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 #if !defined(BTS_HOST_EMU)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1423,7 +1502,7 @@ template <int EC, bool CROWD = true> __global__ __launch_bounds__(1024) void k_l
             RST(&w.hdr[H_READY], 1 + C);
         }
         TR(w, 8);
-    } else {
+    } else if (wait_for_0) {
         TRH(w, 9);
         if (tid == 0) {
             int v = 0;
@@ -1439,19 +1518,21 @@ template <int EC, bool CROWD = true> __global__ __launch_bounds__(1024) void k_l
     if (C == 0) return;
     WaveLds *lds = reinterpret_cast<WaveLds *>(lds_raw);
     const int gw = blockIdx.y * (nth >> 6) + wid, nw = (solo ? 1 : gridDim.y) * (nth >> 6);
-    for (int c = gw; c < C; c += nw) {
+    const int32_t *order = xw >= 0 ? packed_of(w, xw).order : nullptr;      // SELF form: rank -> this workgroup's component id
+    for (int c0 = gw; c0 < C; c0 += nw) {
+        const int c = order ? order[c0] : c0;
         if constexpr (!CROWD) {
-            if (solve_packed(A, c, lane, lds[wid].s) || solve_packed_tall(A, c, lane, lds[wid].s)) continue;
+            if (solve_packed(A, c, lane, lds[wid].s, xw) || solve_packed_tall(A, c, lane, lds[wid].s, xw)) continue;
         } else {
             // one search per row (solve_packed) or per column (solve_tall_cols), whichever side is shorter; small components
             // stay with the row form and its dense cost block
-            const int dz = w.cdesc[c].z, r_ = dz & 0xff, cn_ = (dz >> 8) & 0xff;
-            if (r_ > COLFORM_MIN_ROWS && r_ > cn_ ? solve_tall_cols(A, c, lane, lds[wid].t) : solve_packed(A, c, lane, lds[wid].s)) continue;
-            if (solve_tall_cols(A, c, lane, lds[wid].t)) continue;       // (more than 64 rows but not more rows than columns)
+            const int dz = packed_of(w, xw).cdesc[c].z, r_ = dz & 0xff, cn_ = (dz >> 8) & 0xff;
+            if (r_ > COLFORM_MIN_ROWS && r_ > cn_ ? solve_tall_cols(A, c, lane, lds[wid].t, xw) : solve_packed(A, c, lane, lds[wid].s, xw)) continue;
+            if (solve_tall_cols(A, c, lane, lds[wid].t, xw)) continue;       // (more than 64 rows but not more rows than columns)
             // beyond a wavefront's share of LDS: queued for the end of the loop (the SMALL preparation admits nothing that
             // solve_big_cols cannot take, and never more such components than the queue holds; the LARGE one also feeds the
             // global-memory solver)
-            if (fits_big(w, c)) {
+            if (fits_big(w, c, xw)) {
                 int slot = 0;
                 if (lane == 0) slot = atomicAdd(&s_nbig, 1);
                 slot = __shfl(slot, 0);
@@ -1465,7 +1546,7 @@ template <int EC, bool CROWD = true> __global__ __launch_bounds__(1024) void k_l
         __syncthreads();                              // every wavefront is done with its share of the dynamic LDS
         if (wid == 0) {
             const int nb = s_nbig < BIG_QUEUE ? s_nbig : BIG_QUEUE;
-            for (int k = 0; k < nb; ++k) solve_big_cols(A, s_big[k], lane, *reinterpret_cast<BigLds *>(lds_raw));
+            for (int k = 0; k < nb; ++k) solve_big_cols(A, s_big[k], lane, *reinterpret_cast<BigLds *>(lds_raw), xw);
         }
     }
 #ifdef BTS_LAP_TRACE
@@ -1524,7 +1605,7 @@ __global__ __launch_bounds__(1024) void k_lap_exact(ExactPair P) {
 // ---------------------------------------------------------------------------------------- host
 static size_t carve(size_t &off, size_t bytes) { const size_t o = off; off = bts_align(off + bytes); return o; }
 
-static void layout(bts_lap_work *w, char *base, size_t &off, int n, int m, int64_t e, int64_t ovr) {
+static void layout(bts_lap_work *w, char *base, size_t &off, int n, int m, int64_t e, int64_t ovr, int slices) {
 #define SLOT(field, type, count) { size_t o = carve(off, sizeof(type) * (size_t)(count)); w->field = base ? (type *)(base + o) : nullptr; }
     SLOT(hdr, int32_t, BTS_LAP_HDR_INTS);
     SLOT(e_row, int32_t, e + ovr); SLOT(e_col, int32_t, e + ovr); SLOT(e_cost, double, e + ovr);      // (+ the overrides' own region)
@@ -1538,19 +1619,31 @@ static void layout(bts_lap_work *w, char *base, size_t &off, int n, int m, int64
     SLOT(cdesc, int4, n + 1); SLOT(rowinfo, int4, n); SLOT(rpos, int32_t, n); SLOT(gstart, int32_t, n + 1); SLOT(rlo, int32_t, n); SLOT(rhi, int32_t, n); SLOT(csr_lcol, int32_t, e); SLOT(arow, int32_t, n); SLOT(acol, int32_t, m); SLOT(hard, int32_t, e);
     SLOT(u, double, n); SLOT(v, double, m); SLOT(dist, double, m);
     SLOT(pred, int32_t, m); SLOT(scanned, int32_t, m);
+    // SELF form (bts_lap_work::x_slices): the packed-component arrays once more per helper workgroup, sized by what the LDS
+    // preparation can export (SM_EH_MAX edges, that many + SM_EH / 2 nodes, SM_EH / 2 components), plus the rank -> component
+    // table of every slice incl. workgroup 0's
+    w->x_slices = slices;
+    if (slices > 0) {
+        const int nodes = SM_EH_MAX + SM_C;
+        w->xr_cap = n < nodes ? n : nodes; w->xc_cap = m < nodes ? m : nodes;
+        w->xd_cap = (n < SM_C ? n : SM_C) + 1; w->xe_cap = (int32_t)(e < SM_EH_MAX ? e : SM_EH_MAX);
+        SLOT(x_rowinfo, int4, (size_t)slices * w->xr_cap); SLOT(x_cdesc, int4, (size_t)slices * w->xd_cap);
+        SLOT(x_colid, int32_t, (size_t)slices * w->xc_cap); SLOT(x_lcol, int32_t, (size_t)slices * w->xe_cap);
+        SLOT(x_cost, double, (size_t)slices * w->xe_cap); SLOT(x_order, int32_t, (size_t)(slices + 1) * w->xd_cap);
+    }
 #undef SLOT
 }
 
-size_t bts_lap_work_bytes(int n_cap, int m_cap, int64_t e_cap, int64_t o_cap) {
+size_t bts_lap_work_bytes(int n_cap, int m_cap, int64_t e_cap, int64_t o_cap, int self_slices) {
     bts_lap_work w; size_t off = 0;
-    layout(&w, nullptr, off, n_cap < 1 ? 1 : n_cap, m_cap < 1 ? 1 : m_cap, e_cap < 1 ? 1 : e_cap, o_cap < 0 ? 0 : o_cap);
+    layout(&w, nullptr, off, n_cap < 1 ? 1 : n_cap, m_cap < 1 ? 1 : m_cap, e_cap < 1 ? 1 : e_cap, o_cap < 0 ? 0 : o_cap, self_slices < 0 ? 0 : self_slices);
     return off;
 }
 
-void bts_lap_work_carve(bts_lap_work *w, void *block, int n_cap, int m_cap, int64_t e_cap, int64_t o_cap) {
+void bts_lap_work_carve(bts_lap_work *w, void *block, int n_cap, int m_cap, int64_t e_cap, int64_t o_cap, int self_slices) {
     size_t off = 0;
     n_cap = n_cap < 1 ? 1 : n_cap; m_cap = m_cap < 1 ? 1 : m_cap; e_cap = e_cap < 1 ? 1 : e_cap; o_cap = o_cap < 0 ? 0 : o_cap;
-    layout(w, (char *)block, off, n_cap, m_cap, e_cap, o_cap);
+    layout(w, (char *)block, off, n_cap, m_cap, e_cap, o_cap, self_slices < 0 ? 0 : self_slices);
     w->n_cap = n_cap; w->m_cap = m_cap; w->e_cap = e_cap; w->o_cap = o_cap; w->bytes = off;
 }
 
@@ -1569,6 +1662,11 @@ int bts_lap_init() {      // the solver kernel needs more than the default 64 Ki
         attr_set = true;
     }
     return BTS_OK;
+}
+
+int bts_lap_helpers_for(int n_max, int helpers) {
+    if (helpers >= 0 && helpers <= 255) return helpers;
+    return n_max >= 2048 ? LAP_HELPERS_BIG : LAP_HELPERS;
 }
 
 int bts_lap_form_from_env() { const char *e = bts_form_get("BTS_LAP_FORM"); return e && !strcmp(e, "row") ? 1 : 0; }

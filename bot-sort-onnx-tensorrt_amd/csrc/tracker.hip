@@ -2441,7 +2441,7 @@ struct bts_tracker {
     int lap_helpers = -1;         // BTS_LAP_HELPERS at create: helper workgroups per assignment problem (< 0: automatic)
     int filter_pw = 0;            // BTS_FILTER_PW at create: persistent GEMM workgroups of the pre-filter (0: FILTER_PW)
     int tile_goal = 768;          // BTS_TILE_GOAL at create: workgroup count the stage-1 / duplicate tile heights aim at
-    char forms[256] = "";         // the switches in effect, as bts_tracker_forms reports them
+    char forms[384] = "";         // the switches in effect, as bts_tracker_forms reports them
     bool onepass = false;         // BTS_FILTER_ONEPASS=1 at create: the persistent one-pass pre-filter also for split-K-sized problems
     bool predict_front = false;   // BTS_PREDICT_FRONT=1 at create (with BTS_LISTS_AHEAD): the predict workgroups in the frame's first launch
     bool predict_first = false;   // BTS_PREDICT_FIRST=1 at create: k_filter_i8<.., KF_FIRST> (experiment, see the kernel)
@@ -2604,6 +2604,14 @@ static int derive_sizes(const bts_tracker_config *cfg, Dev &d, int64_t *e_cap_ou
     return BTS_OK;
 }
 
+// BTS_LAP_SELF=1 (read at create): every workgroup of an assignment launch prepares the problem itself (lap.hip, struct Packed);
+// -> the number of extra packed-component slices the two work areas carry (one per helper workgroup the launches will have)
+static int lap_self_slices(const Dev &d) {
+    if (bts_form_get("BTS_LAP_SELF") == nullptr) return 0;
+    const char *e = bts_form_get("BTS_LAP_HELPERS");
+    return bts_lap_helpers_for(d.T, e && atoi(e) >= 0 && atoi(e) <= 255 ? atoi(e) : -1);
+}
+
 int bts_tracker_memory_bytes(const bts_tracker_config *cfg, uint64_t *out_bytes) {
     BTS_REQUIRE(cfg && out_bytes, "null argument");
     BTS_REQUIRE(cfg->max_tracks > 0 && cfg->max_dets > 0 && cfg->feat_dim > 0 && cfg->face_dim >= 0, "capacities");
@@ -2622,7 +2630,8 @@ int bts_tracker_memory_bytes(const bts_tracker_config *cfg, uint64_t *out_bytes)
     size_t off = 0;
     tracker_layout(t, nullptr, off);
     const int64_t o_cap = (cfg->tie_mode && d.Df > 0) ? e_cap : 0;      // overrides of the exact-tie step (tk_edges_xo): their own region
-    off += bts_lap_work_bytes(d.T, d.Mx, e_cap, o_cap) + bts_lap_work_bytes(d.T, d.Mx, e_cap);
+    const int xs = lap_self_slices(d);
+    off += bts_lap_work_bytes(d.T, d.Mx, e_cap, o_cap, xs) + bts_lap_work_bytes(d.T, d.Mx, e_cap, 0, xs);
     if (cfg->tie_mode) {
         size_t nd = 0, ni = 0;
         bts_lap_exact_sizes(d.T, d.Mx, e_cap + o_cap, &nd, &ni);
@@ -2684,17 +2693,18 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
     // the forms in effect (a requested form that the configuration rules out -- the sorted edges with a motion gate, say --
     // does not appear), for bts_tracker_forms
     snprintf(t->forms, sizeof(t->forms), "edges=%s,lists_ahead=%d,merge_early=%d,renorm_fused=%d,cvt_overlap=%d,predict_front=%d,predict_first=%d,lap_form=%s,lap_helpers=%d,list_chunks=%d,"
-             "filter_pw=%d,filter_first16=%d,filter_onepass=%d,filter_guess=%d,tile_goal=%d",
+             "filter_pw=%d,filter_first16=%d,filter_onepass=%d,filter_guess=%d,tile_goal=%d,lap_self=%d",
              d.sorted ? "sorted" : (d.use_grid && d.filter) ? "grid" : "tiles", d.ahead, d.merge_early, d.renorm_fused, t->cvt_overlap ? 1 : 0, t->predict_front ? 1 : 0, t->predict_first ? 1 : 0,
              t->lap_form == 1 ? "row" : "col", t->lap_helpers, d.nch, t->filter_pw > 0 ? t->filter_pw : FILTER_PW, d.chk_first,
-             t->onepass ? 1 : 0, d.f_guess, t->tile_goal);
+             t->onepass ? 1 : 0, d.f_guess, t->tile_goal, lap_self_slices(d) > 0 ? 1 : 0);
     size_t off = 0;
     tracker_layout(t, nullptr, off);
     const int64_t o_cap = (cfg->tie_mode && d.Df > 0) ? e_cap : 0;      // overrides of the exact-tie step (tk_edges_xo): their own region
     const size_t lap_off = off;
-    off += bts_lap_work_bytes(d.T, d.Mx, e_cap, o_cap);
+    const int xs = lap_self_slices(d);
+    off += bts_lap_work_bytes(d.T, d.Mx, e_cap, o_cap, xs);
     const size_t lap3_off = off;
-    off += bts_lap_work_bytes(d.T, d.Mx, e_cap);
+    off += bts_lap_work_bytes(d.T, d.Mx, e_cap, 0, xs);
     size_t xk_off[2][2] = {{0, 0}, {0, 0}}, xk_nd = 0, xk_ni = 0;
     if (cfg->tie_mode) {
         bts_lap_exact_sizes(d.T, d.Mx, e_cap + o_cap, &xk_nd, &xk_ni);
@@ -2712,8 +2722,8 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
     }
     off = 0;
     tracker_layout(t, t->block, off);
-    bts_lap_work_carve(&t->lap, t->block + lap_off, d.T, d.Mx, e_cap, o_cap);
-    bts_lap_work_carve(&t->lap3, t->block + lap3_off, d.T, d.Mx, e_cap);
+    bts_lap_work_carve(&t->lap, t->block + lap_off, d.T, d.Mx, e_cap, o_cap, xs);
+    bts_lap_work_carve(&t->lap3, t->block + lap3_off, d.T, d.Mx, e_cap, 0, xs);
     for (int k = 0; k < 2 && cfg->tie_mode; ++k) {
         t->xk[k].dbl = (double *)(t->block + xk_off[k][0]); t->xk[k].ndbl = xk_nd;
         t->xk[k].ints = (int32_t *)(t->block + xk_off[k][1]); t->xk[k].nints = xk_ni;

@@ -275,6 +275,7 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
  *   BTS_PREDICT_FRONT=1  (with BTS_LISTS_AHEAD) the Kalman predict in the frame's first launch, none in the pre-filter's
  *   BTS_FILTER_GUESS=1   a pre-filter workgroup predicts its FIRST tile, too, to stop at the first checkpoint (prefetch only)
  *   BTS_LAP_FORM=row|col component solvers of the assignment kernel (col: default)
+ *   BTS_LAP_SELF=1       every workgroup of an assignment launch prepares the problem itself (no hand-over between workgroups)
  *   BTS_LAP_HELPERS=n    helper workgroups per assignment problem (default 15 / 63)
  *   BTS_CHUNK_ROWS=n     list jobs split into chunks of n entries (default: unsplit up to 6144 tracks, then 2048)
  *   BTS_FILTER_PW=n      persistent workgroups of the pre-filter (default 512)

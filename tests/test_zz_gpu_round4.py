@@ -121,11 +121,18 @@ def test_config5_mode_halves_the_kalman_bytes_and_is_validated(bts):
     trk.close()
 
 
-@pytest.mark.parametrize("form", ["col", "row"])
+@pytest.mark.parametrize("form", ["col", "row", "col+self", "row+self", "col+self3"])
 @pytest.mark.parametrize("name", ["crowd@c2", "plain"])
 def test_solver_forms_agree(bts, monkeypatch, name, form):
     """k_lap<EC, CROWD>: the column forms (default) and the round-2 row forms (BTS_LAP_FORM=row when the tracker is created)
-    both return the oracle's assignment -- on a plain scene and on a dense crowd (components of 100+ rows)."""
+    both return the oracle's assignment -- on a plain scene and on a dense crowd (components of 100+ rows).  "+self": the SELF
+    form of the launch (BTS_LAP_SELF=1: every workgroup prepares the problem itself, components ranked by their smallest row id
+    and dealt round-robin; "self3": with three helper workgroups only, so that every wavefront takes several components)."""
+    if "self" in form:
+        monkeypatch.setenv("BTS_LAP_SELF", "1")
+        if form.endswith("3"):
+            monkeypatch.setenv("BTS_LAP_HELPERS", "3")
+        form = form.split("+")[0]
     synth = bts.synth
     from oracle import bts_oracle as bo
     if name == "plain":
@@ -136,14 +143,25 @@ def test_solver_forms_agree(bts, monkeypatch, name, form):
     ora = bo.TrackerOracle(faithful_iou=False)
     monkeypatch.setenv("BTS_LAP_FORM", form)
     trk = bts.DeviceTracker(max_tracks=K + 256, max_dets=max(K, M), feat_dim=D)
-    monkeypatch.delenv("BTS_LAP_FORM")
+    want_self = "1" if "BTS_LAP_SELF" in __import__("os").environ else "0"
+    assert trk.forms()["lap_self"] == want_self and trk.forms()["lap_form"] == form
+    for v in ("BTS_LAP_FORM", "BTS_LAP_SELF", "BTS_LAP_HELPERS"):
+        monkeypatch.delenv(v, raising=False)
+    hard, modes = 0, set()
     for f in range(5):
         fr = st.next()
         trk.step(*_dev(fr))
         ora.update_arrays(fr.boxes, fr.scores.astype(np.float64), fr.feats.copy(), None)
         for k in (1, 2, 3):
             assert np.array_equal(trk.stage_result(k)["m"], np.asarray(ora.trace["m%d" % k]).reshape(-1, 2)), (f, k)
+        hard += int(trk.debug_lap(1)[1])
+        if f >= 2:                        # which preparation ran (hdr word 8): 1 = LDS form, classic hand-over; 3 = SELF form
+            mode = int(trk.debug_lap(1)[8])   # (2 = the global-memory preparation took over -- the row forms on the crowd: every
+            assert mode == 2 or mode == (3 if want_self == "1" else 1), (f, trk.debug_lap(1)[:10])      # workgroup of a SELF launch then falls back to the classic hand-over)
+            modes.add(mode)
     assert trk.counts()["errors"] == 0
+    assert hard > 0                       # (non-trivial components were solved, not only isolated pairs)
+    assert (2 in modes) == (name.startswith("crowd") and form == "row"), modes
     trk.close()
 
 
@@ -465,3 +483,35 @@ def test_renorm_fused_changes_no_row(bts, monkeypatch, K, M, D, F, combo):
         assert ref.counts() == exp.counts() and exp.counts()["errors"] == 0
     assert matched > 3 * M
     ref.close(); exp.close()
+
+
+@pytest.mark.parametrize("K,M,side,want", [(3400, 3200, 80.0, "B"), (4096, 1024, 40.0, "classic")])
+def test_lap_self_form_on_dense_crowds(bts, monkeypatch, K, M, side, want):
+    """BTS_LAP_SELF on dense crowds.  "B": 3400 x 3200 on a canvas that leaves ~5 000 non-trivial edges -- more than 4096, so the
+    preparation takes its SECOND LDS layout, and the detections are wide enough (> 3072) for the instantiation that keeps 8 edges
+    per thread in registers: every workgroup prepares the problem itself, ranks the components by their smallest row id and takes
+    every (wavefronts of the launch)-th one.  "classic": 4096 x 1024, 5 300 edges but only 1024 columns -- the list is longer than
+    what the 4-edges-per-thread instantiation keeps in registers, so the SELF form stands back and the launch runs the classic
+    hand-over (every workgroup reaches that verdict from the edge count alone).  Assignments = the oracle's in both."""
+    from oracle import bts_oracle as bo
+    D = 64
+    st = bts.synth.SyntheticStream(K, M, D, seed=77, side_scale=side)
+    ora = bo.TrackerOracle(faithful_iou=False)
+    monkeypatch.setenv("BTS_LAP_SELF", "1")
+    trk = bts.DeviceTracker(max_tracks=K + 512, max_dets=max(K, M), feat_dim=D)
+    monkeypatch.delenv("BTS_LAP_SELF")
+    assert trk.forms()["lap_self"] == "1"
+    most = 0
+    for f in range(3):
+        fr = st.next()
+        trk.step(*_dev(fr))
+        ora.update_arrays(fr.boxes, fr.scores.astype(np.float64), fr.feats.copy(), None)
+        for k in (1, 2, 3):
+            assert np.array_equal(trk.stage_result(k)["m"], np.asarray(ora.trace["m%d" % k]).reshape(-1, 2)), (f, k)
+        h = trk.debug_lap(1)
+        if f >= 1:
+            assert int(h[8]) == (3 if want == "B" else 1), (f, h[:10])
+            most = max(most, int(h[6]))
+    assert most > 4096, most                              # (non-trivial edges: beyond the first LDS layout)
+    assert trk.counts()["errors"] == 0
+    trk.close()
