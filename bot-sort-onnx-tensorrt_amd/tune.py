@@ -41,6 +41,8 @@ CANDIDATES: Tuple[Tuple[str, str, Dict[str, str]], ...] = (
     ("edges", "edges_grid", {"BTS_EDGES_GRID": "1"}),
     ("predict_first", "predict_first", {"BTS_PREDICT_FIRST": "1"}),
     ("filter_guess", "filter_guess", {"BTS_FILTER_GUESS": "1"}),
+    ("filter_first16", "filter_first16_5", {"BTS_I8_FIRST16": "5"}),
+    ("filter_first16", "filter_first16_7", {"BTS_I8_FIRST16": "7"}),
     ("lap_self", "lap_self", {"BTS_LAP_SELF": "1"}),
     ("lap_form", "lap_row", {"BTS_LAP_FORM": "row"}),
     ("lap_helpers", "lap_helpers_31", {"BTS_LAP_HELPERS": "31"}),
