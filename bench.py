@@ -131,12 +131,12 @@ def kernel_model(kern, K, M, D, dense, filt=None):
             return "mfma", 2.0 * 128 * 128 * 128 * filt["k_stages"], "op", I8_MFMA_PEAK_TF
         return "mfma", 2.0 * N * Mh * D, "op", I8_MFMA_PEAK_TF
     table = {
-        # stage-1 matches: Kalman rows read + written, measurement read; det row, smooth r+w, curr w, fp8 shadow w
+        # stage-1 matches: Kalman rows read + written, measurement read; det row, smooth r+w, curr w, int8 shadow w
         "k_mid2": Km * (2 * 72 + 4) * 8 + Km * D * (4 + 4 + 4 + 4 + 2),
         "k_apply23": (M // 8) * ((2 * 72 + 4) * 8 + D * 18),    # the low-score matches of stage 2 (stage 3 is empty in steady state)
         "k_edges1": (N + Mh) * 32 + E * 16 + Mh * 2 * D * 4,    # boxes in, sparse edges out, two feature rows per refined candidate
         "k_lap": E * 16 + 8 * Mh,                               # edge list in, assignment vectors out
-        "prep": M * D * 6 + M * 48,                             # detection rows read (f32) + fp8 shadows written, boxes
+        "prep": M * D * 6 + M * 48,                             # detection rows read (f32) + int8 shadows written, boxes
         "merge": (N + M) * 16,                                  # list entries and per-slot flags
     }
     return "hbm", float(table[kern]), "byte", HBM_PEAK_GBS
