@@ -1386,15 +1386,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     // (NaN / non-positive bounds: nothing is excluded)
                     const int ti0 = t0 > 0.0f ? (int)fminf(t0 * 0.999999f, 2.0e9f) - 1 : (int)0x80000000;
                     const int ti1 = t1 > 0.0f ? (int)fminf(t1 * 0.999999f, 2.0e9f) - 1 : (int)0x80000000;
+                    // Survivors are rare (a 128 x 128 tile holds one or two true matches): the lane's 32 accumulators of a column
+                    // block are first reduced to their maximum (v_max3 trees) and only a wavefront in which some lane's maximum
+                    // reaches its threshold extracts the bits -- the same bits, most of the time none.
+                    int mx0 = acc[0][0][0], mx1 = acc[0][1][0];
 #pragma unroll
                     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            sv[mi] |= (acc[mi][0][r] >= ti0 ? 1u : 0u) << r;
-                            sv[mi] |= (acc[mi][1][r] >= ti1 ? 1u : 0u) << (16 + r);
-                        }
+                        for (int r = 0; r < 16; ++r) { mx0 = max(mx0, acc[mi][0][r]); mx1 = max(mx1, acc[mi][1][r]); }
+                    if (__ballot((mx0 >= ti0) | (mx1 >= ti1)) != 0ull) {
+#pragma unroll
+                        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                sv[mi] |= (acc[mi][0][r] >= ti0 ? 1u : 0u) << r;
+                                sv[mi] |= (acc[mi][1][r] >= ti1 ? 1u : 0u) << (16 + r);
+                            }
+                    }
                 }
-                {
+                if (__ballot((sv[0] | sv[1]) != 0u) != 0ull) {      // (wave-uniform: most wavefronts hold no survivor and skip the extents)
                     // which of this lane's 64 accumulators lie inside the live extents (edge tiles)
                     unsigned vmask0, vmask1;
                     {
