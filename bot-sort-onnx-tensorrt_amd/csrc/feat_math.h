@@ -207,7 +207,13 @@ __device__ __forceinline__ int i8_round(float v) { return (int)__builtin_rintf(f
 
 // x[d] -> q[d] (int8), meta[I8_META].  `gate` = the similarity the appearance term must reach (1 - appearance_thresh).
 // Called by all threads of the row group; inactive groups only take part in the barriers.
-__device__ __forceinline__ void to_i8_row(const float *x, int8_t *q, float *meta, int d, float gate, bool active = true, int first16 = 5) {
+// Shadow layout.  A shadow array keeps its rows ROW-MAJOR (row r = d consecutive bytes: chunk stride I8_STAGE) or -- form
+// BTS_SHADOW_PLANES -- in K-STAGE PLANES: plane s holds the s-th I8_STAGE-byte chunk of every row, rows consecutive inside a
+// plane, so that the 128 rows x 128 bytes a pre-filter tile loads per K stage are (for consecutive table slots) ONE contiguous
+// 16-KiB block instead of 128 pieces a whole feature row apart (a power-of-two stride at the reference's widths).  `q` is the
+// row's first chunk, `cs` the bytes between consecutive chunks of the row: element e lives at q + (e / I8_STAGE) cs + e % I8_STAGE.
+__host__ __device__ inline size_t i8_elem(int e, unsigned cs) { return (size_t)(e / I8_STAGE) * cs + (size_t)(e % I8_STAGE); }
+__device__ __forceinline__ void to_i8_row(const float *x, int8_t *q, float *meta, int d, float gate, bool active = true, int first16 = 5, unsigned cs = I8_STAGE) {
     const int t = row_tid();
     int cst[I8_NCHK];
     i8_checkpoints(d / I8_STAGE, cst, first16);
@@ -238,7 +244,6 @@ __device__ __forceinline__ void to_i8_row(const float *x, int8_t *q, float *meta
     auto add = [&](int b, float qq) { acc[1] += b == 0 ? qq : 0.f; acc[2] += b == 1 ? qq : 0.f; acc[3] += b == 2 ? qq : 0.f;
                                       acc[4] += b == 3 ? qq : 0.f; acc[5] += b == 4 ? qq : 0.f; };
     if (v4) {
-        unsigned *q4 = reinterpret_cast<unsigned *>(q);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int k = t + u * ROW_G;
@@ -254,7 +259,7 @@ __device__ __forceinline__ void to_i8_row(const float *x, int8_t *q, float *meta
                 add(b, dq * dq);
                 w |= (unsigned)(qi & 0xff) << (8 * c);
             }
-            q4[k] = w;
+            *reinterpret_cast<unsigned *>(q + i8_elem(4 * k, cs)) = w;      // (four elements never straddle a chunk)
         }
     } else if (active) {
         for (int k = t; k < d; k += ROW_G) {
@@ -263,7 +268,7 @@ __device__ __forceinline__ void to_i8_row(const float *x, int8_t *q, float *meta
             const float dq = (float)qi * inv, res = e - dq;
             acc[0] += res * res;
             add(bucket(k), dq * dq);
-            q[k] = (int8_t)qi;
+            q[i8_elem(k, cs)] = (int8_t)qi;
         }
     }
     block_sum6(acc);

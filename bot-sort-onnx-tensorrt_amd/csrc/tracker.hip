@@ -93,6 +93,10 @@ struct Dev {
     float gate_sim;                                    // the similarity the appearance term must reach: 1 - appearance_thresh
     int sf32;                                          // kalman_dtype BTS_F32: mean / cov hold float32 elements (same rows, half the bytes)
     int c16;                                           // cost_dtype BTS_F16: association costs rounded to binary16 before thresholds and the solver
+    // shadow layout (feat_math.h, i8_elem): row stride / chunk stride in bytes of the track-side and detection-side shadow arrays,
+    // body [0] and face [1] (row-major: D, 128; BTS_SHADOW_PLANES: 128, rows * 128)
+    unsigned sh_rt[2], sh_ct[2], sh_rd[2], sh_cd[2];
+    int sh_planes;
     int f_guess;                                       // BTS_FILTER_GUESS=1: a workgroup's first tile is already predicted to stop at the first checkpoint
     int chk_first;                                     // first prefix checkpoint of the pre-filter, in sixteenths of the row (feat::i8_checkpoints)
     int32_t use_grid;                                   // BTS_EDGES_GRID=1 at create: stage-1 edges by neighbour search (experimental; wins only for very large frames)
@@ -381,21 +385,21 @@ __device__ __forceinline__ void prep_free(const Dev &d) {
 __device__ __forceinline__ void cvt_body(const Dev &d, long blk) {        // four rows per 1024-thread workgroup
     const long j = blk * 4 + feat::row_group();
     const bool on = j < IN(d, m);
-    feat::to_i8_row(IN(d, feats) + j * d.D, d.det_h + j * d.D, d.det_m + j * feat::I8_META, d.D, d.gate_sim, on, d.chk_first);
-    if (d.Df) feat::to_i8_row(IN(d, face_feats) + j * d.Df, d.dface_h + j * d.Df, d.dface_m + j * feat::I8_META, d.Df, d.gate_sim, on, d.chk_first);
+    feat::to_i8_row(IN(d, feats) + j * d.D, d.det_h + j * d.sh_rd[0], d.det_m + j * feat::I8_META, d.D, d.gate_sim, on, d.chk_first, d.sh_cd[0]);
+    if (d.Df) feat::to_i8_row(IN(d, face_feats) + j * d.Df, d.dface_h + j * d.sh_rd[1], d.dface_m + j * feat::I8_META, d.Df, d.gate_sim, on, d.chk_first, d.sh_cd[1]);
 }
 // A track's latest feature IS a detection row (curr = the matched / born detection's renormalised row, D:492-502): its
 // shadow is that detection's, copied, and so is its record -- which tk_mid1 has by then turned into the record of the
 // UNIT row x / |x| (feat::i8_track_side: a detection row need not arrive unit-norm; the record's slack covers the 1e-7
 // between x / |x| in exact arithmetic and the float32 row).  Called by the 256 threads that handle the row.
-__device__ __forceinline__ void copy_shadow(const int8_t *src_q, const float *src_m, int8_t *dst_q, float *dst_m, int dim) {
+// (src_cs / dst_cs: chunk strides of the two shadow arrays, feat::i8_elem)
+__device__ __forceinline__ void copy_shadow(const int8_t *src_q, const float *src_m, int8_t *dst_q, float *dst_m, int dim, unsigned src_cs, unsigned dst_cs) {
     const int t = feat::row_tid();
     if (dim % 16 == 0) {
-        const uint4 *s4 = reinterpret_cast<const uint4 *>(src_q);
-        uint4 *d4 = reinterpret_cast<uint4 *>(dst_q);
-        for (int k = t; k < dim / 16; k += feat::ROW_G) d4[k] = s4[k];
+        for (int k = t; k < dim / 16; k += feat::ROW_G)          // (sixteen elements never straddle a chunk)
+            *reinterpret_cast<uint4 *>(dst_q + feat::i8_elem(16 * k, dst_cs)) = *reinterpret_cast<const uint4 *>(src_q + feat::i8_elem(16 * k, src_cs));
     } else {
-        for (int k = t; k < dim; k += feat::ROW_G) dst_q[k] = src_q[k];
+        for (int k = t; k < dim; k += feat::ROW_G) dst_q[feat::i8_elem(k, dst_cs)] = src_q[feat::i8_elem(k, src_cs)];
     }
     if (t < feat::I8_META) dst_m[t] = src_m[t];
 }
@@ -1141,14 +1145,14 @@ __global__ __launch_bounds__(256) void k_filter_splitk(Dev d, int m_max, int nti
         const int r = (4 * s + wid) * 8 + prow;
         const int i = bm * FBM + r, j = bn * FBN + r;
         const int sw = (pchunk ^ ((r >> 1) & 7)) * 16;
-        asrc[s] = A + (long)d.pool_slot[i < n ? i : bm * FBM] * Dd + sw;       // rows past the end: any valid row, ignored later
-        bsrc[s] = B + (long)d.hi_idx[j < m ? j : bn * FBN] * Dd + sw;
+        asrc[s] = A + (long)d.pool_slot[i < n ? i : bm * FBM] * (long)d.sh_rt[FACE] + sw;       // rows past the end: any valid row, ignored later
+        bsrc[s] = B + (long)d.hi_idx[j < m ? j : bn * FBN] * (long)d.sh_rd[FACE] + sw;
     }
     auto stage = [&](int buf, int kt) {                  // 8 wavefront loads per stage and wave
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            __builtin_amdgcn_global_load_lds((gbl_void *)(asrc[s] + kt * DBK), (lds_void *)&As2[buf][(4 * s + wid) * 8 * DBK], 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gbl_void *)(bsrc[s] + kt * DBK), (lds_void *)&Bs2[buf][(4 * s + wid) * 8 * DBK], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void *)(asrc[s] + (size_t)kt * d.sh_ct[FACE]), (lds_void *)&As2[buf][(4 * s + wid) * 8 * DBK], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void *)(bsrc[s] + (size_t)kt * d.sh_cd[FACE]), (lds_void *)&Bs2[buf][(4 * s + wid) * 8 * DBK], 16, 0, 0);
         }
     };
     i32x16 acc[2][2];
@@ -1219,6 +1223,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int Dd = FACE ? d.Df : d.D;
     const int8_t *A = FACE ? d.face_h : d.body_h, *B = FACE ? d.dface_h : d.det_h;
     const float *ma = FACE ? d.face_m : d.body_m, *mb = FACE ? d.dface_m : d.det_m;
+    const unsigned rs_a = d.sh_rt[FACE], cs_a = d.sh_ct[FACE], rs_b = d.sh_rd[FACE], cs_b = d.sh_cd[FACE];      // shadow layout (feat::i8_elem)
     const int nbn = (m_max + FBN - 1) / FBN;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid >> 1, wc = wid & 1;
     const int kt_all = Dd / DBK;
@@ -1261,15 +1266,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int s = 0; s < 4; ++s) {
             const int r = (4 * s + wid) * 8 + prow;
             const unsigned sw = (unsigned)((pchunk ^ ((r >> 1) & 7)) * 16);
-            asrc[s] = (unsigned)ia[s] * (unsigned)Dd + sw;
-            bsrc[s] = (unsigned)ib[s] * (unsigned)Dd + sw;
+            asrc[s] = (unsigned)ia[s] * rs_a + sw;
+            bsrc[s] = (unsigned)ib[s] * rs_b + sw;
         }
     };
     auto stage = [&](int buf, int kt) {                  // 8 wavefront loads per stage and wave
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            __builtin_amdgcn_global_load_lds((gbl_void *)(A + ((size_t)asrc[s] + (size_t)(kt * DBK))), (lds_void *)&As2[buf][(4 * s + wid) * 8 * DBK], 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gbl_void *)(B + ((size_t)bsrc[s] + (size_t)(kt * DBK))), (lds_void *)&Bs2[buf][(4 * s + wid) * 8 * DBK], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void *)(A + ((size_t)asrc[s] + (size_t)kt * cs_a)), (lds_void *)&As2[buf][(4 * s + wid) * 8 * DBK], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void *)(B + ((size_t)bsrc[s] + (size_t)kt * cs_b)), (lds_void *)&Bs2[buf][(4 * s + wid) * 8 * DBK], 16, 0, 0);
         }
     };
     // the NEXT tile's first stage (its offsets are derived from the prefetched indices on the spot: the current tile's stay intact)
@@ -1278,8 +1283,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int s = 0; s < 4; ++s) {
             const int r = (4 * s + wid) * 8 + prow;
             const size_t sw = (size_t)((pchunk ^ ((r >> 1) & 7)) * 16);
-            __builtin_amdgcn_global_load_lds((gbl_void *)(A + ((size_t)((unsigned)ia[s] * (unsigned)Dd) + sw)), (lds_void *)&As2[buf][(4 * s + wid) * 8 * DBK], 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gbl_void *)(B + ((size_t)((unsigned)ib[s] * (unsigned)Dd) + sw)), (lds_void *)&Bs2[buf][(4 * s + wid) * 8 * DBK], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void *)(A + ((size_t)((unsigned)ia[s] * rs_a) + sw)), (lds_void *)&As2[buf][(4 * s + wid) * 8 * DBK], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void *)(B + ((size_t)((unsigned)ib[s] * rs_b) + sw)), (lds_void *)&Bs2[buf][(4 * s + wid) * 8 * DBK], 16, 0, 0);
         }
     };
     // survivors a tile may hand to the exact refinement when it stops at a prefix: the true matches it holds anyway
@@ -1867,8 +1872,8 @@ __device__ __forceinline__ void apply_body(const Dev &d, int bid) {
         if (d.Df)
             feat::ema_row(d.face_curr + s * d.Df, d.face_smooth + s * d.Df, IN(d, face_feats) + det * d.Df, d.Df, d.has_face[s] != 0, d.ema_a, d.ema_b);
         if (d.filter) {        // the track's latest feature is this detection's row: so is its shadow
-            copy_shadow(d.det_h + det * d.D, d.det_m + det * feat::I8_META, d.body_h + s * d.D, d.body_m + s * feat::I8_META, d.D);
-            if (d.Df) copy_shadow(d.dface_h + det * d.Df, d.dface_m + det * feat::I8_META, d.face_h + s * d.Df, d.face_m + s * feat::I8_META, d.Df);
+            copy_shadow(d.det_h + det * d.sh_rd[0], d.det_m + det * feat::I8_META, d.body_h + s * d.sh_rt[0], d.body_m + s * feat::I8_META, d.D, d.sh_cd[0], d.sh_ct[0]);
+            if (d.Df) copy_shadow(d.dface_h + det * d.sh_rd[1], d.dface_m + det * feat::I8_META, d.face_h + s * d.sh_rt[1], d.face_m + s * feat::I8_META, d.Df, d.sh_cd[1], d.sh_ct[1]);
         }
         if (threadIdx.x == 0) { d.has_body[s] = 1; if (d.Df) d.has_face[s] = 1; }
         return;
@@ -1922,8 +1927,8 @@ __device__ __forceinline__ void apply_feat4(const Dev &d, int bid) {
         feat::ema_row(d.face_curr + s * d.Df, d.face_smooth + s * d.Df, IN(d, face_feats) + det * d.Df, d.Df, on && d.has_face[s] != 0, d.ema_a, d.ema_b, on);
     if (!on) return;
     if (d.filter) {
-        copy_shadow(d.det_h + det * d.D, d.det_m + det * feat::I8_META, d.body_h + s * d.D, d.body_m + s * feat::I8_META, d.D);
-        if (d.Df) copy_shadow(d.dface_h + det * d.Df, d.dface_m + det * feat::I8_META, d.face_h + s * d.Df, d.face_m + s * feat::I8_META, d.Df);
+        copy_shadow(d.det_h + det * d.sh_rd[0], d.det_m + det * feat::I8_META, d.body_h + s * d.sh_rt[0], d.body_m + s * feat::I8_META, d.D, d.sh_cd[0], d.sh_ct[0]);
+        if (d.Df) copy_shadow(d.dface_h + det * d.sh_rd[1], d.dface_m + det * feat::I8_META, d.face_h + s * d.sh_rt[1], d.face_m + s * feat::I8_META, d.Df, d.sh_cd[1], d.sh_ct[1]);
     }
     if (feat::row_tid() == 0) { d.has_body[s] = 1; if (d.Df) d.has_face[s] = 1; }
 }
@@ -2184,8 +2189,8 @@ __device__ __forceinline__ void birth_body(const Dev &d, int k) {
         d.face_curr[s * d.Df + c] = v; d.face_smooth[s * d.Df + c] = v;
     }
     if (d.filter) {
-        copy_shadow(d.det_h + det * d.D, d.det_m + det * feat::I8_META, d.body_h + s * d.D, d.body_m + s * feat::I8_META, d.D);
-        if (d.Df) copy_shadow(d.dface_h + det * d.Df, d.dface_m + det * feat::I8_META, d.face_h + s * d.Df, d.face_m + s * feat::I8_META, d.Df);
+        copy_shadow(d.det_h + det * d.sh_rd[0], d.det_m + det * feat::I8_META, d.body_h + s * d.sh_rt[0], d.body_m + s * feat::I8_META, d.D, d.sh_cd[0], d.sh_ct[0]);
+        if (d.Df) copy_shadow(d.dface_h + det * d.sh_rd[1], d.dface_m + det * feat::I8_META, d.face_h + s * d.sh_rt[1], d.face_m + s * feat::I8_META, d.Df, d.sh_cd[1], d.sh_ct[1]);
     }
 }
 
@@ -2592,6 +2597,15 @@ static int derive_sizes(const bts_tracker_config *cfg, Dev &d, int64_t *e_cap_ou
     // BTS_MERGE_EARLY=1 (read at create): tk_merge's jobs in the launch of tk_apply23 (tk_apply23_merge)
     d.merge_early = bts_form_get("BTS_MERGE_EARLY") != nullptr ? 1 : 0;
     d.renorm_fused = bts_form_get("BTS_RENORM_FUSED") != nullptr ? 1 : 0;
+    {   // BTS_SHADOW_PLANES=1 (read at create): the int8 shadows in K-stage planes (feat_math.h, i8_elem); default row-major
+        const bool planes = bts_form_get("BTS_SHADOW_PLANES") != nullptr && d.filter;
+        const int dim[2] = {d.D, d.Df};
+        d.sh_planes = planes ? 1 : 0;
+        for (int f = 0; f < 2; ++f) {
+            d.sh_rt[f] = planes ? (unsigned)feat::I8_STAGE : (unsigned)dim[f]; d.sh_ct[f] = planes ? (unsigned)d.T * feat::I8_STAGE : (unsigned)feat::I8_STAGE;
+            d.sh_rd[f] = planes ? (unsigned)feat::I8_STAGE : (unsigned)dim[f]; d.sh_cd[f] = planes ? (unsigned)d.Mx * feat::I8_STAGE : (unsigned)feat::I8_STAGE;
+        }
+    }
     d.sf32 = cfg->kalman_dtype == BTS_F32 ? 1 : 0;
     d.c16 = cfg->cost_dtype == BTS_F16 ? 1 : 0;
     if (cfg->tie_mode) {
@@ -2703,10 +2717,10 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
     // the forms in effect (a requested form that the configuration rules out -- the sorted edges with a motion gate, say --
     // does not appear), for bts_tracker_forms
     snprintf(t->forms, sizeof(t->forms), "edges=%s,lists_ahead=%d,merge_early=%d,renorm_fused=%d,cvt_overlap=%d,predict_front=%d,predict_first=%d,lap_form=%s,lap_helpers=%d,list_chunks=%d,"
-             "filter_pw=%d,filter_first16=%d,filter_onepass=%d,filter_guess=%d,tile_goal=%d,lap_self=%d",
+             "filter_pw=%d,filter_first16=%d,filter_onepass=%d,filter_guess=%d,shadow_planes=%d,tile_goal=%d,lap_self=%d",
              d.sorted ? "sorted" : (d.use_grid && d.filter) ? "grid" : "tiles", d.ahead, d.merge_early, d.renorm_fused, t->cvt_overlap ? 1 : 0, t->predict_front ? 1 : 0, t->predict_first ? 1 : 0,
              t->lap_form == 1 ? "row" : "col", t->lap_helpers, d.nch, t->filter_pw > 0 ? t->filter_pw : FILTER_PW, d.chk_first,
-             t->onepass ? 1 : 0, d.f_guess, t->tile_goal, lap_self_slices(d) > 0 ? 1 : 0);
+             t->onepass ? 1 : 0, d.f_guess, d.sh_planes, t->tile_goal, lap_self_slices(d) > 0 ? 1 : 0);
     size_t off = 0;
     tracker_layout(t, nullptr, off);
     const int64_t o_cap = (cfg->tie_mode && d.Df > 0) ? e_cap : 0;      // overrides of the exact-tie step (tk_edges_xo): their own region

@@ -40,6 +40,7 @@ CANDIDATES: Tuple[Tuple[str, str, Dict[str, str]], ...] = (
     ("edges", "edges_sorted", {"BTS_EDGES_SORTED": "1"}),
     ("edges", "edges_grid", {"BTS_EDGES_GRID": "1"}),
     ("predict_first", "predict_first", {"BTS_PREDICT_FIRST": "1"}),
+    ("shadow_planes", "shadow_planes", {"BTS_SHADOW_PLANES": "1"}),
     ("filter_guess", "filter_guess", {"BTS_FILTER_GUESS": "1"}),
     ("filter_first16", "filter_first16_5", {"BTS_I8_FIRST16": "5"}),
     ("filter_first16", "filter_first16_7", {"BTS_I8_FIRST16": "7"}),

@@ -273,6 +273,8 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
  *   BTS_CVT_OVERLAP=1    the detection-row conversion of a frame runs on a side stream (see bts_tracker_inputs_resident)
  *   BTS_PREDICT_FIRST=1  the Kalman-predict workgroups in front of the pre-filter's persistent workgroups
  *   BTS_PREDICT_FRONT=1  (with BTS_LISTS_AHEAD) the Kalman predict in the frame's first launch, none in the pre-filter's
+ *   BTS_SHADOW_PLANES=1  the int8 shadows of the feature rows in K-stage planes (a pre-filter tile's 128 rows x 128 bytes of a
+ *                        stage are one contiguous block for consecutive slots) instead of row-major
  *   BTS_FILTER_GUESS=1   a pre-filter workgroup predicts its FIRST tile, too, to stop at the first checkpoint (prefetch only)
  *   BTS_LAP_FORM=row|col component solvers of the assignment kernel (col: default)
  *   BTS_LAP_SELF=1       every workgroup of an assignment launch prepares the problem itself (no hand-over between workgroups)

@@ -165,7 +165,7 @@ def test_solver_forms_agree(bts, monkeypatch, name, form):
     trk.close()
 
 
-@pytest.mark.parametrize("first16", [None, "5", "8", "guess", "guess8"])
+@pytest.mark.parametrize("first16", [None, "5", "8", "guess", "guess8", "planes", "planes+guess"])
 def test_one_pass_prefilter_prefix_exits_vs_dense(bts, monkeypatch, first16):
     """The persistent one-pass form of the pre-filter (k_filter_i8: tile walk, LDS-DMA double buffering, prefix checkpoints,
     exit prediction, the next tile's first stage issued under the test) at a size small enough for a CPU emulation:
@@ -174,6 +174,10 @@ def test_one_pass_prefilter_prefix_exits_vs_dense(bts, monkeypatch, first16):
     DENSE frame by frame, for the round-2 checkpoint set (5), the gate-derived default and a late first checkpoint (8)."""
     import torch
     monkeypatch.setenv("BTS_FILTER_ONEPASS", "1")
+    if first16 is not None and first16.startswith("planes"):         # BTS_SHADOW_PLANES: the int8 shadows in K-stage planes (16 planes here)
+        monkeypatch.setenv("BTS_SHADOW_PLANES", "1")
+        first16 = first16[7:] or None
+    planes = "BTS_SHADOW_PLANES" in __import__("os").environ
     guess = first16 is not None and first16.startswith("guess")      # BTS_FILTER_GUESS: a workgroup's first tile is predicted to stop
     if guess:                                                        # at the first checkpoint as well (changes prefetches only); with
         monkeypatch.setenv("BTS_FILTER_GUESS", "1")                  # a late first checkpoint the prediction is sometimes wrong
@@ -186,7 +190,7 @@ def test_one_pass_prefilter_prefix_exits_vs_dense(bts, monkeypatch, first16):
     proto = rng.standard_normal((K, D))
     proto /= np.linalg.norm(proto, axis=1, keepdims=True)
     a = bts.DeviceTracker(max_tracks=384, max_dets=K, feat_dim=D)
-    assert a.forms()["filter_guess"] == ("1" if guess else "0")
+    assert a.forms()["filter_guess"] == ("1" if guess else "0") and a.forms()["shadow_planes"] == ("1" if planes else "0")
     b = bts.DeviceTracker(max_tracks=384, max_dets=K, feat_dim=D, appearance_mode=1)
     early, matched1 = 0, 0
     for f in range(4):
@@ -431,7 +435,8 @@ def test_lists_ahead_changes_no_result(bts, monkeypatch, combo, K, M, D):
     ref.close(); exp.close()
 
 
-@pytest.mark.parametrize("K,M,D,F,combo", [(300, 150, 128, 0, "fused"), (200, 120, 128, 128, "fused"), (300, 150, 128, 0, "fused+merge_early+ahead")])
+@pytest.mark.parametrize("K,M,D,F,combo", [(300, 150, 128, 0, "fused"), (200, 120, 128, 128, "fused"), (300, 150, 128, 0, "fused+merge_early+ahead"),
+                                           (200, 120, 384, 256, "fused+planes"), (200, 120, 384, 0, "planes")])
 def test_renorm_fused_changes_no_row(bts, monkeypatch, K, M, D, F, combo):
     """BTS_RENORM_FUSED=1: the in-place renormalisation (Q8, D:492-514) of a detection row that stage 1 matched moves from tk_mid1
     into the tk_mid2 workgroup that absorbs the row into its track.  Detection rows arrive with norms between 0.5 and 2, so the
@@ -441,14 +446,18 @@ def test_renorm_fused_changes_no_row(bts, monkeypatch, K, M, D, F, combo):
     st = bts.synth.SyntheticStream(K, M, D, seed=77, churn=0.08, face_dim=F)
     rng = np.random.default_rng(5)
     ref = bts.DeviceTracker(max_tracks=K + K // 2, max_dets=max(K, M), feat_dim=D, face_dim=F)
-    monkeypatch.setenv("BTS_RENORM_FUSED", "1")
+    if "fused" in combo:
+        monkeypatch.setenv("BTS_RENORM_FUSED", "1")
+    if "planes" in combo:                     # (shadows in K-stage planes: conversion, copies into the table, births, the split-K pre-filter)
+        monkeypatch.setenv("BTS_SHADOW_PLANES", "1")
     if "merge_early" in combo:
         monkeypatch.setenv("BTS_MERGE_EARLY", "1")
     if "ahead" in combo:
         monkeypatch.setenv("BTS_LISTS_AHEAD", "1")
     exp = bts.DeviceTracker(max_tracks=K + K // 2, max_dets=max(K, M), feat_dim=D, face_dim=F)
-    assert exp.forms()["renorm_fused"] == "1" and ref.forms()["renorm_fused"] == "0"
-    for v in ("BTS_RENORM_FUSED", "BTS_MERGE_EARLY", "BTS_LISTS_AHEAD"):
+    assert exp.forms()["renorm_fused"] == ("1" if "fused" in combo else "0") and ref.forms()["renorm_fused"] == "0"
+    assert exp.forms()["shadow_planes"] == ("1" if "planes" in combo else "0")
+    for v in ("BTS_RENORM_FUSED", "BTS_MERGE_EARLY", "BTS_LISTS_AHEAD", "BTS_SHADOW_PLANES"):
         monkeypatch.delenv(v, raising=False)
     matched = 0
     for f in range(8):
