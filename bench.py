@@ -531,9 +531,9 @@ def main():
     ms.barrier(ddist)
     counts = trk.counts()
     IGNORE = bool(os.environ.get("BTS_BENCH_IGNORE_ERRORS"))       # (kernel timing experiments whose results are meaningless)
-    assert counts["errors"] == 0 or IGNORE, counts
-    for e in extra:
-        assert e[0].counts()["errors"] == 0
+    # a device-side error in the timed region (a truncated frame: table full, edge list overflow, an in-kernel wait that timed
+    # out) does not stop the line from being printed -- it is printed WITH the verdict that the measurement is invalid
+    timed_errors = 0 if IGNORE else int(counts["errors"]) + sum(int(e[0].counts()["errors"]) for e in extra)
     elapsed = ms.max_over_ranks(t1 - t0, ddist)
 
     # ---- behind the timed region: which kernel dominates a step, and its duration (separate event passes)
@@ -638,6 +638,9 @@ def main():
             "algorithmic_bytes_survey_formula": b_survey, "achieved_survey": b_survey / step_s / 1e9, "frac_survey": b_survey / step_s / 1e9 / HBM_PEAK_GBS,
             "algorithmic_bytes_as_built": b_built, "achieved_as_built": b_built / step_s / 1e9, "frac_as_built": b_built / step_s / 1e9 / HBM_PEAK_GBS,
             "formula": "SURVEY.md 8(d) with fp32 element sizes (survey) / float64 Kalman rows, no N x M matrix, int8 shadows (as built): bench.py step_bytes()"}
+        if timed_errors:
+            out["invalid"] = ("device error flags %d raised inside the timed region: frames were truncated, `value` is NOT a measurement "
+                              "of the full step (device message: %s)" % (timed_errors, str(guarded("device_error_message", trk.export, 0))[:300]))
         out["segments_us"] = {k: round(v, 2) for k, v in breakdown.items()}
         if selection is not None:
             # every candidate's us/step and whether its results were bit-identical to the default forms' on the verified frames

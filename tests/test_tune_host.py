@@ -161,3 +161,18 @@ print(json.dumps(r))
     for name in ("default", "lists_ahead", "predict_first"):
         assert by[name]["identical"] is True and by[name]["errors"] == 0, by[name]
     assert "lap_row" not in o["forms"].lower() and "BTS_LAP_FORM" not in o["forms"]
+
+
+def test_rescue_when_the_default_forms_fail(monkeypatch):
+    """The default forms raise a device error: nothing can be verified against them, the first candidate that runs error-free is
+    offered as a rescue and flagged as unverified."""
+    monkeypatch.setattr(tune.time, "perf_counter", lambda: _Double.clock[0])
+    frames = [(None, None, None)] * 12
+
+    def make(forms):
+        t = _Double(forms, lambda f: 100.0)
+        t.err = "BTS_LAP_FORM=row" not in (forms or "")          # everything but the row-form solver fails
+        return t
+    r = tune.select_forms(make, frames, warm=4, verify=3, repeats=1, clone=lambda fr: fr, sync=lambda: None)
+    assert r["forms"] == "BTS_LAP_FORM=row" and r["rescue"] is True and "UNVERIFIED" in r["note"]
+    assert {m["name"]: m for m in r["table"]}["default"]["errors"] == 1
