@@ -1219,13 +1219,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #endif
         return;
     }
-    const int n = __builtin_amdgcn_readfirstlane(d.hdr[H_NPOOL]), m = __builtin_amdgcn_readfirstlane(d.hdr[H_NHI]);     // (scalar registers)
+    // The chain that opens a workgroup -- live extents -> index lists -> first operand stage, three dependent (cold) loads -- is
+    // cut by one link: the index loads of the workgroup's FIRST tile position are issued together with the extents' (indices
+    // clamped to the arrays' capacities, so that the addresses need no extent) and sorted out once the extents are known.
+    const int n_raw = d.hdr[H_NPOOL], m_raw = d.hdr[H_NHI];
     const int Dd = FACE ? d.Df : d.D;
     const int8_t *A = FACE ? d.face_h : d.body_h, *B = FACE ? d.dface_h : d.det_h;
     const float *ma = FACE ? d.face_m : d.body_m, *mb = FACE ? d.dface_m : d.det_m;
     const unsigned rs_a = d.sh_rt[FACE], cs_a = d.sh_ct[FACE], rs_b = d.sh_rd[FACE], cs_b = d.sh_cd[FACE];      // shadow layout (feat::i8_elem)
     const int nbn = (m_max + FBN - 1) / FBN;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid >> 1, wc = wid & 1;
+    const int vt_first = (int)blockIdx.x - (KF_FIRST ? (int)gridDim.x - gemm_blocks : 0);
+    int sia[4], sib[4], sirec = 0, sfa = 0, sfb = 0, sbm = 0, sbn = 0;      // the first position's indices, fetched ahead of the extents
+    if (vt_first < ntiles) {
+        const int vb = xcd_remap(vt_first, ntiles);
+        sbm = vb / nbn; sbn = vb % nbn;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int r = (4 * s + wid) * 8 + (lane >> 3);
+            sia[s] = d.pool_slot[min(sbm * FBM + r, d.T - 1)];
+            sib[s] = d.hi_idx[min(sbn * FBN + r, d.Mx - 1)];
+        }
+        sfa = d.pool_slot[sbm * FBM]; sfb = d.hi_idx[min(sbn * FBN, d.Mx - 1)];
+        sirec = tid < FBM ? d.pool_slot[min(sbm * FBM + tid, d.T - 1)] : d.hi_idx[min(sbn * FBN + (tid - FBM), d.Mx - 1)];
+    }
+    const int n = __builtin_amdgcn_readfirstlane(n_raw), m = __builtin_amdgcn_readfirstlane(m_raw);     // (scalar registers)
     const int kt_all = Dd / DBK;
     int chk[feat::I8_NCHK];
     feat::i8_checkpoints(kt_all, chk, d.chk_first);
@@ -1295,7 +1313,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int vt = next_live((int)blockIdx.x - kf_front, bm, bn);
     if (vt >= ntiles) return;
     int ia[4], ib[4], irec;
-    fetch_idx(bm, bn, ia, ib, irec);
+    if (vt == vt_first) {
+        // the position fetched ahead is live: rows / columns past the extents take the tile's first row / column like in fetch_idx
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int r = (4 * s + wid) * 8 + prow;
+            ia[s] = sbm * FBM + r < n ? sia[s] : sfa;
+            ib[s] = sbn * FBN + r < m ? sib[s] : sfb;
+        }
+        irec = tid < FBM ? (sbm * FBM + tid < n ? sirec : sfa) : (sbn * FBN + (tid - FBM) < m ? sirec : sfb);
+    } else {
+        fetch_idx(bm, bn, ia, ib, irec);
+    }
     set_src(ia, ib);
     const float *mbase = tid < FBM ? ma : mb;
     unsigned my_meta_o = (unsigned)irec * feat::I8_META;                             // this thread's row / column record (element offset)
