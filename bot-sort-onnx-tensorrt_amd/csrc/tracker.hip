@@ -412,8 +412,9 @@ template <bool NEXT = false> __device__ __forceinline__ void predict_body(const 
     if (g < d.T) { d.x1[g] = -1; d.x2[g] = -1; d.x3[g] = -1; }
     if (g < IN(d, m)) { d.y1[g] = -1; d.y2[g] = -1; d.y3[g] = -1; }
     const int r = g >> 3, i = g & 7;                     // 8 lanes per pool row
+    const int s_raw = d.pool_slot[min(r, d.T - 1)];      // (travels with the extent)
     if (r >= d.hdr[NEXT ? H_NPOOL_N : H_NPOOL]) return;
-    const int s = d.pool_slot[r];
+    const int s = s_raw;
     double mi, Pr[8];
     load_row(d, s, i, mi, Pr);
     if (i >= 6 && d.state[s] != BTS_TRACKED) mi = 0.0;   // D:529-532
@@ -530,15 +531,20 @@ __device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, 
     __shared__ float4 srec[ROWS], srec_f[ROWS];       // full-row records of the tile's tracks (split-K form of the pre-filter)
     __shared__ iou::ScreenBox sboxf[ROWS];       // row boxes rounded OUTWARD to 16-bit pixels (conservative overlap pre-test)
     const int32_t *h = d.hdr;
+    const int i0 = by * ROWS, q = bx * CT_COLS + threadIdx.x;
+    // every chain of dependent loads of the tile starts here, before the barrier, so that they overlap:
+    // (1) this thread's detection column, (2) the row boxes, (3) the wavefront's candidate-bitmap words.
+    // Chain (1) does not wait for the extents: the column's list entry is fetched at its capacity-clamped position together
+    // with them (an entry past the end is a stale but valid index, see bts_tracker_create) and discarded if the column is dead
+    const int qc = min(q, d.Mx - 1);
+    const int det_raw = STAGE == 1 ? d.hi_idx[qc] : STAGE == 2 ? d.lo_idx[qc] : d.left_det[qc];
     const int n = STAGE == 1 ? h[H_NPOOL] : STAGE == 2 ? h[H_NR2] : h[H_NUNC];
     const int m = STAGE == 1 ? h[H_NHI] : STAGE == 2 ? h[H_NLO] : h[H_NLEFT];
-    const int i0 = by * ROWS, q = bx * CT_COLS + threadIdx.x;
     const double *abox = STAGE == 1 ? d.pool_tlbr : STAGE == 2 ? d.r2_tlbr : d.unc_tlbr;
-    // every chain of dependent loads of the tile starts here, before the barrier, so that they overlap:
-    // (1) this thread's detection column, (2) the row boxes, (3) the wavefront's candidate-bitmap words
+    const double bb_raw[4] = {d.det_tlbr[det_raw * 4 + 0], d.det_tlbr[det_raw * 4 + 1], d.det_tlbr[det_raw * 4 + 2], d.det_tlbr[det_raw * 4 + 3]};
     const bool live = q < m;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int det = !live ? 0 : STAGE == 1 ? d.hi_idx[q] : STAGE == 2 ? d.lo_idx[q] : d.left_det[q];
+    const int det = live ? det_raw : 0;
     __shared__ unsigned long long scw[CT_COLS / 64][ROWS];      // [wave][row]: candidate lanes of the row (stage 1)
     if (MODE == 1 && STAGE == 1 && !accum) {
         // the bitmap row segment of this wavefront's 64 columns is one aligned 8-byte word: lane u fetches
@@ -554,7 +560,9 @@ __device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, 
             scw[wid][u] = v;
         }
     }
-    const double bb[4] = {d.det_tlbr[det * 4 + 0], d.det_tlbr[det * 4 + 1], d.det_tlbr[det * 4 + 2], d.det_tlbr[det * 4 + 3]};
+    // (a dead column used detection 0's box: its values never reach a result -- `live` guards every use -- so the box fetched
+    //  through the stale entry serves as well)
+    const double bb[4] = {bb_raw[0], bb_raw[1], bb_raw[2], bb_raw[3]};
     float4 crec = make_float4(0.f, 0.f, 0.f, 0.f), crec_f = crec;
     if (STAGE == 1 && MODE == 1 && accum && live) {
         crec = feat::i8_rec(d.det_m + (long)det * feat::I8_META, feat::I8_NCHK);
@@ -1879,13 +1887,14 @@ __device__ __forceinline__ void apply_body(const Dev &d, int bid) {
     if (FEAT) {                                               // ---- feature rows: one workgroup per matched COLUMN
         // (a stage matches at most one row per detection column and there are far fewer columns than table rows:
         // the grid is max_dets workgroups, not max_tracks)
-        const int m = STAGE == 1 ? h[H_NHI] : STAGE == 2 ? h[H_NLO] : h[H_NLEFT];
         const int32_t *ys = STAGE == 1 ? d.y1 : STAGE == 2 ? d.y2 : d.y3;
-        const int xq = bid;
+        const int xq = bid, xqc = min(xq, d.Mx - 1);
+        const int r_raw = ys[xqc], det_raw = cdet[xqc];          // (fetched together with the extents: capacity-clamped positions)
+        const int m = STAGE == 1 ? h[H_NHI] : STAGE == 2 ? h[H_NLO] : h[H_NLEFT];
         if (xq >= m) return;
-        const int r = ys[xq];
+        const int r = r_raw;
         if (r < 0 || r >= n) return;
-        const long s = rslot[r], det = cdet[xq];
+        const long s = rslot[r], det = det_raw;
         if (STAGE == 1 && d.renorm_fused) {
             // this row was skipped by renorm_body (tk_mid1): renormalised here, in place (Q8), by the threads that read it next
             // (thread t rewrites exactly the elements it reads back below); the record turns into the unit row's like there
@@ -1908,10 +1917,11 @@ __device__ __forceinline__ void apply_body(const Dev &d, int bid) {
         return;
     }
     const int g = bid * (int)blockDim.x + threadIdx.x;        // ---- Kalman + lifecycle: 8 lanes per row
-    const int r = g >> 3, i = g & 7;
+    const int r = g >> 3, i = g & 7, rcl = min(r, d.T - 1);
+    const int s_raw = rslot[rcl], xq_raw = xs[rcl];           // (the row's list entries travel with the extent: see bts_tracker_create)
     if (r >= n) return;
-    const int s = rslot[r];
-    const int xq = xs[r];
+    const int s = s_raw;
+    const int xq = xq_raw;
     if (xq < 0) {
         if (i == 0) {
             if (STAGE == 2) d.state[s] = BTS_LOST;                     // D:1582-1586 (tk_merge finds them by x2 < 0)
@@ -2772,6 +2782,17 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
         bts_set_error("device allocation of %zu bytes for the track table failed", t->bytes);
         delete t;
         return BTS_ENOMEM;
+    }
+    // Every index list of the table starts out as zeros and is only ever written with valid indices: a kernel may therefore
+    // issue the loads behind a list entry BEFORE it knows how long the list is this frame (the entry past the end is a stale or
+    // zero, but valid, index; what was loaded through it is discarded once the extent is known) -- one dependent load less at
+    // the head of the chains that open a kernel (edges_tile, apply_body, predict_body)
+    if (hipMemset(t->block, 0, t->bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(t->block);
+        bts_set_error("hipMemset failed");
+        delete t;
+        return BTS_EHIP;
     }
     off = 0;
     tracker_layout(t, t->block, off);
