@@ -267,6 +267,7 @@ def _main():
     ap.add_argument("--frames", type=int, default=36)
     ap.add_argument("--warm", type=int, default=6)
     ap.add_argument("--verify", type=int, default=4)
+    ap.add_argument("--repeats", type=int, default=2)
     ap.add_argument("--skip", default="")
     ap.add_argument("--tracker-args", default="{}")
     a = ap.parse_args()
@@ -298,7 +299,7 @@ def _main():
 
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
-        res = select_forms(make, frames, warm=a.warm, verify=a.verify, skip=[s for s in a.skip.split(",") if s], report=report)
+        res = select_forms(make, frames, warm=a.warm, verify=a.verify, skip=[s for s in a.skip.split(",") if s], report=report, repeats=a.repeats)
     print(json.dumps({"event": "result", "result": res}), flush=True)
 
 
