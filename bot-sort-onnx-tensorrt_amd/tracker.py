@@ -430,8 +430,9 @@ class STrack(BaseTrack):
         return "OT_{}_({}-{})".format(self.track_id, self.start_frame, self.end_frame)   # D:687-688
 
 
-def tracker_memory_bytes(max_tracks: int, max_dets: int, feat_dim: int, face_dim: int = 0, record_costs: bool = False, **options) -> int:
-    """Device bytes a DeviceTracker with these capacities allocates (bts_tracker_memory_bytes: host-only, no GPU needed)."""
+def tracker_memory_bytes(max_tracks: int, max_dets: int, feat_dim: int, face_dim: int = 0, record_costs: bool = False, forms=None, **options) -> int:
+    """Device bytes a DeviceTracker with these capacities (and execution forms) allocates (bts_tracker_memory_bytes[_forms]:
+    host-only, no GPU needed)."""
     lib = _lib.load()
     cfg = _lib.TrackerConfig()
     _lib.check(lib.bts_tracker_default_config(ctypes.byref(cfg)))
@@ -442,7 +443,12 @@ def tracker_memory_bytes(max_tracks: int, max_dets: int, feat_dim: int, face_dim
             raise TypeError("unknown tracker option %r" % k)
         setattr(cfg, k, v)
     out = ctypes.c_uint64()
-    _lib.check(lib.bts_tracker_memory_bytes(ctypes.byref(cfg), ctypes.byref(out)))
+    if isinstance(forms, dict):
+        forms = ",".join("%s=%s" % kv for kv in forms.items())
+    if forms:
+        _lib.check(lib.bts_tracker_memory_bytes_forms(ctypes.byref(cfg), str(forms).encode(), ctypes.byref(out)))
+    else:
+        _lib.check(lib.bts_tracker_memory_bytes(ctypes.byref(cfg), ctypes.byref(out)))
     return int(out.value)
 
 

@@ -138,3 +138,22 @@ def test_binding_argument_counts_match_the_header():
             is_ptr_c = "*" in decl or decl.startswith("bts_stream ")      # (typedef void *bts_stream)
             is_ptr_py = at in pointer_types or hasattr(at, "contents") or at is lib_mod._P
             assert is_ptr_c == is_ptr_py, (name, decl, at)
+
+
+def test_memory_bytes_follow_the_execution_forms():
+    """bts_tracker_memory_bytes_forms (host-only): the forms that carry extra arrays are accounted for -- the second set of
+    detection shadows of the side-stream conversion, the per-helper slices of the self-preparing solver, the slot -> list-index
+    maps of the early merge; forms that only change launches or layouts cost nothing."""
+    pkg = importlib.import_module("bot-sort-onnx-tensorrt_amd")
+    f = pkg.tracker_memory_bytes
+    T, M, D = 11250, 10000, 2048
+    base = f(T, M, D)
+    assert f(T, M, D, forms="") == base and f(T, M, D, forms="BTS_LISTS_AHEAD=1,BTS_PREDICT_FRONT=1,BTS_FILTER_GUESS=1,BTS_SHADOW_PLANES=1,BTS_RENORM_FUSED=1") == base
+    cvt = f(T, M, D, forms="BTS_CVT_OVERLAP=1") - base
+    assert M * D <= cvt <= M * D + 2 * M * 80 + 4096                  # one more [M][D] int8 image + the records (body, face)
+    merge = f(T, M, D, forms={"BTS_MERGE_EARLY": "1"}) - base
+    assert 2 * 4 * (T - 1) <= merge <= 2 * 4 * T + 1024               # two int32 maps over the slots
+    self63 = f(T, M, D, forms="BTS_LAP_SELF=1") - base
+    self15 = f(T, M, D, forms="BTS_LAP_SELF=1,BTS_LAP_HELPERS=15") - base
+    assert 0 < self15 < self63 < 64 * 2 * 400 * 1024                    # (two work areas, <= ~300 KB per helper and area)
+    assert abs(self63 / self15 - 63 / 15) < 0.25
