@@ -150,7 +150,7 @@ def test_memory_bytes_follow_the_execution_forms():
     base = f(T, M, D)
     assert f(T, M, D, forms="") == base and f(T, M, D, forms="BTS_LISTS_AHEAD=1,BTS_PREDICT_FRONT=1,BTS_FILTER_GUESS=1,BTS_SHADOW_PLANES=1,BTS_RENORM_FUSED=1") == base
     cvt = f(T, M, D, forms="BTS_CVT_OVERLAP=1") - base
-    assert M * D <= cvt <= M * D + 2 * M * 80 + 4096                  # one more [M][D] int8 image + the records (body, face)
+    assert M * D <= cvt <= M * D + 2 * M * 80 + 65536                 # one more [M][D] int8 image + the records (body, face)
     merge = f(T, M, D, forms={"BTS_MERGE_EARLY": "1"}) - base
     assert 2 * 4 * (T - 1) <= merge <= 2 * 4 * T + 1024               # two int32 maps over the slots
     self63 = f(T, M, D, forms="BTS_LAP_SELF=1") - base
