@@ -152,7 +152,7 @@ def test_memory_bytes_follow_the_execution_forms():
     cvt = f(T, M, D, forms="BTS_CVT_OVERLAP=1") - base
     assert M * D <= cvt <= M * D + 2 * M * 80 + 65536                 # one more [M][D] int8 image + the records (body, face)
     merge = f(T, M, D, forms={"BTS_MERGE_EARLY": "1"}) - base
-    assert 2 * 4 * (T - 1) <= merge <= 2 * 4 * T + 1024               # two int32 maps over the slots
+    assert 2 * 4 * T - 1024 <= merge <= 2 * 4 * T + 1024              # two int32 maps over the slots
     self63 = f(T, M, D, forms="BTS_LAP_SELF=1") - base
     self15 = f(T, M, D, forms="BTS_LAP_SELF=1,BTS_LAP_HELPERS=15") - base
     assert 0 < self15 < self63 < 64 * 2 * 400 * 1024                    # (two work areas, <= ~300 KB per helper and area)
