@@ -479,11 +479,22 @@ def main():
                                tracker_args=dict(max_tracks=table_rows(K, a.motion_gate), max_dets=max(K, M), feat_dim=D, **opts))
         sel_thread = threading.Thread(target=select, daemon=True)
         sel_thread.start()
-    frames = [next_frame() for _ in range(a.warmup)]
-    timed = [next_frame() for _ in range(a.steps)]
+    if sel_thread is not None:
+        # frames are generated on the host while the selection child has the GPU to itself and uploaded once it is done (an
+        # upload under the child's timed loops would be noise in the candidates' times)
+        host = []
+        for _ in range(a.warmup + a.steps):
+            fr = st.next()
+            host.append((fr.boxes, fr.scores, fr.feats))
+        sel_thread.join()
+        up = [tuple(torch.from_numpy(x).cuda() for x in fr) for fr in host]
+        del host
+        frames, timed = up[:a.warmup], up[a.warmup:]
+    else:
+        frames = [next_frame() for _ in range(a.warmup)]
+        timed = [next_frame() for _ in range(a.steps)]
     forms = "" if a.forms in ("auto", "default", "env") else a.forms
     if sel_thread is not None:
-        sel_thread.join()
         selection = box.get("r")
         if isinstance(selection, dict) and selection.get("forms") and "error" not in selection:
             forms = selection["forms"]

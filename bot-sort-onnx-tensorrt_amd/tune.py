@@ -42,6 +42,8 @@ CANDIDATES: Tuple[Tuple[str, str, Dict[str, str]], ...] = (
     ("predict_first", "predict_first", {"BTS_PREDICT_FIRST": "1"}),
     ("shadow_planes", "shadow_planes", {"BTS_SHADOW_PLANES": "1"}),
     ("filter_guess", "filter_guess", {"BTS_FILTER_GUESS": "1"}),
+    ("filter_pw", "filter_pw_768", {"BTS_FILTER_PW": "768"}),       # more workgroups than resident slots: finer tail, colder tile openings
+    ("filter_pw", "filter_pw_2048", {"BTS_FILTER_PW": "2048"}),     # (one tile per workgroup at the headline size: the hardware's own backfill)
     ("filter_first16", "filter_first16_5", {"BTS_I8_FIRST16": "5"}),
     ("filter_first16", "filter_first16_7", {"BTS_I8_FIRST16": "7"}),
     ("lap_self", "lap_self", {"BTS_LAP_SELF": "1"}),
