@@ -1456,17 +1456,9 @@ template <int EC, bool CROWD = true> __global__ __launch_bounds__(1024) void k_l
         if (!self && blockIdx.y > 0 && E0 <= LAP_SOLO_EDGES) return;      // (workgroup 0 solves a short list alone)
     }
     int xw = self ? (int)blockIdx.y : -1;
-    bool wait_for_0 = blockIdx.y > 0 && !self;
-    if (blockIdx.y > 0 && self) {
-        // a helper of the SELF form: the same preparation as workgroup 0, into this workgroup's slice
-        const int n = A.dims ? A.dims[0] : A.n_max, m = A.dims ? A.dims[1] : A.m_max;
-        const int state = small_pipeline<EC, CROWD>(A, lds_raw, E0, n, m, tmp, xw);
-        __syncthreads();
-        if (state == 0) C = RLX(&w.hdr[H_HARD]);          // (this workgroup's own store -- every workgroup stores the same count)
-        else { wait_for_0 = true; xw = -1; }              // the LDS preparation gave up (so did workgroup 0's): classic hand-over
-        __syncthreads();
-    }
-    if (blockIdx.y == 0) {
+    const bool prepares = blockIdx.y == 0 || self;        // workgroup 0 always; in the SELF form every workgroup (ONE call site of
+    bool wait_for_0 = !prepares;                          //  the preparation: it is the bulk of this kernel's code)
+    if (prepares) {
         const int n = A.dims ? A.dims[0] : A.n_max, m = A.dims ? A.dims[1] : A.m_max;
         TR(w, 0);
         int E = RLX(&w.hdr[H_EDGES]);
@@ -1475,34 +1467,45 @@ template <int EC, bool CROWD = true> __global__ __launch_bounds__(1024) void k_l
         // A short edge list means few components: this workgroup's 16 wavefronts solve them straight away
         // (no release / poll / re-read of the packed problem through memory); the helpers are sent home.
         solo = E <= LAP_SOLO_EDGES;
-        if (solo && tid == 0) RST(&w.hdr[H_READY], 1);
-        if (!A.fresh) {
-            for (int i = tid; i < n; i += nth) { RST(&w.deg[i], 0); A.x[i] = -1; }
-            for (int j = tid; j < m; j += nth) { RST(&w.cdeg[j], 0); A.y[j] = -1; }
-            __syncthreads();
+        if (blockIdx.y == 0) {
+            if (solo && tid == 0) RST(&w.hdr[H_READY], 1);
+            if (!A.fresh) {
+                for (int i = tid; i < n; i += nth) { RST(&w.deg[i], 0); A.x[i] = -1; }
+                for (int j = tid; j < m; j += nth) { RST(&w.cdeg[j], 0); A.y[j] = -1; }
+                __syncthreads();
+            }
         }
         int state = E > 0 ? -2 : 0;
         if (E > 0 && n + m <= TABLE_CAP) state = small_pipeline<EC, CROWD>(A, lds_raw, E, n, m, tmp, xw);
-        if (self && state < 0) { self = false; xw = -1; }      // (the helpers reached the same verdict and wait for the flag)
-        if (state < 0) {                                  // LARGE form: global degree arrays
+        if (self && state < 0) { self = false; xw = -1; }      // (every workgroup reaches the same verdict: classic hand-over)
+        if (blockIdx.y == 0) {
+            if (state < 0) {                              // LARGE form: global degree arrays
+                __syncthreads();
+                const int EH = state == -1 && n + m <= TABLE_CAP ? RLX(&w.hdr[H_NH]) : isolated_pairs(A, E);
+                PSTAT(LS_PREP_LARGE);
+                if (state == -2) PSTAT(LS_PREP_AGAIN);
+                if (EH > 0) large_pipeline(A, EH, tmp, reinterpret_cast<int32_t *>(lds_raw), (int)(LAP_LDS_BYTES / sizeof(int32_t)));
+            }
             __syncthreads();
-            const int EH = state == -1 && n + m <= TABLE_CAP ? RLX(&w.hdr[H_NH]) : isolated_pairs(A, E);
-            PSTAT(LS_PREP_LARGE);
-            if (state == -2) PSTAT(LS_PREP_AGAIN);
-            if (EH > 0) large_pipeline(A, EH, tmp, reinterpret_cast<int32_t *>(lds_raw), (int)(LAP_LDS_BYTES / sizeof(int32_t)));
-        }
-        __syncthreads();
-        C = RLX(&w.hdr[H_HARD]);
-        __syncthreads();
-        if (!solo && !self && tid == 0) {       // publish (stores -> barrier -> one lane: agent release, drain, relaxed flag)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            C = RLX(&w.hdr[H_HARD]);
+            __syncthreads();
+            if (!solo && !self && tid == 0) {       // publish (stores -> barrier -> one lane: agent release, drain, relaxed flag)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 #if !defined(BTS_HOST_EMU)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
-            RST(&w.hdr[H_READY], 1 + C);
+                RST(&w.hdr[H_READY], 1 + C);
+            }
+            TR(w, 8);
+        } else {
+            // a helper of the SELF form: its own preparation, into its own slice
+            __syncthreads();
+            if (state == 0) C = RLX(&w.hdr[H_HARD]);      // (this workgroup's own store -- every workgroup stores the same count)
+            else wait_for_0 = true;                       // the LDS preparation gave up (so did workgroup 0's)
+            __syncthreads();
         }
-        TR(w, 8);
-    } else if (wait_for_0) {
+    }
+    if (wait_for_0) {
         TRH(w, 9);
         if (tid == 0) {
             int v = 0;
