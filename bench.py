@@ -476,6 +476,7 @@ def main():
         def select():
             box["r"] = guarded("form_selection", tune.run_isolated, a.workload, ms_seed(pkg, rank * S), local % ndev,
                                n_frames=int(os.environ.get("BTS_TUNE_FRAMES", "36")), timeout_s=float(os.environ.get("BTS_TUNE_TIMEOUT", "420")),
+                               repeats=int(os.environ.get("BTS_TUNE_REPEATS", "2")),
                                tracker_args=dict(max_tracks=table_rows(K, a.motion_gate), max_dets=max(K, M), feat_dim=D, **opts))
         sel_thread = threading.Thread(target=select, daemon=True)
         sel_thread.start()

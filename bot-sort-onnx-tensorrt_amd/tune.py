@@ -214,7 +214,7 @@ def _strip(table):
 
 # ------------------------------------------------------------------------------------------- isolated (child process)
 def run_isolated(workload: str, seed: int, device: int = 0, n_frames: int = 36, tracker_args: Optional[dict] = None,
-                 timeout_s: float = 600.0, max_restarts: int = 3, python: str = None, extra_env: Optional[dict] = None) -> dict:
+                 timeout_s: float = 600.0, max_restarts: int = 3, python: str = None, extra_env: Optional[dict] = None, repeats: int = 2) -> dict:
     """select_forms on `n_frames` of the seeded synthetic workload in a child process; a candidate that kills the child (or
     hangs it past `timeout_s`) is skipped on the restart.  Returns select_forms' dictionary plus "crashed": [names]."""
     crashed: List[str] = []
@@ -222,7 +222,7 @@ def run_isolated(workload: str, seed: int, device: int = 0, n_frames: int = 36, 
     deadline = time.time() + timeout_s
     for _ in range(max_restarts + 1):
         cmd = [python or sys.executable, os.path.abspath(__file__), "--workload", workload, "--seed", str(seed), "--device", str(device),
-               "--frames", str(n_frames), "--tracker-args", json.dumps(tracker_args or {})] + (["--skip", ",".join(crashed)] if crashed else [])
+               "--frames", str(n_frames), "--repeats", str(repeats), "--tracker-args", json.dumps(tracker_args or {})] + (["--skip", ",".join(crashed)] if crashed else [])
         env = dict(os.environ, **(extra_env or {}))
         running, result, lines = None, None, []
         try:

@@ -90,7 +90,7 @@ def test_bench_two_ranks_run_the_product(tmp_path):
     (site / "sitecustomize.py").write_text("import tests.hip_emu.emu_prelude\n")
     # (--forms auto, the default, runs the execution-form selection in a child process per rank: here with ONE candidate and few
     #  frames -- the emulator takes a second per step)
-    env = dict(os.environ, BTS_LIB_PATH=os.path.join(EMU, "libbotsort_emu.so"), BTS_TUNE_ONLY="merge_early", BTS_TUNE_FRAMES="8",
+    env = dict(os.environ, BTS_LIB_PATH=os.path.join(EMU, "libbotsort_emu.so"), BTS_TUNE_ONLY="merge_early", BTS_TUNE_FRAMES="8", BTS_TUNE_REPEATS="1",
                PYTHONPATH=os.pathsep.join([str(site), REPO] + ([os.environ["PYTHONPATH"]] if os.environ.get("PYTHONPATH") else [])))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)

@@ -149,7 +149,7 @@ def test_isolated_selection_survives_a_candidate_that_kills_the_child(tmp_path):
     code = r'''
 import importlib, json
 tune = importlib.import_module("bot-sort-onnx-tensorrt_amd.tune")
-r = tune.run_isolated("c1", 1234, 0, n_frames=9, timeout_s=1200, tracker_args={"max_tracks": 128, "max_dets": 64, "feat_dim": 2048})
+r = tune.run_isolated("c1", 1234, 0, n_frames=7, repeats=1, timeout_s=1200, tracker_args={"max_tracks": 128, "max_dets": 64, "feat_dim": 2048})
 print(json.dumps(r))
 '''
     r = subprocess.run([sys.executable, "-c", code], cwd=REPO, env=env, capture_output=True, text=True, timeout=1500)
