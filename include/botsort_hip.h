@@ -138,9 +138,10 @@ int bts_lapjv(bts_context *ctx, const double *cost, int n, int m, int ld, double
  * a uniqueness certificate and -- only where it fails, or with force_replay != 0 -- lap 0.4.0's dense JV replayed on the
  * implicit extended matrix (csrc/lap_exact.h).  cost_limit >= 0; (n+m)^2 < 2^31.
  * Cost scale: "tied" means another assignment within an ABSOLUTE 1e-9 of the optimum (lapx::TIE_TOL), chosen for the
- * tracker's costs, which live in [0, 1]; matrices on another scale should be rescaled by the caller (a tolerance that is
- * too tight only costs replays that were not needed -- the replay itself is exact; one that is too loose cannot make the
- * result wrong either: the replay then decides).
+ * tracker's costs, which live in [0, 1]; matrices on another scale should be rescaled by the caller: for much SMALLER
+ * costs the tolerance is loose and only triggers replays that were not needed (the replay is exact); for much LARGER ones
+ * rounding can hide a tie from the certificate, and the result is then the fast solver's optimum (one of the optima, as
+ * bts_lapjv returns it) rather than lap's.
  * info3_host (nullable; synchronises when given): {certificate said "tied", replay ran, error flags (0 = none)}. */
 int bts_lapjv_exact(bts_context *ctx, const double *cost, int n, int m, int ld, double cost_limit,
                     int32_t *x, int32_t *y, int force_replay, int32_t *info3_host, bts_stream stream);
