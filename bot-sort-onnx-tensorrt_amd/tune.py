@@ -214,49 +214,88 @@ def _strip(table):
 
 # ------------------------------------------------------------------------------------------- isolated (child process)
 def run_isolated(workload: str, seed: int, device: int = 0, n_frames: int = 36, tracker_args: Optional[dict] = None,
-                 timeout_s: float = 600.0, max_restarts: int = 3, python: str = None, extra_env: Optional[dict] = None, repeats: int = 2) -> dict:
-    """select_forms on `n_frames` of the seeded synthetic workload in a child process; a candidate that kills the child (or
-    hangs it past `timeout_s`) is skipped on the restart.  Returns select_forms' dictionary plus "crashed": [names]."""
+                 timeout_s: float = 600.0, max_restarts: int = 3, python: str = None, extra_env: Optional[dict] = None, repeats: int = 2,
+                 candidate_timeout_s: float = 90.0, startup_timeout_s: float = 300.0, margin: float = 0.01) -> dict:
+    """select_forms on `n_frames` of the seeded synthetic workload in a child process.  The child's progress lines are read as
+    they come: a candidate that kills the child, or keeps it silent for more than `candidate_timeout_s` (a hang), is blamed and
+    skipped on the restart (the child's start -- interpreter, frames -- gets `startup_timeout_s`).  Returns select_forms'
+    dictionary plus "crashed": [names]; if the selection cannot be completed within `timeout_s`, the best single candidate that
+    WAS measured identical, error-free and faster is returned (marked "partial"), else the defaults."""
+    import queue
+    import threading
     crashed: List[str] = []
     last = None
+    measured: Dict[str, dict] = {}          # name -> its "end" record, over all restarts
     deadline = time.time() + timeout_s
     for _ in range(max_restarts + 1):
         cmd = [python or sys.executable, os.path.abspath(__file__), "--workload", workload, "--seed", str(seed), "--device", str(device),
                "--frames", str(n_frames), "--repeats", str(repeats), "--tracker-args", json.dumps(tracker_args or {})] + (["--skip", ",".join(crashed)] if crashed else [])
         env = dict(os.environ, **(extra_env or {}))
-        running, result, lines = None, None, []
+        running, result, hung = None, None, False
         try:
-            p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
-            try:
-                out, err = p.communicate(timeout=max(5.0, deadline - time.time()))
-            except subprocess.TimeoutExpired:
-                p.kill()
-                out, err = p.communicate()
-                err = (err or "") + "\n[timeout]"
-            for ln in out.splitlines():
+            p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, bufsize=1)
+            q: "queue.Queue" = queue.Queue()
+            err_tail: List[str] = []
+
+            def pump(stream, sink):
+                for ln in stream:
+                    sink(ln)
+                sink(None)
+            threading.Thread(target=pump, args=(p.stdout, q.put), daemon=True).start()
+            threading.Thread(target=pump, args=(p.stderr, lambda ln: err_tail.append(ln) if ln else None), daemon=True).start()
+            quiet_since, limit = time.time(), startup_timeout_s
+            while True:
+                try:
+                    ln = q.get(timeout=1.0)
+                except queue.Empty:
+                    now = time.time()
+                    if now - quiet_since > limit or now >= deadline:
+                        hung = True
+                        p.kill()
+                        break
+                    continue
+                if ln is None:
+                    break
                 if not ln.startswith("{"):
                     continue
                 try:
                     rec = json.loads(ln)
                 except ValueError:
                     continue
-                lines.append(rec)
+                quiet_since, limit = time.time(), candidate_timeout_s * max(1, repeats)
                 if rec.get("event") == "begin":
                     running = rec["name"]
                 elif rec.get("event") == "end":
                     running = None
+                    if "name" in rec:
+                        measured[rec["name"]] = rec
                 elif rec.get("event") == "result":
                     result = rec["result"]
-            last = {"rc": p.returncode, "stderr_tail": (err or "")[-400:]}
+            p.wait(timeout=30)
+            last = {"rc": p.returncode, "hung": hung, "stderr_tail": "".join(err_tail)[-400:]}
         except Exception as e:
             last = {"rc": None, "stderr_tail": "%s: %s" % (type(e).__name__, e)}
         if result is not None:
             result["crashed"] = crashed
             return result
         if running is None or running == "default" or running in crashed or time.time() >= deadline:
-            break                          # (nothing to blame, or the default forms themselves failed: no selection)
+            break                          # (nothing to blame, or the default forms themselves failed, or out of time)
         crashed.append(running)
-    return {"forms": "", "crashed": crashed, "note": "form selection did not complete: the defaults are used", "child": last}
+    # not completed: whatever was measured still counts
+    ref = measured.get("default")
+    best = None
+    if ref and not ref.get("errors"):
+        for name, m in measured.items():
+            if name != "default" and m.get("eligible") and m.get("us_per_step", 0) > 0 and ref["us_per_step"] / m["us_per_step"] > 1.0 + margin:
+                if best is None or m["us_per_step"] < best["us_per_step"]:
+                    best = m
+    out = {"forms": best["forms"] if best else "", "chosen": best["name"] if best else "default", "crashed": crashed, "partial": True,
+           "table": list(measured.values()), "child": last,
+           "note": "form selection did not complete" + (": the best single candidate measured so far is used" if best else ": the defaults are used")}
+    if ref:
+        out["default_us"] = ref.get("us_per_step")
+        out["chosen_us"] = (best or ref).get("us_per_step")
+    return out
 
 
 def _main():
@@ -298,6 +337,8 @@ def _main():
         print(json.dumps(rec), flush=True)
         if rec.get("event") == "begin" and rec.get("name") == os.environ.get("BTS_TUNE_CRASH_AT"):
             os._exit(9)                  # (tests/test_tune_host.py: a candidate that takes the process down)
+        if rec.get("event") == "begin" and rec.get("name") == os.environ.get("BTS_TUNE_HANG_AT"):
+            time.sleep(1e6)              # (... and one that hangs)
 
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):

@@ -176,3 +176,24 @@ def test_rescue_when_the_default_forms_fail(monkeypatch):
     r = tune.select_forms(make, frames, warm=4, verify=3, repeats=1, clone=lambda fr: fr, sync=lambda: None)
     assert r["forms"] == "BTS_LAP_FORM=row" and r["rescue"] is True and "UNVERIFIED" in r["note"]
     assert {m["name"]: m for m in r["table"]}["default"]["errors"] == 1
+
+
+@needs_toolchain
+def test_isolated_selection_survives_a_candidate_that_hangs(tmp_path):
+    """A candidate that never comes back (a kernel spinning on a flag nobody sets): the parent watches the child's progress
+    lines, kills it after `candidate_timeout_s` of silence, blames the candidate that was running and restarts without it."""
+    env = _emu_env(tmp_path, BTS_TUNE_ONLY="lists_ahead,lap_row", BTS_TUNE_HANG_AT="lists_ahead")
+    code = r'''
+import importlib, json
+tune = importlib.import_module("bot-sort-onnx-tensorrt_amd.tune")
+r = tune.run_isolated("c1", 1234, 0, n_frames=7, repeats=1, timeout_s=1200, candidate_timeout_s=30,
+                      tracker_args={"max_tracks": 128, "max_dets": 64, "feat_dim": 2048})
+print(json.dumps(r))
+'''
+    r = subprocess.run([sys.executable, "-c", code], cwd=REPO, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    o = json.loads(r.stdout.strip().splitlines()[-1])
+    assert o["crashed"] == ["lists_ahead"] and not o.get("partial"), o
+    by = {m["name"]: m for m in o["table"]}
+    assert by["lists_ahead"].get("skipped") is True
+    assert by["default"]["identical"] is True and by["lap_row"]["identical"] is True and by["lap_row"]["errors"] == 0
