@@ -584,7 +584,7 @@ def main():
 
     facade = None
     if rank == 0 and world == 1 and S == 1 and not a.no_export and not a.graph and not a.dense and not a.motion_gate:
-        nf = max(16, min(a.steps, 64))
+        nf = max(16, min(a.steps, 64 if K <= 1024 else 24))      # (big workloads: generating a frame on the host takes ~0.4 s)
         facade = guarded("facade", facade_leg, pkg, torch, a.workload, nf, ms_seed(pkg, 0), forms)
         if a.workload == "target":
             facade = {"target": facade, "c2": guarded("facade_c2", facade_leg, pkg, torch, "c2", 4 * nf, ms_seed(pkg, 0))}
