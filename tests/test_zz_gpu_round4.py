@@ -524,3 +524,46 @@ def test_lap_self_form_on_dense_crowds(bts, monkeypatch, K, M, side, want):
     assert most > 4096, most                              # (non-trivial edges: beyond the first LDS layout)
     assert trk.counts()["errors"] == 0
     trk.close()
+
+
+@pytest.mark.parametrize("combo", ["planes", "planes+ahead+merge_early+predict_front+sorted+self"])
+def test_shadow_planes_one_pass_with_churn(bts, monkeypatch, combo):
+    """BTS_SHADOW_PLANES through the persistent one-pass pre-filter (BTS_FILTER_ONEPASS: 4 x 2 tiles, 2 planes) on a stream with
+    births, expiries and re-found tracks -- the shadows are written by the conversion (detections), copied into the table by the
+    matches and the births, and read by the tiles in the plane layout; results = the default layout's and the oracle's."""
+    from oracle import bts_oracle as bo
+    K, M, D = 300, 150, 256
+    monkeypatch.setenv("BTS_FILTER_ONEPASS", "1")
+    ref = bts.DeviceTracker(max_tracks=K + K // 2, max_dets=max(K, M), feat_dim=D)
+    monkeypatch.setenv("BTS_SHADOW_PLANES", "1")
+    for key, env in (("ahead", "BTS_LISTS_AHEAD"), ("merge_early", "BTS_MERGE_EARLY"), ("predict_front", "BTS_PREDICT_FRONT"),
+                     ("sorted", "BTS_EDGES_SORTED"), ("self", "BTS_LAP_SELF")):
+        if key in combo:
+            monkeypatch.setenv(env, "1")
+    exp = bts.DeviceTracker(max_tracks=K + K // 2, max_dets=max(K, M), feat_dim=D)
+    assert exp.forms()["shadow_planes"] == "1" and ref.forms()["shadow_planes"] == "0"
+    for v in ("BTS_FILTER_ONEPASS", "BTS_SHADOW_PLANES", "BTS_LISTS_AHEAD", "BTS_MERGE_EARLY", "BTS_PREDICT_FRONT", "BTS_EDGES_SORTED", "BTS_LAP_SELF"):
+        monkeypatch.delenv(v, raising=False)
+    ora = bo.TrackerOracle(faithful_iou=False)
+    st = bts.synth.SyntheticStream(K, M, D, seed=13, churn=0.1)
+    cands = 0
+    for f in range(8):
+        fr = st.next()
+        ref.step(*_dev(fr)); exp.step(*_dev(fr))
+        ora.update_arrays(fr.boxes, fr.scores.astype(np.float64), fr.feats.copy(), None)
+        for k in (1, 2, 3):
+            a, b = ref.stage_result(k), exp.stage_result(k)
+            assert np.array_equal(a["x"], b["x"]) and np.array_equal(a["y"], b["y"]), (f, k)
+            assert np.array_equal(b["m"], np.asarray(ora.trace["m%d" % k]).reshape(-1, 2)), (f, k)
+        for which in (0, 1):
+            ta, tb = ref.export(which), exp.export(which)
+            for key in INT_KEYS + ("slot",):
+                assert np.array_equal(ta[key], tb[key]), (f, which, key)
+            assert np.array_equal(ta["mean"], tb["mean"]), (f, which)
+        if f >= 1:
+            sa, sb = ref.debug_filter(), exp.debug_filter()
+            assert sa["candidates"] == sb["candidates"] and sa["tiles"] == sb["tiles"] and sa["k_stages"] == sb["k_stages"], (f, sa, sb)
+            cands += sb["candidates"]
+        assert ref.counts() == exp.counts() and exp.counts()["errors"] == 0
+    assert cands > 4 * M // 2
+    ref.close(); exp.close()
