@@ -344,7 +344,7 @@ __device__ __forceinline__ Packed packed_of(const bts_lap_work &w, int xw) {
 }
 
 // second half of the SMALL preparation, for one tail layout: slots -> components -> packed export
-template <int EC, bool CROWD, class Tail>
+template <int EC, bool CROWD, bool SELF, class Tail>
 __device__ __forceinline__ int small_tail(const LapArgs &A, SmallHead &H, Tail &L, int32_t *tab, int EH, int n, bool cached,
                                           const int (&hs)[EC], const double (&hcost)[EC], int xw) {
     const bts_lap_work &w = A.w;
@@ -447,7 +447,7 @@ __device__ __forceinline__ int small_tail(const LapArgs &A, SmallHead &H, Tail &
         }
     }
     if (tid == 0) { RST(&w.hdr[H_COMPS], C); RST(&w.hdr[H_HARD], C); RST(&w.hdr[H_MODE], xw >= 0 ? 3 : 1); RST(&w.hdr[H_NH], EH); }      // (mode 3: SELF form)
-    if (xw >= 0) {
+    if (SELF && xw >= 0) {               // (compiled into the SELF instantiations only: k_lap<EC, CROWD, true>)
         // SELF form: rank -> component, by the smallest global row id of each component (see Packed).  Everything of the tail is
         // dead except comp() / arow(): cmin and the bitmap live in parent[], the word prefix in rptr[] (+ a throw-away copy in crp[])
         static_assert(Tail::kNodes >= 2 * 2048 && Tail::kEdges >= 2048, "the ranking borrows parent[] (2 x 2048 words) and rptr[] (2049)");
@@ -475,7 +475,7 @@ __device__ __forceinline__ int small_tail(const LapArgs &A, SmallHead &H, Tail &
 }
 
 // xw: -1 = classic (this is workgroup 0, the only one that prepares); >= 0 = SELF form, this workgroup's slice (0 = workgroup 0)
-template <int EC, bool CROWD> __device__ __forceinline__ int small_pipeline(const LapArgs &A, char *lds, int E, int n, int m, int32_t *tmp, int xw) {
+template <int EC, bool CROWD, bool SELF> __device__ __forceinline__ int small_pipeline(const LapArgs &A, char *lds, int E, int n, int m, int32_t *tmp, int xw) {
     constexpr int EH_MAX = CROWD ? SM_EH_MAX : SM_EH;      // (the row form keeps the one layout of round 2)
     const bts_lap_work &w = A.w;
     const int tid = threadIdx.x, nth = blockDim.x;
@@ -544,8 +544,8 @@ template <int EC, bool CROWD> __device__ __forceinline__ int small_pipeline(cons
 #pragma unroll
     for (int k = 0; k < EC; ++k) hcost[k] = hs[k] >= 0 ? w.e_cost[tid + k * nth] : 0.0;      // consumed by the export at the very end
     PSTAT(EH <= SM_EH ? LS_PREP_A : LS_PREP_B);
-    if (!CROWD || EH <= SM_EH) return small_tail<EC, CROWD>(A, H, *reinterpret_cast<SmallTailA *>(lds + sizeof(SmallHead)), tab, EH, n, cached, hs, hcost, xw);
-    if constexpr (CROWD) return small_tail<EC, CROWD>(A, H, *reinterpret_cast<SmallTailB *>(lds + sizeof(SmallHead)), tab, EH, n, cached, hs, hcost, xw);
+    if (!CROWD || EH <= SM_EH) return small_tail<EC, CROWD, SELF>(A, H, *reinterpret_cast<SmallTailA *>(lds + sizeof(SmallHead)), tab, EH, n, cached, hs, hcost, xw);
+    if constexpr (CROWD) return small_tail<EC, CROWD, SELF>(A, H, *reinterpret_cast<SmallTailB *>(lds + sizeof(SmallHead)), tab, EH, n, cached, hs, hcost, xw);
     return -2;
 }
 
@@ -1429,7 +1429,7 @@ static_assert(LAP_LDS_BYTES + 4096 + 512 <= 160 * 1024, "k_lap: dynamic + static
 
 struct LapPair { LapArgs p[2]; };     // (indexed by blockIdx.x straight out of the kernel-argument segment)
 
-template <int EC, bool CROWD = true> __global__ __launch_bounds__(1024) void k_lap(LapPair P) {
+template <int EC, bool CROWD = true, bool SELF = false> __global__ __launch_bounds__(1024) void k_lap(LapPair P) {
 #if defined(BTS_HOST_EMU)
     char *const lds_raw = emu::dynamic_lds();
 #else
@@ -1447,7 +1447,7 @@ template <int EC, bool CROWD = true> __global__ __launch_bounds__(1024) void k_l
     // SELF form (see Packed): every workgroup of the launch prepares for itself -- a tracker's problem (x / y preset), slices for
     // every helper, an edge list short enough to stay in registers across the passes (the export then needs no queue in memory)
     int E0 = 0;
-    bool self = A.fresh && gridDim.y > 1 && w.x_slices >= (int)gridDim.y - 1;
+    bool self = SELF && A.fresh && gridDim.y > 1 && w.x_slices >= (int)gridDim.y - 1;      // (SELF = false: the classic launch only)
     if (self) {
         E0 = RLX(&w.hdr[H_EDGES]);
         if ((long)E0 > w.e_cap) E0 = (int)w.e_cap;
@@ -1476,7 +1476,7 @@ template <int EC, bool CROWD = true> __global__ __launch_bounds__(1024) void k_l
             }
         }
         int state = E > 0 ? -2 : 0;
-        if (E > 0 && n + m <= TABLE_CAP) state = small_pipeline<EC, CROWD>(A, lds_raw, E, n, m, tmp, xw);
+        if (E > 0 && n + m <= TABLE_CAP) state = small_pipeline<EC, CROWD, SELF>(A, lds_raw, E, n, m, tmp, xw);
         if (self && state < 0) { self = false; xw = -1; }      // (every workgroup reaches the same verdict: classic hand-over)
         if (blockIdx.y == 0) {
             if (state < 0) {                              // LARGE form: global degree arrays
@@ -1658,6 +1658,10 @@ int bts_lap_enqueue_reset(const bts_lap_work *w, hipStream_t stream) {
 int bts_lap_init() {      // the solver kernel needs more than the default 64 KiB of dynamic LDS
     static bool attr_set = false;
     if (!attr_set) {
+        BTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lap<4, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LAP_LDS_BYTES));
+        BTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lap<8, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LAP_LDS_BYTES));
+        BTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lap<4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LAP_LDS_BYTES));
+        BTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lap<8, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LAP_LDS_BYTES));
         BTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lap<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LAP_LDS_BYTES));
         BTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lap<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LAP_LDS_BYTES));
         BTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lap<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LAP_LDS_BYTES));
@@ -1698,7 +1702,16 @@ int bts_lap_enqueue(const bts_lap_problem *probs, int count, hipStream_t stream,
     const bool row_form = (form < 0 ? env_form : form) == 1;
     const bool wide = A.m_max > 3072 || B.m_max > 3072;
     const dim3 grid(count, 1 + helpers);
-    if (row_form) {
+    // (the SELF form -- work areas carved with slices, BTS_LAP_SELF -- has its own instantiations: the classic kernels do not
+    //  carry its ranking pass)
+    const bool selfk = A.w.x_slices > 0 || B.w.x_slices > 0;
+    if (selfk) {
+        if (row_form) {
+            if (wide) hipLaunchKernelGGL((k_lap<8, false, true>), grid, dim3(1024), LAP_LDS_BYTES, stream, P);
+            else hipLaunchKernelGGL((k_lap<4, false, true>), grid, dim3(1024), LAP_LDS_BYTES, stream, P);
+        } else if (wide) hipLaunchKernelGGL((k_lap<8, true, true>), grid, dim3(1024), LAP_LDS_BYTES, stream, P);
+        else hipLaunchKernelGGL((k_lap<4, true, true>), grid, dim3(1024), LAP_LDS_BYTES, stream, P);
+    } else if (row_form) {
         if (wide) hipLaunchKernelGGL((k_lap<8, false>), grid, dim3(1024), LAP_LDS_BYTES, stream, P);
         else hipLaunchKernelGGL((k_lap<4, false>), grid, dim3(1024), LAP_LDS_BYTES, stream, P);
     } else if (wide) hipLaunchKernelGGL((k_lap<8, true>), grid, dim3(1024), LAP_LDS_BYTES, stream, P);
