@@ -34,6 +34,10 @@ from typing import Callable, Dict, List, Optional, Sequence, Tuple
 CANDIDATES: Tuple[Tuple[str, str, Dict[str, str]], ...] = (
     ("lists_ahead", "lists_ahead", {"BTS_LISTS_AHEAD": "1"}),
     ("lists_ahead", "lists_ahead_predict_front", {"BTS_LISTS_AHEAD": "1", "BTS_PREDICT_FRONT": "1"}),
+    # (forms that only pay TOGETHER are also offered together: the conversion leaves the first launch for nothing while the list
+    #  jobs still sit in it)
+    ("lists_ahead", "lists_ahead_cvt", {"BTS_LISTS_AHEAD": "1", "BTS_CVT_OVERLAP": "1"}),
+    ("lists_ahead", "lists_ahead_cvt_predict_front", {"BTS_LISTS_AHEAD": "1", "BTS_CVT_OVERLAP": "1", "BTS_PREDICT_FRONT": "1"}),
     ("merge_early", "merge_early", {"BTS_MERGE_EARLY": "1"}),
     ("renorm_fused", "renorm_fused", {"BTS_RENORM_FUSED": "1"}),
     ("cvt_overlap", "cvt_overlap", {"BTS_CVT_OVERLAP": "1"}),

@@ -61,7 +61,8 @@ def test_selection_keeps_what_is_identical_and_faster(monkeypatch):
     def cost(f):       # lists_ahead -10 %, sorted edges -20 %, row solver +5 %, together they add up
         c = 100.0
         c *= 0.9 if "BTS_LISTS_AHEAD" in f else 1.0
-        c *= 1.02 if "BTS_PREDICT_FRONT" in f else 1.0       # (an alternative of the same group that is a little slower)
+        c *= 1.02 if "BTS_PREDICT_FRONT" in f else 1.0       # (alternatives of the same group that are a little slower)
+        c *= 1.01 if "BTS_CVT_OVERLAP" in f else 1.0
         c *= 0.8 if "BTS_EDGES_SORTED" in f else 1.0
         c *= 1.05 if "BTS_LAP_FORM=row" in f else 1.0
         return c
