@@ -656,6 +656,8 @@ def main():
         out["segments_us"] = {k: round(v, 2) for k, v in breakdown.items()}
         if selection is not None:
             # every candidate's us/step and whether its results were bit-identical to the default forms' on the verified frames
+            if isinstance(selection.get("table"), list):      # (the forms in effect of every candidate stay in the child's log: the line keeps the verdicts)
+                selection = dict(selection, table=[{k: v for k, v in m.items() if k != "effective"} for m in selection["table"] if isinstance(m, dict)])
             out["form_selection"] = selection
         if not isinstance(late_errors, dict) and late_errors != 0:
             out["device_errors_after_timed_region"] = late_errors
