@@ -22,7 +22,7 @@ class BtsError(RuntimeError):
 class TrackerConfig(ctypes.Structure):
     """bts_tracker_config (defaults = the reference's hard-coded values, D:1268-1277)."""
     _fields_ = [
-        ("max_tracks", c_int32), ("max_dets", c_int32), ("feat_dim", c_int32), ("face_dim", c_int32),
+        ("struct_size", c_int32), ("abi_version", c_int32), ("max_tracks", c_int32), ("max_dets", c_int32), ("feat_dim", c_int32), ("face_dim", c_int32),
         ("frame_rate", c_int32), ("track_buffer", c_int32),
         ("track_high_thresh", c_double), ("track_low_thresh", c_double), ("new_track_thresh", c_double),
         ("match_thresh", c_double), ("second_match_thresh", c_double), ("unconfirmed_match_thresh", c_double),
@@ -64,6 +64,7 @@ SIGNATURES = {
     "bts_debug_launch_floor": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "bts_associate_parts": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, _P, c_int, _P, _P]),
     "bts_dedupe_pairs": (c_int, [_P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_double, _P, _P, _P]),
+    "bts_tracker_config_size": (c_int, []),
     "bts_tracker_default_config": (c_int, [POINTER(TrackerConfig)]),
     "bts_tracker_memory_bytes": (c_int, [POINTER(TrackerConfig), POINTER(ctypes.c_uint64)]),
     "bts_tracker_create": (c_int, [_P, POINTER(TrackerConfig), POINTER(c_void_p)]),
@@ -113,6 +114,9 @@ def load(require_gpu: bool = False) -> ctypes.CDLL:
             fn = getattr(lib, name)          # AttributeError here = header/library mismatch
             fn.restype = res
             fn.argtypes = args
+        if hasattr(lib, "bts_tracker_config_size") and lib.bts_tracker_config_size() != ctypes.sizeof(TrackerConfig):
+            raise BtsError("%s: bts_tracker_config is %d bytes in the library, %d in this binding (stale _lib.TrackerConfig?)"
+                           % (LIB_PATH, lib.bts_tracker_config_size(), ctypes.sizeof(TrackerConfig)))
         _lib = lib
     if require_gpu:
         import torch

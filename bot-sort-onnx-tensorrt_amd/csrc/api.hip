@@ -1,5 +1,6 @@
 // api.hip -- library-level entry points: version, error reporting, contexts, scratch arena.
 #include <stdarg.h>
+#include <strings.h>
 
 #include "bts_internal.h"
 
@@ -38,6 +39,16 @@ const char *bts_form_get(const char *key) {
         p = e;
     }
     return getenv(key);
+}
+
+// Boolean forms: on for any value except "", "0", "false", "off", "no" (any case) -- so KEY=0 from a caller's dict or an A/B
+// script's environment switches a form OFF like KEY= does (`!= nullptr` turned "KEY=0" ON).
+bool bts_form_flag(const char *key) {
+    const char *v = bts_form_get(key);
+    if (!v) return false;
+    while (*v == ' ') ++v;
+    if (!*v || !strcmp(v, "0") || !strcasecmp(v, "false") || !strcasecmp(v, "off") || !strcasecmp(v, "no")) return false;
+    return true;
 }
 
 int bts_arena::ensure(size_t bytes) {

@@ -49,6 +49,7 @@ void bts_set_error(const char *fmt, ...);
 // thread), then in the process environment.  "KEY=" (empty value) in the string turns a form off whatever the environment says.
 // The returned pointer is valid until the next bts_form_get on this thread.
 const char *bts_form_get(const char *key);
+bool bts_form_flag(const char *key);       // boolean forms: "", "0", "false", "off", "no" are OFF
 struct bts_forms_scope {
     const char *prev;
     explicit bts_forms_scope(const char *forms);

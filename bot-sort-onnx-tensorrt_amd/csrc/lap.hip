@@ -1688,9 +1688,10 @@ int bts_lap_enqueue(const bts_lap_problem *probs, int count, hipStream_t stream,
     // a component is one wavefront's job: big problems (hundreds of components) get more helper workgroups
     int helpers = (A.n_max >= 2048 || B.n_max >= 2048) ? LAP_HELPERS_BIG : LAP_HELPERS;
     {   // BTS_LAP_HELPERS: sweep knob (host side only: the grid's second dimension); a tracker passes what it read at create,
-        // the standalone entry points read the process environment once
-        static const int forced = [] { const char *e = getenv("BTS_LAP_HELPERS"); return e ? atoi(e) : -1; }();
-        const int want = helpers_want >= 0 ? helpers_want : forced;
+        // the standalone entry points read the process environment per call (no latching: the same key has the same lifetime
+        // on both paths)
+        int want = helpers_want;
+        if (want < 0) { const char *e = getenv("BTS_LAP_HELPERS"); want = e ? atoi(e) : -1; }
         if (want >= 0 && want <= 255) helpers = want;
     }
     // edges a thread keeps in registers across the preparation passes: 4 (lists up to 4096 edges are read once), or 8 for
@@ -1698,8 +1699,7 @@ int bts_lap_enqueue(const bts_lap_problem *probs, int count, hipStream_t stream,
     // the solver's FORM (see Admit<>): column forms unless the caller (a tracker: BTS_LAP_FORM when it was created) or, for the
     // standalone entry points, the process environment asks for the round-2 row forms.  Both are exact -- on tie-free costs they
     // return the same indices
-    static const int env_form = bts_lap_form_from_env();
-    const bool row_form = (form < 0 ? env_form : form) == 1;
+    const bool row_form = (form < 0 ? bts_lap_form_from_env() : form) == 1;
     const bool wide = A.m_max > 3072 || B.m_max > 3072;
     const dim3 grid(count, 1 + helpers);
     // (the SELF form -- work areas carved with slices, BTS_LAP_SELF -- has its own instantiations: the classic kernels do not

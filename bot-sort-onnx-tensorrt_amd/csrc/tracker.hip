@@ -2592,9 +2592,12 @@ static void tracker_layout(bts_tracker *t, char *base, size_t &off) {
 
 extern "C" {
 
+int bts_tracker_config_size(void) { return (int)sizeof(bts_tracker_config); }
+
 int bts_tracker_default_config(bts_tracker_config *cfg) {
     BTS_REQUIRE(cfg, "cfg");
     memset(cfg, 0, sizeof(*cfg));
+    cfg->struct_size = (int32_t)sizeof(*cfg); cfg->abi_version = BTS_ABI_VERSION;
     cfg->max_tracks = 1024; cfg->max_dets = 512; cfg->feat_dim = 2048; cfg->face_dim = 0;
     cfg->frame_rate = 30; cfg->track_buffer = 300;
     cfg->track_high_thresh = 0.40; cfg->track_low_thresh = 0.1; cfg->new_track_thresh = 0.9;
@@ -2614,6 +2617,9 @@ int bts_tracker_default_config(bts_tracker_config *cfg) {
 // cost tiles then keep all rows, `!(limit < 1.0)`) and small tables keep the T * M that cannot overflow.  Overflow
 // raises the sticky capacity error (BTS_ECAPACITY from the next export).
 static int derive_sizes(const bts_tracker_config *cfg, Dev &d, int64_t *e_cap_out) {
+    BTS_REQUIRE(cfg->struct_size == (int32_t)sizeof(bts_tracker_config) && cfg->abi_version == BTS_ABI_VERSION,
+                "bts_tracker_config.struct_size / abi_version do not match this library's bts_tracker_config_size(): start from "
+                "bts_tracker_default_config, and check the binding's mirror of the struct against include/botsort_hip.h");
     d.T = cfg->max_tracks; d.Mx = cfg->max_dets; d.D = cfg->feat_dim; d.Df = cfg->face_dim;
     d.record = cfg->record_costs ? 1 : 0;
     // the pre-filter works on 128-element K steps; other feature widths take the dense float32 path
@@ -2629,15 +2635,15 @@ static int derive_sizes(const bts_tracker_config *cfg, Dev &d, int64_t *e_cap_ou
     BTS_REQUIRE(cfg->cost_dtype == BTS_F64 || cfg->cost_dtype == BTS_F16, "cost_dtype: BTS_F64 or BTS_F16");
     BTS_REQUIRE(!(cfg->cost_dtype == BTS_F16 && cfg->tie_mode), "cost_dtype BTS_F16 needs tie_mode 0 (the exact-tie replay prices pairs from the boxes)");
     // BTS_EDGES_SORTED=1 (read when the tracker is created / sized): stage-1 edges in the sorted / list form (tk_edges_sorted)
-    d.sorted = (bts_form_get("BTS_EDGES_SORTED") != nullptr && d.filter && d.Df == 0 && !cfg->motion_gate && !cfg->record_costs &&
+    d.sorted = (bts_form_flag("BTS_EDGES_SORTED") && d.filter && d.Df == 0 && !cfg->motion_gate && !cfg->record_costs &&
                 cfg->match_thresh < 1.0 && !cfg->use_graph) ? 1 : 0;
     // BTS_LISTS_AHEAD=1 (read at create): the next frame's pool / unconfirmed / free lists are built by tk_finalize
-    d.ahead = (bts_form_get("BTS_LISTS_AHEAD") != nullptr && !cfg->use_graph) ? 1 : 0;
+    d.ahead = (bts_form_flag("BTS_LISTS_AHEAD") && !cfg->use_graph) ? 1 : 0;
     // BTS_MERGE_EARLY=1 (read at create): tk_merge's jobs in the launch of tk_apply23 (tk_apply23_merge)
-    d.merge_early = bts_form_get("BTS_MERGE_EARLY") != nullptr ? 1 : 0;
-    d.renorm_fused = bts_form_get("BTS_RENORM_FUSED") != nullptr ? 1 : 0;
+    d.merge_early = bts_form_flag("BTS_MERGE_EARLY") ? 1 : 0;
+    d.renorm_fused = bts_form_flag("BTS_RENORM_FUSED") ? 1 : 0;
     {   // BTS_SHADOW_PLANES=1 (read at create): the int8 shadows in K-stage planes (feat_math.h, i8_elem); default row-major
-        const bool planes = bts_form_get("BTS_SHADOW_PLANES") != nullptr && d.filter;
+        const bool planes = bts_form_flag("BTS_SHADOW_PLANES") && d.filter;
         const int dim[2] = {d.D, d.Df};
         d.sh_planes = planes ? 1 : 0;
         for (int f = 0; f < 2; ++f) {
@@ -2670,7 +2676,7 @@ static int derive_sizes(const bts_tracker_config *cfg, Dev &d, int64_t *e_cap_ou
 // BTS_LAP_SELF=1 (read at create): every workgroup of an assignment launch prepares the problem itself (lap.hip, struct Packed);
 // -> the number of extra packed-component slices the two work areas carry (one per helper workgroup the launches will have)
 static int lap_self_slices(const Dev &d) {
-    if (bts_form_get("BTS_LAP_SELF") == nullptr) return 0;
+    if (!bts_form_flag("BTS_LAP_SELF")) return 0;
     const char *e = bts_form_get("BTS_LAP_HELPERS");
     return bts_lap_helpers_for(d.T, e && atoi(e) >= 0 && atoi(e) <= 255 ? atoi(e) : -1);
 }
@@ -2689,7 +2695,7 @@ int bts_tracker_memory_bytes(const bts_tracker_config *cfg, uint64_t *out_bytes)
     int64_t e_cap = 0;
     const int rc = derive_sizes(cfg, d, &e_cap);
     if (rc) { delete t; return rc; }
-    t->cvt_overlap = bts_form_get("BTS_CVT_OVERLAP") != nullptr && d.filter && !cfg->use_graph;
+    t->cvt_overlap = bts_form_flag("BTS_CVT_OVERLAP") && d.filter && !cfg->use_graph;
     size_t off = 0;
     tracker_layout(t, nullptr, off);
     const int64_t o_cap = (cfg->tie_mode && d.Df > 0) ? e_cap : 0;      // overrides of the exact-tie step (tk_edges_xo): their own region
@@ -2737,17 +2743,17 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
         d.nch = (!forced && d.T <= 6144) ? 1 : bts_cdiv(d.T, rows);
         d.nch = d.nch < 1 ? 1 : d.nch > 8 ? 8 : d.nch;
     }
-    d.use_grid = bts_form_get("BTS_EDGES_GRID") != nullptr ? 1 : 0;
-    t->predict_first = bts_form_get("BTS_PREDICT_FIRST") != nullptr;
-    t->predict_front = bts_form_get("BTS_PREDICT_FRONT") != nullptr && d.ahead;
-    t->cvt_overlap = bts_form_get("BTS_CVT_OVERLAP") != nullptr && d.filter && !cfg->use_graph;
+    d.use_grid = bts_form_flag("BTS_EDGES_GRID") ? 1 : 0;
+    t->predict_first = bts_form_flag("BTS_PREDICT_FIRST");
+    t->predict_front = bts_form_flag("BTS_PREDICT_FRONT") && d.ahead;
+    t->cvt_overlap = bts_form_flag("BTS_CVT_OVERLAP") && d.filter && !cfg->use_graph;
     t->lap_form = bts_lap_form_from_env();
     { const char *e = bts_form_get("BTS_LAP_HELPERS"); t->lap_helpers = e && atoi(e) >= 0 && atoi(e) <= 255 ? atoi(e) : -1; }
     { const char *e = bts_form_get("BTS_FILTER_PW"); const int v = e ? atoi(e) : 0; t->filter_pw = v > 0 && v <= 2048 ? v : 0; }
     { const char *e = bts_form_get("BTS_TILE_GOAL"); const int v = e ? atoi(e) : 0; t->tile_goal = v >= 64 && v <= 16384 ? v : 768; }
-    t->onepass = bts_form_get("BTS_FILTER_ONEPASS") != nullptr;
+    t->onepass = bts_form_flag("BTS_FILTER_ONEPASS");
     d.gate_sim = 1.0f - d.app;
-    d.f_guess = bts_form_get("BTS_FILTER_GUESS") != nullptr ? 1 : 0;
+    d.f_guess = bts_form_flag("BTS_FILTER_GUESS") ? 1 : 0;
     {   // first prefix checkpoint of the pre-filter: from the gate, or BTS_I8_FIRST16 (3 .. 12; 5 = the round-2 set)
         const char *e = bts_form_get("BTS_I8_FIRST16");
         const int f = e ? atoi(e) : 0;

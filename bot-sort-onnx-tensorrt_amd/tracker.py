@@ -430,6 +430,14 @@ class STrack(BaseTrack):
         return "OT_{}_({}-{})".format(self.track_id, self.start_frame, self.end_frame)   # D:687-688
 
 
+def forms_string(forms) -> str:
+    """"KEY=VALUE,..." for bts_tracker_create_forms from a dict or a string.  A dict value of False / 0 / None / "" becomes
+    "KEY=" -- the form switched OFF whatever the environment says (the library also reads "KEY=0" / "false" / "off" as off)."""
+    if isinstance(forms, dict):
+        return ",".join("%s=%s" % (k, "" if (v is None or v is False or v == 0 or v == "") else (1 if v is True else v)) for k, v in forms.items())
+    return str(forms) if forms else ""
+
+
 def tracker_memory_bytes(max_tracks: int, max_dets: int, feat_dim: int, face_dim: int = 0, record_costs: bool = False, forms=None, **options) -> int:
     """Device bytes a DeviceTracker with these capacities (and execution forms) allocates (bts_tracker_memory_bytes[_forms]:
     host-only, no GPU needed)."""
@@ -443,8 +451,7 @@ def tracker_memory_bytes(max_tracks: int, max_dets: int, feat_dim: int, face_dim
             raise TypeError("unknown tracker option %r" % k)
         setattr(cfg, k, v)
     out = ctypes.c_uint64()
-    if isinstance(forms, dict):
-        forms = ",".join("%s=%s" % kv for kv in forms.items())
+    forms = forms_string(forms)
     if forms:
         _lib.check(lib.bts_tracker_memory_bytes_forms(ctypes.byref(cfg), str(forms).encode(), ctypes.byref(out)))
     else:
@@ -552,8 +559,7 @@ class DeviceTracker:
             setattr(cfg, k, v)
         self.cfg = cfg
         h = ctypes.c_void_p()
-        if isinstance(forms, dict):
-            forms = ",".join("%s=%s" % (k, v) for k, v in forms.items())
+        forms = forms_string(forms)
         if forms:
             _lib.check(lib.bts_tracker_create_forms(self.ctx.handle, ctypes.byref(cfg), str(forms).encode(), ctypes.byref(h)))
         else:

@@ -205,7 +205,15 @@ int bts_associate_parts(bts_context *ctx, const int32_t *base_boxes, const int32
  * DENSE:  the dense float32 similarity and cost matrices, as the reference forms them. */
 enum bts_appearance_mode { BTS_APPEARANCE_FILTER = 0, BTS_APPEARANCE_DENSE = 1 };
 
+#define BTS_ABI_VERSION 5
 typedef struct bts_tracker_config {
+    int32_t struct_size;     /* = bts_tracker_config_size() of the library the caller was written against: filled in by
+                                bts_tracker_default_config; create / memory_bytes reject any other value (BTS_EINVAL), so a
+                                binding whose mirror of this struct is stale fails at the first call instead of reading
+                                fields at the wrong offsets */
+    int32_t abi_version;     /* = BTS_ABI_VERSION of the header the caller was built against (set by
+                                bts_tracker_default_config; checked like struct_size: a field that changes MEANING without
+                                changing the size bumps it) */
     int32_t max_tracks;      /* capacity of the resident track table (tracked + lost + unconfirmed) */
     int32_t max_dets;        /* max detections per frame */
     int32_t feat_dim;        /* body ReID feature dimension D */
@@ -256,7 +264,11 @@ typedef struct bts_tracker_config {
 } bts_tracker_config;
 enum bts_dtype { BTS_F64 = 0, BTS_F32 = 1, BTS_F16 = 2 };
 
-/* Fill cfg with the reference's hard-coded values (D:1268-1277). */
+/* sizeof(bts_tracker_config) in THIS library.  A binding in another language checks its mirror of the struct against it
+   BEFORE it hands a buffer to bts_tracker_default_config (which writes that many bytes). */
+int bts_tracker_config_size(void);
+
+/* Fill cfg with the reference's hard-coded values (D:1268-1277); sets cfg->struct_size. */
 int bts_tracker_default_config(bts_tracker_config *cfg);
 
 /* Device bytes bts_tracker_create(cfg) allocates for the track table and its per-frame work arrays (one block; the

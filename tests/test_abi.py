@@ -56,7 +56,42 @@ def test_config_struct_layout_matches_the_header():
     decl = re.findall(r"(int32_t|double)\s+(\w+)\s*;", body)
     want = [(n, {"int32_t": ctypes.c_int32, "double": ctypes.c_double}[t]) for t, n in decl]
     assert want == list(lib_mod.TrackerConfig._fields_)
-    assert ctypes.sizeof(lib_mod.TrackerConfig) == 6 * 4 + 10 * 8 + 8 * 4          # (6 + 8 int32 fields, 10 doubles; no padding)
+    assert ctypes.sizeof(lib_mod.TrackerConfig) == 8 * 4 + 10 * 8 + 8 * 4          # (8 + 8 int32 fields, 10 doubles; no padding)
+    assert lib_mod.load().bts_tracker_config_size() == ctypes.sizeof(lib_mod.TrackerConfig)
+
+
+def _integration_stub_cfg():
+    """The `_Cfg` class of INTEGRATION.md's ctypes stub, executed as written (the documented stub had fallen
+    behind the header and nothing checked it)."""
+    md = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    m = re.search(r"^class _Cfg\(ctypes\.Structure\):.*?(?=^\S)", md, re.S | re.M)
+    assert m, "INTEGRATION.md no longer carries the _Cfg stub"
+    ns = {"ctypes": ctypes}
+    exec(m.group(0), ns)
+    return ns["_Cfg"]
+
+
+def test_integration_md_stub_matches_the_library():
+    lib_mod = importlib.import_module("bot-sort-onnx-tensorrt_amd._lib")
+    stub = _integration_stub_cfg()
+    assert ctypes.sizeof(stub) == lib_mod.load().bts_tracker_config_size()
+    assert [(n, t) for n, t in stub._fields_] == list(lib_mod.TrackerConfig._fields_)
+
+
+def test_a_stale_config_struct_is_rejected():
+    """create / memory_bytes refuse a config whose struct_size / abi_version is not this library's (host-only entry point)."""
+    lib_mod = importlib.import_module("bot-sort-onnx-tensorrt_amd._lib")
+    lib = lib_mod.load()
+    cfg = lib_mod.TrackerConfig()
+    assert lib.bts_tracker_default_config(ctypes.byref(cfg)) == 0
+    assert cfg.struct_size == ctypes.sizeof(cfg) and cfg.abi_version >= 5
+    out = ctypes.c_uint64(0)
+    assert lib.bts_tracker_memory_bytes(ctypes.byref(cfg), ctypes.byref(out)) == 0 and out.value > 0
+    for field, bad in (("struct_size", cfg.struct_size - 8), ("struct_size", 0), ("abi_version", cfg.abi_version - 1)):
+        c2 = lib_mod.TrackerConfig.from_buffer_copy(cfg)
+        setattr(c2, field, bad)
+        assert lib.bts_tracker_memory_bytes(ctypes.byref(c2), ctypes.byref(out)) == -1      # BTS_EINVAL
+        assert b"struct_size" in lib.bts_last_error()
 
 
 def test_product_path_never_imports_the_oracle():
@@ -157,3 +192,25 @@ def test_memory_bytes_follow_the_execution_forms():
     self15 = f(T, M, D, forms="BTS_LAP_SELF=1,BTS_LAP_HELPERS=15") - base
     assert 0 < self15 < self63 < 64 * 2 * 400 * 1024                    # (two work areas, <= ~300 KB per helper and area)
     assert abs(self63 / self15 - 63 / 15) < 0.25
+
+
+def test_boolean_forms_read_zero_false_off_as_off(monkeypatch):
+    """"KEY=0" / "false" / "off" / a dict value of 0 / False / None switch a boolean form OFF (they used to
+    switch it ON: any non-empty value did), and so does "KEY=" against an environment that says 1.  Witness: the forms whose
+    extra arrays show in bts_tracker_memory_bytes_forms (host-only)."""
+    pkg = importlib.import_module("bot-sort-onnx-tensorrt_amd")
+    f = pkg.tracker_memory_bytes
+    T, M, D = 4608, 4096, 2048
+    base = f(T, M, D)
+    on = f(T, M, D, forms="BTS_CVT_OVERLAP=1")
+    assert on > base
+    for off in ("BTS_CVT_OVERLAP=0", "BTS_CVT_OVERLAP=false", "BTS_CVT_OVERLAP=OFF", "BTS_CVT_OVERLAP=no", "BTS_CVT_OVERLAP=",
+                {"BTS_CVT_OVERLAP": 0}, {"BTS_CVT_OVERLAP": False}, {"BTS_CVT_OVERLAP": None}, {"BTS_MERGE_EARLY": 0, "BTS_LAP_SELF": False}):
+        assert f(T, M, D, forms=off) == base, off
+    for still_on in ("BTS_CVT_OVERLAP", "BTS_CVT_OVERLAP=true", "BTS_CVT_OVERLAP=2", {"BTS_CVT_OVERLAP": True}, {"BTS_CVT_OVERLAP": 1}):
+        assert f(T, M, D, forms=still_on) == on, still_on
+    monkeypatch.setenv("BTS_CVT_OVERLAP", "0")
+    assert f(T, M, D) == base
+    monkeypatch.setenv("BTS_CVT_OVERLAP", "1")
+    assert f(T, M, D) == on and f(T, M, D, forms={"BTS_CVT_OVERLAP": 0}) == base
+    assert pkg.tracker.forms_string({"A": 0, "B": True, "C": "row", "D": None}) == "A=,B=1,C=row,D="
