@@ -1599,6 +1599,376 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 
+// ---- the one-pass pre-filter with the TILE SHAPE as a parameter (round 5; opt-in: BTS_FILTER_TILE at create; NOT yet measured) ----
+// k_filter_i8 above is tied to 128 x 128 tiles, two resident workgroups per CU, 2 x 2 wavefronts of 64 x 64.  Its measured model at
+// the headline size (round 2) is ~22 us fixed + three tile ROUNDS (1 106 live tiles over 512 resident workgroups; the third
+// round holds 82) of ~8 us each -- a tile's time is its latency chain, not its size.  This template keeps the kernel's structure
+// (persistent workgroups, LDS-DMA double buffering in 128-byte stages, records one stage ahead, stop prediction, the next tile's
+// first stage issued under the test) and frees the shape:
+//   TM x TN       tile (multiples of 32), 4 wavefronts as WR x WC, each (TM / WR) x (TN / WC) = MI x NI blocks of 32 x 32;
+//   OCC           resident workgroups per CU (the register cap follows: 512 / OCC per lane);
+//   NIMG          record images in LDS: with ONE image a test's readers must be through before the next checkpoint's records are
+//                 staged -- the count exchange's barrier, which every test of this kernel therefore runs (k_filter_i8 skips it at the
+//                 end of a row) -- in exchange for (TM + TN) * 16 bytes of LDS.
+// Instantiations:   160 x 128 (1 x 4 wavefronts of 160 x 32: 80 accumulators per lane; 78.5 KB of LDS with one record image, two
+//                   workgroups per CU) -- 882 live tiles at the headline size = TWO rounds;
+//                   128 x 64 (2 x 2 wavefronts of 64 x 32; 52.4 KB, 168 registers: THREE workgroups per CU, 768 resident).
+// Same bound, same records, same stop rule as k_filter_i8; the tile's row summary is taken over TM rows and stop_thr scales with
+// the tile's area, so the candidate SET may differ from the 128 x 128 tiles' (both are supersets of the pairs the exact refinement
+// accepts: the step's results are identical).  No face pass, no candidate list (the sorted-edge form keeps k_filter_i8).
+template <int TM, int TN, int WR, int WC>
+struct FragMapT {
+    static constexpr int MI = TM / (32 * WR), NI = TN / (32 * WC);
+    // pa[x] = byte offset of this lane's fragment row in an operand image, with the row's swizzle and the lane's K half folded in:
+    // the 16-byte chunk of K step k (0..3) is at  pa ^ (k << 5)  -- row offsets are multiples of 128, the chunk index
+    // ((2 k + fh) ^ swz(row)) << 4 lives in bits 4-6, so "^" composes (one xor + one add per read, one register per block)
+    int pa[MI], pb[NI];
+    __device__ __forceinline__ void init(int wr, int wc, int frow, int fh) {
+#pragma unroll
+        for (int x = 0; x < MI; ++x) { const int ra = wr * (TM / WR) + x * 32 + frow; pa[x] = ra * DBK + ((((ra >> 1) & 7) ^ fh) << 4); }
+#pragma unroll
+        for (int x = 0; x < NI; ++x) { const int rb = wc * (TN / WC) + x * 32 + frow; pb[x] = rb * DBK + ((((rb >> 1) & 7) ^ fh) << 4); }
+    }
+};
+#if !defined(BTS_HOST_EMU)
+// (the first statement carries the wait; the others only tie their operand behind it -- volatile asm statements keep their order --
+//  so that no MFMA can be scheduled above the wait whichever fragment it reads)
+__device__ __forceinline__ void lds_wait_first(v4i &a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a)); }
+__device__ __forceinline__ void lds_tie(v4i &a) { asm volatile("" : "+v"(a)); }
+__device__ __forceinline__ void lds_tie_f(f32x4 &a) { asm volatile("" : "+v"(a)); }
+#else
+__device__ __forceinline__ void lds_wait_first(v4i &) {}
+__device__ __forceinline__ void lds_tie(v4i &) {}
+__device__ __forceinline__ void lds_tie_f(f32x4 &) {}
+#endif
+// one K stage (128 int8 per row) of a wave's MI x NI blocks: four K = 32 steps; TB of them per batch of LDS reads (2 like
+// k_filter_i8 while the fragments of two steps fit the register budget, 1 for the tall shapes: 80 accumulators + 2 x 24 fragment
+// registers pushed the 160 x 128 kernel into scratch)
+template <int TM, int TN, int WR, int WC>
+__device__ __forceinline__ void stage_mfma_t(lds_t abase, lds_t bbase, const FragMapT<TM, TN, WR, WC> &fm,
+                                             i32x16 (&acc)[FragMapT<TM, TN, WR, WC>::MI][FragMapT<TM, TN, WR, WC>::NI]) {
+    constexpr int MI = FragMapT<TM, TN, WR, WC>::MI, NI = FragMapT<TM, TN, WR, WC>::NI;
+    constexpr int TB = (MI + NI) * 2 * 4 + MI * NI * 16 > 112 ? 1 : 2;
+#pragma unroll
+    for (int h = 0; h < 4 / TB; ++h) {
+        v4i fa[TB][MI], fb[TB][NI];
+#pragma unroll
+        for (int t = 0; t < TB; ++t) {
+            const int kx = (h * TB + t) << 5;            // K step: bytes [32 k, +32) of the stage, this lane half takes 16 of them
+#pragma unroll
+            for (int x = 0; x < MI; ++x) fa[t][x] = lds_read16(abase + (lds_t)(fm.pa[x] ^ kx));
+#pragma unroll
+            for (int x = 0; x < NI; ++x) fb[t][x] = lds_read16(bbase + (lds_t)(fm.pb[x] ^ kx));
+        }
+        lds_wait_first(fa[0][0]);
+#pragma unroll
+        for (int t = 0; t < TB; ++t) {
+#pragma unroll
+            for (int x = 0; x < MI; ++x) if (t || x) lds_tie(fa[t][x]);
+#pragma unroll
+            for (int x = 0; x < NI; ++x) lds_tie(fb[t][x]);
+        }
+#pragma unroll
+        for (int t = 0; t < TB; ++t)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[t][mi], fb[t][ni], acc[mi][ni], 0, 0, 0);
+    }
+}
+
+template <int TM, int TN, int WR, int WC, int OCC, int NIMG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void k_filter_t(Dev d, int m_max, int ntiles, int gemm_blocks) {
+    typedef FragMapT<TM, TN, WR, WC> FM;
+    constexpr int MI = FM::MI, NI = FM::NI;
+    constexpr int PA = TM / 32, PB = TN / 32;            // 1-KiB wavefront loads (8 full 128-byte rows) per stage, wavefront and operand
+    constexpr int E = TM + TN;                           // records of a tile: rows [0, TM), columns [TM, E)
+    constexpr int NRW = (TM + 63) / 64;                  // wavefronts that summarise the rows' records
+    static_assert(WR * WC == 4 && TM % (32 * WR) == 0 && TN % (32 * WC) == 0 && NI <= 2 && E <= 512 && E % 32 == 0 && NRW <= 4, "tile shape");
+    static_assert(NIMG == 1 || NIMG == 2, "record images");
+    __shared__ __attribute__((aligned(1024))) int8_t As2[DNS][TM * DBK];
+    __shared__ __attribute__((aligned(1024))) int8_t Bs2[DNS][TN * DBK];
+    __shared__ float4 srec2[NIMG][E];
+    __shared__ __attribute__((aligned(16))) int s_cnt[2][4];     // survivors per wavefront
+    __shared__ __attribute__((aligned(16))) float sred[2][16];   // {min uh, max alpha, max r, -} of the rows' records, per summarising wavefront
+    if ((int)blockIdx.x >= gemm_blocks) { predict_body(d, (int)blockIdx.x - gemm_blocks); return; }
+    // (the chain that opens a workgroup is cut like k_filter_i8's: the index loads of the first tile position travel with the extents')
+    const int n_raw = d.hdr[H_NPOOL], m_raw = d.hdr[H_NHI];
+    const int Dd = d.D;
+    const int8_t *A = d.body_h, *B = d.det_h;
+    const float *ma = d.body_m, *mb = d.det_m;
+    const unsigned rs_a = d.sh_rt[0], cs_a = d.sh_ct[0], rs_b = d.sh_rd[0], cs_b = d.sh_cd[0];      // shadow layout (feat::i8_elem)
+    const int nbn = (m_max + TN - 1) / TN;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid / WC, wc = wid % WC;
+    const int prow = lane >> 3, pchunk = lane & 7;
+    const int frow = lane & 31, fh = lane >> 5;
+    // record entry e of a tile: row e (e < TM) or column e - TM; thread tid carries entry tid and, when E > 256, entry 256 + tid as well
+    const bool rec1 = tid < E, rec2 = E > 256 && tid < E - 256;
+    const int e1 = tid, e2 = 256 + tid;
+    auto rec_index = [&](int e, int bm, int bn, int n, int m) {
+        const int g = e < TM ? bm * TM + e : bn * TN + (e - TM);
+        return e < TM ? d.pool_slot[g < n ? g : bm * TM] : d.hi_idx[g < m ? g : bn * TN];
+    };
+    const int vt_first = (int)blockIdx.x;
+    int sia[PA], sib[PB], sirec = 0, sirec2 = 0, sfa = 0, sfb = 0, sbm = 0, sbn = 0;      // the first position's indices, fetched ahead of the extents
+    if (vt_first < ntiles) {
+        const int vb = xcd_remap(vt_first, ntiles);
+        sbm = vb / nbn; sbn = vb % nbn;
+#pragma unroll
+        for (int s = 0; s < PA; ++s) sia[s] = d.pool_slot[min(sbm * TM + (4 * s + wid) * 8 + prow, d.T - 1)];
+#pragma unroll
+        for (int s = 0; s < PB; ++s) sib[s] = d.hi_idx[min(sbn * TN + (4 * s + wid) * 8 + prow, d.Mx - 1)];
+        sfa = d.pool_slot[min(sbm * TM, d.T - 1)]; sfb = d.hi_idx[min(sbn * TN, d.Mx - 1)];
+        if (rec1) sirec = e1 < TM ? d.pool_slot[min(sbm * TM + e1, d.T - 1)] : d.hi_idx[min(sbn * TN + (e1 - TM), d.Mx - 1)];
+        if (rec2) sirec2 = e2 < TM ? d.pool_slot[min(sbm * TM + e2, d.T - 1)] : d.hi_idx[min(sbn * TN + (e2 - TM), d.Mx - 1)];
+    }
+    const int n = __builtin_amdgcn_readfirstlane(n_raw), m = __builtin_amdgcn_readfirstlane(m_raw);     // (scalar registers)
+    const int kt_all = Dd / DBK;
+    int chk[feat::I8_NCHK];
+    feat::i8_checkpoints(kt_all, chk, d.chk_first);
+    static_assert(feat::I8_NCHK == 4, "chk_at selects by hand (a runtime-indexed register array would go to scratch)");
+    auto chk_at = [&](int j) { return j == 0 ? chk[0] : j == 1 ? chk[1] : j == 2 ? chk[2] : chk[3]; };
+    auto skip_unused = [&](int j) { return (j < feat::I8_NCHK && chk_at(j) >= kt_all) ? (int)feat::I8_NCHK : j; };
+    const lds_t lds_a = LDS_ADDR(&As2[0][0]), lds_b = LDS_ADDR(&Bs2[0][0]);
+    FM fm;
+    fm.init(wr, wc, frow, fh);
+    const lds_t lds_rec = LDS_ADDR(&srec2[0][0]), lds_cnt = LDS_ADDR(&s_cnt[0][0]), lds_red = LDS_ADDR(&sred[0][0]);
+    auto next_live = [&](int vt, int &bm, int &bn) {
+        for (; vt < ntiles; vt += gemm_blocks) {
+            const int vb = xcd_remap(vt, ntiles);
+            bm = vb / nbn; bn = vb % nbn;
+            if (bm * TM < n && bn * TN < m) return vt;
+        }
+        return ntiles;
+    };
+    auto fetch_idx = [&](int bm, int bn, int (&ia)[PA], int (&ib)[PB], int &irec, int &irec2) {
+#pragma unroll
+        for (int s = 0; s < PA; ++s) { const int i = bm * TM + (4 * s + wid) * 8 + prow; ia[s] = d.pool_slot[i < n ? i : bm * TM]; }       // rows past the end: any valid row, ignored later
+#pragma unroll
+        for (int s = 0; s < PB; ++s) { const int j = bn * TN + (4 * s + wid) * 8 + prow; ib[s] = d.hi_idx[j < m ? j : bn * TN]; }
+        if (rec1) irec = rec_index(e1, bm, bn, n, m);
+        if (rec2) irec2 = rec_index(e2, bm, bn, n, m);
+    };
+    unsigned asrc[PA], bsrc[PB];                         // byte offsets into A / B (tables up to 4 GiB of shadows)
+    auto set_src = [&](const int (&ia)[PA], const int (&ib)[PB]) {
+#pragma unroll
+        for (int s = 0; s < PA; ++s) { const int r = (4 * s + wid) * 8 + prow; asrc[s] = (unsigned)ia[s] * rs_a + (unsigned)((pchunk ^ ((r >> 1) & 7)) * 16); }
+#pragma unroll
+        for (int s = 0; s < PB; ++s) { const int r = (4 * s + wid) * 8 + prow; bsrc[s] = (unsigned)ib[s] * rs_b + (unsigned)((pchunk ^ ((r >> 1) & 7)) * 16); }
+    };
+    auto stage = [&](int buf, int kt) {                  // PA + PB wavefront loads per stage and wave
+#pragma unroll
+        for (int s = 0; s < PA; ++s)
+            __builtin_amdgcn_global_load_lds((gbl_void *)(A + ((size_t)asrc[s] + (size_t)kt * cs_a)), (lds_void *)&As2[buf][(4 * s + wid) * 8 * DBK], 16, 0, 0);
+#pragma unroll
+        for (int s = 0; s < PB; ++s)
+            __builtin_amdgcn_global_load_lds((gbl_void *)(B + ((size_t)bsrc[s] + (size_t)kt * cs_b)), (lds_void *)&Bs2[buf][(4 * s + wid) * 8 * DBK], 16, 0, 0);
+    };
+    auto stage_next = [&](int buf, const int (&ia)[PA], const int (&ib)[PB]) {      // the NEXT tile's first stage, from the prefetched indices
+#pragma unroll
+        for (int s = 0; s < PA; ++s) {
+            const int r = (4 * s + wid) * 8 + prow;
+            __builtin_amdgcn_global_load_lds((gbl_void *)(A + ((size_t)((unsigned)ia[s] * rs_a) + (size_t)((pchunk ^ ((r >> 1) & 7)) * 16))), (lds_void *)&As2[buf][(4 * s + wid) * 8 * DBK], 16, 0, 0);
+        }
+#pragma unroll
+        for (int s = 0; s < PB; ++s) {
+            const int r = (4 * s + wid) * 8 + prow;
+            __builtin_amdgcn_global_load_lds((gbl_void *)(B + ((size_t)((unsigned)ib[s] * rs_b) + (size_t)((pchunk ^ ((r >> 1) & 7)) * 16))), (lds_void *)&Bs2[buf][(4 * s + wid) * 8 * DBK], 16, 0, 0);
+        }
+    };
+    const int stop_thr = 6 + (3 * TM * TN) / (2 * (n > 0 ? n : 1));
+    const float i8_s2 = feat::i8_scale(Dd) * feat::i8_scale(Dd) * 0.99999f;        // integer dot products per unit of dequantised dot product
+    int bm, bn;
+    int vt = next_live((int)blockIdx.x, bm, bn);
+    if (vt >= ntiles) return;
+    int ia[PA], ib[PB], irec = 0, irec2 = 0;
+    if (vt == vt_first) {
+#pragma unroll
+        for (int s = 0; s < PA; ++s) ia[s] = sbm * TM + (4 * s + wid) * 8 + prow < n ? sia[s] : sfa;
+#pragma unroll
+        for (int s = 0; s < PB; ++s) ib[s] = sbn * TN + (4 * s + wid) * 8 + prow < m ? sib[s] : sfb;
+        if (rec1) irec = e1 < TM ? (sbm * TM + e1 < n ? sirec : sfa) : (sbn * TN + (e1 - TM) < m ? sirec : sfb);
+        if (rec2) irec2 = e2 < TM ? (sbm * TM + e2 < n ? sirec2 : sfa) : (sbn * TN + (e2 - TM) < m ? sirec2 : sfb);
+    } else {
+        fetch_idx(bm, bn, ia, ib, irec, irec2);
+    }
+    set_src(ia, ib);
+    const float *mbase1 = e1 < TM ? ma : mb, *mbase2 = e2 < TM ? ma : mb;
+    unsigned meta_o1 = (unsigned)irec * feat::I8_META, meta_o2 = (unsigned)irec2 * feat::I8_META;
+    // records of checkpoint c into image img: entry e lands at srec2[img][e] (the LDS image of a wavefront load is lane-linear)
+    auto stage_rec = [&](int img, int c) {
+        if (rec1) __builtin_amdgcn_global_load_lds((gbl_void *)(mbase1 + ((size_t)meta_o1 + (size_t)(4 * c))), (lds_void *)&srec2[img][wid * 64], 16, 0, 0);
+        if (rec2) __builtin_amdgcn_global_load_lds((gbl_void *)(mbase2 + ((size_t)meta_o2 + (size_t)(4 * c))), (lds_void *)&srec2[img][256 + wid * 64], 16, 0, 0);
+    };
+    int rimg = 0;                                // image the NEXT test's records are in (or on their way to)
+    stage(0, 0);
+    int cur = 0, flip = 0;
+    int last_exit = d.f_guess ? chk[0] : -1, early_run = 0, tile_no = 0;        // (stop prediction: see k_filter_i8)
+    int st_stages = 0, st_early = 0, st_cand = 0;
+    for (;;) {
+        int nbm = 0, nbnn = 0;
+        const int nvt = next_live(vt + gemm_blocks, nbm, nbnn);
+        if (nvt < ntiles) fetch_idx(nbm, nbnn, ia, ib, irec, irec2);        // the next tile's indices travel while this tile's K loop runs
+        i32x16 acc[MI][NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0;
+        int ci = skip_unused(0);                     // next checkpoint (feat::I8_NCHK = the full row)
+        if ((tile_no & 3) != 3)
+            while (ci < feat::I8_NCHK && chk_at(ci) < last_exit) ci = skip_unused(ci + 1);
+        stage_rec(rimg, ci);
+        int issued = 1, kt = 0;
+        bool next_staged = false;
+        for (;;) {
+            const bool at_end = kt == kt_all;
+            if (at_end || (ci < feat::I8_NCHK && kt == chk_at(ci))) {
+                // ---- candidate test on the prefix of kt stages (checkpoint ci; at the end: the full-row records)
+                if (at_end && nvt < ntiles && !next_staged) { stage_next(cur, ia, ib); next_staged = true; }
+                const lds_t srec_a = lds_rec + (unsigned)rimg * (unsigned)(E * 16);
+                const lds_t scnt_a = lds_cnt + (unsigned)flip * 16u, sred_a = lds_red + (unsigned)flip * 64u;
+                unsigned sv[MI];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) sv[mi] = 0u;
+                {
+                    if (wid < NRW) {                 // these wavefronts summarise the rows' records
+                        const int e = wid * 64 + lane;
+                        f32x4 mine = lds_read16f(srec_a + (unsigned)(e < TM ? e : TM - 1) * 16u);
+                        lds_wait_f1(mine);
+                        const bool live = e < TM;
+                        const float m_u = wave_min_f(live ? mine.w : 3.0e38f), m_a = wave_max_f(live ? mine.z : -3.0e38f), m_r = wave_max_f(live ? mine.y : -3.0e38f);
+                        if (lane == 0) lds_write16(sred_a + (unsigned)wid * 16u, f32x4{m_u, m_a, m_r, 0.0f});
+                    }
+                    bscan::lds_barrier();
+                    f32x4 rr[NRW], cc[NI];
+#pragma unroll
+                    for (int w = 0; w < NRW; ++w) rr[w] = lds_read16f(sred_a + (unsigned)w * 16u);
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) cc[ni] = lds_read16f(srec_a + (unsigned)(TM + wc * (TN / WC) + ni * 32 + frow) * 16u);
+                    lds_wait_f1(rr[0]);
+#pragma unroll
+                    for (int w = 1; w < NRW; ++w) lds_tie_f(rr[w]);
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) lds_tie_f(cc[ni]);
+                    float u_min = rr[0].x, a_max = rr[0].y, r_max = rr[0].z;
+#pragma unroll
+                    for (int w = 1; w < NRW; ++w) { u_min = fminf(u_min, rr[w].x); a_max = fmaxf(a_max, rr[w].y); r_max = fmaxf(r_max, rr[w].z); }
+                    int ti[NI], mx[NI];
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        const float t0 = ((u_min + cc[ni].w) - (a_max * cc[ni].y + cc[ni].z * r_max)) * i8_s2;
+                        // (NaN / non-positive bounds: nothing is excluded)
+                        ti[ni] = t0 > 0.0f ? (int)fminf(t0 * 0.999999f, 2.0e9f) - 1 : (int)0x80000000;
+                        mx[ni] = acc[0][ni][0];
+                    }
+                    // survivors are rare: reduce a lane's accumulators per column block to their maximum first, extract bits only
+                    // in a wavefront where some maximum reaches its threshold
+                    bool any = false;
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) mx[ni] = max(mx[ni], acc[mi][ni][r]);
+                        any |= mx[ni] >= ti[ni];
+                    }
+                    if (__ballot(any) != 0ull) {
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) sv[mi] |= (acc[mi][ni][r] >= ti[ni] ? 1u : 0u) << (ni * 16 + r);
+                    }
+                }
+                unsigned svany = 0u;
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) svany |= sv[mi];
+                if (__ballot(svany != 0u) != 0ull) {      // (wave-uniform: most wavefronts hold no survivor and skip the extents)
+                    const int lim = n - bm * TM - (wr * (TM / WR) + 4 * fh);       // local row (mi * 32 + 8 g + u) is live iff < lim
+                    const int q0 = bn * TN + wc * (TN / WC) + frow;
+                    unsigned cm = 0u;
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) cm |= q0 + ni * 32 < m ? (0xffffu << (ni * 16)) : 0u;
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) {
+                        unsigned rv = 0u;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) rv |= (mi * 32 + (r & 3) + 8 * (r >> 2) < lim ? 1u : 0u) << r;
+                        sv[mi] &= (rv | (rv << 16)) & cm;      // rows / columns past the live extents
+                    }
+                }
+                int cnt = 0;
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) cnt += __popc(sv[mi]);
+                bool stop = at_end;
+                if (!at_end || NIMG == 1) {
+                    // the workgroup's survivors: every wavefront leaves its count, everybody adds the four up (with one record
+                    // image this exchange's barrier is also what lets the next records be staged: every test runs it)
+                    int wcnt = cnt;
+#pragma unroll
+                    for (int off = 32; off; off >>= 1) wcnt += __shfl_xor(wcnt, off);
+                    if (lane == 0) lds_write4(scnt_a + (unsigned)wid * 4u, wcnt);
+                    bscan::lds_barrier();
+                    v4i c4 = lds_read16(scnt_a);
+                    lds_wait_i(c4);
+                    const int total = __builtin_amdgcn_readfirstlane((c4.x + c4.y) + (c4.z + c4.w));
+                    flip ^= 1;
+                    if (!at_end) stop = total <= stop_thr;
+                }
+                if (stop) {
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) {
+                        unsigned bits = sv[mi];
+                        while (bits) {                           // (rare: about one survivor per detection column)
+                            const int b = __ffs((int)bits) - 1, r = b & 15;
+                            bits &= bits - 1;
+                            const int q = bn * TN + wc * (TN / WC) + (b >> 4) * 32 + frow;
+                            const int i = bm * TM + wr * (TM / WR) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                            atomicOr(&d.cbits[(long)i * d.cb_ld + (q >> 5)], 1u << (q & 31));
+                        }
+                    }
+                    st_cand += cnt;
+                    if (!at_end) ++st_early;
+                    const int here = at_end ? kt_all : kt;
+                    if (here >= last_exit) { last_exit = here; early_run = 0; }
+                    else if (++early_run >= 3) { last_exit = here; early_run = 0; }
+                    break;
+                }
+                ci = skip_unused(ci + 1);
+                if (NIMG == 2) rimg ^= 1;            // (two images: the one just tested may still be read by the slower wavefronts)
+                stage_rec(rimg, ci);
+            }
+            // ---- K stage kt
+            if (issued <= kt) { stage(cur, kt); issued = kt + 1; next_staged = false; }      // its prefetch was skipped (a predicted exit that did not happen)
+            wait_stage_barrier<0>();             // stage kt has landed; every wave is past its reads of the other buffer
+            if (kt + 1 < kt_all && issued == kt + 1) {
+                if (kt + 1 != last_exit) { stage(cur ^ 1, kt + 1); issued = kt + 2; }
+                else if (nvt < ntiles && !next_staged) { stage_next(cur ^ 1, ia, ib); next_staged = true; }
+            }
+            stage_mfma_t<TM, TN, WR, WC>(lds_a + cur * (TM * DBK), lds_b + cur * (TN * DBK), fm, acc);
+            cur ^= 1;
+            ++kt;
+            ++st_stages;
+        }
+        ++tile_no;
+        if (nvt >= ntiles) break;
+        vt = nvt; bm = nbm; bn = nbnn;
+        meta_o1 = (unsigned)irec * feat::I8_META; meta_o2 = (unsigned)irec2 * feat::I8_META;
+        if (NIMG == 2) rimg ^= 1;
+        if (!next_staged) { cur ^= 1; stage_next(cur, ia, ib); }      // stopped at an unpredicted checkpoint: see k_filter_i8
+        set_src(ia, ib);
+    }
+    if (tid == 0) { atomicAdd(&d.fstat[FS_STAGES], st_stages); atomicAdd(&d.fstat[FS_EARLY], st_early); atomicAdd(&d.fstat[FS_TILES], tile_no); }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) st_cand += __shfl_xor(st_cand, off);
+    if (lane == 0 && st_cand) atomicAdd(&d.fstat[FS_CAND], st_cand);
+}
+
+
 // ---- stage-1 edges, SORTED / LIST form (opt-in: BTS_EDGES_SORTED=1 when the tracker is created; NOT yet measured) --------------
 // What the tile form above spends its time on is (a) screening every row of a tile against every wavefront's 64 columns --
 // N M / 64 wave-rows of ~20 instructions, nearly all of them for nothing: a wavefront's columns are 64 detections from all over
@@ -2494,6 +2864,8 @@ struct bts_tracker {
     int lap_form = 0;             // BTS_LAP_FORM=row at create: the assignment kernel's round-2 row forms (bts_lap_enqueue)
     int lap_helpers = -1;         // BTS_LAP_HELPERS at create: helper workgroups per assignment problem (< 0: automatic)
     int filter_pw = 0;            // BTS_FILTER_PW at create: persistent GEMM workgroups of the pre-filter (0: FILTER_PW)
+    int filter_tile = 0;          // BTS_FILTER_TILE at create: 0 = 128x128 (k_filter_i8), 1 = 160x128, 2 = 128x64 (k_filter_t)
+    int last_ftm = FBM, last_ftn = FBN;      // tile shape the last step's pre-filter ran with (bts_tracker_debug_filter)
     int tile_goal = 768;          // BTS_TILE_GOAL at create: workgroup count the stage-1 / duplicate tile heights aim at
     char forms[384] = "";         // the switches in effect, as bts_tracker_forms reports them
     bool onepass = false;         // BTS_FILTER_ONEPASS=1 at create: the persistent one-pass pre-filter also for split-K-sized problems
@@ -2752,6 +3124,15 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
     { const char *e = bts_form_get("BTS_FILTER_PW"); const int v = e ? atoi(e) : 0; t->filter_pw = v > 0 && v <= 2048 ? v : 0; }
     { const char *e = bts_form_get("BTS_TILE_GOAL"); const int v = e ? atoi(e) : 0; t->tile_goal = v >= 64 && v <= 16384 ? v : 768; }
     t->onepass = bts_form_flag("BTS_FILTER_ONEPASS");
+    {   // BTS_FILTER_TILE=160x128 | 128x64 (read at create): tile shape of the one-pass pre-filter (k_filter_t); anything else = 128x128
+        const char *e = bts_form_get("BTS_FILTER_TILE");
+        t->filter_tile = !e ? 0 : !strcmp(e, "160x128") ? 1 : !strcmp(e, "128x64") ? 2 : 0;
+#ifdef BTS_HOST_EMU
+        if (e && !strcmp(e, "128x128t")) t->filter_tile = 3;      // (emulator build only: the template at k_filter_i8's own shape, two record
+                                                                 //  images -- tests/test_emu_gpu_subset.py holds the two kernels against each other)
+#endif
+        if (d.Df > 0 || d.sorted) t->filter_tile = 0;      // (no face pass, no candidate list in k_filter_t)
+    }
     d.gate_sim = 1.0f - d.app;
     d.f_guess = bts_form_flag("BTS_FILTER_GUESS") ? 1 : 0;
     {   // first prefix checkpoint of the pre-filter: from the gate, or BTS_I8_FIRST16 (3 .. 12; 5 = the round-2 set)
@@ -2762,10 +3143,11 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
     // the forms in effect (a requested form that the configuration rules out -- the sorted edges with a motion gate, say --
     // does not appear), for bts_tracker_forms
     snprintf(t->forms, sizeof(t->forms), "edges=%s,lists_ahead=%d,merge_early=%d,renorm_fused=%d,cvt_overlap=%d,predict_front=%d,predict_first=%d,lap_form=%s,lap_helpers=%d,list_chunks=%d,"
-             "filter_pw=%d,filter_first16=%d,filter_onepass=%d,filter_guess=%d,shadow_planes=%d,tile_goal=%d,lap_self=%d",
+             "filter_pw=%d,filter_first16=%d,filter_onepass=%d,filter_guess=%d,shadow_planes=%d,tile_goal=%d,lap_self=%d,filter_tile=%s",
              d.sorted ? "sorted" : (d.use_grid && d.filter) ? "grid" : "tiles", d.ahead, d.merge_early, d.renorm_fused, t->cvt_overlap ? 1 : 0, t->predict_front ? 1 : 0, t->predict_first ? 1 : 0,
-             t->lap_form == 1 ? "row" : "col", t->lap_helpers, d.nch, t->filter_pw > 0 ? t->filter_pw : FILTER_PW, d.chk_first,
-             t->onepass ? 1 : 0, d.f_guess, d.sh_planes, t->tile_goal, lap_self_slices(d) > 0 ? 1 : 0);
+             t->lap_form == 1 ? "row" : "col", t->lap_helpers, d.nch, t->filter_pw > 0 ? t->filter_pw : (t->filter_tile == 2 ? 768 : FILTER_PW), d.chk_first,
+             t->onepass ? 1 : 0, d.f_guess, d.sh_planes, t->tile_goal, lap_self_slices(d) > 0 ? 1 : 0,
+             t->filter_tile == 1 ? "160x128" : t->filter_tile == 2 ? "128x64" : t->filter_tile == 3 ? "128x128t" : "128x128");
     size_t off = 0;
     tracker_layout(t, nullptr, off);
     const int64_t o_cap = (cfg->tie_mode && d.Df > 0) ? e_cap : 0;      // overrides of the exact-tie step (tk_edges_xo): their own region
@@ -3043,7 +3425,21 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
         // (BTS_FILTER_PW: sweep knob for the number of persistent GEMM workgroups, host side only)
         const int pw = t->filter_pw > 0 ? t->filter_pw : FILTER_PW;
         const int gemm_blocks = ftiles < pw ? ftiles : pw;
-        if (!accum && d.sorted && t->predict_first) { LAUNCH((k_filter_i8<false, 0, true, true>), dim3(gemm_blocks + kf_pre), dim3(256), mc, ftiles, gemm_blocks); }
+        t->last_ftm = FBM; t->last_ftn = FBN;
+        if (!accum && t->filter_tile && !d.sorted && d.Df == 0) {
+            // BTS_FILTER_TILE: the shape-generic kernel (predict workgroups behind the GEMM ones, like the default)
+            const int tm = t->filter_tile == 1 ? 160 : 128, tn = t->filter_tile == 2 ? 64 : 128;
+            const int ttiles = bts_cdiv(T, tm) * bts_cdiv(mc, tn);
+            const int tpw = t->filter_pw > 0 ? t->filter_pw : (t->filter_tile == 2 ? 768 : FILTER_PW);
+            const int tblocks = ttiles < tpw ? ttiles : tpw;
+            if (t->filter_tile == 1) { LAUNCH((k_filter_t<160, 128, 1, 4, 2, 1>), dim3(tblocks + kf_pre), dim3(256), mc, ttiles, tblocks); }
+#ifdef BTS_HOST_EMU
+            else if (t->filter_tile == 3) { LAUNCH((k_filter_t<128, 128, 2, 2, 2, 2>), dim3(tblocks + kf_pre), dim3(256), mc, ttiles, tblocks); }
+#endif
+            else { LAUNCH((k_filter_t<128, 64, 2, 2, 3, 1>), dim3(tblocks + kf_pre), dim3(256), mc, ttiles, tblocks); }
+            t->last_ftm = tm; t->last_ftn = tn;
+        }
+        else if (!accum && d.sorted && t->predict_first) { LAUNCH((k_filter_i8<false, 0, true, true>), dim3(gemm_blocks + kf_pre), dim3(256), mc, ftiles, gemm_blocks); }
         else if (!accum && d.sorted) { LAUNCH((k_filter_i8<false, 0, false, true>), dim3(gemm_blocks + kf_pre), dim3(256), mc, ftiles, gemm_blocks); }
         else if (!accum && t->predict_first) { LAUNCH((k_filter_i8<false, 0, true>), dim3(gemm_blocks + kf_pre), dim3(256), mc, ftiles, gemm_blocks); }
         else if (!accum) { LAUNCH(k_filter_i8<false>, dim3(gemm_blocks + kf_pre), dim3(256), mc, ftiles, gemm_blocks); }
@@ -3476,6 +3872,7 @@ int bts_tracker_debug_filter(bts_tracker *t, int32_t *out8_host, bts_stream stre
     if (!t->dv.filter) return BTS_OK;
     BTS_HIP(hipMemcpyAsync(out8_host, t->dv.fstat, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
     BTS_HIP(hipStreamSynchronize((hipStream_t)stream));
+    out8_host[14] = t->last_ftm; out8_host[15] = t->last_ftn;      // tile shape of the one-pass form (a K stage = that many rows x columns x 128)
     return BTS_OK;
 }
 

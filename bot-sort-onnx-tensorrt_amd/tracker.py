@@ -669,6 +669,7 @@ class DeviceTracker:
         _lib.check(self._lib.bts_tracker_debug_filter(self.handle, h.ctypes.data, _lib.current_stream()))
         self._filter_raw = h
         return {"k_stages": int(h[0]), "tiles": int(h[1]), "prefix_exits": int(h[2]), "candidates": int(h[3]), "tests": int(h[4]),
+                "tile": (int(h[14]) or 128, int(h[15]) or 128),      # rows x columns of a tile: a K stage is that x 128 elements (BTS_FILTER_TILE)
                 # clock cycles summed over the persistent workgroups (one wave's view): candidate tests, waits for operand stages, total
                 "cycles_tests": int(h[5]) * 64, "cycles_stage_waits": int(h[6]) * 64, "cycles_total": int(h[7]) * 64}
 

@@ -281,7 +281,8 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
 /* EXECUTION FORMS.  Several kernels / launch structures of a step exist in more than one form with bit-identical RESULTS
  * (which one is faster depends on the table size and the scene): `forms` = "KEY=VALUE,KEY=VALUE,..." selects them for this
  * tracker; a key that is absent falls back to the process environment variable of the same name, then to the default;
- * "KEY=" (empty value) switches a form off whatever the environment says.  NULL / "" = bts_tracker_create.
+ * "KEY=" (empty value) switches a form off whatever the environment says, and so do the values 0 / false / off / no of a
+ * boolean form.  NULL / "" = bts_tracker_create.
  *   BTS_EDGES_SORTED=1   stage-1 edges: detections in grid order + candidate list (tk_edges_sorted) instead of the tile form
  *   BTS_EDGES_GRID=1     stage-1 edges by neighbour search on the detection grid
  *   BTS_LISTS_AHEAD=1    the next frame's pool / unconfirmed / free lists are built in this frame's last launch
@@ -298,9 +299,11 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
  *   BTS_LAP_HELPERS=n    helper workgroups per assignment problem (default 15 / 63)
  *   BTS_CHUNK_ROWS=n     list jobs split into chunks of n entries (default: unsplit up to 6144 tracks, then 2048)
  *   BTS_FILTER_PW=n      persistent workgroups of the pre-filter (default 512)
+ *   BTS_FILTER_TILE=160x128|128x64  tile shape of the one-pass pre-filter (default 128x128): 160 x 128 = two tile rounds instead of
+ *                        three at 10 000 x 2 000; 128 x 64 = three resident workgroups per CU (768 persistent workgroups)
  *   BTS_I8_FIRST16=k     first prefix checkpoint of the pre-filter, in sixteenths of the feature width (3..12)
  *   BTS_TILE_GOAL=n      workgroup count the stage-1 tile height aims at (default 768)
- * None of them changes a result (tests/test_zz_gpu_round4.py: identical assignment indices, lists and state per frame);
+ * None of them changes a result (tests/test_zz_gpu_round4.py, test_zz_gpu_round5.py: identical assignment indices, lists and state per frame);
  * the Python package's `tune` module times them on the caller's own frames and keeps what is fastest AND identical.
  * bts_tracker_forms writes the forms IN EFFECT (a requested form the configuration rules out does not appear) as text into
  * buf (NUL-terminated, truncated to capacity) and returns its full length. */

@@ -97,3 +97,31 @@ def test_every_header_is_a_make_dependency():
     hdrs = re.search(r"^HDRS\s*=\s*(.*)$", mk, flags=re.M).group(1).split()
     have = sorted(os.path.basename(p) for p in glob.glob(os.path.join(csrc, "*.h")))
     assert sorted(h for h in hdrs if "/" not in h) == have, (hdrs, have)
+
+
+def test_prefilter_tile_shapes_fit_their_occupancy(code_objects):
+    """k_filter_t (BTS_FILTER_TILE): what each shape was built FOR is a property of its code object -- two resident workgroups per
+    CU for the 160 x 128 tiles (<= 256 registers per lane, <= 80 KB of LDS), three for the 128 x 64 tiles (<= 168 registers,
+    <= 53.3 KB), no scratch (any scratch use measured ~2 us per launch in round 2) -- and can be checked without a GPU."""
+    ks = _kernels(code_objects)
+    dem = dict(zip(sorted(ks), subprocess.run(["c++filt"], input="\n".join(sorted(ks)), capture_output=True, text=True, check=True).stdout.splitlines()))
+    want = {"k_filter_t<160, 128, 1, 4, 2, 1>": (256, 160 * 1024 // 2), "k_filter_t<128, 64, 2, 2, 3, 1>": (168, 160 * 1024 // 3)}
+    seen = set()
+    for name, f in ks.items():
+        for key, (vmax, lmax) in want.items():
+            if key in dem[name]:
+                seen.add(key)
+                assert f["vgpr_count"] <= vmax, (key, f)
+                assert f["group_segment_fixed_size"] <= lmax, (key, f)
+                assert f.get("private_segment_fixed_size", 0) == 0 and f.get("vgpr_spill_count", 0) == 0, (key, f)
+    assert seen == set(want), seen
+    # the K loop of every shape: one MFMA per 32 x 32 block and K step (4 K steps per stage), fed by LDS-DMA
+    for o in code_objects:
+        asm = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", o], capture_output=True, text=True, check=True).stdout
+        for sym, blocks, loads in (("k_filter_tILi160ELi128", 5, 9), ("k_filter_tILi128ELi64", 2, 6)):
+            m = re.search(r"<[^>]*%s[^>]*>:\n(.*?)(?=\n\n|\Z)" % sym, asm, flags=re.S)
+            if not m:
+                continue
+            body = m.group(1)
+            assert len(re.findall(r"v_mfma_i32_32x32x32_i8", body)) == 4 * blocks, sym
+            assert len(re.findall(r"global_load_lds_dwordx4", body)) >= 2 * loads, sym       # (stage + next-tile first stage + records)

@@ -35,10 +35,16 @@ SUBSET = [
     "tests/test_zz_gpu_round4.py::test_solver_forms_agree",                         # (plain scene, SELF form: -k below)
     "tests/test_zz_gpu_round4.py::test_renorm_fused_changes_no_row",                # (fused + merge early + lists ahead)
     "tests/test_zz_gpu_round4.py::test_lists_ahead_changes_no_result",              # (lists ahead + predict front + cvt + sorted edges)
+    # round 5: the shape-generic pre-filter (k_filter_t) -- the template at k_filter_i8's own shape against k_filter_i8, counter by
+    # counter; both new tile shapes on a stream with churn against the default tiles and the oracle; boolean forms given as 0
+    "tests/test_zz_gpu_round5.py::test_template_at_the_default_shape_is_k_filter_i8",
+    "tests/test_zz_gpu_round5.py::test_prefilter_tile_shapes_with_churn_vs_oracle",   # (160x128 with the other forms, 128x64 alone: -k below)
+    "tests/test_zz_gpu_round5.py::test_a_boolean_form_given_as_zero_is_off",
 ]
 DESELECT = ("not (ragged and not (5-2-64 or 4-1-64 or 17-9-128)) and not (column_form and not 0)"
             " and not (solver_forms_agree and not plain-col+self) and not (renorm_fused and not 300-150-128-0-fused+merge_early+ahead)"
-            " and not (lists_ahead_changes and not 300-150-128-ahead+predict_front+cvt+sorted)")
+            " and not (lists_ahead_changes and not 300-150-128-ahead+predict_front+cvt+sorted)"
+            " and not (churn_vs_oracle and not (160x128-ahead or (128x64 and not merge_early)))")
 
 
 def _run(nodes, deselect, at_least, order=None):
@@ -60,7 +66,7 @@ needs_toolchain = pytest.mark.skipif(not os.path.exists(CLANG) or shutil.which("
 
 @needs_toolchain
 def test_gpu_parity_tests_pass_on_the_emulated_kernels():
-    _run(SUBSET, DESELECT, 71)
+    _run(SUBSET, DESELECT, 75)
 
 
 @needs_toolchain
