@@ -70,6 +70,41 @@ for _name in ("empty", "zeros", "ones", "full", "tensor", "as_tensor"):
     setattr(torch, _name, _wrap)
 
 
+# ---- HIPEMU_STREAMS=sidelate | mainlate (hip/hip_runtime.h): one side of the library's two-stream forms lags as far behind as the
+# program's own event dependencies allow.  What the device would order for a real torch program is re-created here: a host
+# synchronisation (torch.cuda.synchronize, Tensor.cpu) is a "device idle" point, and the tensors handed to a step stay alive
+# while the step may still be queued (on a GPU the caching allocator's stream semantics do that).
+if os.environ.get("HIPEMU_STREAMS"):
+    import collections
+    import ctypes as _ct
+
+    _emu = _ct.CDLL(os.environ["BTS_LIB_PATH"])
+    torch.cuda.synchronize = lambda *a, **k: _emu.hipemu_drain_all()
+    _Stream.synchronize = lambda self: _emu.hipemu_drain_all()
+    _Event.synchronize = lambda self: _emu.hipemu_drain_all()
+    _cpu = torch.Tensor.cpu
+
+    def _cpu_sync(self, *a, **k):
+        _emu.hipemu_drain_all()
+        return _cpu(self, *a, **k)
+    torch.Tensor.cpu = _cpu_sync
+    _alive = collections.deque(maxlen=64)
+
+    def _keep_step_inputs():
+        import importlib
+        trk_mod = importlib.import_module("bot-sort-onnx-tensorrt_amd.tracker")
+        if getattr(trk_mod.DeviceTracker, "_emu_keeps_inputs", False):
+            return
+        _step = trk_mod.DeviceTracker.step
+
+        def step(self, *a, **k):
+            _alive.append((a, k))
+            return _step(self, *a, **k)
+        trk_mod.DeviceTracker.step = step
+        trk_mod.DeviceTracker._emu_keeps_inputs = True
+    _keep_step_inputs()
+
+
 # ---- BTS_HOST_TIME_REPORT=path: per test, the wall time spent OUTSIDE the library's entry points (oracle, stream generation,
 # NumPy, pytest) -- on a GPU box the library calls take milliseconds, so this is what a test costs there; the driver's limit for
 # the whole `-m gpu` suite is 1200 s.  Written as JSON at session end (one file per xdist worker).

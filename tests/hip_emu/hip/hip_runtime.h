@@ -206,7 +206,8 @@ static inline void emu_global_load_lds(const void *g, void *lds_base, int size) 
 typedef int hipError_t;
 enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2 };
 typedef struct EmuStream *hipStream_t;
-typedef struct EmuEvent { double t; } *hipEvent_t;
+// an event remembers the stream of its latest record and two counters: records enqueued / records executed (HIPEMU_STREAMS)
+typedef struct EmuEvent { double t; struct EmuStream *owner; unsigned long long enq, done; } *hipEvent_t;
 typedef struct EmuGraph *hipGraph_t;
 typedef struct EmuGraphExec *hipGraphExec_t;
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
@@ -218,31 +219,52 @@ static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
 static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
-static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+namespace emu { void drain_all(); }
+static inline hipError_t hipDeviceSynchronize() { emu::drain_all(); return hipSuccess; }
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { memset(p, 0, sizeof(*p)); strcpy(p->name, "CPU emulation of gfx950"); strcpy(p->gcnArchName, "gfx950:sramecc+:xnack-"); p->multiProcessorCount = 256; p->totalGlobalMem = (size_t)1 << 34; return hipSuccess; }
 static inline hipError_t hipMalloc(void **p, size_t n) { *p = aligned_alloc(256, (n + 255) / 256 * 256); return *p ? hipSuccess : hipErrorOutOfMemory; }
-static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+static inline hipError_t hipFree(void *p) { emu::drain_all(); free(p); return hipSuccess; }
 static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
-static inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
-static inline hipError_t hipMemset(void *p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
+// ---- streams and events (HIPEMU_STREAMS) -------------------------------------------------------------------------------------
+// Default ("eager"): every operation runs when it is enqueued, streams are in-order no-ops -- one legal schedule of a correct
+// program, and blind to a MISSING cross-stream dependency.  HIPEMU_STREAMS=sidelate | mainlate makes one side of the library's
+// two-stream forms (BTS_CVT_OVERLAP: the step's stream + a side stream, ordered by events only) LAZY: its operations queue up and
+// run only when something legally forces them -- another stream's hipStreamWaitEvent on one of its records, a synchronising
+// call, or a full queue -- i.e. as LATE as the program's own dependencies allow, while the other side runs at once.  "sidelate":
+// created streams lag behind the null stream (which the tests step on); "mainlate": the null stream lags behind the created
+// ones.  A dependency the program forgot to state (a side-stream kernel that overwrites a buffer the lagging stream has not
+// consumed yet, a consumer that does not wait for its producer) then produces a different result, which the digests of
+// tests/test_zz_gpu_round5.py::test_cvt_overlap_under_adversarial_stream_schedules catch.  Not a timing model: two legal extremes.
+namespace emu {
+void stream_op(hipStream_t s, std::function<void()> f);       // a kernel / asynchronous memory operation on stream s
+void stream_record(hipStream_t s, hipEvent_t e);
+void stream_wait(hipStream_t s, hipEvent_t e);
+void stream_sync(hipStream_t s);                               // run everything queued on s (and what it waits for)
+void event_sync(hipEvent_t e);
+void drain_all();                                              // device idle
+hipStream_t stream_create();
+void stream_destroy(hipStream_t s);
+}
+static inline hipError_t hipHostFree(void *p) { emu::drain_all(); free(p); return hipSuccess; }
+static inline hipError_t hipMemset(void *p, int v, size_t n) { emu::drain_all(); memset(p, v, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t = nullptr);
-static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { emu::drain_all(); memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t = nullptr);
-static inline hipError_t hipMemcpy2DAsync(void *d, size_t dp, const void *s, size_t sp, size_t w, size_t h, hipMemcpyKind, hipStream_t = nullptr) {
-    for (size_t r = 0; r < h; ++r) memmove((char *)d + r * dp, (const char *)s + r * sp, w);
+static inline hipError_t hipMemcpy2DAsync(void *d, size_t dp, const void *s, size_t sp, size_t w, size_t h, hipMemcpyKind, hipStream_t st = nullptr) {
+    emu::stream_op(st, [=]() { for (size_t r = 0; r < h; ++r) memmove((char *)d + r * dp, (const char *)s + r * sp, w); });
     return hipSuccess;
 }
-template <class T> static inline hipError_t hipMemcpyFromSymbol(void *d, T *sym, size_t n) { memcpy(d, (const void *)sym, n); return hipSuccess; }
-static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
-static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = (hipStream_t)malloc(8); return hipSuccess; }
-static inline hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
-static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+template <class T> static inline hipError_t hipMemcpyFromSymbol(void *d, T *sym, size_t n) { emu::drain_all(); memcpy(d, (const void *)sym, n); return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t s) { emu::stream_sync(s); return hipSuccess; }
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = emu::stream_create(); return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t s) { emu::stream_destroy(s); return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned) { emu::stream_wait(s, e); return hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = (hipEvent_t)calloc(1, sizeof(EmuEvent)); return hipSuccess; }
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return hipEventCreate(e); }
-static inline hipError_t hipEventDestroy(hipEvent_t e) { free(e); return hipSuccess; }
-static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t = nullptr) { return hipSuccess; }
-static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
-static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.001f; return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t e) { emu::drain_all(); free(e); return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t s = nullptr) { emu::stream_record(s, e); return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t e) { emu::event_sync(e); return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { emu::event_sync(a); emu::event_sync(b); *ms = 0.001f; return hipSuccess; }
 template <class F> static inline hipError_t hipFuncSetAttribute(F, hipFuncAttribute, int) { return hipSuccess; }
 // hipGraph: while a capture is open, launches / async copies / memsets are RECORDED as closures (arguments frozen by value,
 // like kernel nodes) instead of executed; a graph launch runs the recorded list in order.  One capture at a time; forked
@@ -251,18 +273,18 @@ struct EmuGraph { std::vector<std::function<void()>> nodes; };
 struct EmuGraphExec { std::vector<std::function<void()>> nodes; };
 namespace emu {
 EmuGraph *&capturing();
-void launch_or_record(dim3 grid, dim3 block, size_t dyn_lds, std::function<void()> body);
+void launch_or_record(dim3 grid, dim3 block, size_t dyn_lds, hipStream_t stream, std::function<void()> body);
 static inline bool record(std::function<void()> f) { if (!capturing()) return false; capturing()->nodes.push_back(std::move(f)); return true; }
 }
 static inline hipError_t hipStreamBeginCapture(hipStream_t, int) { if (emu::capturing()) return hipErrorInvalidValue; emu::capturing() = new EmuGraph(); return hipSuccess; }
 static inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t *g) { *g = emu::capturing(); emu::capturing() = nullptr; return *g ? hipSuccess : hipErrorInvalidValue; }
 static inline hipError_t hipGraphInstantiate(hipGraphExec_t *e, hipGraph_t g, void *, void *, size_t) { *e = new EmuGraphExec{g->nodes}; return hipSuccess; }
 static inline hipError_t hipGraphDestroy(hipGraph_t g) { delete g; return hipSuccess; }
-static inline hipError_t hipGraphLaunch(hipGraphExec_t e, hipStream_t) { for (auto &f : e->nodes) f(); return hipSuccess; }
-static inline hipError_t hipGraphExecDestroy(hipGraphExec_t e) { delete e; return hipSuccess; }
+static inline hipError_t hipGraphLaunch(hipGraphExec_t e, hipStream_t s) { emu::stream_op(s, [e]() { for (auto &f : e->nodes) f(); }); return hipSuccess; }
+static inline hipError_t hipGraphExecDestroy(hipGraphExec_t e) { emu::drain_all(); delete e; return hipSuccess; }
 
-static inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { if (!emu::record([=]() { memset(p, v, n); })) memset(p, v, n); return hipSuccess; }
-static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { if (!emu::record([=]() { memmove(d, s, n); })) memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t st) { if (!emu::record([=]() { memset(p, v, n); })) emu::stream_op(st, [=]() { memset(p, v, n); }); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t st) { if (!emu::record([=]() { memmove(d, s, n); })) emu::stream_op(st, [=]() { memmove(d, s, n); }); return hipSuccess; }
 
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
-    emu::launch_or_record(dim3(grid), dim3(block), (size_t)(shmem), [=]() { kern(__VA_ARGS__); })
+    emu::launch_or_record(dim3(grid), dim3(block), (size_t)(shmem), (hipStream_t)(stream), [=]() { kern(__VA_ARGS__); })

@@ -8,6 +8,8 @@
 #include <ucontext.h>
 #include <sys/mman.h>
 #include <algorithm>
+#include <deque>
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -256,9 +258,113 @@ void launch(dim3 grid, dim3 block, size_t dyn_lds, const std::function<void()> &
 }
 
 EmuGraph *&capturing() { static EmuGraph *g = nullptr; return g; }
-void launch_or_record(dim3 grid, dim3 block, size_t dyn_lds, std::function<void()> body) {
+void launch_or_record(dim3 grid, dim3 block, size_t dyn_lds, hipStream_t stream, std::function<void()> body) {
     if (capturing()) { capturing()->nodes.push_back([=]() { launch(grid, block, dyn_lds, body); }); return; }
-    launch(grid, block, dyn_lds, body);
+    stream_op(stream, [=]() { launch(grid, block, dyn_lds, body); });
+}
+
+// ---- streams and events: see hip/hip_runtime.h (HIPEMU_STREAMS) ---------------------------------------------------------------
+namespace {
+enum { SOP_RUN, SOP_RECORD, SOP_WAIT };
+struct SOp { int kind; std::function<void()> f; EmuEvent *ev; unsigned long long seq; EmuStream *from; };
+struct StreamState { std::deque<SOp> q; };
+std::map<EmuStream *, StreamState> g_streams;          // key nullptr = the null stream
+std::recursive_mutex g_stream_mu;
+int g_forced_ops = 0, g_queued_ops = 0, g_cross_forces = 0;
+int stream_mode() {                                    // 0 eager (default), 1 sidelate, 2 mainlate
+    static const int m = [] { const char *e = getenv("HIPEMU_STREAMS"); return !e ? 0 : !strcmp(e, "sidelate") ? 1 : !strcmp(e, "mainlate") ? 2 : 0; }();
+    return m;
+}
+bool lazy(EmuStream *s) { const int m = stream_mode(); return m == 1 ? s != nullptr : m == 2 ? s == nullptr : false; }
+constexpr size_t QUEUE_LIMIT = 48;                     // operations a lagging stream may hold (~4 steps of the tracker)
+
+// run the operations queued on s, oldest first, up to and including the record (ev, seq) -- everything if ev is null.  A wait
+// whose record is still queued on another stream forces that stream first (a cycle would be a deadlock of the program itself).
+void force(EmuStream *s, EmuEvent *ev, unsigned long long seq, int depth) {
+    if (depth > 16) { fprintf(stderr, "hipemu: streams wait for each other in a cycle\n"); abort(); }
+    std::deque<SOp> &q = g_streams[s].q;
+    while (!q.empty()) {
+        SOp op = std::move(q.front());
+        q.pop_front();
+        ++g_forced_ops;
+        if (op.kind == SOP_RUN) op.f();
+        else if (op.kind == SOP_RECORD) {
+            if (op.ev->done < op.seq) op.ev->done = op.seq;
+            if (ev && op.ev == ev && op.seq >= seq) return;
+        } else if (op.ev->done < op.seq) { ++g_cross_forces; force(op.from, op.ev, op.seq, depth + 1); }
+    }
+}
+}  // namespace
+
+void stream_op(hipStream_t s, std::function<void()> f) {
+    if (stream_mode() == 0) { f(); return; }
+    std::lock_guard<std::recursive_mutex> lock(g_stream_mu);
+    if (!lazy(s)) { f(); return; }                     // (an eager stream never holds anything back: its queue is empty)
+    std::deque<SOp> &q = g_streams[s].q;
+    q.push_back(SOp{SOP_RUN, std::move(f), nullptr, 0, nullptr});
+    ++g_queued_ops;
+    while (q.size() > QUEUE_LIMIT) {                   // running the OLDEST operations early is still a legal schedule
+        SOp op = std::move(q.front());
+        q.pop_front();
+        if (op.kind == SOP_RUN) op.f();
+        else if (op.kind == SOP_RECORD) { if (op.ev->done < op.seq) op.ev->done = op.seq; }
+        else if (op.ev->done < op.seq) force(op.from, op.ev, op.seq, 1);
+    }
+}
+void stream_record(hipStream_t s, hipEvent_t e) {
+    if (!e) return;
+    if (stream_mode() == 0) { e->owner = s; e->done = ++e->enq; return; }
+    std::lock_guard<std::recursive_mutex> lock(g_stream_mu);
+    e->owner = s;
+    const unsigned long long seq = ++e->enq;
+    if (lazy(s)) g_streams[s].q.push_back(SOp{SOP_RECORD, nullptr, e, seq, s}); else e->done = seq;
+}
+void stream_wait(hipStream_t s, hipEvent_t e) {
+    if (!e || stream_mode() == 0) return;
+    // HIPEMU_DROP_WAITS=main | side: FAULT INJECTION for the schedule tests -- the waits issued on the null stream / on created
+    // streams are ignored, i.e. the program "forgot" those dependencies; the adversarial schedules must then change a result
+    // (tests/test_emu_gpu_subset.py: the detector detects)
+    static const char *drop = getenv("HIPEMU_DROP_WAITS");
+    if (drop && ((!strcmp(drop, "main") && s == nullptr) || (!strcmp(drop, "side") && s != nullptr))) return;
+    std::lock_guard<std::recursive_mutex> lock(g_stream_mu);
+    const unsigned long long seq = e->enq;             // (HIP: the wait is for the latest record enqueued at this point)
+    if (seq == 0 || e->done >= seq || e->owner == s) return;
+    if (lazy(s)) g_streams[s].q.push_back(SOp{SOP_WAIT, nullptr, e, seq, e->owner});
+    else { ++g_cross_forces; force(e->owner, e, seq, 0); }
+}
+void stream_sync(hipStream_t s) {
+    if (stream_mode() == 0) return;
+    std::lock_guard<std::recursive_mutex> lock(g_stream_mu);
+    force(s, nullptr, 0, 0);
+    drain_all();       // the lag is bounded: once the host has waited for s, the other streams catch up (AFTER s: late, not never --
+                       // a stream that never ran would leave the zero-initialised shadows in place, which the design tolerates)
+}
+void event_sync(hipEvent_t e) {
+    if (!e || stream_mode() == 0) return;
+    std::lock_guard<std::recursive_mutex> lock(g_stream_mu);
+    if (e->done < e->enq) force(e->owner, e, e->enq, 0);
+    drain_all();
+}
+void drain_all() {
+    if (stream_mode() == 0) return;
+    std::lock_guard<std::recursive_mutex> lock(g_stream_mu);
+    for (bool again = true; again;) {
+        again = false;
+        for (auto &kv : g_streams) if (!kv.second.q.empty()) { force(kv.first, nullptr, 0, 0); again = true; }
+    }
+}
+hipStream_t stream_create() { return (hipStream_t)malloc(8); }
+void stream_destroy(hipStream_t s) {
+    if (stream_mode() != 0) { std::lock_guard<std::recursive_mutex> lock(g_stream_mu); force(s, nullptr, 0, 0); g_streams.erase(s); }
+    free(s);
 }
 
 }  // namespace emu
+
+// for the Python prelude (tests/hip_emu/emu_prelude.py): torch.cuda.synchronize() / Tensor.cpu() are "device idle" points too
+extern "C" void hipemu_drain_all() { emu::drain_all(); }
+extern "C" int hipemu_stream_mode() { return emu::stream_mode(); }
+// [0] operations that were queued on a lagging stream, [1] operations run because something forced them, [2] forces that crossed
+// streams (a wait on a record still queued elsewhere): a test asserts that the lagging really happened
+extern "C" void hipemu_stream_stats(int *out3) { out3[0] = emu::g_queued_ops; out3[1] = emu::g_forced_ops; out3[2] = emu::g_cross_forces; }
+

@@ -78,3 +78,33 @@ def test_results_do_not_depend_on_the_order_workgroups_run_in():
     _run(["tests/test_gpu_kernels.py", "tests/test_gpu_tracker.py::test_edge_frames", "tests/test_gpu_tracker.py::test_ragged_shapes_vs_oracle",
           "tests/test_zz_gpu_round3.py::test_lapjv_lds_preparation_layouts_vs_oracle"],
          "not (ragged and not (5-2-64 or 4-1-64 or 17-9-128))", 56, order="shuffle:3")
+
+
+@needs_toolchain
+def test_cvt_overlap_survives_adversarial_stream_schedules_and_the_detector_detects():
+    """BTS_CVT_OVERLAP's side-stream ordering had ZERO evidence -- events were no-ops in the emulator.  The
+    emulator's runtime now has two adversarial schedules (HIPEMU_STREAMS, tests/hip_emu/hip/hip_runtime.h): `sidelate` lets every
+    created stream lag behind the null stream as far as the program's own events allow (its operations run only when a wait on
+    one of its records, a synchronising call or a full queue forces them), `mainlate` lets the null stream -- the one the tests step
+    on -- lag behind the created ones.  The form must return the default forms' digests under both (24 teleporting frames, only the
+    converted detection shadows can associate them, digests every sixth frame, no host synchronisation in between).  And the
+    DETECTOR must detect: with the waits issued on the null stream ignored (HIPEMU_DROP_WAITS=main: the consumer no longer waits for
+    the conversion) `sidelate` has to fail, with the waits issued on the side stream ignored (`side`: the conversion no longer waits
+    for the previous user of its buffer) `mainlate` has to fail -- fault injection inside the emulator's runtime, the library's
+    source is untouched."""
+    subprocess.check_call(["make", "-C", EMU, "-s", "-j4"])
+    node = "tests/test_zz_gpu_round5.py::test_cvt_overlap_without_host_synchronisation_between_steps"
+    runs = {}
+    for mode, drop in (("sidelate", None), ("mainlate", None), ("sidelate", "main"), ("mainlate", "side")):
+        env = dict(os.environ, BTS_LIB_PATH=os.path.join(EMU, "libbotsort_emu.so"), HIPEMU_STREAMS=mode)
+        env.pop("HIPEMU_DROP_WAITS", None)
+        if drop:
+            env["HIPEMU_DROP_WAITS"] = drop
+        cmd = [sys.executable, "-m", "pytest", "-m", "gpu", "-p", "tests.hip_emu.emu_prelude", "-p", "no:cacheprovider", "-q", "--no-header",
+               "--timeout", "900", "-k", "True", node]
+        runs[(mode, drop)] = subprocess.Popen(cmd, cwd=REPO, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    out = {k: (p.communicate(timeout=1400)[0], p.returncode) for k, p in runs.items()}
+    for key in (("sidelate", None), ("mainlate", None)):
+        assert out[key][1] == 0 and "1 passed" in out[key][0], (key, out[key][0][-1500:])
+    for key in (("sidelate", "main"), ("mainlate", "side")):
+        assert out[key][1] != 0 and "1 failed" in out[key][0], (key, out[key][0][-1500:])

@@ -34,9 +34,10 @@ class _GateBand:
     """Frames whose cosines to the tracks' rows sit within +-0.01 of the appearance gate while the boxes teleport: only pairs the
     pre-filter hands to the exact refinement can re-associate."""
 
-    def __init__(self, K, D, seed):
+    def __init__(self, K, D, seed, inside=None):
         self.rng = np.random.default_rng(seed)
         self.K, self.D = K, D
+        self.inside = inside                 # (lo, hi): every cosine inside the gate instead (the stream then sustains itself)
         proto = self.rng.standard_normal((K, D))
         self.proto = proto / np.linalg.norm(proto, axis=1, keepdims=True)
         self.f = 0
@@ -48,6 +49,8 @@ class _GateBand:
         boxes = np.stack([cx, cy, cx + 5, cy + 9], 1).astype(np.int32)
         scores = (rng.uniform(0.91, 0.99, K) if self.f == 0 else rng.uniform(0.5, 0.85, K)).astype(np.float32)
         c = 0.75 + rng.uniform(3e-5, 0.01, K) * rng.choice([-1.0, 1.0], K)
+        if self.inside:
+            c = rng.uniform(self.inside[0], self.inside[1], K)
         if self.f == 0:
             c[:] = 1.0
         noise = rng.standard_normal((K, D))
@@ -218,4 +221,34 @@ def test_template_at_the_default_shape_is_k_filter_i8(bts, monkeypatch):
             for key in ("tiles", "k_stages", "prefix_exits", "candidates", "tile"):
                 assert sa[key] == sb[key], (f, key, sa, sb)
     assert ref.counts() == exp.counts() and exp.counts()["errors"] == 0
+    ref.close(); exp.close()
+
+
+@pytest.mark.parametrize("resident", [True, False])
+def test_cvt_overlap_without_host_synchronisation_between_steps(bts, monkeypatch, resident):
+    """BTS_CVT_OVERLAP (+ BTS_LISTS_AHEAD, the pairing it is offered in) over 24 frames whose boxes teleport while the cosines stay
+    inside the gate -- ONLY the appearance candidates, i.e. the converted detection shadows, can associate a frame, so a conversion
+    that ran at the wrong time changes every assignment -- digests compared with the default forms' every SIXTH frame only -- nothing synchronises the host with the device in between, so on a GPU the side
+    stream's conversion of frame t + 1 really runs under frame t's kernels.  On the CPU emulation this test is also run under
+    HIPEMU_STREAMS=sidelate / mainlate (tests/test_emu_gpu_subset.py): one of the two streams then lags as far behind the other as
+    the form's events allow, and a dependency the form forgot to state changes a digest."""
+    tune = importlib.import_module("bot-sort-onnx-tensorrt_amd.tune")
+    K, M, D = 96, 96, 128
+    ref = bts.DeviceTracker(max_tracks=K + 64, max_dets=max(K, M), feat_dim=D)
+    exp = bts.DeviceTracker(max_tracks=K + 64, max_dets=max(K, M), feat_dim=D, forms={"BTS_CVT_OVERLAP": 1, "BTS_LISTS_AHEAD": 1})
+    assert exp.forms()["cvt_overlap"] == "1" and ref.forms()["cvt_overlap"] == "0"
+    exp.inputs_resident(resident)
+    st = _GateBand(K, D, 31, inside=(0.8, 0.92))
+    frames = [_dev(st.next()) for _ in range(24)]
+    frames2 = [(b, s, f.clone()) for (b, s, f) in frames]
+    import torch
+    torch.cuda.synchronize()
+    for f, (fa, fb) in enumerate(zip(frames, frames2)):
+        ref.step(*fa)
+        exp.step(*fb)
+        if f % 6 == 5:
+            assert tune._digest(ref) == tune._digest(exp), f
+    assert tune._state_digest(ref) == tune._state_digest(exp)
+    assert ref.counts() == exp.counts() and exp.counts()["errors"] == 0
+    assert ref.counts()["n_tracked"] > K // 2           # (the stream sustained itself on appearance alone)
     ref.close(); exp.close()
