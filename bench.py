@@ -325,6 +325,30 @@ def several_streams(a, counts):
     return out
 
 
+def trace_legs(workload):
+    """The trace VARIANTS of the library (ab/ftrace.so, ab/trace.so: scripts/prepare_gpu_batches.sh; git-ignored, they travel with the
+    working tree) decoded by their scripts in child processes: k_filter_i8's own cycle accounting -- the decomposition of the
+    pre-filter's "fixed 22.5 us" (scripts/dbg_filtertrace.py) -- and k_lap's phase timeline (scripts/dbg_laptrace.py).  Last legs of
+    the line, own processes, own library: nothing measured above is touched.  They are in the line so that the ONE bench run a
+    round may get on a GPU also answers the questions the next round's work depends on."""
+    out = {}
+    for key, lib, script in (("prefilter_phases", "ftrace.so", "dbg_filtertrace.py"), ("lap_phases", "trace.so", "dbg_laptrace.py"),
+                             ("list_job_phases", "trace.so", "dbg_jobtrace.py")):
+        path = os.path.join(REPO, "ab", lib)
+        if not os.path.exists(path):
+            continue
+        try:
+            env = dict(os.environ, BTS_LIB_PATH=path)
+            for k in [k for k in env if k.startswith("BTS_") and k != "BTS_LIB_PATH"]:
+                env.pop(k)
+            r = subprocess.run([sys.executable, os.path.join(REPO, "scripts", script), workload], cwd=REPO, env=env, capture_output=True, text=True, timeout=240)
+            out[key] = {"library": "ab/" + lib, "rc": r.returncode, "table": [ln for ln in r.stdout.splitlines() if ln.strip()][-30:],
+                        "stderr_tail": r.stderr[-300:] if r.returncode else ""}
+        except Exception as e:
+            out[key] = {"library": "ab/" + lib, "error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+    return out
+
+
 def guarded(name, fn, *args, **kw):
     """Every leg BEHIND the timed region is an extra: whatever it raises becomes {"error": ...} in its object and the
     headline line (value, roofline, cpu_baseline) is still printed -- a first-contact failure in the export, facade or
@@ -832,6 +856,10 @@ def main():
                 out["id_match"] = guarded("id_match", checker.result)
             elif checker_err:
                 out["id_match"] = checker_err
+        if world == 1 and S == 1 and not a.no_cpu and not os.environ.get("BTS_LIB_PATH") and not a.graph and not a.dense:
+            tl = guarded("trace_legs", trace_legs, a.workload)
+            if tl:
+                out["trace_variants"] = tl
         guard.emit(out)
     elif guard.timer is not None:
         guard.timer.cancel()
