@@ -1689,7 +1689,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     static_assert(NIMG == 1 || NIMG == 2, "record images");
     __shared__ __attribute__((aligned(1024))) int8_t As2[DNS][TM * DBK];
     __shared__ __attribute__((aligned(1024))) int8_t Bs2[DNS][TN * DBK];
-    __shared__ float4 srec2[NIMG][E];
+    constexpr int EP = (E + 63) / 64 * 64;               // (padded to whole wavefront loads: every LDS-DMA below is issued by a FULL wavefront)
+    __shared__ float4 srec2[NIMG][EP];
     __shared__ __attribute__((aligned(16))) int s_cnt[2][4];     // survivors per wavefront
     __shared__ __attribute__((aligned(16))) float sred[2][16];   // {min uh, max alpha, max r, -} of the rows' records, per summarising wavefront
     if ((int)blockIdx.x >= gemm_blocks) { predict_body(d, (int)blockIdx.x - gemm_blocks); return; }
@@ -1703,9 +1704,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid / WC, wc = wid % WC;
     const int prow = lane >> 3, pchunk = lane & 7;
     const int frow = lane & 31, fh = lane >> 5;
-    // record entry e of a tile: row e (e < TM) or column e - TM; thread tid carries entry tid and, when E > 256, entry 256 + tid as well
-    const bool rec1 = tid < E, rec2 = E > 256 && tid < E - 256;
-    const int e1 = tid, e2 = 256 + tid;
+    // record entry e of a tile: row e (e < TM) or column e - TM; thread tid carries entry tid and, when E > 256, the threads of the
+    // first wavefront(s) entry 256 + tid as well (entries past E repeat the last one: whole wavefronts load, the padding is never read)
+    const bool rec1 = tid < EP, rec2 = E > 256 && tid < EP - 256;
+    const int e1 = tid < E ? tid : E - 1, e2 = 256 + tid < E ? 256 + tid : E - 1;
     auto rec_index = [&](int e, int bm, int bn, int n, int m) {
         const int g = e < TM ? bm * TM + e : bn * TN + (e - TM);
         return e < TM ? d.pool_slot[g < n ? g : bm * TM] : d.hi_idx[g < m ? g : bn * TN];
@@ -1800,6 +1802,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     auto stage_rec = [&](int img, int c) {
         if (rec1) __builtin_amdgcn_global_load_lds((gbl_void *)(mbase1 + ((size_t)meta_o1 + (size_t)(4 * c))), (lds_void *)&srec2[img][wid * 64], 16, 0, 0);
         if (rec2) __builtin_amdgcn_global_load_lds((gbl_void *)(mbase2 + ((size_t)meta_o2 + (size_t)(4 * c))), (lds_void *)&srec2[img][256 + wid * 64], 16, 0, 0);
+        static_assert(EP % 64 == 0 && (EP <= 256 || EP - 256 <= 256), "rec1 / rec2 are wave-uniform");
     };
     int rimg = 0;                                // image the NEXT test's records are in (or on their way to)
     stage(0, 0);
@@ -1828,7 +1831,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
             if (at_end || (ci < feat::I8_NCHK && kt == chk_at(ci))) {
                 // ---- candidate test on the prefix of kt stages (checkpoint ci; at the end: the full-row records)
                 if (at_end && nvt < ntiles && !next_staged) { stage_next(cur, ia, ib); next_staged = true; }
-                const lds_t srec_a = lds_rec + (unsigned)rimg * (unsigned)(E * 16);
+                const lds_t srec_a = lds_rec + (unsigned)rimg * (unsigned)(EP * 16);
                 const lds_t scnt_a = lds_cnt + (unsigned)flip * 16u, sred_a = lds_red + (unsigned)flip * 64u;
                 unsigned sv[MI];
 #pragma unroll
