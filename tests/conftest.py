@@ -30,3 +30,23 @@ def has_gpu():
         return torch.cuda.is_available()
     except Exception:
         return False
+
+
+@pytest.fixture(scope="session")
+def c5_oracle_frames(synth):
+    """BASELINE config 5's stream (16384 tracks x 4096 detections x 384-d, seed 1234) through the vectorised float64 oracle, ONCE per
+    session: three frames cost ~3 minutes of host time, and two GPU tests (default arithmetic, config 5's arithmetic mode) check
+    against the same run -- the driver's limit for the whole `-m gpu` suite is 1200 s.  Per frame: the inputs and what the oracle
+    made of them (stage matches, ordered tables, id counter)."""
+    from oracle import bts_oracle as bo
+    st = synth.SyntheticStream(16384, 4096, 384, seed=1234)
+    ora = bo.TrackerOracle(faithful_iou=False)
+    out = []
+    for _ in range(3):
+        fr = st.next()
+        feats0 = fr.feats.copy()
+        ora.update_arrays(fr.boxes, fr.scores.astype(np.float64), fr.feats.copy(), None)
+        out.append({"boxes": fr.boxes, "scores": fr.scores, "feats": feats0,
+                    "m": {k: np.asarray(ora.trace["m%d" % k]).reshape(-1, 2).copy() for k in (1, 2, 3)},
+                    "tables": [bo.TrackerOracle.table(ora.tracked), bo.TrackerOracle.table(ora.lost)], "count": ora._count})
+    return out

@@ -84,11 +84,32 @@ def test_config5_arithmetic_mode_id_match_rate(bts, K, M, D, frames):
     assert same64 == min(frames, 6) and worst64 <= 1e-12
 
 
-def test_config5_arithmetic_mode_full_size(bts):
-    """The mode at config 5's own size, 16384 tracks x 4096 detections x 384-d: three frames against the vectorised oracle."""
+def test_config5_arithmetic_mode_full_size(bts, c5_oracle_frames):
+    """The mode at config 5's own size, 16384 tracks x 4096 detections x 384-d: three frames against the vectorised oracle (its run
+    is shared with tests/test_gpu_round2.py::test_config5_stress_size_vs_oracle: conftest.c5_oracle_frames)."""
+    import torch
     K, M, D = 16384, 4096, 384
-    same, worst, pairs, pairs_eq = _id_match_rate(bts, bts.synth.SyntheticStream(K, M, D, seed=1234), K, M, D, 3,
-                                                  kalman_dtype=BTS_F32, cost_dtype=BTS_F16)
+    trk = bts.DeviceTracker(max_tracks=K + K // 2, max_dets=max(K, M), feat_dim=D, kalman_dtype=BTS_F32, cost_dtype=BTS_F16)
+    same, worst, pairs, pairs_eq = 0, 0.0, 0, 0
+    for fr in c5_oracle_frames:
+        trk.step(torch.from_numpy(fr["boxes"]).cuda(), torch.from_numpy(fr["scores"]).cuda(), torch.from_numpy(fr["feats"].copy()).cuda())
+        ok = True
+        for k in (1, 2, 3):
+            got, want = np.asarray(trk.stage_result(k)["m"]).reshape(-1, 2), fr["m"][k]
+            eq = got.shape == want.shape and bool((got == want).all())
+            pairs += len(want)
+            pairs_eq += len(want) if eq else len(set(map(tuple, got)) & set(map(tuple, want)))
+            ok &= eq
+        for which in (0, 1):
+            g, w = trk.export(which), fr["tables"][which]
+            tab_ok = all(np.array_equal(g[key], w[key]) for key in INT_KEYS)
+            ok &= tab_ok
+            if tab_ok and len(w["track_id"]):
+                scale = np.maximum(1.0, np.abs(w["mean"][:, :4]).max(axis=1, keepdims=True))
+                worst = max(worst, float((np.abs(g["mean"] - w["mean"]) / scale).max()))
+        same += int(ok)
+    assert trk.counts()["errors"] == 0
+    trk.close()
     assert pairs > 3500 and pairs_eq >= 0.995 * pairs and same >= 2 and worst <= 1e-6, (same, worst, pairs, pairs_eq)
 
 
