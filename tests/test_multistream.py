@@ -1,9 +1,9 @@
-"""The N>1 path of bench.py on CPU: two gloo ranks, one independent stream each (no data-path
-collective).  Each rank runs its stream through the CPU oracle (the GPU is not available here; on
-the GPU box the same sharding drives the HIP tracker) and the test checks that
-  * rank r gets stream r (seed base+r) and the two streams differ,
-  * a rank's result is identical to running that stream alone in a single process,
-  * the control plane (barrier, max/sum over ranks, aggregate steps/s) works."""
+"""The N>1 path on CPU, two gloo ranks, one independent stream each (no data-path collective):
+  * test_two_streams_two_ranks -- the control plane alone (multistream.py: stream r gets seed base+r, barrier, max / sum over
+    ranks, aggregate steps/s); the oracle stands in for the tracker there because only the sharding is under test;
+  * test_bench_two_ranks_run_the_product -- `bench.py --gpus 2` through its own self-spawn path with every rank driving the
+    PRODUCT library (the CPU emulation of its kernel sources, tests/hip_emu): own tracker handle per rank, default forms timed
+    first, a per-rank selection child, the selected forms re-timed, per-rank ID match against the oracle, ONE JSON line."""
 import importlib
 import json
 import os
