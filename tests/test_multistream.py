@@ -109,6 +109,11 @@ def test_bench_two_ranks_run_the_product(tmp_path):
     sel = {m["name"]: m for m in d["form_selection"]["table"]}
     assert sel["default"]["eligible"] and sel["merge_early"]["identical"] is True and sel["merge_early"]["errors"] == 0, d["form_selection"]
     assert d["form_selection"]["crashed"] == []
+    # round 5: the default forms are timed FIRST, the selected ones (under --gpus N: always re-measured, so that the ranks' barriers
+    # pair up) second; the line carries both and says which one `value` is
+    assert d["value_default_forms"] > 0 and d["value_selected_forms"] > 0 and d["value_is"] in ("default forms", "selected forms")
+    assert d["value"] == max(d["value_default_forms"], d["value_selected_forms"]) or d["value"] in (d["value_default_forms"], d["value_selected_forms"])
+    assert "noise_pct" in d["form_selection"] and len(d["form_selection"]["default_us_both"]) == 2
     im = d["id_match"]
     assert "error" not in im, im
     assert im["streams"] == 2 and len(im["frames_identical_per_stream"]) == 2
