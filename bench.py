@@ -325,6 +325,9 @@ def several_streams(a, counts):
     return out
 
 
+T_START = time.time()
+
+
 def trace_legs(workload):
     """The trace VARIANTS of the library (ab/ftrace.so, ab/trace.so: scripts/prepare_gpu_batches.sh; git-ignored, they travel with the
     working tree) decoded by their scripts in child processes: k_filter_i8's own cycle accounting -- the decomposition of the
@@ -332,6 +335,8 @@ def trace_legs(workload):
     the line, own processes, own library: nothing measured above is touched.  They are in the line so that the ONE bench run a
     round may get on a GPU also answers the questions the next round's work depends on."""
     out = {}
+    if time.time() - T_START > 480:          # (extras never push the line past the driver's patience: skipped when the run is already long)
+        return {"skipped": "the run had taken %d s when the trace legs were due" % int(time.time() - T_START)}
     for key, lib, script in (("prefilter_phases", "ftrace.so", "dbg_filtertrace.py"), ("lap_phases", "trace.so", "dbg_laptrace.py"),
                              ("list_job_phases", "trace.so", "dbg_jobtrace.py")):
         path = os.path.join(REPO, "ab", lib)
@@ -341,7 +346,7 @@ def trace_legs(workload):
             env = dict(os.environ, BTS_LIB_PATH=path)
             for k in [k for k in env if k.startswith("BTS_") and k != "BTS_LIB_PATH"]:
                 env.pop(k)
-            r = subprocess.run([sys.executable, os.path.join(REPO, "scripts", script), workload], cwd=REPO, env=env, capture_output=True, text=True, timeout=240)
+            r = subprocess.run([sys.executable, os.path.join(REPO, "scripts", script), workload], cwd=REPO, env=env, capture_output=True, text=True, timeout=100)
             out[key] = {"library": "ab/" + lib, "rc": r.returncode, "table": [ln for ln in r.stdout.splitlines() if ln.strip()][-30:],
                         "stderr_tail": r.stderr[-300:] if r.returncode else ""}
         except Exception as e:
