@@ -1679,7 +1679,7 @@ __device__ __forceinline__ void stage_mfma_t(lds_t abase, lds_t bbase, const Fra
 }
 
 template <int TM, int TN, int WR, int WC, int OCC, int NIMG>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void k_filter_t(Dev d, int m_max, int ntiles, int gemm_blocks) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void k_filter_t(Dev d, int m_max, int ntiles, int gemm_blocks, int kf_front) {
     typedef FragMapT<TM, TN, WR, WC> FM;
     constexpr int MI = FM::MI, NI = FM::NI;
     constexpr int PA = TM / 32, PB = TN / 32;            // 1-KiB wavefront loads (8 full 128-byte rows) per stage, wavefront and operand
@@ -1693,7 +1693,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     __shared__ float4 srec2[NIMG][EP];
     __shared__ __attribute__((aligned(16))) int s_cnt[2][4];     // survivors per wavefront
     __shared__ __attribute__((aligned(16))) float sred[2][16];   // {min uh, max alpha, max r, -} of the rows' records, per summarising wavefront
-    if ((int)blockIdx.x >= gemm_blocks) { predict_body(d, (int)blockIdx.x - gemm_blocks); return; }
+    // Kalman-predict workgroups of the same launch: behind the GEMM workgroups (kf_front = 0, the default) or in FRONT of them
+    // (BTS_PREDICT_FIRST: kf_front of them; a kernel argument here, not a second instantiation)
+    if (kf_front > 0 ? (int)blockIdx.x < kf_front : (int)blockIdx.x >= gemm_blocks) { predict_body(d, kf_front > 0 ? (int)blockIdx.x : (int)blockIdx.x - gemm_blocks); return; }
+    const int gb = (int)blockIdx.x - kf_front;           // this workgroup's index among the GEMM workgroups
     // (the chain that opens a workgroup is cut like k_filter_i8's: the index loads of the first tile position travel with the extents')
     const int n_raw = d.hdr[H_NPOOL], m_raw = d.hdr[H_NHI];
     const int Dd = d.D;
@@ -1712,7 +1715,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
         const int g = e < TM ? bm * TM + e : bn * TN + (e - TM);
         return e < TM ? d.pool_slot[g < n ? g : bm * TM] : d.hi_idx[g < m ? g : bn * TN];
     };
-    const int vt_first = (int)blockIdx.x;
+    const int vt_first = gb;
     int sia[PA], sib[PB], sirec = 0, sirec2 = 0, sfa = 0, sfb = 0, sbm = 0, sbn = 0;      // the first position's indices, fetched ahead of the extents
     if (vt_first < ntiles) {
         const int vb = xcd_remap(vt_first, ntiles);
@@ -1782,7 +1785,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     const int stop_thr = 6 + (3 * TM * TN) / (2 * (n > 0 ? n : 1));
     const float i8_s2 = feat::i8_scale(Dd) * feat::i8_scale(Dd) * 0.99999f;        // integer dot products per unit of dequantised dot product
     int bm, bn;
-    int vt = next_live((int)blockIdx.x, bm, bn);
+    int vt = next_live(gb, bm, bn);
     if (vt >= ntiles) return;
     int ia[PA], ib[PB], irec = 0, irec2 = 0;
     if (vt == vt_first) {
@@ -3434,16 +3437,20 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
         const int gemm_blocks = ftiles < pw ? ftiles : pw;
         t->last_ftm = FBM; t->last_ftn = FBN;
         if (!accum && t->filter_tile && !d.sorted && d.Df == 0) {
-            // BTS_FILTER_TILE: the shape-generic kernel (predict workgroups behind the GEMM ones, like the default)
+            // BTS_FILTER_TILE: the shape-generic kernel (predict workgroups behind the GEMM ones like the default, in front with BTS_PREDICT_FIRST)
             const int tm = t->filter_tile == 1 ? 160 : 128, tn = t->filter_tile == 2 ? 64 : 128;
             const int ttiles = bts_cdiv(T, tm) * bts_cdiv(mc, tn);
             const int tpw = t->filter_pw > 0 ? t->filter_pw : (t->filter_tile == 2 ? 768 : FILTER_PW);
             const int tblocks = ttiles < tpw ? ttiles : tpw;
-            if (t->filter_tile == 1) { LAUNCH((k_filter_t<160, 128, 1, 4, 2, 1>), dim3(tblocks + kf_pre), dim3(256), mc, ttiles, tblocks); }
+            // (in front: a multiple of 8 predict workgroups, so that GEMM workgroup g still runs on XCD g % 8 -- the tile order's
+            //  assumption; surplus predict workgroups find no row and exit)
+            const int kff = (t->predict_first && kf_pre) ? (kf_pre + 7) / 8 * 8 : 0;
+            const int tgrid = tblocks + (kff ? kff : kf_pre);
+            if (t->filter_tile == 1) { LAUNCH((k_filter_t<160, 128, 1, 4, 2, 1>), dim3(tgrid), dim3(256), mc, ttiles, tblocks, kff); }
 #ifdef BTS_HOST_EMU
-            else if (t->filter_tile == 3) { LAUNCH((k_filter_t<128, 128, 2, 2, 2, 2>), dim3(tblocks + kf_pre), dim3(256), mc, ttiles, tblocks); }
+            else if (t->filter_tile == 3) { LAUNCH((k_filter_t<128, 128, 2, 2, 2, 2>), dim3(tgrid), dim3(256), mc, ttiles, tblocks, kff); }
 #endif
-            else { LAUNCH((k_filter_t<128, 64, 2, 2, 3, 1>), dim3(tblocks + kf_pre), dim3(256), mc, ttiles, tblocks); }
+            else { LAUNCH((k_filter_t<128, 64, 2, 2, 3, 1>), dim3(tgrid), dim3(256), mc, ttiles, tblocks, kff); }
             t->last_ftm = tm; t->last_ftn = tn;
         }
         else if (!accum && d.sorted && t->predict_first) { LAUNCH((k_filter_i8<false, 0, true, true>), dim3(gemm_blocks + kf_pre), dim3(256), mc, ftiles, gemm_blocks); }

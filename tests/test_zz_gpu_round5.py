@@ -81,7 +81,7 @@ def _same_frame(a, b, f, means=True):
             assert np.array_equal(ta["mean"], tb["mean"]), (f, which)
 
 
-@pytest.mark.parametrize("extra", ["", "guess", "planes", "first16_8"])
+@pytest.mark.parametrize("extra", ["", "guess", "planes", "first16_8", "predict_first"])
 @pytest.mark.parametrize("tile", ["160x128", "128x64"])
 def test_prefilter_tile_shapes_vs_dense(bts, monkeypatch, tile, extra):
     """k_filter_t at 384 x 256 x 2048 (BTS_FILTER_ONEPASS sends the problem through the one-pass form; 256 live rows and columns):
@@ -97,6 +97,8 @@ def test_prefilter_tile_shapes_vs_dense(bts, monkeypatch, tile, extra):
         monkeypatch.setenv("BTS_SHADOW_PLANES", "1")
     elif extra == "first16_8":
         monkeypatch.setenv("BTS_I8_FIRST16", "8")
+    elif extra == "predict_first":                      # the Kalman-predict workgroups in FRONT of the tile workgroups (a kernel argument)
+        monkeypatch.setenv("BTS_PREDICT_FIRST", "1")
     K, D = 256, 2048
     a = bts.DeviceTracker(max_tracks=384, max_dets=K, feat_dim=D)
     assert a.forms()["filter_tile"] == tile
