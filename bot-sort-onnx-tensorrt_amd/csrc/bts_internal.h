@@ -179,6 +179,11 @@ int bts_lap_init();
 // `form`: 0 = column forms (default), 1 = the round-2 row forms (k_lap<EC, false>), -1 = the process default (BTS_LAP_FORM=row | col).
 // form: 0 column forms, 1 row forms, < 0 the process default (BTS_LAP_FORM); helpers: helper workgroups per problem, < 0 automatic
 int bts_lap_enqueue(const bts_lap_problem *probs, int count, hipStream_t stream, hipEvent_t *ev = nullptr, int form = -1, int helpers = -1);
+#ifdef BTS_HOST_EMU
+#include <utility>
+#include <vector>
+extern thread_local std::vector<std::pair<size_t, size_t>> *bts_emu_lap_zones;      // red zones of the work area being carved (lap.hip)
+#endif
 int bts_lap_form_from_env();      // (BTS_LAP_FORM through bts_form_get)
 // reset hdr before edges are appended
 int bts_lap_enqueue_reset(const bts_lap_work *w, hipStream_t stream);

@@ -1606,7 +1606,18 @@ __global__ __launch_bounds__(1024) void k_lap_exact(ExactPair P) {
 }  // namespace
 
 // ---------------------------------------------------------------------------------------- host
+#ifdef BTS_HOST_EMU
+// (CPU emulation build only: red zones behind every array of a work area, like the track table's -- tracker.hip, take())
+thread_local std::vector<std::pair<size_t, size_t>> *bts_emu_lap_zones = nullptr;
+static size_t carve(size_t &off, size_t bytes) {
+    const size_t o = off;
+    off = bts_align(off + bytes) + 256;
+    if (bts_emu_lap_zones) bts_emu_lap_zones->push_back({o + bytes, off - (o + bytes)});
+    return o;
+}
+#else
 static size_t carve(size_t &off, size_t bytes) { const size_t o = off; off = bts_align(off + bytes); return o; }
+#endif
 
 static void layout(bts_lap_work *w, char *base, size_t &off, int n, int m, int64_t e, int64_t ovr, int slices) {
 #define SLOT(field, type, count) { size_t o = carve(off, sizeof(type) * (size_t)(count)); w->field = base ? (type *)(base + o) : nullptr; }

@@ -2874,6 +2874,10 @@ struct bts_tracker {
     int lap_form = 0;             // BTS_LAP_FORM=row at create: the assignment kernel's round-2 row forms (bts_lap_enqueue)
     int lap_helpers = -1;         // BTS_LAP_HELPERS at create: helper workgroups per assignment problem (< 0: automatic)
     int filter_pw = 0;            // BTS_FILTER_PW at create: persistent GEMM workgroups of the pre-filter (0: FILTER_PW)
+#ifdef BTS_HOST_EMU
+    std::vector<std::pair<size_t, size_t>> redzones;      // (offset, bytes) inside `block`: see take()
+    bool redzones_armed = false;
+#endif
     int filter_tile = 0;          // BTS_FILTER_TILE at create: 0 = 128x128 (k_filter_i8), 1 = 160x128, 2 = 128x64 (k_filter_t)
     int last_ftm = FBM, last_ftn = FBN;      // tile shape the last step's pre-filter ran with (bts_tracker_debug_filter)
     int tile_goal = 768;          // BTS_TILE_GOAL at create: workgroup count the stage-1 / duplicate tile heights aim at
@@ -2913,7 +2917,22 @@ struct bts_tracker {
 
 constexpr size_t SPLITK_MAX_ENTRIES = (size_t)8 << 20;     // T x M entries up to which the split-K accumulators are allocated
 
+#ifdef BTS_HOST_EMU
+// CPU emulation build only (tests/hip_emu): every array of the table block is followed by a RED ZONE -- its alignment slack plus
+// 256 bytes -- filled with a canary when the tracker is created and checked at every bts_tracker_counts and at destroy: a kernel
+// that writes past the end of an array (a ragged tile, an off-by-one at a capacity edge) is caught on the CPU, whatever the
+// GPU's allocator would have let it get away with.  The product build has neither the zones nor the checks (its layout and
+// bts_tracker_memory_bytes are unchanged).
+static thread_local std::vector<std::pair<size_t, size_t>> *g_redzones = nullptr;
+static size_t take(size_t &off, size_t bytes) {
+    const size_t o = off;
+    off = bts_align(off + bytes) + 256;
+    if (g_redzones) g_redzones->push_back({o + bytes, off - (o + bytes)});
+    return o;
+}
+#else
 static size_t take(size_t &off, size_t bytes) { const size_t o = off; off = bts_align(off + bytes); return o; }
+#endif
 
 static void tracker_layout(bts_tracker *t, char *base, size_t &off) {
     Dev &d = t->dv;
@@ -3193,9 +3212,26 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
         return BTS_EHIP;
     }
     off = 0;
+#ifdef BTS_HOST_EMU
+    g_redzones = &t->redzones;
+#endif
     tracker_layout(t, t->block, off);
+#ifdef BTS_HOST_EMU
+    g_redzones = nullptr;
+#endif
+#ifdef BTS_HOST_EMU
+    {   // the two solver work areas carry red zones as well (offsets relative to their own base)
+        std::vector<std::pair<size_t, size_t>> z1, z3;
+        bts_emu_lap_zones = &z1; bts_lap_work_carve(&t->lap, t->block + lap_off, d.T, d.Mx, e_cap, o_cap, xs);
+        bts_emu_lap_zones = &z3; bts_lap_work_carve(&t->lap3, t->block + lap3_off, d.T, d.Mx, e_cap, 0, xs);
+        bts_emu_lap_zones = nullptr;
+        for (const auto &z : z1) t->redzones.push_back({lap_off + z.first, z.second});
+        for (const auto &z : z3) t->redzones.push_back({lap3_off + z.first, z.second});
+    }
+#else
     bts_lap_work_carve(&t->lap, t->block + lap_off, d.T, d.Mx, e_cap, o_cap, xs);
     bts_lap_work_carve(&t->lap3, t->block + lap3_off, d.T, d.Mx, e_cap, 0, xs);
+#endif
     for (int k = 0; k < 2 && cfg->tie_mode; ++k) {
         t->xk[k].dbl = (double *)(t->block + xk_off[k][0]); t->xk[k].ndbl = xk_nd;
         t->xk[k].ints = (int32_t *)(t->block + xk_off[k][1]); t->xk[k].nints = xk_ni;
@@ -3243,6 +3279,13 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
     }
     if (!ok) { (void)hipGetLastError(); bts_set_error("stream / event / descriptor allocation failed"); bts_tracker_destroy(t); return BTS_EHIP; }
     t->dv.in = nullptr;
+#ifdef BTS_HOST_EMU
+    for (const auto &z : t->redzones) memset(t->block + z.first, 0xA5, z.second);      // (after the last memset of create)
+    t->redzones_armed = true;
+    // (HIPEMU_POKE_REDZONE=k: fault injection for tests/test_emu_gpu_subset.py -- one byte of zone k is overwritten the way a
+    //  kernel's off-by-one store would; the next counts() / destroy must abort)
+    if (const char *pk = getenv("HIPEMU_POKE_REDZONE")) { const size_t k = (size_t)atoi(pk) % t->redzones.size(); t->block[t->redzones[k].first] = 0; }
+#endif
     bts_lap_init();
     int rc = bts_tracker_reset(t, nullptr);
     if (rc == BTS_OK && hipStreamSynchronize(nullptr) != hipSuccess) rc = BTS_EHIP;
@@ -3312,9 +3355,28 @@ int bts_tracker_profile_read(bts_tracker *t, double *total_ms, int32_t *count) {
     return BTS_OK;
 }
 
+#ifdef BTS_HOST_EMU
+static void emu_check_redzones(const bts_tracker *t, const char *where) {
+    if (!t->redzones_armed) return;
+    (void)hipDeviceSynchronize();
+    for (size_t k = 0; k < t->redzones.size(); ++k) {
+        const unsigned char *p = (const unsigned char *)t->block + t->redzones[k].first;
+        for (size_t b = 0; b < t->redzones[k].second; ++b)
+            if (p[b] != 0xA5) {
+                fprintf(stderr, "hipemu: red zone %zu of the table block (offset %zu, %zu bytes) overwritten at byte %zu (value %u), found at %s, frame %d\n",
+                        k, t->redzones[k].first, t->redzones[k].second, b, (unsigned)p[b], where, t->block ? ((const int32_t *)t->dv.hdr)[H_FRAME] : -1);
+                abort();
+            }
+    }
+}
+#endif
+
 int bts_tracker_destroy(bts_tracker *t) {
     if (!t) return BTS_OK;
     BTS_ON_DEVICE(t->ctx);
+#ifdef BTS_HOST_EMU
+    if (t->block) emu_check_redzones(t, "bts_tracker_destroy");
+#endif
     for (int k = 0; t->prof_ev && k < 2 * t->prof_cap + 2; ++k) (void)hipEventDestroy(t->prof_ev[k]);
     delete[] t->prof_ev;
     if (t->gexec) (void)hipGraphExecDestroy(t->gexec);
@@ -3723,6 +3785,9 @@ int bts_tracker_counts(bts_tracker *t, int32_t *counts12_host, bts_stream stream
     const int32_t *h = t->host_hdr;
     const int map[12] = {H_FRAME, H_NTRACKED, H_NLOST, H_NREMOVED, H_LASTID, H_NPOOL, H_NHI, H_NLO, H_NUNC, H_NR2, H_NLEFT, H_ERR};
     for (int k = 0; k < 12; ++k) counts12_host[k] = h[map[k]];
+#ifdef BTS_HOST_EMU
+    emu_check_redzones(t, "bts_tracker_counts");
+#endif
     return BTS_OK;
 }
 

@@ -108,3 +108,25 @@ def test_cvt_overlap_survives_adversarial_stream_schedules_and_the_detector_dete
         assert out[key][1] == 0 and "1 passed" in out[key][0], (key, out[key][0][-1500:])
     for key in (("sidelate", "main"), ("mainlate", "side")):
         assert out[key][1] != 0 and "1 failed" in out[key][0], (key, out[key][0][-1500:])
+
+
+@needs_toolchain
+def test_red_zones_between_the_table_arrays_catch_a_store_past_an_array():
+    """The emulated library pads every array of the track-table block with a canary-filled red zone and checks the zones at every
+    bts_tracker_counts and at destroy (csrc/tracker.hip, BTS_HOST_EMU only): every GPU test that runs on the emulator is thereby
+    also a test that no kernel stores past the end of a table array.  Here: the check is alive -- a poked zone aborts the process,
+    an untouched run does not."""
+    subprocess.check_call(["make", "-C", EMU, "-s", "-j4"])
+    code = ("import importlib, torch\n"
+            "import tests.hip_emu.emu_prelude\n"
+            "pkg = importlib.import_module('bot-sort-onnx-tensorrt_amd')\n"
+            "t = pkg.DeviceTracker(max_tracks=128, max_dets=64, feat_dim=128)\n"
+            "fr = pkg.synth.SyntheticStream(32, 16, 128, seed=1).next()\n"
+            "t.step(torch.from_numpy(fr.boxes).cuda(), torch.from_numpy(fr.scores).cuda(), torch.from_numpy(fr.feats).cuda())\n"
+            "print('errors', t.counts()['errors']); t.close(); print('clean exit')\n")
+    env = dict(os.environ, BTS_LIB_PATH=os.path.join(EMU, "libbotsort_emu.so"), PYTHONPATH=REPO)
+    env.pop("HIPEMU_POKE_REDZONE", None)
+    ok = subprocess.run([sys.executable, "-c", code], cwd=REPO, env=env, capture_output=True, text=True, timeout=300)
+    assert ok.returncode == 0 and "clean exit" in ok.stdout, ok.stderr[-800:]
+    bad = subprocess.run([sys.executable, "-c", code], cwd=REPO, env=dict(env, HIPEMU_POKE_REDZONE="17"), capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "red zone" in bad.stderr and "clean exit" not in bad.stdout, (bad.returncode, bad.stderr[-800:])
