@@ -53,7 +53,7 @@ def _run(nodes, deselect, at_least, order=None):
     if order:
         env["HIPEMU_ORDER"] = order
     cmd = [sys.executable, "-m", "pytest", "-m", "gpu", "-p", "tests.hip_emu.emu_prelude", "-p", "no:cacheprovider", "-q",
-           "--no-header", "-n", "4", "--timeout", "600", "-k", deselect] + nodes
+           "--no-header", "-n", str(max(2, min(7, (os.cpu_count() or 4) - 1))), "--timeout", "600", "-k", deselect] + nodes
     out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=1500)
     tail = "\n".join(out.stdout.splitlines()[-25:]) + out.stderr[-2000:]
     assert out.returncode == 0, tail
