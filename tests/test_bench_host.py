@@ -54,3 +54,33 @@ def test_no_gpu_means_no_number():
         for ln in p.stdout.splitlines():
             if ln.startswith("{"):
                 raise AssertionError("bench.py printed a result line without a GPU: " + json.dumps(ln)[:200])
+
+
+def test_line_guard_prints_what_was_measured_if_a_later_leg_wedges(tmp_path):
+    """bench.LineGuard: once the first measurement exists its contract fields are armed; if the legs behind it
+    never finish the watchdog prints them with a `truncated` note and ends the process with rc 0; a normal run prints the complete
+    line instead and the watchdog stays silent.  Exactly ONE line on stdout either way."""
+    import json
+    import subprocess
+    import sys
+    code = r'''
+import sys, time
+sys.path.insert(0, %r)
+import bench
+g = bench.LineGuard(0)
+g.arm({"metric": "m", "value": 123.0, "roofline": None}, 1.0)
+if sys.argv[1] == "wedge":
+    time.sleep(30)                      # a leg that never comes back
+else:
+    g.emit({"metric": "m", "value": 456.0, "roofline": {"frac": 0.5}})
+    time.sleep(2.5)                     # (the cancelled watchdog must not print a second line)
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code, "wedge"], capture_output=True, text=True, timeout=60)
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout, r.stderr[-500:])
+    d = json.loads(lines[0])
+    assert d["value"] == 123.0 and "truncated" in d and "watchdog" in d["truncated"]
+    r = subprocess.run([sys.executable, "-c", code, "ok"], capture_output=True, text=True, timeout=60)
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout, r.stderr[-500:])
+    assert json.loads(lines[0])["value"] == 456.0 and "truncated" not in lines[0]
