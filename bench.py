@@ -612,7 +612,17 @@ def main():
 
     # ---- 1. the DEFAULT forms (or the caller's) first: this measurement exists before any never-run candidate form is stepped
     #         (a wedged candidate then costs the extras, not the line)
-    first = measure(forms0)
+    try:
+        first = measure(forms0)
+    except BaseException as e:
+        # the product path failed outright (no library, a HIP error at create or in a step): there is no number, and the line says so
+        # instead of leaving stdout empty -- value null, the error in plain text, non-zero exit
+        if rank == 0 and not isinstance(e, KeyboardInterrupt):
+            print(json.dumps({"metric": "tracker update-steps/sec (N_tracks x M_dets)", "value": None, "unit": "steps/s", "n_gpus": world,
+                              "steps": a.steps, "warmup": a.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                              "config": {"workload": a.workload}, "roofline": None, "cpu_baseline": None,
+                              "error": "the timed region of the default forms did not complete: %s: %s" % (type(e).__name__, str(e)[:400])}), flush=True)
+        raise
     run = first
     selection, second = None, None
 
