@@ -84,6 +84,8 @@ def parse():
                     "auto = selected on this GPU in the untimed set-up (tune.run_isolated: a child process steps each candidate on frames "
                     "of this workload, keeps what is bit-identical to the default forms AND faster; the line carries the whole table), "
                     "default = the library's defaults, or an explicit 'KEY=VALUE,...'")
+    ap.add_argument("--compare-forms", default="", help="'KEY=VALUE,...': no selection -- the default forms and THESE forms through the same timed region on "
+                    "the same frames, both figures (and both per-kernel tables) in the line; `value` is the better error-free one")
     ap.add_argument("--oversubscribe", action="store_true", help="allow --gpus N on a box with fewer GPUs (ranks share devices; "
                     "for testing the launch path only -- the line says so)")
     return ap.parse_args()
@@ -548,7 +550,7 @@ def main():
                  "BTS_TILE_GOAL", "BTS_FILTER_ONEPASS", "BTS_SHADOW_PLANES", "BTS_LAP_SELF", "BTS_FILTER_TILE")
     if a.forms == "auto" and any(k in os.environ for k in FORM_KEYS):
         a.forms = "env"                 # (forms given through the environment -- an A/B run -- are taken as they are: no selection)
-    auto = a.forms == "auto" and S == 1 and not a.graph and not a.dense and not os.environ.get("BTS_BENCH_NO_TUNE")
+    auto = a.forms == "auto" and S == 1 and not a.graph and not a.dense and not os.environ.get("BTS_BENCH_NO_TUNE") and not a.compare_forms
     forms0 = "" if a.forms in ("auto", "default", "env") else a.forms        # what the FIRST measurement runs: the defaults, or the caller's
     # every frame of the run, uploaded once and kept pristine: a measurement steps on its own copy of the feature rows (the step
     # renormalises used rows in place, Q8), so the default and the selected forms are timed on bit-identical inputs
@@ -659,8 +661,30 @@ def main():
             ok2 = second["timed_errors"] == 0 or first["timed_errors"] != 0
             if ok2 and second["elapsed"] < first["elapsed"]:
                 run = second
+    if a.compare_forms and S == 1:
+        second = guarded("compare_forms", measure, a.compare_forms)
+        if isinstance(second, dict) and "error" in second:
+            second = None
+        if second is not None and second["timed_errors"] == 0 and second["elapsed"] < first["elapsed"]:
+            run = second
     loser = second if run is first else first
+    other_segments = None
     if loser is not None and loser is not run:
+        # the per-kernel picture of the forms that did NOT become `value` as well (same event passes as below, on frames behind the
+        # timed ones): the line then holds a per-kernel A/B of the default forms against the selected ones
+        def probe_other():
+            seg_us = {}
+            fr4 = [(b, sc, f.clone()) for (b, sc, f) in pristine[-PROBE:]]
+            for seg in SEGMENTS + tuple(k for k in KERNELS if k not in SEGMENTS) + ("step",):
+                loser["trk"].profile_enable(seg, PROBE)
+                for fr in fr4:
+                    loser["trk"].step(*fr)
+                ms_, n_ = loser["trk"].profile_read()
+                seg_us[seg] = round(1e3 * ms_ / max(n_, 1), 2)
+            loser["trk"].profile_enable("step", 0)
+            return seg_us
+        if rank == 0 and second is not None and (second["forms"] or "") != (first["forms"] or ""):
+            other_segments = guarded("segments_other_forms", probe_other)
         guarded("close", loser["trk"].close)
     trk, elapsed, counts, timed_errors, timed, forms = run["trk"], run["elapsed"], run["counts"], run["timed_errors"], run["timed"], run["forms"]
     if run is second:
@@ -785,6 +809,9 @@ def main():
             out["invalid"] = ("device error flags %d raised inside the timed region: frames were truncated, `value` is NOT a measurement "
                               "of the full step (device message: %s)" % (timed_errors, str(guarded("device_error_message", trk.export, 0))[:300]))
         out["segments_us"] = {k: round(v, 2) for k, v in breakdown.items()}
+        if other_segments is not None:
+            # (the forms `value` is NOT: "default forms" when the selected ones won, the selected ones when the defaults stayed)
+            out["segments_us_other_forms"] = {"forms": loser["forms"] or "", "segments_us": other_segments}
         if selection is not None:
             # every candidate's us/step and whether its results were bit-identical to the default forms' on the verified frames
             if isinstance(selection.get("table"), list):      # (the forms in effect of every candidate stay in the child's log: the line keeps the verdicts)

@@ -46,6 +46,13 @@ def line_report(path):
             if k in seg:
                 print("| %s | %.1f | %.1f | %s |" % (k, old, seg[k], bud))
         print("(event pairs add ~4 us per segment; `step` is the whole step with one pair)")
+    oth = d.get("segments_us_other_forms")
+    if oth and seg:
+        print("\nper kernel, forms of `value` vs the other forms measured (%r):" % oth.get("forms"))
+        print("| segment | value's forms | other forms | delta |\n|---|---|---|---|")
+        for k, v in oth["segments_us"].items():
+            if k in seg:
+                print("| %s | %.1f | %.1f | %+.1f |" % (k, seg[k], v, seg[k] - v))
     fs = d.get("form_selection") or {}
     if fs.get("table"):
         print("\nform selection: chosen %r, default %s us (both %s, noise %.2f %%), needed speed-up %.3f" % (fs.get("forms"), fs.get("default_us"), fs.get("default_us_both"), fs.get("noise_pct") or 0.0, fs.get("needed_speedup") or 0.0))
