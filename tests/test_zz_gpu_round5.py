@@ -226,8 +226,9 @@ def test_template_at_the_default_shape_is_k_filter_i8(bts, monkeypatch):
     ref.close(); exp.close()
 
 
+@pytest.mark.parametrize("ahead", [1, 0])
 @pytest.mark.parametrize("resident", [True, False])
-def test_cvt_overlap_without_host_synchronisation_between_steps(bts, monkeypatch, resident):
+def test_cvt_overlap_without_host_synchronisation_between_steps(bts, monkeypatch, resident, ahead):
     """BTS_CVT_OVERLAP (+ BTS_LISTS_AHEAD, the pairing it is offered in) over 24 frames whose boxes teleport while the cosines stay
     inside the gate -- ONLY the appearance candidates, i.e. the converted detection shadows, can associate a frame, so a conversion
     that ran at the wrong time changes every assignment -- digests compared with the default forms' every SIXTH frame only -- nothing synchronises the host with the device in between, so on a GPU the side
@@ -237,8 +238,8 @@ def test_cvt_overlap_without_host_synchronisation_between_steps(bts, monkeypatch
     tune = importlib.import_module("bot-sort-onnx-tensorrt_amd.tune")
     K, M, D = 96, 96, 128
     ref = bts.DeviceTracker(max_tracks=K + 64, max_dets=max(K, M), feat_dim=D)
-    exp = bts.DeviceTracker(max_tracks=K + 64, max_dets=max(K, M), feat_dim=D, forms={"BTS_CVT_OVERLAP": 1, "BTS_LISTS_AHEAD": 1})
-    assert exp.forms()["cvt_overlap"] == "1" and ref.forms()["cvt_overlap"] == "0"
+    exp = bts.DeviceTracker(max_tracks=K + 64, max_dets=max(K, M), feat_dim=D, forms={"BTS_CVT_OVERLAP": 1, "BTS_LISTS_AHEAD": ahead})
+    assert exp.forms()["cvt_overlap"] == "1" and ref.forms()["cvt_overlap"] == "0" and exp.forms()["lists_ahead"] == str(ahead)
     exp.inputs_resident(resident)
     st = _GateBand(K, D, 31, inside=(0.8, 0.92))
     frames = [_dev(st.next()) for _ in range(24)]
