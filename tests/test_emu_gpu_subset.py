@@ -21,6 +21,7 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 
 SUBSET = [
     "tests/test_gpu_kernels.py",                                                    # every standalone kernel vs oracle / golden
+    "tests/test_zz_gpu_kernels_new.py",                                             # (k_lap, the int8 shadows: same bars)
     "tests/test_gpu_tracker.py::test_edge_frames",
     "tests/test_gpu_tracker.py::test_tracker_gmc",
     "tests/test_gpu_tracker.py::test_botsort_update_image_with_parts",
@@ -75,7 +76,7 @@ def test_results_do_not_depend_on_the_order_workgroups_run_in():
     HIPEMU_ORDER=shuffle they run in a scrambled order (a workgroup that waits for one that has not run yet is re-run later):
     whatever depends on it -- the order entries are appended through atomic counters, which chunk publishes first -- must not
     reach a result.  (The longer campaign of DESIGN.md section 3 ran 85 tests reversed and shuffled.)"""
-    _run(["tests/test_gpu_kernels.py", "tests/test_gpu_tracker.py::test_edge_frames", "tests/test_gpu_tracker.py::test_ragged_shapes_vs_oracle",
+    _run(["tests/test_gpu_kernels.py", "tests/test_zz_gpu_kernels_new.py", "tests/test_gpu_tracker.py::test_edge_frames", "tests/test_gpu_tracker.py::test_ragged_shapes_vs_oracle",
           "tests/test_zz_gpu_round3.py::test_lapjv_lds_preparation_layouts_vs_oracle"],
          "not (ragged and not (5-2-64 or 4-1-64 or 17-9-128))", 56, order="shuffle:3")
 
