@@ -547,7 +547,7 @@ def main():
     opts = dict(appearance_mode=1 if a.dense else 0, use_graph=1 if a.graph else 0, motion_gate=1 if a.motion_gate else 0)
     FORM_KEYS = ("BTS_EDGES_SORTED", "BTS_EDGES_GRID", "BTS_LISTS_AHEAD", "BTS_MERGE_EARLY", "BTS_RENORM_FUSED", "BTS_CVT_OVERLAP", "BTS_PREDICT_FIRST",
                  "BTS_PREDICT_FRONT", "BTS_FILTER_GUESS", "BTS_LAP_FORM", "BTS_LAP_HELPERS", "BTS_CHUNK_ROWS", "BTS_FILTER_PW", "BTS_I8_FIRST16",
-                 "BTS_TILE_GOAL", "BTS_FILTER_ONEPASS", "BTS_SHADOW_PLANES", "BTS_LAP_SELF", "BTS_FILTER_TILE")
+                 "BTS_TILE_GOAL", "BTS_FILTER_ONEPASS", "BTS_SHADOW_PLANES", "BTS_LAP_SELF", "BTS_FILTER_TILE", "BTS_FILTER_AHEAD", "BTS_FILTER_AHEAD_PW")
     if a.forms == "auto" and any(k in os.environ for k in FORM_KEYS):
         a.forms = "env"                 # (forms given through the environment -- an A/B run -- are taken as they are: no selection)
     auto = a.forms == "auto" and S == 1 and not a.graph and not a.dense and not os.environ.get("BTS_BENCH_NO_TUNE") and not a.compare_forms
@@ -563,46 +563,63 @@ def main():
         """warm-up + the timed region for one tracker with `forms`: -> dict(trk, elapsed (max over ranks), counts, timed_errors,
         timed (its frames), extra).  K steps, nothing else on the stream (no events, no read-backs), barrier + synchronize on both
         sides (the contract of the task statement)."""
-        mine = [(b, sc, f.clone()) for (b, sc, f) in pristine]
-        torch.cuda.synchronize()
-        frames, timed = mine[:a.warmup], mine[a.warmup:]
-        o = dict(opts, forms=forms or None)
-        trk = pkg.DeviceTracker(max_tracks=table_rows(K, a.motion_gate), max_dets=max(K, M), feat_dim=D, device=torch.cuda.current_device(), **o)
-        if hasattr(pkg._lib.load(), "bts_tracker_inputs_resident"):
-            trk.inputs_resident(True)    # (every frame is uploaded and synchronised before the loop that steps on it; only the
-                                         #  opt-in BTS_CVT_OVERLAP pipelining looks at this promise)
-        for k in range(a.warmup):
-            trk.step(*frames[k])
-        torch.cuda.synchronize()
-        extra = []                       # further streams of this GPU: (tracker, HIP stream, frames), warmed up the same way
-        for k in range(1, S):
-            st_k = pkg.synth.make_workload(a.workload, seed=ms_seed(pkg, rank * S + k))
-            with torch.cuda.stream(torch.cuda.default_stream()):      # (set-up on the default stream: see multistream.run_concurrent)
-                tk = pkg.DeviceTracker(max_tracks=table_rows(K, a.motion_gate), max_dets=max(K, M), feat_dim=D, device=torch.cuda.current_device(), **o)
-                for _ in range(a.warmup + 6):
-                    fr = st_k.next()
-                    tk.step(torch.from_numpy(fr.boxes).cuda(), torch.from_numpy(fr.scores).cuda(), torch.from_numpy(fr.feats).cuda())
-                fl = []
-                for _ in range(a.steps):
-                    fr = st_k.next()
-                    fl.append((torch.from_numpy(fr.boxes).cuda(), torch.from_numpy(fr.scores).cuda(), torch.from_numpy(fr.feats).cuda()))
-            extra.append((tk, None, fl))
-        if a.graph:                                              # capture happens on the first replayed step: keep it untimed
-            trk.step(*next_frame())
+        # Every rank passes the SAME sequence of collectives (barrier, barrier, three all-reduces) whatever happens to its own leg:
+        # a rank whose tracker cannot be created or whose step raises still meets the others at the barriers, and the failure is
+        # then raised on every rank (ADVICE r5: a guarded second measurement that failed on one rank left the others waiting).
+        fail, trk, timed, extra, t0, t1 = None, None, [], [], 0.0, 0.0
+        try:
+            mine = [(b, sc, f.clone()) for (b, sc, f) in pristine]
             torch.cuda.synchronize()
+            frames, timed = mine[:a.warmup], mine[a.warmup:]
+            o = dict(opts, forms=forms or None)
+            trk = pkg.DeviceTracker(max_tracks=table_rows(K, a.motion_gate), max_dets=max(K, M), feat_dim=D, device=torch.cuda.current_device(), **o)
+            if hasattr(pkg._lib.load(), "bts_tracker_inputs_resident"):
+                trk.inputs_resident(True)    # (every frame is uploaded and synchronised before the loop that steps on it; only the
+                                             #  opt-in BTS_CVT_OVERLAP pipelining looks at this promise)
+            for k in range(a.warmup):
+                trk.step(*frames[k])
+            torch.cuda.synchronize()
+            extra = []                       # further streams of this GPU: (tracker, HIP stream, frames), warmed up the same way
+            for k in range(1, S):
+                st_k = pkg.synth.make_workload(a.workload, seed=ms_seed(pkg, rank * S + k))
+                with torch.cuda.stream(torch.cuda.default_stream()):      # (set-up on the default stream: see multistream.run_concurrent)
+                    tk = pkg.DeviceTracker(max_tracks=table_rows(K, a.motion_gate), max_dets=max(K, M), feat_dim=D, device=torch.cuda.current_device(), **o)
+                    for _ in range(a.warmup + 6):
+                        fr = st_k.next()
+                        tk.step(torch.from_numpy(fr.boxes).cuda(), torch.from_numpy(fr.scores).cuda(), torch.from_numpy(fr.feats).cuda())
+                    fl = []
+                    for _ in range(a.steps):
+                        fr = st_k.next()
+                        fl.append((torch.from_numpy(fr.boxes).cuda(), torch.from_numpy(fr.scores).cuda(), torch.from_numpy(fr.feats).cuda()))
+                extra.append((tk, None, fl))
+            if a.graph:                                              # capture happens on the first replayed step: keep it untimed
+                trk.step(*next_frame())
+                torch.cuda.synchronize()
+        except BaseException as e:      # noqa: BLE001  (re-raised below, behind the collectives)
+            fail = e
         # ---- the timed region
         ms.barrier(ddist)
-        torch.cuda.synchronize()
-        if S == 1:
-            t0 = time.perf_counter()
-            for fr in timed:
-                trk.step(*fr)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-        else:
-            t0 = 0.0
-            t1 = ms.run_concurrent([trk] + [e[0] for e in extra], [timed] + [e[2] for e in extra])
+        if fail is None:
+            try:
+                torch.cuda.synchronize()
+                if S == 1:
+                    t0 = time.perf_counter()
+                    for fr in timed:
+                        trk.step(*fr)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                else:
+                    t0 = 0.0
+                    t1 = ms.run_concurrent([trk] + [e[0] for e in extra], [timed] + [e[2] for e in extra])
+            except BaseException as e:  # noqa: BLE001
+                fail = e
         ms.barrier(ddist)
+        any_fail = ms.max_over_ranks(1.0 if fail is not None else 0.0, ddist) > 0
+        if any_fail:
+            ms.max_over_ranks(0.0, ddist); ms.max_over_ranks(0.0, ddist)      # (the two all-reduces of the success path)
+            if fail is not None:
+                raise fail
+            raise RuntimeError("the measurement failed on another rank")
         counts = trk.counts()
         # a device-side error in the timed region (a truncated frame: table full, edge list overflow, an in-kernel wait that timed
         # out) does not stop the line from being printed -- it is printed WITH the verdict that the measurement is invalid
@@ -626,7 +643,7 @@ def main():
                               "error": "the timed region of the default forms did not complete: %s: %s" % (type(e).__name__, str(e)[:400])}), flush=True)
         raise
     run = first
-    selection, second = None, None
+    selection, second, any_selected = None, None, False
 
     def contract(elapsed_s, which):
         """the contract fields of one completed measurement (nothing here touches the device)"""
@@ -653,20 +670,25 @@ def main():
         sel_forms = selection.get("forms") if isinstance(selection, dict) and "error" not in selection else ""
         # ---- 3. the selected forms through the SAME timed region (same frames, same barriers); under --gpus N every rank
         #         re-measures (with its own selection, possibly the defaults again) so that the barriers pair up
+        any_selected = ms.max_over_ranks(1.0 if sel_forms else 0.0, ddist) > 0      # (rank-agreed)
         if world > 1 or sel_forms:
             second = guarded("selected_forms", measure, sel_forms or "")
             if isinstance(second, dict) and "error" in second:
                 second = None
         if second is not None:
+            # WHICH figure becomes `value` is the selection's verdict (3 x 110 steps per candidate, the default measured twice as the
+            # noise floor, 2 % margin), not a comparison of this --steps-long re-run with the first one: the better of two short
+            # timed regions is biased upward by their run-to-run spread.  Forms were selected (on some rank)
+            # -> the re-run with them is `value`; nothing selected -> the default forms' first measurement is, and under --gpus N the
+            # second run of the same forms is only reported (value_selected_forms), never taken as a maximum.
             ok2 = second["timed_errors"] == 0 or first["timed_errors"] != 0
-            if ok2 and second["elapsed"] < first["elapsed"]:
+            if ok2 and any_selected:
                 run = second
     if a.compare_forms and S == 1:
+        # an A/B asked for by the caller: `value` stays the default forms' figure, the compared set is value_selected_forms
         second = guarded("compare_forms", measure, a.compare_forms)
         if isinstance(second, dict) and "error" in second:
             second = None
-        if second is not None and second["timed_errors"] == 0 and second["elapsed"] < first["elapsed"]:
-            run = second
     loser = second if run is first else first
     other_segments = None
     if loser is not None and loser is not run:
@@ -688,7 +710,7 @@ def main():
         guarded("close", loser["trk"].close)
     trk, elapsed, counts, timed_errors, timed, forms = run["trk"], run["elapsed"], run["counts"], run["timed_errors"], run["timed"], run["forms"]
     if run is second:
-        better = contract(second["elapsed"], "selected forms" if second["forms"] else "default forms")
+        better = contract(second["elapsed"], "selected forms" if (second["forms"] or any_selected) else "default forms")
         better["config"]["forms"]["requested"] = second["forms"]
         better["value_default_forms"], better["value_selected_forms"] = partial["value"], better["value"]
         if second["timed_errors"]:
@@ -777,11 +799,12 @@ def main():
             "value": ms.aggregate_throughput(a.steps * S, elapsed, world),
             "unit": "steps/s",
             # both measurements of the same timed region (same frames, same barriers): the library's default forms, taken FIRST, and
-            # the forms selected on this GPU afterwards; `value` is the better one that ran without a device error, and the
-            # id_match / roofline / export legs below run the forms of `value`
+            # the forms selected on this GPU afterwards; `value` is the selected forms' figure when the selection (its own 3 x 110-step
+            # statistics) kept any, else the default forms' -- never the better of the two short regions -- and the id_match /
+            # roofline / export legs below run the forms of `value`
             "value_default_forms": ms.aggregate_throughput(a.steps * S, first["elapsed"], world) if forms0 == "" else None,
             "value_selected_forms": ms.aggregate_throughput(a.steps * S, second["elapsed"], world) if second is not None else None,
-            "value_is": ("selected forms" if (second is not None and run is second and second["forms"]) else
+            "value_is": ("selected forms" if (second is not None and run is second and (second["forms"] or any_selected)) else
                          "default forms" if forms0 == "" else "requested forms"),
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * elapsed / a.steps,      # (one step of every stream)
@@ -790,7 +813,11 @@ def main():
             "config": {"workload": "%s: %s" % (a.workload, pkg.synth.workload_text(a.workload)) + (", Mahalanobis gate on" if a.motion_gate else "")
                                    + ", IoU+cosine fused cost, 3-stage association, one stream per GPU",
                        "tracks": K, "dets": M, "feat_dim": D, "streams": world * S, "parallelism": "%d stream%s/GPU, no collective" % (S, "" if S == 1 else "s (own HIP stream + host thread each)"),
-                       "launch": "hipGraph replay" if a.graph else "eager", "motion_gate": bool(a.motion_gate),
+                       # (BTS_FILTER_AHEAD is a THROUGHPUT mode -- frame f's pre-filter runs on a side stream under step f-1 -- and is
+                       #  named here whenever it is in effect: the figure then needs frames stepped back to back)
+                       "launch": ("hipGraph replay" if a.graph else "eager") + (", pre-filter ahead on a side stream (BTS_FILTER_AHEAD)"
+                                                                                 if (guarded("forms", trk.forms) or {}).get("filter_ahead") == "1" else ""),
+                       "motion_gate": bool(a.motion_gate),
                        "spawn": "self-spawned ranks" if os.environ.get("BTS_BENCH_SPAWNED") else ("torch.distributed.run" if world > 1 else "single process"),
                        "oversubscribed": bool(world > ndev),
                        "opt_in": {k: v for k, v in os.environ.items() if k.startswith("BTS_") and k not in ("BTS_BENCH_SPAWNED", "BTS_LIB_PATH")},

@@ -72,6 +72,32 @@ __device__ __forceinline__ float renorm_row(float *row, int d, bool active = tru
     }
 }
 
+// ||row||_2 exactly as renorm_row computes it (same per-thread expression, same block_sum order), without touching the row: the
+// norm a later renorm_row of the same row will divide by (tk_cvt_ahead: a detection row's track-side record ahead of its absorption)
+__device__ __forceinline__ float row_norm(const float *row, int d, bool active = true) {
+    const int t = row_tid();
+    float ss = 0.0f;
+    const bool v4 = active && vec4_ok(row, d);
+    if (v4 && d / 4 <= 2 * ROW_G) {
+        const float4 *r4 = reinterpret_cast<const float4 *>(row);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int k = t + u * ROW_G;
+            const float4 v = k < d / 4 ? r4[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+            ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+    } else if (v4) {
+        const float4 *r4 = reinterpret_cast<const float4 *>(row);
+        for (int k = t; k < d / 4; k += ROW_G) {
+            const float4 v = r4[k];
+            ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+    } else if (active) {
+        for (int k = t; k < d; k += ROW_G) ss += row[k] * row[k];
+    }
+    return sqrtf(block_sum(ss));
+}
+
 // curr = f ; smooth = normalise(has ? alpha*smooth + beta*f : f)
 __device__ __forceinline__ void ema_row(float *curr, float *smooth, const float *f, int d, bool has, float alpha,
                                         float beta, bool active = true) {

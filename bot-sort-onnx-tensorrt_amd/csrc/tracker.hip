@@ -90,6 +90,11 @@ struct Dev {
     int32_t *approx, *approx_f;                        // [T][Mx] split-K accumulation of the pre-filter, body / face (self-cleaning; exact integers)
     uint32_t *cbits;                                   // [T][cb_ld] candidate bitmap of the one-pass pre-filter (self-cleaning)
     int cb_ld;                                         // 32-bit words per bitmap row
+    // BTS_FILTER_AHEAD=1 at create (opt-in throughput mode, round 6; see enqueue_step): the bitmap of a frame is [T + Mx][cb_ld]
+    // -- rows [0, T) by table SLOT (main pass), rows [T, T + Mx) by the detection index of the PREVIOUS frame (det x det pass) --
+    // and pool row i finds its bitmap row in pool_cbrow[i] (written with the pool list by tk_finalize); nullptr = bitmap row i
+    int32_t fahead;
+    int32_t *pool_cbrow;
     float gate_sim;                                    // the similarity the appearance term must reach: 1 - appearance_thresh
     int sf32;                                          // kalman_dtype BTS_F32: mean / cov hold float32 elements (same rows, half the bytes)
     int c16;                                           // cost_dtype BTS_F16: association costs rounded to binary16 before thresholds and the solver
@@ -442,6 +447,33 @@ template <bool CH, bool GRID = false, bool CVT = true> __global__ __launch_bound
     else if constexpr (CVT) { cvt_body(d, (long)b - front_jobs(nch)); if (b == front_jobs(nch)) TJ_END(0, 4); }
 }
 __global__ __launch_bounds__(1024) void tk_cvt(Dev d) { cvt_body(d, (long)blockIdx.x); }
+// BTS_FILTER_AHEAD: the side stream's opening launch for a frame.  The row workgroups convert the frame's detection rows like
+// tk_cvt and ALSO leave each row's record in its track-side form in `det_mts` (what feat::i8_track_side makes of it when the row is
+// renormalised and absorbed by a track, with the norm taken in renorm_row's own summation order: bit-identical to what the
+// absorbing track's record will be) -- the row records of the NEXT frame's det x det pass.  The last workgroup builds the frame's
+// high-score list for the side passes (the predicate and order of prep_dets, which builds the step's own copy later) and the two
+// little headers the unchanged pre-filter kernel reads its extents from.
+__global__ __launch_bounds__(1024) void tk_cvt_ahead(Dev d, float *det_mts, int32_t *hi_b, int32_t *hdr_main, int32_t *hdr_dd, int32_t *fstat_b, int n_prev) {
+    if (blockIdx.x + 1 == gridDim.x) {
+        __shared__ int32_t tmp[1024];
+        const float *scores = IN(d, scores);
+        const int nhi = bscan::compact_ws(IN(d, m), tmp, [&](int j) { return __float_as_int(scores[j]); },
+                                          [&](int j, int v) { return (double)__int_as_float(v) > d.high; }, [&](int p, int j, int) { hi_b[p] = j; });
+        if (threadIdx.x < 16) fstat_b[threadIdx.x] = threadIdx.x == 8 || threadIdx.x == 12 ? 0x7fffffff : 0;
+        if (threadIdx.x == 0) { hdr_main[H_NPOOL] = d.T; hdr_main[H_NHI] = nhi; hdr_dd[H_NPOOL] = n_prev; hdr_dd[H_NHI] = nhi; }
+        return;
+    }
+    const long j = (long)blockIdx.x * 4 + feat::row_group();
+    const bool on = j < IN(d, m);
+    cvt_body(d, (long)blockIdx.x);
+    const float nrm = feat::row_norm(IN(d, feats) + j * d.D, d.D, on);      // (every thread of the workgroup: barriers inside)
+    if (on && feat::row_tid() == 0) {       // (the thread that wrote the row's record in to_i8_row)
+        float rec[feat::I8_META];
+        for (int k = 0; k < feat::I8_META; ++k) rec[k] = d.det_m[j * feat::I8_META + k];
+        feat::i8_track_side(rec, nrm, d.gate_sim);
+        for (int k = 0; k < feat::I8_META; ++k) det_mts[j * feat::I8_META + k] = rec[k];
+    }
+}
 // BTS_LISTS_AHEAD: the frame opens with the detection side alone -- workgroup 0 builds the detection lists, moves the sizes the
 // previous tk_finalize left in the *_N header words into place (what prep_pool / prep_unconfirmed wrote at this point) and
 // clears the duplicate-removal flags; the others convert the detection rows (unless tk_cvt does, CVT = false)
@@ -552,8 +584,9 @@ __device__ __forceinline__ void edges_tile(const Dev &d, const bts_lap_work &w, 
         for (int u = lane; u < ROWS; u += 64) {
             unsigned long long v = 0;
             if (i0 + u < n && bx * CT_COLS + wid * 64 < d.Mx) {
+                const long brow = d.pool_cbrow ? (long)d.pool_cbrow[i0 + u] : (long)(i0 + u);      // (BTS_FILTER_AHEAD: by slot / previous detection)
                 unsigned long long *pw = reinterpret_cast<unsigned long long *>(
-                    &d.cbits[(long)(i0 + u) * d.cb_ld + ((bx * CT_COLS + wid * 64) >> 5)]);
+                    &d.cbits[brow * d.cb_ld + ((bx * CT_COLS + wid * 64) >> 5)]);
                 v = *pw;
                 if (v) *pw = 0ull;
             }
@@ -1029,22 +1062,23 @@ __device__ __forceinline__ void lds_write16(lds_t addr, f32x4 v) { asm volatile(
 __device__ __forceinline__ void lds_write4(lds_t addr, int v) { asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
 #else
 // tests/hip_emu: the same kernels on the CPU.  An "LDS address" is the host address of the __shared__ object; the LDS accesses
-// above become plain loads / stores, the waits vanish (the emulator's LDS-DMA is immediate) and the stage barrier is the
-// workgroup barrier.  The MFMA and global_load_lds builtins are served by tests/hip_emu/hip/hip_runtime.h at instruction level.
+// above become plain loads / stores behind a hazard check against LDS-DMA transfers in flight, the stage wait lands the calling
+// thread's transfers (the emulator's global_load_lds is asynchronous since round 6: tests/hip_emu/hip/hip_runtime.h) and the stage
+// barrier is the workgroup barrier.  The MFMA and global_load_lds builtins are served by hip_runtime.h at instruction level.
 typedef void lds_void;
 typedef const void gbl_void;
 typedef uintptr_t lds_t;
 #define LDS_ADDR(p) ((lds_t)(p))
-template <int N> __device__ __forceinline__ void wait_stage_barrier() { __syncthreads(); }
-__device__ __forceinline__ v4i lds_read16(lds_t addr) { v4i v; memcpy(&v, (const void *)addr, 16); return v; }
+template <int N> __device__ __forceinline__ void wait_stage_barrier() { emu::lds_dma_wait(N); __syncthreads(); }
+__device__ __forceinline__ v4i lds_read16(lds_t addr) { emu::lds_dma_check((const void *)addr, 16, "ds_read_b128 of"); v4i v; memcpy(&v, (const void *)addr, 16); return v; }
 template <int N> __device__ __forceinline__ void lds_wait(v4i &, v4i &, v4i &, v4i &) {}
-__device__ __forceinline__ f32x4 lds_read16f(lds_t addr) { f32x4 v; memcpy(&v, (const void *)addr, 16); return v; }
+__device__ __forceinline__ f32x4 lds_read16f(lds_t addr) { emu::lds_dma_check((const void *)addr, 16, "ds_read_b128 of"); f32x4 v; memcpy(&v, (const void *)addr, 16); return v; }
 __device__ __forceinline__ void lds_wait_f(f32x4 &, f32x4 &) {}
 __device__ __forceinline__ void lds_wait_i(v4i &) {}
 __device__ __forceinline__ void lds_wait_f1(f32x4 &) {}
-__device__ __forceinline__ void lds_write8(lds_t addr, float x, float y) { float v[2] = {x, y}; memcpy((void *)addr, v, 8); }
-__device__ __forceinline__ void lds_write16(lds_t addr, f32x4 v) { memcpy((void *)addr, &v, 16); }
-__device__ __forceinline__ void lds_write4(lds_t addr, int v) { memcpy((void *)addr, &v, 4); }
+__device__ __forceinline__ void lds_write8(lds_t addr, float x, float y) { emu::lds_dma_check((const void *)addr, 8, "ds_write_b64 to"); float v[2] = {x, y}; memcpy((void *)addr, v, 8); }
+__device__ __forceinline__ void lds_write16(lds_t addr, f32x4 v) { emu::lds_dma_check((const void *)addr, 16, "ds_write_b128 to"); memcpy((void *)addr, &v, 16); }
+__device__ __forceinline__ void lds_write4(lds_t addr, int v) { emu::lds_dma_check((const void *)addr, 4, "ds_write_b32 to"); memcpy((void *)addr, &v, 4); }
 #endif
 
 // minimum / maximum over a wavefront, returned to every lane: DPP steps inside the 16-lane rows, then the four rows through the scalar side
@@ -1344,6 +1378,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __builtin_amdgcn_global_load_lds((gbl_void *)(mbase + ((size_t)my_meta_o + (size_t)(4 * c))), (lds_void *)&srec2[img][wid * 64], 16, 0, 0);
     };
     int rimg = 0;                                // image the NEXT test's records are in (or on their way to)
+    // (everything derived from the index loads is materialised BEFORE the first LDS-DMA goes out: behind one, the compiler turns
+    //  the wait for ANY vector load into a full drain -- the record offset, sunk below stage(0, 0), cost the first stage a drain of
+    //  its own in front of the record transfer; scripts/isa_chain.py)
+#if !defined(BTS_HOST_EMU)
+    asm volatile("" : "+v"(my_meta_o));
+#endif
     stage(0, 0);
     int cur = 0, flip = 0;
     // Where this workgroup's tiles have been stopping: `last_exit` = the stage count of the predicted stop (-1: none yet).
@@ -1366,6 +1406,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #define FT_ADD(acc, v) do { } while (0)
 #endif
     for (;;) {
+        int ci = VAR == 2 ? (int)feat::I8_NCHK : skip_unused(0);     // next checkpoint (feat::I8_NCHK = the full row)
+        // checkpoints before the predicted stop are not tested, except on every fourth tile (the probe that lets the
+        // prediction move down)
+        if ((tile_no & 3) != 3)
+            while (ci < feat::I8_NCHK && chk_at(ci) < last_exit) ci = skip_unused(ci + 1);
+        // The record transfer goes out BEFORE the next tile's index loads (round 6, read off the ISA: scripts/isa_chain.py): the
+        // compiler consumes those indices as soon as they are issued (my_meta_o, the source offsets) and every vector-memory wait
+        // behind an LDS-DMA is a full drain (vmcnt(0)), so with the records issued behind them a tile opened with TWO serial drains
+        // -- first stage + indices, then the records -- in front of its first stage barrier; now one drain covers all three.
+        stage_rec(rimg, ci);
         // the next tile's indices travel while this tile's K loop runs
         int nbm = 0, nbnn = 0;
         const int nvt = next_live(vt + gemm_blocks, nbm, nbnn);
@@ -1377,12 +1427,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0;
-        int ci = VAR == 2 ? (int)feat::I8_NCHK : skip_unused(0);     // next checkpoint (feat::I8_NCHK = the full row)
-        // checkpoints before the predicted stop are not tested, except on every fourth tile (the probe that lets the
-        // prediction move down)
-        if ((tile_no & 3) != 3)
-            while (ci < feat::I8_NCHK && chk_at(ci) < last_exit) ci = skip_unused(ci + 1);
-        stage_rec(rimg, ci);
         int issued = 1;                              // stages whose loads have been issued
         int kt = 0;
         bool next_staged = false;                    // the next tile's first stage is already on its way
@@ -1808,11 +1852,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
         static_assert(EP % 64 == 0 && (EP <= 256 || EP - 256 <= 256), "rec1 / rec2 are wave-uniform");
     };
     int rimg = 0;                                // image the NEXT test's records are in (or on their way to)
+#if !defined(BTS_HOST_EMU)
+    asm volatile("" : "+v"(meta_o1), "+v"(meta_o2));      // (materialised before the first LDS-DMA: see k_filter_i8)
+#endif
     stage(0, 0);
     int cur = 0, flip = 0;
     int last_exit = d.f_guess ? chk[0] : -1, early_run = 0, tile_no = 0;        // (stop prediction: see k_filter_i8)
     int st_stages = 0, st_early = 0, st_cand = 0;
     for (;;) {
+        int ci = skip_unused(0);                     // next checkpoint (feat::I8_NCHK = the full row)
+        if ((tile_no & 3) != 3)
+            while (ci < feat::I8_NCHK && chk_at(ci) < last_exit) ci = skip_unused(ci + 1);
+        stage_rec(rimg, ci);                         // (in FRONT of the index loads below: one drain instead of two, see k_filter_i8)
         int nbm = 0, nbnn = 0;
         const int nvt = next_live(vt + gemm_blocks, nbm, nbnn);
         if (nvt < ntiles) fetch_idx(nbm, nbnn, ia, ib, irec, irec2);        // the next tile's indices travel while this tile's K loop runs
@@ -1823,10 +1874,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
             for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0;
-        int ci = skip_unused(0);                     // next checkpoint (feat::I8_NCHK = the full row)
-        if ((tile_no & 3) != 3)
-            while (ci < feat::I8_NCHK && chk_at(ci) < last_exit) ci = skip_unused(ci + 1);
-        stage_rec(rimg, ci);
         int issued = 1, kt = 0;
         bool next_staged = false;
         for (;;) {
@@ -2701,10 +2748,16 @@ template <bool CH> __device__ __forceinline__ void ahead_body(const Dev &d, int 
         }
         int nconf = 0;
         bool any64 = false;
+        // BTS_FILTER_AHEAD: the bitmap row the next frame's stage-1 tiles read for this pool row -- a track rewritten during THIS
+        // frame (frame_id == the frame: update / re_activate / activate, which also set det_index) holds the shadow and track-side
+        // record of detection det_index of this frame: row T + det_index of the det x det pass; any other track's shadow has been
+        // stable since before this frame began: row `slot` of the main pass
+        const int fr = h[H_FRAME];
+        auto cbrow = [&](int s) { return d.frame_id[s] == fr ? d.T + d.det_index[s] : s; };
         job_compact<CH>(ca, nt2, tmp, [&](int k) { return tracked2_at(d, k); }, [&](int k, int s) { return !d.drop_t[k] && d.is_activated[s] != 0; },
-                        [&](int p, int k, int s) { d.pool_slot[p] = s; }, f64 != 0, true, &nconf, &any64);
+                        [&](int p, int k, int s) { d.pool_slot[p] = s; if (d.pool_cbrow) d.pool_cbrow[p] = cbrow(s); }, f64 != 0, true, &nconf, &any64);
         const int nl = job_compact<CH>(cb, nl2, tmp, [&](int k) { return lost2_at(d, k); }, [&](int k, int s) { return !d.drop_l[k]; },
-                                       [&](int p, int k, int s) { d.pool_slot[nconf + p] = s; });
+                                       [&](int p, int k, int s) { d.pool_slot[nconf + p] = s; if (d.pool_cbrow) d.pool_cbrow[nconf + p] = cbrow(s); });
         if (last && tid == 0) {
             const int N = nconf + nl;
             h[H_NPOOL_N] = N; h[H_NCONF_N] = nconf;
@@ -2881,7 +2934,7 @@ struct bts_tracker {
     int filter_tile = 0;          // BTS_FILTER_TILE at create: 0 = 128x128 (k_filter_i8), 1 = 160x128, 2 = 128x64 (k_filter_t)
     int last_ftm = FBM, last_ftn = FBN;      // tile shape the last step's pre-filter ran with (bts_tracker_debug_filter)
     int tile_goal = 768;          // BTS_TILE_GOAL at create: workgroup count the stage-1 / duplicate tile heights aim at
-    char forms[384] = "";         // the switches in effect, as bts_tracker_forms reports them
+    char forms[448] = "";         // the switches in effect, as bts_tracker_forms reports them
     bool onepass = false;         // BTS_FILTER_ONEPASS=1 at create: the persistent one-pass pre-filter also for split-K-sized problems
     bool predict_front = false;   // BTS_PREDICT_FRONT=1 at create (with BTS_LISTS_AHEAD): the predict workgroups in the frame's first launch
     bool predict_first = false;   // BTS_PREDICT_FIRST=1 at create: k_filter_i8<.., KF_FIRST> (experiment, see the kernel)
@@ -2895,6 +2948,14 @@ struct bts_tracker {
     bool inputs_resident = false; // bts_tracker_inputs_resident
     hipEvent_t ev_in = nullptr;   // "the caller's stream has reached this step": the side stream waits for it before it reads the frame's arrays
     bool ev_done_used[2] = {};
+    // BTS_FILTER_AHEAD=1 at create (implies the side stream above, BTS_LISTS_AHEAD and BTS_PREDICT_FRONT): see enqueue_step
+    float *det_mts[2] = {};       // track-side records of a frame's detection rows (tk_cvt_ahead), per shadow buffer
+    int32_t *hi_b[2] = {};        // the side passes' own high-score list of the frame
+    int32_t *shdr = nullptr;      // [2 buffers][main, det x det] headers (H_SIZE ints each: H_NPOOL, H_NHI) the pre-filter kernel reads
+    int32_t *fstat_b = nullptr;   // [2][16] pre-filter counters of the side passes
+    int32_t *iota = nullptr;      // 0, 1, 2, ...: the identity "list" of the side passes' rows
+    int mc_prev = 0;              // detections of the previous step (rows of the det x det pass)
+    int filter_ahead_pw = 0;      // BTS_FILTER_AHEAD_PW: persistent workgroups per side pass (default 384: some CUs stay free for the step)
     bts_lap_exact xk[2];   // tie_mode 1: scratch of the exact-tie step, [0] stages 1 and 2 (sequential), [1] stage 3
     char *block = nullptr;
     size_t bytes = 0;
@@ -2975,6 +3036,12 @@ static void tracker_layout(bts_tracker *t, char *base, size_t &off) {
             SLOT(t->det_h2, int8_t, M * D); SLOT(t->det_m2, float, M * feat::I8_META);
             SLOT(t->dface_h2, int8_t, M * Df); SLOT(t->dface_m2, float, M * feat::I8_META);
         }
+        if (d.fahead) {
+            SLOT(t->det_mts[0], float, M * feat::I8_META); SLOT(t->det_mts[1], float, M * feat::I8_META);
+            SLOT(t->hi_b[0], int32_t, M); SLOT(t->hi_b[1], int32_t, M);
+            SLOT(t->shdr, int32_t, 4 * H_SIZE); SLOT(t->fstat_b, int32_t, 2 * 16);
+            SLOT(t->iota, int32_t, T > M ? T : M); SLOT(d.pool_cbrow, int32_t, T);
+        }
         if (d.sorted) {
             const size_t slots = (size_t)bts_cdiv((int)T, FBM) * (size_t)bts_cdiv((int)M, FBN) * 4;
             SLOT(d.cand_cnt, int32_t, slots); SLOT(d.cand, int2, slots * CAND_W);
@@ -2985,7 +3052,7 @@ static void tracker_layout(bts_tracker *t, char *base, size_t &off) {
         if (T * M <= SPLITK_MAX_ENTRIES) { SLOT(d.approx, int32_t, T * M); SLOT(d.approx_f, int32_t, d.Df ? T * M : 1); }
         else { d.approx = nullptr; d.approx_f = nullptr; }
         d.cb_ld = (int)((M + 63) / 64) * 2;        // 64 columns = one aligned 8-byte word
-        SLOT(d.cbits, uint32_t, T * (size_t)d.cb_ld);
+        SLOT(d.cbits, uint32_t, (d.fahead ? 2 * (T + M) : T) * (size_t)d.cb_ld);      // (BTS_FILTER_AHEAD: two frames' [T + Mx] rows)
     }
     SLOT(t->x_ints, int32_t, 8 * T); SLOT(t->x_mean, double, 8 * T); SLOT(t->x_tlbr, double, 4 * T); SLOT(t->x_score, float, T); SLOT(t->x_mot, double, 10 * T);
 #undef SLOT
@@ -3040,6 +3107,11 @@ static int derive_sizes(const bts_tracker_config *cfg, Dev &d, int64_t *e_cap_ou
                 cfg->match_thresh < 1.0 && !cfg->use_graph) ? 1 : 0;
     // BTS_LISTS_AHEAD=1 (read at create): the next frame's pool / unconfirmed / free lists are built by tk_finalize
     d.ahead = (bts_form_flag("BTS_LISTS_AHEAD") && !cfg->use_graph) ? 1 : 0;
+    // BTS_FILTER_AHEAD=1 (read at create; opt-in THROUGHPUT mode, see enqueue_step): the pre-filter of a frame runs on the side
+    // stream ahead of the step that consumes it.  Body features only, bitmap consumers = the tile forms; the pool list it selects
+    // bitmap rows for is the one tk_finalize builds (it implies BTS_LISTS_AHEAD; create adds BTS_PREDICT_FRONT and the side stream)
+    d.fahead = (bts_form_flag("BTS_FILTER_AHEAD") && d.filter && d.Df == 0 && !d.sorted && !cfg->use_graph && !cfg->record_costs) ? 1 : 0;
+    if (d.fahead) d.ahead = 1;
     // BTS_MERGE_EARLY=1 (read at create): tk_merge's jobs in the launch of tk_apply23 (tk_apply23_merge)
     d.merge_early = bts_form_flag("BTS_MERGE_EARLY") ? 1 : 0;
     d.renorm_fused = bts_form_flag("BTS_RENORM_FUSED") ? 1 : 0;
@@ -3079,7 +3151,7 @@ static int derive_sizes(const bts_tracker_config *cfg, Dev &d, int64_t *e_cap_ou
 static int lap_self_slices(const Dev &d) {
     if (!bts_form_flag("BTS_LAP_SELF")) return 0;
     const char *e = bts_form_get("BTS_LAP_HELPERS");
-    return bts_lap_helpers_for(d.T, e && atoi(e) >= 0 && atoi(e) <= 255 ? atoi(e) : -1);
+    return bts_lap_helpers_for(d.T, e && *e && atoi(e) >= 0 && atoi(e) <= 255 ? atoi(e) : -1);
 }
 
 int bts_tracker_memory_bytes(const bts_tracker_config *cfg, uint64_t *out_bytes) {
@@ -3096,7 +3168,7 @@ int bts_tracker_memory_bytes(const bts_tracker_config *cfg, uint64_t *out_bytes)
     int64_t e_cap = 0;
     const int rc = derive_sizes(cfg, d, &e_cap);
     if (rc) { delete t; return rc; }
-    t->cvt_overlap = bts_form_flag("BTS_CVT_OVERLAP") && d.filter && !cfg->use_graph;
+    t->cvt_overlap = (bts_form_flag("BTS_CVT_OVERLAP") || d.fahead) && d.filter && !cfg->use_graph;
     size_t off = 0;
     tracker_layout(t, nullptr, off);
     const int64_t o_cap = (cfg->tie_mode && d.Df > 0) ? e_cap : 0;      // overrides of the exact-tie step (tk_edges_xo): their own region
@@ -3144,12 +3216,17 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
         d.nch = (!forced && d.T <= 6144) ? 1 : bts_cdiv(d.T, rows);
         d.nch = d.nch < 1 ? 1 : d.nch > 8 ? 8 : d.nch;
     }
-    d.use_grid = bts_form_flag("BTS_EDGES_GRID") ? 1 : 0;
+    d.use_grid = (bts_form_flag("BTS_EDGES_GRID") && !d.fahead) ? 1 : 0;      // (the neighbour search reads the bitmap by pool row)
     t->predict_first = bts_form_flag("BTS_PREDICT_FIRST");
-    t->predict_front = bts_form_flag("BTS_PREDICT_FRONT") && d.ahead;
-    t->cvt_overlap = bts_form_flag("BTS_CVT_OVERLAP") && d.filter && !cfg->use_graph;
+    t->predict_front = (bts_form_flag("BTS_PREDICT_FRONT") || d.fahead) && d.ahead;
+    t->cvt_overlap = (bts_form_flag("BTS_CVT_OVERLAP") || d.fahead) && d.filter && !cfg->use_graph;
+    { const char *e = bts_form_get("BTS_FILTER_AHEAD_PW"); const int v = e ? atoi(e) : 0; t->filter_ahead_pw = v > 0 && v <= 2048 ? v : 384; }
     t->lap_form = bts_lap_form_from_env();
-    { const char *e = bts_form_get("BTS_LAP_HELPERS"); t->lap_helpers = e && atoi(e) >= 0 && atoi(e) <= 255 ? atoi(e) : -1; }
+    {   // resolved ONCE, here: an absent / empty key is the automatic count for this table size, never a later look at the
+        // process environment -- the SELF form's slices below are carved for exactly this many helper workgroups
+        const char *e = bts_form_get("BTS_LAP_HELPERS");
+        t->lap_helpers = bts_lap_helpers_for(d.T, e && *e && atoi(e) >= 0 && atoi(e) <= 255 ? atoi(e) : -1);
+    }
     { const char *e = bts_form_get("BTS_FILTER_PW"); const int v = e ? atoi(e) : 0; t->filter_pw = v > 0 && v <= 2048 ? v : 0; }
     { const char *e = bts_form_get("BTS_TILE_GOAL"); const int v = e ? atoi(e) : 0; t->tile_goal = v >= 64 && v <= 16384 ? v : 768; }
     t->onepass = bts_form_flag("BTS_FILTER_ONEPASS");
@@ -3160,7 +3237,8 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
         if (e && !strcmp(e, "128x128t")) t->filter_tile = 3;      // (emulator build only: the template at k_filter_i8's own shape, two record
                                                                  //  images -- tests/test_emu_gpu_subset.py holds the two kernels against each other)
 #endif
-        if (d.Df > 0 || d.sorted) t->filter_tile = 0;      // (no face pass, no candidate list in k_filter_t)
+        if (d.Df > 0 || d.sorted || d.fahead) t->filter_tile = 0;      // (no face pass, no candidate list in k_filter_t; the side passes run k_filter_i8)
+        if (!d.filter) t->filter_tile = 0;                 // (dense appearance mode: no pre-filter at all -- bts_tracker_forms reports forms IN EFFECT)
     }
     d.gate_sim = 1.0f - d.app;
     d.f_guess = bts_form_flag("BTS_FILTER_GUESS") ? 1 : 0;
@@ -3172,11 +3250,11 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
     // the forms in effect (a requested form that the configuration rules out -- the sorted edges with a motion gate, say --
     // does not appear), for bts_tracker_forms
     snprintf(t->forms, sizeof(t->forms), "edges=%s,lists_ahead=%d,merge_early=%d,renorm_fused=%d,cvt_overlap=%d,predict_front=%d,predict_first=%d,lap_form=%s,lap_helpers=%d,list_chunks=%d,"
-             "filter_pw=%d,filter_first16=%d,filter_onepass=%d,filter_guess=%d,shadow_planes=%d,tile_goal=%d,lap_self=%d,filter_tile=%s",
+             "filter_pw=%d,filter_first16=%d,filter_onepass=%d,filter_guess=%d,shadow_planes=%d,tile_goal=%d,lap_self=%d,filter_tile=%s,filter_ahead=%d",
              d.sorted ? "sorted" : (d.use_grid && d.filter) ? "grid" : "tiles", d.ahead, d.merge_early, d.renorm_fused, t->cvt_overlap ? 1 : 0, t->predict_front ? 1 : 0, t->predict_first ? 1 : 0,
              t->lap_form == 1 ? "row" : "col", t->lap_helpers, d.nch, t->filter_pw > 0 ? t->filter_pw : (t->filter_tile == 2 ? 768 : FILTER_PW), d.chk_first,
              t->onepass ? 1 : 0, d.f_guess, d.sh_planes, t->tile_goal, lap_self_slices(d) > 0 ? 1 : 0,
-             t->filter_tile == 1 ? "160x128" : t->filter_tile == 2 ? "128x64" : t->filter_tile == 3 ? "128x128t" : "128x128");
+             t->filter_tile == 1 ? "160x128" : t->filter_tile == 2 ? "128x64" : t->filter_tile == 3 ? "128x128t" : "128x128", d.fahead);
     size_t off = 0;
     tracker_layout(t, nullptr, off);
     const int64_t o_cap = (cfg->tie_mode && d.Df > 0) ? e_cap : 0;      // overrides of the exact-tie step (tk_edges_xo): their own region
@@ -3247,11 +3325,21 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
     if (t->dv.filter && ((t->dv.approx && (hipMemset(t->dv.approx, 0, sizeof(int32_t) * tm) != hipSuccess ||
                                            hipMemset(t->dv.approx_f, 0, sizeof(int32_t) * (t->dv.Df ? tm : 1)) != hipSuccess)) ||
                          hipMemset(t->dv.fstat, 0, sizeof(int32_t) * 16) != hipSuccess ||
-                         hipMemset(t->dv.cbits, 0, sizeof(uint32_t) * (size_t)t->dv.T * t->dv.cb_ld) != hipSuccess)) {
+                         hipMemset(t->dv.cbits, 0, sizeof(uint32_t) * (size_t)(t->dv.fahead ? 2 * (t->dv.T + t->dv.Mx) : t->dv.T) * t->dv.cb_ld) != hipSuccess)) {
         (void)hipGetLastError();
         bts_set_error("hipMemset failed");
         bts_tracker_destroy(t);
         return BTS_EHIP;
+    }
+    if (t->dv.fahead) {       // the identity list of the side passes' rows
+        std::vector<int32_t> io((size_t)(t->dv.T > t->dv.Mx ? t->dv.T : t->dv.Mx));
+        for (size_t k = 0; k < io.size(); ++k) io[k] = (int32_t)k;
+        if (hipMemcpy(t->iota, io.data(), io.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipGetLastError();
+            bts_set_error("hipMemcpy failed");
+            bts_tracker_destroy(t);
+            return BTS_EHIP;
+        }
     }
     if (t->dv.sorted && hipMemset(t->dv.cand_cnt, 0, sizeof(int32_t) * (size_t)bts_cdiv(t->dv.T, FBM) * (size_t)bts_cdiv(t->dv.Mx, FBN) * 4) != hipSuccess) {
         (void)hipGetLastError();
@@ -3413,6 +3501,9 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
     Dev dstep = t->dv;
     dstep.f_ntiles = bts_cdiv(dstep.T, FBM) * bts_cdiv(mc, FBN); dstep.f_mc = mc;      // (the pre-filter's tiling of this step: candidate-list slots decode with it)
     if (ov && ovp) { dstep.det_h = t->det_h2; dstep.det_m = t->det_m2; dstep.dface_h = t->dface_h2; dstep.dface_m = t->dface_m2; }
+    // BTS_FILTER_AHEAD: this frame's candidate bitmap ([T + Mx] rows) is buffer (step & 1) as well
+    const bool fa = dstep.fahead && ov;
+    if (fa) dstep.cbits = t->dv.cbits + (size_t)ovp * (size_t)(dstep.T + dstep.Mx) * (size_t)dstep.cb_ld;
     const Dev &d = dstep;
     const int T = d.T, M = d.Mx;
     const int cos_kernel = t->ctx->cos_kernel;
@@ -3451,7 +3542,39 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
             BTS_HIP(hipStreamWaitEvent(t->side, t->ev_in, 0));
         }
         if (t->ev_done_used[ovp]) BTS_HIP(hipStreamWaitEvent(t->side, t->ev_done[ovp], 0));
-        LAUNCH_ON(t->side, tk_cvt, dim3(bts_cdiv(mc, 4)), dim3(1024));
+        if (fa) {
+            // BTS_FILTER_AHEAD (opt-in throughput mode, round 6).  Everything the pre-filter of frame f computes is known before
+            // step f-1 has finished, so it runs HERE, on the side stream, under step f-1's latency-bound kernels (the host enqueues
+            // step f while the device is still in step f-1 or earlier), and the step's own stream carries no pre-filter launch:
+            //   main pass   rows = ALL table slots x this frame's high-score detections.  Valid for every track whose shadow has
+            //               been stable since step f-2 ended (the side stream waited for that above); rows step f-1 is rewriting
+            //               meanwhile may be read torn -- their bits are never consulted (a torn record can only make a tile's
+            //               row summary {min uh, max alpha, max r} more conservative for the other rows);
+            //   det x det   rows = the detections of frame f-1 (their shadows and TRACK-SIDE records, tk_cvt_ahead) x the same
+            //               columns.  A track rewritten in step f-1 holds exactly the shadow and record of the detection it
+            //               absorbed (copy_shadow; det_index[slot]), whichever detection that turns out to be.
+            // Both are the UNCHANGED default kernel k_filter_i8<false>, fed a Dev whose row list is the identity and whose extents
+            // sit in a small header of their own; the stage-1 tiles find a pool row's bitmap row through pool_cbrow (tk_finalize).
+            const size_t brows = (size_t)(T + M);
+            BTS_HIP(hipMemsetAsync(d.cbits, 0, sizeof(uint32_t) * brows * (size_t)d.cb_ld, t->side));
+            int32_t *sh_main = t->shdr + (size_t)(ovp * 2 + 0) * H_SIZE, *sh_dd = t->shdr + (size_t)(ovp * 2 + 1) * H_SIZE;
+            LAUNCH_ON(t->side, tk_cvt_ahead, dim3(bts_cdiv(mc, 4) + 1), dim3(1024), t->det_mts[ovp], t->hi_b[ovp], sh_main, sh_dd, t->fstat_b + 16 * ovp, t->mc_prev);
+            Dev dm = dstep;
+            dm.pool_slot = t->iota; dm.hdr = sh_main; dm.hi_idx = t->hi_b[ovp]; dm.fstat = t->fstat_b + 16 * ovp;
+            const int mt = bts_cdiv(T, FBM) * bts_cdiv(mc, FBN), mb = mt < t->filter_ahead_pw ? mt : t->filter_ahead_pw;
+            hipLaunchKernelGGL(k_filter_i8<false>, dim3(mb), dim3(256), 0, t->side, dm, mc, mt, mb); BTS_LAUNCH_CHECK();
+            if (t->mc_prev > 0) {
+                Dev dd = dm;
+                dd.hdr = sh_dd; dd.T = M;                                  // (rows = detections of the previous frame: the clamps of the row fetch)
+                dd.body_h = ovp ? t->dv.det_h : t->det_h2; dd.body_m = t->det_mts[ovp ^ 1];
+                dd.sh_rt[0] = d.sh_rd[0]; dd.sh_ct[0] = d.sh_cd[0];      // (the row operand is a detection-side shadow array)
+                dd.cbits = d.cbits + (size_t)T * (size_t)d.cb_ld;
+                const int dt = bts_cdiv(t->mc_prev, FBM) * bts_cdiv(mc, FBN), db = dt < t->filter_ahead_pw ? dt : t->filter_ahead_pw;
+                hipLaunchKernelGGL(k_filter_i8<false>, dim3(db), dim3(256), 0, t->side, dd, mc, dt, db); BTS_LAUNCH_CHECK();
+            }
+        } else {
+            LAUNCH_ON(t->side, tk_cvt, dim3(bts_cdiv(mc, 4)), dim3(1024));
+        }
         BTS_HIP(hipEventRecord(t->ev_cvt[ovp], t->side));
         if (d.ahead) {
             if (want_grid) { LAUNCH((tk_front_dets<true, false>), dim3(1 + pred_front), dim3(1024), pred_front); } else { LAUNCH((tk_front_dets<false, false>), dim3(1 + pred_front), dim3(1024), pred_front); }
@@ -3485,11 +3608,14 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
     }
     // BTS_FILTER_ONEPASS=1 (read at create): the persistent one-pass form (k_filter_i8) also for problems small enough for split K
     // (host side only: lets the tests drive that kernel's tile walk and prefix exits at sizes a CPU emulation handles)
-    if (t->onepass) split = 1;
+    if (t->onepass || fa) split = 1;         // (BTS_FILTER_AHEAD: the side passes are the one-pass kernel at every size)
     const int accum = split > 1;
     // ---- first association: pool x high-score detections
     seg_begin(BTS_SEG_COS1);
-    if (d.filter) {
+    if (fa) {
+        // (nothing here: this frame's candidates were computed on the side stream, the step waited for them right behind its first
+        //  launch, and the Kalman predict rode in that launch -- BTS_PREDICT_FRONT, implied)
+    } else if (d.filter) {
         // Kalman predict rides in the pre-filter's launch (independent work, consecutive workgroups)
         seg_begin(BTS_SEG_K_FILTER);
         // one-pass form (candidate bitmap, prefix exits): up to FILTER_PW persistent workgroups walk the tiles;
@@ -3703,6 +3829,7 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
     seg_end(BTS_SEG_DEDUPE);
     seg_end(BTS_SEG_STEP);
     if (ov) { BTS_HIP(hipEventRecord(t->ev_done[ovp], s)); t->ev_done_used[ovp] = true; }
+    if (fa) t->mc_prev = mc;
 #undef LAUNCH
 #undef LAUNCH_ON
     return BTS_OK;
@@ -3951,7 +4078,9 @@ int bts_tracker_debug_filter(bts_tracker *t, int32_t *out8_host, bts_stream stre
     BTS_ON_DEVICE(t->ctx);
     for (int k = 0; k < 16; ++k) out8_host[k] = 0;
     if (!t->dv.filter) return BTS_OK;
-    BTS_HIP(hipMemcpyAsync(out8_host, t->dv.fstat, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    // (BTS_FILTER_AHEAD: the counters of the last step's two side passes, summed by the kernel's own atomics)
+    const int32_t *fs = (t->dv.fahead && t->fstat_b && t->step_no > 0) ? t->fstat_b + 16 * (int)((t->step_no - 1) & 1) : t->dv.fstat;
+    BTS_HIP(hipMemcpyAsync(out8_host, fs, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
     BTS_HIP(hipStreamSynchronize((hipStream_t)stream));
     out8_host[14] = t->last_ftm; out8_host[15] = t->last_ftn;      // tile shape of the one-pass form (a K stage = that many rows x columns x 128)
     return BTS_OK;

@@ -431,10 +431,11 @@ class STrack(BaseTrack):
 
 
 def forms_string(forms) -> str:
-    """"KEY=VALUE,..." for bts_tracker_create_forms from a dict or a string.  A dict value of False / 0 / None / "" becomes
-    "KEY=" -- the form switched OFF whatever the environment says (the library also reads "KEY=0" / "false" / "off" as off)."""
+    """"KEY=VALUE,..." for bts_tracker_create_forms from a dict or a string.  A dict value of False / None / "" becomes "KEY=" --
+    the form switched OFF whatever the environment says.  An int 0 stays "KEY=0": the library reads "0" as off for the boolean
+    forms, and for a numeric key ({"BTS_LAP_HELPERS": 0} = no helper workgroups) it is a value, not "use the default"."""
     if isinstance(forms, dict):
-        return ",".join("%s=%s" % (k, "" if (v is None or v is False or v == 0 or v == "") else (1 if v is True else v)) for k, v in forms.items())
+        return ",".join("%s=%s" % (k, "" if (v is None or v is False or v == "") else (1 if v is True else v)) for k, v in forms.items())
     return str(forms) if forms else ""
 
 

@@ -301,12 +301,23 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
  *   BTS_FILTER_PW=n      persistent workgroups of the pre-filter (default 512)
  *   BTS_FILTER_TILE=160x128|128x64  tile shape of the one-pass pre-filter (default 128x128): 160 x 128 = two tile rounds instead of
  *                        three at 10 000 x 2 000; 128 x 64 = three resident workgroups per CU (768 persistent workgroups)
+ *   BTS_FILTER_AHEAD=1   THROUGHPUT mode (round 6; body features, tile consumers, eager launches; implies BTS_LISTS_AHEAD,
+ *                        BTS_PREDICT_FRONT and the side stream of BTS_CVT_OVERLAP): the appearance pre-filter of frame f runs on
+ *                        the side stream AHEAD of step f -- one pass over all table slots (valid for every track step f-1 does
+ *                        not rewrite) and one pass detections(f-1) x detections(f) (a track rewritten in step f-1 holds exactly
+ *                        the shadow and record of the detection it absorbed) -- and the step's own stream carries no pre-filter
+ *                        launch.  Pays only when the caller enqueues steps back to back and has promised residency
+ *                        (bts_tracker_inputs_resident); results are identical either way.  BTS_FILTER_AHEAD_PW=n: persistent
+ *                        workgroups per side pass (default 384)
  *   BTS_I8_FIRST16=k     first prefix checkpoint of the pre-filter, in sixteenths of the feature width (3..12)
  *   BTS_TILE_GOAL=n      workgroup count the stage-1 tile height aims at (default 768)
  * None of them changes a result (tests/test_zz_gpu_round4.py, test_zz_gpu_round5.py: identical assignment indices, lists and state per frame);
  * the Python package's `tune` module times them on the caller's own frames and keeps what is fastest AND identical.
  * bts_tracker_forms writes the forms IN EFFECT (a requested form the configuration rules out does not appear) as text into
- * buf (NUL-terminated, truncated to capacity) and returns its full length. */
+ * buf (NUL-terminated, truncated to capacity) and returns its full length.  filter_tile is the shape of the ONE-PASS pre-filter
+ * (128x128 when the tracker has no pre-filter: dense appearance mode, face features, sorted edges); steps small enough for the
+ * split-K form do not run that kernel -- bts_tracker_debug_filter's out[14], out[15] say what the last step ran.
+ * lap_helpers is the resolved count (BTS_LAP_HELPERS, or the automatic one for the table size), fixed for the tracker's life. */
 int bts_tracker_create_forms(bts_context *ctx, const bts_tracker_config *cfg, const char *forms, bts_tracker **out);
 int bts_tracker_memory_bytes_forms(const bts_tracker_config *cfg, const char *forms, uint64_t *out_bytes);
 int bts_tracker_forms(const bts_tracker *trk, char *buf, int capacity);
@@ -391,7 +402,9 @@ int bts_tracker_gmc(bts_tracker *trk, const double *h2x3_host, bts_stream stream
 
 /* Counters of the appearance pre-filter for the last step (synchronises): out[0] K stages (128 elements) run over all
  * tiles, [1] tiles, [2] tiles that stopped at a prefix checkpoint, [3] candidate pairs handed to the exact refinement,
- * [5..7] clock cycles / 64 summed over the kernel's workgroups: in candidate tests, waiting for operand stages, in total. */
+ * [5..7] clock cycles / 64 summed over the kernel's workgroups: in candidate tests, waiting for operand stages, in total,
+ * [14], [15] rows x columns of the tiles the step's pre-filter launch used (0 = 128: BTS_FILTER_TILE shapes only the one-pass
+ * kernel -- a step small enough for the split-K form, decided per step from the live detection count, reports 128 x 128). */
 int bts_tracker_debug_filter(bts_tracker *trk, int32_t *out16_host, bts_stream stream);
 
 /* Counters of the assignment solver for stage s of the last step (synchronises): out[0] feasible

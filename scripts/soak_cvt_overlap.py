@@ -8,7 +8,11 @@ frames.  The form's two events per frame are all that orders its side stream aga
 see them (events are no-ops there), so this soak on the device is the form's evidence.  tune.py offers the form only under
 BTS_TUNE_ALLOW_CVT=1, to be set once this has passed.
 
-    python scripts/soak_cvt_overlap.py [frames=2000]"""
+Round 6: the same soak serves BTS_FILTER_AHEAD (the pre-filter of frame f on the side stream, ahead of its step) -- same kind of
+evidence, same gate:    python scripts/soak_cvt_overlap.py [frames=2000] [forms, default "BTS_CVT_OVERLAP=1,BTS_LISTS_AHEAD=1"]
+
+    python scripts/soak_cvt_overlap.py [frames=2000]
+    python scripts/soak_cvt_overlap.py 2000 BTS_FILTER_AHEAD=1"""
 import importlib
 import os
 import sys
@@ -21,13 +25,16 @@ pkg = importlib.import_module("bot-sort-onnx-tensorrt_amd")
 tune = importlib.import_module("bot-sort-onnx-tensorrt_amd.tune")
 
 
+FORMS = sys.argv[2] if len(sys.argv) > 2 else "BTS_CVT_OVERLAP=1,BTS_LISTS_AHEAD=1"
+
+
 def soak(wl, frames, resident, stride):
     K, M, D = pkg.synth.workload_dims(wl)
     st = pkg.synth.make_workload(wl, seed=4321)
     args = dict(max_tracks=K + max(64, K // 8), max_dets=max(K, M), feat_dim=D)
     ref = pkg.DeviceTracker(**args)
-    exp = pkg.DeviceTracker(forms="BTS_CVT_OVERLAP=1,BTS_LISTS_AHEAD=1", **args)
-    assert exp.forms()["cvt_overlap"] == "1"
+    exp = pkg.DeviceTracker(forms=FORMS, **args)
+    assert exp.forms()["cvt_overlap"] == "1" and ("FILTER_AHEAD" not in FORMS or exp.forms()["filter_ahead"] == "1")
     exp.inputs_resident(resident)
     bad, checked = [], 0
     CH = 64                                               # frames generated and uploaded per chunk (complete before they are stepped)
@@ -60,7 +67,7 @@ def main():
         for resident in (True, False):
             for stride in (1, 17):
                 ok &= soak(wl, frames if stride > 1 else max(32, frames // 4), resident, stride)
-    print("BTS_CVT_OVERLAP soak:", "PASS (tune.py may offer it: BTS_TUNE_ALLOW_CVT=1)" if ok else "FAIL")
+    print(FORMS, "soak:", "PASS (tune.py may offer it: BTS_TUNE_ALLOW_CVT=1)" if ok else "FAIL")
     sys.exit(0 if ok else 1)
 
 

@@ -196,9 +196,21 @@ static inline emu_f32x16 emu_mfma_f32_32x32x2f32(int site, float a, float b, emu
 // (only named inside a discarded `if constexpr` branch of a timing experiment)
 #define __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, ...) (c)
 // global_load_lds (16 B per lane): the LDS image is lane-linear from the wave-uniform base -- lane l's bytes land at base + 16 l.
-// Immediate here (the hardware's is asynchronous: s_waitcnt vmcnt + barrier protocols are not modelled, only their data flow).
+// ASYNCHRONOUS like the hardware's (round 6; hipemu.cpp "LDS-DMA"): the bytes are fetched at issue, the destination is POISONED, and
+// the data lands only when the issuing thread's wavefront executes its s_waitcnt vmcnt (emu::lds_dma_wait -- the kernels' explicit
+// waits; nothing else completes a transfer here, which is stricter than the hardware, where a compiler-inserted wait may help by
+// accident).  A landed transfer is another wavefront's to read only behind the next workgroup barrier.  Every LDS access the
+// kernels make through their inline-assembly wrappers calls emu::lds_dma_check: touching bytes of a transfer that has not landed
+// (or landed in another wavefront with no barrier since) aborts with the block / thread / address.  HIPEMU_LDS_DMA=sync: the old
+// immediate copy; fault injection (the detector must then fire): HIPEMU_LDS_DMA=dropwaits -- the waits are ignored --, =late:N -- every
+// wait leaves N transfers too many in flight, a mis-counted vmcnt.
+namespace emu {
+void lds_dma_issue(const void *g, void *dst, int n);
+void lds_dma_wait(int keep);                                   // s_waitcnt vmcnt(keep), as far as this thread's LDS-DMA goes
+void lds_dma_check(const void *p, int n, const char *what);    // an LDS read / write of [p, p + n)
+}
 static inline void emu_global_load_lds(const void *g, void *lds_base, int size) {
-    memcpy((char *)lds_base + (size_t)(emu::tid_x() & 63) * (size_t)size, g, (size_t)size);
+    emu::lds_dma_issue(g, (char *)lds_base + (size_t)(emu::tid_x() & 63) * (size_t)size, size);
 }
 #define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) emu_global_load_lds((const void *)(g), (void *)(l), (size))
 

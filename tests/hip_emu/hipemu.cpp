@@ -82,6 +82,72 @@ void spin() {
     swapcontext(&g_cur->ctx, &g_sched);          // (stays READY; if the workgroup is dropped it is never resumed)
 }
 
+// ---- LDS-DMA (global_load_lds) ------------------------------------------------------------------------------------------------
+// One in-flight list per workgroup.  issue: fetch now, poison the destination; wait(keep): the calling thread's transfers land in
+// issue order except its newest `keep`; workgroup barrier: landed transfers retire (visible to everybody); check: see the header.
+struct Dma { char *dst; int n, tid; bool landed; char data[16]; };
+static std::vector<Dma> g_dma;
+static std::multimap<uintptr_t, int> g_dma_slot;               // 16-byte LDS slot -> index into g_dma
+static int dma_mode() {                                        // 0 asynchronous (default), 1 sync, 2 dropwaits
+    static const int m = [] { const char *e = getenv("HIPEMU_LDS_DMA"); return !e ? 0 : !strcmp(e, "sync") ? 1 : !strcmp(e, "dropwaits") ? 2 : 0; }();
+    return m;
+}
+static int dma_late() {                                        // HIPEMU_LDS_DMA=late:N -- every wait counts N too many (vmcnt(k + N)): fault injection
+    static const int n = [] { const char *e = getenv("HIPEMU_LDS_DMA"); return e && !strncmp(e, "late:", 5) ? atoi(e + 5) : 0; }();
+    return n;
+}
+static void dma_index(int i) {
+    const uintptr_t a = (uintptr_t)g_dma[i].dst;
+    for (uintptr_t sl = a >> 4; sl <= (a + g_dma[i].n - 1) >> 4; ++sl) g_dma_slot.insert({sl, i});
+}
+void lds_dma_issue(const void *g, void *dst, int n) {
+    if (n <= 0 || n > 16) { fprintf(stderr, "hipemu: global_load_lds of %d bytes per lane\n", n); abort(); }
+    if (dma_mode() == 1) { memcpy(dst, g, (size_t)n); return; }
+    lds_dma_check(dst, n, "global_load_lds into");              // a transfer into bytes another transfer still owns
+    Dma d;
+    d.dst = (char *)dst; d.n = n; d.tid = g_cur->tid; d.landed = false;
+    memcpy(d.data, g, (size_t)n);
+    memset(dst, 0x7f, (size_t)n);                               // (float 3.4e38 / int8 127: a consumer that slips through is wrong loudly)
+    g_dma.push_back(d);
+    dma_index((int)g_dma.size() - 1);
+}
+void lds_dma_wait(int keep) {
+    if (dma_mode() == 2 || g_dma.empty()) return;
+    int mine = 0;
+    for (const Dma &d : g_dma) if (d.tid == g_cur->tid && !d.landed) ++mine;
+    int land = mine - keep - dma_late();
+    for (Dma &d : g_dma) {
+        if (land <= 0) break;
+        if (d.tid == g_cur->tid && !d.landed) { memcpy(d.dst, d.data, (size_t)d.n); d.landed = true; --land; }
+    }
+}
+void lds_dma_check(const void *p, int n, const char *what) {
+    if (g_dma_slot.empty()) return;
+    const uintptr_t a = (uintptr_t)p;
+    for (uintptr_t sl = a >> 4; sl <= (a + n - 1) >> 4; ++sl) {
+        auto r = g_dma_slot.equal_range(sl);
+        for (auto it = r.first; it != r.second; ++it) {
+            const Dma &d = g_dma[it->second];
+            if ((uintptr_t)d.dst >= a + n || (uintptr_t)d.dst + d.n <= a) continue;
+            if (d.tid == g_cur->tid && d.landed) continue;
+            if (!d.landed || (d.tid >> 6) != (g_cur->tid >> 6)) {
+                fprintf(stderr, "hipemu: LDS-DMA hazard in block (%u,%u,%u): thread %d: %s %d bytes at %p, which thread %d's global_load_lds %s\n",
+                        g_bid.x, g_bid.y, g_bid.z, g_cur->tid, what, n, p, d.tid,
+                        d.landed ? "landed in ANOTHER wavefront with no workgroup barrier since" : "has in flight (no s_waitcnt vmcnt of the issuing wavefront yet)");
+                abort();
+            }
+        }
+    }
+}
+static void dma_retire_landed() {                               // at a workgroup barrier's release
+    if (g_dma.empty()) return;
+    std::vector<Dma> keep;
+    for (const Dma &d : g_dma) if (!d.landed) keep.push_back(d);
+    g_dma.swap(keep);
+    g_dma_slot.clear();
+    for (int i = 0; i < (int)g_dma.size(); ++i) dma_index(i);
+}
+
 static void trampoline() {
     (*g_body)();
     g_cur->st = DONE;
@@ -150,6 +216,7 @@ static bool run_block(int nthreads) {        // false: the workgroup was deferre
         g_stacks = (char *)mmap(nullptr, g_nstacks * STACK, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
         if (g_stacks == (char *)MAP_FAILED) { perror("hipemu: mmap"); abort(); }
     }
+    g_dma.clear(); g_dma_slot.clear();      // (transfers still in flight when a workgroup ends are dropped, as on the hardware)
     g_th.assign((size_t)nthreads, Thread());
     for (int t = 0; t < nthreads; ++t) {
         Thread &T = g_th[t];
@@ -208,6 +275,7 @@ static bool run_block(int nthreads) {        // false: the workgroup was deferre
         }
         if (all_bar) {
             g_bar_or = orv != 0;
+            dma_retire_landed();
             for (int t = 0; t < nthreads; ++t) if (g_th[t].st == AT_BARRIER) g_th[t].st = READY;
             continue;
         }

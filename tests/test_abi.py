@@ -213,4 +213,4 @@ def test_boolean_forms_read_zero_false_off_as_off(monkeypatch):
     assert f(T, M, D) == base
     monkeypatch.setenv("BTS_CVT_OVERLAP", "1")
     assert f(T, M, D) == on and f(T, M, D, forms={"BTS_CVT_OVERLAP": 0}) == base
-    assert pkg.tracker.forms_string({"A": 0, "B": True, "C": "row", "D": None}) == "A=,B=1,C=row,D="
+    assert pkg.tracker.forms_string({"A": 0, "B": True, "C": "row", "D": None, "E": False, "F": ""}) == "A=0,B=1,C=row,D=,E=,F="

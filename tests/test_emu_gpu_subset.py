@@ -112,6 +112,33 @@ def test_cvt_overlap_survives_adversarial_stream_schedules_and_the_detector_dete
 
 
 @needs_toolchain
+def test_filter_ahead_survives_adversarial_stream_schedules_and_the_detector_detects():
+    """Round 6: BTS_FILTER_AHEAD runs the pre-filter of frame f on the side stream ahead of step f (a main pass over the table's
+    slots whose rows step f-1 may be rewriting meanwhile, superseded by a det x det pass for exactly those tracks).  Under
+    `sidelate` the side passes run as late as the step's wait allows, under `mainlate` the steps themselves lag behind the side
+    stream as far as the side stream's wait for "step f-2 is done" allows -- the main pass then reads shadows from before step f-1
+    ran at all, which the design claims is harmless.  24 frames of the appearance-only stream with hidden identities (both kinds of
+    bitmap row decide assignments), digests every sixth frame: the form = the default forms under both schedules, and with either
+    dependency dropped the digests differ (the detector detects)."""
+    subprocess.check_call(["make", "-C", EMU, "-s", "-j4"])
+    node = "tests/test_zz_gpu_round6.py::test_filter_ahead_without_host_synchronisation_between_steps"
+    runs = {}
+    for mode, drop in (("sidelate", None), ("mainlate", None), ("sidelate", "main"), ("mainlate", "side")):
+        env = dict(os.environ, BTS_LIB_PATH=os.path.join(EMU, "libbotsort_emu.so"), HIPEMU_STREAMS=mode)
+        env.pop("HIPEMU_DROP_WAITS", None)
+        if drop:
+            env["HIPEMU_DROP_WAITS"] = drop
+        cmd = [sys.executable, "-m", "pytest", "-m", "gpu", "-p", "tests.hip_emu.emu_prelude", "-p", "no:cacheprovider", "-q", "--no-header",
+               "--timeout", "900", "-k", "True", node]
+        runs[(mode, drop)] = subprocess.Popen(cmd, cwd=REPO, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    out = {k: (p.communicate(timeout=1400)[0], p.returncode) for k, p in runs.items()}
+    for key in (("sidelate", None), ("mainlate", None)):
+        assert out[key][1] == 0 and "1 passed" in out[key][0], (key, out[key][0][-1500:])
+    for key in (("sidelate", "main"), ("mainlate", "side")):
+        assert out[key][1] != 0 and "1 failed" in out[key][0] and "AssertionError" in out[key][0], (key, out[key][0][-1500:])
+
+
+@needs_toolchain
 def test_red_zones_between_the_table_arrays_catch_a_store_past_an_array():
     """The emulated library pads every array of the track-table block with a canary-filled red zone and checks the zones at every
     bts_tracker_counts and at destroy (csrc/tracker.hip, BTS_HOST_EMU only): every GPU test that runs on the emulator is thereby
@@ -131,3 +158,43 @@ def test_red_zones_between_the_table_arrays_catch_a_store_past_an_array():
     assert ok.returncode == 0 and "clean exit" in ok.stdout, ok.stderr[-800:]
     bad = subprocess.run([sys.executable, "-c", code], cwd=REPO, env=dict(env, HIPEMU_POKE_REDZONE="17"), capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0 and "red zone" in bad.stderr and "clean exit" not in bad.stdout, (bad.returncode, bad.stderr[-800:])
+
+
+@needs_toolchain
+def test_lds_dma_is_asynchronous_and_a_missing_wait_is_detected():
+    """the emulator used to serve global_load_lds at once, so a missing / mis-counted s_waitcnt vmcnt in front of
+    an LDS read of the pre-filter (operand stages, and the record images that ride the same DMA path one stage ahead of their test)
+    could not show.  Now a transfer lands at the issuing wavefront's explicit wait only, its destination is poisoned until then, it is
+    another wavefront's to read only behind a workgroup barrier, and every inline-assembly LDS access of the kernels is checked
+    against the transfers in flight (tests/hip_emu/hipemu.cpp "LDS-DMA").  Here: the three pre-filter kernels (k_filter_i8,
+    k_filter_t at both shapes' record layouts, k_filter_splitk) run clean with the waits as written and give the digests of the old
+    immediate copy; with the waits dropped, or counting one transfer too many, the process aborts with the hazard report."""
+    subprocess.check_call(["make", "-C", EMU, "-s", "-j4"])
+    code = ("import importlib, sys, hashlib, torch, numpy as np\n"
+            "import tests.hip_emu.emu_prelude\n"
+            "pkg = importlib.import_module('bot-sort-onnx-tensorrt_amd')\n"
+            "h = hashlib.sha256()\n"
+            "for forms in sys.argv[1].split(';'):\n"
+            "    st = pkg.synth.SyntheticStream(200, 150, 1024, seed=7, churn=0.1)\n"
+            "    t = pkg.DeviceTracker(max_tracks=512, max_dets=256, feat_dim=1024, forms=forms)\n"
+            "    for f in range(3):\n"
+            "        fr = st.next()\n"
+            "        t.step(torch.from_numpy(fr.boxes).cuda(), torch.from_numpy(fr.scores).cuda(), torch.from_numpy(fr.feats.copy()).cuda())\n"
+            "        for k in (1, 2, 3):\n"
+            "            h.update(np.ascontiguousarray(t.stage_result(k)['m']).tobytes())\n"
+            "        fs = t.debug_filter()\n"
+            "        h.update(repr((fs['k_stages'], fs['tiles'], fs['prefix_exits'], fs['candidates'])).encode())\n"
+            "    assert t.counts()['errors'] == 0 and fs['tiles'] > 0\n"
+            "    t.close()\n"
+            "print('digest', h.hexdigest())\n")
+    kernels = "BTS_FILTER_ONEPASS=1;BTS_FILTER_ONEPASS=1,BTS_FILTER_TILE=160x128;BTS_FILTER_ONEPASS=1,BTS_FILTER_TILE=128x64;BTS_NONE=1"
+    env = dict(os.environ, BTS_LIB_PATH=os.path.join(EMU, "libbotsort_emu.so"), PYTHONPATH=REPO)
+    env.pop("HIPEMU_LDS_DMA", None)
+    runs = {mode: subprocess.Popen([sys.executable, "-c", code, kernels if mode in (None, "sync") else kernels.split(";")[k]], cwd=REPO,
+                                   env=dict(env, **({"HIPEMU_LDS_DMA": mode} if mode else {})), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+            for mode, k in ((None, 0), ("sync", 0), ("dropwaits", 0), ("late:1", 1), ("late:2", 3))}
+    out = {m: p.communicate(timeout=1200) + (p.returncode,) for m, p in runs.items()}
+    assert out[None][2] == 0 and "digest" in out[None][0], out[None][1][-800:]
+    assert out["sync"][2] == 0 and out["sync"][0] == out[None][0], (out["sync"][0], out[None][0])
+    for m in ("dropwaits", "late:1", "late:2"):
+        assert out[m][2] != 0 and "LDS-DMA hazard" in out[m][1] and "digest" not in out[m][0], (m, out[m][2], out[m][1][-600:])

@@ -1,0 +1,207 @@
+"""(File name: sorts after the suites that have been green on hardware, like the other test_zz_gpu_* files.)
+
+Round-6 GPU parity tests -- written while GPU access was closed and run on the CPU emulation of the kernel sources (tests/hip_emu):
+the opt-in throughput form BTS_FILTER_AHEAD (csrc/tracker.hip, enqueue_step): the appearance pre-filter of frame f runs on the side
+stream ahead of the step that consumes it -- a MAIN pass over all table slots (valid for tracks whose shadow was not rewritten in
+step f-1) and a DET x DET pass frame f-1 x frame f (a track rewritten in step f-1 holds exactly the shadow and track-side record of
+the detection it absorbed) -- and the stage-1 tiles pick each pool row's bitmap row through the selector tk_finalize writes.  Bars:
+identical assignment indices, ordered lists incl. slot numbers and Kalman means per frame against the default forms AND the oracle
+(D:1414-1639), at the sizes VERDICT r5 names (384 x 256 x 2048, 4224 x 2048 x 256 with churn), and on an appearance-only stream
+whose identities disappear and come back, so that both kinds of bitmap row decide assignments.  tests/test_emu_gpu_subset.py runs
+the appearance-only case under the emulator's adversarial stream schedules with fault injection."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+INT_KEYS = ("track_id", "state", "is_activated", "frame_id", "start_frame", "tracklet_len")
+AHEAD = {"BTS_FILTER_AHEAD": 1}
+
+
+@pytest.fixture(scope="module")
+def bts():
+    pkg = importlib.import_module("bot-sort-onnx-tensorrt_amd")
+    pkg._lib.load(require_gpu=True)
+    return pkg
+
+
+def _dev(fr):
+    import torch
+    return (torch.from_numpy(fr.boxes).cuda(), torch.from_numpy(fr.scores).cuda(), torch.from_numpy(fr.feats.copy()).cuda())
+
+
+def _same_frame(a, b, f):
+    for k in (1, 2, 3):
+        ra, rb = a.stage_result(k), b.stage_result(k)
+        assert np.array_equal(ra["x"], rb["x"]) and np.array_equal(ra["y"], rb["y"]), (f, k)
+    for which in (0, 1):
+        ta, tb = a.export(which), b.export(which)
+        for key in INT_KEYS + ("slot",):
+            assert np.array_equal(ta[key], tb[key]), (f, which, key)
+        assert np.array_equal(ta["mean"], tb["mean"]), (f, which)
+
+
+class Flicker:
+    """K identities with fixed unit prototypes; every frame a random `visible` share of them is detected, at a teleported box (no
+    IoU overlap with anything of the previous frame) and with a feature whose cosine to the identity's LAST SHOWN feature lies inside
+    the appearance gate.  Only appearance candidates can associate a detection: an identity shown in consecutive frames is found
+    through the det x det rows of the bitmap, one that was hidden for a frame or more (a lost track) through the main-pass rows."""
+
+    def __init__(self, K, D, seed, visible=0.7, cos=(0.8, 0.92)):
+        self.rng = np.random.default_rng(seed)
+        self.K, self.D, self.visible, self.cos = K, D, visible, cos
+        p = self.rng.standard_normal((K, D))
+        self.last = p / np.linalg.norm(p, axis=1, keepdims=True)
+        self.f = 0
+
+    def next(self):
+        rng, K, D = self.rng, self.K, self.D
+        show = np.ones(K, bool) if self.f == 0 else rng.uniform(size=K) < self.visible
+        ids = np.nonzero(show)[0]
+        n = len(ids)
+        cx = rng.permutation(4 * K)[:n] * 7 + 10
+        cy = rng.integers(100, 8000, n)
+        boxes = np.stack([cx, cy, cx + 5, cy + 9], 1).astype(np.int32)
+        scores = (rng.uniform(0.91, 0.99, n) if self.f == 0 else rng.uniform(0.5, 0.85, n)).astype(np.float32)
+        c = np.ones(n) if self.f == 0 else rng.uniform(self.cos[0], self.cos[1], n)
+        base = self.last[ids]
+        noise = rng.standard_normal((n, D))
+        noise -= (noise * base).sum(1, keepdims=True) * base
+        noise /= np.linalg.norm(noise, axis=1, keepdims=True)
+        feats = (c[:, None] * base + np.sqrt(1 - c[:, None] ** 2) * noise).astype(np.float32)
+        self.last[ids] = feats.astype(np.float64) / np.linalg.norm(feats.astype(np.float64), axis=1, keepdims=True)
+        perm = rng.permutation(n)
+
+        class Fr:
+            pass
+        fr = Fr()
+        fr.boxes, fr.scores, fr.feats = boxes[perm], scores[perm], np.ascontiguousarray(feats[perm])
+        fr.ids = ids[perm]
+        self.f += 1
+        return fr
+
+
+def _pair(bts, T, M, D, extra=None, **kw):
+    ref = bts.DeviceTracker(max_tracks=T, max_dets=M, feat_dim=D, **kw)
+    exp = bts.DeviceTracker(max_tracks=T, max_dets=M, feat_dim=D, forms=dict(AHEAD, **(extra or {})), **kw)
+    eff = exp.forms()
+    assert eff["filter_ahead"] == "1" and eff["lists_ahead"] == "1" and eff["predict_front"] == "1" and eff["cvt_overlap"] == "1", eff
+    assert ref.forms()["filter_ahead"] == "0"
+    exp.inputs_resident(True)
+    return ref, exp
+
+
+@pytest.mark.parametrize("extra", ["", "merge_early+renorm_fused+self", "planes"])
+def test_filter_ahead_on_an_appearance_only_stream_with_hidden_identities(bts, extra):
+    """160 identities x 128-d, 70 % shown per frame, boxes teleport: every association of frames 1.. is an appearance candidate read
+    through pool_cbrow -- det x det rows for identities shown in consecutive frames, main-pass rows for re-found lost tracks.  The
+    form = the default forms frame by frame (indices, lists, slots, means), nothing synchronises the host in between except the
+    reads of the comparison itself, and both kinds of row carried matches."""
+    envs = {"merge_early": "BTS_MERGE_EARLY", "renorm_fused": "BTS_RENORM_FUSED", "self": "BTS_LAP_SELF", "planes": "BTS_SHADOW_PLANES"}
+    K, D = 160, 128
+    ref, exp = _pair(bts, K + 96, K, D, extra={envs[k]: 1 for k in extra.split("+") if k})
+    st = Flicker(K, D, 5)
+    refound, cont = 0, 0
+    prev_ids = None
+    for f in range(14):
+        fr = st.next()
+        ref.step(*_dev(fr)); exp.step(*_dev(fr))
+        _same_frame(ref, exp, f)
+        assert ref.counts() == exp.counts() and exp.counts()["errors"] == 0, (f, exp.counts())
+        if f >= 1:
+            m = len(exp.stage_result(1)["m"])
+            shown_before = np.isin(fr.ids, prev_ids).sum()
+            cont += min(m, int(shown_before))
+            refound += max(0, m - int(shown_before))
+            assert exp.debug_filter()["candidates"] >= m          # every appearance match was a candidate of one of the two passes
+        prev_ids = fr.ids
+    assert cont > 5 * K // 2 and refound > K // 4, (cont, refound)      # both kinds of bitmap row decided assignments
+    ref.close(); exp.close()
+
+
+def test_filter_ahead_at_384x256x2048_vs_default_and_oracle(bts):
+    """VERDICT r5's first size: 384-row table, 256 identities x 2048-d (16 K stages, prefix checkpoints in use), 10 % churn: births,
+    expiries, re-found tracks, low-score detections (stage 2 rewrites tracks from LOW-score rows: det x det rows of detections that are
+    not in the high-score list of their own frame).  Form = default forms = oracle, frame by frame."""
+    from oracle import bts_oracle as bo
+    K, M, D = 256, 160, 2048
+    ref, exp = _pair(bts, 384, 256, D)
+    ora = bo.TrackerOracle(faithful_iou=False)
+    st = bts.synth.SyntheticStream(K, M, D, seed=21, churn=0.1)
+    cands = 0
+    for f in range(6):
+        fr = st.next()
+        ref.step(*_dev(fr)); exp.step(*_dev(fr))
+        ora.update_arrays(fr.boxes, fr.scores.astype(np.float64), fr.feats.copy(), None)
+        _same_frame(ref, exp, f)
+        for k in (1, 2, 3):
+            assert np.array_equal(exp.stage_result(k)["m"], np.asarray(ora.trace["m%d" % k]).reshape(-1, 2)), (f, k)
+        if f >= 1:
+            cands += exp.debug_filter()["candidates"]
+        assert ref.counts() == exp.counts() and exp.counts()["errors"] == 0
+    assert cands > 2 * M
+    ref.close(); exp.close()
+
+
+def test_filter_ahead_at_4224x2048x256_with_churn(bts):
+    """VERDICT r5's second size: a 4224-row table, 2048 detections x 256-d per frame with 10 % churn: 33 x 16 main-pass tiles and
+    16 x 16 det x det tiles over the side passes' persistent workgroups (several tiles each: next-tile prefetch, stop prediction),
+    ragged extents on both sides.  Form = default forms frame by frame, and the oracle's assignment on the last frame."""
+    from oracle import bts_oracle as bo
+    K, M, D = 2048, 2048, 256          # (the stream's first frame shows every identity: K <= max_dets)
+    ref, exp = _pair(bts, 4224, 2048, D)
+    ora = bo.TrackerOracle(faithful_iou=False)          # (faithful_iou=False: the vectorised IoU form of the checker)
+    st = bts.synth.SyntheticStream(K, M, D, seed=9, churn=0.1)
+    for f in range(4):
+        fr = st.next()
+        ref.step(*_dev(fr)); exp.step(*_dev(fr))
+        ora.update_arrays(fr.boxes, fr.scores.astype(np.float64), fr.feats.copy(), None)
+        _same_frame(ref, exp, f)
+        assert ref.counts() == exp.counts() and exp.counts()["errors"] == 0, (f, exp.counts())
+    for k in (1, 2, 3):
+        assert np.array_equal(exp.stage_result(k)["m"], np.asarray(ora.trace["m%d" % k]).reshape(-1, 2)), k
+    fs = exp.debug_filter()
+    assert fs["tiles"] >= 33 * 12 and fs["candidates"] >= len(exp.stage_result(1)["m"]) // 2       # (main pass: every slot row tile x the live column tiles)
+    ref.close(); exp.close()
+
+
+@pytest.mark.parametrize("resident", [True, False])
+def test_filter_ahead_without_host_synchronisation_between_steps(bts, resident):
+    """24 frames of the appearance-only stream stepped back to back, digests compared with the default forms' every sixth frame
+    only: on a GPU the side passes of frame f really run under step f-1's kernels.  Without the residency promise the side stream is
+    ordered behind the caller's stream at every step (correct, no overlap).  On the CPU emulation this test is also run under
+    HIPEMU_STREAMS=sidelate / mainlate with fault injection (tests/test_emu_gpu_subset.py)."""
+    tune = importlib.import_module("bot-sort-onnx-tensorrt_amd.tune")
+    K, D = 96, 128
+    ref, exp = _pair(bts, K + 64, K, D)
+    exp.inputs_resident(resident)
+    st = Flicker(K, D, 31, visible=0.75)
+    frames = [_dev(st.next()) for _ in range(24)]
+    frames2 = [(b, s, f.clone()) for (b, s, f) in frames]
+    import torch
+    torch.cuda.synchronize()
+    for f, (fa, fb) in enumerate(zip(frames, frames2)):
+        ref.step(*fa)
+        exp.step(*fb)
+        if f % 6 == 5:
+            assert tune._digest(ref) == tune._digest(exp), f
+    assert tune._state_digest(ref) == tune._state_digest(exp)
+    assert ref.counts() == exp.counts() and exp.counts()["errors"] == 0
+    assert ref.counts()["n_tracked"] > K // 2           # (the stream sustained itself on appearance alone)
+    ref.close(); exp.close()
+
+
+def test_filter_ahead_is_ruled_out_where_it_does_not_apply(bts):
+    """The form needs the pre-filter, body features only, the tile consumers and eager launches: elsewhere it is not in effect
+    (bts_tracker_forms reports forms IN EFFECT) and the tracker behaves like the default."""
+    for kw in (dict(appearance_mode=1), dict(face_dim=128), dict(use_graph=1), dict(record_costs=True)):
+        t = bts.DeviceTracker(max_tracks=256, max_dets=64, feat_dim=128, forms=AHEAD, **kw)
+        eff = t.forms()
+        t.close()
+        assert eff["filter_ahead"] == "0", (kw, eff)
+    t = bts.DeviceTracker(max_tracks=256, max_dets=64, feat_dim=128, forms=dict(AHEAD, BTS_EDGES_SORTED=1))
+    eff = t.forms()
+    t.close()
+    assert eff["filter_ahead"] == "0" and eff["edges"] == "sorted", eff
