@@ -1654,7 +1654,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 //   NIMG          record images in LDS: with ONE image a test's readers must be through before the next checkpoint's records are
 //                 staged -- the count exchange's barrier, which every test of this kernel therefore runs (k_filter_i8 skips it at the
 //                 end of a row) -- in exchange for (TM + TN) * 16 bytes of LDS.
-// Instantiations:   160 x 128 (1 x 4 wavefronts of 160 x 32: 80 accumulators per lane; 78.5 KB of LDS with one record image, two
+// Instantiations:   160 x 128 (1 x 4 wavefronts of 160 x 32: 80 accumulators per lane; 79 008 B of LDS with one record image, two
 //                   workgroups per CU) -- 882 live tiles at the headline size = TWO rounds;
 //                   128 x 64 (2 x 2 wavefronts of 64 x 32; 52.4 KB, 168 registers: THREE workgroups per CU, 768 resident).
 // Same bound, same records, same stop rule as k_filter_i8; the tile's row summary is taken over TM rows and stop_thr scales with
@@ -2955,7 +2955,9 @@ struct bts_tracker {
     int32_t *fstat_b = nullptr;   // [2][16] pre-filter counters of the side passes
     int32_t *iota = nullptr;      // 0, 1, 2, ...: the identity "list" of the side passes' rows
     int mc_prev = 0;              // detections of the previous step (rows of the det x det pass)
-    int filter_ahead_pw = 0;      // BTS_FILTER_AHEAD_PW: persistent workgroups per side pass (default 384: some CUs stay free for the step)
+    int filter_ahead_pw = 0;      // BTS_FILTER_AHEAD_PW: persistent workgroups per side pass.  Default 256 = one per CU: a pre-filter wave holds
+                                  // ~244 VGPRs, two of them close a SIMD to everything else -- with one per SIMD the step's own kernels keep
+                                  // half of every register file while the side passes run (unmeasured; 384 / 512 are tune candidates)
     bts_lap_exact xk[2];   // tie_mode 1: scratch of the exact-tie step, [0] stages 1 and 2 (sequential), [1] stage 3
     char *block = nullptr;
     size_t bytes = 0;
@@ -3220,7 +3222,7 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
     t->predict_first = bts_form_flag("BTS_PREDICT_FIRST");
     t->predict_front = (bts_form_flag("BTS_PREDICT_FRONT") || d.fahead) && d.ahead;
     t->cvt_overlap = (bts_form_flag("BTS_CVT_OVERLAP") || d.fahead) && d.filter && !cfg->use_graph;
-    { const char *e = bts_form_get("BTS_FILTER_AHEAD_PW"); const int v = e ? atoi(e) : 0; t->filter_ahead_pw = v > 0 && v <= 2048 ? v : 384; }
+    { const char *e = bts_form_get("BTS_FILTER_AHEAD_PW"); const int v = e ? atoi(e) : 0; t->filter_ahead_pw = v > 0 && v <= 2048 ? v : 256; }
     t->lap_form = bts_lap_form_from_env();
     {   // resolved ONCE, here: an absent / empty key is the automatic count for this table size, never a later look at the
         // process environment -- the SELF form's slices below are carved for exactly this many helper workgroups
@@ -3359,6 +3361,13 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
     for (int k = 0; ok && k < bts_tracker::RING; ++k) ok = hipEventCreateWithFlags(&t->in_ev[k], hipEventDisableTiming) == hipSuccess;
     ok = ok && hipStreamCreateWithFlags(&t->cs[0], hipStreamNonBlocking) == hipSuccess;
     if (t->cvt_overlap) {
+        if (t->dv.fahead) {
+            // the side passes of BTS_FILTER_AHEAD are background work with a whole step of slack: lowest priority, so that when both
+            // streams have workgroups to place the step's go first
+            int least = 0, greatest = 0;
+            ok = ok && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess &&
+                 hipStreamCreateWithPriority(&t->side, hipStreamNonBlocking, least) == hipSuccess;
+        } else
         ok = ok && hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking) == hipSuccess;
         for (int k = 0; ok && k < 2; ++k)
             ok = hipEventCreateWithFlags(&t->ev_cvt[k], hipEventDisableTiming) == hipSuccess &&

@@ -75,6 +75,8 @@ CVT_CANDIDATES: Tuple[Tuple[str, str, Dict[str, str]], ...] = (
     # when the caller steps frames back to back (the host ahead of the device), which is how the selection times its candidates.
     ("lists_ahead", "filter_ahead", {"BTS_FILTER_AHEAD": "1"}),
     ("lists_ahead", "filter_ahead_merge_early", {"BTS_FILTER_AHEAD": "1", "BTS_MERGE_EARLY": "1"}),
+    ("lists_ahead", "filter_ahead_pw_384", {"BTS_FILTER_AHEAD": "1", "BTS_FILTER_AHEAD_PW": "384"}),      # (default: 256 side workgroups, one per CU)
+    ("lists_ahead", "filter_ahead_pw_512", {"BTS_FILTER_AHEAD": "1", "BTS_FILTER_AHEAD_PW": "512"}),
 )
 
 

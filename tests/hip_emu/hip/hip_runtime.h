@@ -270,6 +270,8 @@ template <class T> static inline hipError_t hipMemcpyFromSymbol(void *d, T *sym,
 static inline hipError_t hipStreamSynchronize(hipStream_t s) { emu::stream_sync(s); return hipSuccess; }
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = emu::stream_create(); return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t s) { emu::stream_destroy(s); return hipSuccess; }
+static inline hipError_t hipDeviceGetStreamPriorityRange(int *least, int *greatest) { *least = 0; *greatest = -1; return hipSuccess; }
+static inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { *s = emu::stream_create(); return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned) { emu::stream_wait(s, e); return hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = (hipEvent_t)calloc(1, sizeof(EmuEvent)); return hipSuccess; }
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return hipEventCreate(e); }
