@@ -3571,8 +3571,9 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
             Dev dm = dstep;
             dm.pool_slot = t->iota; dm.hdr = sh_main; dm.hi_idx = t->hi_b[ovp]; dm.fstat = t->fstat_b + 16 * ovp;
             const int mt = bts_cdiv(T, FBM) * bts_cdiv(mc, FBN), mb = mt < t->filter_ahead_pw ? mt : t->filter_ahead_pw;
-            hipLaunchKernelGGL(k_filter_i8<false>, dim3(mb), dim3(256), 0, t->side, dm, mc, mt, mb); BTS_LAUNCH_CHECK();
-            if (t->mc_prev > 0) {
+            // (an empty frame has no tiles: a grid of zero workgroups is not a launch -- the memset above leaves "no candidates")
+            if (mt > 0) { hipLaunchKernelGGL(k_filter_i8<false>, dim3(mb), dim3(256), 0, t->side, dm, mc, mt, mb); BTS_LAUNCH_CHECK(); }
+            if (t->mc_prev > 0 && mc > 0) {
                 Dev dd = dm;
                 dd.hdr = sh_dd; dd.T = M;                                  // (rows = detections of the previous frame: the clamps of the row fetch)
                 dd.body_h = ovp ? t->dv.det_h : t->det_h2; dd.body_m = t->det_mts[ovp ^ 1];

@@ -294,6 +294,12 @@ void launch(dim3 grid, dim3 block, size_t dyn_lds, const std::function<void()> &
     std::lock_guard<std::mutex> lock(g_launch_mu);
     if (g_cur) { fprintf(stderr, "hipemu: nested launch\n"); abort(); }
     if (dyn_lds > sizeof(g_dyn_lds)) { fprintf(stderr, "hipemu: %zu bytes of dynamic LDS\n", dyn_lds); abort(); }
+    // (the hardware refuses an empty grid or block -- hipErrorInvalidConfiguration -- where a loop over zero workgroups would
+    //  silently do nothing: a launch whose size comes out of a frame's counts must be guarded by the caller)
+    if ((size_t)grid.x * grid.y * grid.z == 0 || (size_t)block.x * block.y * block.z == 0 || (size_t)block.x * block.y * block.z > 1024) {
+        fprintf(stderr, "hipemu: invalid launch configuration: grid (%u,%u,%u) block (%u,%u,%u)\n", grid.x, grid.y, grid.z, block.x, block.y, block.z);
+        abort();
+    }
     g_body = &body;
     g_gdim = grid; g_bdim = block;
     const int nthreads = (int)(block.x * block.y * block.z);

@@ -184,7 +184,7 @@ def test_lds_dma_is_asynchronous_and_a_missing_wait_is_detected():
             "            h.update(np.ascontiguousarray(t.stage_result(k)['m']).tobytes())\n"
             "        fs = t.debug_filter()\n"
             "        h.update(repr((fs['k_stages'], fs['tiles'], fs['prefix_exits'], fs['candidates'])).encode())\n"
-            "    assert t.counts()['errors'] == 0 and fs['tiles'] > 0\n"
+            "    assert t.counts()['errors'] == 0 and (fs['tiles'] > 0 or 'ONEPASS' not in forms)\n"      # (the split-K form keeps no tile counters)
             "    t.close()\n"
             "print('digest', h.hexdigest())\n")
     kernels = "BTS_FILTER_ONEPASS=1;BTS_FILTER_ONEPASS=1,BTS_FILTER_TILE=160x128;BTS_FILTER_ONEPASS=1,BTS_FILTER_TILE=128x64;BTS_NONE=1"

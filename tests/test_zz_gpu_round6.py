@@ -205,3 +205,65 @@ def test_filter_ahead_is_ruled_out_where_it_does_not_apply(bts):
     eff = t.forms()
     t.close()
     assert eff["filter_ahead"] == "0" and eff["edges"] == "sorted", eff
+
+
+def test_filter_ahead_edge_frames_reset_and_gmc(bts):
+    """Empty frames (the side passes have no tiles: nothing may be launched with an empty grid), a frame of low-score detections only
+    (Q19 shape: no stage-1 columns), detection counts that change from frame to frame (the det x det pass has the PREVIOUS frame's row
+    count), a camera-motion warp between steps and a reset in mid-stream (the det x det rows of the frame before the reset are stale:
+    nothing may consult them).  Form = oracle = default forms, frame by frame."""
+    import torch
+    from oracle import bts_oracle as bo
+    rng = np.random.default_rng(4)
+    D = 128
+    ref, exp = _pair(bts, 64, 16, D)
+    ora = bo.TrackerOracle()
+    protos = rng.standard_normal((8, D))
+    protos /= np.linalg.norm(protos, axis=1, keepdims=True)
+
+    def frame(boxes, scores, ids, n):
+        m = len(boxes)
+        f = (protos[ids] + 0.05 * rng.standard_normal((m, D))).astype(np.float32) if m else np.zeros((0, D), np.float32)
+        if m:
+            f /= np.linalg.norm(f, axis=1, keepdims=True)
+        b = np.asarray(boxes, dtype=np.int32).reshape(m, 4)
+        s = np.asarray(scores, dtype=np.float32)
+        for t in (ref, exp):
+            t.step(torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda(), torch.from_numpy(f.copy()).cuda())
+        ora.update_arrays(b, s.astype(np.float64), f.copy())
+        _same_frame(ref, exp, n)
+        for k in (1, 2, 3):
+            assert np.array_equal(exp.stage_result(k)["m"], np.asarray(ora.trace["m%d" % k]).reshape(-1, 2)), (n, k)
+        for which, lst in ((0, ora.tracked), (1, ora.lost)):
+            want = bo.TrackerOracle.table(lst)
+            for key in INT_KEYS:
+                assert np.array_equal(exp.export(which)[key], want[key]), (n, key)
+        assert exp.counts()["errors"] == 0
+
+    frames = [
+        ([], [], []),
+        ([[10, 10, 60, 120], [200, 50, 260, 190], [400, 400, 450, 500]], [0.95, 0.97, 0.99], [0, 1, 2]),
+        ([], [], []),
+        ([[11, 11, 61, 121], [201, 52, 262, 191]], [0.3, 0.35], [0, 1]),                       # only low scores
+        ([[900, 900, 950, 1000]], [0.6], [2]),                                                 # teleported: appearance only (main-pass row)
+        ([[12, 12, 62, 122], [203, 52, 263, 192], [905, 903, 955, 1003], [600, 10, 640, 90]], [0.96, 0.93, 0.7, 0.99], [0, 1, 2, 3]),
+        ([[13, 12, 63, 122], [1500, 700, 1550, 800]], [0.96, 0.8], [0, 2]),                    # id 2 teleports again right after a match (det x det row)
+        ([[14, 13, 64, 123], [204, 53, 264, 193], [1502, 701, 1552, 801], [601, 11, 641, 91], [50, 700, 90, 790]], [0.9, 0.5, 0.6, 0.7, 0.95], [0, 1, 2, 3, 4]),
+    ]
+    for n, (b, s, ids) in enumerate(frames):
+        frame(b, s, ids, n)
+    H = np.asarray([[1.01, -0.02, 4.0], [0.02, 1.01, -2.5]])
+    for t in (ref, exp):
+        t.gmc(H)
+    for lst in (ora.tracked, ora.lost):          # (STrack.multi_gmc on the oracle's lists, like tests/test_gpu_tracker.py::test_tracker_gmc)
+        if lst:
+            m, c = bo.KalmanOracle.multi_gmc(np.asarray([t.mean for t in lst], dtype=np.float64), np.asarray([t.cov for t in lst], dtype=np.float64), H)
+            for t, mm, cc in zip(lst, m, c):
+                t.mean, t.cov = mm, cc
+    frame([[18, 10, 69, 121], [1521, 735, 1572, 836]], [0.9, 0.8], [0, 2], 100)
+    for t in (ref, exp):
+        t.reset()
+    ora = bo.TrackerOracle()
+    for n, (b, s, ids) in enumerate(frames[1:6]):
+        frame(b, s, ids, 200 + n)
+    ref.close(); exp.close()
