@@ -33,7 +33,9 @@ INSN = re.compile(r"^\t(\S+)\s*(.*?)\s*//\s*([0-9A-Fa-f]+):")
 HEAD = re.compile(r"^([0-9a-f]+) <(.*)>:$")
 
 
-def disassemble(lib):
+def disassemble(lib, patterns=None):
+    """{demangled kernel name: [(address, mnemonic, operands), ...]} of the gfx950 code objects in `lib`; with `patterns` only the
+    code objects whose symbol table holds a match are disassembled (the library has eight; a kernel lives in one)."""
     d = tempfile.mkdtemp(prefix="isa_chain_")
     shutil.copy(lib, os.path.join(d, "lib.so"))
     subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", "lib.so"], cwd=d, check=True, capture_output=True)
@@ -41,6 +43,10 @@ def disassemble(lib):
     for f in sorted(os.listdir(d)):
         if "amdgcn" not in f:
             continue
+        if patterns:
+            syms = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-t", "-C", os.path.join(d, f)], capture_output=True, text=True).stdout
+            if not any(re.search(p, syms) for p in patterns):
+                continue
         txt = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "-C", os.path.join(d, f)], capture_output=True, text=True, check=True).stdout
         name = None
         for ln in txt.splitlines():
@@ -115,65 +121,71 @@ def walk(insns, until, start_idx=0):
                 work.append(j)
             dirty[j].add(st)
 
-    def step(t, vm, lg, a, mn, ops):
-        k_, l_, d_, w_, b_, c_, tr = t
-        c_ += 1
+    # every instruction decoded once: (class, vm kind, lgkm kind, vmcnt, lgkmcnt, is_until, successors)
+    RE_VM, RE_LG = re.compile(r"vmcnt\((\d+)\)"), re.compile(r"lgkmcnt\((\d+)\)")
+    dec = []
+    for i, (a, mn, ops) in enumerate(insns):
         cnt, kd = kind_of(mn)
+        vmc = lgc = None
+        if mn == "s_waitcnt":
+            m = RE_VM.search(ops)
+            vmc = int(m.group(1)) if m else None
+            m = RE_LG.search(ops)
+            lgc = int(m.group(1)) if m else None
+        if mn == "s_endpgm" or mn.startswith(("s_setpc", "s_swappc")):
+            succ = ()
+        elif mn == "s_branch":
+            succ = (a + 4 + 4 * ((int(ops.split()[0]) + 0x8000) % 0x10000 - 0x8000),)
+        elif mn.startswith("s_cbranch"):
+            succ = (a + 4 + 4 * ((int(ops.split()[0]) + 0x8000) % 0x10000 - 0x8000), insns[i + 1][0] if i + 1 < n else None)
+        else:
+            succ = (insns[i + 1][0] if i + 1 < n else None,)
+        succ = tuple(addr2i[x] for x in succ if x is not None and x in addr2i)
+        dec.append((cnt, kd, mn == "s_waitcnt", vmc, lgc, mn == "s_barrier", bool(re.search(until, mn)), succ))
+
+    def step(t, vm, lg, i):
+        k_, l_, d_, w_, b_, c_, tr = t
+        cnt, kd, is_wait, vmc, lgc, is_bar, _, _ = dec[i]
+        c_ += 1
         if cnt == "vm":
             vm = vm + kd
         elif cnt == "lgkm":
             lg = lg + kd
-        elif mn == "s_waitcnt":
-            m = re.search(r"vmcnt\((\d+)\)", ops)
-            if m and len(vm) > int(m.group(1)):
-                keep = int(m.group(1))
-                gone, vm = vm[:len(vm) - keep], vm[len(vm) - keep:]
+        elif is_wait:
+            a = insns[i][0]
+            if vmc is not None and len(vm) > vmc:
+                gone, vm = vm[:len(vm) - vmc], vm[len(vm) - vmc:]
                 if "L" in gone:
                     l_ += 1
                     tr = tr + (("L", a, gone),)
                 elif "D" in gone:
                     d_ += 1
                     tr = tr + (("D", a, gone),)
-            m = re.search(r"lgkmcnt\((\d+)\)", ops)
-            if m and len(lg) > int(m.group(1)):
-                keep = int(m.group(1))
-                if keep == 0 or "K" in lg:      # scalar loads return out of order: any wait that must cover one is a full wait
-                    gone, lg = (lg, "") if keep == 0 else (lg[:len(lg) - keep], lg[len(lg) - keep:])
-                else:
-                    gone, lg = lg[:len(lg) - keep], lg[len(lg) - keep:]
+            if lgc is not None and len(lg) > lgc:
+                # scalar loads return out of order: only lgkmcnt(0) guarantees them (a wait that must cover one is a full wait)
+                gone, lg = (lg, "") if (lgc == 0 or "K" in lg) else (lg[:len(lg) - lgc], lg[len(lg) - lgc:])
                 if "K" in gone:
                     k_ += 1
                     tr = tr + (("K", a, gone),)
                 elif "M" in gone:
                     w_ += 1
-        elif mn == "s_barrier":
+        elif is_bar:
             b_ += 1
         return (k_, l_, d_, w_, b_, c_, tr), vm, lg
 
     while work:
         i = work.pop()
         todo, dirty[i] = dirty[i], set()
-        a, mn, ops = insns[i]
+        is_until, succ = dec[i][6], dec[i][7]
         for st in todo:
             val = nodes[i][st]
             vm, lg, nb = st
-            if re.search(until, mn):
+            if is_until:
                 results.append((val["min"][:5] + (val["min"][5] + 1,) + val["min"][6:], val["max"][:5] + (val["max"][5] + 1,) + val["max"][6:]))
                 continue
-            tmin, vm2, lg2 = step(val["min"], vm, lg, a, mn, ops)
-            tmax, _, _ = step(val["max"], vm, lg, a, mn, ops)
-            if mn == "s_endpgm" or mn.startswith(("s_setpc", "s_swappc")):
-                succ = []
-            elif mn == "s_branch":
-                succ = [a + 4 + 4 * ((int(ops.split()[0]) + 0x8000) % 0x10000 - 0x8000)]
-            elif mn.startswith("s_cbranch"):
-                succ = [a + 4 + 4 * ((int(ops.split()[0]) + 0x8000) % 0x10000 - 0x8000), insns[i + 1][0] if i + 1 < n else None]
-            else:
-                succ = [insns[i + 1][0] if i + 1 < n else None]
-            for s_ in succ:
-                if s_ is None or s_ not in addr2i:
-                    continue
-                j = addr2i[s_]
+            tmin, vm2, lg2 = step(val["min"], vm, lg, i)
+            tmax = tmin if val["max"] is val["min"] or val["max"] == val["min"] else step(val["max"], vm, lg, i)[0]
+            for j in succ:
                 back = 1 if (j <= i and i <= last_end) else 0
                 if nb + back > BACK:
                     continue
@@ -190,7 +202,7 @@ def main():
                     help="start behind the N-th conditional branch of the kernel, TAKEN (k_filter_*: 1 = the GEMM workgroups' side of the predict / GEMM split)")
     ap.add_argument("--clock-ghz", type=float, default=2.4)
     a = ap.parse_args()
-    ks = disassemble(a.lib)
+    ks = disassemble(a.lib, a.kernels)
     rc = 0
     for pat in a.kernels:
         names = [k for k in ks if re.search(pat, k)]

@@ -125,3 +125,37 @@ def test_prefilter_tile_shapes_fit_their_occupancy(code_objects):
             body = m.group(1)
             assert len(re.findall(r"v_mfma_i32_32x32x32_i8", body)) == 4 * blocks, sym
             assert len(re.findall(r"global_load_lds_dwordx4", body)) >= 2 * loads, sym       # (stage + next-tile first stage + records)
+
+
+def test_prefilter_opens_with_one_lds_dma_drain():
+    """Round 6, read off the ISA (scripts/isa_chain.py): behind an LDS-DMA the compiler turns the wait for ANY vector
+    load into a full drain (vmcnt(0)).  With the record transfer issued behind the next tile's index loads, and the index-derived
+    record offset sunk below the first stage, a tile of the pre-filter opened with TWO serial LDS-DMA drains in front of its first
+    MFMA (first stage, then the records).  The source now issues the records first and materialises the offsets before the first
+    LDS-DMA: ONE drain on the straight path of the tile workgroups (same change in k_filter_t).  A change that
+    brings the second drain back (a new load consumed between the first stage and the stage barrier) shows up here, on the CPU."""
+    import importlib.util
+    if not os.path.exists(os.path.join(LLVM, "llvm-objdump")):
+        pytest.skip("no ROCm LLVM tools")
+    spec = importlib.util.spec_from_file_location("isa_chain", os.path.join(REPO, "scripts", "isa_chain.py"))
+    ic = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ic)
+    lib_mod = importlib.import_module("bot-sort-onnx-tensorrt_amd._lib")
+    # (the default kernel only: its first MFMA is one loop-entry away from the entry, a walk of seconds; the 160 x 128 shape needs two
+    #  and minutes -- its figures are in profiles/r06_isa_chain_kfilter.txt, from the same tool)
+    pats = ((r"k_filter_i8<false, 0, false, false>", 3),)
+    ks = ic.disassemble(lib_mod.LIB_PATH, [p for p, _ in pats])
+    ic.BACK = 1
+    for pat, max_trips in pats:
+        name = [k for k in ks if re.search(pat, k)]
+        assert len(name) == 1, (pat, name)
+        insns = ks[name[0]]
+        # start behind the predict / tile split: the first conditional branch of the kernel, taken = the tile workgroups' side
+        first = next(i for i, x in enumerate(insns) if x[1].startswith("s_cbranch"))
+        tgt = insns[first][0] + 4 + 4 * ((int(insns[first][2].split()[0]) + 0x8000) % 0x10000 - 0x8000)
+        start = next(j for j, x in enumerate(insns) if x[0] == tgt)
+        res = ic.walk(insns, r"^v_mfma", start)
+        assert res, pat
+        k_, l_, d_, w_, b_, c_, tr = min((r[0] for r in res), key=lambda t: (t[0] + t[1] + t[2], t[5]))
+        assert d_ == 1, (pat, "LDS-DMA drains before the first MFMA on the straight path", d_, tr)
+        assert k_ + l_ + d_ <= max_trips and b_ == 1, (pat, k_, l_, d_, b_)
