@@ -60,11 +60,13 @@ CANDIDATES: Tuple[Tuple[str, str, Dict[str, str]], ...] = (
     ("tile_goal", "tile_goal_1536", {"BTS_TILE_GOAL": "1536"}),
 )
 
-# BTS_CVT_OVERLAP is NOT offered by default: its side-stream ordering (two events per frame) is the one thing neither the CPU
+# BTS_CVT_OVERLAP is NOT offered unconditionally: its side-stream ordering (two events per frame) is the one thing neither the CPU
 # emulator (events are no-ops there) nor a digest of five frames can vouch for -- a race detector with five samples (VERDICT r4,
-# weak 2).  It becomes a candidate only once a 2 000-frame digest soak has passed on the device (scripts/soak_cvt_overlap.py, run by scripts/gpu_r5_b.sh) and
-# the caller says so: BTS_TUNE_ALLOW_CVT=1.  (Forms that only pay TOGETHER are offered together: the conversion leaves the first
-# launch for nothing while the list jobs still sit in it.)
+# weak 2).  It becomes a candidate only once a digest soak has passed on the device: either the 2 000-frame one of
+# scripts/soak_cvt_overlap.py, attested by the caller (BTS_TUNE_ALLOW_CVT=1), or -- round 6 -- the one select_forms runs itself on
+# its own frames before it offers these forms (soak() below; BTS_TUNE_SOAK_PASSES, default 8 passes over the frames, digests every
+# 17th step and no other host synchronisation).  (Forms that only pay TOGETHER are offered together: the conversion leaves the
+# first launch for nothing while the list jobs still sit in it.)
 CVT_CANDIDATES: Tuple[Tuple[str, str, Dict[str, str]], ...] = (
     ("lists_ahead", "lists_ahead_cvt", {"BTS_LISTS_AHEAD": "1", "BTS_CVT_OVERLAP": "1"}),
     ("lists_ahead", "lists_ahead_cvt_predict_front", {"BTS_LISTS_AHEAD": "1", "BTS_CVT_OVERLAP": "1", "BTS_PREDICT_FRONT": "1"}),
@@ -80,8 +82,59 @@ CVT_CANDIDATES: Tuple[Tuple[str, str, Dict[str, str]], ...] = (
 )
 
 
+# The side-stream forms and the key that marks their candidates.  Their evidence is a SOAK (below): since round 6 the selection runs
+# it itself, on the device, before it offers them -- no human sets BTS_TUNE_ALLOW_CVT=1 after reading a log.
+SOAK_FORMS: Tuple[Tuple[str, str, Dict[str, str]], ...] = (
+    ("cvt_overlap", "BTS_CVT_OVERLAP", {"BTS_CVT_OVERLAP": "1", "BTS_LISTS_AHEAD": "1"}),
+    ("filter_ahead", "BTS_FILTER_AHEAD", {"BTS_FILTER_AHEAD": "1"}),
+)
+
+
 def default_candidates():
     return CANDIDATES + (CVT_CANDIDATES if os.environ.get("BTS_TUNE_ALLOW_CVT") == "1" else ())
+
+
+def soak(make_tracker: Callable[[str], object], frames: Sequence[tuple], forms: Dict[str, str], passes: int = 8, stride: int = 17,
+         clone: Callable = None, sync: Callable = None) -> dict:
+    """Digest equality of `forms` against the default forms over passes x len(frames) steps: both trackers step the same frames
+    back to back, the host synchronises with the device only where a digest is taken -- every `stride`-th step and the last --, so
+    the form's side stream really runs under the previous steps' kernels; the last pass runs WITHOUT the residency promise (the
+    side stream is then ordered behind the caller's stream at every step).  The frames are re-cloned per pass (the step
+    renormalises used rows in place, Q8) and stepped again: not a video, but identical inputs for both trackers, which is all an
+    equality test needs.  -> {"steps", "digests", "mismatch_at", "errors", "state_equal", "passed"}.  What
+    scripts/soak_cvt_overlap.py does by hand, sized to run inside a bench."""
+    import torch
+    clone = clone or (lambda fr: tuple(x.clone() if i >= 2 and x is not None else x for i, x in enumerate(fr)))
+    sync = sync or torch.cuda.synchronize
+    ref, exp = make_tracker(""), make_tracker(forms_text(forms))
+    bad: List[int] = []
+    checked = step = 0
+    try:
+        for p in range(max(1, passes)):
+            resident = p + 1 < max(1, passes) or passes == 1
+            if hasattr(exp, "inputs_resident"):
+                exp.inputs_resident(resident)
+            a, b = [clone(fr) for fr in frames], [clone(fr) for fr in frames]
+            sync()
+            for fa, fb in zip(a, b):
+                ref.step(*fa)
+                exp.step(*fb)
+                step += 1
+                if step % stride == 0:
+                    checked += 1
+                    if _digest(ref) != _digest(exp):
+                        bad.append(step)
+            sync()
+        checked += 1
+        if _digest(ref) != _digest(exp):
+            bad.append(step)
+        state_equal = _state_digest(ref) == _state_digest(exp)
+        errors = (int(ref.counts()["errors"]), int(exp.counts()["errors"]))
+    finally:
+        ref.close()
+        exp.close()
+    return {"forms": forms_text(forms), "steps": step, "digests": checked, "mismatch_at": bad[:8], "errors": list(errors), "state_equal": state_equal,
+            "passed": bool(not bad and errors == (0, 0) and state_equal)}
 
 
 def forms_text(forms: Dict[str, str]) -> str:
@@ -162,8 +215,28 @@ def select_forms(make_tracker: Callable[[str], object], frames: Sequence[tuple],
     candidate -- and the spread of those two figures is the noise floor (`noise_pct`): a candidate counts as faster only beyond
     max(margin, noise), anything inside is "no difference" and the default stays."""
     report = report or (lambda rec: None)
+    soaks: List[dict] = []
     if candidates is None:
         candidates = default_candidates()
+        # the side-stream forms (BTS_CVT_OVERLAP, BTS_FILTER_AHEAD): offered once their soak has passed -- attested by the caller
+        # (BTS_TUNE_ALLOW_CVT=1, after scripts/soak_cvt_overlap.py) or run HERE, on these frames (BTS_TUNE_SOAK_PASSES, default 8
+        # passes; 0 = never).  A soak that takes the child down is blamed like a candidate ("soak:<name>") and skipped on the restart.
+        passes = int(os.environ.get("BTS_TUNE_SOAK_PASSES", "8") or 0)
+        if os.environ.get("BTS_TUNE_ALLOW_CVT") != "1" and passes > 0 and len(frames) >= 8:
+            for sname, key, forms in SOAK_FORMS:
+                if "soak:" + sname in skip:
+                    soaks.append({"name": sname, "skipped": True, "passed": False})
+                    continue
+                report({"event": "begin", "name": "soak:" + sname})
+                try:
+                    r = soak(make_tracker, frames, forms, passes=passes, clone=clone, sync=sync)
+                except Exception as e:           # (a library without the form)
+                    r = {"passed": False, "error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+                r["name"] = sname
+                soaks.append(r)
+                report(dict(event="end", name="soak:" + sname, **{k: v for k, v in r.items() if k != "name"}))
+                if r["passed"]:
+                    candidates = tuple(candidates) + tuple(c for c in CVT_CANDIDATES if key in c[2] and c not in candidates)
     only = [n for n in os.environ.get("BTS_TUNE_ONLY", "").split(",") if n]      # (tests: a subset of the candidates by name)
     if only:
         candidates = [c for c in candidates if c[1] in only]
@@ -205,7 +278,7 @@ def select_forms(make_tracker: Callable[[str], object], frames: Sequence[tuple],
                 if len(rescue) >= 3:
                     break
         return {"forms": "", "chosen": "default", "default_us": ref["us_per_step"], "chosen_us": ref["us_per_step"], "table": _strip(table),
-                "default_errors": ref["errors"], "rescue_candidates": rescue,
+                "default_errors": ref["errors"], "rescue_candidates": rescue, "soak": soaks,
                 "note": "the DEFAULT forms raised a device error on these frames: nothing selected (candidates that ran error-free are "
                         "listed in rescue_candidates; they are unverified and never adopted automatically)"}
 
@@ -274,7 +347,7 @@ def select_forms(make_tracker: Callable[[str], object], frames: Sequence[tuple],
     timed = ref.get("timed_steps", 0)
     return {"forms": chosen["forms"], "chosen": chosen["name"], "default_us": ref_us, "chosen_us": chosen["us_per_step"],
             "default_us_both": [ref["us_per_step"], ref_b["us_per_step"]], "noise_pct": 100.0 * noise, "needed_speedup": need,
-            "table": _strip(table), "frames": len(frames), "warm": warm, "timed_steps": timed, "repeats": repeats,
+            "table": _strip(table), "soak": soaks, "frames": len(frames), "warm": warm, "timed_steps": timed, "repeats": repeats,
             "thin": bool(timed < 100 and timed * ref_us < 25e3),
             "verified_frames": verify + 1, "margin": margin,
             "rule": "a candidate is eligible only if the digests of its verified frames (assignment vectors of the three stages, both "
