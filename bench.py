@@ -547,7 +547,7 @@ def main():
     opts = dict(appearance_mode=1 if a.dense else 0, use_graph=1 if a.graph else 0, motion_gate=1 if a.motion_gate else 0)
     FORM_KEYS = ("BTS_EDGES_SORTED", "BTS_EDGES_GRID", "BTS_LISTS_AHEAD", "BTS_MERGE_EARLY", "BTS_RENORM_FUSED", "BTS_CVT_OVERLAP", "BTS_PREDICT_FIRST",
                  "BTS_PREDICT_FRONT", "BTS_FILTER_GUESS", "BTS_LAP_FORM", "BTS_LAP_HELPERS", "BTS_CHUNK_ROWS", "BTS_FILTER_PW", "BTS_I8_FIRST16",
-                 "BTS_TILE_GOAL", "BTS_FILTER_ONEPASS", "BTS_SHADOW_PLANES", "BTS_LAP_SELF", "BTS_FILTER_TILE", "BTS_FILTER_AHEAD", "BTS_FILTER_AHEAD_PW")
+                 "BTS_TILE_GOAL", "BTS_FILTER_ONEPASS", "BTS_SHADOW_PLANES", "BTS_LAP_SELF", "BTS_FILTER_TILE", "BTS_FILTER_AHEAD", "BTS_FILTER_AHEAD_PW", "BTS_SMOOTH_DEFERRED")
     if a.forms == "auto" and any(k in os.environ for k in FORM_KEYS):
         a.forms = "env"                 # (forms given through the environment -- an A/B run -- are taken as they are: no selection)
     auto = a.forms == "auto" and S == 1 and not a.graph and not a.dense and not os.environ.get("BTS_BENCH_NO_TUNE") and not a.compare_forms
@@ -816,7 +816,9 @@ def main():
                        # (BTS_FILTER_AHEAD is a THROUGHPUT mode -- frame f's pre-filter runs on a side stream under step f-1 -- and is
                        #  named here whenever it is in effect: the figure then needs frames stepped back to back)
                        "launch": ("hipGraph replay" if a.graph else "eager") + (", pre-filter ahead on a side stream (BTS_FILTER_AHEAD)"
-                                                                                 if (guarded("forms", trk.forms) or {}).get("filter_ahead") == "1" else ""),
+                                                                                 if (guarded("forms", trk.forms) or {}).get("filter_ahead") == "1" else "")
+                                                                              + (", smooth EMA behind the step on a third stream (BTS_SMOOTH_DEFERRED)"
+                                                                                 if (guarded("forms", trk.forms) or {}).get("smooth_deferred") == "1" else ""),
                        "motion_gate": bool(a.motion_gate),
                        "spawn": "self-spawned ranks" if os.environ.get("BTS_BENCH_SPAWNED") else ("torch.distributed.run" if world > 1 else "single process"),
                        "oversubscribed": bool(world > ndev),

@@ -98,6 +98,19 @@ __device__ __forceinline__ float row_norm(const float *row, int d, bool active =
     return sqrtf(block_sum(ss));
 }
 
+// curr = f, nothing else (BTS_SMOOTH_DEFERRED: the smooth half of ema_row runs later, from curr).  No barriers.
+__device__ __forceinline__ void copy_row(float *curr, const float *f, int d, bool active = true) {
+    if (!active) return;
+    const int t = row_tid();
+    if (vec4_ok(curr, d) && vec4_ok(f, d)) {
+        const float4 *f4 = reinterpret_cast<const float4 *>(f);
+        float4 *c4 = reinterpret_cast<float4 *>(curr);
+        for (int k = t; k < d / 4; k += ROW_G) c4[k] = f4[k];
+    } else {
+        for (int k = t; k < d; k += ROW_G) curr[k] = f[k];
+    }
+}
+
 // curr = f ; smooth = normalise(has ? alpha*smooth + beta*f : f)
 __device__ __forceinline__ void ema_row(float *curr, float *smooth, const float *f, int d, bool has, float alpha,
                                         float beta, bool active = true) {

@@ -95,6 +95,11 @@ struct Dev {
     // and pool row i finds its bitmap row in pool_cbrow[i] (written with the pool list by tk_finalize); nullptr = bitmap row i
     int32_t fahead;
     int32_t *pool_cbrow;
+    // BTS_SMOOTH_DEFERRED=1 at create (with BTS_FILTER_AHEAD): a step writes a rewritten track's `curr` row only and marks the slot
+    // (1: update with a previous feature, 2: update without, 3: newborn); tk_smooth, on a third stream behind the step, brings the
+    // `smooth` row up to date from `curr` -- nothing in a step reads `smooth` (the matcher reads `curr`, Q1)
+    int32_t smooth_def;
+    uint8_t *ema_pending;
     float gate_sim;                                    // the similarity the appearance term must reach: 1 - appearance_thresh
     int sf32;                                          // kalman_dtype BTS_F32: mean / cov hold float32 elements (same rows, half the bytes)
     int c16;                                           // cost_dtype BTS_F16: association costs rounded to binary16 before thresholds and the solver
@@ -2329,6 +2334,10 @@ __device__ __forceinline__ void apply_body(const Dev &d, int bid) {
             }
             __syncthreads();                 // (the record: copy_shadow below reads it with other threads)
         }
+        if (d.smooth_def) {      // (body features only: the form is ruled out with face features)
+            feat::copy_row(d.body_curr + s * d.D, IN(d, feats) + det * d.D, d.D);
+            if (threadIdx.x == 0) d.ema_pending[s] = d.has_body[s] != 0 ? 1 : 2;
+        } else
         feat::ema_row(d.body_curr + s * d.D, d.body_smooth + s * d.D, IN(d, feats) + det * d.D, d.D, d.has_body[s] != 0, d.ema_a, d.ema_b);
         if (d.Df)
             feat::ema_row(d.face_curr + s * d.Df, d.face_smooth + s * d.Df, IN(d, face_feats) + det * d.Df, d.Df, d.has_face[s] != 0, d.ema_a, d.ema_b);
@@ -2384,6 +2393,10 @@ __device__ __forceinline__ void apply_feat4(const Dev &d, int bid) {
     const int r = xq < m ? ys[xq] : -1;
     const bool on = r >= 0 && r < n;
     const long s = on ? rslot[r] : 0, det = on ? cdet[xq] : 0;
+    if (d.smooth_def) {
+        feat::copy_row(d.body_curr + s * d.D, IN(d, feats) + det * d.D, d.D, on);
+        if (on && feat::row_tid() == 0) d.ema_pending[s] = d.has_body[s] != 0 ? 1 : 2;
+    } else
     feat::ema_row(d.body_curr + s * d.D, d.body_smooth + s * d.D, IN(d, feats) + det * d.D, d.D, on && d.has_body[s] != 0, d.ema_a, d.ema_b, on);
     if (d.Df)
         feat::ema_row(d.face_curr + s * d.Df, d.face_smooth + s * d.Df, IN(d, face_feats) + det * d.Df, d.Df, on && d.has_face[s] != 0, d.ema_a, d.ema_b, on);
@@ -2644,8 +2657,10 @@ __device__ __forceinline__ void birth_body(const Dev &d, int k) {
     // the detection row was renormalised in place; curr and smooth alias it in the reference
     for (int c = threadIdx.x; c < d.D; c += blockDim.x) {
         const float v = IN(d, feats)[det * d.D + c];
-        d.body_curr[s * d.D + c] = v; d.body_smooth[s * d.D + c] = v;
+        d.body_curr[s * d.D + c] = v;
+        if (!d.smooth_def) d.body_smooth[s * d.D + c] = v;
     }
+    if (d.smooth_def && threadIdx.x == 0) d.ema_pending[s] = 3;
     for (int c = threadIdx.x; c < d.Df; c += blockDim.x) {
         const float v = IN(d, face_feats)[det * d.Df + c];
         d.face_curr[s * d.Df + c] = v; d.face_smooth[s * d.Df + c] = v;
@@ -2822,12 +2837,27 @@ template <bool CH, bool AHEAD> __global__ __launch_bounds__(1024) void tk_finali
     if (ch == nch - 1) TJ_END(3, job);
 }
 
+// BTS_SMOOTH_DEFERRED: the `smooth` rows of the slots the step just rewrote, from their `curr` rows -- the row ema_row blended is
+// bit for bit the row it stored in `curr`, so this is ema_row's own arithmetic, later.  One 256-thread workgroup per table slot;
+// most exit on the mark.  Runs on the tracker's third stream, behind "the step is done", in front of the next step's first apply.
+__global__ __launch_bounds__(256) void tk_smooth(Dev d) {
+    const long s = blockIdx.x;
+    const int p = d.ema_pending[s];                   // (uniform over the workgroup)
+    if (p == 0) return;
+    float *curr = d.body_curr + s * d.D, *smooth = d.body_smooth + s * d.D;
+    if (p == 3) feat::copy_row(smooth, curr, d.D);                               // newborn: smooth aliases curr in the reference (D:556-568)
+    else feat::ema_row(curr, smooth, curr, d.D, p == 1, d.ema_a, d.ema_b);       // (rewrites curr with itself)
+    __syncthreads();                                  // every thread has read the mark before it is cleared
+    if (threadIdx.x == 0) d.ema_pending[s] = 0;
+}
+
 __global__ __launch_bounds__(1024) void tk_reset(Dev d) {
     const int tid = threadIdx.x, nth = blockDim.x;
     for (int s = tid; s < d.T; s += nth) {
         d.free_list[s] = s; d.in_use[s] = 0; d.in_removed[s] = 0; d.f32[s] = 0; d.state[s] = BTS_NEW;
         d.drop_t[s] = 0; d.drop_l[s] = 0;
         d.is_activated[s] = 0; d.track_id[s] = 0; d.has_body[s] = 0; d.has_face[s] = 0;
+        if (d.ema_pending) d.ema_pending[s] = 0;
     }
     for (int k = tid; k < H_SIZE; k += nth) d.hdr[k] = 0;
     for (int k = tid; k < J_COUNT * bscan::CHUNK_MAX; k += nth) d.agg[k] = 0ull;
@@ -2955,6 +2985,9 @@ struct bts_tracker {
     int32_t *fstat_b = nullptr;   // [2][16] pre-filter counters of the side passes
     int32_t *iota = nullptr;      // 0, 1, 2, ...: the identity "list" of the side passes' rows
     int mc_prev = 0;              // detections of the previous step (rows of the det x det pass)
+    hipStream_t side2 = nullptr;  // BTS_SMOOTH_DEFERRED: tk_smooth's stream
+    hipEvent_t ev_smooth[2] = {};
+    bool ev_smooth_used[2] = {};
     int filter_ahead_pw = 0;      // BTS_FILTER_AHEAD_PW: persistent workgroups per side pass.  Default 256 = one per CU: a pre-filter wave holds
                                   // ~244 VGPRs, two of them close a SIMD to everything else -- with one per SIMD the step's own kernels keep
                                   // half of every register file while the side passes run (unmeasured; 384 / 512 are tune candidates)
@@ -3043,6 +3076,7 @@ static void tracker_layout(bts_tracker *t, char *base, size_t &off) {
             SLOT(t->hi_b[0], int32_t, M); SLOT(t->hi_b[1], int32_t, M);
             SLOT(t->shdr, int32_t, 4 * H_SIZE); SLOT(t->fstat_b, int32_t, 2 * 16);
             SLOT(t->iota, int32_t, T > M ? T : M); SLOT(d.pool_cbrow, int32_t, T);
+            if (d.smooth_def) SLOT(d.ema_pending, uint8_t, T);
         }
         if (d.sorted) {
             const size_t slots = (size_t)bts_cdiv((int)T, FBM) * (size_t)bts_cdiv((int)M, FBN) * 4;
@@ -3114,6 +3148,8 @@ static int derive_sizes(const bts_tracker_config *cfg, Dev &d, int64_t *e_cap_ou
     // bitmap rows for is the one tk_finalize builds (it implies BTS_LISTS_AHEAD; create adds BTS_PREDICT_FRONT and the side stream)
     d.fahead = (bts_form_flag("BTS_FILTER_AHEAD") && d.filter && d.Df == 0 && !d.sorted && !cfg->use_graph && !cfg->record_costs) ? 1 : 0;
     if (d.fahead) d.ahead = 1;
+    // BTS_SMOOTH_DEFERRED=1 (read at create; needs BTS_FILTER_AHEAD's streams): the `smooth` EMA of the rewritten tracks leaves the step
+    d.smooth_def = (bts_form_flag("BTS_SMOOTH_DEFERRED") && d.fahead) ? 1 : 0;
     // BTS_MERGE_EARLY=1 (read at create): tk_merge's jobs in the launch of tk_apply23 (tk_apply23_merge)
     d.merge_early = bts_form_flag("BTS_MERGE_EARLY") ? 1 : 0;
     d.renorm_fused = bts_form_flag("BTS_RENORM_FUSED") ? 1 : 0;
@@ -3252,11 +3288,11 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
     // the forms in effect (a requested form that the configuration rules out -- the sorted edges with a motion gate, say --
     // does not appear), for bts_tracker_forms
     snprintf(t->forms, sizeof(t->forms), "edges=%s,lists_ahead=%d,merge_early=%d,renorm_fused=%d,cvt_overlap=%d,predict_front=%d,predict_first=%d,lap_form=%s,lap_helpers=%d,list_chunks=%d,"
-             "filter_pw=%d,filter_first16=%d,filter_onepass=%d,filter_guess=%d,shadow_planes=%d,tile_goal=%d,lap_self=%d,filter_tile=%s,filter_ahead=%d",
+             "filter_pw=%d,filter_first16=%d,filter_onepass=%d,filter_guess=%d,shadow_planes=%d,tile_goal=%d,lap_self=%d,filter_tile=%s,filter_ahead=%d,smooth_deferred=%d",
              d.sorted ? "sorted" : (d.use_grid && d.filter) ? "grid" : "tiles", d.ahead, d.merge_early, d.renorm_fused, t->cvt_overlap ? 1 : 0, t->predict_front ? 1 : 0, t->predict_first ? 1 : 0,
              t->lap_form == 1 ? "row" : "col", t->lap_helpers, d.nch, t->filter_pw > 0 ? t->filter_pw : (t->filter_tile == 2 ? 768 : FILTER_PW), d.chk_first,
              t->onepass ? 1 : 0, d.f_guess, d.sh_planes, t->tile_goal, lap_self_slices(d) > 0 ? 1 : 0,
-             t->filter_tile == 1 ? "160x128" : t->filter_tile == 2 ? "128x64" : t->filter_tile == 3 ? "128x128t" : "128x128", d.fahead);
+             t->filter_tile == 1 ? "160x128" : t->filter_tile == 2 ? "128x64" : t->filter_tile == 3 ? "128x128t" : "128x128", d.fahead, d.smooth_def);
     size_t off = 0;
     tracker_layout(t, nullptr, off);
     const int64_t o_cap = (cfg->tie_mode && d.Df > 0) ? e_cap : 0;      // overrides of the exact-tie step (tk_edges_xo): their own region
@@ -3373,6 +3409,12 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
             ok = hipEventCreateWithFlags(&t->ev_cvt[k], hipEventDisableTiming) == hipSuccess &&
                  hipEventCreateWithFlags(&t->ev_done[k], hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&t->ev_in, hipEventDisableTiming) == hipSuccess;
+        if (t->dv.smooth_def) {
+            int least = 0, greatest = 0;
+            ok = ok && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess &&
+                 hipStreamCreateWithPriority(&t->side2, hipStreamNonBlocking, least) == hipSuccess;
+            for (int k = 0; ok && k < 2; ++k) ok = hipEventCreateWithFlags(&t->ev_smooth[k], hipEventDisableTiming) == hipSuccess;
+        }
     }
     if (!ok) { (void)hipGetLastError(); bts_set_error("stream / event / descriptor allocation failed"); bts_tracker_destroy(t); return BTS_EHIP; }
     t->dv.in = nullptr;
@@ -3480,6 +3522,8 @@ int bts_tracker_destroy(bts_tracker *t) {
     for (int k = 0; k < bts_tracker::RING; ++k) if (t->in_ev[k]) (void)hipEventDestroy(t->in_ev[k]);
     if (t->cs[0]) (void)hipStreamDestroy(t->cs[0]);
     if (t->side) { (void)hipStreamSynchronize(t->side); (void)hipStreamDestroy(t->side); }
+    if (t->side2) { (void)hipStreamSynchronize(t->side2); (void)hipStreamDestroy(t->side2); }
+    for (int k = 0; k < 2; ++k) if (t->ev_smooth[k]) (void)hipEventDestroy(t->ev_smooth[k]);
     for (int k = 0; k < 2; ++k) { if (t->ev_cvt[k]) (void)hipEventDestroy(t->ev_cvt[k]); if (t->ev_done[k]) (void)hipEventDestroy(t->ev_done[k]); }
     if (t->ev_in) (void)hipEventDestroy(t->ev_in);
     if (t->d_in) (void)hipFree(t->d_in);
@@ -3780,6 +3824,9 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
                              d.sim, M, s);
         if (rc) return rc;
     }
+    // (BTS_SMOOTH_DEFERRED: the previous step's tk_smooth reads the `curr` rows this step's applications are about to overwrite; it
+    //  has had the whole front of this step to run on its own stream)
+    if (fa && d.smooth_def && t->ev_smooth_used[ovp ^ 1]) BTS_HIP(hipStreamWaitEvent(s, t->ev_smooth[ovp ^ 1], 0));
     // stage-1 Kalman updates + stage-1 feature rows + cost tiles of stages 2 and 3: disjoint tracks, one launch
     seg_begin(BTS_SEG_K_MID2);
     {
@@ -3840,6 +3887,13 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
     seg_end(BTS_SEG_STEP);
     if (ov) { BTS_HIP(hipEventRecord(t->ev_done[ovp], s)); t->ev_done_used[ovp] = true; }
     if (fa) t->mc_prev = mc;
+    if (fa && d.smooth_def) {
+        // the `smooth` rows of what this step rewrote, behind the step, on the third stream (one workgroup per table slot; see tk_smooth)
+        BTS_HIP(hipStreamWaitEvent(t->side2, t->ev_done[ovp], 0));
+        hipLaunchKernelGGL(tk_smooth, dim3(T), dim3(256), 0, t->side2, d); BTS_LAUNCH_CHECK();
+        BTS_HIP(hipEventRecord(t->ev_smooth[ovp], t->side2));
+        t->ev_smooth_used[ovp] = true;
+    }
 #undef LAUNCH
 #undef LAUNCH_ON
     return BTS_OK;
@@ -4007,11 +4061,21 @@ int bts_tracker_export_mot_async(bts_tracker *t, double *rows_pinned, int32_t *n
     return BTS_OK;
 }
 
+// BTS_SMOOTH_DEFERRED: whoever reads `smooth` rows on `stream` is ordered behind the latest tk_smooth (the step enqueued it on the
+// tracker's third stream right behind itself)
+static int wait_for_smooth(bts_tracker *t, hipStream_t stream) {
+    if (!t->dv.smooth_def || t->step_no == 0) return BTS_OK;
+    const int last = (int)((t->step_no - 1) & 1);
+    if (t->ev_smooth_used[last]) BTS_HIP(hipStreamWaitEvent(stream, t->ev_smooth[last], 0));
+    return BTS_OK;
+}
+
 int bts_tracker_export_state(bts_tracker *t, int which, double *cov_host, float *body_curr_host, float *body_smooth_host,
                              float *face_curr_host, float *face_smooth_host, bts_stream stream) {
     BTS_REQUIRE(t && (which == 0 || which == 1), "tracker, which");
     BTS_ON_DEVICE(t->ctx);
     hipStream_t s = (hipStream_t)stream;
+    if (int rc = wait_for_smooth(t, s)) return rc;
     BTS_HIP(hipMemcpyAsync(t->host_hdr, t->dv.hdr, H_SIZE * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     BTS_HIP(hipStreamSynchronize(s));
     if (int rc = device_error_status(t)) return rc;
@@ -4049,6 +4113,7 @@ int bts_tracker_read_slot(bts_tracker *t, int slot, int field, void *out_host, b
         return BTS_OK;
     }
     BTS_REQUIRE(field < 4 || d.Df > 0, "the tracker carries no face features");
+    if (int rc = wait_for_smooth(t, (hipStream_t)stream)) return rc;
     if (d.sf32 && field <= 1) {       // float32 state rows: widened on the host (the call's contract is float64)
         const int cnt = field == 0 ? 8 : 64;
         float tmp[64];

@@ -79,6 +79,9 @@ CVT_CANDIDATES: Tuple[Tuple[str, str, Dict[str, str]], ...] = (
     ("lists_ahead", "filter_ahead_merge_early", {"BTS_FILTER_AHEAD": "1", "BTS_MERGE_EARLY": "1"}),
     ("lists_ahead", "filter_ahead_pw_384", {"BTS_FILTER_AHEAD": "1", "BTS_FILTER_AHEAD_PW": "384"}),      # (default: 256 side workgroups, one per CU)
     ("lists_ahead", "filter_ahead_pw_512", {"BTS_FILTER_AHEAD": "1", "BTS_FILTER_AHEAD_PW": "512"}),
+    # + the `smooth` EMA of the rewritten tracks on a third stream behind the step (half of tk_mid2's bytes leave the step's stream)
+    ("lists_ahead", "filter_ahead_smooth", {"BTS_FILTER_AHEAD": "1", "BTS_SMOOTH_DEFERRED": "1"}),
+    ("lists_ahead", "filter_ahead_smooth_merge_early", {"BTS_FILTER_AHEAD": "1", "BTS_SMOOTH_DEFERRED": "1", "BTS_MERGE_EARLY": "1"}),
 )
 
 
@@ -87,6 +90,7 @@ CVT_CANDIDATES: Tuple[Tuple[str, str, Dict[str, str]], ...] = (
 SOAK_FORMS: Tuple[Tuple[str, str, Dict[str, str]], ...] = (
     ("cvt_overlap", "BTS_CVT_OVERLAP", {"BTS_CVT_OVERLAP": "1", "BTS_LISTS_AHEAD": "1"}),
     ("filter_ahead", "BTS_FILTER_AHEAD", {"BTS_FILTER_AHEAD": "1"}),
+    ("smooth_deferred", "BTS_SMOOTH_DEFERRED", {"BTS_FILTER_AHEAD": "1", "BTS_SMOOTH_DEFERRED": "1"}),
 )
 
 
@@ -235,8 +239,10 @@ def select_forms(make_tracker: Callable[[str], object], frames: Sequence[tuple],
                 r["name"] = sname
                 soaks.append(r)
                 report(dict(event="end", name="soak:" + sname, **{k: v for k, v in r.items() if k != "name"}))
-                if r["passed"]:
-                    candidates = tuple(candidates) + tuple(c for c in CVT_CANDIDATES if key in c[2] and c not in candidates)
+            # a gated candidate is offered iff EVERY side-stream key it uses has passed its soak
+            passed = {key for (sname, key, _), r in zip(SOAK_FORMS, soaks) if r.get("passed")}
+            keys = {key for _, key, _ in SOAK_FORMS}
+            candidates = tuple(candidates) + tuple(c for c in CVT_CANDIDATES if (keys & set(c[2])) and (keys & set(c[2])) <= passed and c not in candidates)
     only = [n for n in os.environ.get("BTS_TUNE_ONLY", "").split(",") if n]      # (tests: a subset of the candidates by name)
     if only:
         candidates = [c for c in candidates if c[1] in only]

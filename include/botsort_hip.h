@@ -309,6 +309,10 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
  *                        launch.  Pays only when the caller enqueues steps back to back and has promised residency
  *                        (bts_tracker_inputs_resident); results are identical either way.  BTS_FILTER_AHEAD_PW=n: persistent
  *                        workgroups per side pass (default 256: one per CU)
+ *   BTS_SMOOTH_DEFERRED=1  (with BTS_FILTER_AHEAD) a step writes a rewritten track's `curr` feature row only; the `smooth` EMA row --
+ *                        which nothing in a step reads -- is brought up to date by a kernel on a third stream behind the step, in
+ *                        front of the next step's first feature write.  bts_tracker_export_state / bts_tracker_read_slot are
+ *                        ordered behind it.  Same arithmetic on the same values, later
  *   BTS_I8_FIRST16=k     first prefix checkpoint of the pre-filter, in sixteenths of the feature width (3..12)
  *   BTS_TILE_GOAL=n      workgroup count the stage-1 tile height aims at (default 768)
  * None of them changes a result (tests/test_zz_gpu_round4.py, test_zz_gpu_round5.py: identical assignment indices, lists and state per frame);

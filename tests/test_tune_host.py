@@ -116,7 +116,7 @@ def test_cvt_overlap_is_not_offered_before_its_soak(monkeypatch):
     monkeypatch.delenv("BTS_TUNE_ALLOW_CVT")
     monkeypatch.setenv("BTS_TUNE_SOAK_PASSES", "8")              # the selection's own soak: 8 passes x 12 frames, both forms pass
     r = _select(cost, monkeypatch)
-    assert [(x["name"], x["passed"], x["steps"]) for x in r["soak"]] == [("cvt_overlap", True, 96), ("filter_ahead", True, 96)]
+    assert [(x["name"], x["passed"], x["steps"]) for x in r["soak"]] == [("cvt_overlap", True, 96), ("filter_ahead", True, 96), ("smooth_deferred", True, 96)]
     assert "BTS_FILTER_AHEAD=1" in r["forms"]
     r = _select(cost, monkeypatch, late_wrong=("BTS_FILTER_AHEAD",))      # diverges at step 41: the soak sees it, twelve frames would not
     by = {x["name"]: x for x in r["soak"]}
@@ -125,7 +125,8 @@ def test_cvt_overlap_is_not_offered_before_its_soak(monkeypatch):
     assert not any("FILTER_AHEAD" in m.get("forms", "") for m in r["table"])
     r = tune.select_forms(lambda forms: _Double(forms, cost), [(None, None, None)] * 12, warm=4, verify=3, repeats=1, clone=lambda fr: fr,
                           sync=lambda: None, skip=["soak:filter_ahead"])                # (blamed for a crash on an earlier attempt: skipped)
-    assert {x["name"]: x.get("skipped", False) for x in r["soak"]} == {"cvt_overlap": False, "filter_ahead": True} and "FILTER_AHEAD" not in r["forms"]
+    assert {x["name"]: x.get("skipped", False) for x in r["soak"]} == {"cvt_overlap": False, "filter_ahead": True, "smooth_deferred": False}
+    assert "FILTER_AHEAD" not in r["forms"]           # (the smooth variant uses BTS_FILTER_AHEAD too: every key it uses has to have passed)
 
 
 def test_a_candidate_inside_the_noise_floor_is_no_difference(monkeypatch):
@@ -275,6 +276,6 @@ print(json.dumps(out))
     r = subprocess.run([sys.executable, "-c", code], cwd=REPO, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads(r.stdout.strip().splitlines()[-1])
-    assert [o["forms"] for o in out] == ["BTS_CVT_OVERLAP=1,BTS_LISTS_AHEAD=1", "BTS_FILTER_AHEAD=1"]
+    assert [o["forms"] for o in out] == ["BTS_CVT_OVERLAP=1,BTS_LISTS_AHEAD=1", "BTS_FILTER_AHEAD=1", "BTS_FILTER_AHEAD=1,BTS_SMOOTH_DEFERRED=1"]
     for o in out:
         assert o["passed"] and o["steps"] == 16 and o["digests"] == 4 and o["mismatch_at"] == [] and o["errors"] == [0, 0] and o["state_equal"], o

@@ -167,15 +167,18 @@ def test_filter_ahead_at_4224x2048x256_with_churn(bts):
     ref.close(); exp.close()
 
 
+@pytest.mark.parametrize("smooth", [0, 1])
 @pytest.mark.parametrize("resident", [True, False])
-def test_filter_ahead_without_host_synchronisation_between_steps(bts, resident):
+def test_filter_ahead_without_host_synchronisation_between_steps(bts, resident, smooth):
     """24 frames of the appearance-only stream stepped back to back, digests compared with the default forms' every sixth frame
     only: on a GPU the side passes of frame f really run under step f-1's kernels.  Without the residency promise the side stream is
     ordered behind the caller's stream at every step (correct, no overlap).  On the CPU emulation this test is also run under
-    HIPEMU_STREAMS=sidelate / mainlate with fault injection (tests/test_emu_gpu_subset.py)."""
+    HIPEMU_STREAMS=sidelate / mainlate with fault injection (tests/test_emu_gpu_subset.py).  The final state digest covers the
+    covariances and the `curr` / `smooth` feature rows of both lists."""
     tune = importlib.import_module("bot-sort-onnx-tensorrt_amd.tune")
     K, D = 96, 128
-    ref, exp = _pair(bts, K + 64, K, D)
+    ref, exp = _pair(bts, K + 64, K, D, extra={"BTS_SMOOTH_DEFERRED": smooth})      # (smooth = 1: + the `smooth` EMA on the third stream)
+    assert exp.forms()["smooth_deferred"] == str(smooth)
     exp.inputs_resident(resident)
     st = Flicker(K, D, 31, visible=0.75)
     frames = [_dev(st.next()) for _ in range(24)]
@@ -266,4 +269,32 @@ def test_filter_ahead_edge_frames_reset_and_gmc(bts):
     ora = bo.TrackerOracle()
     for n, (b, s, ids) in enumerate(frames[1:6]):
         frame(b, s, ids, 200 + n)
+    ref.close(); exp.close()
+
+
+def test_smooth_deferred_rows_equal_the_default_forms_every_frame(bts):
+    """BTS_SMOOTH_DEFERRED (with BTS_FILTER_AHEAD): a step writes a rewritten track's `curr` row only; tk_smooth, on a third stream
+    behind the step, recomputes `smooth = normalise(alpha smooth + beta curr)` (newborn: smooth = curr) -- ema_row's own arithmetic on
+    the row it stored.  After EVERY frame of a stream with births, re-found tracks and low-score matches the exported covariances,
+    `curr` and `smooth` rows of both lists are bit-identical to the default forms' (the export is ordered behind tk_smooth), as are
+    indices, lists and means; also across a reset."""
+    K, M, D = 96, 64, 256
+    ref, exp = _pair(bts, 192, 96, D, extra={"BTS_SMOOTH_DEFERRED": 1, "BTS_MERGE_EARLY": 1})
+    assert exp.forms()["smooth_deferred"] == "1" and ref.forms()["smooth_deferred"] == "0"
+    st = bts.synth.SyntheticStream(K, M, D, seed=17, churn=0.15)
+    for f in range(12):
+        if f == 8:
+            ref.reset(); exp.reset()
+            st = bts.synth.SyntheticStream(K, M, D, seed=18, churn=0.15)
+        fr = st.next()
+        ref.step(*_dev(fr)); exp.step(*_dev(fr))
+        _same_frame(ref, exp, f)
+        for which in (0, 1):
+            a, b = ref.export_state(which, cov=True, body=True, face=False), exp.export_state(which, cov=True, body=True, face=False)
+            for key in ("covariance", "body_curr_feature", "body_smooth_feature"):
+                assert a[key].shape == b[key].shape and np.array_equal(a[key], b[key]), (f, which, key)
+        assert exp.counts()["errors"] == 0
+    t = bts.DeviceTracker(max_tracks=64, max_dets=32, feat_dim=128, forms={"BTS_SMOOTH_DEFERRED": 1})       # needs the ahead mode's streams
+    assert t.forms()["smooth_deferred"] == "0"
+    t.close()
     ref.close(); exp.close()
