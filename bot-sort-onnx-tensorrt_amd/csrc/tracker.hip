@@ -100,6 +100,12 @@ struct Dev {
     // `smooth` row up to date from `curr` -- nothing in a step reads `smooth` (the matcher reads `curr`, Q1)
     int32_t smooth_def;
     uint8_t *ema_pending;
+    // BTS_EDGES_SORTED together with BTS_FILTER_AHEAD: the candidate LISTS of the two side passes sit one behind the other (fa_mt main
+    // tiles, then fa_dt det x det tiles, four slots each; the det x det region starts at slot fa_dd_slot0) and name rows by table slot /
+    // previous-frame detection; the candidate wavefronts translate them to pool rows through pool_of_slot / pool_of_pdet (written
+    // with pool_cbrow by tk_finalize, validated by reading pool_cbrow back: a stale entry is never taken for a membership)
+    int32_t fa_mt, fa_dt, fa_dd_slot0, fa_nprev;
+    int32_t *pool_of_slot, *pool_of_pdet;
     float gate_sim;                                    // the similarity the appearance term must reach: 1 - appearance_thresh
     int sf32;                                          // kalman_dtype BTS_F32: mean / cov hold float32 elements (same rows, half the bytes)
     int c16;                                           // cost_dtype BTS_F16: association costs rounded to binary16 before thresholds and the solver
@@ -2115,7 +2121,10 @@ __device__ __forceinline__ void edges_tile_sorted(const Dev &d, const bts_lap_wo
         for (int k0 = 0; k0 < SE_EB / 64; ++k0) {
             const int k = k0 * 64 + lane;
             bool kp = false;
-            if (k < wcount) kp = !((d.cbits[(long)S.r[wid][k] * d.cb_ld + (S.q[wid][k] >> 5)] >> (S.q[wid][k] & 31)) & 1u);
+            if (k < wcount) {
+                const long brow = d.pool_cbrow ? (long)d.pool_cbrow[S.r[wid][k]] : (long)S.r[wid][k];      // (BTS_FILTER_AHEAD: by slot / previous detection)
+                kp = !((d.cbits[brow * d.cb_ld + (S.q[wid][k] >> 5)] >> (S.q[wid][k] & 31)) & 1u);
+            }
             keep[k0] = __ballot(kp);
             kept += __popcll(keep[k0]);
         }
@@ -2199,7 +2208,8 @@ __device__ __forceinline__ void cand_all(const Dev &d, const bts_lap_work &w, in
     const int32_t *h = d.hdr;
     const int n = h[H_NPOOL], m = h[H_NHI];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int nslots = d.f_ntiles * 4, nbn = (d.f_mc + FBN - 1) / FBN;
+    const bool fa = d.pool_of_slot != nullptr;               // BTS_FILTER_AHEAD: two lists, rows named by slot / previous detection
+    const int nslots = (fa ? d.fa_mt + d.fa_dt : d.f_ntiles) * 4, nbn = (d.f_mc + FBN - 1) / FBN;
     int wcount = 0;
     auto flush = [&]() {
         if (wcount == 0) return;
@@ -2213,7 +2223,15 @@ __device__ __forceinline__ void cand_all(const Dev &d, const bts_lap_work &w, in
         }
         wcount = 0;
     };
+    // (ahead form) a side pass's row -> the pool row that reads it, or -1: the track is not in this frame's pool, or its bitmap row is
+    // of the other kind (a slot the previous step rewrote / a detection nobody absorbed)
+    auto pool_row = [&](int pass, int i) {
+        if (!fa) return i;
+        const int r = pass ? d.pool_of_pdet[i] : d.pool_of_slot[i];
+        return ((unsigned)r < (unsigned)n && d.pool_cbrow[r] == (pass ? d.T + i : i)) ? r : -1;
+    };
     auto pair = [&](int i, int q) {                           // convergent
+        if (i < 0) return;
         double c;
         const bool edge = cand_pair(d, i, q, lane, c);
         if (edge) {
@@ -2224,27 +2242,32 @@ __device__ __forceinline__ void cand_all(const Dev &d, const bts_lap_work &w, in
             __builtin_amdgcn_wave_barrier();
         }
     };
-    for (int s = bid * (CT_COLS / 64) + wid; s < nslots; s += nblk * (CT_COLS / 64)) {
-        const int cnt = __builtin_amdgcn_readfirstlane(d.cand_cnt[s]);
+    for (int sv = bid * (CT_COLS / 64) + wid; sv < nslots; sv += nblk * (CT_COLS / 64)) {
+        // (ahead form: virtual slot sv -> the pass it belongs to, its slot inside that pass's list, the list's place in memory)
+        const int pass = (fa && sv >= d.fa_mt * 4) ? 1 : 0;
+        const int s = pass ? sv - d.fa_mt * 4 : sv, sm = pass ? d.fa_dd_slot0 + s : s;
+        const int cnt = __builtin_amdgcn_readfirstlane(d.cand_cnt[sm]);
         if (cnt == 0) continue;
         if (cnt > 0) {
-            const int2 mine = lane < cnt ? d.cand[(long)s * CAND_W + lane] : make_int2(0, 0);
-            for (int e = 0; e < cnt; ++e) pair(__shfl(mine.x, e), __shfl(mine.y, e));
+            const int2 mine = lane < cnt ? d.cand[(long)sm * CAND_W + lane] : make_int2(0, 0);
+            for (int e = 0; e < cnt; ++e) pair(pool_row(pass, __shfl(mine.x, e)), __shfl(mine.y, e));
         } else {
             // the slot overflowed: sweep the quadrant's 64 bitmap words (64 rows x the one aligned 8-byte word of its 64 columns)
-            const int vb = xcd_remap(s >> 2, d.f_ntiles), bm = vb / nbn, bn = vb % nbn, wr = (s & 3) >> 1, wc = s & 1;
+            const int ntl = !fa ? d.f_ntiles : pass ? d.fa_dt : d.fa_mt, nrow = !fa ? n : pass ? d.fa_nprev : d.T;
+            const int vb = xcd_remap(s >> 2, ntl), bm = vb / nbn, bn = vb % nbn, wr = (s & 3) >> 1, wc = s & 1;
             const int row = bm * FBM + wr * 64 + lane, col0 = bn * FBN + wc * 64;
             unsigned long long word = 0ull;
-            if (row < n && col0 < d.Mx) word = *reinterpret_cast<const unsigned long long *>(&d.cbits[(long)row * d.cb_ld + (col0 >> 5)]);
+            if (row < nrow && col0 < d.Mx) word = *reinterpret_cast<const unsigned long long *>(&d.cbits[(long)((pass ? d.T : 0) + row) * d.cb_ld + (col0 >> 5)]);
             unsigned long long any = __ballot(word != 0ull);
             while (any) {
                 const int src = __ffsll((long long)any) - 1;
                 any &= any - 1;
                 unsigned long long bits = ((unsigned long long)(unsigned)__shfl((int)(word >> 32), src) << 32) | (unsigned)__shfl((int)word, src);
+                const int prow = pool_row(pass, bm * FBM + wr * 64 + src);         // (wave-uniform: one row per step)
                 while (bits) {
                     const int b = __ffsll((long long)bits) - 1;
                     bits &= bits - 1;
-                    if (col0 + b < m) pair(bm * FBM + wr * 64 + src, col0 + b);
+                    if (col0 + b < m) pair(prow, col0 + b);
                 }
             }
         }
@@ -2769,10 +2792,17 @@ template <bool CH> __device__ __forceinline__ void ahead_body(const Dev &d, int 
         // stable since before this frame began: row `slot` of the main pass
         const int fr = h[H_FRAME];
         auto cbrow = [&](int s) { return d.frame_id[s] == fr ? d.T + d.det_index[s] : s; };
+        // (+ the sorted edges: the reverse maps its candidate wavefronts translate the side passes' rows with)
+        auto put = [&](int p, int s) {
+            if (!d.pool_cbrow) return;
+            const int cb = cbrow(s);
+            d.pool_cbrow[p] = cb;
+            if (d.pool_of_slot) { if (cb >= d.T) d.pool_of_pdet[cb - d.T] = p; else d.pool_of_slot[s] = p; }
+        };
         job_compact<CH>(ca, nt2, tmp, [&](int k) { return tracked2_at(d, k); }, [&](int k, int s) { return !d.drop_t[k] && d.is_activated[s] != 0; },
-                        [&](int p, int k, int s) { d.pool_slot[p] = s; if (d.pool_cbrow) d.pool_cbrow[p] = cbrow(s); }, f64 != 0, true, &nconf, &any64);
+                        [&](int p, int k, int s) { d.pool_slot[p] = s; put(p, s); }, f64 != 0, true, &nconf, &any64);
         const int nl = job_compact<CH>(cb, nl2, tmp, [&](int k) { return lost2_at(d, k); }, [&](int k, int s) { return !d.drop_l[k]; },
-                                       [&](int p, int k, int s) { d.pool_slot[nconf + p] = s; if (d.pool_cbrow) d.pool_cbrow[nconf + p] = cbrow(s); });
+                                       [&](int p, int k, int s) { d.pool_slot[nconf + p] = s; put(nconf + p, s); });
         if (last && tid == 0) {
             const int N = nconf + nl;
             h[H_NPOOL_N] = N; h[H_NCONF_N] = nconf;
@@ -3030,6 +3060,11 @@ static size_t take(size_t &off, size_t bytes) {
 static size_t take(size_t &off, size_t bytes) { const size_t o = off; off = bts_align(off + bytes); return o; }
 #endif
 
+// slots of the sorted form's candidate list(s): four per pre-filter tile; with BTS_FILTER_AHEAD the main pass's tiles (all table
+// slots) and the det x det pass's, per shadow buffer
+static size_t cand_slots_main(const Dev &d) { return (size_t)bts_cdiv(d.T, FBM) * (size_t)bts_cdiv(d.Mx, FBN) * 4; }
+static size_t cand_slots(const Dev &d) { return cand_slots_main(d) + (d.fahead ? (size_t)bts_cdiv(d.Mx, FBM) * (size_t)bts_cdiv(d.Mx, FBN) * 4 : 0); }
+
 static void tracker_layout(bts_tracker *t, char *base, size_t &off) {
     Dev &d = t->dv;
     const size_t T = d.T, M = d.Mx, D = d.D, Df = d.Df ? d.Df : 1;
@@ -3079,8 +3114,10 @@ static void tracker_layout(bts_tracker *t, char *base, size_t &off) {
             if (d.smooth_def) SLOT(d.ema_pending, uint8_t, T);
         }
         if (d.sorted) {
-            const size_t slots = (size_t)bts_cdiv((int)T, FBM) * (size_t)bts_cdiv((int)M, FBN) * 4;
+            // (with BTS_FILTER_AHEAD: per shadow buffer, the main pass's list followed by the det x det pass's)
+            const size_t slots = cand_slots(d) * (d.fahead ? 2 : 1);
             SLOT(d.cand_cnt, int32_t, slots); SLOT(d.cand, int2, slots * CAND_W);
+            if (d.fahead) { SLOT(d.pool_of_slot, int32_t, T); SLOT(d.pool_of_pdet, int32_t, M); }
         }
         SLOT(d.fstat, int32_t, 16);
         SLOT(d.grid_hdr, int32_t, 8); SLOT(d.cell_start, int32_t, GRID_CELLS + 1); SLOT(d.cell_items, int32_t, M);
@@ -3146,7 +3183,7 @@ static int derive_sizes(const bts_tracker_config *cfg, Dev &d, int64_t *e_cap_ou
     // BTS_FILTER_AHEAD=1 (read at create; opt-in THROUGHPUT mode, see enqueue_step): the pre-filter of a frame runs on the side
     // stream ahead of the step that consumes it.  Body features only, bitmap consumers = the tile forms; the pool list it selects
     // bitmap rows for is the one tk_finalize builds (it implies BTS_LISTS_AHEAD; create adds BTS_PREDICT_FRONT and the side stream)
-    d.fahead = (bts_form_flag("BTS_FILTER_AHEAD") && d.filter && d.Df == 0 && !d.sorted && !cfg->use_graph && !cfg->record_costs) ? 1 : 0;
+    d.fahead = (bts_form_flag("BTS_FILTER_AHEAD") && d.filter && d.Df == 0 && !cfg->use_graph && !cfg->record_costs) ? 1 : 0;      // (with or without the sorted edges)
     if (d.fahead) d.ahead = 1;
     // BTS_SMOOTH_DEFERRED=1 (read at create; needs BTS_FILTER_AHEAD's streams): the `smooth` EMA of the rewritten tracks leaves the step
     d.smooth_def = (bts_form_flag("BTS_SMOOTH_DEFERRED") && d.fahead) ? 1 : 0;
@@ -3379,7 +3416,7 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
             return BTS_EHIP;
         }
     }
-    if (t->dv.sorted && hipMemset(t->dv.cand_cnt, 0, sizeof(int32_t) * (size_t)bts_cdiv(t->dv.T, FBM) * (size_t)bts_cdiv(t->dv.Mx, FBN) * 4) != hipSuccess) {
+    if (t->dv.sorted && hipMemset(t->dv.cand_cnt, 0, sizeof(int32_t) * cand_slots(t->dv) * (t->dv.fahead ? 2 : 1)) != hipSuccess) {
         (void)hipGetLastError();
         bts_set_error("hipMemset failed");
         bts_tracker_destroy(t);
@@ -3557,6 +3594,14 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
     // BTS_FILTER_AHEAD: this frame's candidate bitmap ([T + Mx] rows) is buffer (step & 1) as well
     const bool fa = dstep.fahead && ov;
     if (fa) dstep.cbits = t->dv.cbits + (size_t)ovp * (size_t)(dstep.T + dstep.Mx) * (size_t)dstep.cb_ld;
+    // the side passes' tilings of this step (main: every table slot; det x det: the previous step's detections)
+    const int fa_mt = fa ? bts_cdiv(dstep.T, FBM) * bts_cdiv(mc, FBN) : 0;
+    const int fa_dt = (fa && t->mc_prev > 0 && mc > 0) ? bts_cdiv(t->mc_prev, FBM) * bts_cdiv(mc, FBN) : 0;
+    if (fa && dstep.sorted) {       // the sorted edges: this buffer's two candidate lists, main pass first
+        const size_t per = cand_slots(t->dv);
+        dstep.cand_cnt = t->dv.cand_cnt + (size_t)ovp * per; dstep.cand = t->dv.cand + (size_t)ovp * per * CAND_W;
+        dstep.fa_mt = fa_mt; dstep.fa_dt = fa_dt; dstep.fa_dd_slot0 = (int)cand_slots_main(t->dv); dstep.fa_nprev = t->mc_prev;
+    }
     const Dev &d = dstep;
     const int T = d.T, M = d.Mx;
     const int cos_kernel = t->ctx->cos_kernel;
@@ -3614,17 +3659,22 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
             LAUNCH_ON(t->side, tk_cvt_ahead, dim3(bts_cdiv(mc, 4) + 1), dim3(1024), t->det_mts[ovp], t->hi_b[ovp], sh_main, sh_dd, t->fstat_b + 16 * ovp, t->mc_prev);
             Dev dm = dstep;
             dm.pool_slot = t->iota; dm.hdr = sh_main; dm.hi_idx = t->hi_b[ovp]; dm.fstat = t->fstat_b + 16 * ovp;
-            const int mt = bts_cdiv(T, FBM) * bts_cdiv(mc, FBN), mb = mt < t->filter_ahead_pw ? mt : t->filter_ahead_pw;
+            const int mt = fa_mt, mb = mt < t->filter_ahead_pw ? mt : t->filter_ahead_pw;
+            if (d.sorted) BTS_HIP(hipMemsetAsync(d.cand_cnt, 0, sizeof(int32_t) * cand_slots(t->dv), t->side));      // (both lists of this buffer)
             // (an empty frame has no tiles: a grid of zero workgroups is not a launch -- the memset above leaves "no candidates")
-            if (mt > 0) { hipLaunchKernelGGL(k_filter_i8<false>, dim3(mb), dim3(256), 0, t->side, dm, mc, mt, mb); BTS_LAUNCH_CHECK(); }
-            if (t->mc_prev > 0 && mc > 0) {
+            if (mt > 0 && d.sorted) { hipLaunchKernelGGL((k_filter_i8<false, 0, false, true>), dim3(mb), dim3(256), 0, t->side, dm, mc, mt, mb); BTS_LAUNCH_CHECK(); }
+            else if (mt > 0) { hipLaunchKernelGGL(k_filter_i8<false>, dim3(mb), dim3(256), 0, t->side, dm, mc, mt, mb); BTS_LAUNCH_CHECK(); }
+            if (fa_dt > 0) {
                 Dev dd = dm;
                 dd.hdr = sh_dd; dd.T = M;                                  // (rows = detections of the previous frame: the clamps of the row fetch)
                 dd.body_h = ovp ? t->dv.det_h : t->det_h2; dd.body_m = t->det_mts[ovp ^ 1];
                 dd.sh_rt[0] = d.sh_rd[0]; dd.sh_ct[0] = d.sh_cd[0];      // (the row operand is a detection-side shadow array)
                 dd.cbits = d.cbits + (size_t)T * (size_t)d.cb_ld;
-                const int dt = bts_cdiv(t->mc_prev, FBM) * bts_cdiv(mc, FBN), db = dt < t->filter_ahead_pw ? dt : t->filter_ahead_pw;
-                hipLaunchKernelGGL(k_filter_i8<false>, dim3(db), dim3(256), 0, t->side, dd, mc, dt, db); BTS_LAUNCH_CHECK();
+                const int dt = fa_dt, db = dt < t->filter_ahead_pw ? dt : t->filter_ahead_pw;
+                if (d.sorted) {
+                    dd.cand_cnt = d.cand_cnt + d.fa_dd_slot0; dd.cand = d.cand + (size_t)d.fa_dd_slot0 * CAND_W;
+                    hipLaunchKernelGGL((k_filter_i8<false, 0, false, true>), dim3(db), dim3(256), 0, t->side, dd, mc, dt, db); BTS_LAUNCH_CHECK();
+                } else { hipLaunchKernelGGL(k_filter_i8<false>, dim3(db), dim3(256), 0, t->side, dd, mc, dt, db); BTS_LAUNCH_CHECK(); }
             }
         } else {
             LAUNCH_ON(t->side, tk_cvt, dim3(bts_cdiv(mc, 4)), dim3(1024));
@@ -3733,7 +3783,7 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
         int srows = trows < 32 ? 32 : trows;
         while (srows < 256 && bts_cdiv(mc, CT_COLS) * bts_cdiv(T, srows) > TILE_GOAL) srows *= 2;
         const int stiles = bts_cdiv(mc, CT_COLS) * bts_cdiv(T, srows);
-        int cblocks = bts_cdiv(d.f_ntiles * 4, CT_COLS / 64);
+        int cblocks = bts_cdiv((fa ? fa_mt + fa_dt : d.f_ntiles) * 4, CT_COLS / 64);
         if (cblocks > 512) cblocks = 512;
         switch (srows) {
         case 32: LAUNCH(tk_edges_sorted<32>, dim3(stiles + cblocks), dim3(CT_COLS), lap[0], stiles); break;
@@ -3816,7 +3866,7 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
     }
     seg_end(BTS_SEG_LAP1);
     seg_begin(BTS_SEG_APPLY1);
-    const int clear_blocks = d.sorted ? 16 : 0;      // (the sorted / list form: the candidate list and its bitmap bits are cleared here)
+    const int clear_blocks = (d.sorted && !fa) ? 16 : 0;      // (BTS_FILTER_AHEAD: the side stream clears the next buffer's lists and bitmap)      // (the sorted / list form: the candidate list and its bitmap bits are cleared here)
     if (d.nch > 1) { LAUNCH(tk_mid1<true>, dim3(mid1_jobs(d.nch) + bts_cdiv(mc, 4) + clear_blocks), dim3(1024), clear_blocks); }
     else { LAUNCH(tk_mid1<false>, dim3(mid1_jobs(1) + bts_cdiv(mc, 4) + clear_blocks), dim3(1024), clear_blocks); }       // stage-2/3 lists read pre-update states: before the stage-1 updates
     if (dense) {

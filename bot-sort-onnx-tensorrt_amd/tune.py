@@ -82,6 +82,11 @@ CVT_CANDIDATES: Tuple[Tuple[str, str, Dict[str, str]], ...] = (
     # + the `smooth` EMA of the rewritten tracks on a third stream behind the step (half of tk_mid2's bytes leave the step's stream)
     ("lists_ahead", "filter_ahead_smooth", {"BTS_FILTER_AHEAD": "1", "BTS_SMOOTH_DEFERRED": "1"}),
     ("lists_ahead", "filter_ahead_smooth_merge_early", {"BTS_FILTER_AHEAD": "1", "BTS_SMOOTH_DEFERRED": "1", "BTS_MERGE_EARLY": "1"}),
+    # + the sorted stage-1 edges reading the side passes' candidate lists (rows translated from slot / previous-detection space)
+    ("lists_ahead", "filter_ahead_sorted_smooth", {"BTS_FILTER_AHEAD": "1", "BTS_SMOOTH_DEFERRED": "1", "BTS_EDGES_SORTED": "1"}),
+    # everything DESIGN.md 3.3's budget counts on, in one candidate (the greedy combination of single winners would also get here)
+    ("lists_ahead", "throughput_all", {"BTS_FILTER_AHEAD": "1", "BTS_SMOOTH_DEFERRED": "1", "BTS_EDGES_SORTED": "1", "BTS_MERGE_EARLY": "1",
+                                       "BTS_RENORM_FUSED": "1", "BTS_LAP_SELF": "1"}),
 )
 
 

@@ -301,7 +301,7 @@ int bts_tracker_create(bts_context *ctx, const bts_tracker_config *cfg, bts_trac
  *   BTS_FILTER_PW=n      persistent workgroups of the pre-filter (default 512)
  *   BTS_FILTER_TILE=160x128|128x64  tile shape of the one-pass pre-filter (default 128x128): 160 x 128 = two tile rounds instead of
  *                        three at 10 000 x 2 000; 128 x 64 = three resident workgroups per CU (768 persistent workgroups)
- *   BTS_FILTER_AHEAD=1   THROUGHPUT mode (round 6; body features, tile consumers, eager launches; implies BTS_LISTS_AHEAD,
+ *   BTS_FILTER_AHEAD=1   THROUGHPUT mode (round 6; body features, tile or sorted consumers, eager launches; implies BTS_LISTS_AHEAD,
  *                        BTS_PREDICT_FRONT and the side stream of BTS_CVT_OVERLAP): the appearance pre-filter of frame f runs on
  *                        the side stream AHEAD of step f -- one pass over all table slots (valid for every track step f-1 does
  *                        not rewrite) and one pass detections(f-1) x detections(f) (a track rewritten in step f-1 holds exactly

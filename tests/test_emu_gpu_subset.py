@@ -129,7 +129,7 @@ def test_filter_ahead_survives_adversarial_stream_schedules_and_the_detector_det
         if drop:
             env["HIPEMU_DROP_WAITS"] = drop
         cmd = [sys.executable, "-m", "pytest", "-m", "gpu", "-p", "tests.hip_emu.emu_prelude", "-p", "no:cacheprovider", "-q", "--no-header",
-               "--timeout", "900", "-k", "True-1", node]          # (resident, + BTS_SMOOTH_DEFERRED: the third stream lags like the second)
+               "--timeout", "900", "-k", "True-2", node]          # (resident; + BTS_SMOOTH_DEFERRED: the third stream lags like the second; + the sorted edges and merge-early)
         runs[(mode, drop)] = subprocess.Popen(cmd, cwd=REPO, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     out = {k: (p.communicate(timeout=1400)[0], p.returncode) for k, p in runs.items()}
     for key in (("sidelate", None), ("mainlate", None)):

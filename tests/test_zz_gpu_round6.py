@@ -93,15 +93,17 @@ def _pair(bts, T, M, D, extra=None, **kw):
     return ref, exp
 
 
-@pytest.mark.parametrize("extra", ["", "merge_early+renorm_fused+self", "planes"])
+@pytest.mark.parametrize("extra", ["", "merge_early+renorm_fused+self", "planes", "sorted", "sorted+smooth+merge_early"])
 def test_filter_ahead_on_an_appearance_only_stream_with_hidden_identities(bts, extra):
     """160 identities x 128-d, 70 % shown per frame, boxes teleport: every association of frames 1.. is an appearance candidate read
     through pool_cbrow -- det x det rows for identities shown in consecutive frames, main-pass rows for re-found lost tracks.  The
     form = the default forms frame by frame (indices, lists, slots, means), nothing synchronises the host in between except the
     reads of the comparison itself, and both kinds of row carried matches."""
-    envs = {"merge_early": "BTS_MERGE_EARLY", "renorm_fused": "BTS_RENORM_FUSED", "self": "BTS_LAP_SELF", "planes": "BTS_SHADOW_PLANES"}
+    envs = {"merge_early": "BTS_MERGE_EARLY", "renorm_fused": "BTS_RENORM_FUSED", "self": "BTS_LAP_SELF", "planes": "BTS_SHADOW_PLANES",
+            "sorted": "BTS_EDGES_SORTED", "smooth": "BTS_SMOOTH_DEFERRED"}
     K, D = 160, 128
     ref, exp = _pair(bts, K + 96, K, D, extra={envs[k]: 1 for k in extra.split("+") if k})
+    assert exp.forms()["edges"] == ("sorted" if "sorted" in extra else "tiles")      # (sorted: candidate LISTS of both side passes, rows translated)
     st = Flicker(K, D, 5)
     refound, cont = 0, 0
     prev_ids = None
@@ -121,13 +123,14 @@ def test_filter_ahead_on_an_appearance_only_stream_with_hidden_identities(bts, e
     ref.close(); exp.close()
 
 
-def test_filter_ahead_at_384x256x2048_vs_default_and_oracle(bts):
+@pytest.mark.parametrize("extra", ["", "sorted+smooth"])
+def test_filter_ahead_at_384x256x2048_vs_default_and_oracle(bts, extra):
     """VERDICT r5's first size: 384-row table, 256 identities x 2048-d (16 K stages, prefix checkpoints in use), 10 % churn: births,
     expiries, re-found tracks, low-score detections (stage 2 rewrites tracks from LOW-score rows: det x det rows of detections that are
     not in the high-score list of their own frame).  Form = default forms = oracle, frame by frame."""
     from oracle import bts_oracle as bo
     K, M, D = 256, 160, 2048
-    ref, exp = _pair(bts, 384, 256, D)
+    ref, exp = _pair(bts, 384, 256, D, extra={"BTS_EDGES_SORTED": 1, "BTS_SMOOTH_DEFERRED": 1} if extra else None)
     ora = bo.TrackerOracle(faithful_iou=False)
     st = bts.synth.SyntheticStream(K, M, D, seed=21, churn=0.1)
     cands = 0
@@ -145,13 +148,14 @@ def test_filter_ahead_at_384x256x2048_vs_default_and_oracle(bts):
     ref.close(); exp.close()
 
 
-def test_filter_ahead_at_4224x2048x256_with_churn(bts):
+@pytest.mark.parametrize("extra", ["", "sorted"])
+def test_filter_ahead_at_4224x2048x256_with_churn(bts, extra):
     """VERDICT r5's second size: a 4224-row table, 2048 detections x 256-d per frame with 10 % churn: 33 x 16 main-pass tiles and
     16 x 16 det x det tiles over the side passes' persistent workgroups (several tiles each: next-tile prefetch, stop prediction),
     ragged extents on both sides.  Form = default forms frame by frame, and the oracle's assignment on the last frame."""
     from oracle import bts_oracle as bo
     K, M, D = 2048, 2048, 256          # (the stream's first frame shows every identity: K <= max_dets)
-    ref, exp = _pair(bts, 4224, 2048, D)
+    ref, exp = _pair(bts, 4224, 2048, D, extra={"BTS_EDGES_SORTED": 1} if extra else None)
     ora = bo.TrackerOracle(faithful_iou=False)          # (faithful_iou=False: the vectorised IoU form of the checker)
     st = bts.synth.SyntheticStream(K, M, D, seed=9, churn=0.1)
     for f in range(4):
@@ -167,7 +171,7 @@ def test_filter_ahead_at_4224x2048x256_with_churn(bts):
     ref.close(); exp.close()
 
 
-@pytest.mark.parametrize("smooth", [0, 1])
+@pytest.mark.parametrize("smooth", [0, 1, 2])
 @pytest.mark.parametrize("resident", [True, False])
 def test_filter_ahead_without_host_synchronisation_between_steps(bts, resident, smooth):
     """24 frames of the appearance-only stream stepped back to back, digests compared with the default forms' every sixth frame
@@ -177,8 +181,13 @@ def test_filter_ahead_without_host_synchronisation_between_steps(bts, resident, 
     covariances and the `curr` / `smooth` feature rows of both lists."""
     tune = importlib.import_module("bot-sort-onnx-tensorrt_amd.tune")
     K, D = 96, 128
-    ref, exp = _pair(bts, K + 64, K, D, extra={"BTS_SMOOTH_DEFERRED": smooth})      # (smooth = 1: + the `smooth` EMA on the third stream)
-    assert exp.forms()["smooth_deferred"] == str(smooth)
+    # (smooth = 1: + the `smooth` EMA on the third stream; 2: + the sorted edges -- the side stream also clears and fills the
+    #  candidate lists -- and merge-early)
+    extra = {"BTS_SMOOTH_DEFERRED": 1 if smooth else 0}
+    if smooth == 2:
+        extra.update(BTS_EDGES_SORTED=1, BTS_MERGE_EARLY=1)
+    ref, exp = _pair(bts, K + 64, K, D, extra=extra)
+    assert exp.forms()["smooth_deferred"] == str(1 if smooth else 0) and exp.forms()["edges"] == ("sorted" if smooth == 2 else "tiles")
     exp.inputs_resident(resident)
     st = Flicker(K, D, 31, visible=0.75)
     frames = [_dev(st.next()) for _ in range(24)]
@@ -197,17 +206,17 @@ def test_filter_ahead_without_host_synchronisation_between_steps(bts, resident, 
 
 
 def test_filter_ahead_is_ruled_out_where_it_does_not_apply(bts):
-    """The form needs the pre-filter, body features only, the tile consumers and eager launches: elsewhere it is not in effect
+    """The form needs the pre-filter, body features only, the tile or sorted consumers and eager launches: elsewhere it is not in effect
     (bts_tracker_forms reports forms IN EFFECT) and the tracker behaves like the default."""
     for kw in (dict(appearance_mode=1), dict(face_dim=128), dict(use_graph=1), dict(record_costs=True)):
         t = bts.DeviceTracker(max_tracks=256, max_dets=64, feat_dim=128, forms=AHEAD, **kw)
         eff = t.forms()
         t.close()
         assert eff["filter_ahead"] == "0", (kw, eff)
-    t = bts.DeviceTracker(max_tracks=256, max_dets=64, feat_dim=128, forms=dict(AHEAD, BTS_EDGES_SORTED=1))
+    t = bts.DeviceTracker(max_tracks=256, max_dets=64, feat_dim=128, forms=dict(AHEAD, BTS_EDGES_GRID=1))      # (the neighbour search reads the bitmap by pool row)
     eff = t.forms()
     t.close()
-    assert eff["filter_ahead"] == "0" and eff["edges"] == "sorted", eff
+    assert eff["filter_ahead"] == "1" and eff["edges"] == "tiles", eff
 
 
 def test_filter_ahead_edge_frames_reset_and_gmc(bts):
@@ -297,4 +306,44 @@ def test_smooth_deferred_rows_equal_the_default_forms_every_frame(bts):
     t = bts.DeviceTracker(max_tracks=64, max_dets=32, feat_dim=128, forms={"BTS_SMOOTH_DEFERRED": 1})       # needs the ahead mode's streams
     assert t.forms()["smooth_deferred"] == "0"
     t.close()
+    ref.close(); exp.close()
+
+
+def test_filter_ahead_sorted_edges_when_the_candidate_slots_overflow(bts):
+    """All identities share one appearance (pairwise cosines ~ 0.97): every (track, detection) pair is a candidate, a 64 x 64 quadrant
+    of a side pass holds thousands -- far more than a list slot -- so the candidate wavefronts of the sorted form SWEEP the quadrant's
+    bitmap words instead, rows translated from slot / previous-detection space one row at a time, in both passes.  Boxes move
+    slowly, so IoU decides among the many candidates.  Form = default forms = oracle."""
+    from oracle import bts_oracle as bo
+    K, D = 150, 128
+    ref, exp = _pair(bts, 256, 160, D, extra={"BTS_EDGES_SORTED": 1})
+    assert exp.forms()["edges"] == "sorted"
+    ora = bo.TrackerOracle(faithful_iou=False)
+    rng = np.random.default_rng(12)
+    proto = rng.standard_normal(D)
+    proto /= np.linalg.norm(proto)
+    cx, cy = rng.permutation(K) * 40 + 20, rng.integers(50, 3000, K)
+    swept = 0
+    for f in range(6):
+        show = np.ones(K, bool) if f == 0 else rng.uniform(size=K) < 0.8
+        ids = np.nonzero(show)[0]
+        cx = cx + rng.integers(-2, 3, K)
+        boxes = np.stack([cx[ids], cy[ids], cx[ids] + 30, cy[ids] + 60], 1).astype(np.int32)
+        scores = (rng.uniform(0.91, 0.99, len(ids)) if f == 0 else rng.uniform(0.5, 0.85, len(ids))).astype(np.float32)
+        feats = proto[None, :] + 0.02 * rng.standard_normal((len(ids), D))
+        feats = (feats / np.linalg.norm(feats, axis=1, keepdims=True)).astype(np.float32)
+
+        class Fr:
+            pass
+        fr = Fr()
+        fr.boxes, fr.scores, fr.feats = boxes, scores, np.ascontiguousarray(feats)
+        ref.step(*_dev(fr)); exp.step(*_dev(fr))
+        ora.update_arrays(fr.boxes, fr.scores.astype(np.float64), fr.feats.copy(), None)
+        _same_frame(ref, exp, f)
+        for k in (1, 2, 3):
+            assert np.array_equal(exp.stage_result(k)["m"], np.asarray(ora.trace["m%d" % k]).reshape(-1, 2)), (f, k)
+        assert exp.counts()["errors"] == 0
+        if f >= 1:
+            swept += exp.debug_filter()["candidates"]
+    assert swept > 5 * 64 * 64          # (quadrants far beyond a slot's capacity)
     ref.close(); exp.close()
