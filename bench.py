@@ -85,7 +85,7 @@ def parse():
                     "of this workload, keeps what is bit-identical to the default forms AND faster; the line carries the whole table), "
                     "default = the library's defaults, or an explicit 'KEY=VALUE,...'")
     ap.add_argument("--compare-forms", default="", help="'KEY=VALUE,...': no selection -- the default forms and THESE forms through the same timed region on "
-                    "the same frames, both figures (and both per-kernel tables) in the line; `value` is the better error-free one")
+                    "the same frames, both figures (and both per-kernel tables) in the line; `value` stays the default forms' figure")
     ap.add_argument("--oversubscribe", action="store_true", help="allow --gpus N on a box with fewer GPUs (ranks share devices; "
                     "for testing the launch path only -- the line says so)")
     return ap.parse_args()

@@ -19,12 +19,16 @@ for rep in 1 2 3; do
     one $wl default BTS_NONE=1
     one $wl ahead BTS_FILTER_AHEAD=1
     one $wl ahead_all BTS_FILTER_AHEAD=1 BTS_MERGE_EARLY=1 BTS_RENORM_FUSED=1 BTS_LAP_SELF=1
+    one $wl ahead_smooth BTS_FILTER_AHEAD=1 BTS_SMOOTH_DEFERRED=1
+    one $wl ahead_sorted_smooth BTS_FILTER_AHEAD=1 BTS_SMOOTH_DEFERRED=1 BTS_EDGES_SORTED=1
+    one $wl throughput_all BTS_FILTER_AHEAD=1 BTS_SMOOTH_DEFERRED=1 BTS_EDGES_SORTED=1 BTS_MERGE_EARLY=1 BTS_RENORM_FUSED=1 BTS_LAP_SELF=1
     one $wl ahead_pw384 BTS_FILTER_AHEAD=1 BTS_FILTER_AHEAD_PW=384
     one $wl ahead_pw512 BTS_FILTER_AHEAD=1 BTS_FILTER_AHEAD_PW=512
     one $wl lists_front BTS_LISTS_AHEAD=1 BTS_PREDICT_FRONT=1
   done
 done
 timeout 1500 python scripts/soak_cvt_overlap.py 2000 BTS_FILTER_AHEAD=1 > $O/soak_filter_ahead.txt 2>&1; tail -14 $O/soak_filter_ahead.txt
+timeout 1500 python scripts/soak_cvt_overlap.py 1000 BTS_FILTER_AHEAD=1,BTS_SMOOTH_DEFERRED=1,BTS_EDGES_SORTED=1,BTS_MERGE_EARLY=1 > $O/soak_throughput_all.txt 2>&1; tail -14 $O/soak_throughput_all.txt
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 BTS_FILTER_AHEAD=1 timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof_ahead -- python bench.py --forms default --steps 100 --no-cpu --no-export > $O/prof_ahead.log 2>&1
 python scripts/prof_top.py $O/prof_ahead > $O/target_ahead_kernel_stats.csv 2>/dev/null; head -20 $O/target_ahead_kernel_stats.csv
