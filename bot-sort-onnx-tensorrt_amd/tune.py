@@ -104,7 +104,7 @@ def default_candidates():
 
 
 def soak(make_tracker: Callable[[str], object], frames: Sequence[tuple], forms: Dict[str, str], passes: int = 8, stride: int = 17,
-         clone: Callable = None, sync: Callable = None) -> dict:
+         clone: Callable = None, sync: Callable = None, progress: Callable[[], None] = None) -> dict:
     """Digest equality of `forms` against the default forms over passes x len(frames) steps: both trackers step the same frames
     back to back, the host synchronises with the device only where a digest is taken -- every `stride`-th step and the last --, so
     the form's side stream really runs under the previous steps' kernels; the last pass runs WITHOUT the residency promise (the
@@ -125,6 +125,8 @@ def soak(make_tracker: Callable[[str], object], frames: Sequence[tuple], forms: 
                 exp.inputs_resident(resident)
             a, b = [clone(fr) for fr in frames], [clone(fr) for fr in frames]
             sync()
+            if progress:
+                progress()               # (one sign of life per pass: run_isolated's parent takes silence for a hang)
             for fa, fb in zip(a, b):
                 ref.step(*fa)
                 exp.step(*fb)
@@ -231,21 +233,26 @@ def select_forms(make_tracker: Callable[[str], object], frames: Sequence[tuple],
         # (BTS_TUNE_ALLOW_CVT=1, after scripts/soak_cvt_overlap.py) or run HERE, on these frames (BTS_TUNE_SOAK_PASSES, default 8
         # passes; 0 = never).  A soak that takes the child down is blamed like a candidate ("soak:<name>") and skipped on the restart.
         passes = int(os.environ.get("BTS_TUNE_SOAK_PASSES", "8") or 0)
+        only0 = [n for n in os.environ.get("BTS_TUNE_ONLY", "").split(",") if n]
         if os.environ.get("BTS_TUNE_ALLOW_CVT") != "1" and passes > 0 and len(frames) >= 8:
             for sname, key, forms in SOAK_FORMS:
+                if only0 and not any(c[1] in only0 for c in CVT_CANDIDATES if key in c[2]):
+                    continue                 # (a subset of the candidates was asked for and none of this form's is in it)
                 if "soak:" + sname in skip:
                     soaks.append({"name": sname, "skipped": True, "passed": False})
                     continue
                 report({"event": "begin", "name": "soak:" + sname})
                 try:
-                    r = soak(make_tracker, frames, forms, passes=passes, clone=clone, sync=sync)
+                    r = soak(make_tracker, frames, forms, passes=passes, clone=clone, sync=sync,
+                             progress=lambda n=sname: report({"event": "tick", "name": "soak:" + n}))
                 except Exception as e:           # (a library without the form)
                     r = {"passed": False, "error": "%s: %s" % (type(e).__name__, str(e)[:200])}
                 r["name"] = sname
                 soaks.append(r)
                 report(dict(event="end", name="soak:" + sname, **{k: v for k, v in r.items() if k != "name"}))
             # a gated candidate is offered iff EVERY side-stream key it uses has passed its soak
-            passed = {key for (sname, key, _), r in zip(SOAK_FORMS, soaks) if r.get("passed")}
+            key_of = {sname: key for sname, key, _ in SOAK_FORMS}
+            passed = {key_of[r["name"]] for r in soaks if r.get("passed")}
             keys = {key for _, key, _ in SOAK_FORMS}
             candidates = tuple(candidates) + tuple(c for c in CVT_CANDIDATES if (keys & set(c[2])) and (keys & set(c[2])) <= passed and c not in candidates)
     only = [n for n in os.environ.get("BTS_TUNE_ONLY", "").split(",") if n]      # (tests: a subset of the candidates by name)
