@@ -3653,8 +3653,11 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
             //               absorbed (copy_shadow; det_index[slot]), whichever detection that turns out to be.
             // Both are the UNCHANGED default kernel k_filter_i8<false>, fed a Dev whose row list is the identity and whose extents
             // sit in a small header of their own; the stage-1 tiles find a pool row's bitmap row through pool_cbrow (tk_finalize).
-            const size_t brows = (size_t)(T + M);
-            BTS_HIP(hipMemsetAsync(d.cbits, 0, sizeof(uint32_t) * brows * (size_t)d.cb_ld, t->side));
+            // (only what this frame can touch: the words of its mc columns -- whole 8-byte words, the tiles read aligned pairs -- in the
+            //  rows of the two passes; the row stride is sized for max_dets, which a caller may set far above a frame's count)
+            const size_t cw = (size_t)bts_cdiv(mc, 64) * 8;
+            BTS_HIP(hipMemset2DAsync(d.cbits, sizeof(uint32_t) * (size_t)d.cb_ld, 0, cw, (size_t)T, t->side));
+            if (fa_dt > 0) BTS_HIP(hipMemset2DAsync(d.cbits + (size_t)T * (size_t)d.cb_ld, sizeof(uint32_t) * (size_t)d.cb_ld, 0, cw, (size_t)t->mc_prev, t->side));
             int32_t *sh_main = t->shdr + (size_t)(ovp * 2 + 0) * H_SIZE, *sh_dd = t->shdr + (size_t)(ovp * 2 + 1) * H_SIZE;
             LAUNCH_ON(t->side, tk_cvt_ahead, dim3(bts_cdiv(mc, 4) + 1), dim3(1024), t->det_mts[ovp], t->hi_b[ovp], sh_main, sh_dd, t->fstat_b + 16 * ovp, t->mc_prev);
             Dev dm = dstep;

@@ -298,6 +298,11 @@ static inline hipError_t hipGraphLaunch(hipGraphExec_t e, hipStream_t s) { emu::
 static inline hipError_t hipGraphExecDestroy(hipGraphExec_t e) { emu::drain_all(); delete e; return hipSuccess; }
 
 static inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t st) { if (!emu::record([=]() { memset(p, v, n); })) emu::stream_op(st, [=]() { memset(p, v, n); }); return hipSuccess; }
+static inline hipError_t hipMemset2DAsync(void *p, size_t pitch, int v, size_t w, size_t h, hipStream_t st) {
+    auto f = [=]() { for (size_t r = 0; r < h; ++r) memset((char *)p + r * pitch, v, w); };
+    if (!emu::record(f)) emu::stream_op(st, f);
+    return hipSuccess;
+}
 static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t st) { if (!emu::record([=]() { memmove(d, s, n); })) emu::stream_op(st, [=]() { memmove(d, s, n); }); return hipSuccess; }
 
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
