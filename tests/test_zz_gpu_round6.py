@@ -347,3 +347,30 @@ def test_filter_ahead_sorted_edges_when_the_candidate_slots_overflow(bts):
             swept += exp.debug_filter()["candidates"]
     assert swept > 5 * 64 * 64          # (quadrants far beyond a slot's capacity)
     ref.close(); exp.close()
+
+
+@pytest.mark.parametrize("mode", ["motion_gate", "tie_mode", "config5", "motion_gate+sorted"])
+def test_the_ahead_forms_under_the_trackers_other_modes(bts, mode):
+    """The consumers the ahead mode touches exist in several instantiations: the GATE forms of the stage-1 tiles (motion_gate), the
+    exact-tie step behind every assignment (tie_mode 1: its cost source is the stage's boxes and edges), config 5's arithmetic
+    (float32 Kalman rows, binary16 costs).  BTS_FILTER_AHEAD + BTS_SMOOTH_DEFERRED + merge-early (+ the sorted edges where the mode
+    allows them: the sorted form is ruled out WITH the motion gate, and then the tiles must take over) against the default forms under
+    the SAME mode, frame by frame: indices, lists, slots, means; at the end covariances and feature rows."""
+    tune = importlib.import_module("bot-sort-onnx-tensorrt_amd.tune")
+    kw = {"motion_gate": dict(motion_gate=1), "tie_mode": dict(tie_mode=1), "config5": dict(kalman_dtype=1, cost_dtype=2),
+          "motion_gate+sorted": dict(motion_gate=1)}[mode]
+    extra = {"BTS_SMOOTH_DEFERRED": 1, "BTS_MERGE_EARLY": 1}
+    if mode in ("tie_mode", "motion_gate+sorted"):
+        extra["BTS_EDGES_SORTED"] = 1
+    K, M, D = 120, 80, 128
+    ref, exp = _pair(bts, 256, 128, D, extra=extra, **kw)
+    eff = exp.forms()
+    assert eff["smooth_deferred"] == "1" and eff["edges"] == ("sorted" if mode == "tie_mode" else "tiles"), eff
+    st = bts.synth.SyntheticStream(K, M, D, seed=23, churn=0.15)
+    for f in range(8):
+        fr = st.next()
+        ref.step(*_dev(fr)); exp.step(*_dev(fr))
+        _same_frame(ref, exp, f)
+        assert ref.counts() == exp.counts() and exp.counts()["errors"] == 0, (f, exp.counts())
+    assert tune._state_digest(ref) == tune._state_digest(exp)
+    ref.close(); exp.close()
