@@ -3664,6 +3664,10 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
             dm.pool_slot = t->iota; dm.hdr = sh_main; dm.hi_idx = t->hi_b[ovp]; dm.fstat = t->fstat_b + 16 * ovp;
             const int mt = fa_mt, mb = mt < t->filter_ahead_pw ? mt : t->filter_ahead_pw;
             if (d.sorted) BTS_HIP(hipMemsetAsync(d.cand_cnt, 0, sizeof(int32_t) * cand_slots(t->dv), t->side));      // (both lists of this buffer)
+            // (bts_tracker_profile_*: the K_FILTER segment of this mode is the pair of side passes, timed on THEIR stream -- not part of
+            //  the step's critical path, but what the first A/B wants to see next to the step's own segments)
+            const bool prof_side = prof_room && t->prof_seg == BTS_SEG_K_FILTER;
+            if (prof_side) (void)hipEventRecord(t->prof_ev[2 * t->prof_n], t->side);
             // (an empty frame has no tiles: a grid of zero workgroups is not a launch -- the memset above leaves "no candidates")
             if (mt > 0 && d.sorted) { hipLaunchKernelGGL((k_filter_i8<false, 0, false, true>), dim3(mb), dim3(256), 0, t->side, dm, mc, mt, mb); BTS_LAUNCH_CHECK(); }
             else if (mt > 0) { hipLaunchKernelGGL(k_filter_i8<false>, dim3(mb), dim3(256), 0, t->side, dm, mc, mt, mb); BTS_LAUNCH_CHECK(); }
@@ -3679,6 +3683,7 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
                     hipLaunchKernelGGL((k_filter_i8<false, 0, false, true>), dim3(db), dim3(256), 0, t->side, dd, mc, dt, db); BTS_LAUNCH_CHECK();
                 } else { hipLaunchKernelGGL(k_filter_i8<false>, dim3(db), dim3(256), 0, t->side, dd, mc, dt, db); BTS_LAUNCH_CHECK(); }
             }
+            if (prof_side) { (void)hipEventRecord(t->prof_ev[2 * t->prof_n + 1], t->side); t->prof_n++; }
         } else {
             LAUNCH_ON(t->side, tk_cvt, dim3(bts_cdiv(mc, 4)), dim3(1024));
         }
