@@ -464,7 +464,20 @@ __global__ __launch_bounds__(1024) void tk_cvt(Dev d) { cvt_body(d, (long)blockI
 // absorbing track's record will be) -- the row records of the NEXT frame's det x det pass.  The last workgroup builds the frame's
 // high-score list for the side passes (the predicate and order of prep_dets, which builds the step's own copy later) and the two
 // little headers the unchanged pre-filter kernel reads its extents from.
-__global__ __launch_bounds__(1024) void tk_cvt_ahead(Dev d, float *det_mts, int32_t *hi_b, int32_t *hdr_main, int32_t *hdr_dd, int32_t *fstat_b, int n_prev) {
+// The first `clear_blocks` workgroups clear what the two passes behind this launch write with atomics: the words of the frame's mc
+// columns (`row_words` per row) in bitmap rows [0, T + n_prev) -- the row stride is sized for max_dets, far above a frame's count in
+// some callers -- and, for the sorted edges, the counts of the buffer's two candidate lists.  (Three memsets on the side stream
+// before: three launches and three host calls per step.)
+__global__ __launch_bounds__(1024) void tk_cvt_ahead(Dev d, float *det_mts, int32_t *hi_b, int32_t *hdr_main, int32_t *hdr_dd, int32_t *fstat_b, int n_prev,
+                                                     int clear_blocks, int row_words, int cand_slots_n) {
+    if ((int)blockIdx.x < clear_blocks) {
+        const long nth = (long)clear_blocks * blockDim.x, t0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+        const long words = (long)(d.T + n_prev) * row_words;
+        for (long k = t0; k < words; k += nth) d.cbits[(k / row_words) * d.cb_ld + k % row_words] = 0u;
+        for (long k = t0; k < cand_slots_n; k += nth) d.cand_cnt[k] = 0;
+        return;
+    }
+    const int b = (int)blockIdx.x - clear_blocks;
     if (blockIdx.x + 1 == gridDim.x) {
         __shared__ int32_t tmp[1024];
         const float *scores = IN(d, scores);
@@ -474,9 +487,9 @@ __global__ __launch_bounds__(1024) void tk_cvt_ahead(Dev d, float *det_mts, int3
         if (threadIdx.x == 0) { hdr_main[H_NPOOL] = d.T; hdr_main[H_NHI] = nhi; hdr_dd[H_NPOOL] = n_prev; hdr_dd[H_NHI] = nhi; }
         return;
     }
-    const long j = (long)blockIdx.x * 4 + feat::row_group();
+    const long j = (long)b * 4 + feat::row_group();
     const bool on = j < IN(d, m);
-    cvt_body(d, (long)blockIdx.x);
+    cvt_body(d, (long)b);
     const float nrm = feat::row_norm(IN(d, feats) + j * d.D, d.D, on);      // (every thread of the workgroup: barriers inside)
     if (on && feat::row_tid() == 0) {       // (the thread that wrote the row's record in to_i8_row)
         float rec[feat::I8_META];
@@ -3653,17 +3666,16 @@ static int enqueue_step(bts_tracker *t, hipStream_t s, float *feats, float *face
             //               absorbed (copy_shadow; det_index[slot]), whichever detection that turns out to be.
             // Both are the UNCHANGED default kernel k_filter_i8<false>, fed a Dev whose row list is the identity and whose extents
             // sit in a small header of their own; the stage-1 tiles find a pool row's bitmap row through pool_cbrow (tk_finalize).
-            // (only what this frame can touch: the words of its mc columns -- whole 8-byte words, the tiles read aligned pairs -- in the
-            //  rows of the two passes; the row stride is sized for max_dets, which a caller may set far above a frame's count)
-            const size_t cw = (size_t)bts_cdiv(mc, 64) * 8;
-            BTS_HIP(hipMemset2DAsync(d.cbits, sizeof(uint32_t) * (size_t)d.cb_ld, 0, cw, (size_t)T, t->side));
-            if (fa_dt > 0) BTS_HIP(hipMemset2DAsync(d.cbits + (size_t)T * (size_t)d.cb_ld, sizeof(uint32_t) * (size_t)d.cb_ld, 0, cw, (size_t)t->mc_prev, t->side));
+            // (the launch also clears what the passes write with atomics -- only what this frame can touch: the words of its mc columns,
+            //  whole 8-byte words since the tiles read aligned pairs, in the rows of the two passes; and the sorted edges' list counts)
+            const int row_words = bts_cdiv(mc, 64) * 2, n_prev = fa_dt > 0 ? t->mc_prev : 0;
+            const int clear_blocks = 1 + (int)(((size_t)(T + n_prev) * (size_t)row_words) / (16 * 1024));      // ~16 words per thread
             int32_t *sh_main = t->shdr + (size_t)(ovp * 2 + 0) * H_SIZE, *sh_dd = t->shdr + (size_t)(ovp * 2 + 1) * H_SIZE;
-            LAUNCH_ON(t->side, tk_cvt_ahead, dim3(bts_cdiv(mc, 4) + 1), dim3(1024), t->det_mts[ovp], t->hi_b[ovp], sh_main, sh_dd, t->fstat_b + 16 * ovp, t->mc_prev);
+            LAUNCH_ON(t->side, tk_cvt_ahead, dim3(clear_blocks + bts_cdiv(mc, 4) + 1), dim3(1024), t->det_mts[ovp], t->hi_b[ovp], sh_main, sh_dd, t->fstat_b + 16 * ovp, t->mc_prev,
+                      clear_blocks, row_words, d.sorted ? (int)cand_slots(t->dv) : 0);
             Dev dm = dstep;
             dm.pool_slot = t->iota; dm.hdr = sh_main; dm.hi_idx = t->hi_b[ovp]; dm.fstat = t->fstat_b + 16 * ovp;
             const int mt = fa_mt, mb = mt < t->filter_ahead_pw ? mt : t->filter_ahead_pw;
-            if (d.sorted) BTS_HIP(hipMemsetAsync(d.cand_cnt, 0, sizeof(int32_t) * cand_slots(t->dv), t->side));      // (both lists of this buffer)
             // (bts_tracker_profile_*: the K_FILTER segment of this mode is the pair of side passes, timed on THEIR stream -- not part of
             //  the step's critical path, but what the first A/B wants to see next to the step's own segments)
             const bool prof_side = prof_room && t->prof_seg == BTS_SEG_K_FILTER;
