@@ -2,7 +2,7 @@
 """Assemble the record of an emulator campaign (profiles/rNN_emu_campaign.txt) from the per-worker time reports that
 tests/hip_emu/emu_prelude.py writes under BTS_HOST_TIME_REPORT and the pytest log.  CPU only.
 
-    python scripts/emu_campaign_report.py <report prefix, e.g. /tmp/emu_final_times/t.json> <pytest log> <commit> > profiles/r06_emu_campaign.txt"""
+    python scripts/emu_campaign_report.py <report prefix, e.g. /tmp/emu_final_times/t.json> <pytest log> <commit> [workers=6] > profiles/r06_emu_campaign.txt"""
 import glob
 import json
 import re
@@ -11,6 +11,7 @@ import sys
 
 def main():
     prefix, log, commit = sys.argv[1], sys.argv[2], sys.argv[3]
+    workers = int(sys.argv[4]) if len(sys.argv) > 4 else 6
     rows = {}
     for f in sorted(glob.glob(prefix + "*")):
         rows.update(json.load(open(f)))
@@ -19,8 +20,8 @@ def main():
     verdict = m.group(1) if m else "no verdict line found"
     failed = re.findall(r"^FAILED (\S+)", txt, flags=re.M)
     print("Round 6 emulator campaign at %s: BTS_HOST_TIME_REPORT=... BTS_LIB_PATH=<copy of tests/hip_emu/libbotsort_emu.so> pytest tests -m gpu "
-          "-p tests.hip_emu.emu_prelude -n 6" % commit)
-    print(verdict + " on 8 cores (6 workers)" + ("; FAILED: " + ", ".join(failed) if failed else ""))
+          "-p tests.hip_emu.emu_prelude -n %d" % (commit, workers))
+    print(verdict + " on 8 cores (%d workers)" % workers + ("; FAILED: " + ", ".join(failed) if failed else ""))
     print()
     print("The emulator of this round: global_load_lds is ASYNCHRONOUS (data lands at the issuing wavefront's explicit s_waitcnt vmcnt, the destination")
     print("is poisoned until then, another wavefront may read it only behind a workgroup barrier; every inline-assembly LDS access of the kernels is")
@@ -29,7 +30,7 @@ def main():
     print()
     print("host_s = wall time of the test OUTSIDE the library's entry points (oracle, stream generation, NumPy, pytest) -- what the test costs on a GPU box,")
     print("where the library calls take milliseconds; library_s = time inside the emulated library (CPU emulation: says nothing about a GPU).  Measured with")
-    print("6 workers sharing 8 cores (BLAS threads oversubscribed): an UPPER bound (round 5 re-measured the heaviest entries uncontended: ~10x lower).")
+    print("the workers sharing 8 cores (BLAS threads oversubscribed): an UPPER bound (round 5 re-measured the heaviest entries uncontended: ~10x lower).")
     print("Driver limit for the suite: 1200 s.")
     print()
     hs = sum(r["host_s"] for r in rows.values())
